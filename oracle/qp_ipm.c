@@ -1,0 +1,261 @@
+/*
+ * oracle/qp_ipm.c -- CPU ORACLE (test infrastructure).
+ *
+ * Primal-dual interior-point solve of the OCP-structured QP that one SQP_RTI iteration poses
+ * (SURVEY Appendix B step 4).  The reference delegates this to HPIPM (qp_solver =
+ * PARTIAL_CONDENSING_HPIPM, no condensing horizon set => stage-structured Riccati factorisation,
+ * generate_acados_solver.py:171-173), whose source is not in /root/reference.  After MIRROR every W_k
+ * is positive definite, so the QP solution is unique and any solver converged to qp_tol reproduces
+ * it; this file is a textbook Mehrotra predictor-corrector with a Riccati factor/solve per iteration.
+ *
+ * Unknowns per node k: v_k = [du_k; dx_k] (node N: dx only), multipliers pi_k of the dynamics
+ * equations, and (lam_i, t_i) >= 0 for every one-sided row  sgn_i (c_i^T v - beta_i) - t_i = 0.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include "qp.h"
+
+typedef struct {
+    double Hh[ORC_MAX_N + 1][ORC_NV][ORC_NV];   /* W + sum (lam/t) c c^T */
+    double gh[ORC_MAX_N + 1][ORC_NV];
+    double rb[ORC_MAX_N][ORC_NX];
+    double rg[ORC_MAX_N + 1][ORC_NV];
+    double rd[ORC_MAX_N + 1][ORC_MAX_ROWS];
+    double q[ORC_MAX_N + 1][ORC_MAX_ROWS];
+    /* Riccati */
+    double P[ORC_MAX_N + 1][ORC_NX][ORC_NX];
+    double p[ORC_MAX_N + 1][ORC_NX];
+    double K[ORC_MAX_N][ORC_NU][ORC_NX];
+    double kff[ORC_MAX_N][ORC_NU];
+    double Fuu_inv[ORC_MAX_N][ORC_NU][ORC_NU];
+    double Fux[ORC_MAX_N][ORC_NU][ORC_NX];
+    /* steps */
+    double dv[ORC_MAX_N + 1][ORC_NV];
+    double dpi[ORC_MAX_N + 1][ORC_NX];
+    double dlam[ORC_MAX_N + 1][ORC_MAX_ROWS];
+    double dt[ORC_MAX_N + 1][ORC_MAX_ROWS];
+    int bad;
+} ipm_ws;
+
+static void riccati_factor(const orc_qp *qp, ipm_ws *w)
+{
+    const int N = qp->N;
+    for (int i = 0; i < ORC_NX; i++)
+        for (int j = 0; j < ORC_NX; j++) w->P[N][i][j] = w->Hh[N][ORC_NU + i][ORC_NU + j];
+    for (int k = N - 1; k >= 0; k--) {
+        double T[ORC_NX][ORC_NV], F[ORC_NV][ORC_NV];
+        for (int i = 0; i < ORC_NX; i++)
+            for (int j = 0; j < ORC_NV; j++) {
+                double acc = 0.0;
+                for (int l = 0; l < ORC_NX; l++) acc += w->P[k + 1][i][l] * qp->BA[k][l][j];
+                T[i][j] = acc;
+            }
+        for (int i = 0; i < ORC_NV; i++)
+            for (int j = 0; j < ORC_NV; j++) {
+                double acc = w->Hh[k][i][j];
+                for (int l = 0; l < ORC_NX; l++) acc += qp->BA[k][l][i] * T[l][j];
+                F[i][j] = acc;
+            }
+        /* 2x2 Cholesky of Fuu and explicit inverse */
+        double l00 = sqrt(F[0][0]);
+        double l10 = F[1][0] / l00;
+        double d11 = F[1][1] - l10 * l10;
+        if (!(F[0][0] > 0.0) || !(d11 > 0.0)) w->bad = 1;
+        double l11 = sqrt(d11);
+        double i00 = 1.0 / l00, i11 = 1.0 / l11, i10 = -l10 * i00 * i11;   /* L^-1 */
+        w->Fuu_inv[k][0][0] = i00 * i00 + i10 * i10;
+        w->Fuu_inv[k][0][1] = w->Fuu_inv[k][1][0] = i10 * i11;
+        w->Fuu_inv[k][1][1] = i11 * i11;
+        for (int a = 0; a < ORC_NU; a++)
+            for (int j = 0; j < ORC_NX; j++) w->Fux[k][a][j] = F[a][ORC_NU + j];
+        for (int a = 0; a < ORC_NU; a++)
+            for (int j = 0; j < ORC_NX; j++)
+                w->K[k][a][j] = -(w->Fuu_inv[k][a][0] * w->Fux[k][0][j] + w->Fuu_inv[k][a][1] * w->Fux[k][1][j]);
+        for (int i = 0; i < ORC_NX; i++)
+            for (int j = 0; j < ORC_NX; j++)
+                w->P[k][i][j] = F[ORC_NU + i][ORC_NU + j] + w->Fux[k][0][i] * w->K[k][0][j] + w->Fux[k][1][i] * w->K[k][1][j];
+        for (int i = 0; i < ORC_NX; i++)
+            for (int j = i + 1; j < ORC_NX; j++) {
+                double s = 0.5 * (w->P[k][i][j] + w->P[k][j][i]);
+                w->P[k][i][j] = w->P[k][j][i] = s;
+            }
+    }
+}
+
+static void riccati_solve(const orc_qp *qp, ipm_ws *w)
+{
+    const int N = qp->N;
+    for (int i = 0; i < ORC_NX; i++) w->p[N][i] = w->gh[N][ORC_NU + i];
+    for (int k = N - 1; k >= 0; k--) {
+        double Pb[ORC_NX], f[ORC_NV];
+        for (int i = 0; i < ORC_NX; i++) {
+            double acc = w->p[k + 1][i];
+            for (int l = 0; l < ORC_NX; l++) acc += w->P[k + 1][i][l] * w->rb[k][l];
+            Pb[i] = acc;
+        }
+        for (int j = 0; j < ORC_NV; j++) {
+            double acc = w->gh[k][j];
+            for (int l = 0; l < ORC_NX; l++) acc += qp->BA[k][l][j] * Pb[l];
+            f[j] = acc;
+        }
+        for (int a = 0; a < ORC_NU; a++) w->kff[k][a] = -(w->Fuu_inv[k][a][0] * f[0] + w->Fuu_inv[k][a][1] * f[1]);
+        for (int i = 0; i < ORC_NX; i++)
+            w->p[k][i] = f[ORC_NU + i] + w->Fux[k][0][i] * w->kff[k][0] + w->Fux[k][1][i] * w->kff[k][1];
+    }
+    double dx[ORC_NX] = {0};
+    for (int k = 0; k < N; k++) {
+        for (int a = 0; a < ORC_NU; a++) {
+            double acc = w->kff[k][a];
+            for (int j = 0; j < ORC_NX; j++) acc += w->K[k][a][j] * dx[j];
+            w->dv[k][a] = acc;
+        }
+        for (int j = 0; j < ORC_NX; j++) w->dv[k][ORC_NU + j] = dx[j];
+        double dxn[ORC_NX];
+        for (int i = 0; i < ORC_NX; i++) {
+            double acc = w->rb[k][i];
+            for (int j = 0; j < ORC_NV; j++) acc += qp->BA[k][i][j] * w->dv[k][j];
+            dxn[i] = acc;
+        }
+        for (int i = 0; i < ORC_NX; i++) {
+            double acc = w->p[k + 1][i];
+            for (int l = 0; l < ORC_NX; l++) acc += w->P[k + 1][i][l] * dxn[l];
+            w->dpi[k + 1][i] = acc;
+        }
+        memcpy(dx, dxn, sizeof dx);
+    }
+    w->dv[N][0] = w->dv[N][1] = 0.0;
+    for (int j = 0; j < ORC_NX; j++) w->dv[N][ORC_NU + j] = dx[j];
+}
+
+/* gh = rg + sum_i sgn c (q + lam rd)/t ; then Riccati vector solve; then dt, dlam */
+static void newton_direction(const orc_qp *qp, const orc_qp_sol *s, ipm_ws *w)
+{
+    const int N = qp->N;
+    for (int k = 0; k <= N; k++) {
+        for (int j = 0; j < ORC_NV; j++) w->gh[k][j] = w->rg[k][j];
+        for (int i = 0; i < qp->nrow[k]; i++) {
+            double coef = qp->sgn[k][i] * (w->q[k][i] + s->lam[k][i] * w->rd[k][i]) / s->t[k][i];
+            for (int j = 0; j < ORC_NV; j++) w->gh[k][j] += coef * qp->C[k][i][j];
+        }
+    }
+    riccati_solve(qp, w);
+    for (int k = 0; k <= N; k++)
+        for (int i = 0; i < qp->nrow[k]; i++) {
+            double cdv = 0.0;
+            for (int j = 0; j < ORC_NV; j++) cdv += qp->C[k][i][j] * w->dv[k][j];
+            w->dt[k][i] = qp->sgn[k][i] * cdv + w->rd[k][i];
+            w->dlam[k][i] = -(w->q[k][i] + s->lam[k][i] * w->dt[k][i]) / s->t[k][i];
+        }
+}
+
+static double max_step(const orc_qp *qp, const orc_qp_sol *s, const ipm_ws *w)
+{
+    double alpha = 1e300;
+    for (int k = 0; k <= qp->N; k++)
+        for (int i = 0; i < qp->nrow[k]; i++) {
+            if (w->dt[k][i] < 0.0) { double a = -s->t[k][i] / w->dt[k][i]; if (a < alpha) alpha = a; }
+            if (w->dlam[k][i] < 0.0) { double a = -s->lam[k][i] / w->dlam[k][i]; if (a < alpha) alpha = a; }
+        }
+    return alpha;
+}
+
+void orc_qp_solve(const orc_qp *qp, orc_qp_sol *s, int iter_max, double tol, double mu0, double thr0)
+{
+    const int N = qp->N;
+    ipm_ws *w = (ipm_ws *)calloc(1, sizeof(ipm_ws));
+    int m = 0;
+    /* cold start: v = 0 (dx_0 = given), pi = 0, t = max(residual, thr0), lam = mu0 / t */
+    memset(s->v, 0, sizeof s->v); memset(s->pi, 0, sizeof s->pi);
+    for (int j = 0; j < ORC_NX; j++) s->v[0][ORC_NU + j] = qp->dx0[j];
+    for (int k = 0; k <= N; k++)
+        for (int i = 0; i < qp->nrow[k]; i++, m++) {
+            double cv = 0.0;
+            for (int j = 0; j < ORC_NV; j++) cv += qp->C[k][i][j] * s->v[k][j];
+            double r = qp->sgn[k][i] * (cv - qp->beta[k][i]);
+            s->t[k][i] = r > thr0 ? r : thr0;
+            s->lam[k][i] = mu0 / s->t[k][i];
+        }
+    s->status = 2; s->iters = 0;
+    for (int it = 0;; it++) {
+        /* ---- residuals ---- */
+        double res_g = 0.0, res_b = 0.0, res_d = 0.0, res_m = 0.0, mu = 0.0;
+        for (int k = 0; k <= N; k++) {
+            for (int i = 0; i < ORC_NV; i++) {
+                double acc = qp->g[k][i];
+                for (int j = 0; j < ORC_NV; j++) acc += qp->W[k][i][j] * s->v[k][j];
+                if (k < N) for (int l = 0; l < ORC_NX; l++) acc += qp->BA[k][l][i] * s->pi[k + 1][l];
+                if (i >= ORC_NU && k >= 1) acc -= s->pi[k][i - ORC_NU];
+                w->rg[k][i] = acc;
+            }
+            for (int i = 0; i < qp->nrow[k]; i++) {
+                double cv = 0.0;
+                for (int j = 0; j < ORC_NV; j++) cv += qp->C[k][i][j] * s->v[k][j];
+                for (int j = 0; j < ORC_NV; j++) w->rg[k][j] -= qp->sgn[k][i] * s->lam[k][i] * qp->C[k][i][j];
+                w->rd[k][i] = qp->sgn[k][i] * (cv - qp->beta[k][i]) - s->t[k][i];
+                double comp = s->lam[k][i] * s->t[k][i];
+                mu += comp;
+                if (fabs(w->rd[k][i]) > res_d) res_d = fabs(w->rd[k][i]);
+                if (comp > res_m) res_m = comp;
+            }
+            if (k == N) w->rg[k][0] = w->rg[k][1] = 0.0;               /* no inputs at the terminal node */
+            if (k == 0) for (int i = ORC_NU; i < ORC_NV; i++) w->rg[k][i] = 0.0;   /* dx_0 is fixed */
+            for (int i = 0; i < ORC_NV; i++) if (fabs(w->rg[k][i]) > res_g) res_g = fabs(w->rg[k][i]);
+            if (k < N)
+                for (int i = 0; i < ORC_NX; i++) {
+                    double acc = qp->b[k][i] - s->v[k + 1][ORC_NU + i];
+                    for (int j = 0; j < ORC_NV; j++) acc += qp->BA[k][i][j] * s->v[k][j];
+                    w->rb[k][i] = acc;
+                    if (fabs(acc) > res_b) res_b = fabs(acc);
+                }
+        }
+        mu = m > 0 ? mu / m : 0.0;
+        if (!(isfinite(res_g) && isfinite(res_b) && isfinite(res_d) && isfinite(res_m))) { s->status = 4; break; }
+        if (res_g <= tol && res_b <= tol && res_d <= tol && res_m <= tol) { s->status = 0; break; }
+        if (it >= iter_max) { s->status = 2; break; }
+        s->iters = it + 1;
+
+        /* ---- barrier-augmented Hessian + factorisation ---- */
+        for (int k = 0; k <= N; k++) {
+            memcpy(w->Hh[k], qp->W[k], sizeof w->Hh[k]);
+            for (int i = 0; i < qp->nrow[k]; i++) {
+                double d = s->lam[k][i] / s->t[k][i];
+                for (int a = 0; a < ORC_NV; a++)
+                    for (int b = 0; b < ORC_NV; b++) w->Hh[k][a][b] += d * qp->C[k][i][a] * qp->C[k][i][b];
+            }
+        }
+        w->bad = 0;
+        riccati_factor(qp, w);
+        if (w->bad) { s->status = 4; break; }
+
+        /* ---- predictor (sigma = 0) ---- */
+        for (int k = 0; k <= N; k++) for (int i = 0; i < qp->nrow[k]; i++) w->q[k][i] = s->lam[k][i] * s->t[k][i];
+        newton_direction(qp, s, w);
+        double a_aff = max_step(qp, s, w); if (a_aff > 1.0) a_aff = 1.0;
+        double mu_aff = 0.0;
+        for (int k = 0; k <= N; k++)
+            for (int i = 0; i < qp->nrow[k]; i++)
+                mu_aff += (s->lam[k][i] + a_aff * w->dlam[k][i]) * (s->t[k][i] + a_aff * w->dt[k][i]);
+        mu_aff = m > 0 ? mu_aff / m : 0.0;
+        double sigma = mu > 0.0 ? (mu_aff / mu) : 0.0; sigma = sigma * sigma * sigma;
+
+        /* ---- corrector ---- */
+        for (int k = 0; k <= N; k++)
+            for (int i = 0; i < qp->nrow[k]; i++)
+                w->q[k][i] = s->lam[k][i] * s->t[k][i] - sigma * mu + w->dt[k][i] * w->dlam[k][i];
+        newton_direction(qp, s, w);
+        double alpha = 0.995 * max_step(qp, s, w); if (alpha > 1.0) alpha = 1.0;
+        if (!isfinite(alpha)) { s->status = 4; break; }
+        if (alpha < 1e-12) { s->status = 3; break; }
+
+        for (int k = 0; k <= N; k++) {
+            for (int j = 0; j < ORC_NV; j++) s->v[k][j] += alpha * w->dv[k][j];
+            if (k >= 1) for (int j = 0; j < ORC_NX; j++) s->pi[k][j] += alpha * w->dpi[k][j];
+            for (int i = 0; i < qp->nrow[k]; i++) {
+                s->lam[k][i] += alpha * w->dlam[k][i];
+                s->t[k][i] += alpha * w->dt[k][i];
+            }
+        }
+    }
+    free(w);
+}

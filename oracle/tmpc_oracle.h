@@ -1,0 +1,130 @@
+/*
+ * oracle/tmpc_oracle.h -- CPU ORACLE (TEST INFRASTRUCTURE, NOT PRODUCT CODE)
+ *
+ * Plain-C FP64 restatement of what tud-amr/mpc_planner's `Solver::solve()` makes acados do for the
+ * Jackal T-MPC problem (SURVEY.md Appendix A + B).  Only tests/, __graft_entry__.smoke() and the
+ * `cpu_baseline` leg of bench.py may link or call this library; the product path
+ * (mpc_planner_amd/) never does.
+ *
+ * PARITY STATUS: "parity unpinned" at the acados boundary -- acados/HPIPM/CasADi are un-vendored,
+ * unpinned third parties absent from /root/reference (README.md:225-232) and the reference's own tests
+ * assert no numerical solve result.  What IS pinned:
+ *   - stage cost / constraints / dynamics and all first+second derivatives against golden vectors made
+ *     by executing the reference's own python modules (tests/golden/make_golden.py),
+ *   - the reference-test anchors objective = 25.0, constraint = 125.0 (test_control_modules.py:56-59,89-95),
+ *   - parameter counts / index map (test_control_modules.py:53,86),
+ *   - converged-SQP optimum against scipy SLSQP on the same NLP (tests/test_oracle_solve.py).
+ * Every [UPSTREAM] default assumed about acados is listed in DESIGN.md.
+ *
+ * Reference files restated (see each function for file:line):
+ *   solver_generator/solver_model.py:193-214          dynamics, bounds
+ *   solver_generator/generate_acados_solver.py:86-177  OCP + solver options
+ *   solver_generator/spline.py:4-86, util/math.py:5-7  glued spline, rotation matrix
+ *   mpc_planner_modules/scripts/{mpc_base,contouring,ellipsoid_constraints,guidance_constraints}.py
+ *   mpc_planner_solver/src/acados_solver_interface.cpp:86-204,274-284   runtime protocol
+ *   mpc_planner_modules/src/guidance_constraints.cpp:264-434            batch loop + selection
+ */
+#ifndef TMPC_ORACLE_H
+#define TMPC_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_NU 2
+#define ORC_NX 5
+#define ORC_NV 7
+#define ORC_MAX_N 32
+#define ORC_MAX_NH 32   /* general inequality rows per stage */
+
+/* Problem description: sizes + parameter index map (util/parameters.py:25-55). */
+typedef struct {
+    int N;          /* horizon (shooting intervals); nodes 0..N */
+    int S;          /* contouring spline segments */
+    int n_lin;      /* topology halfspace rows per stage (0 = no GuidanceConstraints module) */
+    int M;          /* ellipsoid rows per stage (max_obstacles * n_discs, n_discs = 1) */
+    int npar;       /* parameters per stage */
+    double dt;      /* integrator_step */
+    /* solver options (generate_acados_solver.py:143-177, settings.yaml:16-17) */
+    int n_sqp;          /* RTI iterations per solve() */
+    int qp_iter_max;    /* 50 */
+    double qp_tol;      /* 1e-5 */
+    double reg_eps;     /* MIRROR epsilon, [UPSTREAM default] 1e-4 */
+    double ipm_mu0;     /* IPM initial barrier */
+    double ipm_thr0;    /* IPM slack floor at initialisation */
+    int erk_steps;      /* 3 */
+    /* state/input box bounds, order [a,w,x,y,psi,v,spline] (solver_model.py:204-205) */
+    double lb[ORC_NV];
+    double ub[ORC_NV];
+} orc_problem;
+
+/* Fill sizes, default options and bounds for the Jackal contouring unicycle. */
+void orc_problem_init(orc_problem *pb, int N, int S, int n_lin, int M);
+
+/* parameter index helpers (index into one stage's parameter row) */
+int orc_idx_weight(const orc_problem *pb, int which);           /* 0..7 */
+int orc_idx_spline(const orc_problem *pb, int seg, int which);  /* which: 0..8 = xa,xb,xc,xd,ya,yb,yc,yd,start */
+int orc_idx_lin(const orc_problem *pb, int j, int which);       /* which: 0..2 = a1,a2,b */
+int orc_idx_disc_radius(const orc_problem *pb);
+int orc_idx_disc_offset(const orc_problem *pb);
+int orc_idx_ellipsoid(const orc_problem *pb, int j, int which); /* which: 0..6 = x,y,psi,major,minor,chi,r */
+
+/* ---- stage functions with exact first/second derivatives (forward-mode 2nd-order jets) ---------- */
+/* z = [a,w,x,y,psi,v,spline]; p = one stage's parameter row. */
+void orc_stage_cost(const orc_problem *pb, const double *z, const double *p,
+                    double *val, double grad[ORC_NV], double hess[ORC_NV * ORC_NV]);
+/* h[0..n_lin) topology rows (<= 0), h[n_lin..n_lin+M) ellipsoid rows (>= 1) */
+void orc_stage_constraints(const orc_problem *pb, const double *z, const double *p,
+                           double *h, double *jac /* nh x NV */, double *hess /* nh x NV x NV */);
+void orc_continuous_dynamics(const double *z, double f[ORC_NX]);
+/* ERK4 x erk_steps over dt.  jac: NX x NV (d x_next / d [u;x]); hess: NX x NV x NV */
+void orc_discrete_dynamics(const orc_problem *pb, const double *z,
+                           double xnext[ORC_NX], double *jac, double *hess);
+void orc_constraint_bounds(const orc_problem *pb, double *lh, double *uh);
+
+/* MIRROR regularisation of an n x n symmetric matrix (row-major, in place): V max(|e|,eps) V^T */
+void orc_mirror(double *W, int n, double eps);
+
+/* ---- one solve ------------------------------------------------------------------------------- */
+typedef struct {
+    double pobj;      /* ocp_nlp_eval_cost at the returned iterate */
+    double res_eq;    /* inf-norm of dynamics defects + initial condition at the returned iterate */
+    int exit_code;    /* Forces-style: 1 success, 0 generic failure, 2 maxit, 3 minstep, 4 QP failure */
+    int qp_status;    /* 0 ok, 2 max iter, 3 min step, 4 NaN */
+    int sqp_iter;     /* RTI iterations executed */
+    int qp_iter_total;/* IPM iterations summed over all QPs */
+} orc_info;
+
+/* xinit[NX]; x0[(N+1)*NV] warm start laid out [u_k; x_k] per node (acados_solver_interface.h:53-54);
+ * params[N*npar]; xtraj[(N+1)*NX]; utraj[N*NU].  Fresh solver state (zero multipliers). */
+void orc_solve(const orc_problem *pb, const double *xinit, const double *x0, const double *params,
+               double *xtraj, double *utraj, orc_info *info);
+
+/* Optional debug capture of the first linearisation / QP of a solve (for per-phase GPU diffing). */
+typedef struct {
+    double W[(ORC_MAX_N + 1) * ORC_NV * ORC_NV];
+    double g[(ORC_MAX_N + 1) * ORC_NV];
+    double BA[ORC_MAX_N * ORC_NX * ORC_NV];
+    double b[ORC_MAX_N * ORC_NX];
+    double h[ORC_MAX_N * ORC_MAX_NH];
+    double D[ORC_MAX_N * ORC_MAX_NH * ORC_NV];
+    double dz[(ORC_MAX_N + 1) * ORC_NV];   /* QP solution */
+    double pi[(ORC_MAX_N + 1) * ORC_NX];
+    int qp_iters;
+} orc_debug;
+void orc_solve_debug(const orc_problem *pb, const double *xinit, const double *x0, const double *params,
+                     double *xtraj, double *utraj, orc_info *info, orc_debug *dbg, int capture_sqp_iter);
+
+/* ---- batch (restates the OpenMP loop of guidance_constraints.cpp:279-361) ------------------------ */
+/* B trajectories; xinit[B][NX], x0[B][(N+1)*NV], params[B][N*npar]; outputs per trajectory. */
+void orc_solve_batch(const orc_problem *pb, int B, const double *xinit, const double *x0,
+                     const double *params, double *xtraj, double *utraj, orc_info *info, int num_threads);
+
+/* FindBestPlanner (guidance_constraints.cpp:416-434): argmin of objective*weight over enabled &
+ * success; init 1e10, strict '<' => lowest index wins ties; -1 if none. */
+int orc_find_best(int B, const double *objective, const int *exit_code, const unsigned char *disabled);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,132 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle_tmpc.so).  TEST INFRASTRUCTURE ONLY:
+imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg -- never by the product."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+NU, NX, NV = 2, 5, 7
+MAX_N, MAX_NH = 32, 32
+
+
+class Problem(C.Structure):
+    _fields_ = [("N", C.c_int), ("S", C.c_int), ("n_lin", C.c_int), ("M", C.c_int), ("npar", C.c_int),
+                ("dt", C.c_double), ("n_sqp", C.c_int), ("qp_iter_max", C.c_int), ("qp_tol", C.c_double),
+                ("reg_eps", C.c_double), ("ipm_mu0", C.c_double), ("ipm_thr0", C.c_double),
+                ("erk_steps", C.c_int), ("lb", C.c_double * NV), ("ub", C.c_double * NV)]
+
+
+class Info(C.Structure):
+    _fields_ = [("pobj", C.c_double), ("res_eq", C.c_double), ("exit_code", C.c_int),
+                ("qp_status", C.c_int), ("sqp_iter", C.c_int), ("qp_iter_total", C.c_int)]
+
+
+class Debug(C.Structure):
+    _fields_ = [("W", C.c_double * ((MAX_N + 1) * NV * NV)), ("g", C.c_double * ((MAX_N + 1) * NV)),
+                ("BA", C.c_double * (MAX_N * NX * NV)), ("b", C.c_double * (MAX_N * NX)),
+                ("h", C.c_double * (MAX_N * MAX_NH)), ("D", C.c_double * (MAX_N * MAX_NH * NV)),
+                ("dz", C.c_double * ((MAX_N + 1) * NV)), ("pi", C.c_double * ((MAX_N + 1) * NX)),
+                ("qp_iters", C.c_int)]
+
+
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(ORACLE_DIR, "liboracle_tmpc.so")
+        if not os.path.exists(path):
+            build()
+        _lib = C.CDLL(path)
+        _lib.orc_find_best.restype = C.c_int
+    return _lib
+
+
+def dptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def problem(N=20, S=5, n_lin=8, M=8, **opts):
+    pb = Problem()
+    lib().orc_problem_init(C.byref(pb), N, S, n_lin, M)
+    for k, v in opts.items():
+        setattr(pb, k, v)
+    return pb
+
+
+def stage_cost(pb, z, p):
+    z = np.ascontiguousarray(z, float); p = np.ascontiguousarray(p, float)
+    val = C.c_double(); g = np.zeros(NV); H = np.zeros((NV, NV))
+    lib().orc_stage_cost(C.byref(pb), dptr(z), dptr(p), C.byref(val), dptr(g), dptr(H))
+    return val.value, g, H
+
+
+def stage_constraints(pb, z, p):
+    z = np.ascontiguousarray(z, float); p = np.ascontiguousarray(p, float)
+    nh = pb.n_lin + pb.M
+    h = np.zeros(nh); J = np.zeros((nh, NV)); H = np.zeros((nh, NV, NV))
+    lib().orc_stage_constraints(C.byref(pb), dptr(z), dptr(p), dptr(h), dptr(J), dptr(H))
+    return h, J, H
+
+
+def discrete_dynamics(pb, z):
+    z = np.ascontiguousarray(z, float)
+    xn = np.zeros(NX); J = np.zeros((NX, NV)); H = np.zeros((NX, NV, NV))
+    lib().orc_discrete_dynamics(C.byref(pb), dptr(z), dptr(xn), dptr(J), dptr(H))
+    return xn, J, H
+
+
+def continuous_dynamics(z):
+    z = np.ascontiguousarray(z, float); f = np.zeros(NX)
+    lib().orc_continuous_dynamics(dptr(z), dptr(f))
+    return f
+
+
+def mirror(W, eps=1e-4):
+    W = np.array(W, float, order="C"); n = W.shape[0]
+    lib().orc_mirror(dptr(W), n, C.c_double(eps))
+    return W
+
+
+def solve(pb, xinit, x0, params, debug_iter=None):
+    xinit = np.ascontiguousarray(xinit, float); x0 = np.ascontiguousarray(x0, float)
+    params = np.ascontiguousarray(params, float)
+    xt = np.zeros((pb.N + 1, NX)); ut = np.zeros((pb.N, NU)); info = Info()
+    if debug_iter is None:
+        lib().orc_solve(C.byref(pb), dptr(xinit), dptr(x0), dptr(params), dptr(xt), dptr(ut), C.byref(info))
+        return xt, ut, info
+    dbg = Debug()
+    lib().orc_solve_debug(C.byref(pb), dptr(xinit), dptr(x0), dptr(params), dptr(xt), dptr(ut),
+                          C.byref(info), C.byref(dbg), int(debug_iter))
+    return xt, ut, info, dbg
+
+
+def solve_batch(pb, xinit, x0, params, num_threads=0):
+    B = xinit.shape[0]
+    xinit = np.ascontiguousarray(xinit, float); x0 = np.ascontiguousarray(x0, float)
+    params = np.ascontiguousarray(params, float)
+    xt = np.zeros((B, pb.N + 1, NX)); ut = np.zeros((B, pb.N, NU)); infos = (Info * B)()
+    nt = num_threads or os.cpu_count()
+    lib().orc_solve_batch(C.byref(pb), B, dptr(xinit), dptr(x0), dptr(params), dptr(xt), dptr(ut), infos, nt)
+    out = dict(pobj=np.array([i.pobj for i in infos]), res_eq=np.array([i.res_eq for i in infos]),
+               exit_code=np.array([i.exit_code for i in infos], np.int32),
+               qp_status=np.array([i.qp_status for i in infos], np.int32),
+               sqp_iter=np.array([i.sqp_iter for i in infos], np.int32),
+               qp_iter_total=np.array([i.qp_iter_total for i in infos], np.int32))
+    return xt, ut, out
+
+
+def find_best(objective, exit_code, disabled=None):
+    objective = np.ascontiguousarray(objective, float)
+    exit_code = np.ascontiguousarray(exit_code, np.int32)
+    B = len(objective)
+    dis = None if disabled is None else np.ascontiguousarray(disabled, np.uint8).ctypes.data_as(C.POINTER(C.c_ubyte))
+    return lib().orc_find_best(B, dptr(objective), exit_code.ctypes.data_as(C.POINTER(C.c_int)), dis)
