@@ -1,0 +1,125 @@
+"""Deterministic synthetic Jackal T-MPC scenes.
+
+seed = 1000 + scene_idx; weights/geometry from mpc_planner_jackalsimulator/config/settings.yaml:33-40,75-89.
+A scene = one control tick: one initial state, one reference path, M obstacles with constant-velocity
+predictions, and a batch of B guidance trajectories (+1 non-guided T-MPC++ planner if requested), each of
+which becomes one independent NLP (guidance_constraints.cpp:279-361).
+"""
+import numpy as np
+
+from . import modules as md
+from .parameters import define_parameters
+
+WEIGHTS = dict(acceleration=0.34, angular_velocity=0.85, velocity=0.55, reference_velocity=2.0,
+               contour=0.05, lag=0.75, terminal_angle=100.0, terminal_contouring=10.0)
+ROBOT_RADIUS = 0.325
+OBSTACLE_RADIUS = 0.4
+DT = 0.2
+A_MAX = 2.0   # max lateral amplitude of a guidance trajectory [m] (keeps homotopy classes dynamically reachable)
+
+
+def reference_path_segments(rng, S=5, seg_len=6.0):
+    """S cubic segments of 6 m along +x with a lateral sine, (a,b,c,d,start) per contouring.cpp:94-124."""
+    amp = rng.uniform(0.0, 1.0)
+    wavelength = rng.uniform(18.0, 36.0)
+    phase = rng.uniform(0.0, 2 * np.pi)
+    f = lambda x: amp * (np.sin(2 * np.pi * x / wavelength + phase) - np.sin(phase))
+    df = lambda x: amp * 2 * np.pi / wavelength * np.cos(2 * np.pi * x / wavelength + phase)
+    segs = np.zeros((S, 9))
+    for i in range(S):
+        x0, x1, L = seg_len * i, seg_len * (i + 1), seg_len
+        y0, y1, m0, m1 = f(x0), f(x1), df(x0), df(x1)
+        # cubic Hermite in t = s - start
+        d = y0; c = m0
+        b = (3 * (y1 - y0) / L - 2 * m0 - m1) / L
+        a = (m0 + m1 - 2 * (y1 - y0) / L) / (L * L)
+        segs[i] = [0.0, 0.0, 1.0, x0, a, b, c, d, x0]
+    return segs
+
+
+def make_scene(scene_idx, N=20, M=8, B=64, S=5, tmpc_pp=False, gaussian=False, guidance=True):
+    """Returns dict(xinit [Bt][5], x0 [Bt][N+1][7], params [Bt][N][npar], pm, guidance_id [Bt])."""
+    rng = np.random.Generator(np.random.PCG64(1000 + scene_idx))
+    pm = define_parameters(S, M, guidance=guidance)
+    npar = pm.length()
+    state = np.array([0.0, 0.0, 0.0, rng.uniform(0.5, 2.0), 0.0])           # x,y,psi,v,spline
+    segs = reference_path_segments(rng, S)
+    # obstacles: constant velocity (data_preparation.cpp:58-79): mode[i] = pos0 + vel*dt*i.
+    # Half of them are "crossing pedestrians" timed to meet the robot's nominal progress along the path
+    # (so that topology / collision rows are active at the optimum, like the reference's
+    # pedestrian_simulator scenarios); the rest are background obstacles from the SURVEY 8d box.
+    speed = rng.uniform(0.6, 1.6, M)
+    heading = np.where(rng.uniform(size=M) < 0.5, 1.0, -1.0) * np.pi / 2 + rng.uniform(-0.5, 0.5, M)
+    vel = np.stack([speed * np.cos(heading), speed * np.sin(heading)], 1)
+    pos0 = np.stack([rng.uniform(3.0, 18.0, M), rng.uniform(-4.0, 4.0, M)], 1)
+    n_cross = (M + 1) // 2
+    v_nom = 0.5 * (state[3] + WEIGHTS["reference_velocity"])
+    for j in range(n_cross):
+        x_c = rng.uniform(1.5, 7.0)
+        t_c = x_c / v_nom + rng.uniform(-0.5, 0.5)
+        y_c = rng.uniform(-0.3, 0.3)
+        pos0[j] = np.array([x_c, y_c]) - vel[j] * t_c
+    steps = np.arange(N)[None, :, None]
+    obs = dict(pos=pos0[:, None, :] + vel[:, None, :] * DT * steps, angle=np.zeros((M, N)),
+               radius=np.full(M, OBSTACLE_RADIUS), major=np.zeros((M, N)), minor=np.zeros((M, N)),
+               chi=np.ones(M))
+    if gaussian:                                                            # data_preparation.cpp:170-186
+        acc = np.sqrt(np.cumsum(np.full(N, (0.3 * DT) ** 2)))
+        obs["major"][:] = acc; obs["minor"][:] = acc
+        obs["chi"][:] = -np.log(0.05) / 0.5                                 # ExponentialQuantile(0.5, 0.95)
+
+    base = np.zeros((N, npar))
+    md.mpc_base_set_parameters(pm, base, WEIGHTS)
+    md.contouring_set_parameters(pm, base, WEIGHTS, segs)
+    md.ellipsoid_set_parameters(pm, base, state[:2], obs, ROBOT_RADIUS)
+    main_x0 = md.initialize_with_forward_propagation(state, N, DT)
+
+    Bt = B + (1 if tmpc_pp else 0)
+    xinit = np.tile(state, (Bt, 1))
+    x0 = np.zeros((Bt, N + 1, 7)); params = np.zeros((Bt, N, npar))
+    guidance_id = np.zeros(Bt, np.int32)
+    T = N * DT; t = np.arange(N + 1) * DT
+    v_ref = WEIGHTS["reference_velocity"]
+    # longitudinal profile: accelerate from the current speed to v_ref within t_acc, then cruise
+    t_acc = 1.5
+    vx = state[3] + (v_ref - state[3]) * np.minimum(t / t_acc, 1.0)
+    xs = np.where(t < t_acc, state[3] * t + 0.5 * (v_ref - state[3]) * t * t / t_acc,
+                  state[3] * t_acc + 0.5 * (v_ref - state[3]) * t_acc + v_ref * (t - t_acc))
+    amps = np.linspace(-A_MAX, A_MAX, B) + rng.normal(0.0, 0.05, B) if B > 1 else np.array([rng.normal(0.0, 0.5)])
+    clearance = OBSTACLE_RADIUS + ROBOT_RADIUS + 0.1
+    for b in range(B):
+        best = None
+        for attempt in range(200):
+            A = amps[b] if attempt == 0 else rng.uniform(-A_MAX, A_MAX)
+            # lateral profile A sin^2(pi t/T): leaves and rejoins the path tangentially
+            gpos = np.stack([xs, A * np.sin(np.pi * t / T) ** 2], 1)
+            gvel = np.stack([vx, A * np.pi / T * np.sin(2 * np.pi * t / T)], 1)
+            d = np.linalg.norm(gpos[None, 1:N, :] - obs["pos"][:, :N - 1, :], axis=2).min()
+            if best is None or d > best[0]:
+                best = (d, gpos, gvel)
+            if d >= clearance:
+                break
+        _, gpos, gvel = best
+        x0[b] = md.initialize_solver_with_guidance(main_x0.copy(), gpos, gvel)
+        params[b] = base
+        if guidance:
+            lin = md.linearized_update(x0[b], obs["pos"], ROBOT_RADIUS)
+            md.linearized_set_parameters(pm, params[b], state[0], lin, n_rows=M)
+        guidance_id[b] = b
+    if tmpc_pp:                                                             # non-guided planner
+        x0[B] = main_x0
+        params[B] = base
+        md.linearized_set_parameters(pm, params[B], state[0], None, n_rows=M)
+        guidance_id[B] = 2 * B                                              # guidance_constraints.cpp:349
+    return dict(xinit=xinit, x0=x0, params=params, pm=pm, guidance_id=guidance_id, obstacles=obs,
+                segments=segs, N=N, M=M, S=S, n_lin=(M if guidance else 0))
+
+
+def make_batch(scene_indices, **kw):
+    """Concatenate scenes into one launch batch (throughput mode: S scenes x B trajectories)."""
+    scenes = [make_scene(i, **kw) for i in scene_indices]
+    out = dict(scenes[0])
+    for key in ("xinit", "x0", "params", "guidance_id"):
+        out[key] = np.concatenate([s[key] for s in scenes], 0)
+    out["scene_of"] = np.concatenate([np.full(len(s["xinit"]), i, np.int32) for i, s in enumerate(scenes)])
+    return out

@@ -12,6 +12,7 @@
  * equations, and (lam_i, t_i) >= 0 for every one-sided row  sgn_i (c_i^T v - beta_i) - t_i = 0.
  */
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include "qp.h"
@@ -24,12 +25,10 @@ typedef struct {
     double rd[ORC_MAX_N + 1][ORC_MAX_ROWS];
     double q[ORC_MAX_N + 1][ORC_MAX_ROWS];
     /* Riccati */
-    double P[ORC_MAX_N + 1][ORC_NX][ORC_NX];
+    double Lp[ORC_MAX_N + 1][ORC_NX][ORC_NX];   /* P_k = Lp Lp^T */
+    double L[ORC_MAX_N][ORC_NV][ORC_NV];        /* chol of the stage matrix F_k */
     double p[ORC_MAX_N + 1][ORC_NX];
-    double K[ORC_MAX_N][ORC_NU][ORC_NX];
-    double kff[ORC_MAX_N][ORC_NU];
-    double Fuu_inv[ORC_MAX_N][ORC_NU][ORC_NU];
-    double Fux[ORC_MAX_N][ORC_NU][ORC_NX];
+    double y[ORC_MAX_N][ORC_NU];
     /* steps */
     double dv[ORC_MAX_N + 1][ORC_NV];
     double dpi[ORC_MAX_N + 1][ORC_NX];
@@ -38,49 +37,73 @@ typedef struct {
     int bad;
 } ipm_ws;
 
+/*
+ * Square-root (Cholesky) Riccati recursion -- the form HPIPM uses [UPSTREAM], robust when the barrier
+ * terms lam/t become huge.  With P_{k+1} = Lp Lp^T:
+ *     G = Lp^T [B A]            (5 x 7)
+ *     F = Hh_k + G^T G          (7 x 7, ordering [u; x])
+ *     F = L L^T,  L = [Luu 0; Lxu Lxx]   =>   P_k = Lxx Lxx^T  (no subtraction of large numbers)
+ * The factor L of every stage is kept for the vector solves.
+ */
 static void riccati_factor(const orc_qp *qp, ipm_ws *w)
 {
     const int N = qp->N;
-    for (int i = 0; i < ORC_NX; i++)
-        for (int j = 0; j < ORC_NX; j++) w->P[N][i][j] = w->Hh[N][ORC_NU + i][ORC_NU + j];
+    /* terminal: Lp = chol(Hh_N,xx) */
+    {
+        double A[ORC_NX][ORC_NX];
+        for (int i = 0; i < ORC_NX; i++) for (int j = 0; j < ORC_NX; j++) A[i][j] = w->Hh[N][ORC_NU + i][ORC_NU + j];
+        for (int j = 0; j < ORC_NX; j++) {
+            double d = A[j][j];
+            for (int l = 0; l < j; l++) d -= w->Lp[N][j][l] * w->Lp[N][j][l];
+            if (!(d > 0.0)) w->bad = 1;
+            double ljj = sqrt(d);
+            w->Lp[N][j][j] = ljj;
+            for (int i = j + 1; i < ORC_NX; i++) {
+                double a = A[i][j];
+                for (int l = 0; l < j; l++) a -= w->Lp[N][i][l] * w->Lp[N][j][l];
+                w->Lp[N][i][j] = a / ljj;
+            }
+            for (int i = 0; i < j; i++) w->Lp[N][i][j] = 0.0;
+        }
+    }
     for (int k = N - 1; k >= 0; k--) {
-        double T[ORC_NX][ORC_NV], F[ORC_NV][ORC_NV];
+        double G[ORC_NX][ORC_NV], F[ORC_NV][ORC_NV];
         for (int i = 0; i < ORC_NX; i++)
             for (int j = 0; j < ORC_NV; j++) {
                 double acc = 0.0;
-                for (int l = 0; l < ORC_NX; l++) acc += w->P[k + 1][i][l] * qp->BA[k][l][j];
-                T[i][j] = acc;
+                for (int l = i; l < ORC_NX; l++) acc += w->Lp[k + 1][l][i] * qp->BA[k][l][j];   /* (Lp^T)_{il} = Lp_{li} */
+                G[i][j] = acc;
             }
         for (int i = 0; i < ORC_NV; i++)
-            for (int j = 0; j < ORC_NV; j++) {
+            for (int j = 0; j <= i; j++) {
                 double acc = w->Hh[k][i][j];
-                for (int l = 0; l < ORC_NX; l++) acc += qp->BA[k][l][i] * T[l][j];
+                for (int l = 0; l < ORC_NX; l++) acc += G[l][i] * G[l][j];
                 F[i][j] = acc;
             }
-        /* 2x2 Cholesky of Fuu and explicit inverse */
-        double l00 = sqrt(F[0][0]);
-        double l10 = F[1][0] / l00;
-        double d11 = F[1][1] - l10 * l10;
-        if (!(F[0][0] > 0.0) || !(d11 > 0.0)) w->bad = 1;
-        double l11 = sqrt(d11);
-        double i00 = 1.0 / l00, i11 = 1.0 / l11, i10 = -l10 * i00 * i11;   /* L^-1 */
-        w->Fuu_inv[k][0][0] = i00 * i00 + i10 * i10;
-        w->Fuu_inv[k][0][1] = w->Fuu_inv[k][1][0] = i10 * i11;
-        w->Fuu_inv[k][1][1] = i11 * i11;
-        for (int a = 0; a < ORC_NU; a++)
-            for (int j = 0; j < ORC_NX; j++) w->Fux[k][a][j] = F[a][ORC_NU + j];
-        for (int a = 0; a < ORC_NU; a++)
-            for (int j = 0; j < ORC_NX; j++)
-                w->K[k][a][j] = -(w->Fuu_inv[k][a][0] * w->Fux[k][0][j] + w->Fuu_inv[k][a][1] * w->Fux[k][1][j]);
-        for (int i = 0; i < ORC_NX; i++)
-            for (int j = 0; j < ORC_NX; j++)
-                w->P[k][i][j] = F[ORC_NU + i][ORC_NU + j] + w->Fux[k][0][i] * w->K[k][0][j] + w->Fux[k][1][i] * w->K[k][1][j];
-        for (int i = 0; i < ORC_NX; i++)
-            for (int j = i + 1; j < ORC_NX; j++) {
-                double s = 0.5 * (w->P[k][i][j] + w->P[k][j][i]);
-                w->P[k][i][j] = w->P[k][j][i] = s;
+        for (int j = 0; j < ORC_NV; j++) {
+            double d = F[j][j];
+            for (int l = 0; l < j; l++) d -= w->L[k][j][l] * w->L[k][j][l];
+            if (!(d > 0.0)) w->bad = 1;
+            double ljj = sqrt(d);
+            w->L[k][j][j] = ljj;
+            for (int i = j + 1; i < ORC_NV; i++) {
+                double a = F[i][j];
+                for (int l = 0; l < j; l++) a -= w->L[k][i][l] * w->L[k][j][l];
+                w->L[k][i][j] = a / ljj;
             }
+            for (int i = 0; i < j; i++) w->L[k][i][j] = 0.0;
+        }
+        for (int i = 0; i < ORC_NX; i++)
+            for (int j = 0; j < ORC_NX; j++) w->Lp[k][i][j] = w->L[k][ORC_NU + i][ORC_NU + j];
     }
+}
+
+/* y = P_{k} r = Lp (Lp^T r) */
+static void apply_P(const double Lp[ORC_NX][ORC_NX], const double *r, double *y)
+{
+    double tmp[ORC_NX];
+    for (int i = 0; i < ORC_NX; i++) { double a = 0.0; for (int l = i; l < ORC_NX; l++) a += Lp[l][i] * r[l]; tmp[i] = a; }
+    for (int i = 0; i < ORC_NX; i++) { double a = 0.0; for (int l = 0; l <= i; l++) a += Lp[i][l] * tmp[l]; y[i] = a; }
 }
 
 static void riccati_solve(const orc_qp *qp, ipm_ws *w)
@@ -89,27 +112,28 @@ static void riccati_solve(const orc_qp *qp, ipm_ws *w)
     for (int i = 0; i < ORC_NX; i++) w->p[N][i] = w->gh[N][ORC_NU + i];
     for (int k = N - 1; k >= 0; k--) {
         double Pb[ORC_NX], f[ORC_NV];
-        for (int i = 0; i < ORC_NX; i++) {
-            double acc = w->p[k + 1][i];
-            for (int l = 0; l < ORC_NX; l++) acc += w->P[k + 1][i][l] * w->rb[k][l];
-            Pb[i] = acc;
-        }
+        apply_P(w->Lp[k + 1], w->rb[k], Pb);
+        for (int i = 0; i < ORC_NX; i++) Pb[i] += w->p[k + 1][i];
         for (int j = 0; j < ORC_NV; j++) {
             double acc = w->gh[k][j];
             for (int l = 0; l < ORC_NX; l++) acc += qp->BA[k][l][j] * Pb[l];
             f[j] = acc;
         }
-        for (int a = 0; a < ORC_NU; a++) w->kff[k][a] = -(w->Fuu_inv[k][a][0] * f[0] + w->Fuu_inv[k][a][1] * f[1]);
+        /* y = Luu^-1 f_u ;  p_k = f_x - Lxu y */
+        double y0 = f[0] / w->L[k][0][0];
+        double y1 = (f[1] - w->L[k][1][0] * y0) / w->L[k][1][1];
+        w->y[k][0] = y0; w->y[k][1] = y1;
         for (int i = 0; i < ORC_NX; i++)
-            w->p[k][i] = f[ORC_NU + i] + w->Fux[k][0][i] * w->kff[k][0] + w->Fux[k][1][i] * w->kff[k][1];
+            w->p[k][i] = f[ORC_NU + i] - w->L[k][ORC_NU + i][0] * y0 - w->L[k][ORC_NU + i][1] * y1;
     }
     double dx[ORC_NX] = {0};
     for (int k = 0; k < N; k++) {
-        for (int a = 0; a < ORC_NU; a++) {
-            double acc = w->kff[k][a];
-            for (int j = 0; j < ORC_NX; j++) acc += w->K[k][a][j] * dx[j];
-            w->dv[k][a] = acc;
-        }
+        /* du = -Luu^-T (Lxu^T dx + y) */
+        double r0 = w->y[k][0], r1 = w->y[k][1];
+        for (int j = 0; j < ORC_NX; j++) { r0 += w->L[k][ORC_NU + j][0] * dx[j]; r1 += w->L[k][ORC_NU + j][1] * dx[j]; }
+        double u1 = -r1 / w->L[k][1][1];
+        double u0 = (-r0 - w->L[k][1][0] * u1) / w->L[k][0][0];
+        w->dv[k][0] = u0; w->dv[k][1] = u1;
         for (int j = 0; j < ORC_NX; j++) w->dv[k][ORC_NU + j] = dx[j];
         double dxn[ORC_NX];
         for (int i = 0; i < ORC_NX; i++) {
@@ -117,11 +141,8 @@ static void riccati_solve(const orc_qp *qp, ipm_ws *w)
             for (int j = 0; j < ORC_NV; j++) acc += qp->BA[k][i][j] * w->dv[k][j];
             dxn[i] = acc;
         }
-        for (int i = 0; i < ORC_NX; i++) {
-            double acc = w->p[k + 1][i];
-            for (int l = 0; l < ORC_NX; l++) acc += w->P[k + 1][i][l] * dxn[l];
-            w->dpi[k + 1][i] = acc;
-        }
+        apply_P(w->Lp[k + 1], dxn, w->dpi[k + 1]);
+        for (int i = 0; i < ORC_NX; i++) w->dpi[k + 1][i] += w->p[k + 1][i];
         memcpy(dx, dxn, sizeof dx);
     }
     w->dv[N][0] = w->dv[N][1] = 0.0;
@@ -210,6 +231,7 @@ void orc_qp_solve(const orc_qp *qp, orc_qp_sol *s, int iter_max, double tol, dou
                 }
         }
         mu = m > 0 ? mu / m : 0.0;
+        if (getenv("ORC_IPM_TRACE")) fprintf(stderr, "ipm it %d res_g %.3e res_b %.3e res_d %.3e res_m %.3e mu %.3e\n", it, res_g, res_b, res_d, res_m, mu);
         if (!(isfinite(res_g) && isfinite(res_b) && isfinite(res_d) && isfinite(res_m))) { s->status = 4; break; }
         if (res_g <= tol && res_b <= tol && res_d <= tol && res_m <= tol) { s->status = 0; break; }
         if (it >= iter_max) { s->status = 2; break; }
@@ -226,7 +248,7 @@ void orc_qp_solve(const orc_qp *qp, orc_qp_sol *s, int iter_max, double tol, dou
         }
         w->bad = 0;
         riccati_factor(qp, w);
-        if (w->bad) { s->status = 4; break; }
+        if (w->bad) { if (getenv("ORC_IPM_TRACE")) fprintf(stderr, "riccati: Fuu not PD\n"); s->status = 4; break; }
 
         /* ---- predictor (sigma = 0) ---- */
         for (int k = 0; k <= N; k++) for (int i = 0; i < qp->nrow[k]; i++) w->q[k][i] = s->lam[k][i] * s->t[k][i];
@@ -245,6 +267,7 @@ void orc_qp_solve(const orc_qp *qp, orc_qp_sol *s, int iter_max, double tol, dou
                 w->q[k][i] = s->lam[k][i] * s->t[k][i] - sigma * mu + w->dt[k][i] * w->dlam[k][i];
         newton_direction(qp, s, w);
         double alpha = 0.995 * max_step(qp, s, w); if (alpha > 1.0) alpha = 1.0;
+        if (getenv("ORC_IPM_TRACE")) fprintf(stderr, "   a_aff %.3e sigma %.3e alpha %.3e\n", a_aff, sigma, alpha);
         if (!isfinite(alpha)) { s->status = 4; break; }
         if (alpha < 1e-12) { s->status = 3; break; }
 

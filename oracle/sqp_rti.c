@@ -53,6 +53,12 @@ static void build_qp(const orc_problem *pb, const nlp_state *st, const double *x
         for (int r = 0; r < nh; r++)
             for (int i = 0; i < ORC_NV * ORC_NV; i++) W[i] += st->lam_h[k][r] * Hh[r * ORC_NV * ORC_NV + i];
         free(Hh);
+        if (dbg) {
+            memcpy(&dbg->W_raw[k * ORC_NV * ORC_NV], W, sizeof W);
+            for (int j = 0; j < ORC_NV; j++) dbg->z_in[k * ORC_NV + j] = z[j];
+            for (int j = 0; j < ORC_NX; j++) dbg->pi_in[(k + 1) * ORC_NX + j] = st->pi[k + 1][j];
+            for (int r = 0; r < nh; r++) dbg->lamh_in[k * ORC_MAX_NH + r] = st->lam_h[k][r];
+        }
         orc_mirror(W, ORC_NV, pb->reg_eps);
         for (int i = 0; i < ORC_NV; i++) {
             for (int j = 0; j < ORC_NV; j++) qp->W[k][i][j] = W[i * ORC_NV + j];

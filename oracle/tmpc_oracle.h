@@ -108,6 +108,10 @@ typedef struct {
     double b[ORC_MAX_N * ORC_NX];
     double h[ORC_MAX_N * ORC_MAX_NH];
     double D[ORC_MAX_N * ORC_MAX_NH * ORC_NV];
+    double W_raw[(ORC_MAX_N + 1) * ORC_NV * ORC_NV];  /* Lagrangian Hessian before MIRROR */
+    double z_in[(ORC_MAX_N + 1) * ORC_NV];             /* linearisation point */
+    double pi_in[(ORC_MAX_N + 1) * ORC_NX];            /* multipliers used in W_raw */
+    double lamh_in[ORC_MAX_N * ORC_MAX_NH];
     double dz[(ORC_MAX_N + 1) * ORC_NV];   /* QP solution */
     double pi[(ORC_MAX_N + 1) * ORC_NX];
     int qp_iters;

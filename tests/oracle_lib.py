@@ -28,6 +28,8 @@ class Debug(C.Structure):
     _fields_ = [("W", C.c_double * ((MAX_N + 1) * NV * NV)), ("g", C.c_double * ((MAX_N + 1) * NV)),
                 ("BA", C.c_double * (MAX_N * NX * NV)), ("b", C.c_double * (MAX_N * NX)),
                 ("h", C.c_double * (MAX_N * MAX_NH)), ("D", C.c_double * (MAX_N * MAX_NH * NV)),
+                ("W_raw", C.c_double * ((MAX_N + 1) * NV * NV)), ("z_in", C.c_double * ((MAX_N + 1) * NV)),
+                ("pi_in", C.c_double * ((MAX_N + 1) * NX)), ("lamh_in", C.c_double * (MAX_N * MAX_NH)),
                 ("dz", C.c_double * ((MAX_N + 1) * NV)), ("pi", C.c_double * ((MAX_N + 1) * NX)),
                 ("qp_iters", C.c_int)]
 
