@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""bench.py -- MPC solves/s of the batched T-MPC solve path on MI355X (BASELINE.json metric).
+
+A "step" = one pass of the hot path over one launch batch: `scenes` scenes x 64 guidance trajectories
+(configs[1]: Jackal MPCC, N=20, 8 obstacles, 64 T-MPC guidance trajectories per control tick), i.e. the batched
+counterpart of GuidanceConstraints::optimize (guidance_constraints.cpp:264-388): one solve launch over all
+trajectories + record packing + (N>1: ONE RCCL all-gather of the 16-byte records) + FindBestPlanner per scene.
+Inputs are resident in HBM before the timed region.  One solve = one trajectory's full Solver::solve()
+(n_sqp = 10 RTI iterations).  Weak scaling: every rank owns `scenes` x 64 trajectories of each scene's
+(64 x world_size)-trajectory guidance set.
+
+Usage: python bench.py --gpus N --steps K --warmup W        (N>1 via torch.distributed.run, see README/DESIGN)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_H, M_OBS, S_SEG, TRAJ = 20, 8, 5, 64          # configs[1]
+NV, NX, NU = 7, 5, 2
+HBM_PEAK_GBS = 8000.0                           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_VALU_PEAK_TFLOPS = 78.6                    # MI355X FP64 vector peak (AMD spec; f64 MFMA has the same rate)
+
+
+def flops_per_solve(n_sqp_mean, n_ipm_per_qp, N=N_H, nv=NV, nx=NX, nh=2 * M_OBS):
+    """SURVEY.md 8(d) algorithmic FP64 flop model, with MEASURED iteration counts."""
+    f_dyn = 12 * (2 * nx * nx * nv + 2 * nx * nv * nv + 20)
+    f_cost = 927
+    f_con = 43 * nh
+    f_reg = 10 * nv ** 3
+    f_ric = 2 * nh * nv * nv + 2 * nv ** 3 + 12 * nv * nv + 40 * (nv + nh)
+    return n_sqp_mean * (N * (f_dyn + f_cost + f_con + f_reg) + n_ipm_per_qp * N * f_ric)
+
+
+def bytes_per_solve(N=N_H, npar=135, nv=NV, nx=NX, nu=NU):
+    """SURVEY.md 8(d) compulsory HBM bytes: parameters + warm start + xinit in, trajectories out."""
+    return 8 * (N * npar + (N + 1) * nv + nx + (N + 1) * nx + N * nu)
+
+
+def cpu_baseline(n_scenes):
+    """Reported baseline (NOT the target): the restated acados-equivalent CPU path (oracle/, kind 'port'),
+    OpenMP over trajectories like guidance_constraints.cpp:279, on all host cores, bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    from mpc_planner_amd import scenes
+    pb = O.problem(N=N_H, S=S_SEG, n_lin=M_OBS, M=M_OBS)
+    cores = os.cpu_count()
+    batch = scenes.make_batch(range(n_scenes), N=N_H, M=M_OBS, B=TRAJ)
+    B = batch["xinit"].shape[0]
+    args = (pb, batch["xinit"], batch["x0"].reshape(B, -1), batch["params"].reshape(B, -1))
+    O.solve_batch(*args[:1], args[1][:cores], args[2][:cores], args[3][:cores], num_threads=cores)   # warm-up
+    t0 = time.perf_counter()
+    _, _, info = O.solve_batch(*args, num_threads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": B / dt, "unit": "solves/s", "cores": cores, "kind": "port",
+            "sample": f"{n_scenes} scenes x {TRAJ} trajectories = {B} solves of the same workload in {dt:.2f} s, "
+                      f"restated acados-equivalent C oracle (oracle/), OpenMP over trajectories"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scenes", type=int, default=64, help="scenes (control ticks) per launch per GPU")
+    ap.add_argument("--cpu-scenes", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--latency-reps", type=int, default=100)
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from mpc_planner_amd import scenes, solver, distributed as D
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    assert a.gpus == world, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+
+    # ---- synthetic inputs, resident in HBM before timing ------------------------------------
+    # rank r owns trajectories [64 r, 64 (r+1)) of every scene's guidance set -> different seeds per rank
+    first_scene = 100000 * rank
+    batch = scenes.make_batch(range(first_scene, first_scene + a.scenes), N=N_H, M=M_OBS, B=TRAJ)
+    B = batch["xinit"].shape[0]
+    t_xinit = torch.from_numpy(batch["xinit"]).to(dev)
+    t_x0 = torch.from_numpy(batch["x0"].reshape(B, -1)).to(dev)
+    t_params = torch.from_numpy(batch["params"].reshape(B, -1)).to(dev)
+    t_gid = torch.from_numpy(batch["guidance_id"].astype(np.int32) + TRAJ * rank).to(dev)
+    t_rec = torch.zeros((B, 2), dtype=torch.int64, device=dev)              # 16-byte tmpc_record each
+    t_best = torch.full((a.scenes,), -2, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+
+    dims = solver.default_dims(N=N_H, S=S_SEG, n_lin=M_OBS, M=M_OBS)
+    sv = solver.BatchedSolver(dims, B_max=B, device=local_rank)
+    sv.set_batch_device(B, t_xinit.data_ptr(), t_x0.data_ptr(), t_params.data_ptr())
+    sv.enable_timing(a.steps + a.warmup + 4)
+
+    def step():
+        sv.solve(sync=False)                                                # the dominant kernel
+        sv.pack_records(t_rec.data_ptr(), t_gid.data_ptr())
+        if world > 1:
+            sv.synchronize()                                                # records visible to torch's stream
+            gathered = D.all_gather_records(t_rec, world)                   # ONE RCCL all-gather, 16 B x B per rank
+            torch.cuda.current_stream().synchronize()
+            sv.select_best_records(gathered.data_ptr(), world, a.scenes, TRAJ, t_best.data_ptr())
+            step.keep = gathered
+        else:
+            sv.select_best_records(t_rec.data_ptr(), 1, a.scenes, TRAJ, t_best.data_ptr())
+
+    for _ in range(a.warmup):
+        step()
+    sv.synchronize()
+    sv.get_timings()                                                        # drop warm-up timings
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    sv.synchronize()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+    kernel_ms = sv.get_timings()                                            # HIP events on the launch stream
+
+    res = sv.get()
+    best = t_best.cpu().numpy()
+    ok = res["exit_code"] == 1
+    n_sqp_mean = float(res["sqp_iter"].mean())
+    ipm_per_qp = float(res["qp_iter_total"].sum() / max(res["sqp_iter"].sum(), 1))
+
+    # ---- p50 latency of one control tick (64 trajectories, host call -> best index on host) --------------
+    lat = None
+    if rank == 0 and a.latency_reps > 0:
+        one = solver.BatchedSolver(dims, B_max=TRAJ, device=local_rank)
+        sl = slice(0, TRAJ)
+        hx, h0, hp = batch["xinit"][sl], batch["x0"][sl], batch["params"][sl]
+        ts = []
+        for i in range(a.latency_reps + 10):
+            t1 = time.perf_counter()
+            one.set_batch(hx, h0, hp); one.solve(sync=False); b1 = one.select_best()
+            ts.append(time.perf_counter() - t1)
+        ts = np.array(ts[10:]) * 1e3
+        one.enable_timing(32)
+        for _ in range(20):
+            one.solve(sync=False)
+        k64 = one.get_timings()
+        lat = {"p50_ms": float(np.percentile(ts, 50)), "p90_ms": float(np.percentile(ts, 90)),
+               "kernel_ms_b64": float(np.median(k64)), "solves_per_s_b64": float(TRAJ / (np.percentile(ts, 50) * 1e-3)),
+               "includes": "H2D of params/warm start, solve kernel, FindBestPlanner, D2H of the index"}
+        one.close()
+
+    if rank == 0:
+        solves = B * world * a.steps
+        value = solves / elapsed
+        k_avg = float(np.mean(kernel_ms)) * 1e-3
+        fl = flops_per_solve(n_sqp_mean, ipm_per_qp)
+        by = bytes_per_solve()
+        tflops = B * fl / k_avg / 1e12
+        gbs = B * by / k_avg / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "round1_pmc.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "MPC solves/s (Jackal N=20, 8 obs)", "value": value, "unit": "solves/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"configs[1]: Jackal MPCC N=20, 8 obstacles, 64 T-MPC guidance trajectories per scene; "
+                                   f"{a.scenes} scenes x 64 = {B} trajectories per launch per GPU, n_sqp=10, qp_tol=1e-5",
+                       "trajectories_per_launch_per_gpu": B, "scenes_per_launch": a.scenes,
+                       "success_fraction": float(ok.mean()), "mean_sqp_iter": n_sqp_mean, "mean_ipm_iter_per_qp": ipm_per_qp,
+                       "parallelism": f"trajectory-sharded x{world}, one 16 B/trajectory all-gather" if world > 1 else "single GPU"},
+            "roofline": {"bound": "valu_fp64", "achieved": tflops, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": tflops / FP64_VALU_PEAK_TFLOPS, "traffic": traffic,
+                         "kernel": "tmpc_solve_kernel", "kernel_ms_avg": k_avg * 1e3, "flops_per_solve": fl,
+                         "note": "path is FP64-VALU/latency bound (SURVEY 8d): f64 MFMA on MI355X runs at the vector rate "
+                                 "and the blocks are 7x7, so the VALU roofline is the relevant one; HBM term below",
+                         "hbm": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": gbs / HBM_PEAK_GBS, "bytes_per_solve": by}},
+            "latency_b64": lat,
+            "best_index_sample": best[:4].tolist(),
+        }
+        if not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.cpu_scenes)
+        print(json.dumps(out))
+    sv.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,145 @@
+/*
+ * include/tmpc_hip.h -- C-ABI of the MI355X batched SQP/NLP solve path (libtmpc_hip.so).
+ *
+ * This is the drop-in boundary under tud-amr/mpc_planner's `MPCPlanner::Solver`
+ * (mpc_planner_solver/include/mpc_planner_solver/acados_solver_interface.h:93-222).  It replaces the inner
+ * acados C ABI the reference's Solver calls (all call sites in
+ * mpc_planner_solver/src/acados_solver_interface.cpp) with ONE batch-first interface: B independent
+ * trajectories (= B reference `Solver` instances, i.e. the `planners_` loop of
+ * mpc_planner_modules/src/guidance_constraints.cpp:279-361) are solved by one kernel launch.
+ *
+ * Plain C: opaque handle, plain pointers and sizes, int error codes.  No torch / HIP types in signatures
+ * (device pointers travel as void*), no CUDA-compat headers.
+ *
+ * Layouts (identical to the reference's host structs, so `Solver::_params` can be passed as-is):
+ *   xinit  [B][nx]            AcadosParameters::xinit            (acados_solver_interface.h:53)
+ *   x0     [B][(N+1)*nvar]    AcadosParameters::x0, [u_k; x_k]   (:54)
+ *   params [B][N*npar]        AcadosParameters::all_parameters   (:56), row k = stage k, node N reuses row N-1
+ *   xtraj  [B][(N+1)*nx]      AcadosOutput::xtraj                (:129)
+ *   utraj  [B][N*nu]          AcadosOutput::utraj                (:130)
+ * nx = 5, nu = 2, nvar = 7 (ContouringSecondOrderUnicycleModel, solver_generator/solver_model.py:193-214).
+ *
+ * Error convention: every function returns 0 on success, <0 on error (TMPC_ERR_*); tmpc_last_error()
+ * gives the message.  Per-trajectory solver outcomes use the reference's Forces-style exit codes
+ * (acados_solver_interface.cpp:197-203, 391-424): 1 success, 0 generic failure, 2 max iter, 3 min step,
+ * 4 QP failure; qp_status 0 ok / 2 max iter / 3 min step / 4 NaN.
+ */
+#ifndef TMPC_HIP_H
+#define TMPC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TMPC_NU 2
+#define TMPC_NX 5
+#define TMPC_NV 7
+
+#define TMPC_OK 0
+#define TMPC_ERR_INVALID (-1)      /* bad argument / unsupported dimensions */
+#define TMPC_ERR_HIP (-2)          /* HIP runtime error (message in tmpc_last_error) */
+#define TMPC_ERR_NO_DEVICE (-3)    /* no gfx950 device / kernels missing */
+
+/* Problem dimensions + solver options.  Replaces the compile-time SOLVER_* macros of the generated
+ * acados solver and the options of solver_generator/generate_acados_solver.py:143-177. */
+typedef struct tmpc_dims {
+    int32_t N;            /* horizon (settings.yaml "N"); nodes 0..N */
+    int32_t S;            /* contouring/num_segments */
+    int32_t n_lin;        /* topology halfspace rows per stage (max_obstacles + add_halfspaces; 0 = no guidance module) */
+    int32_t M;            /* ellipsoid rows per stage (max_obstacles, n_discs = 1) */
+    int32_t npar;         /* parameters per stage; must equal 8 + 9 S + 3 n_lin + 2 + 7 M */
+    int32_t n_sqp;        /* solver_settings/acados/iterations (RTI iterations per solve) */
+    int32_t qp_iter_max;  /* qp_solver_iter_max = 50 */
+    int32_t erk_steps;    /* sim_method_num_steps = 3 (ERK4) */
+    double dt;            /* integrator_step */
+    double qp_tol;        /* qp_tol = 1e-5 */
+    double reg_eps;       /* MIRROR epsilon (acados default 1e-4) */
+    double ipm_mu0;       /* interior-point initial barrier (10) */
+    double ipm_thr0;      /* interior-point initial slack floor (0.1) */
+    double lb[TMPC_NV];   /* model bounds, order [a,w,x,y,psi,v,spline] (solver_model.py:204-205) */
+    double ub[TMPC_NV];
+} tmpc_dims;
+
+typedef struct tmpc_handle tmpc_handle;
+
+/* Defaults for the Jackal contouring unicycle (settings.yaml + generate_acados_solver.py). */
+void tmpc_default_dims(tmpc_dims *d, int32_t N, int32_t S, int32_t n_lin, int32_t M);
+
+/* Replaces Solver_acados_create_capsule + Solver_acados_create_with_discretization
+ * (acados_solver_interface.cpp:17,33) for B_max solver instances at once.  Owns device buffers + stream. */
+int tmpc_create(tmpc_handle **out, const tmpc_dims *dims, int32_t B_max, int32_t device);
+/* Replaces Solver_acados_free + Solver_acados_free_capsule (:54,60). */
+void tmpc_destroy(tmpc_handle *h);
+const char *tmpc_last_error(const tmpc_handle *h);
+
+/* Replaces, for B solvers: ocp_nlp_constraints_model_set(lbx/ubx = xinit) (:124-125),
+ * Solver_acados_update_params (:127-135) and loadWarmstart's ocp_nlp_out_set (:274-284).
+ * Host pointers, copied H2D on the handle's stream. */
+int tmpc_set_batch(tmpc_handle *h, int32_t B, const double *xinit, const double *x0, const double *params);
+/* Same, inputs already resident in HBM (device pointers, same layouts); no copy is made. */
+int tmpc_set_batch_device(tmpc_handle *h, int32_t B, const void *d_xinit, const void *d_x0, const void *d_params);
+
+/* Replaces Solver::solve() = initializeOneIteration + n_sqp x solveOneIteration + completeOneIteration
+ * (:86-204) for all B trajectories: one kernel launch, asynchronous on the handle's stream. */
+int tmpc_solve(tmpc_handle *h);
+int tmpc_synchronize(tmpc_handle *h);
+
+/* Replaces ocp_nlp_out_get / ocp_nlp_get / ocp_nlp_eval_cost of completeOneIteration (:162-204).
+ * Any pointer may be NULL.  Synchronises the stream.  Host pointers. */
+int tmpc_get(tmpc_handle *h, double *xtraj, double *utraj, double *pobj, int32_t *exit_code,
+             int32_t *qp_status, int32_t *sqp_iter, double *res_eq, int32_t *qp_iter_total);
+
+/* Replaces FindBestPlanner (guidance_constraints.cpp:416-434) on device: argmin over trajectories
+ * [first, first+count) of pobj*weight among exit_code == 1 && !disabled; init 1e10, strict '<'
+ * (lowest index wins ties); *best = -1 if none.  weight/disabled are host pointers or NULL. */
+int tmpc_select_best(tmpc_handle *h, int32_t first, int32_t count, const double *weight,
+                     const uint8_t *disabled, int32_t *best);
+
+/* Device-resident result records for the multi-GPU all-gather: pointers to the handle's
+ * pobj[B] (f64) and exit_code[B] (i32) device arrays. */
+int tmpc_result_device_ptrs(tmpc_handle *h, void **d_pobj, void **d_exit_code);
+
+/* ---- multi-GPU sharding: a scene's trajectories are split over ranks; after the solve every rank
+ * packs one 16-byte record per local trajectory, the host all-gathers the record arrays (RCCL over xGMI via
+ * torch.distributed) and every rank runs the same deterministic selection over the gathered array. -------- */
+typedef struct tmpc_record {
+    double objective;     /* _info.pobj (x consistency weight if supplied) */
+    int32_t exit_code;    /* SolverResult::exit_code (guidance_constraints.h:32-50) */
+    int32_t guidance_id;  /* SolverResult::guidance_ID */
+} tmpc_record;
+
+/* Pack records of the handle's B trajectories into d_records[B] (device pointer, caller-owned).
+ * d_guidance_id: device int32[B] or NULL (then the local trajectory index); d_weight: device f64[B] or NULL. */
+int tmpc_pack_records(tmpc_handle *h, void *d_records, const void *d_guidance_id, const void *d_weight);
+
+/* FindBestPlanner over gathered records laid out [n_ranks][n_scenes][per_rank] (device pointer): for each scene
+ * the winner is the lowest GLOBAL index (rank*per_rank + t) among exit_code == 1 with the smallest objective
+ * (init 1e10, strict '<').  d_best: device int32[n_scenes], -1 if none.  Runs on the handle's stream. */
+int tmpc_select_best_records(tmpc_handle *h, const void *d_records, int32_t n_ranks, int32_t n_scenes,
+                             int32_t per_rank, void *d_best);
+
+/* Per-launch timing: when enabled, every tmpc_solve is bracketed by HIP events recorded on the handle's stream.
+ * tmpc_get_timings synchronises and returns the durations [ms] of the launches since enable/last read. */
+int tmpc_enable_timing(tmpc_handle *h, int32_t max_records);
+int tmpc_get_timings(tmpc_handle *h, float *ms, int32_t capacity, int32_t *n_out);
+
+/* Timing helper: runs tmpc_solve `reps` times back-to-back on the handle's stream, each bracketed by HIP
+ * events recorded on THAT stream, and returns the per-launch kernel durations in milliseconds. */
+int tmpc_time_solve(tmpc_handle *h, int32_t reps, float *ms_each);
+
+/* ---- test/debug entry points (used by tests/ to diff per-phase tensors against the oracle) -------- */
+/* Evaluate the stage functions on device for n points: z[n][7], p[n][npar] (host pointers).
+ * Outputs (host, may be NULL): cost[n], cost_grad[n][7], cost_hess[n][49], h[n][nh], h_jac[n][nh][7],
+ * x_next[n][5], x_jac[n][5][7]; lag_hess[n][49] = dt*hess(l) + sum_j pi[j] hess(x_next_j) +
+ * sum_r lamh[r] hess(h_r) (pi[n][5], lamh[n][nh] host inputs, NULL = zeros); mirror[n][49] = MIRROR(lag_hess). */
+int tmpc_debug_eval_stage(tmpc_handle *h, int32_t n, const double *z, const double *p, const double *pi,
+                          const double *lamh, double *cost, double *cost_grad, double *cost_hess,
+                          double *hval, double *h_jac, double *x_next, double *x_jac, double *lag_hess,
+                          double *mirror);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

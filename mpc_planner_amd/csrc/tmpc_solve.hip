@@ -1,0 +1,973 @@
+// mpc_planner_amd/csrc/tmpc_solve.hip -- batched SQP_RTI solve kernel for gfx950 (MI355X) + C-ABI.
+//
+// One workgroup (one 64-lane wavefront) owns one trajectory = one reference `Solver` instance
+// (mpc_planner_modules/src/guidance_constraints.cpp:279-361 runs them as OpenMP threads; here they are
+// workgroups of one launch).  All per-trajectory state of a solve -- iterate, multipliers, the stage blocks
+// [W g | B A b | D beta], the interior-point rows and the Riccati factors -- lives in LDS for the whole
+// solve; HBM is touched only for the inputs (xinit, warm start, parameter rows) and the outputs.
+//
+// Phases per RTI iteration (Solver::solve, acados_solver_interface.cpp:86-119):
+//   1. linearise     lane k = stage k: dynamics + sensitivities, cost/rows + derivatives, Lagrangian Hessian,
+//                    MIRROR (registers), stage block -> LDS
+//   2. QP            Mehrotra predictor-corrector IPM; per iteration: residuals, barrier Hessian, square-root
+//                    Riccati factorisation (backward sweep over stages, lanes over matrix entries, wave
+//                    shuffles inside the 7x7 Cholesky), two Riccati vector solves, row updates, wave reductions
+//   3. full step     z += dz, multipliers from the QP
+// then completeOneIteration (:162-204): cost, trajectories, res_eq, exit-code mapping.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/tmpc_hip.h"
+#include "tmpc_stage.hpp"
+
+namespace tmpc {
+
+constexpr int NT = 64;   // threads per trajectory (one wavefront)
+
+__constant__ int c_pi[NP28] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 4, 5, 5, 5, 5, 5, 5, 6, 6, 6, 6, 6, 6, 6};
+__constant__ int c_pj[NP28] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 3, 0, 1, 2, 3, 4, 0, 1, 2, 3, 4, 5, 0, 1, 2, 3, 4, 5, 6};
+
+// ---- per-trajectory LDS layout (doubles) ----------------------------------------------------
+struct Lds {
+    double *z, *pi, *W, *g, *BA, *b, *D, *beta;          // NLP iterate + stage blocks of the current QP
+    double *t, *lam, *invt, *qt;                         // interior-point rows
+    double *v, *pq, *Hh, *rg, *gh, *rb, *dv, *dpi, *pr, *y, *rdiag, *scr;
+    int nh, NG, GB, XB, nrows;
+};
+
+__host__ __device__ inline int lds_doubles(int N, int nh)
+{
+    const int nrows = N * nh + 4 * N + 10 * (N - 1);
+    int n = 0;
+    n += (N + 1) * NV + (N + 1) * NX + (N + 1) * NP28 + (N + 1) * NV + N * NX * NV + N * NX + N * nh * 3 + N * nh;
+    n += 4 * nrows;
+    n += (N + 1) * NV + (N + 1) * NX + (N + 1) * NP28 + 2 * (N + 1) * NV + N * NX + (N + 1) * NV + (N + 1) * NX +
+         (N + 1) * NX + N * NU + N * NU + 64;
+    return n;
+}
+
+__device__ __forceinline__ Lds carve(double *s, const Dims &d)
+{
+    Lds L;
+    const int N = d.N;
+    L.nh = d.n_lin + d.M;
+    L.NG = N * L.nh; L.GB = L.NG; L.XB = L.NG + 4 * N; L.nrows = L.XB + 10 * (N - 1);
+    auto take = [&](int n) { double *p = s; s += n; return p; };
+    L.z = take((N + 1) * NV); L.pi = take((N + 1) * NX); L.W = take((N + 1) * NP28); L.g = take((N + 1) * NV);
+    L.BA = take(N * NX * NV); L.b = take(N * NX); L.D = take(N * L.nh * 3); L.beta = take(N * L.nh);
+    L.t = take(L.nrows); L.lam = take(L.nrows); L.invt = take(L.nrows); L.qt = take(L.nrows);
+    L.v = take((N + 1) * NV); L.pq = take((N + 1) * NX); L.Hh = take((N + 1) * NP28);
+    L.rg = take((N + 1) * NV); L.gh = take((N + 1) * NV); L.rb = take(N * NX); L.dv = take((N + 1) * NV);
+    L.dpi = take((N + 1) * NX); L.pr = take((N + 1) * NX); L.y = take(N * NU); L.rdiag = take(N * NU);
+    L.scr = take(64);
+    return L;
+}
+
+// ---- wave reductions (one wavefront per workgroup) -----------------------------------------------
+__device__ __forceinline__ double wave_max(double x)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) x = fmax(x, __shfl_xor(x, o, 64));
+    return x;
+}
+__device__ __forceinline__ double wave_min(double x)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) x = fmin(x, __shfl_xor(x, o, 64));
+    return x;
+}
+__device__ __forceinline__ double wave_sum(double x)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) x += __shfl_xor(x, o, 64);
+    return x;
+}
+
+// ---- interior-point row access --------------------------------------------------------------------
+struct Row { int k, var, general; double sgn; };   // general: index into D/beta; box: var = z index
+
+__device__ __forceinline__ Row row_decode(const Lds &L, const Dims &d, int r)
+{
+    Row R;
+    if (r < L.NG) {
+        R.k = r / L.nh; const int j = r - R.k * L.nh;
+        R.general = r; R.var = -1; R.sgn = (j < d.n_lin) ? -1.0 : 1.0;   // topology rows: upper 0; ellipsoids: lower 1
+    } else if (r < L.XB) {
+        const int q = r - L.GB;
+        R.k = q >> 2; R.var = (q >> 1) & 1; R.general = -1; R.sgn = (q & 1) ? -1.0 : 1.0;
+    } else {
+        const int q = r - L.XB;
+        R.k = 1 + q / 10; const int rem = q - (R.k - 1) * 10;
+        R.var = 2 + (rem >> 1); R.general = -1; R.sgn = (rem & 1) ? -1.0 : 1.0;
+    }
+    return R;
+}
+__device__ __forceinline__ double row_dot(const Lds &L, const Row &R, const double *vec)
+{
+    const double *vk = vec + R.k * NV;
+    if (R.general >= 0) {
+        const double *Dr = L.D + R.general * 3;
+        return Dr[0] * vk[ZX] + Dr[1] * vk[ZY] + Dr[2] * vk[ZPSI];
+    }
+    return vk[R.var];
+}
+__device__ __forceinline__ double row_beta(const Lds &L, const Dims &d, const Row &R)
+{
+    if (R.general >= 0) return L.beta[R.general];
+    return (R.sgn > 0.0 ? d.lb[R.var] : d.ub[R.var]) - L.z[R.k * NV + R.var];
+}
+
+// ---- square-root Riccati: factorisation --------------------------------------------------------
+// Stage matrices are packed lower 7x7 in L.Hh (in: barrier-augmented Hessian, out: Cholesky factor of
+// F_k = Hh_k + G^T G, G = Lp^T [B A], Lp = trailing 5x5 of the next stage's factor).  Returns true on a
+// non-positive pivot.  Lane e < 28 owns entry (i,j) = (c_pi[e], c_pj[e]).
+__device__ __forceinline__ bool chol_lanes(double &f, int li, int lj, int c0, bool active, double *rinv_out)
+{
+    bool bad = false;
+    for (int c = c0; c < NV; c++) {
+        const double dpiv = __shfl(f, pidx(c, c), 64);
+        if (!(dpiv > 0.0)) bad = true;
+        const double rinv = 1.0 / sqrt(dpiv);
+        if (active && lj == c) f = (li == c) ? dpiv * rinv : f * rinv;
+        if (active && li == c && lj == c && rinv_out) *rinv_out = rinv;
+        const int si = active ? pidx(li, c) : 0, sj = active ? pidx(lj, c) : 0;
+        const double lic = __shfl(f, si, 64), ljc = __shfl(f, sj, 64);
+        if (active && lj > c) f -= lic * ljc;
+    }
+    return bad;
+}
+
+__device__ bool riccati_factor(const Lds &L, const Dims &d, int tid)
+{
+    const int N = d.N;
+    const bool own = tid < NP28;
+    const int li = own ? c_pi[tid] : 0, lj = own ? c_pj[tid] : 0;
+    bool bad = false;
+    // terminal node: Cholesky of the xx-block (rows/cols 2..6)
+    {
+        double f = own ? L.Hh[N * NP28 + tid] : 1.0;
+        const bool act = own && lj >= NU;
+        bad |= chol_lanes(f, li, lj, NU, act, nullptr);
+        if (act) L.Hh[N * NP28 + tid] = f;
+    }
+    __syncthreads();
+    for (int k = N - 1; k >= 0; k--) {
+        // G = Lp^T [B A]  (5 x 7) -> scratch
+        if (tid < NX * NV) {
+            const int i = tid / NV, j = tid - i * NV;
+            const double *Ln = L.Hh + (k + 1) * NP28;
+            const double *BA = L.BA + k * NX * NV;
+            double acc = 0.0;
+            for (int l = i; l < NX; l++) acc += Ln[pidx(NU + l, NU + i)] * BA[l * NV + j];
+            L.scr[tid] = acc;
+        }
+        __syncthreads();
+        double f = 1.0;
+        if (own) {
+            f = L.Hh[k * NP28 + tid];
+#pragma unroll
+            for (int l = 0; l < NX; l++) f += L.scr[l * NV + li] * L.scr[l * NV + lj];
+        }
+        double rinv = 0.0;
+        bad |= chol_lanes(f, li, lj, 0, own, &rinv);
+        if (own) {
+            L.Hh[k * NP28 + tid] = f;
+            if (li == lj && li < NU) L.rdiag[k * NU + li] = rinv;
+        }
+        __syncthreads();
+    }
+    return __any(bad);
+}
+
+// ---- square-root Riccati: vector solve (backward + forward), rhs gh / rb -> dv, dpi ------------------
+__device__ void riccati_solve(const Lds &L, const Dims &d, int tid)
+{
+    const int N = d.N;
+    if (tid < NX) L.pr[N * NX + tid] = L.gh[N * NV + NU + tid];
+    __syncthreads();
+    for (int k = N - 1; k >= 0; k--) {
+        const double *Ln = L.Hh + (k + 1) * NP28;     // Lp = Ln[2.., 2..]
+        const double *Lk = L.Hh + k * NP28;
+        // tmp = Lp^T rb
+        if (tid < NX) {
+            double acc = 0.0;
+            for (int l = tid; l < NX; l++) acc += Ln[pidx(NU + l, NU + tid)] * L.rb[k * NX + l];
+            L.scr[tid] = acc;
+        }
+        __syncthreads();
+        // Pb = Lp tmp + p_{k+1}
+        if (tid < NX) {
+            double acc = L.pr[(k + 1) * NX + tid];
+            for (int l = 0; l <= tid; l++) acc += Ln[pidx(NU + tid, NU + l)] * L.scr[l];
+            L.scr[8 + tid] = acc;
+        }
+        __syncthreads();
+        // f = gh_k + [B A]^T Pb
+        if (tid < NV) {
+            double acc = L.gh[k * NV + tid];
+            const double *BA = L.BA + k * NX * NV;
+#pragma unroll
+            for (int l = 0; l < NX; l++) acc += BA[l * NV + tid] * L.scr[8 + l];
+            L.scr[16 + tid] = acc;
+        }
+        __syncthreads();
+        // y = Luu^-1 f_u ; p_k = f_x - Lxu y
+        if (tid < NX) {
+            const double y0 = L.scr[16] * L.rdiag[k * NU];
+            const double y1 = (L.scr[17] - Lk[pidx(1, 0)] * y0) * L.rdiag[k * NU + 1];
+            if (tid == 0) { L.y[k * NU] = y0; L.y[k * NU + 1] = y1; }
+            L.pr[k * NX + tid] = L.scr[16 + NU + tid] - Lk[pidx(NU + tid, 0)] * y0 - Lk[pidx(NU + tid, 1)] * y1;
+        }
+        __syncthreads();
+    }
+    // forward sweep; dx_0 = 0
+    if (tid < NX) L.dv[NU + tid] = 0.0;
+    __syncthreads();
+    for (int k = 0; k < N; k++) {
+        const double *Lk = L.Hh + k * NP28;
+        if (tid == 0) {     // du = -Luu^-T (Lxu^T dx + y)
+            double r0 = L.y[k * NU], r1 = L.y[k * NU + 1];
+#pragma unroll
+            for (int j = 0; j < NX; j++) {
+                const double dxj = L.dv[k * NV + NU + j];
+                r0 += Lk[pidx(NU + j, 0)] * dxj; r1 += Lk[pidx(NU + j, 1)] * dxj;
+            }
+            const double u1 = -r1 * L.rdiag[k * NU + 1];
+            const double u0 = (-r0 - Lk[pidx(1, 0)] * u1) * L.rdiag[k * NU];
+            L.dv[k * NV] = u0; L.dv[k * NV + 1] = u1;
+        }
+        __syncthreads();
+        if (tid < NX) {
+            double acc = L.rb[k * NX + tid];
+            const double *BA = L.BA + k * NX * NV;
+#pragma unroll
+            for (int j = 0; j < NV; j++) acc += BA[tid * NV + j] * L.dv[k * NV + j];
+            L.dv[(k + 1) * NV + NU + tid] = acc;
+        }
+        __syncthreads();
+    }
+    if (tid < NU) L.dv[N * NV + tid] = 0.0;
+    // dpi_{k} = P_k dx_k + p_k, k = 1..N  (stage-parallel)
+    for (int it = tid; it < N * NX; it += NT) {
+        const int k = 1 + it / NX, i = it - (k - 1) * NX;
+        const double *Lk = L.Hh + k * NP28;
+        const double *dx = L.dv + k * NV + NU;
+        double acc = L.pr[k * NX + i];
+        for (int l = 0; l <= i; l++) {
+            double tl = 0.0;                                   // (Lp^T dx)_l
+            for (int m = l; m < NX; m++) tl += Lk[pidx(NU + m, NU + l)] * dx[m];
+            acc += Lk[pidx(NU + i, NU + l)] * tl;
+        }
+        L.dpi[k * NX + i] = acc;
+    }
+    __syncthreads();
+}
+
+// gh = rg + sum_rows sgn c (qt + d rd),  d = lam/t, rd = sgn (c.v - beta) - t ; predictor: qt = lam
+__device__ void build_rhs(const Lds &L, const Dims &d, int tid, bool predictor)
+{
+    const int N = d.N;
+    for (int it = tid; it < (N + 1) * NV; it += NT) {
+        const int k = it / NV, i = it - k * NV;
+        double acc = L.rg[it];
+        if (i < NU) {
+            if (k < N) {
+                for (int side = 0; side < 2; side++) {
+                    const int r = L.GB + k * 4 + i * 2 + side;
+                    const double sgn = side ? -1.0 : 1.0;
+                    const double beta = (side ? d.ub[i] : d.lb[i]) - L.z[k * NV + i];
+                    const double rd = sgn * (L.v[k * NV + i] - beta) - L.t[r];
+                    const double q = predictor ? L.lam[r] : L.qt[r];
+                    acc += sgn * (q + L.lam[r] * L.invt[r] * rd);
+                }
+            }
+        } else if (k >= 1 && k < N) {
+            for (int side = 0; side < 2; side++) {
+                const int r = L.XB + (k - 1) * 10 + (i - NU) * 2 + side;
+                const double sgn = side ? -1.0 : 1.0;
+                const double beta = (side ? d.ub[i] : d.lb[i]) - L.z[k * NV + i];
+                const double rd = sgn * (L.v[k * NV + i] - beta) - L.t[r];
+                const double q = predictor ? L.lam[r] : L.qt[r];
+                acc += sgn * (q + L.lam[r] * L.invt[r] * rd);
+            }
+        }
+        if (k < N && i >= ZX && i <= ZPSI) {
+            const double *vk = L.v + k * NV;
+            for (int j = 0; j < L.nh; j++) {
+                const int r = k * L.nh + j;
+                const double sgn = (j < d.n_lin) ? -1.0 : 1.0;
+                const double *Dr = L.D + r * 3;
+                const double cv = Dr[0] * vk[ZX] + Dr[1] * vk[ZY] + Dr[2] * vk[ZPSI];
+                const double rd = sgn * (cv - L.beta[r]) - L.t[r];
+                const double q = predictor ? L.lam[r] : L.qt[r];
+                acc += sgn * Dr[i - ZX] * (q + L.lam[r] * L.invt[r] * rd);
+            }
+        }
+        L.gh[it] = acc;
+    }
+    __syncthreads();
+}
+
+// One QP solve.  Returns status (0 ok, 2 max iter, 3 min step, 4 NaN); *iters = IPM iterations.
+__device__ int ipm_solve(const Lds &L, const Dims &d, int tid, int *iters_out)
+{
+    const int N = d.N;
+    const double m_rows = (double)L.nrows;
+    // cold start: v = 0 (dx_0 = xinit - x_0 is already in v[0]), pi = 0, t = max(r, thr0), lam = mu0/t
+    for (int r = tid; r < L.nrows; r += NT) {
+        const Row R = row_decode(L, d, r);
+        const double rr = R.sgn * (row_dot(L, R, L.v) - row_beta(L, d, R));
+        const double t = rr > d.thr0 ? rr : d.thr0;
+        L.t[r] = t; L.invt[r] = 1.0 / t; L.lam[r] = d.mu0 / t;
+    }
+    __syncthreads();
+    int status = 2, iters = 0;
+    for (int it = 0;; it++) {
+        // ---------------- residuals ----------------
+        double res_g = 0.0, res_b = 0.0, res_d = 0.0, res_m = 0.0, mu = 0.0;
+        for (int e = tid; e < (N + 1) * NV; e += NT) {
+            const int k = e / NV, i = e - k * NV;
+            double acc = 0.0;
+            const bool skip = (k == N && i < NU) || (k == 0 && i >= NU);
+            if (!skip) {
+                acc = L.g[e];
+                const double *Wk = L.W + k * NP28; const double *vk = L.v + k * NV;
+#pragma unroll
+                for (int j = 0; j < NV; j++) acc += Wk[sidx(i, j)] * vk[j];
+                if (k < N) {
+                    const double *BA = L.BA + k * NX * NV;
+#pragma unroll
+                    for (int l = 0; l < NX; l++) acc += BA[l * NV + i] * L.pq[(k + 1) * NX + l];
+                }
+                if (i >= NU && k >= 1) acc -= L.pq[k * NX + i - NU];
+                // - sum sgn lam c_i
+                if (i < NU) {
+                    const int r = L.GB + k * 4 + i * 2;
+                    acc += -L.lam[r] + L.lam[r + 1];
+                } else if (k < N) {      // k >= 1 here
+                    const int r = L.XB + (k - 1) * 10 + (i - NU) * 2;
+                    acc += -L.lam[r] + L.lam[r + 1];
+                }
+                if (k < N && i >= ZX && i <= ZPSI)
+                    for (int j = 0; j < L.nh; j++) {
+                        const int r = k * L.nh + j;
+                        const double sgn = (j < d.n_lin) ? -1.0 : 1.0;
+                        acc -= sgn * L.lam[r] * L.D[r * 3 + i - ZX];
+                    }
+            }
+            L.rg[e] = acc;
+            res_g = fmax(res_g, fabs(acc));
+        }
+        for (int e = tid; e < N * NX; e += NT) {
+            const int k = e / NX, i = e - k * NX;
+            double acc = L.b[e] - L.v[(k + 1) * NV + NU + i];
+            const double *BA = L.BA + k * NX * NV + i * NV; const double *vk = L.v + k * NV;
+#pragma unroll
+            for (int j = 0; j < NV; j++) acc += BA[j] * vk[j];
+            L.rb[e] = acc;
+            res_b = fmax(res_b, fabs(acc));
+        }
+        for (int r = tid; r < L.nrows; r += NT) {
+            const Row R = row_decode(L, d, r);
+            const double rd = R.sgn * (row_dot(L, R, L.v) - row_beta(L, d, R)) - L.t[r];
+            const double comp = L.lam[r] * L.t[r];
+            res_d = fmax(res_d, fabs(rd)); res_m = fmax(res_m, comp); mu += comp;
+        }
+        res_g = wave_max(res_g); res_b = wave_max(res_b); res_d = wave_max(res_d); res_m = wave_max(res_m);
+        mu = wave_sum(mu) / m_rows;
+        __syncthreads();
+        if (!(isfinite(res_g) && isfinite(res_b) && isfinite(res_d) && isfinite(res_m))) { status = 4; break; }
+        if (res_g <= d.qp_tol && res_b <= d.qp_tol && res_d <= d.qp_tol && res_m <= d.qp_tol) { status = 0; break; }
+        if (it >= d.qp_iter_max) { status = 2; break; }
+        iters = it + 1;
+
+        // ---------------- barrier-augmented Hessian ----------------
+        for (int e = tid; e < (N + 1) * NP28; e += NT) {
+            const int k = e / NP28, pe = e - k * NP28;
+            const int i = c_pi[pe], j = c_pj[pe];
+            double acc = L.W[e];
+            if (i == j) {
+                if (i < NU) {
+                    if (k < N) { const int r = L.GB + k * 4 + i * 2; acc += L.lam[r] * L.invt[r] + L.lam[r + 1] * L.invt[r + 1]; }
+                } else if (k >= 1 && k < N) {
+                    const int r = L.XB + (k - 1) * 10 + (i - NU) * 2;
+                    acc += L.lam[r] * L.invt[r] + L.lam[r + 1] * L.invt[r + 1];
+                }
+            }
+            if (k < N && j >= ZX && i <= ZPSI)       // i >= j: both in {x, y, psi}
+                for (int q = 0; q < L.nh; q++) {
+                    const int r = k * L.nh + q;
+                    acc += L.lam[r] * L.invt[r] * L.D[r * 3 + i - ZX] * L.D[r * 3 + j - ZX];
+                }
+            L.Hh[e] = acc;
+        }
+        __syncthreads();
+        if (riccati_factor(L, d, tid)) { status = 4; break; }
+
+        // ---------------- predictor ----------------
+        build_rhs(L, d, tid, true);
+        riccati_solve(L, d, tid);
+        double amax = 1e300;
+        for (int r = tid; r < L.nrows; r += NT) {
+            const Row R = row_decode(L, d, r);
+            const double rd = R.sgn * (row_dot(L, R, L.v) - row_beta(L, d, R)) - L.t[r];
+            const double dt = R.sgn * row_dot(L, R, L.dv) + rd;
+            const double dl = -L.lam[r] - L.lam[r] * L.invt[r] * dt;
+            if (dt < 0.0) amax = fmin(amax, -L.t[r] / dt);
+            if (dl < 0.0) amax = fmin(amax, -L.lam[r] / dl);
+            L.qt[r] = dt * dl;                      // keep dt_aff * dlam_aff for the corrector
+        }
+        double a_aff = fmin(1.0, wave_min(amax));
+        double mu_aff = 0.0;
+        for (int r = tid; r < L.nrows; r += NT) {
+            const Row R = row_decode(L, d, r);
+            const double rd = R.sgn * (row_dot(L, R, L.v) - row_beta(L, d, R)) - L.t[r];
+            const double dt = R.sgn * row_dot(L, R, L.dv) + rd;
+            const double dl = -L.lam[r] - L.lam[r] * L.invt[r] * dt;
+            mu_aff += (L.lam[r] + a_aff * dl) * (L.t[r] + a_aff * dt);
+        }
+        mu_aff = wave_sum(mu_aff) / m_rows;
+        double sigma = mu > 0.0 ? mu_aff / mu : 0.0;
+        sigma = sigma * sigma * sigma;
+        // ---------------- corrector ----------------
+        for (int r = tid; r < L.nrows; r += NT)
+            L.qt[r] = L.lam[r] + (L.qt[r] - sigma * mu) * L.invt[r];          // q / t
+        __syncthreads();
+        build_rhs(L, d, tid, false);
+        riccati_solve(L, d, tid);
+        amax = 1e300;
+        for (int r = tid; r < L.nrows; r += NT) {
+            const Row R = row_decode(L, d, r);
+            const double rd = R.sgn * (row_dot(L, R, L.v) - row_beta(L, d, R)) - L.t[r];
+            const double dt = R.sgn * row_dot(L, R, L.dv) + rd;
+            const double dl = -L.qt[r] - L.lam[r] * L.invt[r] * dt;
+            if (dt < 0.0) amax = fmin(amax, -L.t[r] / dt);
+            if (dl < 0.0) amax = fmin(amax, -L.lam[r] / dl);
+        }
+        const double alpha = fmin(1.0, 0.995 * wave_min(amax));
+        if (!isfinite(alpha)) { status = 4; break; }
+        if (alpha < 1e-12) { status = 3; break; }
+        // ---------------- update ----------------
+        for (int r = tid; r < L.nrows; r += NT) {
+            const Row R = row_decode(L, d, r);
+            const double rd = R.sgn * (row_dot(L, R, L.v) - row_beta(L, d, R)) - L.t[r];
+            const double dt = R.sgn * row_dot(L, R, L.dv) + rd;
+            const double dl = -L.qt[r] - L.lam[r] * L.invt[r] * dt;
+            const double tn = L.t[r] + alpha * dt;
+            L.t[r] = tn; L.invt[r] = 1.0 / tn; L.lam[r] += alpha * dl;
+        }
+        __syncthreads();     // rows read v/dv above; v changes below
+        for (int e = tid; e < (N + 1) * NV; e += NT) L.v[e] += alpha * L.dv[e];
+        for (int e = tid; e < N * NX; e += NT) L.pq[NX + e] += alpha * L.dpi[NX + e];
+        __syncthreads();
+    }
+    *iters_out = iters;
+    return status;
+}
+
+// ---- stage linearisation by lane k --------------------------------------------------------------
+__device__ void linearise(const Lds &L, const Dims &d, int tid, const double *params)
+{
+    const int N = d.N;
+    if (tid < N) {
+        const int k = tid;
+        double z[NV];
+#pragma unroll
+        for (int i = 0; i < NV; i++) z[i] = L.z[k * NV + i];
+        const double *p = params + (size_t)k * d.npar;     // Solver_acados_update_params(k, all_parameters[k*NP])
+        double W[NV][NV], g[NV], BA[NX * NV], xn[NX];
+        const int nh = L.nh;
+        auto lamh = [&](int r) {                            // (lam_upper - lam_lower) of the previous QP
+            const double sgn = (r < d.n_lin) ? -1.0 : 1.0;
+            return -sgn * L.lam[k * nh + r];
+        };
+        auto sink = [&](int r, const RowOut &ro) {
+            double *Dr = L.D + (k * nh + r) * 3;
+            Dr[0] = ro.gx; Dr[1] = ro.gy; Dr[2] = ro.gp;
+            const double bound = (r < d.n_lin) ? 0.0 : 1.0;
+            L.beta[k * nh + r] = bound - ro.h;
+        };
+        stage_linearise(d, z, p, 1, L.pi[(k + 1) * NX + 0], L.pi[(k + 1) * NX + 1], lamh, sink, W, g, BA, xn);
+        mirror7(W, d.reg_eps);
+#pragma unroll
+        for (int i = 0; i < NV; i++) {
+            L.g[k * NV + i] = g[i];
+#pragma unroll
+            for (int j = 0; j <= i; j++) L.W[k * NP28 + pidx(i, j)] = W[i][j];
+        }
+#pragma unroll
+        for (int i = 0; i < NX * NV; i++) L.BA[k * NX * NV + i] = BA[i];
+#pragma unroll
+        for (int i = 0; i < NX; i++) L.b[k * NX + i] = xn[i] - L.z[(k + 1) * NV + NU + i];
+    } else if (tid == N) {
+        // terminal node: zero cost, no rows: MIRROR(0) = eps I on the state block
+        for (int e = 0; e < NP28; e++) L.W[N * NP28 + e] = 0.0;
+        for (int i = NU; i < NV; i++) L.W[N * NP28 + pidx(i, i)] = d.reg_eps;
+        for (int i = 0; i < NV; i++) L.g[N * NV + i] = 0.0;
+    }
+}
+
+// ---- the solve kernel ---------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void tmpc_solve_kernel(Dims d, int B, const double *__restrict__ xinit,
+                                                        const double *__restrict__ x0, const double *__restrict__ params,
+                                                        double *__restrict__ xtraj, double *__restrict__ utraj,
+                                                        double *__restrict__ pobj, int *__restrict__ exit_code,
+                                                        int *__restrict__ qp_status_out, int *__restrict__ sqp_iter_out,
+                                                        double *__restrict__ res_eq_out, int *__restrict__ qp_iter_out)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (b >= B) return;
+    const Lds L = carve(smem, d);
+    const int N = d.N;
+    const double *xi = xinit + (size_t)b * NX;
+    const double *pb = params + (size_t)b * N * d.npar;
+
+    // loadWarmstart (acados_solver_interface.cpp:274-284); fresh multipliers
+    for (int e = tid; e < (N + 1) * NV; e += NT) L.z[e] = x0[(size_t)b * (N + 1) * NV + e];
+    for (int e = tid; e < (N + 1) * NX; e += NT) L.pi[e] = 0.0;
+    for (int r = tid; r < L.nrows; r += NT) L.lam[r] = 0.0;
+    __syncthreads();
+    if (tid < NU) L.z[N * NV + tid] = 0.0;
+    __syncthreads();
+
+    int status = 0, qp_status = 0, sqp_iter = 0, qp_iter_total = 0;
+    for (int it = 0; it < d.n_sqp; it++) {
+        linearise(L, d, tid, pb);
+        // QP primal start: dz = 0 except dx_0 = xinit - x_0; duals 0
+        for (int e = tid; e < (N + 1) * NV; e += NT) L.v[e] = 0.0;
+        for (int e = tid; e < (N + 1) * NX; e += NT) L.pq[e] = 0.0;
+        __syncthreads();
+        if (tid < NX) L.v[NU + tid] = xi[tid] - L.z[NU + tid];
+        __syncthreads();
+        int iters = 0;
+        qp_status = ipm_solve(L, d, tid, &iters);
+        sqp_iter = it + 1; qp_iter_total += iters;
+        if (qp_status != 0 && qp_status != 2) { status = 4; break; }      // ACADOS_QP_FAILURE, no step
+        status = 0;
+        __syncthreads();
+        for (int e = tid; e < (N + 1) * NV; e += NT) {
+            const int k = e / NV, i = e - k * NV;
+            if (!(k == N && i < NU)) L.z[e] += L.v[e];
+        }
+        for (int e = tid; e < N * NX; e += NT) L.pi[NX + e] = L.pq[NX + e];
+        __syncthreads();
+        if (qp_status != 0) break;
+    }
+
+    // completeOneIteration (acados_solver_interface.cpp:162-204)
+    double cost = 0.0, res = 0.0;
+    if (tid < N) {
+        double z[NV];
+#pragma unroll
+        for (int i = 0; i < NV; i++) z[i] = L.z[tid * NV + i];
+        CostOut co;
+        cost_eval(d, z, pb + (size_t)tid * d.npar, 1, co, false);
+        cost = d.dt * co.val;
+        DynOut dy;
+        dyn_eval(d, z, dy, false);
+#pragma unroll
+        for (int i = 0; i < NX; i++) res = fmax(res, fabs(dy.xn[i] - L.z[(tid + 1) * NV + NU + i]));
+    }
+    if (tid < NX) res = fmax(res, fabs(L.z[NU + tid] - xi[tid]));
+    cost = wave_sum(cost); res = wave_max(res);
+    for (int e = tid; e < (N + 1) * NX; e += NT) {
+        const int k = e / NX, i = e - k * NX;
+        xtraj[(size_t)b * (N + 1) * NX + e] = L.z[k * NV + NU + i];
+    }
+    for (int e = tid; e < N * NU; e += NT) {
+        const int k = e / NU, i = e - k * NU;
+        utraj[(size_t)b * N * NU + e] = L.z[k * NV + i];
+    }
+    if (tid == 0) {
+        if (res > 1e-2 && status == 0) status = 4;
+        if (!isfinite(cost)) status = 4;
+        pobj[b] = cost; res_eq_out[b] = res;
+        exit_code[b] = status == 0 ? 1 : (status == 1 ? 0 : status);      // Forces-style mapping (:197-201)
+        qp_status_out[b] = qp_status; sqp_iter_out[b] = sqp_iter; qp_iter_out[b] = qp_iter_total;
+    }
+}
+
+// ---- FindBestPlanner on device (guidance_constraints.cpp:416-434) ---------------------------------
+__global__ void tmpc_select_best_kernel(int first, int count, const double *pobj, const int *exit_code,
+                                        const double *weight, const uint8_t *disabled, int *best_out)
+{
+    __shared__ double s_val[256];
+    __shared__ int s_idx[256];
+    double best = 1e10; int idx = -1;
+    for (int i = threadIdx.x; i < count; i += blockDim.x) {
+        const int g = first + i;
+        if (disabled && disabled[i]) continue;
+        if (exit_code[g] != 1) continue;
+        const double o = weight ? pobj[g] * weight[i] : pobj[g];
+        if (o < best) { best = o; idx = i; }       // ascending i per thread: strict '<' keeps the lowest index
+    }
+    s_val[threadIdx.x] = best; s_idx[threadIdx.x] = idx;
+    __syncthreads();
+    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            const double ov = s_val[threadIdx.x + s]; const int oi = s_idx[threadIdx.x + s];
+            const double mv = s_val[threadIdx.x]; const int mi = s_idx[threadIdx.x];
+            const bool take = (oi >= 0) && (mi < 0 || ov < mv || (ov == mv && oi < mi));
+            if (take) { s_val[threadIdx.x] = ov; s_idx[threadIdx.x] = oi; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *best_out = s_idx[0];
+}
+
+// ---- multi-GPU records ------------------------------------------------------------
+__global__ void tmpc_pack_records_kernel(int B, const double *pobj, const int *exit_code, const int *gid,
+                                         const double *weight, tmpc_record *out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B) return;
+    tmpc_record r;
+    r.objective = weight ? pobj[i] * weight[i] : pobj[i];
+    r.exit_code = exit_code[i];
+    r.guidance_id = gid ? gid[i] : i;
+    out[i] = r;
+}
+
+// one workgroup (64 lanes) per scene; records [n_ranks][n_scenes][per_rank]
+__global__ void tmpc_select_best_records_kernel(const tmpc_record *rec, int n_ranks, int n_scenes, int per_rank, int *best_out)
+{
+    const int s = blockIdx.x;
+    double best = 1e10; int idx = -1;
+    const int total = n_ranks * per_rank;
+    for (int g = threadIdx.x; g < total; g += 64) {           // ascending global index per lane
+        const int rk = g / per_rank, t = g - rk * per_rank;
+        const tmpc_record r = rec[((size_t)rk * n_scenes + s) * per_rank + t];
+        if (r.exit_code == 1 && r.objective < best) { best = r.objective; idx = g; }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const double ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(idx, o, 64);
+        const bool take = (oi >= 0) && (idx < 0 || ov < best || (ov == best && oi < idx));
+        if (take) { best = ov; idx = oi; }
+    }
+    if (threadIdx.x == 0) best_out[s] = idx;
+}
+
+// ---- debug: stage functions on device -----------------------------------------------------------
+__global__ void tmpc_debug_eval_kernel(Dims d, int n, const double *z, const double *p, const double *pi, const double *lamh,
+                                       double *cost, double *cgrad, double *chess, double *hval, double *hjac,
+                                       double *xnext, double *xjac, double *lag, double *mir)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const int nh = d.n_lin + d.M;
+    const double *ze = z + (size_t)e * NV; const double *pe = p + (size_t)e * d.npar;
+    double zz[NV];
+    for (int i = 0; i < NV; i++) zz[i] = ze[i];
+    CostOut co;
+    cost_eval(d, zz, pe, 1, co, true);
+    cost[e] = co.val;
+    double Wc[NV][NV];
+    for (int i = 0; i < NV; i++) for (int j = 0; j < NV; j++) Wc[i][j] = 0.0;
+    cost_add_hessian(co, 1.0, Wc);
+    for (int i = 0; i < NV; i++) {
+        cgrad[(size_t)e * NV + i] = co.g[i];
+        for (int j = 0; j < NV; j++) chess[(size_t)e * NV * NV + i * NV + j] = Wc[i][j];
+    }
+    double W[NV][NV], g[NV], BA[NX * NV], xn[NX];
+    auto lam = [&](int r) { return lamh ? lamh[(size_t)e * nh + r] : 0.0; };
+    auto sink = [&](int r, const RowOut &ro) {
+        hval[(size_t)e * nh + r] = ro.h;
+        double *J = hjac + ((size_t)e * nh + r) * NV;
+        for (int i = 0; i < NV; i++) J[i] = 0.0;
+        J[ZX] = ro.gx; J[ZY] = ro.gy; J[ZPSI] = ro.gp;
+    };
+    stage_linearise(d, zz, pe, 1, pi ? pi[(size_t)e * NX] : 0.0, pi ? pi[(size_t)e * NX + 1] : 0.0, lam, sink, W, g, BA, xn);
+    for (int i = 0; i < NX; i++) xnext[(size_t)e * NX + i] = xn[i];
+    for (int i = 0; i < NX * NV; i++) xjac[(size_t)e * NX * NV + i] = BA[i];
+    for (int i = 0; i < NV; i++) for (int j = 0; j < NV; j++) lag[(size_t)e * NV * NV + i * NV + j] = W[i][j];
+    mirror7(W, d.reg_eps);
+    for (int i = 0; i < NV; i++) for (int j = 0; j < NV; j++) mir[(size_t)e * NV * NV + i * NV + j] = W[i][j];
+}
+
+}  // namespace tmpc
+
+// =================================================================================================
+// C-ABI
+// =================================================================================================
+struct tmpc_handle {
+    tmpc::Dims d;
+    int B_max = 0, B = 0, device = 0;
+    hipStream_t stream = nullptr;
+    // inputs: owned staging buffers (tmpc_set_batch) or borrowed device pointers (tmpc_set_batch_device)
+    double *o_xinit = nullptr, *o_x0 = nullptr, *o_params = nullptr;
+    const double *xinit = nullptr, *x0 = nullptr, *params = nullptr;
+    double *xtraj = nullptr, *utraj = nullptr, *pobj = nullptr, *res_eq = nullptr, *d_weight = nullptr;
+    int *exit_code = nullptr, *qp_status = nullptr, *sqp_iter = nullptr, *qp_iter = nullptr, *d_best = nullptr;
+    uint8_t *d_disabled = nullptr;
+    size_t lds_bytes = 0;
+    std::vector<hipEvent_t> ev;      // per-launch timing events (pairs)
+    int ev_used = 0;
+    bool timing = false;
+    std::string err;
+};
+
+#define TMPC_HIP_CHECK(h, expr)                                                                     \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess) {                                                                     \
+            (h)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                           \
+            return TMPC_ERR_HIP;                                                                    \
+        }                                                                                           \
+    } while (0)
+
+extern "C" {
+
+void tmpc_default_dims(tmpc_dims *d, int32_t N, int32_t S, int32_t n_lin, int32_t M)
+{
+    memset(d, 0, sizeof *d);
+    d->N = N; d->S = S; d->n_lin = n_lin; d->M = M;
+    d->npar = 8 + 9 * S + 3 * n_lin + 2 + 7 * M;
+    d->n_sqp = 10; d->qp_iter_max = 50; d->erk_steps = 3;
+    d->dt = 0.2; d->qp_tol = 1e-5; d->reg_eps = 1e-4; d->ipm_mu0 = 10.0; d->ipm_thr0 = 0.1;
+    const double lb[TMPC_NV] = {-2.0, -0.8, -2000.0, -2000.0, -M_PI * 4, -0.01, -1.0};
+    const double ub[TMPC_NV] = {2.0, 0.8, 2000.0, 2000.0, M_PI * 4, 3.0, 10000.0};
+    for (int i = 0; i < TMPC_NV; i++) { d->lb[i] = lb[i]; d->ub[i] = ub[i]; }
+}
+
+static thread_local std::string g_create_err;
+
+int tmpc_create(tmpc_handle **out, const tmpc_dims *dims, int32_t B_max, int32_t device)
+{
+    if (!out || !dims || B_max <= 0) return TMPC_ERR_INVALID;
+    *out = nullptr;
+    if (dims->N < 2 || dims->N > 62 || dims->S < 1 || dims->M < 0 || dims->n_lin < 0 ||
+        dims->npar != 8 + 9 * dims->S + 3 * dims->n_lin + 2 + 7 * dims->M || dims->erk_steps < 1)
+        return TMPC_ERR_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return TMPC_ERR_NO_DEVICE;
+    tmpc_handle *h = new tmpc_handle();
+    h->device = device; h->B_max = B_max;
+    tmpc::Dims &d = h->d;
+    d.N = dims->N; d.S = dims->S; d.n_lin = dims->n_lin; d.M = dims->M; d.npar = dims->npar;
+    d.n_sqp = dims->n_sqp; d.qp_iter_max = dims->qp_iter_max; d.erk_steps = dims->erk_steps;
+    d.dt = dims->dt; d.qp_tol = dims->qp_tol; d.reg_eps = dims->reg_eps; d.mu0 = dims->ipm_mu0; d.thr0 = dims->ipm_thr0;
+    for (int i = 0; i < TMPC_NV; i++) { d.lb[i] = dims->lb[i]; d.ub[i] = dims->ub[i]; }
+    h->lds_bytes = sizeof(double) * (size_t)tmpc::lds_doubles(d.N, d.n_lin + d.M);
+    auto fail = [&](int code) { delete h; return code; };
+    if (hipSetDevice(device) != hipSuccess) return fail(TMPC_ERR_HIP);
+    if (h->lds_bytes > 160 * 1024) return fail(TMPC_ERR_INVALID);
+    if (hipFuncSetAttribute((const void *)tmpc::tmpc_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)h->lds_bytes) != hipSuccess)
+        return fail(TMPC_ERR_NO_DEVICE);
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return fail(TMPC_ERR_HIP);
+    const size_t N = d.N, B = B_max;
+    bool ok = true;
+    ok &= hipMalloc(&h->o_xinit, B * tmpc::NX * 8) == hipSuccess;
+    ok &= hipMalloc(&h->o_x0, B * (N + 1) * tmpc::NV * 8) == hipSuccess;
+    ok &= hipMalloc(&h->o_params, B * N * d.npar * 8) == hipSuccess;
+    ok &= hipMalloc(&h->xtraj, B * (N + 1) * tmpc::NX * 8) == hipSuccess;
+    ok &= hipMalloc(&h->utraj, B * N * tmpc::NU * 8) == hipSuccess;
+    ok &= hipMalloc(&h->pobj, B * 8) == hipSuccess;
+    ok &= hipMalloc(&h->res_eq, B * 8) == hipSuccess;
+    ok &= hipMalloc(&h->d_weight, B * 8) == hipSuccess;
+    ok &= hipMalloc(&h->exit_code, B * 4) == hipSuccess;
+    ok &= hipMalloc(&h->qp_status, B * 4) == hipSuccess;
+    ok &= hipMalloc(&h->sqp_iter, B * 4) == hipSuccess;
+    ok &= hipMalloc(&h->qp_iter, B * 4) == hipSuccess;
+    ok &= hipMalloc(&h->d_best, 4) == hipSuccess;
+    ok &= hipMalloc(&h->d_disabled, B) == hipSuccess;
+    if (!ok) { tmpc_destroy(h); return TMPC_ERR_HIP; }
+    *out = h;
+    return TMPC_OK;
+}
+
+void tmpc_destroy(tmpc_handle *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    void *ptrs[] = {h->o_xinit, h->o_x0, h->o_params, h->xtraj, h->utraj, h->pobj, h->res_eq, h->d_weight,
+                    h->exit_code, h->qp_status, h->sqp_iter, h->qp_iter, h->d_best, h->d_disabled};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (auto &e : h->ev) (void)hipEventDestroy(e);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+const char *tmpc_last_error(const tmpc_handle *h) { return h ? h->err.c_str() : "null handle"; }
+
+int tmpc_set_batch(tmpc_handle *h, int32_t B, const double *xinit, const double *x0, const double *params)
+{
+    if (!h || B <= 0 || B > h->B_max || !xinit || !x0 || !params) { if (h) h->err = "tmpc_set_batch: bad argument"; return TMPC_ERR_INVALID; }
+    TMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    const size_t N = h->d.N;
+    TMPC_HIP_CHECK(h, hipMemcpyAsync(h->o_xinit, xinit, (size_t)B * tmpc::NX * 8, hipMemcpyHostToDevice, h->stream));
+    TMPC_HIP_CHECK(h, hipMemcpyAsync(h->o_x0, x0, (size_t)B * (N + 1) * tmpc::NV * 8, hipMemcpyHostToDevice, h->stream));
+    TMPC_HIP_CHECK(h, hipMemcpyAsync(h->o_params, params, (size_t)B * N * h->d.npar * 8, hipMemcpyHostToDevice, h->stream));
+    h->xinit = h->o_xinit; h->x0 = h->o_x0; h->params = h->o_params; h->B = B;
+    return TMPC_OK;
+}
+
+int tmpc_set_batch_device(tmpc_handle *h, int32_t B, const void *d_xinit, const void *d_x0, const void *d_params)
+{
+    if (!h || B <= 0 || B > h->B_max || !d_xinit || !d_x0 || !d_params) { if (h) h->err = "tmpc_set_batch_device: bad argument"; return TMPC_ERR_INVALID; }
+    h->xinit = (const double *)d_xinit; h->x0 = (const double *)d_x0; h->params = (const double *)d_params; h->B = B;
+    return TMPC_OK;
+}
+
+int tmpc_solve(tmpc_handle *h)
+{
+    if (!h || h->B <= 0 || !h->xinit) { if (h) h->err = "tmpc_solve: no batch set"; return TMPC_ERR_INVALID; }
+    TMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    const bool rec = h->timing && h->ev_used + 2 <= (int)h->ev.size();
+    if (rec) TMPC_HIP_CHECK(h, hipEventRecord(h->ev[h->ev_used], h->stream));
+    hipLaunchKernelGGL(tmpc::tmpc_solve_kernel, dim3(h->B), dim3(tmpc::NT), h->lds_bytes, h->stream, h->d, h->B,
+                       h->xinit, h->x0, h->params, h->xtraj, h->utraj, h->pobj, h->exit_code, h->qp_status,
+                       h->sqp_iter, h->res_eq, h->qp_iter);
+    TMPC_HIP_CHECK(h, hipGetLastError());
+    if (rec) { TMPC_HIP_CHECK(h, hipEventRecord(h->ev[h->ev_used + 1], h->stream)); h->ev_used += 2; }
+    return TMPC_OK;
+}
+
+int tmpc_synchronize(tmpc_handle *h)
+{
+    if (!h) return TMPC_ERR_INVALID;
+    TMPC_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    return TMPC_OK;
+}
+
+int tmpc_get(tmpc_handle *h, double *xtraj, double *utraj, double *pobj, int32_t *exit_code, int32_t *qp_status,
+             int32_t *sqp_iter, double *res_eq, int32_t *qp_iter_total)
+{
+    if (!h || h->B <= 0) return TMPC_ERR_INVALID;
+    TMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    const size_t N = h->d.N, B = h->B;
+    auto cp = [&](void *dst, const void *src, size_t n) { return dst ? hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, h->stream) : hipSuccess; };
+    TMPC_HIP_CHECK(h, cp(xtraj, h->xtraj, B * (N + 1) * tmpc::NX * 8));
+    TMPC_HIP_CHECK(h, cp(utraj, h->utraj, B * N * tmpc::NU * 8));
+    TMPC_HIP_CHECK(h, cp(pobj, h->pobj, B * 8));
+    TMPC_HIP_CHECK(h, cp(res_eq, h->res_eq, B * 8));
+    TMPC_HIP_CHECK(h, cp(exit_code, h->exit_code, B * 4));
+    TMPC_HIP_CHECK(h, cp(qp_status, h->qp_status, B * 4));
+    TMPC_HIP_CHECK(h, cp(sqp_iter, h->sqp_iter, B * 4));
+    TMPC_HIP_CHECK(h, cp(qp_iter_total, h->qp_iter, B * 4));
+    TMPC_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    return TMPC_OK;
+}
+
+int tmpc_select_best(tmpc_handle *h, int32_t first, int32_t count, const double *weight, const uint8_t *disabled, int32_t *best)
+{
+    if (!h || !best || first < 0 || count <= 0 || first + count > h->B) { if (h) h->err = "tmpc_select_best: bad range"; return TMPC_ERR_INVALID; }
+    TMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    if (weight) TMPC_HIP_CHECK(h, hipMemcpyAsync(h->d_weight, weight, (size_t)count * 8, hipMemcpyHostToDevice, h->stream));
+    if (disabled) TMPC_HIP_CHECK(h, hipMemcpyAsync(h->d_disabled, disabled, (size_t)count, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(tmpc::tmpc_select_best_kernel, dim3(1), dim3(256), 0, h->stream, first, count, h->pobj, h->exit_code,
+                       weight ? h->d_weight : nullptr, disabled ? h->d_disabled : nullptr, h->d_best);
+    TMPC_HIP_CHECK(h, hipGetLastError());
+    TMPC_HIP_CHECK(h, hipMemcpyAsync(best, h->d_best, 4, hipMemcpyDeviceToHost, h->stream));
+    TMPC_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    return TMPC_OK;
+}
+
+int tmpc_result_device_ptrs(tmpc_handle *h, void **d_pobj, void **d_exit_code)
+{
+    if (!h) return TMPC_ERR_INVALID;
+    if (d_pobj) *d_pobj = h->pobj;
+    if (d_exit_code) *d_exit_code = h->exit_code;
+    return TMPC_OK;
+}
+
+int tmpc_pack_records(tmpc_handle *h, void *d_records, const void *d_guidance_id, const void *d_weight)
+{
+    if (!h || h->B <= 0 || !d_records) return TMPC_ERR_INVALID;
+    TMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    hipLaunchKernelGGL(tmpc::tmpc_pack_records_kernel, dim3((h->B + 255) / 256), dim3(256), 0, h->stream, h->B, h->pobj,
+                       h->exit_code, (const int *)d_guidance_id, (const double *)d_weight, (tmpc_record *)d_records);
+    TMPC_HIP_CHECK(h, hipGetLastError());
+    return TMPC_OK;
+}
+
+int tmpc_select_best_records(tmpc_handle *h, const void *d_records, int32_t n_ranks, int32_t n_scenes, int32_t per_rank, void *d_best)
+{
+    if (!h || !d_records || !d_best || n_ranks <= 0 || n_scenes <= 0 || per_rank <= 0) return TMPC_ERR_INVALID;
+    TMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    hipLaunchKernelGGL(tmpc::tmpc_select_best_records_kernel, dim3(n_scenes), dim3(64), 0, h->stream,
+                       (const tmpc_record *)d_records, n_ranks, n_scenes, per_rank, (int *)d_best);
+    TMPC_HIP_CHECK(h, hipGetLastError());
+    return TMPC_OK;
+}
+
+int tmpc_enable_timing(tmpc_handle *h, int32_t max_records)
+{
+    if (!h || max_records < 0) return TMPC_ERR_INVALID;
+    TMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    for (auto &e : h->ev) (void)hipEventDestroy(e);
+    h->ev.clear(); h->ev_used = 0; h->timing = max_records > 0;
+    h->ev.resize(2 * (size_t)max_records);
+    for (auto &e : h->ev) TMPC_HIP_CHECK(h, hipEventCreate(&e));
+    return TMPC_OK;
+}
+
+int tmpc_get_timings(tmpc_handle *h, float *ms, int32_t capacity, int32_t *n_out)
+{
+    if (!h || !ms || !n_out) return TMPC_ERR_INVALID;
+    TMPC_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    int n = h->ev_used / 2; if (n > capacity) n = capacity;
+    for (int i = 0; i < n; i++) TMPC_HIP_CHECK(h, hipEventElapsedTime(&ms[i], h->ev[2 * i], h->ev[2 * i + 1]));
+    *n_out = n; h->ev_used = 0;
+    return TMPC_OK;
+}
+
+int tmpc_time_solve(tmpc_handle *h, int32_t reps, float *ms_each)
+{
+    if (!h || reps <= 0 || !ms_each) return TMPC_ERR_INVALID;
+    TMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    std::vector<hipEvent_t> ev(2 * (size_t)reps);
+    for (auto &e : ev) TMPC_HIP_CHECK(h, hipEventCreate(&e));
+    for (int i = 0; i < reps; i++) {
+        TMPC_HIP_CHECK(h, hipEventRecord(ev[2 * i], h->stream));
+        int rc = tmpc_solve(h);
+        if (rc != TMPC_OK) return rc;
+        TMPC_HIP_CHECK(h, hipEventRecord(ev[2 * i + 1], h->stream));
+    }
+    TMPC_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    for (int i = 0; i < reps; i++) TMPC_HIP_CHECK(h, hipEventElapsedTime(&ms_each[i], ev[2 * i], ev[2 * i + 1]));
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    return TMPC_OK;
+}
+
+int tmpc_debug_eval_stage(tmpc_handle *h, int32_t n, const double *z, const double *p, const double *pi, const double *lamh,
+                          double *cost, double *cost_grad, double *cost_hess, double *hval, double *h_jac,
+                          double *x_next, double *x_jac, double *lag_hess, double *mirror)
+{
+    if (!h || n <= 0 || !z || !p) return TMPC_ERR_INVALID;
+    TMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    const int nh = h->d.n_lin + h->d.M;
+    const size_t sz_in[4] = {(size_t)n * 7 * 8, (size_t)n * h->d.npar * 8, (size_t)n * 5 * 8, (size_t)n * nh * 8};
+    const void *src[4] = {z, p, pi, lamh};
+    double *din[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (int i = 0; i < 4; i++) {
+        if (!src[i]) continue;
+        TMPC_HIP_CHECK(h, hipMalloc(&din[i], sz_in[i]));
+        TMPC_HIP_CHECK(h, hipMemcpy(din[i], src[i], sz_in[i], hipMemcpyHostToDevice));
+    }
+    const size_t sz_out[9] = {(size_t)n * 8, (size_t)n * 7 * 8, (size_t)n * 49 * 8, (size_t)n * nh * 8, (size_t)n * nh * 7 * 8,
+                              (size_t)n * 5 * 8, (size_t)n * 35 * 8, (size_t)n * 49 * 8, (size_t)n * 49 * 8};
+    double *dout[9]; void *dst[9] = {cost, cost_grad, cost_hess, hval, h_jac, x_next, x_jac, lag_hess, mirror};
+    for (int i = 0; i < 9; i++) TMPC_HIP_CHECK(h, hipMalloc(&dout[i], sz_out[i] ? sz_out[i] : 8));
+    hipLaunchKernelGGL(tmpc::tmpc_debug_eval_kernel, dim3((n + 63) / 64), dim3(64), 0, h->stream, h->d, n, din[0], din[1], din[2], din[3],
+                       dout[0], dout[1], dout[2], dout[3], dout[4], dout[5], dout[6], dout[7], dout[8]);
+    TMPC_HIP_CHECK(h, hipGetLastError());
+    TMPC_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    for (int i = 0; i < 9; i++) {
+        if (dst[i]) TMPC_HIP_CHECK(h, hipMemcpy(dst[i], dout[i], sz_out[i], hipMemcpyDeviceToHost));
+        (void)hipFree(dout[i]);
+    }
+    for (int i = 0; i < 4; i++) if (din[i]) (void)hipFree(din[i]);
+    return TMPC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,215 @@
+"""ctypes binding of the C-ABI (include/tmpc_hip.h, libtmpc_hip.so) + the batched host-side solver object.
+
+`BatchedSolver` is the batch-first counterpart of the reference's `MPCPlanner::Solver`
+(mpc_planner_solver/include/mpc_planner_solver/acados_solver_interface.h:93-222): B solver instances'
+`_params` (xinit / x0 / all_parameters) in, `_output` (xtraj / utraj) and `_info` out, with the reference's
+exit-code convention.  There is NO CPU fallback: if the HIP library or a GPU is missing, construction raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+NU, NX, NV = 2, 5, 7
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtmpc_hip.so")
+
+
+class TmpcDims(C.Structure):
+    _fields_ = [("N", C.c_int32), ("S", C.c_int32), ("n_lin", C.c_int32), ("M", C.c_int32), ("npar", C.c_int32),
+                ("n_sqp", C.c_int32), ("qp_iter_max", C.c_int32), ("erk_steps", C.c_int32),
+                ("dt", C.c_double), ("qp_tol", C.c_double), ("reg_eps", C.c_double), ("ipm_mu0", C.c_double),
+                ("ipm_thr0", C.c_double), ("lb", C.c_double * NV), ("ub", C.c_double * NV)]
+
+
+EXPORTS = ["tmpc_default_dims", "tmpc_create", "tmpc_destroy", "tmpc_last_error", "tmpc_set_batch",
+           "tmpc_set_batch_device", "tmpc_solve", "tmpc_synchronize", "tmpc_get", "tmpc_select_best",
+           "tmpc_result_device_ptrs", "tmpc_time_solve", "tmpc_debug_eval_stage", "tmpc_pack_records",
+           "tmpc_select_best_records", "tmpc_enable_timing", "tmpc_get_timings"]
+
+_lib = None
+
+
+class TmpcError(RuntimeError):
+    pass
+
+
+def load_library():
+    """Load libtmpc_hip.so; raises (never falls back) if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise TmpcError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        lib.tmpc_last_error.restype = C.c_char_p
+        lib.tmpc_last_error.argtypes = [C.c_void_p]
+        lib.tmpc_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(TmpcDims), C.c_int32, C.c_int32]
+        lib.tmpc_destroy.argtypes = [C.c_void_p]
+        lib.tmpc_default_dims.argtypes = [C.POINTER(TmpcDims), C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+        vp = C.c_void_p
+        lib.tmpc_set_batch.argtypes = [vp, C.c_int32, vp, vp, vp]
+        lib.tmpc_set_batch_device.argtypes = [vp, C.c_int32, vp, vp, vp]
+        lib.tmpc_solve.argtypes = [vp]
+        lib.tmpc_synchronize.argtypes = [vp]
+        lib.tmpc_get.argtypes = [vp] + [vp] * 8
+        lib.tmpc_select_best.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, C.POINTER(C.c_int32)]
+        lib.tmpc_result_device_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
+        lib.tmpc_time_solve.argtypes = [vp, C.c_int32, vp]
+        lib.tmpc_debug_eval_stage.argtypes = [vp, C.c_int32] + [vp] * 13
+        lib.tmpc_pack_records.argtypes = [vp, vp, vp, vp]
+        lib.tmpc_select_best_records.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int32, vp]
+        lib.tmpc_enable_timing.argtypes = [vp, C.c_int32]
+        lib.tmpc_get_timings.argtypes = [vp, vp, C.c_int32, C.POINTER(C.c_int32)]
+        _lib = lib
+    return _lib
+
+
+def default_dims(N=20, S=5, n_lin=8, M=8, **opts):
+    d = TmpcDims()
+    load_library().tmpc_default_dims(C.byref(d), N, S, n_lin, M)
+    for k, v in opts.items():
+        setattr(d, k, v)
+    return d
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class BatchedSolver:
+    """B reference `Solver` instances behind one HIP launch."""
+
+    def __init__(self, dims, B_max, device=0):
+        self.lib = load_library()
+        self.dims = dims
+        self.B_max = int(B_max)
+        self.B = 0
+        self._h = C.c_void_p()
+        rc = self.lib.tmpc_create(C.byref(self._h), C.byref(dims), self.B_max, int(device))
+        if rc != 0:
+            raise TmpcError(f"tmpc_create failed with code {rc} (-1 invalid dims, -2 HIP error, -3 no gfx950 device)")
+        self.N, self.npar = dims.N, dims.npar
+
+    def close(self):
+        if self._h:
+            self.lib.tmpc_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise TmpcError(f"{what} failed ({rc}): {self.lib.tmpc_last_error(self._h).decode()}")
+
+    # --- inputs -----------------------------------------------------------------------------------
+    def set_batch(self, xinit, x0, params):
+        """Host arrays: xinit [B][5], x0 [B][N+1][7], params [B][N][npar] (reference layouts)."""
+        xinit = np.ascontiguousarray(xinit, np.float64); x0 = np.ascontiguousarray(x0, np.float64)
+        params = np.ascontiguousarray(params, np.float64)
+        B = xinit.shape[0]
+        assert xinit.shape == (B, NX) and x0.size == B * (self.N + 1) * NV and params.size == B * self.N * self.npar
+        self._keep = (xinit, x0, params)
+        self._check(self.lib.tmpc_set_batch(self._h, B, _p(xinit), _p(x0), _p(params)), "tmpc_set_batch")
+        self.B = B
+
+    def set_batch_device(self, B, d_xinit, d_x0, d_params):
+        """Raw device pointers (ints), inputs already resident in HBM."""
+        self._check(self.lib.tmpc_set_batch_device(self._h, int(B), C.c_void_p(d_xinit), C.c_void_p(d_x0),
+                                                   C.c_void_p(d_params)), "tmpc_set_batch_device")
+        self.B = int(B)
+
+    # --- solve ------------------------------------------------------------------------------------
+    def solve(self, sync=True):
+        self._check(self.lib.tmpc_solve(self._h), "tmpc_solve")
+        if sync:
+            self._check(self.lib.tmpc_synchronize(self._h), "tmpc_synchronize")
+
+    def synchronize(self):
+        self._check(self.lib.tmpc_synchronize(self._h), "tmpc_synchronize")
+
+    def time_solve(self, reps):
+        ms = np.zeros(reps, np.float32)
+        self._check(self.lib.tmpc_time_solve(self._h, int(reps), _p(ms)), "tmpc_time_solve")
+        return ms
+
+    # --- outputs ----------------------------------------------------------------------------------
+    def get(self):
+        B, N = self.B, self.N
+        out = dict(xtraj=np.zeros((B, N + 1, NX)), utraj=np.zeros((B, N, NU)), pobj=np.zeros(B),
+                   exit_code=np.zeros(B, np.int32), qp_status=np.zeros(B, np.int32), sqp_iter=np.zeros(B, np.int32),
+                   res_eq=np.zeros(B), qp_iter_total=np.zeros(B, np.int32))
+        self._check(self.lib.tmpc_get(self._h, _p(out["xtraj"]), _p(out["utraj"]), _p(out["pobj"]), _p(out["exit_code"]),
+                                      _p(out["qp_status"]), _p(out["sqp_iter"]), _p(out["res_eq"]),
+                                      _p(out["qp_iter_total"])), "tmpc_get")
+        return out
+
+    def select_best(self, first=0, count=None, weight=None, disabled=None):
+        count = self.B - first if count is None else count
+        w = None if weight is None else np.ascontiguousarray(weight, np.float64)
+        dis = None if disabled is None else np.ascontiguousarray(disabled, np.uint8)
+        best = C.c_int32(-2)
+        self._check(self.lib.tmpc_select_best(self._h, int(first), int(count), _p(w), _p(dis), C.byref(best)),
+                    "tmpc_select_best")
+        return best.value
+
+    def enable_timing(self, max_records):
+        self._check(self.lib.tmpc_enable_timing(self._h, int(max_records)), "tmpc_enable_timing")
+
+    def get_timings(self, capacity=4096):
+        ms = np.zeros(capacity, np.float32); n = C.c_int32(0)
+        self._check(self.lib.tmpc_get_timings(self._h, _p(ms), capacity, C.byref(n)), "tmpc_get_timings")
+        return ms[:n.value].copy()
+
+    def pack_records(self, d_records, d_guidance_id=None, d_weight=None):
+        """d_*: raw device pointers (ints). Packs {f64 objective, i32 exit_code, i32 guidance_id} per trajectory."""
+        self._check(self.lib.tmpc_pack_records(self._h, C.c_void_p(d_records),
+                                               C.c_void_p(d_guidance_id) if d_guidance_id else None,
+                                               C.c_void_p(d_weight) if d_weight else None), "tmpc_pack_records")
+
+    def select_best_records(self, d_records, n_ranks, n_scenes, per_rank, d_best):
+        self._check(self.lib.tmpc_select_best_records(self._h, C.c_void_p(d_records), int(n_ranks), int(n_scenes),
+                                                      int(per_rank), C.c_void_p(d_best)), "tmpc_select_best_records")
+
+    def result_device_ptrs(self):
+        a, b = C.c_void_p(), C.c_void_p()
+        self._check(self.lib.tmpc_result_device_ptrs(self._h, C.byref(a), C.byref(b)), "tmpc_result_device_ptrs")
+        return a.value, b.value
+
+    # --- debug ------------------------------------------------------------------------------------
+    def debug_eval_stage(self, z, p, pi=None, lamh=None):
+        z = np.ascontiguousarray(z, np.float64).reshape(-1, NV); n = z.shape[0]
+        p = np.ascontiguousarray(p, np.float64).reshape(n, self.npar)
+        nh = self.dims.n_lin + self.dims.M
+        pi = None if pi is None else np.ascontiguousarray(pi, np.float64).reshape(n, NX)
+        lamh = None if lamh is None else np.ascontiguousarray(lamh, np.float64).reshape(n, nh)
+        o = dict(cost=np.zeros(n), cost_grad=np.zeros((n, NV)), cost_hess=np.zeros((n, NV, NV)), h=np.zeros((n, nh)),
+                 h_jac=np.zeros((n, nh, NV)), x_next=np.zeros((n, NX)), x_jac=np.zeros((n, NX, NV)),
+                 lag_hess=np.zeros((n, NV, NV)), mirror=np.zeros((n, NV, NV)))
+        self._check(self.lib.tmpc_debug_eval_stage(self._h, n, _p(z), _p(p), _p(pi), _p(lamh), _p(o["cost"]),
+                                                   _p(o["cost_grad"]), _p(o["cost_hess"]), _p(o["h"]), _p(o["h_jac"]),
+                                                   _p(o["x_next"]), _p(o["x_jac"]), _p(o["lag_hess"]), _p(o["mirror"])),
+                    "tmpc_debug_eval_stage")
+        return o
+
+
+def optimize_batch(solver, scene_batch, tmpc_consistency_weight=None):
+    """Batched counterpart of GuidanceConstraints::optimize (guidance_constraints.cpp:264-388) for one launch batch:
+    load every local planner's parameters + warm start, solve all of them in one launch, then pick the best
+    planner per scene (FindBestPlanner :416-434).  Returns (results dict, best index per scene)."""
+    solver.set_batch(scene_batch["xinit"], scene_batch["x0"], scene_batch["params"])
+    solver.solve()
+    res = solver.get()
+    scene_of = scene_batch.get("scene_of")
+    if scene_of is None:
+        return res, np.array([solver.select_best()])
+    n_scenes = int(scene_of.max()) + 1
+    best = np.zeros(n_scenes, np.int32)
+    for s in range(n_scenes):
+        idx = np.nonzero(scene_of == s)[0]
+        best[s] = solver.select_best(first=int(idx[0]), count=len(idx))
+    return res, best

@@ -1,0 +1,62 @@
+"""CPU-side checks of the C-ABI boundary: the shared library loads and exports every symbol that
+include/tmpc_hip.h declares (no compute calls without a GPU), and fails loudly without a device."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "tmpc_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(tmpc_[a-z_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__ as g
+    g.build()
+    from mpc_planner_amd import solver
+    lib = C.CDLL(solver.LIB_PATH)
+    names = _declared_symbols()
+    assert len(names) >= 13
+    for n in names:
+        assert hasattr(lib, n), f"libtmpc_hip.so does not export {n}"
+    assert sorted(solver.EXPORTS) == names
+
+
+def test_default_dims_match_reference_settings():
+    from mpc_planner_amd import solver
+    d = solver.default_dims(N=20, S=5, n_lin=8, M=8)
+    assert d.npar == 135 and d.n_sqp == 10 and d.qp_iter_max == 50 and d.erk_steps == 3
+    assert d.dt == 0.2 and d.qp_tol == 1e-5
+    assert solver.default_dims(N=20, S=5, n_lin=0, M=4).npar == 83
+    assert solver.default_dims(N=20, S=5, n_lin=12, M=12).npar == 175
+
+
+def test_no_silent_cpu_fallback():
+    """Without a GPU the product must raise, never compute on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from mpc_planner_amd import solver
+    with pytest.raises(solver.TmpcError):
+        solver.BatchedSolver(solver.default_dims(), B_max=4)
+
+
+def test_invalid_dims_rejected():
+    from mpc_planner_amd import solver
+    lib = solver.load_library()
+    d = solver.default_dims(); d.npar = 7
+    h = C.c_void_p()
+    assert lib.tmpc_create(C.byref(h), C.byref(d), 4, 0) == -1 and not h
+
+
+def test_product_never_imports_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "mpc_planner_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle_lib" not in txt and "liboracle" not in txt and "tmpc_oracle" not in txt, f
