@@ -134,6 +134,10 @@ int tmpc_time_solve(tmpc_handle *h, int32_t reps, float *ms_each);
  * Outputs (host, may be NULL): cost[n], cost_grad[n][7], cost_hess[n][49], h[n][nh], h_jac[n][nh][7],
  * x_next[n][5], x_jac[n][5][7]; lag_hess[n][49] = dt*hess(l) + sum_j pi[j] hess(x_next_j) +
  * sum_r lamh[r] hess(h_r) (pi[n][5], lamh[n][nh] host inputs, NULL = zeros); mirror[n][49] = MIRROR(lag_hess). */
+/* Mean shader-clock cycles per phase over the batch (one extra instrumented solve).  cycles[10]:
+ * linearise, residuals, barrier Hessian, Riccati factor, rhs build, Riccati solve, row passes, update, final, total. */
+int tmpc_debug_profile(tmpc_handle *h, int64_t *cycles, int32_t n_phases);
+
 int tmpc_debug_eval_stage(tmpc_handle *h, int32_t n, const double *z, const double *p, const double *pi,
                           const double *lamh, double *cost, double *cost_grad, double *cost_hess,
                           double *hval, double *h_jac, double *x_next, double *x_jac, double *lag_hess,

@@ -123,62 +123,125 @@ __device__ __forceinline__ double row_beta(const Lds &L, const Dims &d, const Ro
     return (R.sgn > 0.0 ? d.lb[R.var] : d.ub[R.var]) - L.z[R.k * NV + R.var];
 }
 
+// ---- cross-lane helpers ---------------------------------------------------------------------------
+// Broadcast lane `src` (wave-uniform) of a double through two v_readlane_b32: no LDS, no bpermute.
+__device__ __forceinline__ double readlane_d(double x, int src)
+{
+    union { double d; int i[2]; } u;
+    u.d = x;
+    u.i[0] = __builtin_amdgcn_readlane(u.i[0], src);
+    u.i[1] = __builtin_amdgcn_readlane(u.i[1], src);
+    return u.d;
+}
+// 1/sqrt(d): v_rsq_f64 seed + two Newton steps (full double precision for d > 0)
+__device__ __forceinline__ double rsqrt_nr(double d)
+{
+    double y = __builtin_amdgcn_rsq(d);
+    const double hd = 0.5 * d;
+    y = y * (1.5 - hd * y * y);
+    y = y * (1.5 - hd * y * y);
+    return y;
+}
+
 // ---- square-root Riccati: factorisation --------------------------------------------------------
-// Stage matrices are packed lower 7x7 in L.Hh (in: barrier-augmented Hessian, out: Cholesky factor of
-// F_k = Hh_k + G^T G, G = Lp^T [B A], Lp = trailing 5x5 of the next stage's factor).  Returns true on a
-// non-positive pivot.  Lane e < 28 owns entry (i,j) = (c_pi[e], c_pj[e]).
-__device__ __forceinline__ bool chol_lanes(double &f, int li, int lj, int c0, bool active, double *rinv_out)
+// Lane i (< 7) owns ROW i of the stage matrix F_k = Hh_k + G^T G (G = Lp^T [B A], Lp = trailing 5x5 of the
+// next stage's Cholesky factor) in registers f[0..i].  The 7x7 Cholesky runs entirely in registers: pivots
+// and column entries are broadcast with v_readlane, no LDS traffic and no barriers inside the factorisation.
+// In place of Hh_k the "factor block" (28 doubles) is written for the vector solves:
+//   [0..9]  Lxu (5x2, row-major)   [10] L10   [11] 1/L00   [12] 1/L11   [13..27] P_k = Lxx Lxx^T (packed lower 5x5)
+constexpr int FB_LXU = 0, FB_L10 = 10, FB_R0 = 11, FB_R1 = 12, FB_P = 13;
+
+template <int C0>
+__device__ __forceinline__ bool chol_rows(double (&f)[NV], int lane, double *r0, double *r1)
 {
     bool bad = false;
-    for (int c = c0; c < NV; c++) {
-        const double dpiv = __shfl(f, pidx(c, c), 64);
+#pragma unroll
+    for (int c = C0; c < NV; c++) {
+        const double dpiv = readlane_d(f[c], c);
         if (!(dpiv > 0.0)) bad = true;
-        const double rinv = 1.0 / sqrt(dpiv);
-        if (active && lj == c) f = (li == c) ? dpiv * rinv : f * rinv;
-        if (active && li == c && lj == c && rinv_out) *rinv_out = rinv;
-        const int si = active ? pidx(li, c) : 0, sj = active ? pidx(lj, c) : 0;
-        const double lic = __shfl(f, si, 64), ljc = __shfl(f, sj, 64);
-        if (active && lj > c) f -= lic * ljc;
+        const double y = rsqrt_nr(dpiv);
+        f[c] *= y;                                  // lane i >= c: L_ic (i == c: sqrt(d))
+        if (c == 0 && r0) *r0 = y;
+        if (c == 1 && r1) *r1 = y;
+#pragma unroll
+        for (int j = c + 1; j < NV; j++) {
+            const double ljc = readlane_d(f[c], j);
+            f[j] -= f[c] * ljc;                     // lane i >= j: F_ij -= L_ic L_jc
+        }
     }
+#pragma unroll
+    for (int j = 0; j < NV; j++) if (j > lane) f[j] = 0.0;      // clear the unused upper part
     return bad;
 }
 
 __device__ bool riccati_factor(const Lds &L, const Dims &d, int tid)
 {
     const int N = d.N;
-    const bool own = tid < NP28;
-    const int li = own ? c_pi[tid] : 0, lj = own ? c_pj[tid] : 0;
+    const int lane = tid;
+    const bool rowl = lane < NV;
+    const int i5 = lane - NU;                        // state index of lanes 2..6
     bool bad = false;
+    double f[NV];
     // terminal node: Cholesky of the xx-block (rows/cols 2..6)
-    {
-        double f = own ? L.Hh[N * NP28 + tid] : 1.0;
-        const bool act = own && lj >= NU;
-        bad |= chol_lanes(f, li, lj, NU, act, nullptr);
-        if (act) L.Hh[N * NP28 + tid] = f;
-    }
+#pragma unroll
+    for (int j = 0; j < NV; j++) f[j] = (rowl && j <= lane && j >= NU && lane >= NU) ? L.Hh[N * NP28 + pidx(lane, j)] : 0.0;
+    bad |= chol_rows<NU>(f, lane, nullptr, nullptr);
     __syncthreads();
     for (int k = N - 1; k >= 0; k--) {
-        // G = Lp^T [B A]  (5 x 7) -> scratch
-        if (tid < NX * NV) {
-            const int i = tid / NV, j = tid - i * NV;
-            const double *Ln = L.Hh + (k + 1) * NP28;
+        // broadcast Lp (lower 5x5) of stage k+1 to every lane
+        double Lp[NX][NX];
+#pragma unroll
+        for (int m = 0; m < NX; m++)
+#pragma unroll
+            for (int l = 0; l <= m; l++) Lp[m][l] = readlane_d(f[NU + l], NU + m);
+        // P_{k+1} = Lp Lp^T, row i5 by lane 2+i5 (own row of Lp is f[2..6], zero above the diagonal)
+        if (rowl && lane >= NU) {
+            double *Pn = L.Hh + (k + 1) * NP28 + FB_P;
+#pragma unroll
+            for (int l = 0; l < NX; l++) {
+                double acc = 0.0;
+#pragma unroll
+                for (int m = 0; m <= l; m++) acc += f[NU + m] * Lp[l][m];
+                if (l <= i5) Pn[i5 * (i5 + 1) / 2 + l] = acc;
+            }
+        }
+        // G column `lane`: G_l = sum_{m >= l} Lp[m][l] BA[m][lane]
+        double G[NX];
+        if (rowl) {
             const double *BA = L.BA + k * NX * NV;
-            double acc = 0.0;
-            for (int l = i; l < NX; l++) acc += Ln[pidx(NU + l, NU + i)] * BA[l * NV + j];
-            L.scr[tid] = acc;
+            double ba[NX];
+#pragma unroll
+            for (int m = 0; m < NX; m++) ba[m] = BA[m * NV + lane];
+#pragma unroll
+            for (int l = 0; l < NX; l++) {
+                double acc = 0.0;
+#pragma unroll
+                for (int m = l; m < NX; m++) acc += Lp[m][l] * ba[m];
+                G[l] = acc;
+                L.scr[l * 8 + lane] = acc;
+            }
         }
         __syncthreads();
-        double f = 1.0;
-        if (own) {
-            f = L.Hh[k * NP28 + tid];
+        // F row `lane`
+        if (rowl) {
+            const double *Hk = L.Hh + k * NP28;
 #pragma unroll
-            for (int l = 0; l < NX; l++) f += L.scr[l * NV + li] * L.scr[l * NV + lj];
+            for (int j = 0; j < NV; j++) {
+                double acc = (j <= lane) ? Hk[pidx(lane, j <= lane ? j : 0)] : 0.0;
+#pragma unroll
+                for (int l = 0; l < NX; l++) acc += G[l] * L.scr[l * 8 + j];
+                f[j] = acc;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NV; j++) f[j] = 0.0;
         }
-        double rinv = 0.0;
-        bad |= chol_lanes(f, li, lj, 0, own, &rinv);
-        if (own) {
-            L.Hh[k * NP28 + tid] = f;
-            if (li == lj && li < NU) L.rdiag[k * NU + li] = rinv;
+        double r0 = 0.0, r1 = 0.0;
+        bad |= chol_rows<0>(f, lane, &r0, &r1);
+        if (rowl) {
+            double *Fb = L.Hh + k * NP28;
+            if (lane >= NU) { Fb[FB_LXU + 2 * i5] = f[0]; Fb[FB_LXU + 2 * i5 + 1] = f[1]; }
+            if (lane == 1) { Fb[FB_L10] = f[0]; Fb[FB_R0] = r0; Fb[FB_R1] = r1; }
         }
         __syncthreads();
     }
@@ -186,83 +249,83 @@ __device__ bool riccati_factor(const Lds &L, const Dims &d, int tid)
 }
 
 // ---- square-root Riccati: vector solve (backward + forward), rhs gh / rb -> dv, dpi ------------------
+// Lane j (< 7) = component j of the stage vector [u; x]; the cost-to-go gradient p lives in lanes 2..6.
+// Everything cross-lane goes through v_readlane; LDS only supplies the per-stage operands.
 __device__ void riccati_solve(const Lds &L, const Dims &d, int tid)
 {
     const int N = d.N;
-    if (tid < NX) L.pr[N * NX + tid] = L.gh[N * NV + NU + tid];
-    __syncthreads();
+    const int lane = tid;
+    const bool rowl = lane < NV, xl = rowl && lane >= NU;
+    const int i5 = xl ? lane - NU : 0;
+    double p = xl ? L.gh[N * NV + lane] : 0.0;          // p_N
+    if (xl) L.pr[N * NX + i5] = p;
     for (int k = N - 1; k >= 0; k--) {
-        const double *Ln = L.Hh + (k + 1) * NP28;     // Lp = Ln[2.., 2..]
-        const double *Lk = L.Hh + k * NP28;
-        // tmp = Lp^T rb
-        if (tid < NX) {
-            double acc = 0.0;
-            for (int l = tid; l < NX; l++) acc += Ln[pidx(NU + l, NU + tid)] * L.rb[k * NX + l];
-            L.scr[tid] = acc;
-        }
-        __syncthreads();
-        // Pb = Lp tmp + p_{k+1}
-        if (tid < NX) {
-            double acc = L.pr[(k + 1) * NX + tid];
-            for (int l = 0; l <= tid; l++) acc += Ln[pidx(NU + tid, NU + l)] * L.scr[l];
-            L.scr[8 + tid] = acc;
-        }
-        __syncthreads();
-        // f = gh_k + [B A]^T Pb
-        if (tid < NV) {
-            double acc = L.gh[k * NV + tid];
-            const double *BA = L.BA + k * NX * NV;
+        const double *Pn = L.Hh + (k + 1) * NP28 + FB_P;
+        const double *Fb = L.Hh + k * NP28;
+        const double *BA = L.BA + k * NX * NV;
+        // Pb = P_{k+1} rb_k + p_{k+1}   (lane 2+i)
+        double Pb = p;
+        if (xl) {
 #pragma unroll
-            for (int l = 0; l < NX; l++) acc += BA[l * NV + tid] * L.scr[8 + l];
-            L.scr[16 + tid] = acc;
-        }
-        __syncthreads();
-        // y = Luu^-1 f_u ; p_k = f_x - Lxu y
-        if (tid < NX) {
-            const double y0 = L.scr[16] * L.rdiag[k * NU];
-            const double y1 = (L.scr[17] - Lk[pidx(1, 0)] * y0) * L.rdiag[k * NU + 1];
-            if (tid == 0) { L.y[k * NU] = y0; L.y[k * NU + 1] = y1; }
-            L.pr[k * NX + tid] = L.scr[16 + NU + tid] - Lk[pidx(NU + tid, 0)] * y0 - Lk[pidx(NU + tid, 1)] * y1;
-        }
-        __syncthreads();
-    }
-    // forward sweep; dx_0 = 0
-    if (tid < NX) L.dv[NU + tid] = 0.0;
-    __syncthreads();
-    for (int k = 0; k < N; k++) {
-        const double *Lk = L.Hh + k * NP28;
-        if (tid == 0) {     // du = -Luu^-T (Lxu^T dx + y)
-            double r0 = L.y[k * NU], r1 = L.y[k * NU + 1];
-#pragma unroll
-            for (int j = 0; j < NX; j++) {
-                const double dxj = L.dv[k * NV + NU + j];
-                r0 += Lk[pidx(NU + j, 0)] * dxj; r1 += Lk[pidx(NU + j, 1)] * dxj;
+            for (int l = 0; l < NX; l++) {
+                const int a = i5 >= l ? i5 : l, b = i5 >= l ? l : i5;
+                Pb += Pn[a * (a + 1) / 2 + b] * L.rb[k * NX + l];
             }
-            const double u1 = -r1 * L.rdiag[k * NU + 1];
-            const double u0 = (-r0 - Lk[pidx(1, 0)] * u1) * L.rdiag[k * NU];
-            L.dv[k * NV] = u0; L.dv[k * NV + 1] = u1;
         }
-        __syncthreads();
-        if (tid < NX) {
-            double acc = L.rb[k * NX + tid];
-            const double *BA = L.BA + k * NX * NV;
+        double Pbb[NX];
 #pragma unroll
-            for (int j = 0; j < NV; j++) acc += BA[tid * NV + j] * L.dv[k * NV + j];
-            L.dv[(k + 1) * NV + NU + tid] = acc;
+        for (int l = 0; l < NX; l++) Pbb[l] = readlane_d(Pb, NU + l);
+        // f = gh_k + [B A]^T Pb   (lane j)
+        double fj = 0.0;
+        if (rowl) {
+            fj = L.gh[k * NV + lane];
+#pragma unroll
+            for (int l = 0; l < NX; l++) fj += BA[l * NV + lane] * Pbb[l];
         }
-        __syncthreads();
+        const double f0 = readlane_d(fj, 0), f1 = readlane_d(fj, 1);
+        const double y0 = f0 * Fb[FB_R0];
+        const double y1 = (f1 - Fb[FB_L10] * y0) * Fb[FB_R1];
+        if (lane == 0) { L.y[k * NU] = y0; L.y[k * NU + 1] = y1; }
+        if (xl) {
+            p = fj - Fb[FB_LXU + 2 * i5] * y0 - Fb[FB_LXU + 2 * i5 + 1] * y1;
+            L.pr[k * NX + i5] = p;
+        }
     }
-    if (tid < NU) L.dv[N * NV + tid] = 0.0;
-    // dpi_{k} = P_k dx_k + p_k, k = 1..N  (stage-parallel)
+    __syncthreads();
+    // forward sweep; dx_0 = 0 (dx lives in lanes 2..6)
+    double dx = 0.0;
+    for (int k = 0; k < N; k++) {
+        const double *Fb = L.Hh + k * NP28;
+        const double *BA = L.BA + k * NX * NV;
+        double dxb[NX];
+#pragma unroll
+        for (int j = 0; j < NX; j++) dxb[j] = readlane_d(dx, NU + j);
+        double r0 = L.y[k * NU], r1 = L.y[k * NU + 1];
+#pragma unroll
+        for (int j = 0; j < NX; j++) { r0 += Fb[FB_LXU + 2 * j] * dxb[j]; r1 += Fb[FB_LXU + 2 * j + 1] * dxb[j]; }
+        const double u1 = -r1 * Fb[FB_R1];
+        const double u0 = (-r0 - Fb[FB_L10] * u1) * Fb[FB_R0];
+        if (rowl) L.dv[k * NV + lane] = lane == 0 ? u0 : (lane == 1 ? u1 : dx);
+        double dxn = 0.0;
+        if (xl) {
+            dxn = L.rb[k * NX + i5] + BA[i5 * NV] * u0 + BA[i5 * NV + 1] * u1;
+#pragma unroll
+            for (int j = 0; j < NX; j++) dxn += BA[i5 * NV + NU + j] * dxb[j];
+        }
+        dx = dxn;
+    }
+    if (rowl) L.dv[N * NV + lane] = xl ? dx : 0.0;
+    __syncthreads();
+    // dpi_k = P_k dx_k + p_k, k = 1..N  (stage-parallel)
     for (int it = tid; it < N * NX; it += NT) {
         const int k = 1 + it / NX, i = it - (k - 1) * NX;
-        const double *Lk = L.Hh + k * NP28;
-        const double *dx = L.dv + k * NV + NU;
+        const double *Pk = L.Hh + k * NP28 + FB_P;
+        const double *dxk = L.dv + k * NV + NU;
         double acc = L.pr[k * NX + i];
-        for (int l = 0; l <= i; l++) {
-            double tl = 0.0;                                   // (Lp^T dx)_l
-            for (int m = l; m < NX; m++) tl += Lk[pidx(NU + m, NU + l)] * dx[m];
-            acc += Lk[pidx(NU + i, NU + l)] * tl;
+#pragma unroll
+        for (int l = 0; l < NX; l++) {
+            const int a = i >= l ? i : l, b = i >= l ? l : i;
+            acc += Pk[a * (a + 1) / 2 + b] * dxk[l];
         }
         L.dpi[k * NX + i] = acc;
     }
@@ -314,8 +377,16 @@ __device__ void build_rhs(const Lds &L, const Dims &d, int tid, bool predictor)
     __syncthreads();
 }
 
+// ---- optional in-kernel phase profile (debug entry point tmpc_debug_profile) --------------------------
+enum { PH_LIN = 0, PH_RES, PH_HH, PH_FACTOR, PH_RHS, PH_SOLVE, PH_ROWS, PH_UPDATE, PH_FINAL, PH_TOTAL, PH_COUNT };
+struct Prof {
+    long long *out; long long acc[PH_COUNT]; long long t0;
+    __device__ __forceinline__ void start() { if (out) t0 = clock64(); }
+    __device__ __forceinline__ void stop(int ph) { if (out) { const long long t1 = clock64(); acc[ph] += t1 - t0; t0 = t1; } }
+};
+
 // One QP solve.  Returns status (0 ok, 2 max iter, 3 min step, 4 NaN); *iters = IPM iterations.
-__device__ int ipm_solve(const Lds &L, const Dims &d, int tid, int *iters_out)
+__device__ int ipm_solve(const Lds &L, const Dims &d, int tid, int *iters_out, Prof &pf)
 {
     const int N = d.N;
     const double m_rows = (double)L.nrows;
@@ -330,6 +401,7 @@ __device__ int ipm_solve(const Lds &L, const Dims &d, int tid, int *iters_out)
     int status = 2, iters = 0;
     for (int it = 0;; it++) {
         // ---------------- residuals ----------------
+        pf.start();
         double res_g = 0.0, res_b = 0.0, res_d = 0.0, res_m = 0.0, mu = 0.0;
         for (int e = tid; e < (N + 1) * NV; e += NT) {
             const int k = e / NV, i = e - k * NV;
@@ -382,6 +454,7 @@ __device__ int ipm_solve(const Lds &L, const Dims &d, int tid, int *iters_out)
         res_g = wave_max(res_g); res_b = wave_max(res_b); res_d = wave_max(res_d); res_m = wave_max(res_m);
         mu = wave_sum(mu) / m_rows;
         __syncthreads();
+        pf.stop(PH_RES);
         if (!(isfinite(res_g) && isfinite(res_b) && isfinite(res_d) && isfinite(res_m))) { status = 4; break; }
         if (res_g <= d.qp_tol && res_b <= d.qp_tol && res_d <= d.qp_tol && res_m <= d.qp_tol) { status = 0; break; }
         if (it >= d.qp_iter_max) { status = 2; break; }
@@ -408,11 +481,16 @@ __device__ int ipm_solve(const Lds &L, const Dims &d, int tid, int *iters_out)
             L.Hh[e] = acc;
         }
         __syncthreads();
-        if (riccati_factor(L, d, tid)) { status = 4; break; }
+        pf.stop(PH_HH);
+        const bool fbad = riccati_factor(L, d, tid);
+        pf.stop(PH_FACTOR);
+        if (fbad) { status = 4; break; }
 
         // ---------------- predictor ----------------
         build_rhs(L, d, tid, true);
+        pf.stop(PH_RHS);
         riccati_solve(L, d, tid);
+        pf.stop(PH_SOLVE);
         double amax = 1e300;
         for (int r = tid; r < L.nrows; r += NT) {
             const Row R = row_decode(L, d, r);
@@ -439,8 +517,11 @@ __device__ int ipm_solve(const Lds &L, const Dims &d, int tid, int *iters_out)
         for (int r = tid; r < L.nrows; r += NT)
             L.qt[r] = L.lam[r] + (L.qt[r] - sigma * mu) * L.invt[r];          // q / t
         __syncthreads();
+        pf.stop(PH_ROWS);
         build_rhs(L, d, tid, false);
+        pf.stop(PH_RHS);
         riccati_solve(L, d, tid);
+        pf.stop(PH_SOLVE);
         amax = 1e300;
         for (int r = tid; r < L.nrows; r += NT) {
             const Row R = row_decode(L, d, r);
@@ -451,6 +532,7 @@ __device__ int ipm_solve(const Lds &L, const Dims &d, int tid, int *iters_out)
             if (dl < 0.0) amax = fmin(amax, -L.lam[r] / dl);
         }
         const double alpha = fmin(1.0, 0.995 * wave_min(amax));
+        pf.stop(PH_ROWS);
         if (!isfinite(alpha)) { status = 4; break; }
         if (alpha < 1e-12) { status = 3; break; }
         // ---------------- update ----------------
@@ -466,6 +548,7 @@ __device__ int ipm_solve(const Lds &L, const Dims &d, int tid, int *iters_out)
         for (int e = tid; e < (N + 1) * NV; e += NT) L.v[e] += alpha * L.dv[e];
         for (int e = tid; e < N * NX; e += NT) L.pq[NX + e] += alpha * L.dpi[NX + e];
         __syncthreads();
+        pf.stop(PH_UPDATE);
     }
     *iters_out = iters;
     return status;
@@ -519,7 +602,8 @@ __global__ __launch_bounds__(NT) void tmpc_solve_kernel(Dims d, int B, const dou
                                                         double *__restrict__ xtraj, double *__restrict__ utraj,
                                                         double *__restrict__ pobj, int *__restrict__ exit_code,
                                                         int *__restrict__ qp_status_out, int *__restrict__ sqp_iter_out,
-                                                        double *__restrict__ res_eq_out, int *__restrict__ qp_iter_out)
+                                                        double *__restrict__ res_eq_out, int *__restrict__ qp_iter_out,
+                                                        long long *__restrict__ prof_out)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -537,8 +621,12 @@ __global__ __launch_bounds__(NT) void tmpc_solve_kernel(Dims d, int B, const dou
     if (tid < NU) L.z[N * NV + tid] = 0.0;
     __syncthreads();
 
+    Prof pf; pf.out = prof_out;
+    for (int i = 0; i < PH_COUNT; i++) pf.acc[i] = 0;
+    const long long t_begin = prof_out ? clock64() : 0;
     int status = 0, qp_status = 0, sqp_iter = 0, qp_iter_total = 0;
     for (int it = 0; it < d.n_sqp; it++) {
+        pf.start();
         linearise(L, d, tid, pb);
         // QP primal start: dz = 0 except dx_0 = xinit - x_0; duals 0
         for (int e = tid; e < (N + 1) * NV; e += NT) L.v[e] = 0.0;
@@ -546,8 +634,9 @@ __global__ __launch_bounds__(NT) void tmpc_solve_kernel(Dims d, int B, const dou
         __syncthreads();
         if (tid < NX) L.v[NU + tid] = xi[tid] - L.z[NU + tid];
         __syncthreads();
+        pf.stop(PH_LIN);
         int iters = 0;
-        qp_status = ipm_solve(L, d, tid, &iters);
+        qp_status = ipm_solve(L, d, tid, &iters, pf);
         sqp_iter = it + 1; qp_iter_total += iters;
         if (qp_status != 0 && qp_status != 2) { status = 4; break; }      // ACADOS_QP_FAILURE, no step
         status = 0;
@@ -562,6 +651,7 @@ __global__ __launch_bounds__(NT) void tmpc_solve_kernel(Dims d, int B, const dou
     }
 
     // completeOneIteration (acados_solver_interface.cpp:162-204)
+    pf.start();
     double cost = 0.0, res = 0.0;
     if (tid < N) {
         double z[NV];
@@ -591,6 +681,11 @@ __global__ __launch_bounds__(NT) void tmpc_solve_kernel(Dims d, int B, const dou
         pobj[b] = cost; res_eq_out[b] = res;
         exit_code[b] = status == 0 ? 1 : (status == 1 ? 0 : status);      // Forces-style mapping (:197-201)
         qp_status_out[b] = qp_status; sqp_iter_out[b] = sqp_iter; qp_iter_out[b] = qp_iter_total;
+    }
+    if (prof_out) {
+        pf.stop(PH_FINAL);
+        pf.acc[PH_TOTAL] = clock64() - t_begin;
+        if (tid == 0) for (int i = 0; i < PH_COUNT; i++) prof_out[(size_t)b * PH_COUNT + i] = pf.acc[i];
     }
 }
 
@@ -826,7 +921,7 @@ int tmpc_solve(tmpc_handle *h)
     if (rec) TMPC_HIP_CHECK(h, hipEventRecord(h->ev[h->ev_used], h->stream));
     hipLaunchKernelGGL(tmpc::tmpc_solve_kernel, dim3(h->B), dim3(tmpc::NT), h->lds_bytes, h->stream, h->d, h->B,
                        h->xinit, h->x0, h->params, h->xtraj, h->utraj, h->pobj, h->exit_code, h->qp_status,
-                       h->sqp_iter, h->res_eq, h->qp_iter);
+                       h->sqp_iter, h->res_eq, h->qp_iter, (long long *)nullptr);
     TMPC_HIP_CHECK(h, hipGetLastError());
     if (rec) { TMPC_HIP_CHECK(h, hipEventRecord(h->ev[h->ev_used + 1], h->stream)); h->ev_used += 2; }
     return TMPC_OK;
@@ -936,6 +1031,29 @@ int tmpc_time_solve(tmpc_handle *h, int32_t reps, float *ms_each)
     TMPC_HIP_CHECK(h, hipStreamSynchronize(h->stream));
     for (int i = 0; i < reps; i++) TMPC_HIP_CHECK(h, hipEventElapsedTime(&ms_each[i], ev[2 * i], ev[2 * i + 1]));
     for (auto &e : ev) (void)hipEventDestroy(e);
+    return TMPC_OK;
+}
+
+int tmpc_debug_profile(tmpc_handle *h, int64_t *cycles, int32_t n_phases)
+{
+    if (!h || h->B <= 0 || !cycles || n_phases < tmpc::PH_COUNT) return TMPC_ERR_INVALID;
+    TMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    long long *dp = nullptr;
+    const size_t n = (size_t)h->B * tmpc::PH_COUNT;
+    TMPC_HIP_CHECK(h, hipMalloc(&dp, n * 8));
+    hipLaunchKernelGGL(tmpc::tmpc_solve_kernel, dim3(h->B), dim3(tmpc::NT), h->lds_bytes, h->stream, h->d, h->B,
+                       h->xinit, h->x0, h->params, h->xtraj, h->utraj, h->pobj, h->exit_code, h->qp_status,
+                       h->sqp_iter, h->res_eq, h->qp_iter, dp);
+    TMPC_HIP_CHECK(h, hipGetLastError());
+    TMPC_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    std::vector<long long> host(n);
+    TMPC_HIP_CHECK(h, hipMemcpy(host.data(), dp, n * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(dp);
+    for (int i = 0; i < tmpc::PH_COUNT; i++) {
+        double acc = 0.0;
+        for (int b = 0; b < h->B; b++) acc += (double)host[(size_t)b * tmpc::PH_COUNT + i];
+        cycles[i] = (int64_t)(acc / h->B);
+    }
     return TMPC_OK;
 }
 

@@ -50,7 +50,8 @@ def all_gather_records(local_records_tensor, world_size):
     import torch.distributed as dist
     if world_size == 1:
         return local_records_tensor.unsqueeze(0)
-    out = torch.empty((world_size,) + tuple(local_records_tensor.shape), dtype=local_records_tensor.dtype,
+    n = local_records_tensor.shape[0]
+    out = torch.empty((world_size * n,) + tuple(local_records_tensor.shape[1:]), dtype=local_records_tensor.dtype,
                       device=local_records_tensor.device)
-    dist.all_gather_into_tensor(out, local_records_tensor.contiguous())
-    return out
+    dist.all_gather_into_tensor(out, local_records_tensor.contiguous())      # one collective: concat along dim 0
+    return out.view((world_size, n) + tuple(local_records_tensor.shape[1:]))

@@ -25,7 +25,7 @@ class TmpcDims(C.Structure):
 EXPORTS = ["tmpc_default_dims", "tmpc_create", "tmpc_destroy", "tmpc_last_error", "tmpc_set_batch",
            "tmpc_set_batch_device", "tmpc_solve", "tmpc_synchronize", "tmpc_get", "tmpc_select_best",
            "tmpc_result_device_ptrs", "tmpc_time_solve", "tmpc_debug_eval_stage", "tmpc_pack_records",
-           "tmpc_select_best_records", "tmpc_enable_timing", "tmpc_get_timings"]
+           "tmpc_select_best_records", "tmpc_enable_timing", "tmpc_get_timings", "tmpc_debug_profile"]
 
 _lib = None
 
@@ -61,6 +61,7 @@ def load_library():
         lib.tmpc_select_best_records.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int32, vp]
         lib.tmpc_enable_timing.argtypes = [vp, C.c_int32]
         lib.tmpc_get_timings.argtypes = [vp, vp, C.c_int32, C.POINTER(C.c_int32)]
+        lib.tmpc_debug_profile.argtypes = [vp, vp, C.c_int32]
         _lib = lib
     return _lib
 
@@ -181,6 +182,14 @@ class BatchedSolver:
         return a.value, b.value
 
     # --- debug ------------------------------------------------------------------------------------
+    PHASES = ["linearise", "residuals", "barrier_hessian", "riccati_factor", "rhs", "riccati_solve", "row_passes",
+              "update", "final", "total"]
+
+    def debug_profile(self):
+        cyc = np.zeros(10, np.int64)
+        self._check(self.lib.tmpc_debug_profile(self._h, _p(cyc), 10), "tmpc_debug_profile")
+        return dict(zip(self.PHASES, cyc.tolist()))
+
     def debug_eval_stage(self, z, p, pi=None, lamh=None):
         z = np.ascontiguousarray(z, np.float64).reshape(-1, NV); n = z.shape[0]
         p = np.ascontiguousarray(p, np.float64).reshape(n, self.npar)
