@@ -1,0 +1,142 @@
+/*
+ * mpc_planner_solver/solver_interface.h -- HIP flavour of the reference's solver interface.
+ *
+ * Source-compatible mirror of `MPCPlanner::Solver` (reference:
+ * mpc_planner_solver/include/mpc_planner_solver/acados_solver_interface.h:93-222 and
+ * src/acados_solver_interface.cpp) so that the modules (mpc_planner_modules/src/*.cpp) and
+ * Planner::solveMPC (mpc_planner/src/planner.cpp:37-158) compile against it unchanged: same public members
+ * (_params, _info, _output, N, nu, nx, nvar, npar, dt, _num_iterations, _solver_id), same methods, same
+ * exit-code convention.  The acados capsule is replaced by a handle of the batch-first C-ABI
+ * (include/tmpc_hip.h); `solveBatch` is the new entry point that lets GuidanceConstraints::optimize
+ * (guidance_constraints.cpp:279-361) hand all local planners to ONE launch instead of an OpenMP loop.
+ *
+ * yaml-cpp / Eigen / ros_tools are not available in the build image, so the three generated YAML maps are read
+ * by a ~40-line flat reader (the generated files are flat "key: value" / "key: [a, b, c, d]" maps) and
+ * positions use a 2-double struct with Eigen's (i) accessor.
+ */
+#ifndef MPC_PLANNER_HIP_SOLVER_INTERFACE_H
+#define MPC_PLANNER_HIP_SOLVER_INTERFACE_H
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include <mpc_planner_solver/hip_solver_dims.h>
+#include "tmpc_hip.h"
+
+#define NX SOLVER_NX
+#define NU SOLVER_NU
+
+namespace MPCPlanner
+{
+    struct Vector2d
+    {
+        double v[2];
+        Vector2d(double x = 0., double y = 0.) : v{x, y} {}
+        double &operator()(int i) { return v[i]; }
+        double operator()(int i) const { return v[i]; }
+    };
+
+    struct ModelEntry { std::string type; int index; double lb, ub; };          // model_map.yaml row
+    typedef std::map<std::string, int> ParameterMap;                            // parameter_map.yaml
+    typedef std::map<std::string, ModelEntry> ModelMap;
+    void loadSolverConfig(const std::string &dir, std::map<std::string, double> &settings, ParameterMap &pm, ModelMap &mm);
+    void setSolverConfigPath(const std::string &dir);                           // where the generated YAMLs live
+
+    /* state.h:13-30 */
+    struct State
+    {
+        State();
+        void initialize();
+        double get(std::string &&var_name) const;
+        Vector2d getPos() const;
+        void set(std::string &&var_name, double value);
+    private:
+        std::vector<double> _state;
+        ModelMap _model_map;
+        int _nu;
+    };
+
+    /* acados_solver_interface.h:51-91 -- trivially copyable host arrays, identical layout */
+    struct AcadosParameters
+    {
+        double xinit[NX];
+        double x0[(NU + NX) * (SOLVER_N + 1)];
+        double all_parameters[SOLVER_NP * SOLVER_N];
+        double solver_timeout{0.};
+        double *getU0() { return x0; }
+        AcadosParameters();
+    };
+
+    class Solver
+    {
+    public:
+        struct AcadosInfo              /* :96-125 */
+        {
+            double min_time, kkt_norm_inf, elapsed_time;
+            int sqp_iter;
+            double nlp_res, solvetime;
+            int qp_status;
+            double pobj{0.};
+            AcadosInfo() : min_time(1e12), kkt_norm_inf(0.), elapsed_time(0.), sqp_iter(0), nlp_res(0.), solvetime(0.), qp_status(0) {}
+        };
+        struct AcadosOutput            /* :127-148 */
+        {
+            double xtraj[NX * (SOLVER_N + 1)];
+            double utraj[NU * SOLVER_N];
+            AcadosOutput();
+        };
+
+    private:
+        tmpc_handle *_handle{nullptr};          // replaces the acados capsule; created lazily on the first solve
+        int _exit_code_one_iter{-1};
+        int _device{0};
+        void ensureHandle();
+
+    public:
+        int _solver_id;
+        AcadosParameters _params;
+        AcadosInfo _info;
+        AcadosOutput _output;
+        int N;
+        unsigned int nu, nx, nvar, npar;
+        double dt;
+        std::map<std::string, double> _config;
+        ParameterMap _parameter_map;
+        ModelMap _model_map;
+        int _num_iterations;
+
+        Solver(int solver_id = 0);
+        ~Solver();
+        Solver(const Solver &) = delete;
+        Solver &operator=(const Solver &rhs);   // copies _params only (acados_solver_interface.cpp:67-77)
+        void reset();
+
+        int solve();                            // :86-119
+        void initializeOneIteration();          // :121-143 (parameters are handed over at solve time)
+        int solveOneIteration();                // :145-160 (runs the whole fixed-budget solve)
+        int completeOneIteration();             // :162-204
+
+        /* GuidanceConstraints::optimize batch path: solvers[i]->_params in, _output/_info out, exit codes returned */
+        static std::vector<int> solveBatch(const std::vector<Solver *> &solvers);
+
+        bool hasParameter(std::string &&parameter);
+        void setParameter(int k, std::string &&parameter, double value);
+        void setParameter(int k, std::string &parameter, double value);
+        double getParameter(int k, std::string &&parameter);
+        void setXinit(std::string &&state_name, double value);
+        void setXinit(const State &state);
+        void setEgoPrediction(unsigned int k, std::string &&var_name, double value);
+        double getEgoPrediction(unsigned int k, std::string &&var_name);
+        void setEgoPredictionPosition(unsigned int k, const Vector2d &value);
+        Vector2d getEgoPredictionPosition(unsigned int k);
+        void loadWarmstart();
+        void initializeWarmstart(const State &state, bool shift_previous_solution_forward);
+        void initializeWithState(const State &initial_state);
+        void initializeWithBraking(const State &initial_state);
+        double getOutput(int k, std::string &&state_name) const;
+        std::string explainExitFlag(int exitflag) const;
+        void printIfBoundLimited() const;
+    };
+}
+#endif

@@ -1,0 +1,261 @@
+// HIP flavour of MPCPlanner::Solver -- see include/mpc_planner_solver/solver_interface.h.
+// Each method cites the reference method it mirrors (mpc_planner_solver/src/acados_solver_interface.cpp).
+#include <mpc_planner_solver/solver_interface.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+
+namespace MPCPlanner
+{
+    static std::string g_config_dir = "config";
+    void setSolverConfigPath(const std::string &dir) { g_config_dir = dir; }
+
+    static std::string trim(const std::string &s)
+    {
+        size_t a = s.find_first_not_of(" \t\r\n"), b = s.find_last_not_of(" \t\r\n");
+        return a == std::string::npos ? "" : s.substr(a, b - a + 1);
+    }
+    // flat "key: value" / "key: [a, b, c]" reader for the three generated YAML maps
+    static void readFlatYaml(const std::string &path, std::vector<std::pair<std::string, std::vector<std::string>>> &out)
+    {
+        std::ifstream f(path);
+        if (!f) { std::fprintf(stderr, "Solver: cannot open %s\n", path.c_str()); std::exit(1); }
+        std::string line;
+        while (std::getline(f, line)) {
+            size_t c = line.find(':');
+            if (c == std::string::npos) continue;
+            std::string key = trim(line.substr(0, c)), val = trim(line.substr(c + 1));
+            std::vector<std::string> items;
+            if (!val.empty() && val[0] == '[') {
+                std::stringstream ss(val.substr(1, val.size() - 2)); std::string it;
+                while (std::getline(ss, it, ',')) items.push_back(trim(it));
+            } else items.push_back(val);
+            out.push_back({key, items});
+        }
+    }
+    void loadSolverConfig(const std::string &dir, std::map<std::string, double> &settings, ParameterMap &pm, ModelMap &mm)
+    {
+        std::vector<std::pair<std::string, std::vector<std::string>>> kv;
+        readFlatYaml(dir + "/solver_settings.yaml", kv);
+        for (auto &e : kv) settings[e.first] = std::atof(e.second[0].c_str());
+        kv.clear(); readFlatYaml(dir + "/parameter_map.yaml", kv);
+        for (auto &e : kv) pm[e.first] = std::atoi(e.second[0].c_str());
+        kv.clear(); readFlatYaml(dir + "/model_map.yaml", kv);
+        for (auto &e : kv) mm[e.first] = ModelEntry{e.second[0], std::atoi(e.second[1].c_str()), std::atof(e.second[2].c_str()), std::atof(e.second[3].c_str())};
+    }
+
+    // ---- State (state.cpp:8-33) ----
+    State::State()
+    {
+        std::map<std::string, double> cfg; ParameterMap pm;
+        loadSolverConfig(g_config_dir, cfg, pm, _model_map);
+        _nu = (int)cfg["nu"];
+        _state = std::vector<double>((int)cfg["nx"], 0.0);
+    }
+    void State::initialize() { std::fill(_state.begin(), _state.end(), 0.0); }
+    double State::get(std::string &&var_name) const { return _state[_model_map.at(var_name).index - _nu]; }
+    Vector2d State::getPos() const { return Vector2d(get("x"), get("y")); }
+    void State::set(std::string &&var_name, double value) { _state[_model_map.at(var_name).index - _nu] = value; }
+
+    AcadosParameters::AcadosParameters()
+    {
+        std::memset(xinit, 0, sizeof xinit); std::memset(x0, 0, sizeof x0); std::memset(all_parameters, 0, sizeof all_parameters);
+    }
+    Solver::AcadosOutput::AcadosOutput() { std::memset(xtraj, 0, sizeof xtraj); std::memset(utraj, 0, sizeof utraj); }
+
+    // ---- construction (acados_solver_interface.cpp:9-65) ----
+    Solver::Solver(int solver_id)
+    {
+        _solver_id = solver_id;
+        loadSolverConfig(g_config_dir, _config, _parameter_map, _model_map);
+        N = SOLVER_N;
+        nu = (unsigned)_config["nu"]; nx = (unsigned)_config["nx"]; nvar = (unsigned)_config["nvar"]; npar = (unsigned)_config["npar"];
+        dt = _config["integrator_step"];
+        _num_iterations = (int)_config["iterations"];
+        if (nu != SOLVER_NU || nx != SOLVER_NX || npar != SOLVER_NP || (int)_config["N"] != SOLVER_N) {
+            std::fprintf(stderr, "Solver: generated YAML maps do not match hip_solver_dims.h. Exiting.\n");
+            std::exit(1);
+        }
+        reset();
+    }
+    Solver::~Solver() { if (_handle) tmpc_destroy(_handle); }
+
+    void Solver::ensureHandle()
+    {
+        if (_handle) return;
+        tmpc_dims d;
+        tmpc_default_dims(&d, SOLVER_N, SOLVER_S, SOLVER_NLIN, SOLVER_M);
+        d.n_sqp = _num_iterations; d.dt = dt;
+        for (auto &e : _model_map) { d.lb[e.second.index] = e.second.lb; d.ub[e.second.index] = e.second.ub; }
+        int status = tmpc_create(&_handle, &d, 1, _device);
+        if (status) {                                   // reference: exit(1) when the capsule cannot be created (:35-39)
+            std::printf("tmpc_create() returned status %d (no MI355X / library not built). Exiting.\n", status);
+            std::exit(1);
+        }
+    }
+
+    Solver &Solver::operator=(const Solver &rhs) { _params = rhs._params; return *this; }      // (:67-77)
+    void Solver::reset() { _params = AcadosParameters(); _info = AcadosInfo(); _output = AcadosOutput(); }  // (:79-84)
+
+    // ---- solve (:86-204).  The RTI loop runs on the device with a fixed iteration budget (_num_iterations);
+    // the reference's wall-clock early exit (:111-116) is intentionally not reproduced (non-deterministic). ----
+    int Solver::solve()
+    {
+        initializeOneIteration();
+        solveOneIteration();
+        return completeOneIteration();
+    }
+    void Solver::initializeOneIteration()
+    {
+        ensureHandle();
+        _info = AcadosInfo();
+        if (tmpc_set_batch(_handle, 1, _params.xinit, _params.x0, _params.all_parameters)) {
+            std::fprintf(stderr, "tmpc_set_batch: %s\n", tmpc_last_error(_handle)); std::exit(1);
+        }
+    }
+    int Solver::solveOneIteration()
+    {
+        if (tmpc_solve(_handle)) { std::fprintf(stderr, "tmpc_solve: %s\n", tmpc_last_error(_handle)); std::exit(1); }
+        return 0;
+    }
+    int Solver::completeOneIteration()
+    {
+        int32_t exit_code = 0, qp_status = 0, sqp_iter = 0, qp_it = 0; double res_eq = 0.;
+        if (tmpc_get(_handle, _output.xtraj, _output.utraj, &_info.pobj, &exit_code, &qp_status, &sqp_iter, &res_eq, &qp_it)) {
+            std::fprintf(stderr, "tmpc_get: %s\n", tmpc_last_error(_handle)); std::exit(1);
+        }
+        _info.qp_status = qp_status; _info.sqp_iter = sqp_iter; _info.nlp_res = res_eq;
+        _exit_code_one_iter = exit_code;
+        return _exit_code_one_iter;
+    }
+
+    std::vector<int> Solver::solveBatch(const std::vector<Solver *> &solvers)
+    {
+        const int B = (int)solvers.size();
+        std::vector<int> codes(B, 0);
+        if (B == 0) return codes;
+        static tmpc_handle *batch_handle = nullptr; static int batch_cap = 0;
+        Solver *s0 = solvers[0];
+        if (!batch_handle || batch_cap < B) {
+            if (batch_handle) tmpc_destroy(batch_handle);
+            tmpc_dims d; tmpc_default_dims(&d, SOLVER_N, SOLVER_S, SOLVER_NLIN, SOLVER_M);
+            d.n_sqp = s0->_num_iterations; d.dt = s0->dt;
+            for (auto &e : s0->_model_map) { d.lb[e.second.index] = e.second.lb; d.ub[e.second.index] = e.second.ub; }
+            if (tmpc_create(&batch_handle, &d, B, 0)) { std::printf("tmpc_create() failed. Exiting.\n"); std::exit(1); }
+            batch_cap = B;
+        }
+        const size_t n0 = (SOLVER_NU + SOLVER_NX) * (SOLVER_N + 1), np = (size_t)SOLVER_NP * SOLVER_N;
+        std::vector<double> xinit((size_t)B * SOLVER_NX), x0(B * n0), par(B * np);
+        for (int b = 0; b < B; b++) {
+            std::memcpy(&xinit[(size_t)b * SOLVER_NX], solvers[b]->_params.xinit, sizeof(double) * SOLVER_NX);
+            std::memcpy(&x0[b * n0], solvers[b]->_params.x0, sizeof(double) * n0);
+            std::memcpy(&par[b * np], solvers[b]->_params.all_parameters, sizeof(double) * np);
+        }
+        const size_t nxt = (size_t)SOLVER_NX * (SOLVER_N + 1), nut = (size_t)SOLVER_NU * SOLVER_N;
+        std::vector<double> xt(B * nxt), ut(B * nut), pobj(B), res(B);
+        std::vector<int32_t> ec(B), qs(B), si(B), qi(B);
+        if (tmpc_set_batch(batch_handle, B, xinit.data(), x0.data(), par.data()) || tmpc_solve(batch_handle) ||
+            tmpc_get(batch_handle, xt.data(), ut.data(), pobj.data(), ec.data(), qs.data(), si.data(), res.data(), qi.data())) {
+            std::fprintf(stderr, "solveBatch: %s\n", tmpc_last_error(batch_handle)); std::exit(1);
+        }
+        for (int b = 0; b < B; b++) {
+            Solver *s = solvers[b];
+            std::memcpy(s->_output.xtraj, &xt[b * nxt], sizeof(double) * nxt);
+            std::memcpy(s->_output.utraj, &ut[b * nut], sizeof(double) * nut);
+            s->_info = AcadosInfo(); s->_info.pobj = pobj[b]; s->_info.qp_status = qs[b]; s->_info.sqp_iter = si[b]; s->_info.nlp_res = res[b];
+            s->_exit_code_one_iter = ec[b]; codes[b] = ec[b];
+        }
+        return codes;
+    }
+
+    // ---- parameters / xinit / warm start / output: host-only, identical index arithmetic (:206-389) ----
+    bool Solver::hasParameter(std::string &&parameter) { return _parameter_map.count(parameter) > 0; }
+    void Solver::setParameter(int k, std::string &&parameter, double value) { _params.all_parameters[k * npar + _parameter_map.at(parameter)] = value; }
+    void Solver::setParameter(int k, std::string &parameter, double value) { _params.all_parameters[k * npar + _parameter_map.at(parameter)] = value; }
+    double Solver::getParameter(int k, std::string &&parameter) { return _params.all_parameters[k * npar + _parameter_map.at(parameter)]; }
+    void Solver::setXinit(std::string &&state_name, double value) { _params.xinit[_model_map.at(state_name).index - nu] = value; }
+    void Solver::setXinit(const State &state)
+    {
+        for (auto &e : _model_map)
+            if (e.second.type == "x") setXinit(std::string(e.first), state.get(std::string(e.first)));
+    }
+    void Solver::setEgoPrediction(unsigned int k, std::string &&var_name, double value) { _params.x0[k * nvar + _model_map.at(var_name).index] = value; }
+    double Solver::getEgoPrediction(unsigned int k, std::string &&var_name) { return _params.x0[k * nvar + _model_map.at(var_name).index]; }
+    void Solver::setEgoPredictionPosition(unsigned int k, const Vector2d &value) { setEgoPrediction(k, "x", value(0)); setEgoPrediction(k, "y", value(1)); }
+    Vector2d Solver::getEgoPredictionPosition(unsigned int k) { return Vector2d(getEgoPrediction(k, "x"), getEgoPrediction(k, "y")); }
+    void Solver::loadWarmstart() { /* x0 travels with _params at solve time (tmpc_set_batch replaces ocp_nlp_out_set, :274-284) */ }
+
+    void Solver::initializeWithState(const State &initial_state)          // (:286-301)
+    {
+        for (int k = 0; k <= N; k++)
+            for (auto &e : _model_map)
+                setEgoPrediction(k, std::string(e.first), e.second.type == "x" ? initial_state.get(std::string(e.first)) : 0.);
+    }
+    void Solver::initializeWithBraking(const State &initial_state)        // (:303-342); deceleration_at_infeasible = 3.0
+    {
+        initializeWithState(initial_state);
+        double x = initial_state.get("x"), y = initial_state.get("y"), psi = initial_state.get("psi"), v = initial_state.get("v");
+        double spline = initial_state.get("spline");
+        const double deceleration = _config.count("deceleration_at_infeasible") ? std::fabs(_config["deceleration_at_infeasible"]) : 3.0;
+        const double a = -deceleration;
+        for (int k = 0; k <= N; k++) {
+            if (k > 0) { x += v * dt * std::cos(psi); y += v * dt * std::sin(psi); spline += v * dt; v += a * dt; v = std::max(v, 0.); }
+            setEgoPrediction(k, "x", x); setEgoPrediction(k, "y", y); setEgoPrediction(k, "psi", psi); setEgoPrediction(k, "v", v);
+            setEgoPrediction(k, "spline", spline); setEgoPrediction(k, "a", a); setEgoPrediction(k, "w", 0);
+        }
+    }
+    void Solver::initializeWarmstart(const State &initial_state, bool shift_previous_solution_forward)   // (:344-376)
+    {
+        if (shift_previous_solution_forward) {
+            for (int k = 0; k <= N; k++)
+                for (auto &e : _model_map) {
+                    std::string n = e.first;
+                    if (k == 0) setEgoPrediction(0, std::string(n), initial_state.get(std::string(n)));
+                    else if (k == N - 1) setEgoPrediction(N - 1, std::string(n), getOutput(N - 1, std::string(n)));
+                    else if (k == N) setEgoPrediction(N, std::string(n), getOutput(N - 1, std::string(n)));
+                    else setEgoPrediction(k, std::string(n), getOutput(k + 1, std::string(n)));
+                }
+        } else {
+            for (int k = 0; k < N; k++)
+                for (auto &e : _model_map) setEgoPrediction(k, std::string(e.first), getOutput(k, std::string(e.first)));
+        }
+    }
+    double Solver::getOutput(int k, std::string &&state_name) const      // (:379-389)
+    {
+        const ModelEntry &m = _model_map.at(state_name);
+        return m.type == "x" ? _output.xtraj[k * nx + m.index - nu] : _output.utraj[k * nu + m.index];
+    }
+    std::string Solver::explainExitFlag(int exitflag) const              // (:391-424)
+    {
+        switch (exitflag) {
+        case 1: return "Success";
+        case 0: return "Failure (no more information)";
+        case 2: return "Failure (maximum number of iterations reached)";
+        case 3: return "Failure (minimum step size reached)";
+        case 4: break;
+        default: return "Unknown exit code";
+        }
+        switch (_info.qp_status) {
+        case 1: return "QP Failure: No more information on QP failure";
+        case 2: return "QP Failure: Max Iterations";
+        case 3: return "QP Failure: Minimal Step Reached";
+        case 4: return "QP Failure: NAN in solution";
+        case 5: return "QP Failure: Inconsistent Equality Constraints";
+        default: return "QP Failure: UNKNOWN";
+        }
+    }
+    void Solver::printIfBoundLimited() const                             // (:426-446)
+    {
+        for (int k = 0; k < N; k++)
+            for (auto &e : _model_map) {
+                if (k == 0 && e.second.type == "x") continue;
+                const double val = getOutput(k, std::string(e.first));
+                if (std::fabs(val - e.second.lb) < 1e-2) std::printf("%s limited by lower bound\n", e.first.c_str());
+                if (std::fabs(val - e.second.ub) < 1e-2) std::printf("%s limited by upper bound\n", e.first.c_str());
+            }
+    }
+}

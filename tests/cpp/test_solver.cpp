@@ -1,0 +1,103 @@
+// C++ test of the HIP-flavour MPCPlanner::Solver, written after the reference's
+// mpc_planner_solver/test/test_solver.cpp:52-133 (State set/get; dims; setParameter/getParameter; setXinit sums;
+// ego-prediction indices; operator= copies params).  The Forces-only `_output.x01/x02/x03` block (:119-121) is
+// replaced by its acados-flavour equivalent (initializeWarmstart from xtraj).  With `--solve` (GPU) it also checks
+// solve() against solveBatch() and the exit-code convention.
+#include <mpc_planner_solver/solver_interface.h>
+#include <mpc_planner_solver/mpc_planner_parameters.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+
+using namespace MPCPlanner;
+#define ASSERT_TRUE(c) do { if (!(c)) { std::printf("ASSERT FAILED %s:%d: %s\n", __FILE__, __LINE__, #c); return 1; } } while (0)
+
+int main(int argc, char **argv)
+{
+    setSolverConfigPath(argc > 1 ? argv[1] : "config");
+    const bool do_solve = argc > 2 && std::strcmp(argv[2], "--solve") == 0;
+    {
+        State state;
+        state.set("x", 1.5); state.set("y", 3.5);
+        ASSERT_TRUE(state.get("y") == 3.5); ASSERT_TRUE(state.get("x") == 1.5);
+        ASSERT_TRUE(state.getPos()(0) == 1.5); ASSERT_TRUE(state.getPos()(1) == 3.5);
+    }
+    Solver solver;
+    ASSERT_TRUE(solver.nu + solver.nx == solver.nvar);
+    ASSERT_TRUE(solver.npar > 0); ASSERT_TRUE(solver.dt > 0.);
+    ASSERT_TRUE(solver.npar == 135 && solver.N == 20);
+    for (int k = 0; k < solver.N; k++) solver.setParameter(k, "reference_velocity", 1.);
+    for (int k = 0; k < solver.N; k++) ASSERT_TRUE(solver.getParameter(k, "reference_velocity") == 1.);
+    ASSERT_TRUE(solver.hasParameter("lin_constraint_7_b") && !solver.hasParameter("nope"));
+    solver.setXinit("x", 5.4); solver.setXinit("y", 1.4);
+    double sum_init = 0.;
+    for (unsigned int i = 0; i < solver.nx; i++) sum_init += solver._params.xinit[i];
+    ASSERT_TRUE(std::abs(sum_init - 6.8) < 1e-5);
+    State state;
+    state.set("x", 4.4); state.set("y", 1.2);
+    solver.setXinit(state);
+    sum_init = 0.;
+    for (unsigned int i = 0; i < solver.nx; i++) sum_init += solver._params.xinit[i];
+    ASSERT_TRUE(std::abs(sum_init - 5.6) < 1e-5);
+    state = State(); solver.setXinit(state);
+    for (int k = 0; k < solver.N; k++) { solver.setEgoPrediction(k, "x", k * 1.); solver.setEgoPrediction(k, "y", 0.); }
+    for (int k = 0; k < solver.N; k++) { ASSERT_TRUE(solver.getEgoPrediction(k, "x") == k * 1); ASSERT_TRUE(solver.getEgoPrediction(k, "y") == 0); }
+    ASSERT_TRUE(solver._params.x0[3 * solver.nvar + 2] == 3.0);           // layout [u_k; x_k], x is z-index 2
+    // warm start from the previous output (acados flavour of test_solver.cpp:119-127)
+    for (int k = 0; k <= solver.N; k++) solver._output.xtraj[k * solver.nx + 0] = 10. + k;
+    solver.initializeWarmstart(state, false);
+    ASSERT_TRUE(solver.getEgoPrediction(1, "x") == 11.0 && solver.getEgoPrediction(0, "x") == 10.0);
+    state.set("x", 0.8);
+    solver.initializeWarmstart(state, true);
+    ASSERT_TRUE(solver.getEgoPrediction(0, "x") == 0.8 && solver.getEgoPrediction(1, "x") == 12.0);
+    ASSERT_TRUE(solver.getEgoPrediction(solver.N, "x") == 10. + solver.N - 1);
+    // generated fast setters hit the same slots as the string interface
+    setSolverParameterEllipsoidObstX(3, solver._params, 7.25, 2);
+    ASSERT_TRUE(solver.getParameter(3, "ellipsoid_obst_2_x") == 7.25);
+    setSolverParameterLinConstraintB(4, solver._params, -1.5, 7);
+    ASSERT_TRUE(solver.getParameter(4, "lin_constraint_7_b") == -1.5);
+    Solver solver2(1);
+    solver2.setParameter(0, "reference_velocity", 3.);
+    ASSERT_TRUE(solver._solver_id != solver2._solver_id);
+    solver2 = solver;
+    ASSERT_TRUE(solver2.getParameter(0, "reference_velocity") == 1.);
+    ASSERT_TRUE(solver.explainExitFlag(1) == "Success");
+    std::printf("plumbing ok\n");
+    if (!do_solve) return 0;
+
+    // ---- GPU: a straight-road problem with far-away obstacles must succeed; solve() == solveBatch() ----
+    std::vector<std::unique_ptr<Solver>> own; std::vector<Solver *> batch;
+    for (int b = 0; b < 3; b++) {
+        own.emplace_back(new Solver(b)); Solver &s = *own.back();
+        State st; st.set("v", 1.0 + 0.2 * b); s.setXinit(st);
+        s.initializeWithState(st);
+        for (int k = 0; k <= s.N; k++) { s.setEgoPrediction(k, "x", 0.2 * k * (1.0 + 0.2 * b)); s.setEgoPrediction(k, "spline", 0.2 * k * (1.0 + 0.2 * b)); }
+        const char *w[] = {"acceleration", "angular_velocity", "velocity", "reference_velocity", "contour", "lag"};
+        const double wv[] = {0.34, 0.85, 0.55, 2.0, 0.05, 0.75};
+        for (int k = 0; k < s.N; k++) {
+            for (int i = 0; i < 6; i++) s.setParameter(k, std::string(w[i]), wv[i]);
+            for (int i = 0; i < SOLVER_S; i++) { setSolverParameterSplineXC(k, s._params, 1.0, i); setSolverParameterSplineXD(k, s._params, 6.0 * i, i); setSolverParameterSplineStart(k, s._params, 6.0 * i, i); }
+            setSolverParameterEgoDiscRadius(k, s._params, 0.325);
+            for (int j = 0; j < SOLVER_M; j++) {
+                setSolverParameterLinConstraintA1(k, s._params, 1.0, j); setSolverParameterLinConstraintB(k, s._params, 100.0, j);
+                setSolverParameterEllipsoidObstX(k, s._params, 50.0, j); setSolverParameterEllipsoidObstY(k, s._params, 50.0 + j, j);
+                setSolverParameterEllipsoidObstChi(k, s._params, 1.0, j); setSolverParameterEllipsoidObstR(k, s._params, 0.4, j);
+            }
+        }
+        batch.push_back(&s);
+    }
+    std::vector<int> codes = Solver::solveBatch(batch);
+    for (int b = 0; b < 3; b++) {
+        ASSERT_TRUE(codes[b] == 1);
+        Solver single(10 + b); single = *batch[b];
+        single.loadWarmstart();
+        ASSERT_TRUE(single.solve() == 1);
+        ASSERT_TRUE(single._info.pobj == batch[b]->_info.pobj);          // bitwise: same kernel, batch-composition invariant
+        for (int k = 0; k <= single.N; k++) ASSERT_TRUE(single.getOutput(k, "x") == batch[b]->getOutput(k, "x"));
+        ASSERT_TRUE(single.getOutput(5, "v") > 1.0 && single.getOutput(single.N, "x") > 3.0);
+    }
+    std::printf("solve ok: pobj %.6f %.6f %.6f\n", batch[0]->_info.pobj, batch[1]->_info.pobj, batch[2]->_info.pobj);
+    return 0;
+}
