@@ -1,0 +1,349 @@
+// mpc_planner_amd/csrc/tmpc_fast.hpp -- register-resident interior-point rows (included by tmpc_solve.hip).
+//
+// Fast variant of the solve kernel for the registered problem shapes.  Differences to the generic kernel:
+//   * lane = (stage k, sub-lane c), LPS lanes per stage; every lane OWNS the interior-point rows
+//     r = c, c+LPS, c+2 LPS, ... of its stage and keeps their state (t, lam, 1/t, q/t) and their signed
+//     coefficients in REGISTERS for the whole QP: the row passes (residuals, barrier Hessian, right-hand sides,
+//     step lengths, update) touch LDS only to read the stage's v / dv and to accumulate stage sums with ds_add_f64;
+//   * the linearisation's row data [D beta] and the multipliers handed to the next linearisation are staged in LDS
+//     that ALIASES the interior-point work arrays (dead at that time), so a trajectory needs ~28 KB instead of 57 KB.
+#pragma once
+
+namespace tmpc {
+
+template <int NLIN, int MM, int LPS>
+struct FastCfg {
+    static constexpr int NH = NLIN + MM;
+    static constexpr int NR = NH + 14;                 // general rows + 4 input-box rows + 10 state-box rows
+    static constexpr int RPL = (NR + LPS - 1) / LPS;   // rows per lane
+};
+
+__host__ __device__ inline int lds_doubles_fast(int N, int nh)
+{
+    const int persistent = (N + 1) * NV + (N + 1) * NX + (N + 1) * NP28 + (N + 1) * NV + N * NX * NV + N * NX;
+    const int work = (N + 1) * NV + (N + 1) * NX + (N + 1) * NP28 + 2 * (N + 1) * NV + N * NX + (N + 1) * NV +
+                     (N + 1) * NX + (N + 1) * NX + N * NU + 64;
+    const int staging = N * nh * 3 + 2 * N * nh;
+    return persistent + (work > staging ? work : staging);
+}
+
+__device__ __forceinline__ Lds carve_fast(double *s, const Dims &d)
+{
+    Lds L;
+    const int N = d.N;
+    L.nh = d.n_lin + d.M;
+    L.NG = N * L.nh; L.GB = L.NG; L.XB = L.NG + 4 * N; L.nrows = L.XB + 10 * (N - 1);
+    auto take = [&](int n) { double *p = s; s += n; return p; };
+    L.z = take((N + 1) * NV); L.pi = take((N + 1) * NX); L.W = take((N + 1) * NP28); L.g = take((N + 1) * NV);
+    L.BA = take(N * NX * NV); L.b = take(N * NX);
+    double *w = s;                                      // work region (IPM) ...
+    L.v = take((N + 1) * NV); L.pq = take((N + 1) * NX); L.Hh = take((N + 1) * NP28);
+    L.rg = take((N + 1) * NV); L.gh = take((N + 1) * NV); L.rb = take(N * NX); L.dv = take((N + 1) * NV);
+    L.dpi = take((N + 1) * NX); L.pr = take((N + 1) * NX); L.y = take(N * NU); L.scr = take(64);
+    s = w;                                              // ... aliased by the staging region (linearisation <-> IPM)
+    L.D = take(N * L.nh * 3); L.beta = take(N * L.nh); L.lamh = take(N * L.nh);
+    L.t = L.lam = L.invt = L.qt = L.rdiag = nullptr;
+    return L;
+}
+
+// 1/x: v_rcp_f64 seed + two Newton steps
+__device__ __forceinline__ double rcp_nr(double x)
+{
+    double y = __builtin_amdgcn_rcp(x);
+    y = y * (2.0 - x * y);
+    y = y * (2.0 - x * y);
+    return y;
+}
+
+__device__ __forceinline__ void lds_add(double *p, double v) { atomicAdd(p, v); }   // ds_add_f64
+
+template <int NLIN, int MM, int LPS>
+__device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, int *iters_out, Prof &pf,
+                        double (&lam)[FastCfg<NLIN, MM, LPS>::RPL])
+{
+    using C = FastCfg<NLIN, MM, LPS>;
+    constexpr int NH = C::NH, NR = C::NR, RPL = C::RPL;
+    const int N = d.N;
+    const int k = tid / LPS, c = tid - k * LPS;
+    const bool stage_lane = k < N;
+    const int kk = stage_lane ? k : 0;
+    const double m_rows = (double)(N * NH + 4 * N + 10 * (N - 1));
+
+    // ---- load this lane's rows (signed coefficients) from the staging area into registers ----
+    double c0[RPL], c1[RPL], c2[RPL], cu[RPL], sb[RPL];
+    int var[RPL];
+    unsigned act = 0;
+#pragma unroll
+    for (int s = 0; s < RPL; s++) {
+        const int r = c + LPS * s;
+        c0[s] = c1[s] = c2[s] = cu[s] = 0.0; sb[s] = 0.0; var[s] = 0;
+        if (stage_lane && r < NR) {
+            if (r < NH) {
+                const double sgn = (r < NLIN) ? -1.0 : 1.0;     // topology rows: upper bound 0; ellipsoids: lower bound 1
+                const double *Dr = L.D + (k * NH + r) * 3;
+                c0[s] = sgn * Dr[0]; c1[s] = sgn * Dr[1]; c2[s] = sgn * Dr[2];
+                sb[s] = sgn * L.beta[k * NH + r];
+                act |= 1u << s;
+            } else {
+                const int q = r - NH;                           // 0..3 inputs, 4..13 states
+                const int vr = q < 4 ? (q >> 1) : (NU + ((q - 4) >> 1));
+                const bool upper = q & 1;
+                const double sgn = upper ? -1.0 : 1.0;
+                double bnd = 0.0;
+#pragma unroll
+                for (int i = 0; i < NV; i++) if (i == vr) bnd = upper ? d.ub[i] : d.lb[i];
+                cu[s] = sgn; var[s] = vr;
+                sb[s] = sgn * (bnd - L.z[k * NV + vr]);
+                if (q < 4 || k >= 1) act |= 1u << s;            // x_0 is fixed, not boxed
+            }
+        }
+    }
+    __syncthreads();                                             // staging is dead from here on
+    // QP start: dz = 0 except dx_0 = xinit - x_0; duals 0
+    for (int e = tid; e < (N + 1) * NV; e += NT) L.v[e] = 0.0;
+    for (int e = tid; e < (N + 1) * NX; e += NT) L.pq[e] = 0.0;
+    __syncthreads();
+    if (tid < NX) L.v[NU + tid] = xi[tid] - L.z[NU + tid];
+    __syncthreads();
+
+    double t[RPL], invt[RPL], qt[RPL], rd[RPL];
+    {
+        const double vx = L.v[kk * NV + ZX], vy = L.v[kk * NV + ZY], vp = L.v[kk * NV + ZPSI];
+#pragma unroll
+        for (int s = 0; s < RPL; s++) {
+            const double r0 = c0[s] * vx + c1[s] * vy + c2[s] * vp + cu[s] * L.v[kk * NV + var[s]] - sb[s];
+            t[s] = r0 > d.thr0 ? r0 : d.thr0;
+            invt[s] = 1.0 / t[s];
+            lam[s] = (act >> s & 1) ? d.mu0 * invt[s] : 0.0;
+            qt[s] = 0.0; rd[s] = 0.0;
+        }
+    }
+    int status = 2, iters = 0;
+    for (int it = 0;; it++) {
+        pf.start();
+        // ---- stage parts of the residuals: rg0 = g + W v + [B A]^T pi_{k+1} - [0; pi_k];  rb;  Hh <- W ----
+        for (int e = tid; e < (N + 1) * NV; e += NT) {
+            const int ks = e / NV, i = e - ks * NV;
+            double acc = 0.0;
+            const bool skip = (ks == N && i < NU) || (ks == 0 && i >= NU);
+            if (!skip) {
+                acc = L.g[e];
+                const double *Wk = L.W + ks * NP28; const double *vk = L.v + ks * NV;
+#pragma unroll
+                for (int j = 0; j < NV; j++) acc += Wk[sidx(i, j)] * vk[j];
+                if (ks < N) {
+                    const double *BA = L.BA + ks * NX * NV;
+#pragma unroll
+                    for (int l = 0; l < NX; l++) acc += BA[l * NV + i] * L.pq[(ks + 1) * NX + l];
+                }
+                if (i >= NU && ks >= 1) acc -= L.pq[ks * NX + i - NU];
+            }
+            L.rg[e] = acc; L.gh[e] = acc;
+        }
+        double res_b = 0.0;
+        for (int e = tid; e < N * NX; e += NT) {
+            const int ks = e / NX, i = e - ks * NX;
+            double acc = L.b[e] - L.v[(ks + 1) * NV + NU + i];
+            const double *BA = L.BA + ks * NX * NV + i * NV; const double *vk = L.v + ks * NV;
+#pragma unroll
+            for (int j = 0; j < NV; j++) acc += BA[j] * vk[j];
+            L.rb[e] = acc;
+            res_b = fmax(res_b, fabs(acc));
+        }
+        for (int e = tid; e < (N + 1) * NP28; e += NT) L.Hh[e] = L.W[e];
+        __syncthreads();
+        // ---- row pass R (registers): residuals, rg -= lam c, Hh += d c c^T, gh += d rd c ----
+        double res_d = 0.0, res_m = 0.0, mu = 0.0;
+        {
+            const double vx = L.v[kk * NV + ZX], vy = L.v[kk * NV + ZY], vp = L.v[kk * NV + ZPSI];
+            double gs0 = 0, gs1 = 0, gs2 = 0, rs0 = 0, rs1 = 0, rs2 = 0;
+            double h00 = 0, h10 = 0, h11 = 0, h20 = 0, h21 = 0, h22 = 0;
+#pragma unroll
+            for (int s = 0; s < RPL; s++) {
+                const bool a = act >> s & 1;
+                const double vv = L.v[kk * NV + var[s]];
+                const double r = c0[s] * vx + c1[s] * vy + c2[s] * vp + cu[s] * vv - sb[s] - t[s];
+                rd[s] = a ? r : 0.0;
+                const double comp = lam[s] * t[s];
+                const double dd = lam[s] * invt[s];
+                const double w = dd * rd[s];
+                if (a) { res_d = fmax(res_d, fabs(r)); res_m = fmax(res_m, comp); mu += comp; }
+                gs0 += lam[s] * c0[s]; gs1 += lam[s] * c1[s]; gs2 += lam[s] * c2[s];
+                rs0 += w * c0[s]; rs1 += w * c1[s]; rs2 += w * c2[s];
+                const double d0 = dd * c0[s], d1 = dd * c1[s], d2 = dd * c2[s];
+                h00 += d0 * c0[s]; h10 += d1 * c0[s]; h11 += d1 * c1[s];
+                h20 += d2 * c0[s]; h21 += d2 * c1[s]; h22 += d2 * c2[s];
+                if (a && cu[s] != 0.0) {                                  // box row: one variable
+                    lds_add(&L.rg[k * NV + var[s]], -lam[s] * cu[s]);
+                    lds_add(&L.gh[k * NV + var[s]], w * cu[s]);
+                    lds_add(&L.Hh[k * NP28 + pidx(var[s], var[s])], dd);
+                }
+            }
+            if (stage_lane) {
+                lds_add(&L.rg[k * NV + ZX], -gs0); lds_add(&L.rg[k * NV + ZY], -gs1); lds_add(&L.rg[k * NV + ZPSI], -gs2);
+                lds_add(&L.gh[k * NV + ZX], rs0); lds_add(&L.gh[k * NV + ZY], rs1); lds_add(&L.gh[k * NV + ZPSI], rs2);
+                double *Hk = L.Hh + k * NP28;
+                lds_add(&Hk[pidx(ZX, ZX)], h00); lds_add(&Hk[pidx(ZY, ZX)], h10); lds_add(&Hk[pidx(ZY, ZY)], h11);
+                lds_add(&Hk[pidx(ZPSI, ZX)], h20); lds_add(&Hk[pidx(ZPSI, ZY)], h21); lds_add(&Hk[pidx(ZPSI, ZPSI)], h22);
+            }
+        }
+        __syncthreads();
+        // now rg = rg0 - sum lam c (residual) and gh = rg0 + sum d rd c (predictor rhs, q/t = lam)
+        double res_g = 0.0;
+        for (int e = tid; e < (N + 1) * NV; e += NT)
+            if (!(e >= NU && e < NV)) res_g = fmax(res_g, fabs(L.rg[e]));      // dx_0 is fixed: its stationarity row is not a residual
+        res_g = wave_max(res_g); res_b = wave_max(res_b); res_d = wave_max(res_d); res_m = wave_max(res_m);
+        mu = wave_sum(mu) / m_rows;
+        pf.stop(PH_RES);
+        if (!(isfinite(res_g) && isfinite(res_b) && isfinite(res_d) && isfinite(res_m))) { status = 4; break; }
+        if (res_g <= d.qp_tol && res_b <= d.qp_tol && res_d <= d.qp_tol && res_m <= d.qp_tol) { status = 0; break; }
+        if (it >= d.qp_iter_max) { status = 2; break; }
+        iters = it + 1;
+
+        const bool fbad = riccati_factor(L, d, tid);
+        pf.stop(PH_FACTOR);
+        if (fbad) { status = 4; break; }
+        // ---- predictor: rhs = rg + sum c (lam + d rd)  (q/t = lam) ----
+        riccati_solve(L, d, tid);
+        pf.stop(PH_SOLVE);
+        double dt_[RPL], dl_[RPL];
+        double amax = 1e300;
+        {
+            const double dx = L.dv[kk * NV + ZX], dy = L.dv[kk * NV + ZY], dp = L.dv[kk * NV + ZPSI];
+#pragma unroll
+            for (int s = 0; s < RPL; s++) {
+                const bool a = act >> s & 1;
+                const double dvv = L.dv[kk * NV + var[s]];
+                const double ddot = c0[s] * dx + c1[s] * dy + c2[s] * dp + cu[s] * dvv;
+                const double dt = a ? ddot + rd[s] : 0.0;
+                const double dl = a ? -lam[s] - lam[s] * invt[s] * dt : 0.0;
+                dt_[s] = dt; dl_[s] = dl;
+                if (dt < 0.0) amax = fmin(amax, -t[s] / dt);
+                if (dl < 0.0) amax = fmin(amax, -lam[s] / dl);
+            }
+        }
+        const double a_aff = fmin(1.0, wave_min(amax));
+        double mu_aff = 0.0;
+#pragma unroll
+        for (int s = 0; s < RPL; s++) if (act >> s & 1) mu_aff += (lam[s] + a_aff * dl_[s]) * (t[s] + a_aff * dt_[s]);
+        mu_aff = wave_sum(mu_aff) / m_rows;
+        double sigma = mu > 0.0 ? mu_aff / mu : 0.0;
+        sigma = sigma * sigma * sigma;
+        // ---- corrector rhs: gh = rg + sum c (qt + d rd) ----
+        for (int e = tid; e < (N + 1) * NV; e += NT) L.gh[e] = L.rg[e];
+        __syncthreads();
+        {
+            double cs0 = 0, cs1 = 0, cs2 = 0;
+#pragma unroll
+            for (int s = 0; s < RPL; s++) {
+                const bool a = act >> s & 1;
+                qt[s] = a ? lam[s] + (dt_[s] * dl_[s] - sigma * mu) * invt[s] : 0.0;
+                const double w = qt[s] + lam[s] * invt[s] * rd[s];
+                cs0 += w * c0[s]; cs1 += w * c1[s]; cs2 += w * c2[s];
+                if (a && cu[s] != 0.0) lds_add(&L.gh[k * NV + var[s]], w * cu[s]);
+            }
+            if (stage_lane) { lds_add(&L.gh[k * NV + ZX], cs0); lds_add(&L.gh[k * NV + ZY], cs1); lds_add(&L.gh[k * NV + ZPSI], cs2); }
+        }
+        __syncthreads();
+        pf.stop(PH_RHS);
+        riccati_solve(L, d, tid);
+        pf.stop(PH_SOLVE);
+        amax = 1e300;
+        {
+            const double dx = L.dv[kk * NV + ZX], dy = L.dv[kk * NV + ZY], dp = L.dv[kk * NV + ZPSI];
+#pragma unroll
+            for (int s = 0; s < RPL; s++) {
+                const bool a = act >> s & 1;
+                const double dvv = L.dv[kk * NV + var[s]];
+                const double ddot = c0[s] * dx + c1[s] * dy + c2[s] * dp + cu[s] * dvv;
+                const double dt = a ? ddot + rd[s] : 0.0;
+                const double dl = a ? -qt[s] - lam[s] * invt[s] * dt : 0.0;
+                dt_[s] = dt; dl_[s] = dl;
+                if (dt < 0.0) amax = fmin(amax, -t[s] / dt);
+                if (dl < 0.0) amax = fmin(amax, -lam[s] / dl);
+            }
+        }
+        const double alpha = fmin(1.0, 0.995 * wave_min(amax));
+        pf.stop(PH_ROWS);
+        if (!isfinite(alpha)) { status = 4; break; }
+        if (alpha < 1e-12) { status = 3; break; }
+#pragma unroll
+        for (int s = 0; s < RPL; s++) {
+            if (act >> s & 1) {
+                t[s] += alpha * dt_[s]; lam[s] += alpha * dl_[s];
+                invt[s] = 1.0 / t[s];
+            }
+        }
+        for (int e = tid; e < (N + 1) * NV; e += NT) L.v[e] += alpha * L.dv[e];
+        for (int e = tid; e < N * NX; e += NT) L.pq[NX + e] += alpha * L.dpi[NX + e];
+        __syncthreads();
+        pf.stop(PH_UPDATE);
+    }
+    *iters_out = iters;
+    return status;
+}
+
+template <int NLIN, int MM, int LPS>
+__global__ __launch_bounds__(NT) void tmpc_solve_fast_kernel(Dims d, int B, const double *__restrict__ xinit,
+                                                             const double *__restrict__ x0, const double *__restrict__ params,
+                                                             double *__restrict__ xtraj, double *__restrict__ utraj,
+                                                             double *__restrict__ pobj, int *__restrict__ exit_code,
+                                                             int *__restrict__ qp_status_out, int *__restrict__ sqp_iter_out,
+                                                             double *__restrict__ res_eq_out, int *__restrict__ qp_iter_out,
+                                                             long long *__restrict__ prof_out)
+{
+    using C = FastCfg<NLIN, MM, LPS>;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (b >= B) return;
+    const Lds L = carve_fast(smem, d);
+    const int N = d.N;
+    const double *xi = xinit + (size_t)b * NX;
+    const double *pb = params + (size_t)b * N * d.npar;
+    const int k = tid / LPS, c = tid - k * LPS;
+
+    for (int e = tid; e < (N + 1) * NV; e += NT) L.z[e] = x0[(size_t)b * (N + 1) * NV + e];
+    for (int e = tid; e < (N + 1) * NX; e += NT) L.pi[e] = 0.0;
+    for (int e = tid; e < N * C::NH; e += NT) L.lamh[e] = 0.0;
+    __syncthreads();
+    if (tid < NU) L.z[N * NV + tid] = 0.0;
+    __syncthreads();
+
+    Prof pf; pf.out = prof_out;
+    for (int i = 0; i < PH_COUNT; i++) pf.acc[i] = 0;
+    const long long t_begin = prof_out ? clock64() : 0;
+    int status = 0, qp_status = 0, sqp_iter = 0, qp_iter_total = 0;
+    double lam[C::RPL];
+    for (int it = 0; it < d.n_sqp; it++) {
+        pf.start();
+        linearise<true>(L, d, tid, pb);
+        __syncthreads();
+        pf.stop(PH_LIN);
+        int iters = 0;
+        qp_status = ipm_fast<NLIN, MM, LPS>(L, d, tid, xi, &iters, pf, lam);
+        sqp_iter = it + 1; qp_iter_total += iters;
+        if (qp_status != 0 && qp_status != 2) { status = 4; break; }
+        status = 0;
+        __syncthreads();
+        for (int e = tid; e < (N + 1) * NV; e += NT) {
+            const int ks = e / NV, i = e - ks * NV;
+            if (!(ks == N && i < NU)) L.z[e] += L.v[e];
+        }
+        for (int e = tid; e < N * NX; e += NT) L.pi[NX + e] = L.pq[NX + e];
+        __syncthreads();
+        // multipliers of the general rows for the next linearisation: (lam_upper - lam_lower) = -sgn lam
+        if (k < N) {
+#pragma unroll
+            for (int s = 0; s < C::RPL; s++) {
+                const int r = c + LPS * s;
+                if (r < C::NH) L.lamh[k * C::NH + r] = (r < NLIN) ? lam[s] : -lam[s];
+            }
+        }
+        __syncthreads();
+        if (qp_status != 0) break;
+    }
+    solve_epilogue(L, d, tid, b, xi, pb, status, qp_status, sqp_iter, qp_iter_total, xtraj, utraj, pobj, exit_code,
+                   qp_status_out, sqp_iter_out, res_eq_out, qp_iter_out, prof_out, pf, t_begin);
+}
+
+}  // namespace tmpc

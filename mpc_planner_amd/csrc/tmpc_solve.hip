@@ -38,6 +38,7 @@ struct Lds {
     double *z, *pi, *W, *g, *BA, *b, *D, *beta;          // NLP iterate + stage blocks of the current QP
     double *t, *lam, *invt, *qt;                         // interior-point rows
     double *v, *pq, *Hh, *rg, *gh, *rb, *dv, *dpi, *pr, *y, *rdiag, *scr;
+    double *lamh;                                        // fast kernel: staged (lam_upper - lam_lower) of the general rows
     int nh, NG, GB, XB, nrows;
 };
 
@@ -66,6 +67,7 @@ __device__ __forceinline__ Lds carve(double *s, const Dims &d)
     L.rg = take((N + 1) * NV); L.gh = take((N + 1) * NV); L.rb = take(N * NX); L.dv = take((N + 1) * NV);
     L.dpi = take((N + 1) * NX); L.pr = take((N + 1) * NX); L.y = take(N * NU); L.rdiag = take(N * NU);
     L.scr = take(64);
+    L.lamh = nullptr;
     return L;
 }
 
@@ -555,6 +557,7 @@ __device__ int ipm_solve(const Lds &L, const Dims &d, int tid, int *iters_out, P
 }
 
 // ---- stage linearisation by lane k --------------------------------------------------------------
+template <bool FAST>
 __device__ void linearise(const Lds &L, const Dims &d, int tid, const double *params)
 {
     const int N = d.N;
@@ -567,6 +570,7 @@ __device__ void linearise(const Lds &L, const Dims &d, int tid, const double *pa
         double W[NV][NV], g[NV], BA[NX * NV], xn[NX];
         const int nh = L.nh;
         auto lamh = [&](int r) {                            // (lam_upper - lam_lower) of the previous QP
+            if (FAST) return L.lamh[k * nh + r];
             const double sgn = (r < d.n_lin) ? -1.0 : 1.0;
             return -sgn * L.lam[k * nh + r];
         };
@@ -596,61 +600,13 @@ __device__ void linearise(const Lds &L, const Dims &d, int tid, const double *pa
     }
 }
 
-// ---- the solve kernel ---------------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void tmpc_solve_kernel(Dims d, int B, const double *__restrict__ xinit,
-                                                        const double *__restrict__ x0, const double *__restrict__ params,
-                                                        double *__restrict__ xtraj, double *__restrict__ utraj,
-                                                        double *__restrict__ pobj, int *__restrict__ exit_code,
-                                                        int *__restrict__ qp_status_out, int *__restrict__ sqp_iter_out,
-                                                        double *__restrict__ res_eq_out, int *__restrict__ qp_iter_out,
-                                                        long long *__restrict__ prof_out)
+// ---- completeOneIteration (acados_solver_interface.cpp:162-204): cost, trajectories, res_eq, exit-code mapping ----
+__device__ void solve_epilogue(const Lds &L, const Dims &d, int tid, int b, const double *xi, const double *pb, int status,
+                               int qp_status, int sqp_iter, int qp_iter_total, double *xtraj, double *utraj, double *pobj,
+                               int *exit_code, int *qp_status_out, int *sqp_iter_out, double *res_eq_out, int *qp_iter_out,
+                               long long *prof_out, Prof &pf, long long t_begin)
 {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    if (b >= B) return;
-    const Lds L = carve(smem, d);
     const int N = d.N;
-    const double *xi = xinit + (size_t)b * NX;
-    const double *pb = params + (size_t)b * N * d.npar;
-
-    // loadWarmstart (acados_solver_interface.cpp:274-284); fresh multipliers
-    for (int e = tid; e < (N + 1) * NV; e += NT) L.z[e] = x0[(size_t)b * (N + 1) * NV + e];
-    for (int e = tid; e < (N + 1) * NX; e += NT) L.pi[e] = 0.0;
-    for (int r = tid; r < L.nrows; r += NT) L.lam[r] = 0.0;
-    __syncthreads();
-    if (tid < NU) L.z[N * NV + tid] = 0.0;
-    __syncthreads();
-
-    Prof pf; pf.out = prof_out;
-    for (int i = 0; i < PH_COUNT; i++) pf.acc[i] = 0;
-    const long long t_begin = prof_out ? clock64() : 0;
-    int status = 0, qp_status = 0, sqp_iter = 0, qp_iter_total = 0;
-    for (int it = 0; it < d.n_sqp; it++) {
-        pf.start();
-        linearise(L, d, tid, pb);
-        // QP primal start: dz = 0 except dx_0 = xinit - x_0; duals 0
-        for (int e = tid; e < (N + 1) * NV; e += NT) L.v[e] = 0.0;
-        for (int e = tid; e < (N + 1) * NX; e += NT) L.pq[e] = 0.0;
-        __syncthreads();
-        if (tid < NX) L.v[NU + tid] = xi[tid] - L.z[NU + tid];
-        __syncthreads();
-        pf.stop(PH_LIN);
-        int iters = 0;
-        qp_status = ipm_solve(L, d, tid, &iters, pf);
-        sqp_iter = it + 1; qp_iter_total += iters;
-        if (qp_status != 0 && qp_status != 2) { status = 4; break; }      // ACADOS_QP_FAILURE, no step
-        status = 0;
-        __syncthreads();
-        for (int e = tid; e < (N + 1) * NV; e += NT) {
-            const int k = e / NV, i = e - k * NV;
-            if (!(k == N && i < NU)) L.z[e] += L.v[e];
-        }
-        for (int e = tid; e < N * NX; e += NT) L.pi[NX + e] = L.pq[NX + e];
-        __syncthreads();
-        if (qp_status != 0) break;
-    }
-
-    // completeOneIteration (acados_solver_interface.cpp:162-204)
     pf.start();
     double cost = 0.0, res = 0.0;
     if (tid < N) {
@@ -688,6 +644,68 @@ __global__ __launch_bounds__(NT) void tmpc_solve_kernel(Dims d, int B, const dou
         if (tid == 0) for (int i = 0; i < PH_COUNT; i++) prof_out[(size_t)b * PH_COUNT + i] = pf.acc[i];
     }
 }
+
+// ---- the solve kernel ---------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void tmpc_solve_kernel(Dims d, int B, const double *__restrict__ xinit,
+                                                        const double *__restrict__ x0, const double *__restrict__ params,
+                                                        double *__restrict__ xtraj, double *__restrict__ utraj,
+                                                        double *__restrict__ pobj, int *__restrict__ exit_code,
+                                                        int *__restrict__ qp_status_out, int *__restrict__ sqp_iter_out,
+                                                        double *__restrict__ res_eq_out, int *__restrict__ qp_iter_out,
+                                                        long long *__restrict__ prof_out)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (b >= B) return;
+    const Lds L = carve(smem, d);
+    const int N = d.N;
+    const double *xi = xinit + (size_t)b * NX;
+    const double *pb = params + (size_t)b * N * d.npar;
+
+    // loadWarmstart (acados_solver_interface.cpp:274-284); fresh multipliers
+    for (int e = tid; e < (N + 1) * NV; e += NT) L.z[e] = x0[(size_t)b * (N + 1) * NV + e];
+    for (int e = tid; e < (N + 1) * NX; e += NT) L.pi[e] = 0.0;
+    for (int r = tid; r < L.nrows; r += NT) L.lam[r] = 0.0;
+    __syncthreads();
+    if (tid < NU) L.z[N * NV + tid] = 0.0;
+    __syncthreads();
+
+    Prof pf; pf.out = prof_out;
+    for (int i = 0; i < PH_COUNT; i++) pf.acc[i] = 0;
+    const long long t_begin = prof_out ? clock64() : 0;
+    int status = 0, qp_status = 0, sqp_iter = 0, qp_iter_total = 0;
+    for (int it = 0; it < d.n_sqp; it++) {
+        pf.start();
+        linearise<false>(L, d, tid, pb);
+        // QP primal start: dz = 0 except dx_0 = xinit - x_0; duals 0
+        for (int e = tid; e < (N + 1) * NV; e += NT) L.v[e] = 0.0;
+        for (int e = tid; e < (N + 1) * NX; e += NT) L.pq[e] = 0.0;
+        __syncthreads();
+        if (tid < NX) L.v[NU + tid] = xi[tid] - L.z[NU + tid];
+        __syncthreads();
+        pf.stop(PH_LIN);
+        int iters = 0;
+        qp_status = ipm_solve(L, d, tid, &iters, pf);
+        sqp_iter = it + 1; qp_iter_total += iters;
+        if (qp_status != 0 && qp_status != 2) { status = 4; break; }      // ACADOS_QP_FAILURE, no step
+        status = 0;
+        __syncthreads();
+        for (int e = tid; e < (N + 1) * NV; e += NT) {
+            const int k = e / NV, i = e - k * NV;
+            if (!(k == N && i < NU)) L.z[e] += L.v[e];
+        }
+        for (int e = tid; e < N * NX; e += NT) L.pi[NX + e] = L.pq[NX + e];
+        __syncthreads();
+        if (qp_status != 0) break;
+    }
+
+    solve_epilogue(L, d, tid, b, xi, pb, status, qp_status, sqp_iter, qp_iter_total, xtraj, utraj, pobj, exit_code,
+                   qp_status_out, sqp_iter_out, res_eq_out, qp_iter_out, prof_out, pf, t_begin);
+}
+
+}  // namespace tmpc
+#include "tmpc_fast.hpp"
+namespace tmpc {
 
 // ---- FindBestPlanner on device (guidance_constraints.cpp:416-434) ---------------------------------
 __global__ void tmpc_select_best_kernel(int first, int count, const double *pobj, const int *exit_code,
@@ -792,6 +810,26 @@ __global__ void tmpc_debug_eval_kernel(Dims d, int n, const double *z, const dou
 // =================================================================================================
 // C-ABI
 // =================================================================================================
+namespace tmpc {
+typedef void (*SolveKernel)(Dims, int, const double *, const double *, const double *, double *, double *, double *, int *,
+                            int *, int *, double *, int *, long long *);
+// Registered fast shapes (n_lin, M) x lanes-per-stage; anything else runs the generic kernel.
+static SolveKernel pick_fast_kernel(const Dims &d)
+{
+    if (getenv("TMPC_FORCE_GENERIC")) return nullptr;
+    const int lps = (3 * d.N <= NT) ? 3 : ((2 * d.N <= NT) ? 2 : 0);
+    if (lps == 3) {
+        if (d.n_lin == 0 && d.M == 4) return tmpc_solve_fast_kernel<0, 4, 3>;
+        if (d.n_lin == 8 && d.M == 8) return tmpc_solve_fast_kernel<8, 8, 3>;
+        if (d.n_lin == 12 && d.M == 12) return tmpc_solve_fast_kernel<12, 12, 3>;
+    } else if (lps == 2) {
+        if (d.n_lin == 0 && d.M == 4) return tmpc_solve_fast_kernel<0, 4, 2>;
+        if (d.n_lin == 8 && d.M == 8) return tmpc_solve_fast_kernel<8, 8, 2>;
+    }
+    return nullptr;
+}
+}  // namespace tmpc
+
 struct tmpc_handle {
     tmpc::Dims d;
     int B_max = 0, B = 0, device = 0;
@@ -803,6 +841,8 @@ struct tmpc_handle {
     int *exit_code = nullptr, *qp_status = nullptr, *sqp_iter = nullptr, *qp_iter = nullptr, *d_best = nullptr;
     uint8_t *d_disabled = nullptr;
     size_t lds_bytes = 0;
+    tmpc::SolveKernel kernel = nullptr;
+    bool fast = false;
     std::vector<hipEvent_t> ev;      // per-launch timing events (pairs)
     int ev_used = 0;
     bool timing = false;
@@ -850,11 +890,14 @@ int tmpc_create(tmpc_handle **out, const tmpc_dims *dims, int32_t B_max, int32_t
     d.n_sqp = dims->n_sqp; d.qp_iter_max = dims->qp_iter_max; d.erk_steps = dims->erk_steps;
     d.dt = dims->dt; d.qp_tol = dims->qp_tol; d.reg_eps = dims->reg_eps; d.mu0 = dims->ipm_mu0; d.thr0 = dims->ipm_thr0;
     for (int i = 0; i < TMPC_NV; i++) { d.lb[i] = dims->lb[i]; d.ub[i] = dims->ub[i]; }
-    h->lds_bytes = sizeof(double) * (size_t)tmpc::lds_doubles(d.N, d.n_lin + d.M);
+    h->kernel = tmpc::pick_fast_kernel(d);
+    h->fast = h->kernel != nullptr;
+    if (h->fast) h->lds_bytes = sizeof(double) * (size_t)tmpc::lds_doubles_fast(d.N, d.n_lin + d.M);
+    else { h->kernel = tmpc::tmpc_solve_kernel; h->lds_bytes = sizeof(double) * (size_t)tmpc::lds_doubles(d.N, d.n_lin + d.M); }
     auto fail = [&](int code) { delete h; return code; };
     if (hipSetDevice(device) != hipSuccess) return fail(TMPC_ERR_HIP);
     if (h->lds_bytes > 160 * 1024) return fail(TMPC_ERR_INVALID);
-    if (hipFuncSetAttribute((const void *)tmpc::tmpc_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute((const void *)h->kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)h->lds_bytes) != hipSuccess)
         return fail(TMPC_ERR_NO_DEVICE);
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return fail(TMPC_ERR_HIP);
@@ -919,7 +962,7 @@ int tmpc_solve(tmpc_handle *h)
     TMPC_HIP_CHECK(h, hipSetDevice(h->device));
     const bool rec = h->timing && h->ev_used + 2 <= (int)h->ev.size();
     if (rec) TMPC_HIP_CHECK(h, hipEventRecord(h->ev[h->ev_used], h->stream));
-    hipLaunchKernelGGL(tmpc::tmpc_solve_kernel, dim3(h->B), dim3(tmpc::NT), h->lds_bytes, h->stream, h->d, h->B,
+    hipLaunchKernelGGL(h->kernel, dim3(h->B), dim3(tmpc::NT), h->lds_bytes, h->stream, h->d, h->B,
                        h->xinit, h->x0, h->params, h->xtraj, h->utraj, h->pobj, h->exit_code, h->qp_status,
                        h->sqp_iter, h->res_eq, h->qp_iter, (long long *)nullptr);
     TMPC_HIP_CHECK(h, hipGetLastError());
@@ -1041,7 +1084,7 @@ int tmpc_debug_profile(tmpc_handle *h, int64_t *cycles, int32_t n_phases)
     long long *dp = nullptr;
     const size_t n = (size_t)h->B * tmpc::PH_COUNT;
     TMPC_HIP_CHECK(h, hipMalloc(&dp, n * 8));
-    hipLaunchKernelGGL(tmpc::tmpc_solve_kernel, dim3(h->B), dim3(tmpc::NT), h->lds_bytes, h->stream, h->d, h->B,
+    hipLaunchKernelGGL(h->kernel, dim3(h->B), dim3(tmpc::NT), h->lds_bytes, h->stream, h->d, h->B,
                        h->xinit, h->x0, h->params, h->xtraj, h->utraj, h->pobj, h->exit_code, h->qp_status,
                        h->sqp_iter, h->res_eq, h->qp_iter, dp);
     TMPC_HIP_CHECK(h, hipGetLastError());
