@@ -89,8 +89,10 @@ def main():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ           # under torch.distributed.run the collective path runs even for N=1
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     assert a.gpus == world, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
 
@@ -115,7 +117,7 @@ def main():
     def step():
         sv.solve(sync=False)                                                # the dominant kernel
         sv.pack_records(t_rec.data_ptr(), t_gid.data_ptr())
-        if world > 1:
+        if use_dist:
             sv.synchronize()                                                # records visible to torch's stream
             gathered = D.all_gather_records(t_rec, world)                   # ONE RCCL all-gather, 16 B x B per rank
             torch.cuda.current_stream().synchronize()
@@ -128,7 +130,7 @@ def main():
         step()
     sv.synchronize()
     sv.get_timings()                                                        # drop warm-up timings
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -136,10 +138,10 @@ def main():
         step()
     sv.synchronize()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
@@ -210,7 +212,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(a.cpu_scenes)
         print(json.dumps(out))
     sv.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

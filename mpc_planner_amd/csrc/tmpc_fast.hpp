@@ -20,7 +20,7 @@ struct FastCfg {
 
 __host__ __device__ inline int lds_doubles_fast(int N, int nh)
 {
-    const int persistent = (N + 1) * NV + (N + 1) * NX + (N + 1) * NP28 + (N + 1) * NV + N * NX * NV + N * NX;
+    const int persistent = (N + 1) * NV + (N + 1) * NX + (N + 1) * NP28 + (N + 1) * NV + N * NX * NV + N * NX + N * 8;
     const int work = (N + 1) * NV + (N + 1) * NX + (N + 1) * NP28 + 2 * (N + 1) * NV + N * NX + (N + 1) * NV +
                      (N + 1) * NX + (N + 1) * NX + N * NU + 64;
     const int staging = N * nh * 3 + 2 * N * nh;
@@ -35,7 +35,7 @@ __device__ __forceinline__ Lds carve_fast(double *s, const Dims &d)
     L.NG = N * L.nh; L.GB = L.NG; L.XB = L.NG + 4 * N; L.nrows = L.XB + 10 * (N - 1);
     auto take = [&](int n) { double *p = s; s += n; return p; };
     L.z = take((N + 1) * NV); L.pi = take((N + 1) * NX); L.W = take((N + 1) * NP28); L.g = take((N + 1) * NV);
-    L.BA = take(N * NX * NV); L.b = take(N * NX);
+    L.BA = take(N * NX * NV); L.b = take(N * NX); L.dyn8 = take(N * 8);
     double *w = s;                                      // work region (IPM) ...
     L.v = take((N + 1) * NV); L.pq = take((N + 1) * NX); L.Hh = take((N + 1) * NP28);
     L.rg = take((N + 1) * NV); L.gh = take((N + 1) * NV); L.rb = take(N * NX); L.dv = take((N + 1) * NV);
@@ -70,13 +70,14 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
     const double m_rows = (double)(N * NH + 4 * N + 10 * (N - 1));
 
     // ---- load this lane's rows (signed coefficients) from the staging area into registers ----
-    double c0[RPL], c1[RPL], c2[RPL], cu[RPL], sb[RPL];
-    int var[RPL];
-    unsigned act = 0;
+    // per row: signed coefficients on (x, y, psi), signed rhs; box rows: sign in `upper`, variable index packed 3 bits/slot
+    double c0[RPL], c1[RPL], c2[RPL], sb[RPL];
+    unsigned act = 0, box = 0, upper = 0;
+    unsigned long long varpack = 0;
 #pragma unroll
     for (int s = 0; s < RPL; s++) {
         const int r = c + LPS * s;
-        c0[s] = c1[s] = c2[s] = cu[s] = 0.0; sb[s] = 0.0; var[s] = 0;
+        c0[s] = c1[s] = c2[s] = 0.0; sb[s] = 0.0;
         if (stage_lane && r < NR) {
             if (r < NH) {
                 const double sgn = (r < NLIN) ? -1.0 : 1.0;     // topology rows: upper bound 0; ellipsoids: lower bound 1
@@ -87,17 +88,20 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
             } else {
                 const int q = r - NH;                           // 0..3 inputs, 4..13 states
                 const int vr = q < 4 ? (q >> 1) : (NU + ((q - 4) >> 1));
-                const bool upper = q & 1;
-                const double sgn = upper ? -1.0 : 1.0;
+                const bool up = q & 1;
+                const double sgn = up ? -1.0 : 1.0;
                 double bnd = 0.0;
 #pragma unroll
-                for (int i = 0; i < NV; i++) if (i == vr) bnd = upper ? d.ub[i] : d.lb[i];
-                cu[s] = sgn; var[s] = vr;
+                for (int i = 0; i < NV; i++) if (i == vr) bnd = up ? d.ub[i] : d.lb[i];
+                box |= 1u << s; if (up) upper |= 1u << s;
+                varpack |= (unsigned long long)vr << (3 * s);
                 sb[s] = sgn * (bnd - L.z[k * NV + vr]);
                 if (q < 4 || k >= 1) act |= 1u << s;            // x_0 is fixed, not boxed
             }
         }
     }
+    auto VAR = [&](int s) { return (int)((varpack >> (3 * s)) & 7ull); };
+    auto CU = [&](int s) { return (box >> s & 1) ? ((upper >> s & 1) ? -1.0 : 1.0) : 0.0; };   // signed unit coefficient
     __syncthreads();                                             // staging is dead from here on
     // QP start: dz = 0 except dx_0 = xinit - x_0; duals 0
     for (int e = tid; e < (N + 1) * NV; e += NT) L.v[e] = 0.0;
@@ -111,7 +115,7 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
         const double vx = L.v[kk * NV + ZX], vy = L.v[kk * NV + ZY], vp = L.v[kk * NV + ZPSI];
 #pragma unroll
         for (int s = 0; s < RPL; s++) {
-            const double r0 = c0[s] * vx + c1[s] * vy + c2[s] * vp + cu[s] * L.v[kk * NV + var[s]] - sb[s];
+            const double r0 = c0[s] * vx + c1[s] * vy + c2[s] * vp + CU(s) * L.v[kk * NV + VAR(s)] - sb[s];
             t[s] = r0 > d.thr0 ? r0 : d.thr0;
             invt[s] = 1.0 / t[s];
             lam[s] = (act >> s & 1) ? d.mu0 * invt[s] : 0.0;
@@ -161,8 +165,9 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
 #pragma unroll
             for (int s = 0; s < RPL; s++) {
                 const bool a = act >> s & 1;
-                const double vv = L.v[kk * NV + var[s]];
-                const double r = c0[s] * vx + c1[s] * vy + c2[s] * vp + cu[s] * vv - sb[s] - t[s];
+                const double vv = L.v[kk * NV + VAR(s)];
+                const double cus = CU(s);
+                const double r = c0[s] * vx + c1[s] * vy + c2[s] * vp + cus * vv - sb[s] - t[s];
                 rd[s] = a ? r : 0.0;
                 const double comp = lam[s] * t[s];
                 const double dd = lam[s] * invt[s];
@@ -173,10 +178,11 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
                 const double d0 = dd * c0[s], d1 = dd * c1[s], d2 = dd * c2[s];
                 h00 += d0 * c0[s]; h10 += d1 * c0[s]; h11 += d1 * c1[s];
                 h20 += d2 * c0[s]; h21 += d2 * c1[s]; h22 += d2 * c2[s];
-                if (a && cu[s] != 0.0) {                                  // box row: one variable
-                    lds_add(&L.rg[k * NV + var[s]], -lam[s] * cu[s]);
-                    lds_add(&L.gh[k * NV + var[s]], w * cu[s]);
-                    lds_add(&L.Hh[k * NP28 + pidx(var[s], var[s])], dd);
+                if (a && (box >> s & 1)) {                                // box row: one variable
+                    const int vr = VAR(s);
+                    lds_add(&L.rg[k * NV + vr], -lam[s] * cus);
+                    lds_add(&L.gh[k * NV + vr], w * cus);
+                    lds_add(&L.Hh[k * NP28 + pidx(vr, vr)], dd);
                 }
             }
             if (stage_lane) {
@@ -206,18 +212,18 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
         // ---- predictor: rhs = rg + sum c (lam + d rd)  (q/t = lam) ----
         riccati_solve(L, d, tid);
         pf.stop(PH_SOLVE);
-        double dt_[RPL], dl_[RPL];
+        double dt_[RPL];                                                  // dlam is recomputed from dt where needed
         double amax = 1e300;
         {
             const double dx = L.dv[kk * NV + ZX], dy = L.dv[kk * NV + ZY], dp = L.dv[kk * NV + ZPSI];
 #pragma unroll
             for (int s = 0; s < RPL; s++) {
                 const bool a = act >> s & 1;
-                const double dvv = L.dv[kk * NV + var[s]];
-                const double ddot = c0[s] * dx + c1[s] * dy + c2[s] * dp + cu[s] * dvv;
+                const double dvv = L.dv[kk * NV + VAR(s)];
+                const double ddot = c0[s] * dx + c1[s] * dy + c2[s] * dp + CU(s) * dvv;
                 const double dt = a ? ddot + rd[s] : 0.0;
                 const double dl = a ? -lam[s] - lam[s] * invt[s] * dt : 0.0;
-                dt_[s] = dt; dl_[s] = dl;
+                dt_[s] = dt;
                 if (dt < 0.0) amax = fmin(amax, -t[s] / dt);
                 if (dl < 0.0) amax = fmin(amax, -lam[s] / dl);
             }
@@ -225,7 +231,11 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
         const double a_aff = fmin(1.0, wave_min(amax));
         double mu_aff = 0.0;
 #pragma unroll
-        for (int s = 0; s < RPL; s++) if (act >> s & 1) mu_aff += (lam[s] + a_aff * dl_[s]) * (t[s] + a_aff * dt_[s]);
+        for (int s = 0; s < RPL; s++)
+            if (act >> s & 1) {
+                const double dl = -lam[s] - lam[s] * invt[s] * dt_[s];
+                mu_aff += (lam[s] + a_aff * dl) * (t[s] + a_aff * dt_[s]);
+            }
         mu_aff = wave_sum(mu_aff) / m_rows;
         double sigma = mu > 0.0 ? mu_aff / mu : 0.0;
         sigma = sigma * sigma * sigma;
@@ -237,10 +247,11 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
 #pragma unroll
             for (int s = 0; s < RPL; s++) {
                 const bool a = act >> s & 1;
-                qt[s] = a ? lam[s] + (dt_[s] * dl_[s] - sigma * mu) * invt[s] : 0.0;
+                const double dl = -lam[s] - lam[s] * invt[s] * dt_[s];
+                qt[s] = a ? lam[s] + (dt_[s] * dl - sigma * mu) * invt[s] : 0.0;
                 const double w = qt[s] + lam[s] * invt[s] * rd[s];
                 cs0 += w * c0[s]; cs1 += w * c1[s]; cs2 += w * c2[s];
-                if (a && cu[s] != 0.0) lds_add(&L.gh[k * NV + var[s]], w * cu[s]);
+                if (a && (box >> s & 1)) lds_add(&L.gh[k * NV + VAR(s)], w * CU(s));
             }
             if (stage_lane) { lds_add(&L.gh[k * NV + ZX], cs0); lds_add(&L.gh[k * NV + ZY], cs1); lds_add(&L.gh[k * NV + ZPSI], cs2); }
         }
@@ -254,11 +265,11 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
 #pragma unroll
             for (int s = 0; s < RPL; s++) {
                 const bool a = act >> s & 1;
-                const double dvv = L.dv[kk * NV + var[s]];
-                const double ddot = c0[s] * dx + c1[s] * dy + c2[s] * dp + cu[s] * dvv;
+                const double dvv = L.dv[kk * NV + VAR(s)];
+                const double ddot = c0[s] * dx + c1[s] * dy + c2[s] * dp + CU(s) * dvv;
                 const double dt = a ? ddot + rd[s] : 0.0;
                 const double dl = a ? -qt[s] - lam[s] * invt[s] * dt : 0.0;
-                dt_[s] = dt; dl_[s] = dl;
+                dt_[s] = dt;
                 if (dt < 0.0) amax = fmin(amax, -t[s] / dt);
                 if (dl < 0.0) amax = fmin(amax, -lam[s] / dl);
             }
@@ -270,7 +281,8 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
 #pragma unroll
         for (int s = 0; s < RPL; s++) {
             if (act >> s & 1) {
-                t[s] += alpha * dt_[s]; lam[s] += alpha * dl_[s];
+                const double dl = -qt[s] - lam[s] * invt[s] * dt_[s];
+                t[s] += alpha * dt_[s]; lam[s] += alpha * dl;
                 invt[s] = 1.0 / t[s];
             }
         }
@@ -318,6 +330,19 @@ __global__ __launch_bounds__(NT) void tmpc_solve_fast_kernel(Dims d, int B, cons
         pf.start();
         linearise<true>(L, d, tid, pb);
         __syncthreads();
+#ifdef TMPC_DEBUG_DUMP
+        if (prof_out && it == 1 && b == 0) {
+            double *o = (double *)prof_out + 16;
+            for (int e = tid; e < (N + 1) * NP28; e += NT) o[e] = L.W[e];
+            for (int e = tid; e < N * C::NH; e += NT) o[600 + e] = L.lamh[e];
+            for (int e = tid; e < (N + 1) * NX; e += NT) o[700 + e] = L.pi[e];
+            for (int e = tid; e < N * C::NH; e += NT) o[820 + e] = L.beta[e];
+            for (int e = tid; e < N * NP28; e += NT) o[900 + e] = L.rb[e];
+            for (int e = tid; e < (N + 1) * NV; e += NT) o[1500 + e] = L.z[e];
+            if (tid == 0) { o[1700] = d.reg_eps; o[1701] = d.dt; o[1702] = d.qp_tol; }
+            __syncthreads();
+        }
+#endif
         pf.stop(PH_LIN);
         int iters = 0;
         qp_status = ipm_fast<NLIN, MM, LPS>(L, d, tid, xi, &iters, pf, lam);

@@ -38,6 +38,7 @@ struct Lds {
     double *z, *pi, *W, *g, *BA, *b, *D, *beta;          // NLP iterate + stage blocks of the current QP
     double *t, *lam, *invt, *qt;                         // interior-point rows
     double *v, *pq, *Hh, *rg, *gh, *rb, *dv, *dpi, *pr, *y, *rdiag, *scr;
+    double *dyn8;                                        // 8 non-constant entries of [B A] per stage
     double *lamh;                                        // fast kernel: staged (lam_upper - lam_lower) of the general rows
     int nh, NG, GB, XB, nrows;
 };
@@ -49,7 +50,7 @@ __host__ __device__ inline int lds_doubles(int N, int nh)
     n += (N + 1) * NV + (N + 1) * NX + (N + 1) * NP28 + (N + 1) * NV + N * NX * NV + N * NX + N * nh * 3 + N * nh;
     n += 4 * nrows;
     n += (N + 1) * NV + (N + 1) * NX + (N + 1) * NP28 + 2 * (N + 1) * NV + N * NX + (N + 1) * NV + (N + 1) * NX +
-         (N + 1) * NX + N * NU + N * NU + 64;
+         (N + 1) * NX + N * NU + N * NU + 64 + N * 8;
     return n;
 }
 
@@ -66,7 +67,7 @@ __device__ __forceinline__ Lds carve(double *s, const Dims &d)
     L.v = take((N + 1) * NV); L.pq = take((N + 1) * NX); L.Hh = take((N + 1) * NP28);
     L.rg = take((N + 1) * NV); L.gh = take((N + 1) * NV); L.rb = take(N * NX); L.dv = take((N + 1) * NV);
     L.dpi = take((N + 1) * NX); L.pr = take((N + 1) * NX); L.y = take(N * NU); L.rdiag = take(N * NU);
-    L.scr = take(64);
+    L.scr = take(64); L.dyn8 = take(N * 8);
     L.lamh = nullptr;
     return L;
 }
@@ -150,7 +151,7 @@ __device__ __forceinline__ double rsqrt_nr(double d)
 // next stage's Cholesky factor) in registers f[0..i].  The 7x7 Cholesky runs entirely in registers: pivots
 // and column entries are broadcast with v_readlane, no LDS traffic and no barriers inside the factorisation.
 // In place of Hh_k the "factor block" (28 doubles) is written for the vector solves:
-//   [0..9]  Lxu (5x2, row-major)   [10] L10   [11] 1/L00   [12] 1/L11   [13..27] P_k = Lxx Lxx^T (packed lower 5x5)
+//   [0..9]  Lxu (5x2, row-major)   [10] L10   [11] 1/L00   [12] 1/L11   [13..27] Lxx (packed lower 5x5; P_k = Lxx Lxx^T)
 constexpr int FB_LXU = 0, FB_L10 = 10, FB_R0 = 11, FB_R1 = 12, FB_P = 13;
 
 template <int C0>
@@ -176,68 +177,98 @@ __device__ __forceinline__ bool chol_rows(double (&f)[NV], int lane, double *r0,
     return bad;
 }
 
+// dyn8[k] = (Xa, Xw, Xp, Xv, Ya, Yw, Yp, Yv): the only non-constant entries of [B A] for the unicycle
+// (tmpc_stage.hpp dyn_jacobian); the rest is identity / dt / dt^2/2.
+enum { D8_XA = 0, D8_XW, D8_XP, D8_XV, D8_YA, D8_YW, D8_YP, D8_YV };
+
+// The sweeps below are strictly sequential over stages; to keep LDS latency off the critical path every
+// operand of stage k-1 is (re)loaded into the same registers right after its last use in stage k, so the loads
+// complete underneath the dependent Cholesky / readlane chain of stage k.
 __device__ bool riccati_factor(const Lds &L, const Dims &d, int tid)
 {
     const int N = d.N;
     const int lane = tid;
     const bool rowl = lane < NV;
+    const int ls = rowl ? lane : 0;
     const int i5 = lane - NU;                        // state index of lanes 2..6
+    const double dt = d.dt, hdt2 = 0.5 * d.dt * d.dt;
     bool bad = false;
-    double f[NV];
+    double f[NV], hk[NV], ba[NX], dn[8];
+    auto load_stage = [&](int k) {
+        const double *Hk = L.Hh + k * NP28;
+        const double *BA = L.BA + k * NX * NV;
+#pragma unroll
+        for (int j = 0; j < NV; j++) hk[j] = (rowl && j <= lane) ? Hk[pidx(ls, j <= ls ? j : 0)] : 0.0;
+#pragma unroll
+        for (int m = 0; m < NX; m++) ba[m] = rowl ? BA[m * NV + ls] : 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) dn[q] = L.dyn8[k * 8 + q];
+    };
     // terminal node: Cholesky of the xx-block (rows/cols 2..6)
 #pragma unroll
-    for (int j = 0; j < NV; j++) f[j] = (rowl && j <= lane && j >= NU && lane >= NU) ? L.Hh[N * NP28 + pidx(lane, j)] : 0.0;
+    for (int j = 0; j < NV; j++) f[j] = (rowl && j <= lane && j >= NU && lane >= NU) ? L.Hh[N * NP28 + pidx(ls, j <= ls ? j : 0)] : 0.0;
+    load_stage(N - 1);
     bad |= chol_rows<NU>(f, lane, nullptr, nullptr);
-    __syncthreads();
     for (int k = N - 1; k >= 0; k--) {
-        // broadcast Lp (lower 5x5) of stage k+1 to every lane
+        // broadcast Lp (lower 5x5 of the factor of stage k+1) to every lane
         double Lp[NX][NX];
 #pragma unroll
         for (int m = 0; m < NX; m++)
 #pragma unroll
             for (int l = 0; l <= m; l++) Lp[m][l] = readlane_d(f[NU + l], NU + m);
-        // P_{k+1} = Lp Lp^T, row i5 by lane 2+i5 (own row of Lp is f[2..6], zero above the diagonal)
+        // Lxx of stage k+1 (own row of lanes 2..6) is kept for the vector solves: P_{k+1} = Lxx Lxx^T is never formed
         if (rowl && lane >= NU) {
-            double *Pn = L.Hh + (k + 1) * NP28 + FB_P;
+            double *Ln = L.Hh + (k + 1) * NP28 + FB_P;
+#pragma unroll
+            for (int l = 0; l < NX; l++) if (l <= i5) Ln[i5 * (i5 + 1) / 2 + l] = f[NU + l];
+        }
+        // G = Lp^T [B A] (5 x 7).  Own column densely from ba[]; all columns (wave-uniform) from the sparse [B A]:
+        //   x: e0   y: e1   s: e4   psi: (Xp,Yp,1,0,0)   v: (Xv,Yv,0,1,dt)   a: (Xa,Ya,0,dt,dt^2/2)   w: (Xw,Yw,dt,0,0)
+        // Same operation order as the dense product (zeros skipped, ones exact), i.e. F = Hh + G^T G keeps the
+        // square-root structure (a factor-level perturbation only) -- do not replace by Hh + [B A]^T (P [B A]).
+        double Go[NX];
+#pragma unroll
+        for (int l = 0; l < NX; l++) {
+            double acc = 0.0;
+#pragma unroll
+            for (int m = l; m < NX; m++) acc += Lp[m][l] * ba[m];
+            Go[l] = acc;
+        }
+        const double Xa = dn[D8_XA], Xw = dn[D8_XW], Xp = dn[D8_XP], Xv = dn[D8_XV];
+        const double Ya = dn[D8_YA], Yw = dn[D8_YW], Yp = dn[D8_YP], Yv = dn[D8_YV];
+        double Ga[NX], Gw[NX], Gp[3], Gv[NX];
+        Ga[0] = ((Lp[0][0] * Xa + Lp[1][0] * Ya) + Lp[3][0] * dt) + Lp[4][0] * hdt2;
+        Ga[1] = (Lp[1][1] * Ya + Lp[3][1] * dt) + Lp[4][1] * hdt2;
+        Ga[2] = Lp[3][2] * dt + Lp[4][2] * hdt2;
+        Ga[3] = Lp[3][3] * dt + Lp[4][3] * hdt2;
+        Ga[4] = Lp[4][4] * hdt2;
+        Gw[0] = (Lp[0][0] * Xw + Lp[1][0] * Yw) + Lp[2][0] * dt;
+        Gw[1] = Lp[1][1] * Yw + Lp[2][1] * dt;
+        Gw[2] = Lp[2][2] * dt; Gw[3] = 0.0; Gw[4] = 0.0;
+        Gp[0] = (Lp[0][0] * Xp + Lp[1][0] * Yp) + Lp[2][0];
+        Gp[1] = Lp[1][1] * Yp + Lp[2][1];
+        Gp[2] = Lp[2][2];
+        Gv[0] = ((Lp[0][0] * Xv + Lp[1][0] * Yv) + Lp[3][0]) + Lp[4][0] * dt;
+        Gv[1] = (Lp[1][1] * Yv + Lp[3][1]) + Lp[4][1] * dt;
+        Gv[2] = Lp[3][2] + Lp[4][2] * dt;
+        Gv[3] = Lp[3][3] + Lp[4][3] * dt;
+        Gv[4] = Lp[4][4] * dt;
+        // F row `lane`: F_ij = Hh_ij + sum_l G_l,lane G_l,j
+        {
+            double a0 = hk[ZA], a1 = hk[ZW], a2 = hk[ZX], a3 = hk[ZY], a4 = hk[ZPSI], a5 = hk[ZV], a6 = hk[ZS];
 #pragma unroll
             for (int l = 0; l < NX; l++) {
-                double acc = 0.0;
-#pragma unroll
-                for (int m = 0; m <= l; m++) acc += f[NU + m] * Lp[l][m];
-                if (l <= i5) Pn[i5 * (i5 + 1) / 2 + l] = acc;
+                a0 += Go[l] * Ga[l];
+                if (l < 3) a1 += Go[l] * Gw[l];
+                if (l < 1) a2 += Go[l] * Lp[0][0];
+                if (l < 2) a3 += Go[l] * Lp[1][l];
+                if (l < 3) a4 += Go[l] * Gp[l];
+                a5 += Go[l] * Gv[l];
+                a6 += Go[l] * Lp[4][l];
             }
+            f[ZA] = a0; f[ZW] = a1; f[ZX] = a2; f[ZY] = a3; f[ZPSI] = a4; f[ZV] = a5; f[ZS] = a6;
         }
-        // G column `lane`: G_l = sum_{m >= l} Lp[m][l] BA[m][lane]
-        double G[NX];
-        if (rowl) {
-            const double *BA = L.BA + k * NX * NV;
-            double ba[NX];
-#pragma unroll
-            for (int m = 0; m < NX; m++) ba[m] = BA[m * NV + lane];
-#pragma unroll
-            for (int l = 0; l < NX; l++) {
-                double acc = 0.0;
-#pragma unroll
-                for (int m = l; m < NX; m++) acc += Lp[m][l] * ba[m];
-                G[l] = acc;
-                L.scr[l * 8 + lane] = acc;
-            }
-        }
-        __syncthreads();
-        // F row `lane`
-        if (rowl) {
-            const double *Hk = L.Hh + k * NP28;
-#pragma unroll
-            for (int j = 0; j < NV; j++) {
-                double acc = (j <= lane) ? Hk[pidx(lane, j <= lane ? j : 0)] : 0.0;
-#pragma unroll
-                for (int l = 0; l < NX; l++) acc += G[l] * L.scr[l * 8 + j];
-                f[j] = acc;
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < NV; j++) f[j] = 0.0;
-        }
+        if (k > 0) load_stage(k - 1);                 // operands of the next stage, hidden under the Cholesky
         double r0 = 0.0, r1 = 0.0;
         bad |= chol_rows<0>(f, lane, &r0, &r1);
         if (rowl) {
@@ -245,91 +276,107 @@ __device__ bool riccati_factor(const Lds &L, const Dims &d, int tid)
             if (lane >= NU) { Fb[FB_LXU + 2 * i5] = f[0]; Fb[FB_LXU + 2 * i5 + 1] = f[1]; }
             if (lane == 1) { Fb[FB_L10] = f[0]; Fb[FB_R0] = r0; Fb[FB_R1] = r1; }
         }
-        __syncthreads();
     }
+    __syncthreads();
     return __any(bad);
 }
 
 // ---- square-root Riccati: vector solve (backward + forward), rhs gh / rb -> dv, dpi ------------------
 // Lane j (< 7) = component j of the stage vector [u; x]; the cost-to-go gradient p lives in lanes 2..6.
-// Everything cross-lane goes through v_readlane; LDS only supplies the per-stage operands.
 __device__ void riccati_solve(const Lds &L, const Dims &d, int tid)
 {
     const int N = d.N;
     const int lane = tid;
     const bool rowl = lane < NV, xl = rowl && lane >= NU;
+    const int ls = rowl ? lane : 0;
     const int i5 = xl ? lane - NU : 0;
+    // q_k = P_{k+1} rb_k = Lxx (Lxx^T rb_k) for all stages at once (off the sequential chain); parked in dpi[k+1]
+    for (int it = tid; it < N * NX; it += NT) {
+        const int k = it / NX, i = it - k * NX;
+        const double *Ln = L.Hh + (k + 1) * NP28 + FB_P;
+        const double *r = L.rb + k * NX;
+        double acc = 0.0;
+        for (int l = 0; l <= i; l++) {
+            double tl = 0.0;                                   // (Lxx^T r)_l
+            for (int m = l; m < NX; m++) tl += Ln[m * (m + 1) / 2 + l] * r[m];
+            acc += Ln[i * (i + 1) / 2 + l] * tl;
+        }
+        L.dpi[(k + 1) * NX + i] = acc;
+    }
+    __syncthreads();
     double p = xl ? L.gh[N * NV + lane] : 0.0;          // p_N
     if (xl) L.pr[N * NX + i5] = p;
-    for (int k = N - 1; k >= 0; k--) {
-        const double *Pn = L.Hh + (k + 1) * NP28 + FB_P;
-        const double *Fb = L.Hh + k * NP28;
-        const double *BA = L.BA + k * NX * NV;
-        // Pb = P_{k+1} rb_k + p_{k+1}   (lane 2+i)
-        double Pb = p;
-        if (xl) {
+    {
+        double ghj, ba[NX], r0, l10, r1, lx0, lx1, q;
+        auto load_stage = [&](int k) {
+            const double *Fb = L.Hh + k * NP28;
+            const double *BA = L.BA + k * NX * NV;
+            ghj = rowl ? L.gh[k * NV + ls] : 0.0;
 #pragma unroll
-            for (int l = 0; l < NX; l++) {
-                const int a = i5 >= l ? i5 : l, b = i5 >= l ? l : i5;
-                Pb += Pn[a * (a + 1) / 2 + b] * L.rb[k * NX + l];
-            }
-        }
-        double Pbb[NX];
+            for (int l = 0; l < NX; l++) ba[l] = rowl ? BA[l * NV + ls] : 0.0;
+            r0 = Fb[FB_R0]; l10 = Fb[FB_L10]; r1 = Fb[FB_R1];
+            lx0 = xl ? Fb[FB_LXU + 2 * i5] : 0.0; lx1 = xl ? Fb[FB_LXU + 2 * i5 + 1] : 0.0;
+            q = xl ? L.dpi[(k + 1) * NX + i5] : 0.0;
+        };
+        load_stage(N - 1);
+        for (int k = N - 1; k >= 0; k--) {
+            const double Pb = p + q;                                       // (P_{k+1} rb_k + p_{k+1}), lane 2+i
+            double fj = ghj;
 #pragma unroll
-        for (int l = 0; l < NX; l++) Pbb[l] = readlane_d(Pb, NU + l);
-        // f = gh_k + [B A]^T Pb   (lane j)
-        double fj = 0.0;
-        if (rowl) {
-            fj = L.gh[k * NV + lane];
-#pragma unroll
-            for (int l = 0; l < NX; l++) fj += BA[l * NV + lane] * Pbb[l];
-        }
-        const double f0 = readlane_d(fj, 0), f1 = readlane_d(fj, 1);
-        const double y0 = f0 * Fb[FB_R0];
-        const double y1 = (f1 - Fb[FB_L10] * y0) * Fb[FB_R1];
-        if (lane == 0) { L.y[k * NU] = y0; L.y[k * NU + 1] = y1; }
-        if (xl) {
-            p = fj - Fb[FB_LXU + 2 * i5] * y0 - Fb[FB_LXU + 2 * i5 + 1] * y1;
-            L.pr[k * NX + i5] = p;
+            for (int l = 0; l < NX; l++) fj += ba[l] * readlane_d(Pb, NU + l);
+            const double y0 = readlane_d(fj, 0) * r0;
+            const double y1 = (readlane_d(fj, 1) - l10 * y0) * r1;
+            p = fj - lx0 * y0 - lx1 * y1;
+            if (lane == 0) { L.y[k * NU] = y0; L.y[k * NU + 1] = y1; }
+            if (xl) L.pr[k * NX + i5] = p;
+            if (k > 0) load_stage(k - 1);
         }
     }
     __syncthreads();
-    // forward sweep; dx_0 = 0 (dx lives in lanes 2..6)
-    double dx = 0.0;
-    for (int k = 0; k < N; k++) {
-        const double *Fb = L.Hh + k * NP28;
-        const double *BA = L.BA + k * NX * NV;
-        double dxb[NX];
+    // forward sweep; dx_0 = 0 (dx lives in lanes 2..6).  dx+ = A dx + B du + rb with A = I + E (E: columns psi, v).
+    {
+        double dx = 0.0;
+        double lx0, lx1, y0, y1, r0, l10, r1, e_psi, e_v, b_a, b_w, rbi;
+        auto load_stage = [&](int k) {
+            const double *Fb = L.Hh + k * NP28;
+            const double *BAr = L.BA + k * NX * NV + i5 * NV;              // own row of [B A]
+            lx0 = xl ? Fb[FB_LXU + 2 * i5] : 0.0; lx1 = xl ? Fb[FB_LXU + 2 * i5 + 1] : 0.0;
+            y0 = L.y[k * NU]; y1 = L.y[k * NU + 1];
+            r0 = Fb[FB_R0]; l10 = Fb[FB_L10]; r1 = Fb[FB_R1];
+            e_psi = xl ? BAr[ZPSI] - (lane == ZPSI ? 1.0 : 0.0) : 0.0;
+            e_v = xl ? BAr[ZV] - (lane == ZV ? 1.0 : 0.0) : 0.0;
+            b_a = xl ? BAr[ZA] : 0.0; b_w = xl ? BAr[ZW] : 0.0;
+            rbi = xl ? L.rb[k * NX + i5] : 0.0;
+        };
+        load_stage(0);
+        for (int k = 0; k < N; k++) {
+            // du = -Luu^-T (Lxu^T dx + y): the dot products over lanes 2..6 are reduced with readlanes
+            const double p0 = lx0 * dx, p1 = lx1 * dx;
+            double s0 = y0, s1 = y1;
 #pragma unroll
-        for (int j = 0; j < NX; j++) dxb[j] = readlane_d(dx, NU + j);
-        double r0 = L.y[k * NU], r1 = L.y[k * NU + 1];
-#pragma unroll
-        for (int j = 0; j < NX; j++) { r0 += Fb[FB_LXU + 2 * j] * dxb[j]; r1 += Fb[FB_LXU + 2 * j + 1] * dxb[j]; }
-        const double u1 = -r1 * Fb[FB_R1];
-        const double u0 = (-r0 - Fb[FB_L10] * u1) * Fb[FB_R0];
-        if (rowl) L.dv[k * NV + lane] = lane == 0 ? u0 : (lane == 1 ? u1 : dx);
-        double dxn = 0.0;
-        if (xl) {
-            dxn = L.rb[k * NX + i5] + BA[i5 * NV] * u0 + BA[i5 * NV + 1] * u1;
-#pragma unroll
-            for (int j = 0; j < NX; j++) dxn += BA[i5 * NV + NU + j] * dxb[j];
+            for (int j = 0; j < NX; j++) { s0 += readlane_d(p0, NU + j); s1 += readlane_d(p1, NU + j); }
+            const double u1 = -s1 * r1;
+            const double u0 = (-s0 - l10 * u1) * r0;
+            if (rowl) L.dv[k * NV + lane] = lane == 0 ? u0 : (lane == 1 ? u1 : dx);
+            const double dpsi = readlane_d(dx, ZPSI), dvv = readlane_d(dx, ZV);
+            dx = xl ? dx + e_psi * dpsi + e_v * dvv + b_a * u0 + b_w * u1 + rbi : 0.0;
+            if (k + 1 < N) load_stage(k + 1);
         }
-        dx = dxn;
+        if (rowl) L.dv[N * NV + lane] = xl ? dx : 0.0;
     }
-    if (rowl) L.dv[N * NV + lane] = xl ? dx : 0.0;
     __syncthreads();
     // dpi_k = P_k dx_k + p_k, k = 1..N  (stage-parallel)
     for (int it = tid; it < N * NX; it += NT) {
         const int k = 1 + it / NX, i = it - (k - 1) * NX;
-        const double *Pk = L.Hh + k * NP28 + FB_P;
+        const double *Lk = L.Hh + k * NP28 + FB_P;
         const double *dxk = L.dv + k * NV + NU;
-        double acc = L.pr[k * NX + i];
-#pragma unroll
-        for (int l = 0; l < NX; l++) {
-            const int a = i >= l ? i : l, b = i >= l ? l : i;
-            acc += Pk[a * (a + 1) / 2 + b] * dxk[l];
+        double acc = 0.0;
+        for (int l = 0; l <= i; l++) {
+            double tl = 0.0;                                   // (Lxx^T dx)_l
+            for (int m = l; m < NX; m++) tl += Lk[m * (m + 1) / 2 + l] * dxk[m];
+            acc += Lk[i * (i + 1) / 2 + l] * tl;
         }
-        L.dpi[k * NX + i] = acc;
+        L.dpi[k * NX + i] = acc + L.pr[k * NX + i];
     }
     __syncthreads();
 }
@@ -561,8 +608,11 @@ template <bool FAST>
 __device__ void linearise(const Lds &L, const Dims &d, int tid, const double *params)
 {
     const int N = d.N;
-    if (tid < N) {
-        const int k = tid;
+    // Every lane runs the (register-hungry) stage evaluation with the full EXEC mask -- lanes >= N redo stage N-1 and
+    // simply do not store -- so that no spill/reload of live registers happens under a partial mask.
+    const bool owner = tid < N;
+    const int k = owner ? tid : N - 1;
+    {
         double z[NV];
 #pragma unroll
         for (int i = 0; i < NV; i++) z[i] = L.z[k * NV + i];
@@ -575,24 +625,32 @@ __device__ void linearise(const Lds &L, const Dims &d, int tid, const double *pa
             return -sgn * L.lam[k * nh + r];
         };
         auto sink = [&](int r, const RowOut &ro) {
-            double *Dr = L.D + (k * nh + r) * 3;
-            Dr[0] = ro.gx; Dr[1] = ro.gy; Dr[2] = ro.gp;
-            const double bound = (r < d.n_lin) ? 0.0 : 1.0;
-            L.beta[k * nh + r] = bound - ro.h;
+            if (owner) {
+                double *Dr = L.D + (k * nh + r) * 3;
+                Dr[0] = ro.gx; Dr[1] = ro.gy; Dr[2] = ro.gp;
+                const double bound = (r < d.n_lin) ? 0.0 : 1.0;
+                L.beta[k * nh + r] = bound - ro.h;
+            }
         };
         stage_linearise(d, z, p, 1, L.pi[(k + 1) * NX + 0], L.pi[(k + 1) * NX + 1], lamh, sink, W, g, BA, xn);
         mirror7(W, d.reg_eps);
+        if (owner) {
 #pragma unroll
-        for (int i = 0; i < NV; i++) {
-            L.g[k * NV + i] = g[i];
+            for (int i = 0; i < NV; i++) {
+                L.g[k * NV + i] = g[i];
 #pragma unroll
-            for (int j = 0; j <= i; j++) L.W[k * NP28 + pidx(i, j)] = W[i][j];
+                for (int j = 0; j <= i; j++) L.W[k * NP28 + pidx(i, j)] = W[i][j];
+            }
+#pragma unroll
+            for (int i = 0; i < NX * NV; i++) L.BA[k * NX * NV + i] = BA[i];
+            double *d8 = L.dyn8 + k * 8;
+            d8[D8_XA] = BA[0 * NV + ZA]; d8[D8_XW] = BA[0 * NV + ZW]; d8[D8_XP] = BA[0 * NV + ZPSI]; d8[D8_XV] = BA[0 * NV + ZV];
+            d8[D8_YA] = BA[1 * NV + ZA]; d8[D8_YW] = BA[1 * NV + ZW]; d8[D8_YP] = BA[1 * NV + ZPSI]; d8[D8_YV] = BA[1 * NV + ZV];
+#pragma unroll
+            for (int i = 0; i < NX; i++) L.b[k * NX + i] = xn[i] - L.z[(k + 1) * NV + NU + i];
         }
-#pragma unroll
-        for (int i = 0; i < NX * NV; i++) L.BA[k * NX * NV + i] = BA[i];
-#pragma unroll
-        for (int i = 0; i < NX; i++) L.b[k * NX + i] = xn[i] - L.z[(k + 1) * NV + NU + i];
-    } else if (tid == N) {
+    }
+    if (tid == N) {
         // terminal node: zero cost, no rows: MIRROR(0) = eps I on the state block
         for (int e = 0; e < NP28; e++) L.W[N * NP28 + e] = 0.0;
         for (int i = NU; i < NV; i++) L.W[N * NP28 + pidx(i, i)] = d.reg_eps;
@@ -609,17 +667,19 @@ __device__ void solve_epilogue(const Lds &L, const Dims &d, int tid, int b, cons
     const int N = d.N;
     pf.start();
     double cost = 0.0, res = 0.0;
-    if (tid < N) {
+    {   // full EXEC (lanes >= N redo stage N-1 and discard)
+        const int ks = tid < N ? tid : N - 1;
         double z[NV];
 #pragma unroll
-        for (int i = 0; i < NV; i++) z[i] = L.z[tid * NV + i];
+        for (int i = 0; i < NV; i++) z[i] = L.z[ks * NV + i];
         CostOut co;
-        cost_eval(d, z, pb + (size_t)tid * d.npar, 1, co, false);
-        cost = d.dt * co.val;
+        cost_eval(d, z, pb + (size_t)ks * d.npar, 1, co, false);
         DynOut dy;
         dyn_eval(d, z, dy, false);
+        double r = 0.0;
 #pragma unroll
-        for (int i = 0; i < NX; i++) res = fmax(res, fabs(dy.xn[i] - L.z[(tid + 1) * NV + NU + i]));
+        for (int i = 0; i < NX; i++) r = fmax(r, fabs(dy.xn[i] - L.z[(ks + 1) * NV + NU + i]));
+        if (tid < N) { cost = d.dt * co.val; res = r; }
     }
     if (tid < NX) res = fmax(res, fabs(L.z[NU + tid] - xi[tid]));
     cost = wave_sum(cost); res = wave_max(res);
@@ -1082,8 +1142,13 @@ int tmpc_debug_profile(tmpc_handle *h, int64_t *cycles, int32_t n_phases)
     if (!h || h->B <= 0 || !cycles || n_phases < tmpc::PH_COUNT) return TMPC_ERR_INVALID;
     TMPC_HIP_CHECK(h, hipSetDevice(h->device));
     long long *dp = nullptr;
+#ifdef TMPC_DEBUG_DUMP
+    const size_t n = (size_t)h->B * tmpc::PH_COUNT + 2048;
+#else
     const size_t n = (size_t)h->B * tmpc::PH_COUNT;
+#endif
     TMPC_HIP_CHECK(h, hipMalloc(&dp, n * 8));
+    TMPC_HIP_CHECK(h, hipMemset(dp, 0, n * 8));
     hipLaunchKernelGGL(h->kernel, dim3(h->B), dim3(tmpc::NT), h->lds_bytes, h->stream, h->d, h->B,
                        h->xinit, h->x0, h->params, h->xtraj, h->utraj, h->pobj, h->exit_code, h->qp_status,
                        h->sqp_iter, h->res_eq, h->qp_iter, dp);
@@ -1097,6 +1162,9 @@ int tmpc_debug_profile(tmpc_handle *h, int64_t *cycles, int32_t n_phases)
         for (int b = 0; b < h->B; b++) acc += (double)host[(size_t)b * tmpc::PH_COUNT + i];
         cycles[i] = (int64_t)(acc / h->B);
     }
+#ifdef TMPC_DEBUG_DUMP
+    if (getenv("TMPC_DUMP_FILE")) { FILE *fp = fopen(getenv("TMPC_DUMP_FILE"), "wb"); fwrite(host.data() + 16, 8, 1800, fp); fclose(fp); }
+#endif
     return TMPC_OK;
 }
 

@@ -48,7 +48,7 @@ def all_gather_records(local_records_tensor, world_size):
     RCCL).  Returns [world_size][n_local][2]."""
     import torch
     import torch.distributed as dist
-    if world_size == 1:
+    if world_size == 1 and not (dist.is_available() and dist.is_initialized()):
         return local_records_tensor.unsqueeze(0)
     n = local_records_tensor.shape[0]
     out = torch.empty((world_size * n,) + tuple(local_records_tensor.shape[1:]), dtype=local_records_tensor.dtype,
