@@ -20,10 +20,10 @@ struct FastCfg {
 
 __host__ __device__ inline int lds_doubles_fast(int N, int nh)
 {
-    const int persistent = (N + 1) * NV + (N + 1) * NX + (N + 1) * NP28 + (N + 1) * NV + N * NX * NV + N * NX + N * 8;
+    const int persistent = (N + 1) * NV + (N + 1) * NX + (N + 1) * NP28 + (N + 1) * NV + N * NX * NV + N * NX + N * 8 + (N * nh + 1) * 3;
     const int work = (N + 1) * NV + (N + 1) * NX + (N + 1) * NP28 + 2 * (N + 1) * NV + N * NX + (N + 1) * NV +
                      (N + 1) * NX + (N + 1) * NX + N * NU + 64;
-    const int staging = N * nh * 3 + 2 * N * nh;
+    const int staging = 2 * N * nh;
     return persistent + (work > staging ? work : staging);
 }
 
@@ -36,12 +36,13 @@ __device__ __forceinline__ Lds carve_fast(double *s, const Dims &d)
     auto take = [&](int n) { double *p = s; s += n; return p; };
     L.z = take((N + 1) * NV); L.pi = take((N + 1) * NX); L.W = take((N + 1) * NP28); L.g = take((N + 1) * NV);
     L.BA = take(N * NX * NV); L.b = take(N * NX); L.dyn8 = take(N * 8);
+    L.D = take((N * L.nh + 1) * 3);                    // rows' Jacobians stay resident (+ one zero triple for box rows)
     double *w = s;                                      // work region (IPM) ...
     L.v = take((N + 1) * NV); L.pq = take((N + 1) * NX); L.Hh = take((N + 1) * NP28);
     L.rg = take((N + 1) * NV); L.gh = take((N + 1) * NV); L.rb = take(N * NX); L.dv = take((N + 1) * NV);
     L.dpi = take((N + 1) * NX); L.pr = take((N + 1) * NX); L.y = take(N * NU); L.scr = take(64);
     s = w;                                              // ... aliased by the staging region (linearisation <-> IPM)
-    L.D = take(N * L.nh * 3); L.beta = take(N * L.nh); L.lamh = take(N * L.nh);
+    L.beta = take(N * L.nh); L.lamh = take(N * L.nh);
     L.t = L.lam = L.invt = L.qt = L.rdiag = nullptr;
     return L;
 }
@@ -64,25 +65,30 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
     using C = FastCfg<NLIN, MM, LPS>;
     constexpr int NH = C::NH, NR = C::NR, RPL = C::RPL;
     const int N = d.N;
-    const int k = tid / LPS, c = tid - k * LPS;
+    // Opaque copy of the lane id: keeps the compiler from hoisting this QP's per-row setup (masks, LDS addresses) out of
+    // the RTI loop of the caller, where it would stay live across the register-hungry linearisation and be spilled.
+    int tid_q = tid;
+    asm volatile("" : "+v"(tid_q));
+    const int k = tid_q / LPS, c = tid_q - k * LPS;
     const bool stage_lane = k < N;
     const int kk = stage_lane ? k : 0;
     const double m_rows = (double)(N * NH + 4 * N + 10 * (N - 1));
 
     // ---- load this lane's rows (signed coefficients) from the staging area into registers ----
     // per row: signed coefficients on (x, y, psi), signed rhs; box rows: sign in `upper`, variable index packed 3 bits/slot
-    double c0[RPL], c1[RPL], c2[RPL], sb[RPL];
-    unsigned act = 0, box = 0, upper = 0;
+    double sb[RPL];
+    int didx[RPL];                                  // row's Jacobian triple in L.D (box rows: the zero triple)
+    unsigned act = 0, box = 0, upper = 0, neg = 0;  // neg: row sign is -1 (upper-bounded rows)
     unsigned long long varpack = 0;
 #pragma unroll
     for (int s = 0; s < RPL; s++) {
         const int r = c + LPS * s;
-        c0[s] = c1[s] = c2[s] = 0.0; sb[s] = 0.0;
+        sb[s] = 0.0; didx[s] = N * NH * 3;
         if (stage_lane && r < NR) {
             if (r < NH) {
                 const double sgn = (r < NLIN) ? -1.0 : 1.0;     // topology rows: upper bound 0; ellipsoids: lower bound 1
-                const double *Dr = L.D + (k * NH + r) * 3;
-                c0[s] = sgn * Dr[0]; c1[s] = sgn * Dr[1]; c2[s] = sgn * Dr[2];
+                didx[s] = (k * NH + r) * 3;
+                if (r < NLIN) neg |= 1u << s;
                 sb[s] = sgn * L.beta[k * NH + r];
                 act |= 1u << s;
             } else {
@@ -93,7 +99,7 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
                 double bnd = 0.0;
 #pragma unroll
                 for (int i = 0; i < NV; i++) if (i == vr) bnd = up ? d.ub[i] : d.lb[i];
-                box |= 1u << s; if (up) upper |= 1u << s;
+                box |= 1u << s; if (up) { upper |= 1u << s; neg |= 1u << s; }
                 varpack |= (unsigned long long)vr << (3 * s);
                 sb[s] = sgn * (bnd - L.z[k * NV + vr]);
                 if (q < 4 || k >= 1) act |= 1u << s;            // x_0 is fixed, not boxed
@@ -101,6 +107,9 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
         }
     }
     auto VAR = [&](int s) { return (int)((varpack >> (3 * s)) & 7ull); };
+    // signed Jacobian of row s (general rows: +-D from LDS; box rows: zero triple)
+#define ROW_C(s) const double sg_ = (neg >> (s) & 1) ? -1.0 : 1.0; const double *Dr_ = L.D + didx[s]; \
+    const double c0s = sg_ * Dr_[0], c1s = sg_ * Dr_[1], c2s = sg_ * Dr_[2];
     auto CU = [&](int s) { return (box >> s & 1) ? ((upper >> s & 1) ? -1.0 : 1.0) : 0.0; };   // signed unit coefficient
     __syncthreads();                                             // staging is dead from here on
     // QP start: dz = 0 except dx_0 = xinit - x_0; duals 0
@@ -115,7 +124,8 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
         const double vx = L.v[kk * NV + ZX], vy = L.v[kk * NV + ZY], vp = L.v[kk * NV + ZPSI];
 #pragma unroll
         for (int s = 0; s < RPL; s++) {
-            const double r0 = c0[s] * vx + c1[s] * vy + c2[s] * vp + CU(s) * L.v[kk * NV + VAR(s)] - sb[s];
+            ROW_C(s)
+            const double r0 = c0s * vx + c1s * vy + c2s * vp + CU(s) * L.v[kk * NV + VAR(s)] - sb[s];
             t[s] = r0 > d.thr0 ? r0 : d.thr0;
             invt[s] = 1.0 / t[s];
             lam[s] = (act >> s & 1) ? d.mu0 * invt[s] : 0.0;
@@ -125,8 +135,10 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
     int status = 2, iters = 0;
     for (int it = 0;; it++) {
         pf.start();
+        int tl = tid;                                    // per-iteration opaque lane id: per-lane addresses of the item loops and
+        asm volatile("" : "+v"(tl));                   // sweeps are recomputed, not kept live (and spilled) across the whole solve
         // ---- stage parts of the residuals: rg0 = g + W v + [B A]^T pi_{k+1} - [0; pi_k];  rb;  Hh <- W ----
-        for (int e = tid; e < (N + 1) * NV; e += NT) {
+        for (int e = tl; e < (N + 1) * NV; e += NT) {
             const int ks = e / NV, i = e - ks * NV;
             double acc = 0.0;
             const bool skip = (ks == N && i < NU) || (ks == 0 && i >= NU);
@@ -145,7 +157,7 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
             L.rg[e] = acc; L.gh[e] = acc;
         }
         double res_b = 0.0;
-        for (int e = tid; e < N * NX; e += NT) {
+        for (int e = tl; e < N * NX; e += NT) {
             const int ks = e / NX, i = e - ks * NX;
             double acc = L.b[e] - L.v[(ks + 1) * NV + NU + i];
             const double *BA = L.BA + ks * NX * NV + i * NV; const double *vk = L.v + ks * NV;
@@ -154,7 +166,7 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
             L.rb[e] = acc;
             res_b = fmax(res_b, fabs(acc));
         }
-        for (int e = tid; e < (N + 1) * NP28; e += NT) L.Hh[e] = L.W[e];
+        for (int e = tl; e < (N + 1) * NP28; e += NT) L.Hh[e] = L.W[e];
         __syncthreads();
         // ---- row pass R (registers): residuals, rg -= lam c, Hh += d c c^T, gh += d rd c ----
         double res_d = 0.0, res_m = 0.0, mu = 0.0;
@@ -167,23 +179,25 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
                 const bool a = act >> s & 1;
                 const double vv = L.v[kk * NV + VAR(s)];
                 const double cus = CU(s);
-                const double r = c0[s] * vx + c1[s] * vy + c2[s] * vp + cus * vv - sb[s] - t[s];
+                ROW_C(s)
+                const double r = c0s * vx + c1s * vy + c2s * vp + cus * vv - sb[s] - t[s];
                 rd[s] = a ? r : 0.0;
                 const double comp = lam[s] * t[s];
                 const double dd = lam[s] * invt[s];
                 const double w = dd * rd[s];
                 if (a) { res_d = fmax(res_d, fabs(r)); res_m = fmax(res_m, comp); mu += comp; }
-                gs0 += lam[s] * c0[s]; gs1 += lam[s] * c1[s]; gs2 += lam[s] * c2[s];
-                rs0 += w * c0[s]; rs1 += w * c1[s]; rs2 += w * c2[s];
-                const double d0 = dd * c0[s], d1 = dd * c1[s], d2 = dd * c2[s];
-                h00 += d0 * c0[s]; h10 += d1 * c0[s]; h11 += d1 * c1[s];
-                h20 += d2 * c0[s]; h21 += d2 * c1[s]; h22 += d2 * c2[s];
+                gs0 += lam[s] * c0s; gs1 += lam[s] * c1s; gs2 += lam[s] * c2s;
+                rs0 += w * c0s; rs1 += w * c1s; rs2 += w * c2s;
+                const double d0 = dd * c0s, d1 = dd * c1s, d2 = dd * c2s;
+                h00 += d0 * c0s; h10 += d1 * c0s; h11 += d1 * c1s;
+                h20 += d2 * c0s; h21 += d2 * c1s; h22 += d2 * c2s;
                 if (a && (box >> s & 1)) {                                // box row: one variable
                     const int vr = VAR(s);
                     lds_add(&L.rg[k * NV + vr], -lam[s] * cus);
                     lds_add(&L.gh[k * NV + vr], w * cus);
                     lds_add(&L.Hh[k * NP28 + pidx(vr, vr)], dd);
                 }
+                __builtin_amdgcn_sched_barrier(0);             // one row at a time: keeps the unrolled pass from piling up live values
             }
             if (stage_lane) {
                 lds_add(&L.rg[k * NV + ZX], -gs0); lds_add(&L.rg[k * NV + ZY], -gs1); lds_add(&L.rg[k * NV + ZPSI], -gs2);
@@ -196,7 +210,7 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
         __syncthreads();
         // now rg = rg0 - sum lam c (residual) and gh = rg0 + sum d rd c (predictor rhs, q/t = lam)
         double res_g = 0.0;
-        for (int e = tid; e < (N + 1) * NV; e += NT)
+        for (int e = tl; e < (N + 1) * NV; e += NT)
             if (!(e >= NU && e < NV)) res_g = fmax(res_g, fabs(L.rg[e]));      // dx_0 is fixed: its stationarity row is not a residual
         res_g = wave_max(res_g); res_b = wave_max(res_b); res_d = wave_max(res_d); res_m = wave_max(res_m);
         mu = wave_sum(mu) / m_rows;
@@ -206,11 +220,11 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
         if (it >= d.qp_iter_max) { status = 2; break; }
         iters = it + 1;
 
-        const bool fbad = riccati_factor(L, d, tid);
+        const bool fbad = riccati_factor(L, d, tl);
         pf.stop(PH_FACTOR);
         if (fbad) { status = 4; break; }
         // ---- predictor: rhs = rg + sum c (lam + d rd)  (q/t = lam) ----
-        riccati_solve(L, d, tid);
+        riccati_solve(L, d, tl);
         pf.stop(PH_SOLVE);
         double dt_[RPL];                                                  // dlam is recomputed from dt where needed
         double amax = 1e300;
@@ -220,12 +234,14 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
             for (int s = 0; s < RPL; s++) {
                 const bool a = act >> s & 1;
                 const double dvv = L.dv[kk * NV + VAR(s)];
-                const double ddot = c0[s] * dx + c1[s] * dy + c2[s] * dp + CU(s) * dvv;
+                ROW_C(s)
+                const double ddot = c0s * dx + c1s * dy + c2s * dp + CU(s) * dvv;
                 const double dt = a ? ddot + rd[s] : 0.0;
                 const double dl = a ? -lam[s] - lam[s] * invt[s] * dt : 0.0;
                 dt_[s] = dt;
                 if (dt < 0.0) amax = fmin(amax, -t[s] / dt);
                 if (dl < 0.0) amax = fmin(amax, -lam[s] / dl);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         const double a_aff = fmin(1.0, wave_min(amax));
@@ -240,7 +256,7 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
         double sigma = mu > 0.0 ? mu_aff / mu : 0.0;
         sigma = sigma * sigma * sigma;
         // ---- corrector rhs: gh = rg + sum c (qt + d rd) ----
-        for (int e = tid; e < (N + 1) * NV; e += NT) L.gh[e] = L.rg[e];
+        for (int e = tl; e < (N + 1) * NV; e += NT) L.gh[e] = L.rg[e];
         __syncthreads();
         {
             double cs0 = 0, cs1 = 0, cs2 = 0;
@@ -250,14 +266,16 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
                 const double dl = -lam[s] - lam[s] * invt[s] * dt_[s];
                 qt[s] = a ? lam[s] + (dt_[s] * dl - sigma * mu) * invt[s] : 0.0;
                 const double w = qt[s] + lam[s] * invt[s] * rd[s];
-                cs0 += w * c0[s]; cs1 += w * c1[s]; cs2 += w * c2[s];
+                ROW_C(s)
+                cs0 += w * c0s; cs1 += w * c1s; cs2 += w * c2s;
                 if (a && (box >> s & 1)) lds_add(&L.gh[k * NV + VAR(s)], w * CU(s));
+                __builtin_amdgcn_sched_barrier(0);
             }
             if (stage_lane) { lds_add(&L.gh[k * NV + ZX], cs0); lds_add(&L.gh[k * NV + ZY], cs1); lds_add(&L.gh[k * NV + ZPSI], cs2); }
         }
         __syncthreads();
         pf.stop(PH_RHS);
-        riccati_solve(L, d, tid);
+        riccati_solve(L, d, tl);
         pf.stop(PH_SOLVE);
         amax = 1e300;
         {
@@ -266,12 +284,14 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
             for (int s = 0; s < RPL; s++) {
                 const bool a = act >> s & 1;
                 const double dvv = L.dv[kk * NV + VAR(s)];
-                const double ddot = c0[s] * dx + c1[s] * dy + c2[s] * dp + CU(s) * dvv;
+                ROW_C(s)
+                const double ddot = c0s * dx + c1s * dy + c2s * dp + CU(s) * dvv;
                 const double dt = a ? ddot + rd[s] : 0.0;
                 const double dl = a ? -qt[s] - lam[s] * invt[s] * dt : 0.0;
                 dt_[s] = dt;
                 if (dt < 0.0) amax = fmin(amax, -t[s] / dt);
                 if (dl < 0.0) amax = fmin(amax, -lam[s] / dl);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         const double alpha = fmin(1.0, 0.995 * wave_min(amax));
@@ -286,8 +306,8 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
                 invt[s] = 1.0 / t[s];
             }
         }
-        for (int e = tid; e < (N + 1) * NV; e += NT) L.v[e] += alpha * L.dv[e];
-        for (int e = tid; e < N * NX; e += NT) L.pq[NX + e] += alpha * L.dpi[NX + e];
+        for (int e = tl; e < (N + 1) * NV; e += NT) L.v[e] += alpha * L.dv[e];
+        for (int e = tl; e < N * NX; e += NT) L.pq[NX + e] += alpha * L.dpi[NX + e];
         __syncthreads();
         pf.stop(PH_UPDATE);
     }
@@ -312,11 +332,11 @@ __global__ __launch_bounds__(NT) void tmpc_solve_fast_kernel(Dims d, int B, cons
     const int N = d.N;
     const double *xi = xinit + (size_t)b * NX;
     const double *pb = params + (size_t)b * N * d.npar;
-    const int k = tid / LPS, c = tid - k * LPS;
 
     for (int e = tid; e < (N + 1) * NV; e += NT) L.z[e] = x0[(size_t)b * (N + 1) * NV + e];
     for (int e = tid; e < (N + 1) * NX; e += NT) L.pi[e] = 0.0;
     for (int e = tid; e < N * C::NH; e += NT) L.lamh[e] = 0.0;
+    if (tid < 3) L.D[N * C::NH * 3 + tid] = 0.0;      // zero triple read by box rows
     __syncthreads();
     if (tid < NU) L.z[N * NV + tid] = 0.0;
     __syncthreads();
@@ -330,19 +350,6 @@ __global__ __launch_bounds__(NT) void tmpc_solve_fast_kernel(Dims d, int B, cons
         pf.start();
         linearise<true>(L, d, tid, pb);
         __syncthreads();
-#ifdef TMPC_DEBUG_DUMP
-        if (prof_out && it == 1 && b == 0) {
-            double *o = (double *)prof_out + 16;
-            for (int e = tid; e < (N + 1) * NP28; e += NT) o[e] = L.W[e];
-            for (int e = tid; e < N * C::NH; e += NT) o[600 + e] = L.lamh[e];
-            for (int e = tid; e < (N + 1) * NX; e += NT) o[700 + e] = L.pi[e];
-            for (int e = tid; e < N * C::NH; e += NT) o[820 + e] = L.beta[e];
-            for (int e = tid; e < N * NP28; e += NT) o[900 + e] = L.rb[e];
-            for (int e = tid; e < (N + 1) * NV; e += NT) o[1500 + e] = L.z[e];
-            if (tid == 0) { o[1700] = d.reg_eps; o[1701] = d.dt; o[1702] = d.qp_tol; }
-            __syncthreads();
-        }
-#endif
         pf.stop(PH_LIN);
         int iters = 0;
         qp_status = ipm_fast<NLIN, MM, LPS>(L, d, tid, xi, &iters, pf, lam);
@@ -357,6 +364,9 @@ __global__ __launch_bounds__(NT) void tmpc_solve_fast_kernel(Dims d, int B, cons
         for (int e = tid; e < N * NX; e += NT) L.pi[NX + e] = L.pq[NX + e];
         __syncthreads();
         // multipliers of the general rows for the next linearisation: (lam_upper - lam_lower) = -sgn lam
+        int tid_w = tid;
+        asm volatile("" : "+v"(tid_w));                   // opaque (see ipm_fast): keeps these addresses out of the prologue
+        const int k = tid_w / LPS, c = tid_w - k * LPS;
         if (k < N) {
 #pragma unroll
             for (int s = 0; s < C::RPL; s++) {

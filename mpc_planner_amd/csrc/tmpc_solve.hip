@@ -290,18 +290,30 @@ __device__ void riccati_solve(const Lds &L, const Dims &d, int tid)
     const bool rowl = lane < NV, xl = rowl && lane >= NU;
     const int ls = rowl ? lane : 0;
     const int i5 = xl ? lane - NU : 0;
-    // q_k = P_{k+1} rb_k = Lxx (Lxx^T rb_k) for all stages at once (off the sequential chain); parked in dpi[k+1]
-    for (int it = tid; it < N * NX; it += NT) {
-        const int k = it / NX, i = it - k * NX;
+    // q_k = P_{k+1} rb_k = Lxx (Lxx^T rb_k) for all stages at once (off the sequential chain); parked in dpi[k+1].
+    // One lane per stage, fully unrolled (30 FMAs for the 5 components).
+    for (int k = tid; k < N; k += NT) {
         const double *Ln = L.Hh + (k + 1) * NP28 + FB_P;
         const double *r = L.rb + k * NX;
-        double acc = 0.0;
-        for (int l = 0; l <= i; l++) {
-            double tl = 0.0;                                   // (Lxx^T r)_l
-            for (int m = l; m < NX; m++) tl += Ln[m * (m + 1) / 2 + l] * r[m];
-            acc += Ln[i * (i + 1) / 2 + l] * tl;
+        double ll[15], rr[NX], tl[NX];
+#pragma unroll
+        for (int e = 0; e < 15; e++) ll[e] = Ln[e];
+#pragma unroll
+        for (int m = 0; m < NX; m++) rr[m] = r[m];
+#pragma unroll
+        for (int l = 0; l < NX; l++) {
+            double acc = 0.0;
+#pragma unroll
+            for (int m = l; m < NX; m++) acc += ll[m * (m + 1) / 2 + l] * rr[m];
+            tl[l] = acc;
         }
-        L.dpi[(k + 1) * NX + i] = acc;
+#pragma unroll
+        for (int i = 0; i < NX; i++) {
+            double acc = 0.0;
+#pragma unroll
+            for (int l = 0; l <= i; l++) acc += ll[i * (i + 1) / 2 + l] * tl[l];
+            L.dpi[(k + 1) * NX + i] = acc;
+        }
     }
     __syncthreads();
     double p = xl ? L.gh[N * NV + lane] : 0.0;          // p_N
@@ -365,18 +377,30 @@ __device__ void riccati_solve(const Lds &L, const Dims &d, int tid)
         if (rowl) L.dv[N * NV + lane] = xl ? dx : 0.0;
     }
     __syncthreads();
-    // dpi_k = P_k dx_k + p_k, k = 1..N  (stage-parallel)
-    for (int it = tid; it < N * NX; it += NT) {
-        const int k = 1 + it / NX, i = it - (k - 1) * NX;
+    // dpi_k = P_k dx_k + p_k = Lxx (Lxx^T dx_k) + p_k, k = 1..N  (one lane per stage, unrolled)
+    for (int kk = tid; kk < N; kk += NT) {
+        const int k = kk + 1;
         const double *Lk = L.Hh + k * NP28 + FB_P;
         const double *dxk = L.dv + k * NV + NU;
-        double acc = 0.0;
-        for (int l = 0; l <= i; l++) {
-            double tl = 0.0;                                   // (Lxx^T dx)_l
-            for (int m = l; m < NX; m++) tl += Lk[m * (m + 1) / 2 + l] * dxk[m];
-            acc += Lk[i * (i + 1) / 2 + l] * tl;
+        double ll[15], rr[NX], tl[NX];
+#pragma unroll
+        for (int e = 0; e < 15; e++) ll[e] = Lk[e];
+#pragma unroll
+        for (int m = 0; m < NX; m++) rr[m] = dxk[m];
+#pragma unroll
+        for (int l = 0; l < NX; l++) {
+            double acc = 0.0;
+#pragma unroll
+            for (int m = l; m < NX; m++) acc += ll[m * (m + 1) / 2 + l] * rr[m];
+            tl[l] = acc;
         }
-        L.dpi[k * NX + i] = acc + L.pr[k * NX + i];
+#pragma unroll
+        for (int i = 0; i < NX; i++) {
+            double acc = 0.0;
+#pragma unroll
+            for (int l = 0; l <= i; l++) acc += ll[i * (i + 1) / 2 + l] * tl[l];
+            L.dpi[k * NX + i] = acc + L.pr[k * NX + i];
+        }
     }
     __syncthreads();
 }
@@ -610,8 +634,10 @@ __device__ void linearise(const Lds &L, const Dims &d, int tid, const double *pa
     const int N = d.N;
     // Every lane runs the (register-hungry) stage evaluation with the full EXEC mask -- lanes >= N redo stage N-1 and
     // simply do not store -- so that no spill/reload of live registers happens under a partial mask.
-    const bool owner = tid < N;
-    const int k = owner ? tid : N - 1;
+    int tid_l = tid;
+    asm volatile("" : "+v"(tid_l));                       // opaque: no hoisting of per-stage addresses out of the RTI loop
+    const bool owner = tid_l < N;
+    const int k = owner ? tid_l : N - 1;
     {
         double z[NV];
 #pragma unroll
@@ -633,14 +659,10 @@ __device__ void linearise(const Lds &L, const Dims &d, int tid, const double *pa
             }
         };
         stage_linearise(d, z, p, 1, L.pi[(k + 1) * NX + 0], L.pi[(k + 1) * NX + 1], lamh, sink, W, g, BA, xn);
-        mirror7(W, d.reg_eps);
+        // everything but W leaves the registers BEFORE the register-hungry MIRROR
         if (owner) {
 #pragma unroll
-            for (int i = 0; i < NV; i++) {
-                L.g[k * NV + i] = g[i];
-#pragma unroll
-                for (int j = 0; j <= i; j++) L.W[k * NP28 + pidx(i, j)] = W[i][j];
-            }
+            for (int i = 0; i < NV; i++) L.g[k * NV + i] = g[i];
 #pragma unroll
             for (int i = 0; i < NX * NV; i++) L.BA[k * NX * NV + i] = BA[i];
             double *d8 = L.dyn8 + k * 8;
@@ -648,6 +670,13 @@ __device__ void linearise(const Lds &L, const Dims &d, int tid, const double *pa
             d8[D8_YA] = BA[1 * NV + ZA]; d8[D8_YW] = BA[1 * NV + ZW]; d8[D8_YP] = BA[1 * NV + ZPSI]; d8[D8_YV] = BA[1 * NV + ZV];
 #pragma unroll
             for (int i = 0; i < NX; i++) L.b[k * NX + i] = xn[i] - L.z[(k + 1) * NV + NU + i];
+        }
+        mirror7(W, d.reg_eps);
+        if (owner) {
+#pragma unroll
+            for (int i = 0; i < NV; i++)
+#pragma unroll
+                for (int j = 0; j <= i; j++) L.W[k * NP28 + pidx(i, j)] = W[i][j];
         }
     }
     if (tid == N) {
@@ -668,7 +697,9 @@ __device__ void solve_epilogue(const Lds &L, const Dims &d, int tid, int b, cons
     pf.start();
     double cost = 0.0, res = 0.0;
     {   // full EXEC (lanes >= N redo stage N-1 and discard)
-        const int ks = tid < N ? tid : N - 1;
+        int tid_e = tid;
+        asm volatile("" : "+v"(tid_e));
+        const int ks = tid_e < N ? tid_e : N - 1;
         double z[NV];
 #pragma unroll
         for (int i = 0; i < NV; i++) z[i] = L.z[ks * NV + i];
@@ -874,6 +905,10 @@ namespace tmpc {
 typedef void (*SolveKernel)(Dims, int, const double *, const double *, const double *, double *, double *, double *, int *,
                             int *, int *, double *, int *, long long *);
 // Registered fast shapes (n_lin, M) x lanes-per-stage; anything else runs the generic kernel.
+// Only instantiations that compile WITHOUT scratch (zero VGPR spills) are registered: __graft_entry__.build() checks
+// the compiler's resource remarks and fails otherwise.  Reason: with > ~100 spilled VGPRs this kernel was observed to
+// return wrong iterates (spill/reload around partially-masked regions), see DESIGN.md section 5.  Shapes with more rows
+// per lane ((12,12) at 3 lanes/stage, (8,8) at 2 lanes/stage for N > 21) therefore use the generic kernel for now.
 static SolveKernel pick_fast_kernel(const Dims &d)
 {
     if (getenv("TMPC_FORCE_GENERIC")) return nullptr;
@@ -881,10 +916,8 @@ static SolveKernel pick_fast_kernel(const Dims &d)
     if (lps == 3) {
         if (d.n_lin == 0 && d.M == 4) return tmpc_solve_fast_kernel<0, 4, 3>;
         if (d.n_lin == 8 && d.M == 8) return tmpc_solve_fast_kernel<8, 8, 3>;
-        if (d.n_lin == 12 && d.M == 12) return tmpc_solve_fast_kernel<12, 12, 3>;
     } else if (lps == 2) {
         if (d.n_lin == 0 && d.M == 4) return tmpc_solve_fast_kernel<0, 4, 2>;
-        if (d.n_lin == 8 && d.M == 8) return tmpc_solve_fast_kernel<8, 8, 2>;
     }
     return nullptr;
 }
