@@ -129,11 +129,29 @@ int tmpc_get_timings(tmpc_handle *h, float *ms, int32_t capacity, int32_t *n_out
  * events recorded on THAT stream, and returns the per-launch kernel durations in milliseconds. */
 int tmpc_time_solve(tmpc_handle *h, int32_t reps, float *ms_each);
 
+/* ---- next row f-1: LinearizedConstraints::update + setParameters on device -----------------------------------
+ * For every trajectory b of the current batch, stage k = 1..N-1 and obstacle j < n_lin: project the guess position
+ * x0[b][k].(x,y) out of the discs of radius (1e-3 + robot_radius) around the obstacle predictions (<= 3 sweeps,
+ * LinearizedConstraints::projectToSafety, linearized_constraints.cpp:130-148 -- the Douglas-Rachford operator of
+ * ros_tools is not in the reference tree; a radial projection is used, identity for collision-free guesses), then
+ * a = (o - p)/|o - p|, b = a.o - (1e-3 + robot_radius) (:84-105, guidance mode) and write lin_constraint_j_{a1,a2,b}
+ * into params[b][k]; stage 0 and the rows of non-guided planners get the dummies (1, 0, state_x + 100) (:155-166,
+ * guidance_constraints.cpp:301-305).  The batch's params buffer is modified IN PLACE (device memory).
+ *   d_obstacle_pos : f64 [n_scenes][n_lin][N][2]   prediction step i of obstacle j (stage k uses step k-1)
+ *   d_scene_of     : i32 [B]                       scene of trajectory b
+ *   d_state_x      : f64 [n_scenes]                current state x (for the dummy b)
+ *   d_is_original  : u8  [B] or NULL               1 = non-guided T-MPC++ planner (all rows dummy) */
+int tmpc_linearize_topology(tmpc_handle *h, const void *d_obstacle_pos, const void *d_scene_of, const void *d_state_x,
+                            double robot_radius, const void *d_is_original);
+
 /* ---- test/debug entry points (used by tests/ to diff per-phase tensors against the oracle) -------- */
 /* Evaluate the stage functions on device for n points: z[n][7], p[n][npar] (host pointers).
  * Outputs (host, may be NULL): cost[n], cost_grad[n][7], cost_hess[n][49], h[n][nh], h_jac[n][nh][7],
  * x_next[n][5], x_jac[n][5][7]; lag_hess[n][49] = dt*hess(l) + sum_j pi[j] hess(x_next_j) +
  * sum_r lamh[r] hess(h_r) (pi[n][5], lamh[n][nh] host inputs, NULL = zeros); mirror[n][49] = MIRROR(lag_hess). */
+/* Copy the batch's (possibly device-modified) parameter tensor back: params[B][N*npar] host pointer. */
+int tmpc_debug_get_params(tmpc_handle *h, double *params);
+
 /* Mean shader-clock cycles per phase over the batch (one extra instrumented solve).  cycles[10]:
  * linearise, residuals, barrier Hessian, Riccati factor, rhs build, Riccati solve, row passes, update, final, total. */
 int tmpc_debug_profile(tmpc_handle *h, int64_t *cycles, int32_t n_phases);

@@ -859,6 +859,49 @@ __global__ void tmpc_select_best_records_kernel(const tmpc_record *rec, int n_ra
     if (threadIdx.x == 0) best_out[s] = idx;
 }
 
+// ---- f-1: LinearizedConstraints::update + setParameters on device (linearized_constraints.cpp:49-189) ----------
+// one thread per (trajectory, stage)
+__global__ void tmpc_linearize_topology_kernel(Dims d, int B, const double *x0, double *params, const double *obst,
+                                               const int *scene_of, const double *state_x, double robot_radius,
+                                               const uint8_t *is_original)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int N = d.N;
+    if (e >= B * N) return;
+    const int b = e / N, k = e - b * N;
+    const int sc = scene_of[b];
+    double *p = params + ((size_t)b * N + k) * d.npar;
+    const double dummy_b = state_x[sc] + 100.0;                         // _dummy_b (:54)
+    const bool dummy = (k == 0) || (is_original && is_original[b]);
+    const double r = 1e-3 + robot_radius;                               // guidance mode radius (:99)
+    double px = x0[((size_t)b * (N + 1) + k) * NV + ZX], py = x0[((size_t)b * (N + 1) + k) * NV + ZY];
+    const double *ob = obst + (size_t)sc * d.n_lin * N * 2;
+    if (!dummy) {
+        for (int sweep = 0; sweep < 3; sweep++)                         // projectToSafety: at most 3 iterations (:137)
+            for (int j = 0; j < d.n_lin; j++) {
+                const double ox = ob[((size_t)j * N + (k - 1)) * 2], oy = ob[((size_t)j * N + (k - 1)) * 2 + 1];
+                const double dx = px - ox, dy = py - oy;
+                const double dist = sqrt(dx * dx + dy * dy);
+                if (dist < r) {
+                    const double s = dist > 1e-12 ? r * 1.001 / dist : 0.0;
+                    px = dist > 1e-12 ? ox + dx * s : ox;
+                    py = dist > 1e-12 ? oy + dy * s : oy + r * 1.001;
+                }
+            }
+    }
+    for (int j = 0; j < d.n_lin; j++) {
+        double a1 = 1.0, a2 = 0.0, bb = dummy_b;                        // _dummy_a1, _dummy_a2
+        if (!dummy) {
+            const double ox = ob[((size_t)j * N + (k - 1)) * 2], oy = ob[((size_t)j * N + (k - 1)) * 2 + 1];
+            const double dx = ox - px, dy = oy - py;
+            const double dist = sqrt(dx * dx + dy * dy);
+            a1 = dx / dist; a2 = dy / dist;
+            bb = a1 * ox + a2 * oy - r;
+        }
+        p[ip_lin(d, j, 0)] = a1; p[ip_lin(d, j, 1)] = a2; p[ip_lin(d, j, 2)] = bb;
+    }
+}
+
 // ---- debug: stage functions on device -----------------------------------------------------------
 __global__ void tmpc_debug_eval_kernel(Dims d, int n, const double *z, const double *p, const double *pi, const double *lamh,
                                        double *cost, double *cgrad, double *chess, double *hval, double *hjac,
@@ -1131,6 +1174,22 @@ int tmpc_select_best_records(tmpc_handle *h, const void *d_records, int32_t n_ra
     return TMPC_OK;
 }
 
+int tmpc_linearize_topology(tmpc_handle *h, const void *d_obstacle_pos, const void *d_scene_of, const void *d_state_x,
+                            double robot_radius, const void *d_is_original)
+{
+    if (!h || h->B <= 0 || !h->params || !d_obstacle_pos || !d_scene_of || !d_state_x || h->d.n_lin <= 0) {
+        if (h) h->err = "tmpc_linearize_topology: bad argument / no batch / no topology rows";
+        return TMPC_ERR_INVALID;
+    }
+    TMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    const int n = h->B * h->d.N;
+    hipLaunchKernelGGL(tmpc::tmpc_linearize_topology_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->d, h->B,
+                       h->x0, const_cast<double *>(h->params), (const double *)d_obstacle_pos, (const int *)d_scene_of,
+                       (const double *)d_state_x, robot_radius, (const uint8_t *)d_is_original);
+    TMPC_HIP_CHECK(h, hipGetLastError());
+    return TMPC_OK;
+}
+
 int tmpc_enable_timing(tmpc_handle *h, int32_t max_records)
 {
     if (!h || max_records < 0) return TMPC_ERR_INVALID;
@@ -1167,6 +1226,15 @@ int tmpc_time_solve(tmpc_handle *h, int32_t reps, float *ms_each)
     TMPC_HIP_CHECK(h, hipStreamSynchronize(h->stream));
     for (int i = 0; i < reps; i++) TMPC_HIP_CHECK(h, hipEventElapsedTime(&ms_each[i], ev[2 * i], ev[2 * i + 1]));
     for (auto &e : ev) (void)hipEventDestroy(e);
+    return TMPC_OK;
+}
+
+int tmpc_debug_get_params(tmpc_handle *h, double *params)
+{
+    if (!h || h->B <= 0 || !params || !h->params) return TMPC_ERR_INVALID;
+    TMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    TMPC_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    TMPC_HIP_CHECK(h, hipMemcpy(params, h->params, (size_t)h->B * h->d.N * h->d.npar * 8, hipMemcpyDeviceToHost));
     return TMPC_OK;
 }
 

@@ -25,7 +25,8 @@ class TmpcDims(C.Structure):
 EXPORTS = ["tmpc_default_dims", "tmpc_create", "tmpc_destroy", "tmpc_last_error", "tmpc_set_batch",
            "tmpc_set_batch_device", "tmpc_solve", "tmpc_synchronize", "tmpc_get", "tmpc_select_best",
            "tmpc_result_device_ptrs", "tmpc_time_solve", "tmpc_debug_eval_stage", "tmpc_pack_records",
-           "tmpc_select_best_records", "tmpc_enable_timing", "tmpc_get_timings", "tmpc_debug_profile"]
+           "tmpc_select_best_records", "tmpc_enable_timing", "tmpc_get_timings", "tmpc_debug_profile",
+           "tmpc_linearize_topology", "tmpc_debug_get_params"]
 
 _lib = None
 
@@ -62,6 +63,8 @@ def load_library():
         lib.tmpc_enable_timing.argtypes = [vp, C.c_int32]
         lib.tmpc_get_timings.argtypes = [vp, vp, C.c_int32, C.POINTER(C.c_int32)]
         lib.tmpc_debug_profile.argtypes = [vp, vp, C.c_int32]
+        lib.tmpc_linearize_topology.argtypes = [vp, vp, vp, vp, C.c_double, vp]
+        lib.tmpc_debug_get_params.argtypes = [vp, vp]
         _lib = lib
     return _lib
 
@@ -175,6 +178,18 @@ class BatchedSolver:
     def select_best_records(self, d_records, n_ranks, n_scenes, per_rank, d_best):
         self._check(self.lib.tmpc_select_best_records(self._h, C.c_void_p(d_records), int(n_ranks), int(n_scenes),
                                                       int(per_rank), C.c_void_p(d_best)), "tmpc_select_best_records")
+
+    def linearize_topology(self, d_obstacle_pos, d_scene_of, d_state_x, robot_radius, d_is_original=None):
+        """Device LinearizedConstraints::update + setParameters (raw device pointers); modifies the batch params in place."""
+        self._check(self.lib.tmpc_linearize_topology(self._h, C.c_void_p(d_obstacle_pos), C.c_void_p(d_scene_of),
+                                                     C.c_void_p(d_state_x), float(robot_radius),
+                                                     C.c_void_p(d_is_original) if d_is_original else None),
+                    "tmpc_linearize_topology")
+
+    def debug_get_params(self):
+        out = np.zeros((self.B, self.N, self.npar))
+        self._check(self.lib.tmpc_debug_get_params(self._h, _p(out)), "tmpc_debug_get_params")
+        return out
 
     def result_device_ptrs(self):
         a, b = C.c_void_p(), C.c_void_p()

@@ -179,3 +179,48 @@ def test_full_size_properties_multi_scene_batch():
         np.testing.assert_array_equal(alone["xtraj"], res["xtraj"][idx])      # bitwise: no cross-trajectory coupling
         s2.close()
     s.close()
+
+
+def test_device_linearize_topology_matches_host_mirror():
+    """SURVEY 8(f-1): LinearizedConstraints::update + setParameters on device vs the host mirror
+    (mpc_planner_amd/modules.py, written after linearized_constraints.cpp:49-189), incl. the T-MPC++ dummy rows,
+    the k=0 dummies and a guess that needs the projection."""
+    import torch
+    from mpc_planner_amd import scenes, modules as md
+    scs = [scenes.make_scene(60 + i, N=20, M=8, B=16, tmpc_pp=True) for i in range(3)]
+    B = sum(len(s["xinit"]) for s in scs)
+    xinit = np.concatenate([s["xinit"] for s in scs]); x0 = np.concatenate([s["x0"] for s in scs]); want = np.concatenate([s["params"] for s in scs])
+    scene_of = np.concatenate([np.full(len(s["xinit"]), i, np.int32) for i, s in enumerate(scs)])
+    is_orig = np.concatenate([(np.arange(len(s["xinit"])) == len(s["xinit"]) - 1).astype(np.uint8) for s in scs])
+    obst = np.stack([s["obstacles"]["pos"] for s in scs])                       # [3][8][20][2]
+    state_x = np.array([s["xinit"][0, 0] for s in scs])
+    # put one guess inside an obstacle's projection disc: the host mirror gets the same radial projection first
+    x0[5, 7, 2:4] = obst[0, 3, 6] + np.array([0.05, 0.02])
+    pm = scs[0]["pm"]
+    ref = want.copy()
+    g = x0[5].copy(); r = 1e-3 + 0.325
+    for _ in range(3):
+        for j in range(8):
+            o = obst[0, j, 6]; dv = g[7, 2:4] - o; dist = np.sqrt(dv[0] * dv[0] + dv[1] * dv[1])
+            if dist < r: g[7, 2:4] = o + dv * (r * 1.001 / dist)
+    lin = md.linearized_update(g, obst[0], 0.325)
+    md.linearized_set_parameters(pm, ref[5], state_x[0], lin, n_rows=8)
+    start = want.copy()
+    for j in range(8):                                                          # wipe the lin rows: the device must rebuild them
+        for f in ("a1", "a2", "b"):
+            start[:, :, pm.index(f"lin_constraint_{j}_{f}")] = -7.0
+    s = _solver(B_max=B)
+    s.set_batch(xinit, x0, start)
+    dev = torch.device("cuda")
+    t_ob = torch.from_numpy(obst).to(dev); t_sc = torch.from_numpy(scene_of).to(dev)
+    t_sx = torch.from_numpy(state_x).to(dev); t_io = torch.from_numpy(is_orig).to(dev)
+    s.linearize_topology(t_ob.data_ptr(), t_sc.data_ptr(), t_sx.data_ptr(), 0.325, t_io.data_ptr())
+    got = s.debug_get_params()
+    np.testing.assert_allclose(got, ref, rtol=1e-14, atol=1e-14)
+    # and the solve on device-built rows equals the solve on host-built rows
+    s.solve(); a = s.get()
+    s.set_batch(xinit, x0, ref); s.solve(); b = s.get()
+    assert (a["exit_code"] == b["exit_code"]).all()
+    ok = b["exit_code"] == 1
+    np.testing.assert_allclose(a["xtraj"][ok], b["xtraj"][ok], rtol=0, atol=1e-9)
+    s.close()
