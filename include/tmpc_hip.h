@@ -56,8 +56,8 @@ typedef struct tmpc_dims {
     double dt;            /* integrator_step */
     double qp_tol;        /* qp_tol = 1e-5 */
     double reg_eps;       /* MIRROR epsilon (acados default 1e-4) */
-    double ipm_mu0;       /* interior-point initial barrier (10) */
-    double ipm_thr0;      /* interior-point initial slack floor (0.1) */
+    double ipm_mu0;       /* interior-point initial barrier (0.01) */
+    double ipm_thr0;      /* interior-point initial slack floor (0.01) */
     double lb[TMPC_NV];   /* model bounds, order [a,w,x,y,psi,v,spline] (solver_model.py:204-205) */
     double ub[TMPC_NV];
 } tmpc_dims;

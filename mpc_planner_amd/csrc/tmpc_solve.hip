@@ -1002,7 +1002,7 @@ void tmpc_default_dims(tmpc_dims *d, int32_t N, int32_t S, int32_t n_lin, int32_
     d->N = N; d->S = S; d->n_lin = n_lin; d->M = M;
     d->npar = 8 + 9 * S + 3 * n_lin + 2 + 7 * M;
     d->n_sqp = 10; d->qp_iter_max = 50; d->erk_steps = 3;
-    d->dt = 0.2; d->qp_tol = 1e-5; d->reg_eps = 1e-4; d->ipm_mu0 = 10.0; d->ipm_thr0 = 0.1;
+    d->dt = 0.2; d->qp_tol = 1e-5; d->reg_eps = 1e-4; d->ipm_mu0 = 0.01; d->ipm_thr0 = 0.01;
     const double lb[TMPC_NV] = {-2.0, -0.8, -2000.0, -2000.0, -M_PI * 4, -0.01, -1.0};
     const double ub[TMPC_NV] = {2.0, 0.8, 2000.0, 2000.0, M_PI * 4, 3.0, 10000.0};
     for (int i = 0; i < TMPC_NV; i++) { d->lb[i] = lb[i]; d->ub[i] = ub[i]; }

@@ -37,8 +37,8 @@ void orc_problem_init(orc_problem *pb, int N, int S, int n_lin, int M)
     pb->qp_iter_max = 50;         /* generate_acados_solver.py:172 */
     pb->qp_tol = 1e-5;            /* generate_acados_solver.py:162 */
     pb->reg_eps = 1e-4;           /* [UPSTREAM] acados reg_epsilon default */
-    pb->ipm_mu0 = 1e1;            /* own IPM (any converged QP solver reproduces the unique QP solution) */
-    pb->ipm_thr0 = 1e-1;
+    pb->ipm_mu0 = 1e-2;           /* own IPM (any converged QP solver reproduces the unique QP solution); tuned: fewest iterations */
+    pb->ipm_thr0 = 1e-2;
     pb->erk_steps = 3;            /* generate_acados_solver.py:150 */
     /* solver_model.py:204-205 ContouringSecondOrderUnicycleModel bounds, order [a,w,x,y,psi,v,spline] */
     const double lb[ORC_NV] = {-2.0, -0.8, -2000.0, -2000.0, -M_PI * 4, -0.01, -1.0};
