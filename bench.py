@@ -198,11 +198,13 @@ def main():
                        "trajectories_per_launch_per_gpu": B, "scenes_per_launch": a.scenes,
                        "success_fraction": float(ok.mean()), "mean_sqp_iter": n_sqp_mean, "mean_ipm_iter_per_qp": ipm_per_qp,
                        "parallelism": f"trajectory-sharded x{world}, one 16 B/trajectory all-gather" if world > 1 else "single GPU"},
-            "roofline": {"bound": "valu_fp64", "achieved": tflops, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "roofline": {"bound": "mfma", "achieved": tflops, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": tflops / FP64_VALU_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel": "tmpc_solve_kernel", "kernel_ms_avg": k_avg * 1e3, "flops_per_solve": fl,
-                         "note": "path is FP64-VALU/latency bound (SURVEY 8d): f64 MFMA on MI355X runs at the vector rate "
-                                 "and the blocks are 7x7, so the VALU roofline is the relevant one; HBM term below",
+                         "kernel": "tmpc_solve_fast_kernel<8,8,3>", "kernel_ms_avg": k_avg * 1e3, "flops_per_solve": fl,
+                         "note": "compute roofline for dtype f64: on MI355X the dense f64 MFMA peak equals the f64 vector (VALU) "
+                                 "peak, 78.6 TFLOP/s (AMD spec); the kernel issues FP64 VALU (7x7 stage blocks, SURVEY 8d), so "
+                                 "this is the binding roofline; achieved = algorithmic flops (SURVEY 8d model x measured "
+                                 "iteration counts) / HIP-event kernel time; HBM term alongside",
                          "hbm": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": gbs / HBM_PEAK_GBS, "bytes_per_solve": by}},
             "latency_b64": lat,

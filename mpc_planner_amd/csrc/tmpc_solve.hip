@@ -962,6 +962,11 @@ static SolveKernel pick_fast_kernel(const Dims &d)
     } else if (lps == 2) {
         if (d.n_lin == 0 && d.M == 4) return tmpc_solve_fast_kernel<0, 4, 2>;
     }
+#ifdef TMPC_TRY_ALL      // compile-only probe of candidate shapes (resource remarks); never dispatched in the shipped build
+    if (d.n_lin == 12 && d.M == 12 && lps == 3) return tmpc_solve_fast_kernel<12, 12, 3>;
+    if (d.n_lin == 8 && d.M == 8 && lps == 2) return tmpc_solve_fast_kernel<8, 8, 2>;
+    if (d.n_lin == 12 && d.M == 12 && lps == 2) return tmpc_solve_fast_kernel<12, 12, 2>;
+#endif
     return nullptr;
 }
 }  // namespace tmpc

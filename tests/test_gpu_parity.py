@@ -224,3 +224,28 @@ def test_device_linearize_topology_matches_host_mirror():
     ok = b["exit_code"] == 1
     np.testing.assert_allclose(a["xtraj"][ok], b["xtraj"][ok], rtol=0, atol=1e-9)
     s.close()
+
+
+def test_fast_and_generic_kernels_agree():
+    """A/B: the registered fast kernel (rows in registers) against the generic kernel (TMPC_FORCE_GENERIC=1) on the bench
+    shape -- same integer outcomes, trajectories equal to rounding."""
+    import subprocess, sys, tempfile
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "from mpc_planner_amd import scenes, solver\n"
+        "b = scenes.make_batch(range(300, 304), N=20, M=8, B=64)\n"
+        "s = solver.BatchedSolver(solver.default_dims(), B_max=256); s.set_batch(b['xinit'], b['x0'], b['params']); s.solve(); g = s.get()\n"
+        "np.savez(sys.argv[1], **g)\n" % os.path.dirname(HERE))
+    outs = []
+    for env in ({}, {"TMPC_FORCE_GENERIC": "1"}):
+        f = tempfile.NamedTemporaryFile(suffix=".npz", delete=False).name
+        e = dict(os.environ); e.update(env)
+        subprocess.check_call([sys.executable, "-c", code, f], env=e, timeout=300)
+        outs.append(np.load(f))
+    a, b = outs
+    for k in ("exit_code", "qp_status", "sqp_iter", "qp_iter_total"):
+        assert (a[k] == b[k]).all(), k
+    ok = a["exit_code"] == 1
+    assert ok.sum() > 100
+    np.testing.assert_allclose(a["xtraj"][ok], b["xtraj"][ok], rtol=0, atol=1e-8)
+    np.testing.assert_allclose(a["pobj"][ok], b["pobj"][ok], rtol=1e-9)
