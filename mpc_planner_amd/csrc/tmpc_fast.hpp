@@ -110,6 +110,7 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
     // signed Jacobian of row s (general rows: +-D from LDS; box rows: zero triple)
 #define ROW_C(s) const double sg_ = (neg >> (s) & 1) ? -1.0 : 1.0; const double *Dr_ = L.D + didx[s]; \
     const double c0s = sg_ * Dr_[0], c1s = sg_ * Dr_[1], c2s = sg_ * Dr_[2];
+#define INVT(s) (LEAN ? rcp_nr(t[s]) : invt_[(LEAN ? 0 : (s))])
     auto CU = [&](int s) { return (box >> s & 1) ? ((upper >> s & 1) ? -1.0 : 1.0) : 0.0; };   // signed unit coefficient
     __syncthreads();                                             // staging is dead from here on
     // QP start: dz = 0 except dx_0 = xinit - x_0; duals 0
@@ -119,7 +120,9 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
     if (tid < NX) L.v[NU + tid] = xi[tid] - L.z[NU + tid];
     __syncthreads();
 
-    double t[RPL], invt[RPL], qt[RPL], rd[RPL];
+    double t[RPL], qt[RPL];
+    constexpr bool LEAN = RPL > 10;                 // many rows per lane: recompute 1/t instead of keeping it (register budget)
+    double invt_[LEAN ? 1 : RPL];               // the row residual r_d = c.v - sb - t is recomputed where needed
     {
         const double vx = L.v[kk * NV + ZX], vy = L.v[kk * NV + ZY], vp = L.v[kk * NV + ZPSI];
 #pragma unroll
@@ -127,9 +130,9 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
             ROW_C(s)
             const double r0 = c0s * vx + c1s * vy + c2s * vp + CU(s) * L.v[kk * NV + VAR(s)] - sb[s];
             t[s] = r0 > d.thr0 ? r0 : d.thr0;
-            invt[s] = 1.0 / t[s];
-            lam[s] = (act >> s & 1) ? d.mu0 * invt[s] : 0.0;
-            qt[s] = 0.0; rd[s] = 0.0;
+            if constexpr (!LEAN) invt_[s] = 1.0 / t[s];
+            lam[s] = (act >> s & 1) ? d.mu0 / t[s] : 0.0;
+            qt[s] = 0.0;
         }
     }
     int status = 2, iters = 0;
@@ -181,10 +184,10 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
                 const double cus = CU(s);
                 ROW_C(s)
                 const double r = c0s * vx + c1s * vy + c2s * vp + cus * vv - sb[s] - t[s];
-                rd[s] = a ? r : 0.0;
+                const double rds = a ? r : 0.0;
                 const double comp = lam[s] * t[s];
-                const double dd = lam[s] * invt[s];
-                const double w = dd * rd[s];
+                const double dd = lam[s] * INVT(s);
+                const double w = dd * rds;
                 if (a) { res_d = fmax(res_d, fabs(r)); res_m = fmax(res_m, comp); mu += comp; }
                 gs0 += lam[s] * c0s; gs1 += lam[s] * c1s; gs2 += lam[s] * c2s;
                 rs0 += w * c0s; rs1 += w * c1s; rs2 += w * c2s;
@@ -230,14 +233,17 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
         double amax = 1e300;
         {
             const double dx = L.dv[kk * NV + ZX], dy = L.dv[kk * NV + ZY], dp = L.dv[kk * NV + ZPSI];
+            const double vx = L.v[kk * NV + ZX], vy = L.v[kk * NV + ZY], vp = L.v[kk * NV + ZPSI];
 #pragma unroll
             for (int s = 0; s < RPL; s++) {
                 const bool a = act >> s & 1;
-                const double dvv = L.dv[kk * NV + VAR(s)];
+                const double dvv = L.dv[kk * NV + VAR(s)], vv = L.v[kk * NV + VAR(s)];
                 ROW_C(s)
-                const double ddot = c0s * dx + c1s * dy + c2s * dp + CU(s) * dvv;
-                const double dt = a ? ddot + rd[s] : 0.0;
-                const double dl = a ? -lam[s] - lam[s] * invt[s] * dt : 0.0;
+                const double cus = CU(s);
+                const double rds = c0s * vx + c1s * vy + c2s * vp + cus * vv - sb[s] - t[s];
+                const double ddot = c0s * dx + c1s * dy + c2s * dp + cus * dvv;
+                const double dt = a ? ddot + rds : 0.0;
+                const double dl = a ? -lam[s] - lam[s] * INVT(s) * dt : 0.0;
                 dt_[s] = dt;
                 if (dt < 0.0) amax = fmin(amax, -t[s] / dt);
                 if (dl < 0.0) amax = fmin(amax, -lam[s] / dl);
@@ -249,7 +255,7 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
 #pragma unroll
         for (int s = 0; s < RPL; s++)
             if (act >> s & 1) {
-                const double dl = -lam[s] - lam[s] * invt[s] * dt_[s];
+                const double dl = -lam[s] - lam[s] * INVT(s) * dt_[s];
                 mu_aff += (lam[s] + a_aff * dl) * (t[s] + a_aff * dt_[s]);
             }
         mu_aff = wave_sum(mu_aff) / m_rows;
@@ -260,13 +266,15 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
         __syncthreads();
         {
             double cs0 = 0, cs1 = 0, cs2 = 0;
+            const double vx = L.v[kk * NV + ZX], vy = L.v[kk * NV + ZY], vp = L.v[kk * NV + ZPSI];
 #pragma unroll
             for (int s = 0; s < RPL; s++) {
                 const bool a = act >> s & 1;
-                const double dl = -lam[s] - lam[s] * invt[s] * dt_[s];
-                qt[s] = a ? lam[s] + (dt_[s] * dl - sigma * mu) * invt[s] : 0.0;
-                const double w = qt[s] + lam[s] * invt[s] * rd[s];
+                const double dl = -lam[s] - lam[s] * INVT(s) * dt_[s];
+                qt[s] = a ? lam[s] + (dt_[s] * dl - sigma * mu) * INVT(s) : 0.0;
                 ROW_C(s)
+                const double rr = c0s * vx + c1s * vy + c2s * vp + CU(s) * L.v[kk * NV + VAR(s)] - sb[s] - t[s];
+                const double w = qt[s] + lam[s] * INVT(s) * (a ? rr : 0.0);
                 cs0 += w * c0s; cs1 += w * c1s; cs2 += w * c2s;
                 if (a && (box >> s & 1)) lds_add(&L.gh[k * NV + VAR(s)], w * CU(s));
                 __builtin_amdgcn_sched_barrier(0);
@@ -280,14 +288,17 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
         amax = 1e300;
         {
             const double dx = L.dv[kk * NV + ZX], dy = L.dv[kk * NV + ZY], dp = L.dv[kk * NV + ZPSI];
+            const double vx = L.v[kk * NV + ZX], vy = L.v[kk * NV + ZY], vp = L.v[kk * NV + ZPSI];
 #pragma unroll
             for (int s = 0; s < RPL; s++) {
                 const bool a = act >> s & 1;
-                const double dvv = L.dv[kk * NV + VAR(s)];
+                const double dvv = L.dv[kk * NV + VAR(s)], vv = L.v[kk * NV + VAR(s)];
                 ROW_C(s)
-                const double ddot = c0s * dx + c1s * dy + c2s * dp + CU(s) * dvv;
-                const double dt = a ? ddot + rd[s] : 0.0;
-                const double dl = a ? -qt[s] - lam[s] * invt[s] * dt : 0.0;
+                const double cus = CU(s);
+                const double rds = c0s * vx + c1s * vy + c2s * vp + cus * vv - sb[s] - t[s];
+                const double ddot = c0s * dx + c1s * dy + c2s * dp + cus * dvv;
+                const double dt = a ? ddot + rds : 0.0;
+                const double dl = a ? -qt[s] - lam[s] * INVT(s) * dt : 0.0;
                 dt_[s] = dt;
                 if (dt < 0.0) amax = fmin(amax, -t[s] / dt);
                 if (dl < 0.0) amax = fmin(amax, -lam[s] / dl);
@@ -301,9 +312,9 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
 #pragma unroll
         for (int s = 0; s < RPL; s++) {
             if (act >> s & 1) {
-                const double dl = -qt[s] - lam[s] * invt[s] * dt_[s];
+                const double dl = -qt[s] - lam[s] * INVT(s) * dt_[s];
                 t[s] += alpha * dt_[s]; lam[s] += alpha * dl;
-                invt[s] = 1.0 / t[s];
+                if constexpr (!LEAN) invt_[s] = 1.0 / t[s];
             }
         }
         for (int e = tl; e < (N + 1) * NV; e += NT) L.v[e] += alpha * L.dv[e];
