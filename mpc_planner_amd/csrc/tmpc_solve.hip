@@ -197,16 +197,17 @@ __device__ bool riccati_factor(const Lds &L, const Dims &d, int tid)
     auto load_stage = [&](int k) {
         const double *Hk = L.Hh + k * NP28;
         const double *BA = L.BA + k * NX * NV;
+        // unconditional loads (clamped indices): entries above the diagonal / of idle lanes are never used
 #pragma unroll
-        for (int j = 0; j < NV; j++) hk[j] = (rowl && j <= lane) ? Hk[pidx(ls, j <= ls ? j : 0)] : 0.0;
+        for (int j = 0; j < NV; j++) hk[j] = Hk[pidx(ls, j <= ls ? j : ls)];
 #pragma unroll
-        for (int m = 0; m < NX; m++) ba[m] = rowl ? BA[m * NV + ls] : 0.0;
+        for (int m = 0; m < NX; m++) ba[m] = BA[m * NV + ls];
 #pragma unroll
         for (int q = 0; q < 8; q++) dn[q] = L.dyn8[k * 8 + q];
     };
     // terminal node: Cholesky of the xx-block (rows/cols 2..6)
 #pragma unroll
-    for (int j = 0; j < NV; j++) f[j] = (rowl && j <= lane && j >= NU && lane >= NU) ? L.Hh[N * NP28 + pidx(ls, j <= ls ? j : 0)] : 0.0;
+    for (int j = 0; j < NV; j++) f[j] = (j >= NU) ? L.Hh[N * NP28 + pidx(ls, j <= ls ? j : ls)] : 0.0;
     load_stage(N - 1);
     bad |= chol_rows<NU>(f, lane, nullptr, nullptr);
     for (int k = N - 1; k >= 0; k--) {
@@ -316,19 +317,19 @@ __device__ void riccati_solve(const Lds &L, const Dims &d, int tid)
         }
     }
     __syncthreads();
-    double p = xl ? L.gh[N * NV + lane] : 0.0;          // p_N
+    double p = L.gh[N * NV + ls];                       // p_N (lanes 2..6 meaningful)
     if (xl) L.pr[N * NX + i5] = p;
     {
         double ghj, ba[NX], r0, l10, r1, lx0, lx1, q;
         auto load_stage = [&](int k) {
             const double *Fb = L.Hh + k * NP28;
             const double *BA = L.BA + k * NX * NV;
-            ghj = rowl ? L.gh[k * NV + ls] : 0.0;
+            ghj = L.gh[k * NV + ls];
 #pragma unroll
-            for (int l = 0; l < NX; l++) ba[l] = rowl ? BA[l * NV + ls] : 0.0;
+            for (int l = 0; l < NX; l++) ba[l] = BA[l * NV + ls];
             r0 = Fb[FB_R0]; l10 = Fb[FB_L10]; r1 = Fb[FB_R1];
-            lx0 = xl ? Fb[FB_LXU + 2 * i5] : 0.0; lx1 = xl ? Fb[FB_LXU + 2 * i5 + 1] : 0.0;
-            q = xl ? L.dpi[(k + 1) * NX + i5] : 0.0;
+            lx0 = Fb[FB_LXU + 2 * i5]; lx1 = Fb[FB_LXU + 2 * i5 + 1];
+            q = L.dpi[(k + 1) * NX + i5];
         };
         load_stage(N - 1);
         for (int k = N - 1; k >= 0; k--) {
@@ -352,13 +353,13 @@ __device__ void riccati_solve(const Lds &L, const Dims &d, int tid)
         auto load_stage = [&](int k) {
             const double *Fb = L.Hh + k * NP28;
             const double *BAr = L.BA + k * NX * NV + i5 * NV;              // own row of [B A]
-            lx0 = xl ? Fb[FB_LXU + 2 * i5] : 0.0; lx1 = xl ? Fb[FB_LXU + 2 * i5 + 1] : 0.0;
+            lx0 = Fb[FB_LXU + 2 * i5]; lx1 = Fb[FB_LXU + 2 * i5 + 1];
             y0 = L.y[k * NU]; y1 = L.y[k * NU + 1];
             r0 = Fb[FB_R0]; l10 = Fb[FB_L10]; r1 = Fb[FB_R1];
-            e_psi = xl ? BAr[ZPSI] - (lane == ZPSI ? 1.0 : 0.0) : 0.0;
-            e_v = xl ? BAr[ZV] - (lane == ZV ? 1.0 : 0.0) : 0.0;
-            b_a = xl ? BAr[ZA] : 0.0; b_w = xl ? BAr[ZW] : 0.0;
-            rbi = xl ? L.rb[k * NX + i5] : 0.0;
+            e_psi = BAr[ZPSI] - (lane == ZPSI ? 1.0 : 0.0);
+            e_v = BAr[ZV] - (lane == ZV ? 1.0 : 0.0);
+            b_a = BAr[ZA]; b_w = BAr[ZW];
+            rbi = L.rb[k * NX + i5];
         };
         load_stage(0);
         for (int k = 0; k < N; k++) {
@@ -371,7 +372,7 @@ __device__ void riccati_solve(const Lds &L, const Dims &d, int tid)
             const double u0 = (-s0 - l10 * u1) * r0;
             if (rowl) L.dv[k * NV + lane] = lane == 0 ? u0 : (lane == 1 ? u1 : dx);
             const double dpsi = readlane_d(dx, ZPSI), dvv = readlane_d(dx, ZV);
-            dx = xl ? dx + e_psi * dpsi + e_v * dvv + b_a * u0 + b_w * u1 + rbi : 0.0;
+            dx = dx + e_psi * dpsi + e_v * dvv + b_a * u0 + b_w * u1 + rbi;   // lanes 2..6 meaningful
             if (k + 1 < N) load_stage(k + 1);
         }
         if (rowl) L.dv[N * NV + lane] = xl ? dx : 0.0;
