@@ -172,8 +172,7 @@ __device__ __forceinline__ bool chol_rows(double (&f)[NV], int lane, double *r0,
             f[j] -= f[c] * ljc;                     // lane i >= j: F_ij -= L_ic L_jc
         }
     }
-#pragma unroll
-    for (int j = 0; j < NV; j++) if (j > lane) f[j] = 0.0;      // clear the unused upper part
+    (void)lane;                                       // entries above the diagonal are never read
     return bad;
 }
 
