@@ -283,26 +283,28 @@ __device__ __forceinline__ double st_rcp(double x)
     return y;
 }
 
-__device__ __forceinline__ void mirror7(double (*A)[NV], double eps)
+// MIRROR of an n x n symmetric matrix held in registers (fully unrolled cyclic Jacobi): A <- V max(|e|, eps) V^T.
+template <int NN>
+__device__ __forceinline__ void mirror_n(double (&A)[NN][NN], double eps)
 {
-    double V[NV][NV];
+    double V[NN][NN];
 #pragma unroll
-    for (int i = 0; i < NV; i++)
+    for (int i = 0; i < NN; i++)
 #pragma unroll
-        for (int j = 0; j < NV; j++) V[i][j] = (i == j) ? 1.0 : 0.0;
+        for (int j = 0; j < NN; j++) V[i][j] = (i == j) ? 1.0 : 0.0;
     for (int sweep = 0; sweep < 30; sweep++) {
         double off = 0.0, dg = 0.0;
 #pragma unroll
-        for (int i = 0; i < NV; i++) {
+        for (int i = 0; i < NN; i++) {
             dg += A[i][i] * A[i][i];
 #pragma unroll
-            for (int j = i + 1; j < NV; j++) off += A[i][j] * A[i][j];
+            for (int j = i + 1; j < NN; j++) off += A[i][j] * A[i][j];
         }
         if (off <= 1e-32 * (dg + off) || off == 0.0) break;
 #pragma unroll
-        for (int p = 0; p < NV - 1; p++) {
+        for (int p = 0; p < NN - 1; p++) {
 #pragma unroll
-            for (int q = p + 1; q < NV; q++) {
+            for (int q = p + 1; q < NN; q++) {
                 const double apq = A[p][q];
                 if (fabs(apq) > 1e-150) {                       // (also keeps tau^2 + apq^2 away from underflow)
                     // t = sgn(theta) / (|theta| + sqrt(theta^2 + 1)), theta = (aqq - app) / (2 apq), written division-free:
@@ -313,17 +315,17 @@ __device__ __forceinline__ void mirror7(double (*A)[NV], double eps)
                     const double t = (tau >= 0.0 ? apq : -apq) * st_rcp(fabs(tau) + hyp);
                     const double c = st_rsqrt(t * t + 1.0), s = t * c;
 #pragma unroll
-                    for (int k = 0; k < NV; k++) {
+                    for (int k = 0; k < NN; k++) {
                         const double akp = A[k][p], akq = A[k][q];
                         A[k][p] = c * akp - s * akq; A[k][q] = s * akp + c * akq;
                     }
 #pragma unroll
-                    for (int k = 0; k < NV; k++) {
+                    for (int k = 0; k < NN; k++) {
                         const double apk = A[p][k], aqk = A[q][k];
                         A[p][k] = c * apk - s * aqk; A[q][k] = s * apk + c * aqk;
                     }
 #pragma unroll
-                    for (int k = 0; k < NV; k++) {
+                    for (int k = 0; k < NN; k++) {
                         const double vkp = V[k][p], vkq = V[k][q];
                         V[k][p] = c * vkp - s * vkq; V[k][q] = s * vkp + c * vkq;
                     }
@@ -331,22 +333,68 @@ __device__ __forceinline__ void mirror7(double (*A)[NV], double eps)
             }
         }
     }
-    double e[NV];
+    double e[NN];
 #pragma unroll
-    for (int i = 0; i < NV; i++) {
+    for (int i = 0; i < NN; i++) {
         double ei = A[i][i];
         if (ei >= -eps && ei <= eps) ei = eps; else if (ei < 0.0) ei = -ei;
         e[i] = ei;
     }
 #pragma unroll
-    for (int i = 0; i < NV; i++)
+    for (int i = 0; i < NN; i++)
 #pragma unroll
         for (int j = 0; j <= i; j++) {
             double acc = 0.0;
 #pragma unroll
-            for (int k = 0; k < NV; k++) acc += V[i][k] * e[k] * V[j][k];
+            for (int k = 0; k < NN; k++) acc += V[i][k] * e[k] * V[j][k];
             A[i][j] = acc; A[j][i] = acc;
         }
+}
+
+// MIRROR of the 7x7 stage Hessian.  With a zero disc offset (Jackal: one disc at the centre, data_preparation.cpp:25-28)
+// the Lagrangian Hessian is block diagonal under the permutation {a, w, psi, v} | {x, y, spline} (dynamics curvature
+// couples the first set, contouring cost + ellipsoids the second): the two blocks are then regularised separately
+// (same result, ~half the rotations' work); any coupling entry != 0 falls back to the full 7x7 iteration.
+__device__ __forceinline__ void mirror7(double (*A)[NV], double eps)
+{
+    constexpr int IA[4] = {ZA, ZW, ZPSI, ZV}, IB[3] = {ZX, ZY, ZS};
+    bool coupled = false;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) coupled |= (A[IA[i]][IB[j]] != 0.0) | (A[IB[j]][IA[i]] != 0.0);
+    if (!coupled) {
+        double Ba[4][4], Bb[3][3];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) Ba[i][j] = A[IA[i]][IA[j]];
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) Bb[i][j] = A[IB[i]][IB[j]];
+        mirror_n<4>(Ba, eps);
+        mirror_n<3>(Bb, eps);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) A[IA[i]][IA[j]] = Ba[i][j];
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) A[IB[i]][IB[j]] = Bb[i][j];
+    } else {
+        double F[NV][NV];
+#pragma unroll
+        for (int i = 0; i < NV; i++)
+#pragma unroll
+            for (int j = 0; j < NV; j++) F[i][j] = A[i][j];
+        mirror_n<NV>(F, eps);
+#pragma unroll
+        for (int i = 0; i < NV; i++)
+#pragma unroll
+            for (int j = 0; j < NV; j++) A[i][j] = F[i][j];
+    }
 }
 
 // Lagrangian Hessian of one stage (before MIRROR): dt*hess(l) + pi_x hess(x+) + pi_y hess(y+) + sum_r lamh_r hess(h_r),
