@@ -114,10 +114,10 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
     auto CU = [&](int s) { return (box >> s & 1) ? ((upper >> s & 1) ? -1.0 : 1.0) : 0.0; };   // signed unit coefficient
     __syncthreads();                                             // staging is dead from here on
     // QP start: dz = 0 except dx_0 = xinit - x_0; duals 0
-    for (int e = tid; e < (N + 1) * NV; e += NT) L.v[e] = 0.0;
-    for (int e = tid; e < (N + 1) * NX; e += NT) L.pq[e] = 0.0;
+    for (int e = tid_q; e < (N + 1) * NV; e += NT) L.v[e] = 0.0;
+    for (int e = tid_q; e < (N + 1) * NX; e += NT) L.pq[e] = 0.0;
     __syncthreads();
-    if (tid < NX) L.v[NU + tid] = xi[tid] - L.z[NU + tid];
+    if (tid_q < NX) L.v[NU + tid_q] = xi[tid_q] - L.z[NU + tid_q];
     __syncthreads();
 
     double t[RPL], qt[RPL];
@@ -368,15 +368,15 @@ __global__ __launch_bounds__(NT) void tmpc_solve_fast_kernel(Dims d, int B, cons
         if (qp_status != 0 && qp_status != 2) { status = 4; break; }
         status = 0;
         __syncthreads();
-        for (int e = tid; e < (N + 1) * NV; e += NT) {
+        int tid_w = tid;
+        asm volatile("" : "+v"(tid_w));                   // opaque (see ipm_fast): keeps these addresses out of the prologue
+        for (int e = tid_w; e < (N + 1) * NV; e += NT) {
             const int ks = e / NV, i = e - ks * NV;
             if (!(ks == N && i < NU)) L.z[e] += L.v[e];
         }
-        for (int e = tid; e < N * NX; e += NT) L.pi[NX + e] = L.pq[NX + e];
+        for (int e = tid_w; e < N * NX; e += NT) L.pi[NX + e] = L.pq[NX + e];
         __syncthreads();
         // multipliers of the general rows for the next linearisation: (lam_upper - lam_lower) = -sgn lam
-        int tid_w = tid;
-        asm volatile("" : "+v"(tid_w));                   // opaque (see ipm_fast): keeps these addresses out of the prologue
         const int k = tid_w / LPS, c = tid_w - k * LPS;
         if (k < N) {
 #pragma unroll

@@ -712,13 +712,15 @@ __device__ void solve_epilogue(const Lds &L, const Dims &d, int tid, int b, cons
         for (int i = 0; i < NX; i++) r = fmax(r, fabs(dy.xn[i] - L.z[(ks + 1) * NV + NU + i]));
         if (tid < N) { cost = d.dt * co.val; res = r; }
     }
-    if (tid < NX) res = fmax(res, fabs(L.z[NU + tid] - xi[tid]));
+    int tid_o = tid;
+    asm volatile("" : "+v"(tid_o));
+    if (tid_o < NX) res = fmax(res, fabs(L.z[NU + tid_o] - xi[tid_o]));
     cost = wave_sum(cost); res = wave_max(res);
-    for (int e = tid; e < (N + 1) * NX; e += NT) {
+    for (int e = tid_o; e < (N + 1) * NX; e += NT) {
         const int k = e / NX, i = e - k * NX;
         xtraj[(size_t)b * (N + 1) * NX + e] = L.z[k * NV + NU + i];
     }
-    for (int e = tid; e < N * NU; e += NT) {
+    for (int e = tid_o; e < N * NU; e += NT) {
         const int k = e / NU, i = e - k * NU;
         utraj[(size_t)b * N * NU + e] = L.z[k * NV + i];
     }
