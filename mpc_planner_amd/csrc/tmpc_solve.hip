@@ -953,7 +953,8 @@ typedef void (*SolveKernel)(Dims, int, const double *, const double *, const dou
 // Only instantiations that compile WITHOUT scratch (zero VGPR spills) are registered: __graft_entry__.build() checks
 // the compiler's resource remarks and fails otherwise.  Reason: with > ~100 spilled VGPRs this kernel was observed to
 // return wrong iterates (spill/reload around partially-masked regions), see DESIGN.md section 5.  Shapes with more rows
-// per lane ((12,12) at 3 lanes/stage, (8,8) at 2 lanes/stage for N > 21) therefore use the generic kernel for now.
+// per lane ((8,8) at 2 lanes/stage for N > 21, (12,12) at 2 lanes/stage) therefore use the generic kernel for now.  The library is
+// built with -mllvm -disable-machine-licm: hoisted constant materialisations were what pushed (12,12,3) into scratch.
 static SolveKernel pick_fast_kernel(const Dims &d)
 {
     if (getenv("TMPC_FORCE_GENERIC")) return nullptr;
@@ -961,11 +962,11 @@ static SolveKernel pick_fast_kernel(const Dims &d)
     if (lps == 3) {
         if (d.n_lin == 0 && d.M == 4) return tmpc_solve_fast_kernel<0, 4, 3>;
         if (d.n_lin == 8 && d.M == 8) return tmpc_solve_fast_kernel<8, 8, 3>;
+        if (d.n_lin == 12 && d.M == 12) return tmpc_solve_fast_kernel<12, 12, 3>;     // zero scratch only with machine-LICM off (build flag)
     } else if (lps == 2) {
         if (d.n_lin == 0 && d.M == 4) return tmpc_solve_fast_kernel<0, 4, 2>;
     }
 #ifdef TMPC_TRY_ALL      // compile-only probe of candidate shapes (resource remarks); never dispatched in the shipped build
-    if (d.n_lin == 12 && d.M == 12 && lps == 3) return tmpc_solve_fast_kernel<12, 12, 3>;
     if (d.n_lin == 8 && d.M == 8 && lps == 2) return tmpc_solve_fast_kernel<8, 8, 2>;
     if (d.n_lin == 12 && d.M == 12 && lps == 2) return tmpc_solve_fast_kernel<12, 12, 2>;
 #endif
