@@ -105,7 +105,8 @@ def make_scene(scene_idx, N=20, M=8, B=64, S=5, tmpc_pp=False, gaussian=False, g
         # r + robot_radius from every obstacle prediction, push the offending points radially out so the
         # reference's projection would be the identity on what we hand to the solver.
         r_min = 1e-3 + ROBOT_RADIUS + 1e-6
-        for _sweep in range(3):
+        for _sweep in range(50):
+            moved = False
             for k in range(1, N):
                 for j in range(M):
                     o = obs["pos"][j, k - 1]
@@ -113,6 +114,9 @@ def make_scene(scene_idx, N=20, M=8, B=64, S=5, tmpc_pp=False, gaussian=False, g
                     dist = np.sqrt(dvec[0] * dvec[0] + dvec[1] * dvec[1])
                     if dist < r_min:
                         gpos[k] = o + (dvec / dist if dist > 1e-12 else np.array([0.0, 1.0])) * (r_min * 1.001)
+                        moved = True
+            if not moved:
+                break
         x0[b] = md.initialize_solver_with_guidance(main_x0.copy(), gpos, gvel)
         params[b] = base
         if guidance:
