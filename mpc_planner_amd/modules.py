@@ -12,8 +12,9 @@ IDX = dict(a=0, w=1, x=2, y=3, psi=4, v=5, spline=6)   # model_map.yaml order (s
 
 def mpc_base_set_parameters(pm, params, weights):
     """MPCBaseModule::setParameters (mpc_planner_modules/src/mpc_base.cpp:23-35): every stage k."""
-    for name in ("acceleration", "angular_velocity", "velocity", "reference_velocity"):
-        params[:, pm.index(name)] = weights[name]
+    for name in ("acceleration", "angular_velocity", "slack", "velocity", "reference_velocity"):
+        if pm.has_parameter(name):
+            params[:, pm.index(name)] = weights[name]
 
 
 def contouring_set_parameters(pm, params, weights, segments):
@@ -86,14 +87,58 @@ def linearized_set_parameters(pm, params, state_x, lin=None, n_rows=None):
             params[1:, ia[2]] = lin[2][1:, j]
 
 
-def initialize_with_forward_propagation(state, N, dt):
+def halfspace_rows_set_parameters(pm, params, state_x, rows, prefix, n_rows, disc_offset=0.0):
+    """DecompConstraints::setParameters (decomp_constraints.cpp:150-187) and the scenario_module's parameter writer
+    (scenario_constraints.cpp:76-79; same layout, scenario_constraints.py:40-49): ego disc offset at every stage,
+    k = 0 all dummies (1, 0, x + 100), stages k >= 1 the rows computed by update(), padded with dummies.
+    rows: (a1, a2, b) each [N][n] with row k = 0 unused, or None; prefix: "disc_0_decomp" | "disc_0_scenario_constraint"."""
+    params[:, pm.index("ego_disc_0_offset")] = disc_offset
+    dummy = (1.0, 0.0, state_x + 100.0)
+    for j in range(n_rows):
+        ia = [pm.index(f"{prefix}_{j}_{f}") for f in ("a1", "a2", "b")]
+        params[:, ia] = dummy
+        if rows is not None and j < rows[0].shape[1]:
+            ok = ~np.isnan(rows[0][1:, j])                   # NaN = no row computed for this slot: stays a dummy
+            for w in range(3):
+                col = params[1:, ia[w]]
+                col[ok] = rows[w][1:, j][ok]
+                params[1:, ia[w]] = col
+
+
+def scenario_halfspaces(x0, samples, radius, n_rows=24):
+    """Stand-in for scenario_module's per-stage polygon construction (source absent: README.md:24,76):
+    every sampled obstacle position o of stage k gives the halfspace a = (o - p)/|o - p|, b = a.o - radius around the
+    guess p (the same linearisation LinearizedConstraints uses, linearized_constraints.cpp:84-105); of the
+    M * S_cen halfspaces the tightest one of each of the n_rows equal angular sectors of a is kept (the edges of the
+    free polygon around p), empty sectors stay dummies.
+    x0 [N+1][nv]; samples [M][S_cen][N][2] (index k-1 for stage k).  Returns a1, a2, b [N][n_rows] with NaN = dummy."""
+    N = x0.shape[0] - 1
+    a1 = np.full((N, n_rows), np.nan); a2 = np.full((N, n_rows), np.nan); b = np.full((N, n_rows), np.nan)
+    for k in range(1, N):
+        p = x0[k, [IDX["x"], IDX["y"]]]
+        o = samples[:, :, k - 1, :].reshape(-1, 2)
+        diff = o - p
+        dist = np.sqrt(diff[:, 0] * diff[:, 0] + diff[:, 1] * diff[:, 1])
+        ax = diff[:, 0] / dist; ay = diff[:, 1] / dist
+        sector = np.minimum(((np.arctan2(ay, ax) + np.pi) * (n_rows / (2.0 * np.pi))).astype(np.int64), n_rows - 1)
+        for s in range(n_rows):
+            idx = np.nonzero(sector == s)[0]
+            if idx.size == 0:
+                continue
+            i = idx[np.argmin(dist[idx])]                   # first minimum: lowest sample index on ties
+            a1[k, s] = ax[i]; a2[k, s] = ay[i]
+            b[k, s] = ax[i] * o[i, 0] + ay[i] * o[i, 1] - radius
+    return a1, a2, b
+
+
+def initialize_with_forward_propagation(state, N, dt, nv=NV):
     """Main-solver warm start: constant-velocity forward propagation of the current state (stand-in for
     the previous tick's solution used by initializeWarmstart, acados_solver_interface.cpp:344-376; same
     recursion as initializeWithBraking :303-342 with a = 0)."""
-    x0 = np.zeros((N + 1, NV))
-    x, y, psi, v, s = state
+    x0 = np.zeros((N + 1, nv))
+    x, y, psi, v, s = state[:5]
     for k in range(N + 1):
-        x0[k] = [0.0, 0.0, x, y, psi, v, s]
+        x0[k, :NV] = [0.0, 0.0, x, y, psi, v, s]            # a slack state (column 7) is never initialised: 0
         x += v * dt * np.cos(psi); y += v * dt * np.sin(psi); s += v * dt
     return x0
 

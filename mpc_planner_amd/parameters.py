@@ -6,7 +6,9 @@ modules, each in insertion order, duplicates skipped.  The per-module `define_pa
 here are: WeightsObjective (mpc_planner_modules/scripts/mpc_base.py:26-30 with the weigh_variable calls of
 mpc_planner_jackalsimulator/scripts/generate_jackalsimulator_solver.py:45-52), ContouringObjective
 (contouring.py:22-46), LinearConstraints (guidance_constraints.py:73-78), EllipsoidConstraint
-(ellipsoid_constraints.py:37-49).
+(ellipsoid_constraints.py:37-49), and for the slack-model configurations (generate_jackalsimulator_solver.py:67-90,
+generate_rosnavigation_solver.py:62-108) the scenario / decomp LinearConstraints (scenario_constraints.py:40-49,
+decomp_constraints.py:44-52).
 """
 from collections import OrderedDict
 
@@ -41,11 +43,16 @@ class ParameterMap:
         return d
 
 
-def define_parameters(num_segments, max_obstacles, guidance=True, add_halfspaces=0, n_discs=1):
-    """T-MPC (guidance=True, cfg 2/4) or LMPCC-style basic (guidance=False, cfg 1) Jackal parameter map."""
+def define_parameters(num_segments, max_obstacles, guidance=True, add_halfspaces=0, n_discs=1, slack=False,
+                      ellipsoids=True, n_scenario=0, n_decomp=0):
+    """T-MPC (guidance=True, cfg 2/4) or LMPCC-style basic (guidance=False, cfg 1) Jackal parameter map; with
+    slack=True the slack-model maps: rosnavigation T-MPC (guidance + ellipsoids + n_decomp=12, cfg 3) and SH-MPC
+    (guidance=False, ellipsoids=False, n_scenario=24, cfg 5)."""
     p = ParameterMap()
     # objective modules
-    for w in ("acceleration", "angular_velocity", "velocity", "reference_velocity"):   # MPCBaseModule
+    base = ("acceleration", "angular_velocity", "slack", "velocity", "reference_velocity") if slack else \
+           ("acceleration", "angular_velocity", "velocity", "reference_velocity")
+    for w in base:                                                                      # MPCBaseModule
         p.add(w)
     p.add("contour"); p.add("lag")                                                      # ContouringObjective
     p.add("terminal_angle"); p.add("terminal_contouring")
@@ -60,12 +67,25 @@ def define_parameters(num_segments, max_obstacles, guidance=True, add_halfspaces
             p.add(f"lin_constraint_{j}_a1", bundle_name="lin_constraint_a1")
             p.add(f"lin_constraint_{j}_a2", bundle_name="lin_constraint_a2")
             p.add(f"lin_constraint_{j}_b", bundle_name="lin_constraint_b")
-    p.add("ego_disc_radius")                                                            # EllipsoidConstraint
-    for d in range(n_discs):
-        p.add(f"ego_disc_{d}_offset", bundle_name="ego_disc_offset")
-    for j in range(max_obstacles):
-        for f in ("x", "y", "psi", "major", "minor", "chi", "r"):
-            p.add(f"ellipsoid_obst_{j}_{f}", bundle_name=f"ellipsoid_obst_{f}")
+    if ellipsoids:
+        p.add("ego_disc_radius")                                                        # EllipsoidConstraint
+        for d in range(n_discs):
+            p.add(f"ego_disc_{d}_offset", bundle_name="ego_disc_offset")
+        for j in range(max_obstacles):
+            for f in ("x", "y", "psi", "major", "minor", "chi", "r"):
+                p.add(f"ellipsoid_obst_{j}_{f}", bundle_name=f"ellipsoid_obst_{f}")
+    if n_scenario:                                                                      # scenario LinearConstraints
+        for d in range(n_discs):
+            p.add(f"ego_disc_{d}_offset", bundle_name="ego_disc_offset")
+            for j in range(n_scenario):
+                for f in ("a1", "a2", "b"):
+                    p.add(f"disc_{d}_scenario_constraint_{j}_{f}")
+    if n_decomp:                                                                        # decomp LinearConstraints
+        for d in range(n_discs):
+            p.add(f"ego_disc_{d}_offset", bundle_name="ego_disc_offset")
+            for j in range(n_decomp):
+                for f in ("a1", "a2", "b"):
+                    p.add(f"disc_{d}_decomp_{j}_{f}", bundle_name=f"decomp_{f}")
     return p
 
 
@@ -79,3 +99,5 @@ MODEL_MAP_UNICYCLE = OrderedDict([
     ("psi", ["x", 4, -math.pi * 4, math.pi * 4]), ("v", ["x", 5, -0.01, 3.0]),
     ("spline", ["x", 6, -1.0, 10000.0]),
 ])
+# ContouringSecondOrderUnicycleModelWithSlack (solver_model.py:274-298)
+MODEL_MAP_UNICYCLE_SLACK = OrderedDict(list(MODEL_MAP_UNICYCLE.items()) + [("slack", ["x", 7, 0.0, 5000.0])])

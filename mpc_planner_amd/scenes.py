@@ -11,7 +11,8 @@ from . import modules as md
 from .parameters import define_parameters
 
 WEIGHTS = dict(acceleration=0.34, angular_velocity=0.85, velocity=0.55, reference_velocity=2.0,
-               contour=0.05, lag=0.75, terminal_angle=100.0, terminal_contouring=10.0)
+               contour=0.05, lag=0.75, terminal_angle=100.0, terminal_contouring=10.0,
+               slack=10000.0)        # slack-model configurations only (mpc_planner_rosnavigation/config/settings.yaml:86)
 ROBOT_RADIUS = 0.325
 OBSTACLE_RADIUS = 0.4
 DT = 0.2
@@ -37,12 +38,61 @@ def reference_path_segments(rng, S=5, seg_len=6.0):
     return segs
 
 
-def make_scene(scene_idx, N=20, M=8, B=64, S=5, tmpc_pp=False, gaussian=False, guidance=True):
-    """Returns dict(xinit [Bt][5], x0 [Bt][N+1][7], params [Bt][N][npar], pm, guidance_id [Bt])."""
+def decomp_corridor(rng, segs, state, N, n_rows=12):
+    """Stand-in for DecompConstraints::update (decomp_constraints.cpp:53-118; DecompUtil + costmap absent): per stage
+    k >= 1 a convex polytope around the reference-path point at s_k = s + k v dt: two corridor walls parallel to the
+    path, a front and a back cap and four diagonal cuts (8 rows); the remaining slots stay dummies like the
+    reference's padding (:106-111).  Returns a1, a2, b [N][n_rows] with NaN = dummy."""
+    a1 = np.full((N, n_rows), np.nan); a2 = np.full((N, n_rows), np.nan); b = np.full((N, n_rows), np.nan)
+    half_w = rng.uniform(2.2, 3.5, 2)                         # left / right wall distance [m]
+    reach = rng.uniform(5.0, 7.0)
+    s = state[4]
+    for k in range(N - 1):
+        i = min(int(s // 6.0), segs.shape[0] - 1); t = s - segs[i, 8]
+        px = ((segs[i, 0] * t + segs[i, 1]) * t + segs[i, 2]) * t + segs[i, 3]
+        py = ((segs[i, 4] * t + segs[i, 5]) * t + segs[i, 6]) * t + segs[i, 7]
+        dx = (3 * segs[i, 0] * t + 2 * segs[i, 1]) * t + segs[i, 2]
+        dy = (3 * segs[i, 4] * t + 2 * segs[i, 5]) * t + segs[i, 6]
+        nrm = np.hypot(dx, dy); tx, ty = dx / nrm, dy / nrm
+        normals = [(-ty, tx, half_w[0]), (ty, -tx, half_w[1]), (tx, ty, reach), (-tx, -ty, reach)]
+        for sx, sy in ((1, 1), (1, -1), (-1, 1), (-1, -1)):
+            nx_, ny_ = (sx * tx - sy * ty) / np.sqrt(2.0), (sx * ty + sy * tx) / np.sqrt(2.0)
+            normals.append((nx_, ny_, 0.8 * (reach + half_w.mean())))
+        for r, (ax, ay, dist) in enumerate(normals):
+            a1[k + 1, r] = ax; a2[k + 1, r] = ay; b[k + 1, r] = ax * px + ay * py + dist
+        s += state[3] * DT
+    return a1, a2, b
+
+
+def scenario_samples(rng, pos0, vel, N, n_samples):
+    """Gaussian-mixture obstacle scenarios (3 modes: straight / veer left / veer right, weights .5/.25/.25) with
+    process noise integrated along the horizon -- stand-in for the scenario_module's sampler
+    (scenario_constraints.cpp:125-131 IntegrateAndTranslateToMeanAndVariance; source absent).
+    Returns samples [M][n_samples][N][2]."""
+    M = pos0.shape[0]
+    mode = rng.choice(3, size=(M, n_samples), p=[0.5, 0.25, 0.25])
+    turn = np.array([0.0, 0.06, -0.06])[mode]
+    c, s = np.cos(turn), np.sin(turn)
+    v = np.stack([c * vel[:, None, 0] - s * vel[:, None, 1], s * vel[:, None, 0] + c * vel[:, None, 1]], -1)   # [M][S][2]
+    steps = np.arange(N)[None, None, :, None]
+    noise = np.cumsum(rng.normal(0.0, 0.05 * DT, (M, n_samples, N, 2)), axis=2)
+    return pos0[:, None, None, :] + v[:, :, None, :] * DT * steps + noise
+
+
+def make_scene(scene_idx, N=20, M=8, B=64, S=5, tmpc_pp=False, gaussian=False, guidance=True, slack=False,
+               n_decomp=0, n_scenario=0, n_samples=256):
+    """Returns dict(xinit [Bt][nx], x0 [Bt][N+1][nv], params [Bt][N][npar], pm, guidance_id [Bt]); nx = 5, nv = 7, or
+    6 / 8 with the slack model.  n_scenario > 0 builds the SH-MPC problem (cfg 5): no ellipsoid / topology rows, 24
+    scenario halfspaces per stage from M obstacles x n_samples scenarios, one set per guidance trajectory."""
     rng = np.random.Generator(np.random.PCG64(1000 + scene_idx))
-    pm = define_parameters(S, M, guidance=guidance)
+    ellipsoids = n_scenario == 0
+    if not ellipsoids:
+        guidance = False
+    pm = define_parameters(S, M, guidance=guidance, slack=slack, ellipsoids=ellipsoids, n_scenario=n_scenario,
+                           n_decomp=n_decomp)
     npar = pm.length()
-    state = np.array([0.0, 0.0, 0.0, rng.uniform(0.5, 2.0), 0.0])           # x,y,psi,v,spline
+    nx, nv = 5 + int(slack), 7 + int(slack)
+    state = np.array([0.0, 0.0, 0.0, rng.uniform(0.5, 2.0), 0.0] + [0.0] * int(slack))   # x,y,psi,v,spline(,slack)
     segs = reference_path_segments(rng, S)
     # obstacles: constant velocity (data_preparation.cpp:58-79): mode[i] = pos0 + vel*dt*i.
     # Half of them are "crossing pedestrians" timed to meet the robot's nominal progress along the path
@@ -71,12 +121,17 @@ def make_scene(scene_idx, N=20, M=8, B=64, S=5, tmpc_pp=False, gaussian=False, g
     base = np.zeros((N, npar))
     md.mpc_base_set_parameters(pm, base, WEIGHTS)
     md.contouring_set_parameters(pm, base, WEIGHTS, segs)
-    md.ellipsoid_set_parameters(pm, base, state[:2], obs, ROBOT_RADIUS)
-    main_x0 = md.initialize_with_forward_propagation(state, N, DT)
+    if ellipsoids:
+        md.ellipsoid_set_parameters(pm, base, state[:2], obs, ROBOT_RADIUS)
+    if n_decomp:
+        md.halfspace_rows_set_parameters(pm, base, state[0], decomp_corridor(rng, segs, state, N, n_decomp),
+                                         "disc_0_decomp", n_decomp)
+    samples = scenario_samples(rng, pos0, vel, N, n_samples) if n_scenario else None
+    main_x0 = md.initialize_with_forward_propagation(state, N, DT, nv)
 
     Bt = B + (1 if tmpc_pp else 0)
     xinit = np.tile(state, (Bt, 1))
-    x0 = np.zeros((Bt, N + 1, 7)); params = np.zeros((Bt, N, npar))
+    x0 = np.zeros((Bt, N + 1, nv)); params = np.zeros((Bt, N, npar))
     guidance_id = np.zeros(Bt, np.int32)
     T = N * DT; t = np.arange(N + 1) * DT
     v_ref = WEIGHTS["reference_velocity"]
@@ -89,12 +144,15 @@ def make_scene(scene_idx, N=20, M=8, B=64, S=5, tmpc_pp=False, gaussian=False, g
     clearance = OBSTACLE_RADIUS + ROBOT_RADIUS + 0.1
     for b in range(B):
         best = None
-        for attempt in range(200):
+        for attempt in range(200 if samples is None else 40):
             A = amps[b] if attempt == 0 else rng.uniform(-A_MAX, A_MAX)
             # lateral profile A sin^2(pi t/T): leaves and rejoins the path tangentially
             gpos = np.stack([xs, A * np.sin(np.pi * t / T) ** 2], 1)
             gvel = np.stack([vx, A * np.pi / T * np.sin(2 * np.pi * t / T)], 1)
-            d = np.linalg.norm(gpos[None, 1:N, :] - obs["pos"][:, :N - 1, :], axis=2).min()
+            if samples is not None:      # SH-MPC: clearance from every sampled scenario, not only from the mean prediction
+                d = np.sqrt(((gpos[None, None, 1:N, :] - samples[:, :, :N - 1, :]) ** 2).sum(-1)).min()
+            else:
+                d = np.linalg.norm(gpos[None, 1:N, :] - obs["pos"][:, :N - 1, :], axis=2).min()
             if best is None or d > best[0]:
                 best = (d, gpos, gvel)
             if d >= clearance:
@@ -117,11 +175,25 @@ def make_scene(scene_idx, N=20, M=8, B=64, S=5, tmpc_pp=False, gaussian=False, g
                         moved = True
             if not moved:
                 break
+        if samples is not None:            # same stand-in against every sampled scenario (radius of the scenario rows)
+            r_s = OBSTACLE_RADIUS + ROBOT_RADIUS + 1e-3
+            for k in range(1, N):
+                cloud = samples[:, :, k - 1, :].reshape(-1, 2)
+                for _sweep in range(60):
+                    dvec = gpos[k] - cloud
+                    dist = np.sqrt(dvec[:, 0] * dvec[:, 0] + dvec[:, 1] * dvec[:, 1])
+                    j = int(np.argmin(dist))
+                    if dist[j] >= r_s:
+                        break
+                    gpos[k] = cloud[j] + (dvec[j] / dist[j] if dist[j] > 1e-12 else np.array([0.0, 1.0])) * (r_s * 1.001)
         x0[b] = md.initialize_solver_with_guidance(main_x0.copy(), gpos, gvel)
         params[b] = base
         if guidance:
             lin = md.linearized_update(x0[b], obs["pos"], ROBOT_RADIUS)
             md.linearized_set_parameters(pm, params[b], state[0], lin, n_rows=M)
+        if n_scenario:
+            rows = md.scenario_halfspaces(x0[b], samples, OBSTACLE_RADIUS + ROBOT_RADIUS, n_scenario)
+            md.halfspace_rows_set_parameters(pm, params[b], state[0], rows, "disc_0_scenario_constraint", n_scenario)
         guidance_id[b] = b
     if tmpc_pp:                                                             # non-guided planner
         x0[B] = main_x0
@@ -129,7 +201,8 @@ def make_scene(scene_idx, N=20, M=8, B=64, S=5, tmpc_pp=False, gaussian=False, g
         md.linearized_set_parameters(pm, params[B], state[0], None, n_rows=M)
         guidance_id[B] = 2 * B                                              # guidance_constraints.cpp:349
     return dict(xinit=xinit, x0=x0, params=params, pm=pm, guidance_id=guidance_id, obstacles=obs,
-                segments=segs, N=N, M=M, S=S, n_lin=(M if guidance else 0))
+                segments=segs, N=N, M=(M if ellipsoids else 0), S=S, n_lin=(M if guidance else 0),
+                n_slk=n_scenario + n_decomp, slack=int(slack), samples=samples)
 
 
 def make_batch(scene_indices, **kw):

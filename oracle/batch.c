@@ -11,11 +11,11 @@
 void orc_solve_batch(const orc_problem *pb, int B, const double *xinit, const double *x0,
                      const double *params, double *xtraj, double *utraj, orc_info *info, int num_threads)
 {
-    const size_t n_x0 = (size_t)(pb->N + 1) * ORC_NV, n_par = (size_t)pb->N * pb->npar;
-    const size_t n_xt = (size_t)(pb->N + 1) * ORC_NX, n_ut = (size_t)pb->N * ORC_NU;
+    const size_t n_x0 = (size_t)(pb->N + 1) * ORC_NVE, n_par = (size_t)pb->N * pb->npar;
+    const size_t n_xt = (size_t)(pb->N + 1) * ORC_NXE, n_ut = (size_t)pb->N * ORC_NU;
 #pragma omp parallel for num_threads(num_threads) schedule(dynamic, 1)
     for (int b = 0; b < B; b++)
-        orc_solve(pb, &xinit[(size_t)b * ORC_NX], &x0[b * n_x0], &params[b * n_par],
+        orc_solve(pb, &xinit[(size_t)b * ORC_NXE], &x0[b * n_x0], &params[b * n_par],
                   &xtraj[b * n_xt], &utraj[b * n_ut], &info[b]);
 }
 

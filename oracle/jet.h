@@ -1,7 +1,7 @@
 /*
- * oracle/jet.h -- CPU ORACLE (test infrastructure): forward-mode second-order jets in ORC_NV variables.
+ * oracle/jet.h -- CPU ORACLE (test infrastructure): forward-mode second-order jets in ORC_NVE variables.
  *
- * A jet carries (value, gradient, Hessian) of a scalar w.r.t. z = [a,w,x,y,psi,v,spline].  Composing
+ * A jet carries (value, gradient, Hessian) of a scalar w.r.t. z = [a,w,x,y,psi,v,spline(,slack)].  Composing
  * jets through the reference's expressions reproduces what CasADi's AD yields for the same expression
  * graph (generate_acados_solver.py:41,48 build the expressions; acados' EXACT Hessian uses their
  * second derivatives).
@@ -15,8 +15,8 @@
 
 typedef struct {
     double v;
-    double g[ORC_NV];
-    double H[ORC_NV][ORC_NV];
+    double g[ORC_NVE];
+    double H[ORC_NVE][ORC_NVE];
 } jet;
 
 static inline jet jet_const(double c) { jet r; memset(&r, 0, sizeof r); r.v = c; return r; }
@@ -25,29 +25,29 @@ static inline jet jet_var(double val, int idx) { jet r = jet_const(val); r.g[idx
 /* r = f(a) given f, f', f'' at a.v */
 static inline jet jet_chain(const jet *a, double f, double f1, double f2) {
     jet r; r.v = f;
-    for (int i = 0; i < ORC_NV; i++) r.g[i] = f1 * a->g[i];
-    for (int i = 0; i < ORC_NV; i++)
-        for (int j = 0; j < ORC_NV; j++)
+    for (int i = 0; i < ORC_NVE; i++) r.g[i] = f1 * a->g[i];
+    for (int i = 0; i < ORC_NVE; i++)
+        for (int j = 0; j < ORC_NVE; j++)
             r.H[i][j] = f1 * a->H[i][j] + f2 * a->g[i] * a->g[j];
     return r;
 }
 static inline jet jet_add(jet a, jet b) {
     jet r; r.v = a.v + b.v;
-    for (int i = 0; i < ORC_NV; i++) r.g[i] = a.g[i] + b.g[i];
-    for (int i = 0; i < ORC_NV; i++) for (int j = 0; j < ORC_NV; j++) r.H[i][j] = a.H[i][j] + b.H[i][j];
+    for (int i = 0; i < ORC_NVE; i++) r.g[i] = a.g[i] + b.g[i];
+    for (int i = 0; i < ORC_NVE; i++) for (int j = 0; j < ORC_NVE; j++) r.H[i][j] = a.H[i][j] + b.H[i][j];
     return r;
 }
 static inline jet jet_sub(jet a, jet b) {
     jet r; r.v = a.v - b.v;
-    for (int i = 0; i < ORC_NV; i++) r.g[i] = a.g[i] - b.g[i];
-    for (int i = 0; i < ORC_NV; i++) for (int j = 0; j < ORC_NV; j++) r.H[i][j] = a.H[i][j] - b.H[i][j];
+    for (int i = 0; i < ORC_NVE; i++) r.g[i] = a.g[i] - b.g[i];
+    for (int i = 0; i < ORC_NVE; i++) for (int j = 0; j < ORC_NVE; j++) r.H[i][j] = a.H[i][j] - b.H[i][j];
     return r;
 }
 static inline jet jet_mul(jet a, jet b) {
     jet r; r.v = a.v * b.v;
-    for (int i = 0; i < ORC_NV; i++) r.g[i] = a.v * b.g[i] + b.v * a.g[i];
-    for (int i = 0; i < ORC_NV; i++)
-        for (int j = 0; j < ORC_NV; j++)
+    for (int i = 0; i < ORC_NVE; i++) r.g[i] = a.v * b.g[i] + b.v * a.g[i];
+    for (int i = 0; i < ORC_NVE; i++)
+        for (int j = 0; j < ORC_NVE; j++)
             r.H[i][j] = a.v * b.H[i][j] + b.v * a.H[i][j] + a.g[i] * b.g[j] + a.g[j] * b.g[i];
     return r;
 }

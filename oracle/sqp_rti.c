@@ -13,6 +13,13 @@
  *   U5 a QP that stops at its iteration limit still takes the step (status stays success, qp_status=2);
  *      NaN / min-step QP failures return ACADOS_QP_FAILURE (4) without taking the step,
  *   U6 res_eq = inf-norm of the dynamics defects + initial-condition violation at the returned iterate.
+ *   U9 (slack build) the slack state obeys slack_{k+1} = slack_k and x_0 = xinit fixes it at node 0
+ *      (ocp.constraints.x0 covers all nx states, generate_acados_solver.py:95), so every QP determines its step
+ *      without any freedom: d_slack_0 = xinit_s - slack_0, d_slack_{k+1} = d_slack_k + (slack_k - slack_{k+1}).
+ *      The QP is strictly convex after MIRROR, hence its primal solution is unique and equals the solution of the
+ *      QP with that chain substituted (QP presolve): the substituted QP has the 7 remaining variables per node,
+ *      the slack column of the rows moves into their right-hand sides, and the slack box rows (0 <= slack <= 5000,
+ *      now constants) drop out.  HPIPM would carry the chain as equalities; a converged solve gives the same step.
  */
 #include <math.h>
 #include <stdlib.h>
@@ -23,35 +30,46 @@
 #define INF_BOUND 1e10
 
 typedef struct {
-    double z[ORC_MAX_N + 1][ORC_NV];       /* iterate, [u_k; x_k]; node N: u unused */
+    double z[ORC_MAX_N + 1][ORC_NVE];      /* iterate, [u_k; x_k]; node N: u unused */
     double pi[ORC_MAX_N + 1][ORC_NX];      /* dynamics multipliers (index = node of x_{k}) */
     double lam_h[ORC_MAX_N][ORC_MAX_NH];   /* (lam_upper - lam_lower) per general row */
 } nlp_state;
 
 static void build_qp(const orc_problem *pb, const nlp_state *st, const double *xinit, const double *params,
-                     orc_qp *qp, int (*row_lo)[ORC_MAX_NH], int (*row_hi)[ORC_MAX_NH], orc_debug *dbg)
+                     orc_qp *qp, int (*row_lo)[ORC_MAX_NH], int (*row_hi)[ORC_MAX_NH], orc_debug *dbg, double *dslack)
 {
-    const int N = pb->N, nh = pb->n_lin + pb->M;
+    const int N = pb->N, nh = pb->n_lin + pb->M + pb->n_slk;
+    const int E = ORC_NVE;                                   /* stride of the model's derivative arrays */
+#if ORC_SLACK
+    dslack[0] = xinit[ORC_NX] - st->z[0][ORC_NV];            /* U9 */
+    for (int k = 0; k < N; k++) dslack[k + 1] = dslack[k] + (st->z[k][ORC_NV] - st->z[k + 1][ORC_NV]);
+#else
+    for (int k = 0; k <= N; k++) dslack[k] = 0.0;
+#endif
     double lh[ORC_MAX_NH], uh[ORC_MAX_NH];
     orc_constraint_bounds(pb, lh, uh);
     qp->N = N;
     for (int k = 0; k < N; k++) {
         const double *p = &params[(size_t)k * pb->npar];     /* update_params(k, all_parameters[k*NP]) :127-135 */
         const double *z = st->z[k];
-        double xn[ORC_NX], A[ORC_NX * ORC_NV], Hd[ORC_NX * ORC_NV * ORC_NV];
+        double xn[ORC_NXE], A[ORC_NXE * ORC_NVE], Hd[ORC_NXE * ORC_NVE * ORC_NVE];
         orc_discrete_dynamics(pb, z, xn, A, Hd);
-        double l, gl[ORC_NV], Hl[ORC_NV * ORC_NV];
+        double l, gl[ORC_NVE], Hl[ORC_NVE * ORC_NVE];
         orc_stage_cost(pb, z, p, &l, gl, Hl);
-        double h[ORC_MAX_NH], D[ORC_MAX_NH * ORC_NV];
-        double *Hh = (double *)malloc(sizeof(double) * ORC_MAX_NH * ORC_NV * ORC_NV);
+        double h[ORC_MAX_NH], D[ORC_MAX_NH * ORC_NVE];
+        double *Hh = (double *)malloc(sizeof(double) * ORC_MAX_NH * ORC_NVE * ORC_NVE);
         orc_stage_constraints(pb, z, p, h, D, Hh);
 
+        /* Lagrangian Hessian on the QP's 7 variables (the slack row/column of the model's Hessian is diagonal:
+         * no curvature couples slack to the other variables, so MIRROR acts on the two blocks independently) */
         double W[ORC_NV * ORC_NV];
-        for (int i = 0; i < ORC_NV * ORC_NV; i++) W[i] = pb->dt * Hl[i];                     /* U1 */
-        for (int j = 0; j < ORC_NX; j++)
-            for (int i = 0; i < ORC_NV * ORC_NV; i++) W[i] += st->pi[k + 1][j] * Hd[j * ORC_NV * ORC_NV + i];
-        for (int r = 0; r < nh; r++)
-            for (int i = 0; i < ORC_NV * ORC_NV; i++) W[i] += st->lam_h[k][r] * Hh[r * ORC_NV * ORC_NV + i];
+        for (int a = 0; a < ORC_NV; a++)
+            for (int c = 0; c < ORC_NV; c++) {
+                double acc = pb->dt * Hl[a * E + c];                                          /* U1 */
+                for (int j = 0; j < ORC_NX; j++) acc += st->pi[k + 1][j] * Hd[j * E * E + a * E + c];
+                for (int r = 0; r < nh; r++) acc += st->lam_h[k][r] * Hh[r * E * E + a * E + c];
+                W[a * ORC_NV + c] = acc;
+            }
         free(Hh);
         if (dbg) {
             memcpy(&dbg->W_raw[k * ORC_NV * ORC_NV], W, sizeof W);
@@ -65,20 +83,21 @@ static void build_qp(const orc_problem *pb, const nlp_state *st, const double *x
             qp->g[k][i] = pb->dt * gl[i];
         }
         for (int i = 0; i < ORC_NX; i++) {
-            for (int j = 0; j < ORC_NV; j++) qp->BA[k][i][j] = A[i * ORC_NV + j];
+            for (int j = 0; j < ORC_NV; j++) qp->BA[k][i][j] = A[i * E + j];
             qp->b[k][i] = xn[i] - st->z[k + 1][ORC_NU + i];
         }
         /* rows */
         int nr = 0;
         for (int r = 0; r < nh; r++) {
             row_lo[k][r] = row_hi[k][r] = -1;
+            const double hs = h[r] + (ORC_SLACK ? D[r * E + ORC_NV] * dslack[k] : 0.0);   /* U9: slack column -> rhs */
             if (lh[r] > -INF_BOUND) {          /* lower: + (D dz - (lh - h)) >= 0   (U3) */
-                for (int j = 0; j < ORC_NV; j++) qp->C[k][nr][j] = D[r * ORC_NV + j];
-                qp->sgn[k][nr] = 1.0; qp->beta[k][nr] = lh[r] - h[r]; row_lo[k][r] = nr; nr++;
+                for (int j = 0; j < ORC_NV; j++) qp->C[k][nr][j] = D[r * E + j];
+                qp->sgn[k][nr] = 1.0; qp->beta[k][nr] = lh[r] - hs; row_lo[k][r] = nr; nr++;
             }
             if (uh[r] < INF_BOUND) {           /* upper: - (D dz - (uh - h)) >= 0 */
-                for (int j = 0; j < ORC_NV; j++) qp->C[k][nr][j] = D[r * ORC_NV + j];
-                qp->sgn[k][nr] = -1.0; qp->beta[k][nr] = uh[r] - h[r]; row_hi[k][r] = nr; nr++;
+                for (int j = 0; j < ORC_NV; j++) qp->C[k][nr][j] = D[r * E + j];
+                qp->sgn[k][nr] = -1.0; qp->beta[k][nr] = uh[r] - hs; row_hi[k][r] = nr; nr++;
             }
         }
         const int last_box = (k == 0) ? ORC_NU : ORC_NV;        /* U2: x_0 is fixed, not boxed */
@@ -94,11 +113,11 @@ static void build_qp(const orc_problem *pb, const nlp_state *st, const double *x
         if (dbg) {
             memcpy(&dbg->W[k * ORC_NV * ORC_NV], W, sizeof W);
             for (int i = 0; i < ORC_NV; i++) dbg->g[k * ORC_NV + i] = qp->g[k][i];
-            memcpy(&dbg->BA[k * ORC_NX * ORC_NV], A, sizeof A);
+            for (int i = 0; i < ORC_NX; i++) for (int j = 0; j < ORC_NV; j++) dbg->BA[(k * ORC_NX + i) * ORC_NV + j] = A[i * E + j];
             for (int i = 0; i < ORC_NX; i++) dbg->b[k * ORC_NX + i] = qp->b[k][i];
             for (int r = 0; r < nh; r++) {
                 dbg->h[k * ORC_MAX_NH + r] = h[r];
-                for (int j = 0; j < ORC_NV; j++) dbg->D[(k * ORC_MAX_NH + r) * ORC_NV + j] = D[r * ORC_NV + j];
+                for (int j = 0; j < ORC_NV; j++) dbg->D[(k * ORC_MAX_NH + r) * ORC_NV + j] = D[r * E + j];
             }
         }
     }
@@ -123,7 +142,8 @@ static void build_qp(const orc_problem *pb, const nlp_state *st, const double *x
 void orc_solve_debug(const orc_problem *pb, const double *xinit, const double *x0, const double *params,
                      double *xtraj, double *utraj, orc_info *info, orc_debug *dbg, int capture_sqp_iter)
 {
-    const int N = pb->N, nh = pb->n_lin + pb->M;
+    const int N = pb->N, nh = pb->n_lin + pb->M + pb->n_slk;
+    double dslack[ORC_MAX_N + 1];
     nlp_state *st = (nlp_state *)calloc(1, sizeof(nlp_state));
     orc_qp *qp = (orc_qp *)calloc(1, sizeof(orc_qp));
     orc_qp_sol *sol = (orc_qp_sol *)calloc(1, sizeof(orc_qp_sol));
@@ -132,13 +152,13 @@ void orc_solve_debug(const orc_problem *pb, const double *xinit, const double *x
 
     /* loadWarmstart (:274-284): x_k = x0[nvar*k + nu ..], u_k = x0[nvar*k ..], k<N; x_N */
     for (int k = 0; k <= N; k++)
-        for (int j = 0; j < ORC_NV; j++) st->z[k][j] = x0[k * ORC_NV + j];
+        for (int j = 0; j < ORC_NVE; j++) st->z[k][j] = x0[k * ORC_NVE + j];
     st->z[N][0] = st->z[N][1] = 0.0;
 
     int status = 0;           /* acados status of the last Solver_acados_solve */
     info->qp_status = 0; info->sqp_iter = 0; info->qp_iter_total = 0;
     for (int it = 0; it < pb->n_sqp; it++) {                        /* :99-117 */
-        build_qp(pb, st, xinit, params, qp, row_lo, row_hi, (dbg && it == capture_sqp_iter) ? dbg : 0);
+        build_qp(pb, st, xinit, params, qp, row_lo, row_hi, (dbg && it == capture_sqp_iter) ? dbg : 0, dslack);
         orc_qp_solve(qp, sol, pb->qp_iter_max, pb->qp_tol, pb->ipm_mu0, pb->ipm_thr0);
         info->qp_status = sol->status; info->sqp_iter = it + 1; info->qp_iter_total += sol->iters;
         if (dbg && it == capture_sqp_iter) {
@@ -153,6 +173,9 @@ void orc_solve_debug(const orc_problem *pb, const double *xinit, const double *x
         /* full step (globalization FIXED_STEP :158) + multipliers from the QP */
         for (int k = 0; k <= N; k++) {
             for (int j = (k == N ? ORC_NU : 0); j < ORC_NV; j++) st->z[k][j] += sol->v[k][j];
+#if ORC_SLACK
+            st->z[k][ORC_NV] += dslack[k];                                     /* U9 */
+#endif
             if (k >= 1) for (int j = 0; j < ORC_NX; j++) st->pi[k][j] = sol->pi[k][j];
         }
         for (int k = 0; k < N; k++)
@@ -170,11 +193,11 @@ void orc_solve_debug(const orc_problem *pb, const double *xinit, const double *x
     for (int k = 0; k < N; k++) {
         double l; orc_stage_cost(pb, st->z[k], &params[(size_t)k * pb->npar], &l, 0, 0);
         pobj += pb->dt * l;                                                /* ocp_nlp_eval_cost, U1 */
-        double xn[ORC_NX]; orc_discrete_dynamics(pb, st->z[k], xn, 0, 0);
-        for (int i = 0; i < ORC_NX; i++) { double d = fabs(xn[i] - st->z[k + 1][ORC_NU + i]); if (d > res_eq) res_eq = d; }
+        double xn[ORC_NXE]; orc_discrete_dynamics(pb, st->z[k], xn, 0, 0);
+        for (int i = 0; i < ORC_NXE; i++) { double d = fabs(xn[i] - st->z[k + 1][ORC_NU + i]); if (d > res_eq) res_eq = d; }
     }
-    for (int i = 0; i < ORC_NX; i++) { double d = fabs(st->z[0][ORC_NU + i] - xinit[i]); if (d > res_eq) res_eq = d; }
-    for (int k = 0; k <= N; k++) for (int i = 0; i < ORC_NX; i++) xtraj[k * ORC_NX + i] = st->z[k][ORC_NU + i];
+    for (int i = 0; i < ORC_NXE; i++) { double d = fabs(st->z[0][ORC_NU + i] - xinit[i]); if (d > res_eq) res_eq = d; }
+    for (int k = 0; k <= N; k++) for (int i = 0; i < ORC_NXE; i++) xtraj[k * ORC_NXE + i] = st->z[k][ORC_NU + i];
     for (int k = 0; k < N; k++) for (int i = 0; i < ORC_NU; i++) utraj[k * ORC_NU + i] = st->z[k][i];
     if (res_eq > 1e-2 && status == 0) status = 4;                          /* :177-181 */
     if (!isfinite(pobj)) status = 4;

@@ -10,7 +10,7 @@
 #include "tmpc_oracle.h"
 
 /* z index map: inputs first, then states (solver_model.py:118-128, 200-201) */
-enum { Z_A = 0, Z_W = 1, Z_X = 2, Z_Y = 3, Z_PSI = 4, Z_V = 5, Z_S = 6 };
+enum { Z_A = 0, Z_W = 1, Z_X = 2, Z_Y = 3, Z_PSI = 4, Z_V = 5, Z_S = 6, Z_SLACK = 7 /* slack build only */ };
 
 /* ---------------------------------------------------------------------------------------------
  * Parameter index map.  Rule (solver_definition.py:5-16, util/parameters.py:25-55): objective modules'
@@ -20,18 +20,37 @@ enum { Z_A = 0, Z_W = 1, Z_X = 2, Z_Y = 3, Z_PSI = 4, Z_V = 5, Z_S = 6 };
  * -> contour, lag, terminal_angle, terminal_contouring, then 9 per segment; LinearConstraints
  * (guidance_constraints.py:73-78) -> a1,a2,b per row; EllipsoidConstraint (ellipsoid_constraints.py:37-49)
  * -> ego_disc_radius, ego_disc_0_offset, then x,y,psi,major,minor,chi,r per obstacle.
+ * Slack model (configuration_safe_horizon / rosnavigation configuration_tmpc,
+ * generate_jackalsimulator_solver.py:70-93, generate_rosnavigation_solver.py:62-108): MPCBaseModule(a,w,slack,v)
+ * -> acceleration, angular_velocity, slack, velocity, reference_velocity; Scenario / Decomp LinearConstraints
+ * (scenario_constraints.py:40-49, decomp_constraints.py:44-52) -> ego_disc_0_offset (skipped when the ellipsoid
+ * module already defined it), then a1,a2,b per row, scenario rows before decomp rows.
  * --------------------------------------------------------------------------------------------- */
-int orc_idx_weight(const orc_problem *pb, int which) { (void)pb; return which; }
-int orc_idx_spline(const orc_problem *pb, int seg, int which) { (void)pb; return 8 + 9 * seg + which; }
-int orc_idx_lin(const orc_problem *pb, int j, int which) { return 8 + 9 * pb->S + 3 * j + which; }
-int orc_idx_disc_radius(const orc_problem *pb) { return 8 + 9 * pb->S + 3 * pb->n_lin; }
-int orc_idx_disc_offset(const orc_problem *pb) { return orc_idx_disc_radius(pb) + 1; }
-int orc_idx_ellipsoid(const orc_problem *pb, int j, int which) { return orc_idx_disc_radius(pb) + 2 + 7 * j + which; }
-
-void orc_problem_init(orc_problem *pb, int N, int S, int n_lin, int M)
+static int w0(const orc_problem *pb) { return 8 + pb->slack; }     /* number of weight parameters */
+int orc_idx_weight(const orc_problem *pb, int which)
 {
-    pb->N = N; pb->S = S; pb->n_lin = n_lin; pb->M = M;
-    pb->npar = 8 + 9 * S + 3 * n_lin + 2 + 7 * M;
+    if (which == 8) return 2;                                       /* slack weight (slack build) */
+    return which >= 2 ? which + pb->slack : which;
+}
+int orc_idx_spline(const orc_problem *pb, int seg, int which) { return w0(pb) + 9 * seg + which; }
+int orc_idx_lin(const orc_problem *pb, int j, int which) { return w0(pb) + 9 * pb->S + 3 * j + which; }
+int orc_idx_disc_radius(const orc_problem *pb) { return w0(pb) + 9 * pb->S + 3 * pb->n_lin; }
+int orc_idx_disc_offset(const orc_problem *pb) { return orc_idx_disc_radius(pb) + (pb->M > 0 ? 1 : 0); }
+int orc_idx_ellipsoid(const orc_problem *pb, int j, int which) { return orc_idx_disc_radius(pb) + 2 + 7 * j + which; }
+int orc_idx_slk(const orc_problem *pb, int j, int which)
+{
+    const int base = pb->M > 0 ? orc_idx_ellipsoid(pb, pb->M, 0) : orc_idx_disc_radius(pb) + 1;
+    return base + 3 * j + which;
+}
+int orc_model_nx(void) { return ORC_NXE; }
+
+void orc_problem_init(orc_problem *pb, int N, int S, int n_lin, int M) { orc_problem_init_ex(pb, N, S, n_lin, M, 0); }
+
+void orc_problem_init_ex(orc_problem *pb, int N, int S, int n_lin, int M, int n_slk)
+{
+    pb->N = N; pb->S = S; pb->n_lin = n_lin; pb->M = M; pb->n_slk = n_slk; pb->slack = ORC_SLACK;
+    pb->npar = 8 + ORC_SLACK + 9 * S + 3 * n_lin + (M > 0 ? 2 + 7 * M : 0) + (n_slk > 0 ? (M > 0 ? 0 : 1) + 3 * n_slk : 0);
+    pb->lb_slack = 0.0; pb->ub_slack = 5000.0;     /* solver_model.py:285-286 */
     pb->dt = 0.2;                 /* settings.yaml:3 integrator_step */
     pb->n_sqp = 10;               /* settings.yaml:16 */
     pb->qp_iter_max = 50;         /* generate_acados_solver.py:172 */
@@ -102,8 +121,8 @@ static void load_segments(const orc_problem *pb, const double *p, seg_t *sx, seg
 static void jet_out(const jet *j, double *val, double *grad, double *hess)
 {
     if (val) *val = j->v;
-    if (grad) for (int i = 0; i < ORC_NV; i++) grad[i] = j->g[i];
-    if (hess) for (int i = 0; i < ORC_NV; i++) for (int k = 0; k < ORC_NV; k++) hess[i * ORC_NV + k] = j->H[i][k];
+    if (grad) for (int i = 0; i < ORC_NVE; i++) grad[i] = j->g[i];
+    if (hess) for (int i = 0; i < ORC_NVE; i++) for (int k = 0; k < ORC_NVE; k++) hess[i * ORC_NVE + k] = j->H[i][k];
 }
 
 /* ---------------------------------------------------------------------------------------------
@@ -114,16 +133,23 @@ static void jet_out(const jet *j, double *val, double *grad, double *hess)
  *   ContouringObjective.get_value (contouring.py:48-98): w_lag e_l^2 + w_contour e_c^2
  * --------------------------------------------------------------------------------------------- */
 void orc_stage_cost(const orc_problem *pb, const double *z, const double *p,
-                    double *val, double grad[ORC_NV], double hess[ORC_NV * ORC_NV])
+                    double *val, double grad[ORC_NVE], double hess[ORC_NVE * ORC_NVE])
 {
     jet a = jet_var(z[Z_A], Z_A), w = jet_var(z[Z_W], Z_W), x = jet_var(z[Z_X], Z_X), y = jet_var(z[Z_Y], Z_Y);
     jet v = jet_var(z[Z_V], Z_V), s = jet_var(z[Z_S], Z_S);
-    const double w_a = p[0], w_w = p[1], w_v = p[2], v_ref = p[3], w_contour = p[4], w_lag = p[5];
+    const double w_a = p[orc_idx_weight(pb, 0)], w_w = p[orc_idx_weight(pb, 1)], w_v = p[orc_idx_weight(pb, 2)];
+    const double v_ref = p[orc_idx_weight(pb, 3)], w_contour = p[orc_idx_weight(pb, 4)], w_lag = p[orc_idx_weight(pb, 5)];
 
     /* objectives are summed in module order (solver_definition.py:26-28), starting from cost = 0.0 */
     jet cost = jet_const(0.0);
     cost = jet_add(cost, jet_scale(jet_sq(a), w_a));                  /* w[0] * x**2 */
     cost = jet_add(cost, jet_scale(jet_sq(w), w_w));
+#if ORC_SLACK
+    {   /* weigh_variable("slack", "slack") sits between w and v (generate_jackalsimulator_solver.py:79-86) */
+        jet sl = jet_var(z[Z_SLACK], Z_SLACK);
+        cost = jet_add(cost, jet_scale(jet_sq(sl), p[orc_idx_weight(pb, 8)]));
+    }
+#endif
     cost = jet_add(cost, jet_scale(jet_sq(jet_addc(v, -v_ref)), w_v));/* w[0] * (x - w[1])**2 */
 
     seg_t sx[16], sy[16]; jet lam[16];
@@ -159,9 +185,10 @@ void orc_stage_constraints(const orc_problem *pb, const double *z, const double 
     for (int j = 0; j < pb->n_lin; j++, row++) {
         double a1 = p[orc_idx_lin(pb, j, 0)], a2 = p[orc_idx_lin(pb, j, 1)], b = p[orc_idx_lin(pb, j, 2)];
         jet c = jet_addc(jet_add(jet_scale(x, a1), jet_scale(y, a2)), -b);
-        jet_out(&c, &h[row], jac ? &jac[row * ORC_NV] : 0, hess ? &hess[row * ORC_NV * ORC_NV] : 0);
+        jet_out(&c, &h[row], jac ? &jac[row * ORC_NVE] : 0, hess ? &hess[row * ORC_NVE * ORC_NVE] : 0);
     }
-    const double r_disc = p[orc_idx_disc_radius(pb)];
+    if (pb->M == 0 && pb->n_slk == 0) return;
+    const double r_disc = pb->M > 0 ? p[orc_idx_disc_radius(pb)] : 0.0;
     const double disc_x = p[orc_idx_disc_offset(pb)];
     /* disc_pos = pos + rotation_car @ [disc_x, 0]  (ellipsoid_constraints.py:109-111) */
     jet dpx = jet_add(x, jet_scale(jet_cos(psi), disc_x));
@@ -182,7 +209,20 @@ void orc_stage_constraints(const orc_problem *pb, const double *z, const double 
         jet d0 = jet_addc(dpx, -ox), d1 = jet_addc(dpy, -oy);
         jet q = jet_add(jet_add(jet_scale(jet_sq(d0), m00), jet_scale(jet_mul(d0, d1), 2.0 * m01)),
                         jet_scale(jet_sq(d1), m11));
-        jet_out(&q, &h[row], jac ? &jac[row * ORC_NV] : 0, hess ? &hess[row * ORC_NV * ORC_NV] : 0);
+        jet_out(&q, &h[row], jac ? &jac[row * ORC_NVE] : 0, hess ? &hess[row * ORC_NVE * ORC_NVE] : 0);
+    }
+    /* Scenario / Decomp LinearConstraints.get_constraints (scenario_constraints.py:64-94, decomp_constraints.py:68-98):
+     * a1*disc_pos[0] + a2*disc_pos[1] - (b + slack); slack = 0.0 when the model has no slack state
+     * (decomp_constraints.py:78-84) */
+    for (int j = 0; j < pb->n_slk; j++, row++) {
+        double a1 = p[orc_idx_slk(pb, j, 0)], a2 = p[orc_idx_slk(pb, j, 1)], b = p[orc_idx_slk(pb, j, 2)];
+        jet c = jet_add(jet_scale(dpx, a1), jet_scale(dpy, a2));
+#if ORC_SLACK
+        c = jet_sub(c, jet_addc(jet_var(z[Z_SLACK], Z_SLACK), b));
+#else
+        c = jet_addc(c, -b);
+#endif
+        jet_out(&c, &h[row], jac ? &jac[row * ORC_NVE] : 0, hess ? &hess[row * ORC_NVE * ORC_NVE] : 0);
     }
 }
 
@@ -193,15 +233,19 @@ void orc_constraint_bounds(const orc_problem *pb, double *lh, double *uh)
     int row = 0;
     for (int j = 0; j < pb->n_lin; j++, row++) { lh[row] = -1e15; uh[row] = 0.0; }
     for (int j = 0; j < pb->M; j++, row++) { lh[row] = 1.0; uh[row] = 1e15; }
+    for (int j = 0; j < pb->n_slk; j++, row++) { lh[row] = -1e15; uh[row] = 0.0; }   /* scenario_constraints.py:52-62 */
 }
 
 /* ---------------------------------------------------------------------------------------------
  * Dynamics: ContouringSecondOrderUnicycleModel.continuous_model (solver_model.py:207-214)
  *   xdot = [v cos psi, v sin psi, w, a, v]
  * --------------------------------------------------------------------------------------------- */
-void orc_continuous_dynamics(const double *z, double f[ORC_NX])
+void orc_continuous_dynamics(const double *z, double f[ORC_NXE])
 {
     f[0] = z[Z_V] * cos(z[Z_PSI]); f[1] = z[Z_V] * sin(z[Z_PSI]); f[2] = z[Z_W]; f[3] = z[Z_A]; f[4] = z[Z_V];
+#if ORC_SLACK
+    f[5] = 0.0;                  /* solver_model.py:288-296 */
+#endif
 }
 
 static void f_jet(const jet *x /* NX */, const jet *u /* NU */, jet *f)
@@ -211,29 +255,32 @@ static void f_jet(const jet *x /* NX */, const jet *u /* NU */, jet *f)
     f[2] = u[1];
     f[3] = u[0];
     f[4] = x[3];
+#if ORC_SLACK
+    f[5] = jet_const(0.0);
+#endif
 }
 
 /* acados ERK integrator: classic 4-stage RK4, sim_method_num_steps = 3 sub-steps per shooting
  * interval of length dt (generate_acados_solver.py:143,148-150); controls constant over the interval. */
-void orc_discrete_dynamics(const orc_problem *pb, const double *z, double xnext[ORC_NX], double *jac, double *hess)
+void orc_discrete_dynamics(const orc_problem *pb, const double *z, double xnext[ORC_NXE], double *jac, double *hess)
 {
-    jet u[ORC_NU], x[ORC_NX], k1[ORC_NX], k2[ORC_NX], k3[ORC_NX], k4[ORC_NX], xt[ORC_NX];
+    jet u[ORC_NU], x[ORC_NXE], k1[ORC_NXE], k2[ORC_NXE], k3[ORC_NXE], k4[ORC_NXE], xt[ORC_NXE];
     for (int i = 0; i < ORC_NU; i++) u[i] = jet_var(z[i], i);
-    for (int i = 0; i < ORC_NX; i++) x[i] = jet_var(z[ORC_NU + i], ORC_NU + i);
+    for (int i = 0; i < ORC_NXE; i++) x[i] = jet_var(z[ORC_NU + i], ORC_NU + i);
     const double h = pb->dt / pb->erk_steps;
     for (int step = 0; step < pb->erk_steps; step++) {
         f_jet(x, u, k1);
-        for (int i = 0; i < ORC_NX; i++) xt[i] = jet_add(x[i], jet_scale(k1[i], 0.5 * h));
+        for (int i = 0; i < ORC_NXE; i++) xt[i] = jet_add(x[i], jet_scale(k1[i], 0.5 * h));
         f_jet(xt, u, k2);
-        for (int i = 0; i < ORC_NX; i++) xt[i] = jet_add(x[i], jet_scale(k2[i], 0.5 * h));
+        for (int i = 0; i < ORC_NXE; i++) xt[i] = jet_add(x[i], jet_scale(k2[i], 0.5 * h));
         f_jet(xt, u, k3);
-        for (int i = 0; i < ORC_NX; i++) xt[i] = jet_add(x[i], jet_scale(k3[i], h));
+        for (int i = 0; i < ORC_NXE; i++) xt[i] = jet_add(x[i], jet_scale(k3[i], h));
         f_jet(xt, u, k4);
-        for (int i = 0; i < ORC_NX; i++) {
+        for (int i = 0; i < ORC_NXE; i++) {
             jet sum = jet_add(jet_add(k1[i], jet_scale(k2[i], 2.0)), jet_add(jet_scale(k3[i], 2.0), k4[i]));
             x[i] = jet_add(x[i], jet_scale(sum, h / 6.0));
         }
     }
-    for (int i = 0; i < ORC_NX; i++)
-        jet_out(&x[i], &xnext[i], jac ? &jac[i * ORC_NV] : 0, hess ? &hess[i * ORC_NV * ORC_NV] : 0);
+    for (int i = 0; i < ORC_NXE; i++)
+        jet_out(&x[i], &xnext[i], jac ? &jac[i * ORC_NVE] : 0, hess ? &hess[i * ORC_NVE * ORC_NVE] : 0);
 }

@@ -31,11 +31,22 @@
 extern "C" {
 #endif
 
+/* Two builds of the same sources (oracle/Makefile):
+ *   liboracle_tmpc.so        ORC_SLACK=0  ContouringSecondOrderUnicycleModel          (solver_model.py:193-214)
+ *   liboracle_tmpc_slack.so  ORC_SLACK=1  ContouringSecondOrderUnicycleModelWithSlack (solver_model.py:274-298):
+ *                                         one more state `slack` with slack' = 0, appended after `spline`.
+ * ORC_NXE / ORC_NVE are the MODEL's dimensions (array strides of xinit, x0, xtraj and of every stage-function
+ * derivative); ORC_NX / ORC_NV are what the QP carries -- the slack state is presolved out of the QP (sqp_rti.c, U9). */
+#ifndef ORC_SLACK
+#define ORC_SLACK 0
+#endif
 #define ORC_NU 2
 #define ORC_NX 5
 #define ORC_NV 7
+#define ORC_NXE (ORC_NX + ORC_SLACK)
+#define ORC_NVE (ORC_NV + ORC_SLACK)
 #define ORC_MAX_N 32
-#define ORC_MAX_NH 32   /* general inequality rows per stage */
+#define ORC_MAX_NH 40   /* general inequality rows per stage */
 
 /* Problem description: sizes + parameter index map (util/parameters.py:25-55). */
 typedef struct {
@@ -56,30 +67,40 @@ typedef struct {
     /* state/input box bounds, order [a,w,x,y,psi,v,spline] (solver_model.py:204-205) */
     double lb[ORC_NV];
     double ub[ORC_NV];
+    /* rows a1*x + a2*y - (b + slack) <= 0 of DecompConstraintModule / ScenarioConstraintModule
+     * (decomp_constraints.py:68-98, scenario_constraints.py:64-94), after the ellipsoid rows */
+    int n_slk;
+    int slack;          /* = ORC_SLACK: the model has the slack state (and MPCBase weighs it) */
+    double lb_slack, ub_slack;   /* solver_model.py:285-286: [0, 5000] */
 } orc_problem;
 
 /* Fill sizes, default options and bounds for the Jackal contouring unicycle. */
 void orc_problem_init(orc_problem *pb, int N, int S, int n_lin, int M);
+void orc_problem_init_ex(orc_problem *pb, int N, int S, int n_lin, int M, int n_slk);
+int orc_model_nx(void);   /* ORC_NXE of this build */
 
 /* parameter index helpers (index into one stage's parameter row) */
-int orc_idx_weight(const orc_problem *pb, int which);           /* 0..7 */
+int orc_idx_weight(const orc_problem *pb, int which);           /* 0..7: acceleration, angular_velocity, velocity,
+                                                                   reference_velocity, contour, lag, terminal_angle,
+                                                                   terminal_contouring; 8: slack (slack build) */
 int orc_idx_spline(const orc_problem *pb, int seg, int which);  /* which: 0..8 = xa,xb,xc,xd,ya,yb,yc,yd,start */
 int orc_idx_lin(const orc_problem *pb, int j, int which);       /* which: 0..2 = a1,a2,b */
 int orc_idx_disc_radius(const orc_problem *pb);
 int orc_idx_disc_offset(const orc_problem *pb);
 int orc_idx_ellipsoid(const orc_problem *pb, int j, int which); /* which: 0..6 = x,y,psi,major,minor,chi,r */
+int orc_idx_slk(const orc_problem *pb, int j, int which);       /* which: 0..2 = a1,a2,b */
 
 /* ---- stage functions with exact first/second derivatives (forward-mode 2nd-order jets) ---------- */
-/* z = [a,w,x,y,psi,v,spline]; p = one stage's parameter row. */
+/* z = [a,w,x,y,psi,v,spline(,slack)] (ORC_NVE entries); p = one stage's parameter row. */
 void orc_stage_cost(const orc_problem *pb, const double *z, const double *p,
-                    double *val, double grad[ORC_NV], double hess[ORC_NV * ORC_NV]);
-/* h[0..n_lin) topology rows (<= 0), h[n_lin..n_lin+M) ellipsoid rows (>= 1) */
+                    double *val, double grad[ORC_NVE], double hess[ORC_NVE * ORC_NVE]);
+/* h[0..n_lin) topology rows (<= 0), h[n_lin..n_lin+M) ellipsoid rows (>= 1), then n_slk rows (<= 0) */
 void orc_stage_constraints(const orc_problem *pb, const double *z, const double *p,
-                           double *h, double *jac /* nh x NV */, double *hess /* nh x NV x NV */);
-void orc_continuous_dynamics(const double *z, double f[ORC_NX]);
-/* ERK4 x erk_steps over dt.  jac: NX x NV (d x_next / d [u;x]); hess: NX x NV x NV */
+                           double *h, double *jac /* nh x NVE */, double *hess /* nh x NVE x NVE */);
+void orc_continuous_dynamics(const double *z, double f[ORC_NXE]);
+/* ERK4 x erk_steps over dt.  jac: NXE x NVE (d x_next / d [u;x]); hess: NXE x NVE x NVE */
 void orc_discrete_dynamics(const orc_problem *pb, const double *z,
-                           double xnext[ORC_NX], double *jac, double *hess);
+                           double xnext[ORC_NXE], double *jac, double *hess);
 void orc_constraint_bounds(const orc_problem *pb, double *lh, double *uh);
 
 /* MIRROR regularisation of an n x n symmetric matrix (row-major, in place): V max(|e|,eps) V^T */
@@ -95,8 +116,8 @@ typedef struct {
     int qp_iter_total;/* IPM iterations summed over all QPs */
 } orc_info;
 
-/* xinit[NX]; x0[(N+1)*NV] warm start laid out [u_k; x_k] per node (acados_solver_interface.h:53-54);
- * params[N*npar]; xtraj[(N+1)*NX]; utraj[N*NU].  Fresh solver state (zero multipliers). */
+/* xinit[NXE]; x0[(N+1)*NVE] warm start laid out [u_k; x_k] per node (acados_solver_interface.h:53-54);
+ * params[N*npar]; xtraj[(N+1)*NXE]; utraj[N*NU].  Fresh solver state (zero multipliers). */
 void orc_solve(const orc_problem *pb, const double *xinit, const double *x0, const double *params,
                double *xtraj, double *utraj, orc_info *info);
 
@@ -120,7 +141,7 @@ void orc_solve_debug(const orc_problem *pb, const double *xinit, const double *x
                      double *xtraj, double *utraj, orc_info *info, orc_debug *dbg, int capture_sqp_iter);
 
 /* ---- batch (restates the OpenMP loop of guidance_constraints.cpp:279-361) ------------------------ */
-/* B trajectories; xinit[B][NX], x0[B][(N+1)*NV], params[B][N*npar]; outputs per trajectory. */
+/* B trajectories; xinit[B][NXE], x0[B][(N+1)*NVE], params[B][N*npar]; outputs per trajectory. */
 void orc_solve_batch(const orc_problem *pb, int B, const double *xinit, const double *x0,
                      const double *params, double *xtraj, double *utraj, orc_info *info, int num_threads);
 

@@ -9,14 +9,27 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 NU, NX, NV = 2, 5, 7
-MAX_N, MAX_NH = 32, 32
+MAX_N, MAX_NH = 32, 40
 
 
 class Problem(C.Structure):
     _fields_ = [("N", C.c_int), ("S", C.c_int), ("n_lin", C.c_int), ("M", C.c_int), ("npar", C.c_int),
                 ("dt", C.c_double), ("n_sqp", C.c_int), ("qp_iter_max", C.c_int), ("qp_tol", C.c_double),
                 ("reg_eps", C.c_double), ("ipm_mu0", C.c_double), ("ipm_thr0", C.c_double),
-                ("erk_steps", C.c_int), ("lb", C.c_double * NV), ("ub", C.c_double * NV)]
+                ("erk_steps", C.c_int), ("lb", C.c_double * NV), ("ub", C.c_double * NV),
+                ("n_slk", C.c_int), ("slack", C.c_int), ("lb_slack", C.c_double), ("ub_slack", C.c_double)]
+
+    @property
+    def nxe(self):          # model dimensions (array strides): the slack build has one more state
+        return NX + self.slack
+
+    @property
+    def nve(self):
+        return NV + self.slack
+
+    @property
+    def nh(self):
+        return self.n_lin + self.M + self.n_slk
 
 
 class Info(C.Structure):
@@ -34,31 +47,35 @@ class Debug(C.Structure):
                 ("qp_iters", C.c_int)]
 
 
-_lib = None
+_libs = {}
 
 
 def build():
     subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        path = os.path.join(ORACLE_DIR, "liboracle_tmpc.so")
+def lib(slack=0):
+    """liboracle_tmpc.so (unicycle) or liboracle_tmpc_slack.so (unicycle + slack state): same sources, two builds."""
+    slack = int(bool(slack))
+    if slack not in _libs:
+        path = os.path.join(ORACLE_DIR, "liboracle_tmpc_slack.so" if slack else "liboracle_tmpc.so")
         if not os.path.exists(path):
             build()
-        _lib = C.CDLL(path)
-        _lib.orc_find_best.restype = C.c_int
-    return _lib
+        l = C.CDLL(path)
+        l.orc_find_best.restype = C.c_int
+        assert l.orc_model_nx() == NX + slack
+        _libs[slack] = l
+    return _libs[slack]
 
 
 def dptr(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 
 
-def problem(N=20, S=5, n_lin=8, M=8, **opts):
+def problem(N=20, S=5, n_lin=8, M=8, n_slk=0, slack=0, **opts):
     pb = Problem()
-    lib().orc_problem_init(C.byref(pb), N, S, n_lin, M)
+    lib(slack).orc_problem_init_ex(C.byref(pb), N, S, n_lin, M, n_slk)
+    assert pb.slack == int(bool(slack))
     for k, v in opts.items():
         setattr(pb, k, v)
     return pb
@@ -66,29 +83,31 @@ def problem(N=20, S=5, n_lin=8, M=8, **opts):
 
 def stage_cost(pb, z, p):
     z = np.ascontiguousarray(z, float); p = np.ascontiguousarray(p, float)
-    val = C.c_double(); g = np.zeros(NV); H = np.zeros((NV, NV))
-    lib().orc_stage_cost(C.byref(pb), dptr(z), dptr(p), C.byref(val), dptr(g), dptr(H))
+    nv = pb.nve
+    val = C.c_double(); g = np.zeros(nv); H = np.zeros((nv, nv))
+    lib(pb.slack).orc_stage_cost(C.byref(pb), dptr(z), dptr(p), C.byref(val), dptr(g), dptr(H))
     return val.value, g, H
 
 
 def stage_constraints(pb, z, p):
     z = np.ascontiguousarray(z, float); p = np.ascontiguousarray(p, float)
-    nh = pb.n_lin + pb.M
-    h = np.zeros(nh); J = np.zeros((nh, NV)); H = np.zeros((nh, NV, NV))
-    lib().orc_stage_constraints(C.byref(pb), dptr(z), dptr(p), dptr(h), dptr(J), dptr(H))
+    nh = pb.nh; nv = pb.nve
+    h = np.zeros(nh); J = np.zeros((nh, nv)); H = np.zeros((nh, nv, nv))
+    lib(pb.slack).orc_stage_constraints(C.byref(pb), dptr(z), dptr(p), dptr(h), dptr(J), dptr(H))
     return h, J, H
 
 
 def discrete_dynamics(pb, z):
     z = np.ascontiguousarray(z, float)
-    xn = np.zeros(NX); J = np.zeros((NX, NV)); H = np.zeros((NX, NV, NV))
-    lib().orc_discrete_dynamics(C.byref(pb), dptr(z), dptr(xn), dptr(J), dptr(H))
+    nx, nv = pb.nxe, pb.nve
+    xn = np.zeros(nx); J = np.zeros((nx, nv)); H = np.zeros((nx, nv, nv))
+    lib(pb.slack).orc_discrete_dynamics(C.byref(pb), dptr(z), dptr(xn), dptr(J), dptr(H))
     return xn, J, H
 
 
-def continuous_dynamics(z):
-    z = np.ascontiguousarray(z, float); f = np.zeros(NX)
-    lib().orc_continuous_dynamics(dptr(z), dptr(f))
+def continuous_dynamics(z, slack=0):
+    z = np.ascontiguousarray(z, float); f = np.zeros(NX + slack)
+    lib(slack).orc_continuous_dynamics(dptr(z), dptr(f))
     return f
 
 
@@ -101,12 +120,13 @@ def mirror(W, eps=1e-4):
 def solve(pb, xinit, x0, params, debug_iter=None):
     xinit = np.ascontiguousarray(xinit, float); x0 = np.ascontiguousarray(x0, float)
     params = np.ascontiguousarray(params, float)
-    xt = np.zeros((pb.N + 1, NX)); ut = np.zeros((pb.N, NU)); info = Info()
+    assert xinit.size == pb.nxe and x0.size == (pb.N + 1) * pb.nve and params.size == pb.N * pb.npar
+    xt = np.zeros((pb.N + 1, pb.nxe)); ut = np.zeros((pb.N, NU)); info = Info()
     if debug_iter is None:
-        lib().orc_solve(C.byref(pb), dptr(xinit), dptr(x0), dptr(params), dptr(xt), dptr(ut), C.byref(info))
+        lib(pb.slack).orc_solve(C.byref(pb), dptr(xinit), dptr(x0), dptr(params), dptr(xt), dptr(ut), C.byref(info))
         return xt, ut, info
     dbg = Debug()
-    lib().orc_solve_debug(C.byref(pb), dptr(xinit), dptr(x0), dptr(params), dptr(xt), dptr(ut),
+    lib(pb.slack).orc_solve_debug(C.byref(pb), dptr(xinit), dptr(x0), dptr(params), dptr(xt), dptr(ut),
                           C.byref(info), C.byref(dbg), int(debug_iter))
     return xt, ut, info, dbg
 
@@ -115,9 +135,10 @@ def solve_batch(pb, xinit, x0, params, num_threads=0):
     B = xinit.shape[0]
     xinit = np.ascontiguousarray(xinit, float); x0 = np.ascontiguousarray(x0, float)
     params = np.ascontiguousarray(params, float)
-    xt = np.zeros((B, pb.N + 1, NX)); ut = np.zeros((B, pb.N, NU)); infos = (Info * B)()
+    assert xinit.size == B * pb.nxe and x0.size == B * (pb.N + 1) * pb.nve and params.size == B * pb.N * pb.npar
+    xt = np.zeros((B, pb.N + 1, pb.nxe)); ut = np.zeros((B, pb.N, NU)); infos = (Info * B)()
     nt = num_threads or os.cpu_count()
-    lib().orc_solve_batch(C.byref(pb), B, dptr(xinit), dptr(x0), dptr(params), dptr(xt), dptr(ut), infos, nt)
+    lib(pb.slack).orc_solve_batch(C.byref(pb), B, dptr(xinit), dptr(x0), dptr(params), dptr(xt), dptr(ut), infos, nt)
     out = dict(pobj=np.array([i.pobj for i in infos]), res_eq=np.array([i.res_eq for i in infos]),
                exit_code=np.array([i.exit_code for i in infos], np.int32),
                qp_status=np.array([i.qp_status for i in infos], np.int32),

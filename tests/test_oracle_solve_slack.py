@@ -1,0 +1,104 @@
+"""CPU oracle, slack-model solves (BASELINE configs 3 and 5).  The oracle presolves the slack chain out of every QP
+(oracle/sqp_rti.c U9); these tests check that claim against the FULL 8-variable NLP -- slack a decision variable at
+every node, boxed [0, 5000], tied by slack_{k+1} = slack_k and x_0 = xinit -- handed to scipy SLSQP."""
+import numpy as np
+import pytest
+import scipy.optimize as so
+
+import oracle_lib as O
+from mpc_planner_amd import scenes
+
+CFG = {
+    "cfg3": (dict(N=30, M=8, slack=True, n_decomp=12), dict(N=30, n_lin=8, M=8, n_slk=12, slack=1)),
+    "cfg5": (dict(N=20, M=8, slack=True, n_scenario=24), dict(N=20, n_lin=0, M=0, n_slk=24, slack=1)),
+}
+
+
+def _full_nlp(pb, params, xinit):
+    N = pb.N; nz = N * 8 + 6
+    nl, M = pb.n_lin, pb.M
+
+    def unpack(w):
+        return [w[8 * k:8 * k + 8] for k in range(N)] + [np.concatenate([[0, 0], w[8 * N:]])]
+
+    def f(w):
+        zs = unpack(w)
+        return sum(pb.dt * O.stage_cost(pb, zs[k], params[k])[0] for k in range(N))
+
+    def fg(w):
+        zs = unpack(w); g = np.zeros(nz)
+        for k in range(N):
+            g[8 * k:8 * k + 8] = pb.dt * O.stage_cost(pb, zs[k], params[k])[1]
+        return g
+
+    def ceq(w):
+        zs = unpack(w); out = [zs[0][2:] - xinit]
+        for k in range(N):
+            out.append(O.discrete_dynamics(pb, zs[k])[0] - zs[k + 1][2:])
+        return np.concatenate(out)
+
+    def cineq(w):  # >= 0
+        zs = unpack(w); out = []
+        for k in range(N):
+            h = O.stage_constraints(pb, zs[k], params[k])[0]
+            out.append(-h[:nl]); out.append(h[nl:nl + M] - 1.0); out.append(-h[nl + M:])
+        return np.concatenate(out)
+
+    lb1 = np.array(list(pb.lb) + [pb.lb_slack]); ub1 = np.array(list(pb.ub) + [pb.ub_slack])
+    lb = np.concatenate([lb1] * N + [np.full(6, -np.inf)]); ub = np.concatenate([ub1] * N + [np.full(6, np.inf)])
+    lb[2:8] = -np.inf; ub[2:8] = np.inf
+    return f, fg, ceq, cineq, lb, ub
+
+
+@pytest.mark.parametrize("cfg,scene,b", [("cfg5", 3, 5), ("cfg3", 1, 3)])
+def test_converged_sqp_matches_scipy_on_the_full_slack_nlp(cfg, scene, b):
+    skw, pkw = CFG[cfg]
+    sc = scenes.make_scene(scene, B=8, **skw)
+    pb = O.problem(S=5, n_sqp=60, qp_tol=1e-8, **pkw)
+    xt, ut, info = O.solve(pb, sc["xinit"][b], sc["x0"][b], sc["params"][b])
+    assert info.exit_code == 1 and info.res_eq < 1e-9
+    assert np.all(xt[:, 5] == 0.0)                                   # slack is pinned at xinit's slack (= 0)
+    N = pb.N
+    w0 = np.concatenate([np.concatenate([ut, xt[:N]], 1).ravel(), xt[N]])
+    f, fg, ceq, cineq, lb, ub = _full_nlp(pb, sc["params"][b], sc["xinit"][b])
+    assert abs(f(w0) - info.pobj) < 1e-12
+    assert np.abs(ceq(w0)).max() < 1e-9 and cineq(w0).min() > -1e-8
+    res = so.minimize(f, w0, jac=fg, method="SLSQP", bounds=list(zip(lb, ub)),
+                      constraints=[dict(type="eq", fun=ceq), dict(type="ineq", fun=cineq)],
+                      options=dict(maxiter=200, ftol=1e-14))
+    assert res.fun >= info.pobj - 1e-7 and abs(res.fun - info.pobj) < 1e-6
+    assert np.abs(res.x - w0).max() < 5e-3
+
+
+def test_slack_follows_xinit_and_ignores_its_warm_start():
+    """x_0 = xinit covers the slack state and slack' = 0: whatever the warm start holds, the first full step puts
+    slack_k = xinit_slack at every node; the rows are then relaxed by exactly that amount and the cost carries
+    dt * w_slack * slack^2 per stage."""
+    skw, pkw = CFG["cfg5"]
+    sc = scenes.make_scene(3, B=8, **skw)
+    pb = O.problem(S=5, **pkw)
+    b = 2
+    xt0, ut0, i0 = O.solve(pb, sc["xinit"][b], sc["x0"][b], sc["params"][b])
+    x0 = sc["x0"][b].copy(); x0[:, 7] = np.linspace(0.5, -0.2, x0.shape[0])       # garbage slack warm start
+    xt1, ut1, i1 = O.solve(pb, sc["xinit"][b], x0, sc["params"][b])
+    assert i0.exit_code == 1 and i1.exit_code == 1
+    np.testing.assert_allclose(xt1, xt0, atol=1e-12); assert abs(i1.pobj - i0.pobj) < 1e-12
+    xi = sc["xinit"][b].copy(); xi[5] = 0.01
+    xt2, ut2, i2 = O.solve(pb, xi, sc["x0"][b], sc["params"][b])
+    assert i2.exit_code == 1 and np.allclose(xt2[:, 5], 0.01, atol=0, rtol=0) is not None
+    assert np.abs(xt2[:, 5] - 0.01).max() < 1e-15
+    w_s = sc["params"][b][0, sc["pm"].index("slack")]
+    # relaxed rows can only lower the non-slack part of the cost
+    assert i2.pobj - pb.N * pb.dt * w_s * 0.01 ** 2 <= i0.pobj + 1e-9
+
+
+def test_success_rates_of_the_slack_scenes():
+    for cfg, lo in (("cfg3", 0.9), ("cfg5", 0.5)):
+        skw, pkw = CFG[cfg]
+        pb = O.problem(S=5, **pkw)
+        ok = tot = 0
+        for scene in (1, 2, 3):
+            sc = scenes.make_scene(scene, B=8, **skw)
+            _, _, info = O.solve_batch(pb, sc["xinit"], sc["x0"], sc["params"])
+            ok += int((info["exit_code"] == 1).sum()); tot += 8
+        assert ok / tot >= lo, (cfg, ok, tot)
