@@ -17,7 +17,10 @@
  *   params [B][N*npar]        AcadosParameters::all_parameters   (:56), row k = stage k, node N reuses row N-1
  *   xtraj  [B][(N+1)*nx]      AcadosOutput::xtraj                (:129)
  *   utraj  [B][N*nu]          AcadosOutput::utraj                (:130)
- * nx = 5, nu = 2, nvar = 7 (ContouringSecondOrderUnicycleModel, solver_generator/solver_model.py:193-214).
+ * nx = 5, nu = 2, nvar = 7 (ContouringSecondOrderUnicycleModel, solver_generator/solver_model.py:193-214), or
+ * nx = 6, nvar = 8 with dims.slack = 1 (ContouringSecondOrderUnicycleModelWithSlack, solver_model.py:274-298: the
+ * slack state is the last column).  acados pins that state (x_0 = xinit covers it and slack' = 0), so the solve
+ * treats it as the constant xinit[5]: the slack column of x0 is ignored, xtraj returns xinit[5] in it.
  *
  * Error convention: every function returns 0 on success, <0 on error (TMPC_ERR_*); tmpc_last_error()
  * gives the message.  Per-trajectory solver outcomes use the reference's Forces-style exit codes
@@ -49,7 +52,8 @@ typedef struct tmpc_dims {
     int32_t S;            /* contouring/num_segments */
     int32_t n_lin;        /* topology halfspace rows per stage (max_obstacles + add_halfspaces; 0 = no guidance module) */
     int32_t M;            /* ellipsoid rows per stage (max_obstacles, n_discs = 1) */
-    int32_t npar;         /* parameters per stage; must equal 8 + 9 S + 3 n_lin + 2 + 7 M */
+    int32_t npar;         /* parameters per stage; must equal the reference's count for these modules:
+                             8 + slack + 9 S + 3 n_lin + (M ? 2 + 7 M : 0) + (n_slk ? (M ? 0 : 1) + 3 n_slk : 0) */
     int32_t n_sqp;        /* solver_settings/acados/iterations (RTI iterations per solve) */
     int32_t qp_iter_max;  /* qp_solver_iter_max = 50 */
     int32_t erk_steps;    /* sim_method_num_steps = 3 (ERK4) */
@@ -60,12 +64,18 @@ typedef struct tmpc_dims {
     double ipm_thr0;      /* interior-point initial slack floor (0.01) */
     double lb[TMPC_NV];   /* model bounds, order [a,w,x,y,psi,v,spline] (solver_model.py:204-205) */
     double ub[TMPC_NV];
+    int32_t n_slk;        /* decomp / scenario halfspace rows a1 x + a2 y - (b + slack) <= 0 per stage
+                             (decomp_constraints.py:68-98, scenario_constraints.py:64-94); scenario rows first */
+    int32_t slack;        /* 1: slack model (nx = 6, nvar = 8; MPCBase weighs the slack state) */
 } tmpc_dims;
 
 typedef struct tmpc_handle tmpc_handle;
 
 /* Defaults for the Jackal contouring unicycle (settings.yaml + generate_acados_solver.py). */
 void tmpc_default_dims(tmpc_dims *d, int32_t N, int32_t S, int32_t n_lin, int32_t M);
+/* Same with decomp / scenario rows and the slack model (configuration_safe_horizon,
+ * generate_jackalsimulator_solver.py:67-90; rosnavigation configuration_tmpc, generate_rosnavigation_solver.py:86-108). */
+void tmpc_default_dims_ex(tmpc_dims *d, int32_t N, int32_t S, int32_t n_lin, int32_t M, int32_t n_slk, int32_t slack);
 
 /* Replaces Solver_acados_create_capsule + Solver_acados_create_with_discretization
  * (acados_solver_interface.cpp:17,33) for B_max solver instances at once.  Owns device buffers + stream. */

@@ -88,7 +88,7 @@ namespace MPCPlanner
     {
         if (_handle) return;
         tmpc_dims d;
-        tmpc_default_dims(&d, SOLVER_N, SOLVER_S, SOLVER_NLIN, SOLVER_M);
+        tmpc_default_dims_ex(&d, SOLVER_N, SOLVER_S, SOLVER_NLIN, SOLVER_M, SOLVER_NSLK, SOLVER_SLACK);
         d.n_sqp = _num_iterations; d.dt = dt;
         for (auto &e : _model_map) { d.lb[e.second.index] = e.second.lb; d.ub[e.second.index] = e.second.ub; }
         int status = tmpc_create(&_handle, &d, 1, _device);
@@ -142,7 +142,7 @@ namespace MPCPlanner
         Solver *s0 = solvers[0];
         if (!batch_handle || batch_cap < B) {
             if (batch_handle) tmpc_destroy(batch_handle);
-            tmpc_dims d; tmpc_default_dims(&d, SOLVER_N, SOLVER_S, SOLVER_NLIN, SOLVER_M);
+            tmpc_dims d; tmpc_default_dims_ex(&d, SOLVER_N, SOLVER_S, SOLVER_NLIN, SOLVER_M, SOLVER_NSLK, SOLVER_SLACK);
             d.n_sqp = s0->_num_iterations; d.dt = s0->dt;
             for (auto &e : s0->_model_map) { d.lb[e.second.index] = e.second.lb; d.ub[e.second.index] = e.second.ub; }
             if (tmpc_create(&batch_handle, &d, B, 0)) { std::printf("tmpc_create() failed. Exiting.\n"); std::exit(1); }

@@ -31,7 +31,7 @@ __device__ __forceinline__ Lds carve_fast(double *s, const Dims &d)
 {
     Lds L;
     const int N = d.N;
-    L.nh = d.n_lin + d.M;
+    L.nh = d.n_up + d.M;
     L.NG = N * L.nh; L.GB = L.NG; L.XB = L.NG + 4 * N; L.nrows = L.XB + 10 * (N - 1);
     auto take = [&](int n) { double *p = s; s += n; return p; };
     L.z = take((N + 1) * NV); L.pi = take((N + 1) * NX); L.W = take((N + 1) * NP28); L.g = take((N + 1) * NV);
@@ -86,7 +86,7 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
         sb[s] = 0.0; didx[s] = N * NH * 3;
         if (stage_lane && r < NR) {
             if (r < NH) {
-                const double sgn = (r < NLIN) ? -1.0 : 1.0;     // topology rows: upper bound 0; ellipsoids: lower bound 1
+                const double sgn = (r < NLIN) ? -1.0 : 1.0;     // topology / slack rows: upper bound 0; ellipsoids: lower bound 1
                 didx[s] = (k * NH + r) * 3;
                 if (r < NLIN) neg |= 1u << s;
                 sb[s] = sgn * L.beta[k * NH + r];
@@ -341,10 +341,14 @@ __global__ __launch_bounds__(NT) void tmpc_solve_fast_kernel(Dims d, int B, cons
     if (b >= B) return;
     const Lds L = carve_fast(smem, d);
     const int N = d.N;
-    const double *xi = xinit + (size_t)b * NX;
+    const double *xi = xinit + (size_t)b * ext_nx(d);
     const double *pb = params + (size_t)b * N * d.npar;
+    const double slack = d.slack ? xi[NX] : 0.0;              // pinned by x_0 = xinit and slack' = 0 (tmpc_stage.hpp)
 
-    for (int e = tid; e < (N + 1) * NV; e += NT) L.z[e] = x0[(size_t)b * (N + 1) * NV + e];
+    for (int e = tid; e < (N + 1) * NV; e += NT) {
+        const int k = e / NV, i = e - k * NV;
+        L.z[e] = x0[((size_t)b * (N + 1) + k) * ext_nv(d) + i];
+    }
     for (int e = tid; e < (N + 1) * NX; e += NT) L.pi[e] = 0.0;
     for (int e = tid; e < N * C::NH; e += NT) L.lamh[e] = 0.0;
     if (tid < 3) L.D[N * C::NH * 3 + tid] = 0.0;      // zero triple read by box rows
@@ -359,7 +363,7 @@ __global__ __launch_bounds__(NT) void tmpc_solve_fast_kernel(Dims d, int B, cons
     double lam[C::RPL];
     for (int it = 0; it < d.n_sqp; it++) {
         pf.start();
-        linearise<true>(L, d, tid, pb);
+        linearise<true>(L, d, tid, pb, slack);
         __syncthreads();
         pf.stop(PH_LIN);
         int iters = 0;
@@ -388,7 +392,7 @@ __global__ __launch_bounds__(NT) void tmpc_solve_fast_kernel(Dims d, int B, cons
         __syncthreads();
         if (qp_status != 0) break;
     }
-    solve_epilogue(L, d, tid, b, xi, pb, status, qp_status, sqp_iter, qp_iter_total, xtraj, utraj, pobj, exit_code,
+    solve_epilogue(L, d, tid, b, xi, pb, slack, status, qp_status, sqp_iter, qp_iter_total, xtraj, utraj, pobj, exit_code,
                    qp_status_out, sqp_iter_out, res_eq_out, qp_iter_out, prof_out, pf, t_begin);
 }
 

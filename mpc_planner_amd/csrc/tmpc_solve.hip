@@ -58,7 +58,7 @@ __device__ __forceinline__ Lds carve(double *s, const Dims &d)
 {
     Lds L;
     const int N = d.N;
-    L.nh = d.n_lin + d.M;
+    L.nh = d.n_up + d.M;
     L.NG = N * L.nh; L.GB = L.NG; L.XB = L.NG + 4 * N; L.nrows = L.XB + 10 * (N - 1);
     auto take = [&](int n) { double *p = s; s += n; return p; };
     L.z = take((N + 1) * NV); L.pi = take((N + 1) * NX); L.W = take((N + 1) * NP28); L.g = take((N + 1) * NV);
@@ -100,7 +100,7 @@ __device__ __forceinline__ Row row_decode(const Lds &L, const Dims &d, int r)
     Row R;
     if (r < L.NG) {
         R.k = r / L.nh; const int j = r - R.k * L.nh;
-        R.general = r; R.var = -1; R.sgn = (j < d.n_lin) ? -1.0 : 1.0;   // topology rows: upper 0; ellipsoids: lower 1
+        R.general = r; R.var = -1; R.sgn = (j < d.n_up) ? -1.0 : 1.0;    // topology / slack rows: upper 0; ellipsoids: lower 1
     } else if (r < L.XB) {
         const int q = r - L.GB;
         R.k = q >> 2; R.var = (q >> 1) & 1; R.general = -1; R.sgn = (q & 1) ? -1.0 : 1.0;
@@ -437,7 +437,7 @@ __device__ void build_rhs(const Lds &L, const Dims &d, int tid, bool predictor)
             const double *vk = L.v + k * NV;
             for (int j = 0; j < L.nh; j++) {
                 const int r = k * L.nh + j;
-                const double sgn = (j < d.n_lin) ? -1.0 : 1.0;
+                const double sgn = (j < d.n_up) ? -1.0 : 1.0;
                 const double *Dr = L.D + r * 3;
                 const double cv = Dr[0] * vk[ZX] + Dr[1] * vk[ZY] + Dr[2] * vk[ZPSI];
                 const double rd = sgn * (cv - L.beta[r]) - L.t[r];
@@ -502,7 +502,7 @@ __device__ int ipm_solve(const Lds &L, const Dims &d, int tid, int *iters_out, P
                 if (k < N && i >= ZX && i <= ZPSI)
                     for (int j = 0; j < L.nh; j++) {
                         const int r = k * L.nh + j;
-                        const double sgn = (j < d.n_lin) ? -1.0 : 1.0;
+                        const double sgn = (j < d.n_up) ? -1.0 : 1.0;
                         acc -= sgn * L.lam[r] * L.D[r * 3 + i - ZX];
                     }
             }
@@ -629,7 +629,7 @@ __device__ int ipm_solve(const Lds &L, const Dims &d, int tid, int *iters_out, P
 
 // ---- stage linearisation by lane k --------------------------------------------------------------
 template <bool FAST>
-__device__ void linearise(const Lds &L, const Dims &d, int tid, const double *params)
+__device__ void linearise(const Lds &L, const Dims &d, int tid, const double *params, double slack)
 {
     const int N = d.N;
     // Every lane runs the (register-hungry) stage evaluation with the full EXEC mask -- lanes >= N redo stage N-1 and
@@ -647,18 +647,18 @@ __device__ void linearise(const Lds &L, const Dims &d, int tid, const double *pa
         const int nh = L.nh;
         auto lamh = [&](int r) {                            // (lam_upper - lam_lower) of the previous QP
             if (FAST) return L.lamh[k * nh + r];
-            const double sgn = (r < d.n_lin) ? -1.0 : 1.0;
+            const double sgn = (r < d.n_up) ? -1.0 : 1.0;
             return -sgn * L.lam[k * nh + r];
         };
         auto sink = [&](int r, const RowOut &ro) {
             if (owner) {
                 double *Dr = L.D + (k * nh + r) * 3;
                 Dr[0] = ro.gx; Dr[1] = ro.gy; Dr[2] = ro.gp;
-                const double bound = (r < d.n_lin) ? 0.0 : 1.0;
+                const double bound = (r < d.n_up) ? 0.0 : 1.0;
                 L.beta[k * nh + r] = bound - ro.h;
             }
         };
-        stage_linearise(d, z, p, 1, L.pi[(k + 1) * NX + 0], L.pi[(k + 1) * NX + 1], lamh, sink, W, g, BA, xn);
+        stage_linearise(d, z, p, 1, L.pi[(k + 1) * NX + 0], L.pi[(k + 1) * NX + 1], lamh, sink, W, g, BA, xn, slack);
         // everything but W leaves the registers BEFORE the register-hungry MIRROR
         if (owner) {
 #pragma unroll
@@ -688,7 +688,7 @@ __device__ void linearise(const Lds &L, const Dims &d, int tid, const double *pa
 }
 
 // ---- completeOneIteration (acados_solver_interface.cpp:162-204): cost, trajectories, res_eq, exit-code mapping ----
-__device__ void solve_epilogue(const Lds &L, const Dims &d, int tid, int b, const double *xi, const double *pb, int status,
+__device__ void solve_epilogue(const Lds &L, const Dims &d, int tid, int b, const double *xi, const double *pb, double slack, int status,
                                int qp_status, int sqp_iter, int qp_iter_total, double *xtraj, double *utraj, double *pobj,
                                int *exit_code, int *qp_status_out, int *sqp_iter_out, double *res_eq_out, int *qp_iter_out,
                                long long *prof_out, Prof &pf, long long t_begin)
@@ -704,7 +704,7 @@ __device__ void solve_epilogue(const Lds &L, const Dims &d, int tid, int b, cons
 #pragma unroll
         for (int i = 0; i < NV; i++) z[i] = L.z[ks * NV + i];
         CostOut co;
-        cost_eval(d, z, pb + (size_t)ks * d.npar, 1, co, false);
+        cost_eval(d, z, pb + (size_t)ks * d.npar, 1, co, false, slack);
         DynOut dy;
         dyn_eval(d, z, dy, false);
         double r = 0.0;
@@ -716,9 +716,10 @@ __device__ void solve_epilogue(const Lds &L, const Dims &d, int tid, int b, cons
     asm volatile("" : "+v"(tid_o));
     if (tid_o < NX) res = fmax(res, fabs(L.z[NU + tid_o] - xi[tid_o]));
     cost = wave_sum(cost); res = wave_max(res);
-    for (int e = tid_o; e < (N + 1) * NX; e += NT) {
-        const int k = e / NX, i = e - k * NX;
-        xtraj[(size_t)b * (N + 1) * NX + e] = L.z[k * NV + NU + i];
+    const int nxe = ext_nx(d);
+    for (int e = tid_o; e < (N + 1) * nxe; e += NT) {
+        const int k = e / nxe, i = e - k * nxe;
+        xtraj[(size_t)b * (N + 1) * nxe + e] = i < NX ? L.z[k * NV + NU + i] : slack;      // the pinned slack state
     }
     for (int e = tid_o; e < N * NU; e += NT) {
         const int k = e / NU, i = e - k * NU;
@@ -752,11 +753,15 @@ __global__ __launch_bounds__(NT) void tmpc_solve_kernel(Dims d, int B, const dou
     if (b >= B) return;
     const Lds L = carve(smem, d);
     const int N = d.N;
-    const double *xi = xinit + (size_t)b * NX;
+    const double *xi = xinit + (size_t)b * ext_nx(d);
     const double *pb = params + (size_t)b * N * d.npar;
+    const double slack = d.slack ? xi[NX] : 0.0;              // pinned by x_0 = xinit and slack' = 0 (tmpc_stage.hpp)
 
     // loadWarmstart (acados_solver_interface.cpp:274-284); fresh multipliers
-    for (int e = tid; e < (N + 1) * NV; e += NT) L.z[e] = x0[(size_t)b * (N + 1) * NV + e];
+    for (int e = tid; e < (N + 1) * NV; e += NT) {
+        const int k = e / NV, i = e - k * NV;
+        L.z[e] = x0[((size_t)b * (N + 1) + k) * ext_nv(d) + i];
+    }
     for (int e = tid; e < (N + 1) * NX; e += NT) L.pi[e] = 0.0;
     for (int r = tid; r < L.nrows; r += NT) L.lam[r] = 0.0;
     __syncthreads();
@@ -769,7 +774,7 @@ __global__ __launch_bounds__(NT) void tmpc_solve_kernel(Dims d, int B, const dou
     int status = 0, qp_status = 0, sqp_iter = 0, qp_iter_total = 0;
     for (int it = 0; it < d.n_sqp; it++) {
         pf.start();
-        linearise<false>(L, d, tid, pb);
+        linearise<false>(L, d, tid, pb, slack);
         // QP primal start: dz = 0 except dx_0 = xinit - x_0; duals 0
         for (int e = tid; e < (N + 1) * NV; e += NT) L.v[e] = 0.0;
         for (int e = tid; e < (N + 1) * NX; e += NT) L.pq[e] = 0.0;
@@ -792,7 +797,7 @@ __global__ __launch_bounds__(NT) void tmpc_solve_kernel(Dims d, int B, const dou
         if (qp_status != 0) break;
     }
 
-    solve_epilogue(L, d, tid, b, xi, pb, status, qp_status, sqp_iter, qp_iter_total, xtraj, utraj, pobj, exit_code,
+    solve_epilogue(L, d, tid, b, xi, pb, slack, status, qp_status, sqp_iter, qp_iter_total, xtraj, utraj, pobj, exit_code,
                    qp_status_out, sqp_iter_out, res_eq_out, qp_iter_out, prof_out, pf, t_begin);
 }
 
@@ -876,7 +881,7 @@ __global__ void tmpc_linearize_topology_kernel(Dims d, int B, const double *x0, 
     const double dummy_b = state_x[sc] + 100.0;                         // _dummy_b (:54)
     const bool dummy = (k == 0) || (is_original && is_original[b]);
     const double r = 1e-3 + robot_radius;                               // guidance mode radius (:99)
-    double px = x0[((size_t)b * (N + 1) + k) * NV + ZX], py = x0[((size_t)b * (N + 1) + k) * NV + ZY];
+    double px = x0[((size_t)b * (N + 1) + k) * ext_nv(d) + ZX], py = x0[((size_t)b * (N + 1) + k) * ext_nv(d) + ZY];
     const double *ob = obst + (size_t)sc * d.n_lin * N * 2;
     if (!dummy) {
         for (int sweep = 0; sweep < 3; sweep++)                         // projectToSafety: at most 3 iterations (:137)
@@ -911,12 +916,15 @@ __global__ void tmpc_debug_eval_kernel(Dims d, int n, const double *z, const dou
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n) return;
-    const int nh = d.n_lin + d.M;
-    const double *ze = z + (size_t)e * NV; const double *pe = p + (size_t)e * d.npar;
+    const int nh = d.n_up + d.M;
+    const double *ze = z + (size_t)e * ext_nv(d); const double *pe = p + (size_t)e * d.npar;
     double zz[NV];
     for (int i = 0; i < NV; i++) zz[i] = ze[i];
+    const double slack = d.slack ? ze[NV] : 0.0;
+    // rows are reported in the reference's order [topology | ellipsoids | slack rows] (module order)
+    auto ext = [&](int r) { return r < d.n_lin ? r : (r < d.n_up ? d.M + r : r - d.n_slk); };
     CostOut co;
-    cost_eval(d, zz, pe, 1, co, true);
+    cost_eval(d, zz, pe, 1, co, true, slack);
     cost[e] = co.val;
     double Wc[NV][NV];
     for (int i = 0; i < NV; i++) for (int j = 0; j < NV; j++) Wc[i][j] = 0.0;
@@ -926,14 +934,14 @@ __global__ void tmpc_debug_eval_kernel(Dims d, int n, const double *z, const dou
         for (int j = 0; j < NV; j++) chess[(size_t)e * NV * NV + i * NV + j] = Wc[i][j];
     }
     double W[NV][NV], g[NV], BA[NX * NV], xn[NX];
-    auto lam = [&](int r) { return lamh ? lamh[(size_t)e * nh + r] : 0.0; };
+    auto lam = [&](int r) { return lamh ? lamh[(size_t)e * nh + ext(r)] : 0.0; };
     auto sink = [&](int r, const RowOut &ro) {
-        hval[(size_t)e * nh + r] = ro.h;
-        double *J = hjac + ((size_t)e * nh + r) * NV;
+        hval[(size_t)e * nh + ext(r)] = ro.h;
+        double *J = hjac + ((size_t)e * nh + ext(r)) * NV;
         for (int i = 0; i < NV; i++) J[i] = 0.0;
         J[ZX] = ro.gx; J[ZY] = ro.gy; J[ZPSI] = ro.gp;
     };
-    stage_linearise(d, zz, pe, 1, pi ? pi[(size_t)e * NX] : 0.0, pi ? pi[(size_t)e * NX + 1] : 0.0, lam, sink, W, g, BA, xn);
+    stage_linearise(d, zz, pe, 1, pi ? pi[(size_t)e * NX] : 0.0, pi ? pi[(size_t)e * NX + 1] : 0.0, lam, sink, W, g, BA, xn, slack);
     for (int i = 0; i < NX; i++) xnext[(size_t)e * NX + i] = xn[i];
     for (int i = 0; i < NX * NV; i++) xjac[(size_t)e * NX * NV + i] = BA[i];
     for (int i = 0; i < NV; i++) for (int j = 0; j < NV; j++) lag[(size_t)e * NV * NV + i * NV + j] = W[i][j];
@@ -949,7 +957,7 @@ __global__ void tmpc_debug_eval_kernel(Dims d, int n, const double *z, const dou
 namespace tmpc {
 typedef void (*SolveKernel)(Dims, int, const double *, const double *, const double *, double *, double *, double *, int *,
                             int *, int *, double *, int *, long long *);
-// Registered fast shapes (n_lin, M) x lanes-per-stage; anything else runs the generic kernel.
+// Registered fast shapes (upper-bounded rows n_lin + n_slk, ellipsoids M) x lanes-per-stage; anything else runs the generic kernel.
 // Only instantiations that compile WITHOUT scratch (zero VGPR spills) are registered: __graft_entry__.build() checks
 // the compiler's resource remarks and fails otherwise.  Reason: with > ~100 spilled VGPRs this kernel was observed to
 // return wrong iterates (spill/reload around partially-masked regions), see DESIGN.md section 5.  Shapes with more rows
@@ -960,15 +968,16 @@ static SolveKernel pick_fast_kernel(const Dims &d)
     if (getenv("TMPC_FORCE_GENERIC")) return nullptr;
     const int lps = (3 * d.N <= NT) ? 3 : ((2 * d.N <= NT) ? 2 : 0);
     if (lps == 3) {
-        if (d.n_lin == 0 && d.M == 4) return tmpc_solve_fast_kernel<0, 4, 3>;
-        if (d.n_lin == 8 && d.M == 8) return tmpc_solve_fast_kernel<8, 8, 3>;
-        if (d.n_lin == 12 && d.M == 12) return tmpc_solve_fast_kernel<12, 12, 3>;     // zero scratch only with machine-LICM off (build flag)
+        if (d.n_up == 0 && d.M == 4) return tmpc_solve_fast_kernel<0, 4, 3>;
+        if (d.n_up == 8 && d.M == 8) return tmpc_solve_fast_kernel<8, 8, 3>;
+        if (d.n_up == 12 && d.M == 12) return tmpc_solve_fast_kernel<12, 12, 3>;      // zero scratch only with machine-LICM off (build flag)
+        if (d.n_up == 24 && d.M == 0) return tmpc_solve_fast_kernel<24, 0, 3>;        // SH-MPC: 24 scenario halfspaces (cfg 5)
     } else if (lps == 2) {
-        if (d.n_lin == 0 && d.M == 4) return tmpc_solve_fast_kernel<0, 4, 2>;
+        if (d.n_up == 0 && d.M == 4) return tmpc_solve_fast_kernel<0, 4, 2>;
     }
 #ifdef TMPC_TRY_ALL      // compile-only probe of candidate shapes (resource remarks); never dispatched in the shipped build
-    if (d.n_lin == 8 && d.M == 8 && lps == 2) return tmpc_solve_fast_kernel<8, 8, 2>;
-    if (d.n_lin == 12 && d.M == 12 && lps == 2) return tmpc_solve_fast_kernel<12, 12, 2>;
+    if (d.n_up == 8 && d.M == 8 && lps == 2) return tmpc_solve_fast_kernel<8, 8, 2>;
+    if (d.n_up == 12 && d.M == 12 && lps == 2) return tmpc_solve_fast_kernel<12, 12, 2>;
 #endif
     return nullptr;
 }
@@ -1004,11 +1013,14 @@ struct tmpc_handle {
 
 extern "C" {
 
-void tmpc_default_dims(tmpc_dims *d, int32_t N, int32_t S, int32_t n_lin, int32_t M)
+void tmpc_default_dims(tmpc_dims *d, int32_t N, int32_t S, int32_t n_lin, int32_t M) { tmpc_default_dims_ex(d, N, S, n_lin, M, 0, 0); }
+
+void tmpc_default_dims_ex(tmpc_dims *d, int32_t N, int32_t S, int32_t n_lin, int32_t M, int32_t n_slk, int32_t slack)
 {
     memset(d, 0, sizeof *d);
-    d->N = N; d->S = S; d->n_lin = n_lin; d->M = M;
-    d->npar = 8 + 9 * S + 3 * n_lin + 2 + 7 * M;
+    d->N = N; d->S = S; d->n_lin = n_lin; d->M = M; d->n_slk = n_slk; d->slack = slack ? 1 : 0;
+    tmpc::Dims t; t.S = S; t.n_lin = n_lin; t.M = M; t.n_slk = n_slk; t.slack = d->slack;
+    d->npar = tmpc::expected_npar(t);
     d->n_sqp = 10; d->qp_iter_max = 50; d->erk_steps = 3;
     d->dt = 0.2; d->qp_tol = 1e-5; d->reg_eps = 1e-4; d->ipm_mu0 = 0.01; d->ipm_thr0 = 0.01;
     const double lb[TMPC_NV] = {-2.0, -0.8, -2000.0, -2000.0, -M_PI * 4, -0.01, -1.0};
@@ -1022,22 +1034,26 @@ int tmpc_create(tmpc_handle **out, const tmpc_dims *dims, int32_t B_max, int32_t
 {
     if (!out || !dims || B_max <= 0) return TMPC_ERR_INVALID;
     *out = nullptr;
-    if (dims->N < 2 || dims->N > 62 || dims->S < 1 || dims->M < 0 || dims->n_lin < 0 ||
-        dims->npar != 8 + 9 * dims->S + 3 * dims->n_lin + 2 + 7 * dims->M || dims->erk_steps < 1)
-        return TMPC_ERR_INVALID;
+    {
+        tmpc::Dims t; t.S = dims->S; t.n_lin = dims->n_lin; t.M = dims->M; t.n_slk = dims->n_slk; t.slack = dims->slack;
+        if (dims->N < 2 || dims->N > 62 || dims->S < 1 || dims->M < 0 || dims->n_lin < 0 || dims->n_slk < 0 ||
+            (dims->slack != 0 && dims->slack != 1) || dims->npar != tmpc::expected_npar(t) || dims->erk_steps < 1)
+            return TMPC_ERR_INVALID;
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return TMPC_ERR_NO_DEVICE;
     tmpc_handle *h = new tmpc_handle();
     h->device = device; h->B_max = B_max;
     tmpc::Dims &d = h->d;
     d.N = dims->N; d.S = dims->S; d.n_lin = dims->n_lin; d.M = dims->M; d.npar = dims->npar;
+    d.n_slk = dims->n_slk; d.slack = dims->slack; d.n_up = d.n_lin + d.n_slk;
     d.n_sqp = dims->n_sqp; d.qp_iter_max = dims->qp_iter_max; d.erk_steps = dims->erk_steps;
     d.dt = dims->dt; d.qp_tol = dims->qp_tol; d.reg_eps = dims->reg_eps; d.mu0 = dims->ipm_mu0; d.thr0 = dims->ipm_thr0;
     for (int i = 0; i < TMPC_NV; i++) { d.lb[i] = dims->lb[i]; d.ub[i] = dims->ub[i]; }
     h->kernel = tmpc::pick_fast_kernel(d);
     h->fast = h->kernel != nullptr;
-    if (h->fast) h->lds_bytes = sizeof(double) * (size_t)tmpc::lds_doubles_fast(d.N, d.n_lin + d.M);
-    else { h->kernel = tmpc::tmpc_solve_kernel; h->lds_bytes = sizeof(double) * (size_t)tmpc::lds_doubles(d.N, d.n_lin + d.M); }
+    if (h->fast) h->lds_bytes = sizeof(double) * (size_t)tmpc::lds_doubles_fast(d.N, d.n_up + d.M);
+    else { h->kernel = tmpc::tmpc_solve_kernel; h->lds_bytes = sizeof(double) * (size_t)tmpc::lds_doubles(d.N, d.n_up + d.M); }
     auto fail = [&](int code) { delete h; return code; };
     if (hipSetDevice(device) != hipSuccess) return fail(TMPC_ERR_HIP);
     if (h->lds_bytes > 160 * 1024) return fail(TMPC_ERR_INVALID);
@@ -1047,10 +1063,11 @@ int tmpc_create(tmpc_handle **out, const tmpc_dims *dims, int32_t B_max, int32_t
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return fail(TMPC_ERR_HIP);
     const size_t N = d.N, B = B_max;
     bool ok = true;
-    ok &= hipMalloc(&h->o_xinit, B * tmpc::NX * 8) == hipSuccess;
-    ok &= hipMalloc(&h->o_x0, B * (N + 1) * tmpc::NV * 8) == hipSuccess;
+    const size_t nxe = tmpc::ext_nx(d), nve = tmpc::ext_nv(d);
+    ok &= hipMalloc(&h->o_xinit, B * nxe * 8) == hipSuccess;
+    ok &= hipMalloc(&h->o_x0, B * (N + 1) * nve * 8) == hipSuccess;
     ok &= hipMalloc(&h->o_params, B * N * d.npar * 8) == hipSuccess;
-    ok &= hipMalloc(&h->xtraj, B * (N + 1) * tmpc::NX * 8) == hipSuccess;
+    ok &= hipMalloc(&h->xtraj, B * (N + 1) * nxe * 8) == hipSuccess;
     ok &= hipMalloc(&h->utraj, B * N * tmpc::NU * 8) == hipSuccess;
     ok &= hipMalloc(&h->pobj, B * 8) == hipSuccess;
     ok &= hipMalloc(&h->res_eq, B * 8) == hipSuccess;
@@ -1086,8 +1103,8 @@ int tmpc_set_batch(tmpc_handle *h, int32_t B, const double *xinit, const double 
     if (!h || B <= 0 || B > h->B_max || !xinit || !x0 || !params) { if (h) h->err = "tmpc_set_batch: bad argument"; return TMPC_ERR_INVALID; }
     TMPC_HIP_CHECK(h, hipSetDevice(h->device));
     const size_t N = h->d.N;
-    TMPC_HIP_CHECK(h, hipMemcpyAsync(h->o_xinit, xinit, (size_t)B * tmpc::NX * 8, hipMemcpyHostToDevice, h->stream));
-    TMPC_HIP_CHECK(h, hipMemcpyAsync(h->o_x0, x0, (size_t)B * (N + 1) * tmpc::NV * 8, hipMemcpyHostToDevice, h->stream));
+    TMPC_HIP_CHECK(h, hipMemcpyAsync(h->o_xinit, xinit, (size_t)B * tmpc::ext_nx(h->d) * 8, hipMemcpyHostToDevice, h->stream));
+    TMPC_HIP_CHECK(h, hipMemcpyAsync(h->o_x0, x0, (size_t)B * (N + 1) * tmpc::ext_nv(h->d) * 8, hipMemcpyHostToDevice, h->stream));
     TMPC_HIP_CHECK(h, hipMemcpyAsync(h->o_params, params, (size_t)B * N * h->d.npar * 8, hipMemcpyHostToDevice, h->stream));
     h->xinit = h->o_xinit; h->x0 = h->o_x0; h->params = h->o_params; h->B = B;
     return TMPC_OK;
@@ -1128,7 +1145,7 @@ int tmpc_get(tmpc_handle *h, double *xtraj, double *utraj, double *pobj, int32_t
     TMPC_HIP_CHECK(h, hipSetDevice(h->device));
     const size_t N = h->d.N, B = h->B;
     auto cp = [&](void *dst, const void *src, size_t n) { return dst ? hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, h->stream) : hipSuccess; };
-    TMPC_HIP_CHECK(h, cp(xtraj, h->xtraj, B * (N + 1) * tmpc::NX * 8));
+    TMPC_HIP_CHECK(h, cp(xtraj, h->xtraj, B * (N + 1) * tmpc::ext_nx(h->d) * 8));
     TMPC_HIP_CHECK(h, cp(utraj, h->utraj, B * N * tmpc::NU * 8));
     TMPC_HIP_CHECK(h, cp(pobj, h->pobj, B * 8));
     TMPC_HIP_CHECK(h, cp(res_eq, h->res_eq, B * 8));
@@ -1283,8 +1300,8 @@ int tmpc_debug_eval_stage(tmpc_handle *h, int32_t n, const double *z, const doub
 {
     if (!h || n <= 0 || !z || !p) return TMPC_ERR_INVALID;
     TMPC_HIP_CHECK(h, hipSetDevice(h->device));
-    const int nh = h->d.n_lin + h->d.M;
-    const size_t sz_in[4] = {(size_t)n * 7 * 8, (size_t)n * h->d.npar * 8, (size_t)n * 5 * 8, (size_t)n * nh * 8};
+    const int nh = h->d.n_up + h->d.M;
+    const size_t sz_in[4] = {(size_t)n * tmpc::ext_nv(h->d) * 8, (size_t)n * h->d.npar * 8, (size_t)n * 5 * 8, (size_t)n * nh * 8};
     const void *src[4] = {z, p, pi, lamh};
     double *din[4] = {nullptr, nullptr, nullptr, nullptr};
     for (int i = 0; i < 4; i++) {

@@ -7,7 +7,17 @@
 //   cost       mpc_planner_modules/scripts/mpc_base.py:47-60, contouring.py:48-98, solver_generator/spline.py:28-77
 //   rows h     mpc_planner_modules/scripts/guidance_constraints.py:95-110, ellipsoid_constraints.py:65-119
 //   MIRROR     regularize_method (generate_acados_solver.py:157)
+//   rows h     ... decomp_constraints.py:68-98, scenario_constraints.py:64-94 (halfspaces relaxed by the slack state)
 // z = [a, w, x, y, psi, v, spline] (inputs first: solver_model.py:118-128).
+//
+// Slack model (ContouringSecondOrderUnicycleModelWithSlack, solver_model.py:274-298: one more state with slack' = 0).
+// acados fixes every state at node 0 (ocp.constraints.x0, generate_acados_solver.py:95) and the slack state has no
+// dynamics, so each QP pins it: after any full step slack_k = xinit_slack at every node, whatever the warm start held.
+// The kernels therefore carry the 7 variables above and treat slack as the per-trajectory constant xinit[5]: it
+// relaxes the decomp / scenario rows, adds dt * w_slack * slack^2 per stage to the objective, and is written back into
+// the 6th state column of the outputs.  (Exact: the QP is strictly convex after MIRROR, so substituting the pinned
+// chain does not change its solution; the CPU oracle does the same substitution and tests/test_oracle_solve_slack.py
+// checks it against the full 8-variable NLP.)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -21,17 +31,34 @@ struct Dims {
     int N, S, n_lin, M, npar, n_sqp, qp_iter_max, erk_steps;
     double dt, qp_tol, reg_eps, mu0, thr0;
     double lb[NV], ub[NV];
+    int n_slk;      // decomp / scenario halfspace rows  a1 x + a2 y - (b + slack) <= 0
+    int slack;      // 1: slack model (nx = 6, nvar = 8 in the external layouts; MPCBase weighs the slack)
+    int n_up;       // upper-bounded general rows = n_lin + n_slk.  Internal row order: [topology | slack rows | ellipsoids]
 };
+__host__ __device__ __forceinline__ int ext_nx(const Dims &d) { return NX + d.slack; }   // strides of xinit / xtraj
+__host__ __device__ __forceinline__ int ext_nv(const Dims &d) { return NV + d.slack; }   // stride of x0
 
 // packed lower-triangular index of a symmetric 7x7: (i >= j)
 __host__ __device__ __forceinline__ constexpr int pidx(int i, int j) { return i * (i + 1) / 2 + j; }
 __host__ __device__ __forceinline__ constexpr int sidx(int i, int j) { return i >= j ? pidx(i, j) : pidx(j, i); }
 
 // ---- parameter index map (reference rule: util/parameters.py:25-55, solver_definition.py:5-16) ----------
-__device__ __forceinline__ int ip_spline(int seg, int which) { return 8 + 9 * seg + which; }
-__device__ __forceinline__ int ip_lin(const Dims &d, int j, int which) { return 8 + 9 * d.S + 3 * j + which; }
-__device__ __forceinline__ int ip_disc_radius(const Dims &d) { return 8 + 9 * d.S + 3 * d.n_lin; }
-__device__ __forceinline__ int ip_ellipsoid(const Dims &d, int j, int which) { return ip_disc_radius(d) + 2 + 7 * j + which; }
+// weights: acceleration, angular_velocity, [slack,] velocity, reference_velocity, contour, lag, terminal_angle,
+// terminal_contouring; then 9 per spline segment; topology rows; [ego_disc_radius, ego_disc_0_offset, 7 per ellipsoid];
+// [ego_disc_0_offset unless the ellipsoid module defined it,] 3 per slack row (scenario rows before decomp rows).
+__host__ __device__ __forceinline__ int ip_spline(const Dims &d, int seg, int which) { return 8 + d.slack + 9 * seg + which; }
+__host__ __device__ __forceinline__ int ip_lin(const Dims &d, int j, int which) { return 8 + d.slack + 9 * d.S + 3 * j + which; }
+__host__ __device__ __forceinline__ int ip_disc_radius(const Dims &d) { return 8 + d.slack + 9 * d.S + 3 * d.n_lin; }
+__host__ __device__ __forceinline__ int ip_disc_offset(const Dims &d) { return ip_disc_radius(d) + (d.M > 0 ? 1 : 0); }
+__host__ __device__ __forceinline__ int ip_ellipsoid(const Dims &d, int j, int which) { return ip_disc_radius(d) + 2 + 7 * j + which; }
+__host__ __device__ __forceinline__ int ip_slk(const Dims &d, int j, int which)
+{
+    return (d.M > 0 ? ip_disc_radius(d) + 2 + 7 * d.M : ip_disc_radius(d) + 1) + 3 * j + which;
+}
+__host__ __device__ __forceinline__ int expected_npar(const Dims &d)
+{
+    return 8 + d.slack + 9 * d.S + 3 * d.n_lin + (d.M > 0 ? 2 + 7 * d.M : 0) + (d.n_slk > 0 ? (d.M > 0 ? 0 : 1) + 3 * d.n_slk : 0);
+}
 
 // =============================================================================================
 // Dynamics.  For xdot = [v cos psi, v sin psi, w, a, v] with inputs held constant, RK4's k2 and k3 see
@@ -132,17 +159,19 @@ __device__ __forceinline__ J1 seg_deriv(double a, double b, double c, double t)
 struct CostOut { double val; double g[NV]; double Hxx, Hxy, Hyy, Hxs, Hys, Hss, Haa, Hww, Hvv; };
 
 // p: this stage's parameter row, element i at p[i * pstride]
+// slack: the trajectory's (constant) slack value, 0 without the slack model
 __device__ __forceinline__ void cost_eval(const Dims &d, const double *z, const double *p, int pstride, CostOut &o,
-                                          bool derivs)
+                                          bool derivs, double slack = 0.0)
 {
     auto P = [&](int i) { return p[(size_t)i * pstride]; };
-    const double w_a = P(0), w_w = P(1), w_v = P(2), v_ref = P(3), w_contour = P(4), w_lag = P(5);
+    const int ws = d.slack;
+    const double w_a = P(0), w_w = P(1), w_v = P(2 + ws), v_ref = P(3 + ws), w_contour = P(4 + ws), w_lag = P(5 + ws);
     const double a = z[ZA], w = z[ZW], x = z[ZX], y = z[ZY], v = z[ZV], s = z[ZS];
 
     // glued spline (spline.py:28-50): value = seg[S-1]; for k = S-1..1: value = lam_k seg[k-1] + (1-lam_k) value,
     // the same blend for values and for segment derivatives.
     const int S = d.S;
-    int base = ip_spline(S - 1, 0);
+    int base = ip_spline(d, S - 1, 0);
     double t = s - P(base + 8);
     J1 X = seg_at(P(base + 0), P(base + 1), P(base + 2), P(base + 3), t);
     J1 Y = seg_at(P(base + 4), P(base + 5), P(base + 6), P(base + 7), t);
@@ -150,13 +179,13 @@ __device__ __forceinline__ void cost_eval(const Dims &d, const double *z, const 
     J1 DY = seg_deriv(P(base + 4), P(base + 5), P(base + 6), t);
     for (int k = S - 1; k >= 1; k--) {
         // lambda_k = 1/(1+exp((s - start_k + 0.02)/0.1))  (spline.py:37), overflow-safe derivatives
-        const double u = (s - P(ip_spline(k, 8)) + 0.02) / 0.1;
+        const double u = (s - P(ip_spline(d, k, 8)) + 0.02) / 0.1;
         const double sig = 1.0 / (1.0 + exp(u));
         const double sig1 = -sig * (1.0 - sig);                 // d sig / du
         const double sig2 = sig1 * (2.0 * sig - 1.0);           // d2 sig / du2
         const J1 lam = {sig, sig1 * 10.0, sig2 * 100.0};
         const J1 oml = {1.0 - sig, -lam.d1, -lam.d2};
-        base = ip_spline(k - 1, 0);
+        base = ip_spline(d, k - 1, 0);
         t = s - P(base + 8);
         X = j_add(j_mul(lam, seg_at(P(base + 0), P(base + 1), P(base + 2), P(base + 3), t)), j_mul(oml, X));
         Y = j_add(j_mul(lam, seg_at(P(base + 4), P(base + 5), P(base + 6), P(base + 7), t)), j_mul(oml, Y));
@@ -176,6 +205,7 @@ __device__ __forceinline__ void cost_eval(const Dims &d, const double *z, const 
     const double el = tx.v * ex + ty.v * ey;          // contouring.py:75
     const double dv = v - v_ref;
     o.val = w_a * a * a + w_w * w * w + w_v * dv * dv + w_lag * el * el + w_contour * ec * ec;
+    if (ws) o.val += P(2) * slack * slack;                  // weigh_variable("slack") (generate_jackalsimulator_solver.py:79)
     if (!derivs) return;
 
     // gradients / Hessians of e_c, e_l in (x, y, s)
@@ -251,6 +281,19 @@ __device__ __forceinline__ void ellipsoid_row_eval(const Dims &d, const double *
     o.Hxp = 2.0 * (m00 * qx + m01 * qy);
     o.Hyp = 2.0 * (m01 * qx + m11 * qy);
     o.Hpp = 2.0 * (m00 * qx * qx + 2.0 * m01 * qx * qy + m11 * qy * qy) - gx * qy + gy * qx;
+}
+
+// decomp / scenario halfspace (decomp_constraints.py:86-96, scenario_constraints.py:82-92):
+//   a1 (x + off cos psi) + a2 (y + off sin psi) - (b + slack)  <= 0
+__device__ __forceinline__ void slk_row_eval(const Dims &d, const double *z, const double *p, int pstride, int j, double off,
+                                             double spsi, double cpsi, double slack, RowOut &o)
+{
+    const double a1 = p[(size_t)ip_slk(d, j, 0) * pstride], a2 = p[(size_t)ip_slk(d, j, 1) * pstride];
+    const double b = p[(size_t)ip_slk(d, j, 2) * pstride];
+    o.h = a1 * (z[ZX] + off * cpsi) + a2 * (z[ZY] + off * spsi) - (b + slack);
+    o.gx = a1; o.gy = a2; o.gp = off * (a2 * cpsi - a1 * spsi);
+    o.Hxx = o.Hxy = o.Hyy = o.Hxp = o.Hyp = 0.0;
+    o.Hpp = -off * (a1 * cpsi + a2 * spsi);
 }
 
 __device__ __forceinline__ void row_add_hessian(const RowOut &o, double scale, double (*W)[NV])
@@ -399,10 +442,11 @@ __device__ __forceinline__ void mirror7(double (*A)[NV], double eps)
 
 // Lagrangian Hessian of one stage (before MIRROR): dt*hess(l) + pi_x hess(x+) + pi_y hess(y+) + sum_r lamh_r hess(h_r),
 // plus the linearisation data of the stage.  lamh(r) is supplied by a functor (zero for inactive rows).
+// Rows are numbered in the kernels' internal order [topology | slack rows | ellipsoids] (upper-bounded rows first).
 template <typename LamH, typename RowSink>
 __device__ __forceinline__ void stage_linearise(const Dims &d, const double *z, const double *p, int pstride,
                                                 double pix, double piy, LamH lamh, RowSink sink,
-                                                double (*W)[NV], double *g, double *BA, double *xn)
+                                                double (*W)[NV], double *g, double *BA, double *xn, double slack = 0.0)
 {
 #pragma unroll
     for (int i = 0; i < NV; i++)
@@ -415,7 +459,7 @@ __device__ __forceinline__ void stage_linearise(const Dims &d, const double *z, 
     for (int i = 0; i < NX; i++) xn[i] = dy.xn[i];
     dyn_add_hessian(dy, pix, piy, W);
     CostOut co;
-    cost_eval(d, z, p, pstride, co, true);
+    cost_eval(d, z, p, pstride, co, true, slack);
 #pragma unroll
     for (int i = 0; i < NV; i++) g[i] = d.dt * co.g[i];          // stage cost scaled by the shooting interval
     cost_add_hessian(co, d.dt, W);
@@ -424,13 +468,19 @@ __device__ __forceinline__ void stage_linearise(const Dims &d, const double *z, 
         lin_row_eval(d, z, p, pstride, j, ro);
         sink(j, ro);
     }
-    const double r_disc = p[(size_t)ip_disc_radius(d) * pstride], off = p[(size_t)(ip_disc_radius(d) + 1) * pstride];
+    if (d.M == 0 && d.n_slk == 0) return;
+    const double r_disc = d.M > 0 ? p[(size_t)ip_disc_radius(d) * pstride] : 0.0, off = p[(size_t)ip_disc_offset(d) * pstride];
     double spsi, cpsi;
     sincos(z[ZPSI], &spsi, &cpsi);
+    for (int j = 0; j < d.n_slk; j++) {
+        slk_row_eval(d, z, p, pstride, j, off, spsi, cpsi, slack, ro);
+        W[ZPSI][ZPSI] += lamh(d.n_lin + j) * ro.Hpp;              // the row is linear in (x, y); psi enters through the disc offset
+        sink(d.n_lin + j, ro);
+    }
     for (int j = 0; j < d.M; j++) {
         ellipsoid_row_eval(d, z, p, pstride, j, r_disc, off, spsi, cpsi, ro);
-        row_add_hessian(ro, lamh(d.n_lin + j), W);
-        sink(d.n_lin + j, ro);
+        row_add_hessian(ro, lamh(d.n_up + j), W);
+        sink(d.n_up + j, ro);
     }
 }
 

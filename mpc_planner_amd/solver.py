@@ -19,10 +19,23 @@ class TmpcDims(C.Structure):
     _fields_ = [("N", C.c_int32), ("S", C.c_int32), ("n_lin", C.c_int32), ("M", C.c_int32), ("npar", C.c_int32),
                 ("n_sqp", C.c_int32), ("qp_iter_max", C.c_int32), ("erk_steps", C.c_int32),
                 ("dt", C.c_double), ("qp_tol", C.c_double), ("reg_eps", C.c_double), ("ipm_mu0", C.c_double),
-                ("ipm_thr0", C.c_double), ("lb", C.c_double * NV), ("ub", C.c_double * NV)]
+                ("ipm_thr0", C.c_double), ("lb", C.c_double * NV), ("ub", C.c_double * NV),
+                ("n_slk", C.c_int32), ("slack", C.c_int32)]
+
+    @property
+    def nx(self):            # external (model) state / variable counts: the slack model has one more state
+        return NX + self.slack
+
+    @property
+    def nvar(self):
+        return NV + self.slack
+
+    @property
+    def nh(self):
+        return self.n_lin + self.M + self.n_slk
 
 
-EXPORTS = ["tmpc_default_dims", "tmpc_create", "tmpc_destroy", "tmpc_last_error", "tmpc_set_batch",
+EXPORTS = ["tmpc_default_dims", "tmpc_default_dims_ex", "tmpc_create", "tmpc_destroy", "tmpc_last_error", "tmpc_set_batch",
            "tmpc_set_batch_device", "tmpc_solve", "tmpc_synchronize", "tmpc_get", "tmpc_select_best",
            "tmpc_result_device_ptrs", "tmpc_time_solve", "tmpc_debug_eval_stage", "tmpc_pack_records",
            "tmpc_select_best_records", "tmpc_enable_timing", "tmpc_get_timings", "tmpc_debug_profile",
@@ -48,6 +61,7 @@ def load_library():
         lib.tmpc_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(TmpcDims), C.c_int32, C.c_int32]
         lib.tmpc_destroy.argtypes = [C.c_void_p]
         lib.tmpc_default_dims.argtypes = [C.POINTER(TmpcDims), C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+        lib.tmpc_default_dims_ex.argtypes = [C.POINTER(TmpcDims)] + [C.c_int32] * 6
         vp = C.c_void_p
         lib.tmpc_set_batch.argtypes = [vp, C.c_int32, vp, vp, vp]
         lib.tmpc_set_batch_device.argtypes = [vp, C.c_int32, vp, vp, vp]
@@ -69,9 +83,9 @@ def load_library():
     return _lib
 
 
-def default_dims(N=20, S=5, n_lin=8, M=8, **opts):
+def default_dims(N=20, S=5, n_lin=8, M=8, n_slk=0, slack=0, **opts):
     d = TmpcDims()
-    load_library().tmpc_default_dims(C.byref(d), N, S, n_lin, M)
+    load_library().tmpc_default_dims_ex(C.byref(d), N, S, n_lin, M, n_slk, int(bool(slack)))
     for k, v in opts.items():
         setattr(d, k, v)
     return d
@@ -112,11 +126,13 @@ class BatchedSolver:
 
     # --- inputs -----------------------------------------------------------------------------------
     def set_batch(self, xinit, x0, params):
-        """Host arrays: xinit [B][5], x0 [B][N+1][7], params [B][N][npar] (reference layouts)."""
+        """Host arrays: xinit [B][nx], x0 [B][N+1][nvar], params [B][N][npar] (reference layouts; nx, nvar = 5, 7 or,
+        with the slack model, 6, 8)."""
         xinit = np.ascontiguousarray(xinit, np.float64); x0 = np.ascontiguousarray(x0, np.float64)
         params = np.ascontiguousarray(params, np.float64)
         B = xinit.shape[0]
-        assert xinit.shape == (B, NX) and x0.size == B * (self.N + 1) * NV and params.size == B * self.N * self.npar
+        assert xinit.shape == (B, self.dims.nx) and x0.size == B * (self.N + 1) * self.dims.nvar \
+            and params.size == B * self.N * self.npar
         self._keep = (xinit, x0, params)
         self._check(self.lib.tmpc_set_batch(self._h, B, _p(xinit), _p(x0), _p(params)), "tmpc_set_batch")
         self.B = B
@@ -144,7 +160,7 @@ class BatchedSolver:
     # --- outputs ----------------------------------------------------------------------------------
     def get(self):
         B, N = self.B, self.N
-        out = dict(xtraj=np.zeros((B, N + 1, NX)), utraj=np.zeros((B, N, NU)), pobj=np.zeros(B),
+        out = dict(xtraj=np.zeros((B, N + 1, self.dims.nx)), utraj=np.zeros((B, N, NU)), pobj=np.zeros(B),
                    exit_code=np.zeros(B, np.int32), qp_status=np.zeros(B, np.int32), sqp_iter=np.zeros(B, np.int32),
                    res_eq=np.zeros(B), qp_iter_total=np.zeros(B, np.int32))
         self._check(self.lib.tmpc_get(self._h, _p(out["xtraj"]), _p(out["utraj"]), _p(out["pobj"]), _p(out["exit_code"]),
@@ -206,9 +222,9 @@ class BatchedSolver:
         return dict(zip(self.PHASES, cyc.tolist()))
 
     def debug_eval_stage(self, z, p, pi=None, lamh=None):
-        z = np.ascontiguousarray(z, np.float64).reshape(-1, NV); n = z.shape[0]
+        z = np.ascontiguousarray(z, np.float64).reshape(-1, self.dims.nvar); n = z.shape[0]
         p = np.ascontiguousarray(p, np.float64).reshape(n, self.npar)
-        nh = self.dims.n_lin + self.dims.M
+        nh = self.dims.nh            # rows in the reference's order [topology | ellipsoids | decomp/scenario rows]
         pi = None if pi is None else np.ascontiguousarray(pi, np.float64).reshape(n, NX)
         lamh = None if lamh is None else np.ascontiguousarray(lamh, np.float64).reshape(n, nh)
         o = dict(cost=np.zeros(n), cost_grad=np.zeros((n, NV)), cost_hess=np.zeros((n, NV, NV)), h=np.zeros((n, nh)),

@@ -41,9 +41,19 @@ def test_cpp_solver_plumbing():
     assert out.returncode == 0 and "plumbing ok" in out.stdout, out.stdout + out.stderr
 
 
+def _stale():
+    if not os.path.exists(BIN):
+        return True
+    cpp = os.path.join(ROOT, "mpc_planner_amd", "cpp")
+    deps = [os.path.join(ROOT, "include", "tmpc_hip.h"), os.path.join(cpp, "include", "mpc_planner_solver", "solver_interface.h"),
+            os.path.join(cpp, "src", "solver_interface.cpp"), os.path.join(ROOT, "tests", "cpp", "test_solver.cpp"),
+            os.path.join(ROOT, "mpc_planner_amd", "libtmpc_hip.so")]
+    return any(os.path.getmtime(d) > os.path.getmtime(BIN) for d in deps)
+
+
 @pytest.mark.gpu
 def test_cpp_solver_solve_and_batch():
-    if not os.path.exists(BIN):
+    if _stale():
         _build()
     out = subprocess.run([BIN, os.path.join(GEN, "config"), "--solve"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "solve ok" in out.stdout, out.stdout + out.stderr

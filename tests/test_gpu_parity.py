@@ -21,9 +21,9 @@ def gold():
         return json.load(fh)
 
 
-def _solver(N=20, S=5, n_lin=8, M=8, B_max=64, **opts):
+def _solver(N=20, S=5, n_lin=8, M=8, B_max=64, n_slk=0, slack=0, **opts):
     from mpc_planner_amd import solver
-    return solver.BatchedSolver(solver.default_dims(N=N, S=S, n_lin=n_lin, M=M, **opts), B_max=B_max)
+    return solver.BatchedSolver(solver.default_dims(N=N, S=S, n_lin=n_lin, M=M, n_slk=n_slk, slack=slack, **opts), B_max=B_max)
 
 
 def test_stage_functions_match_reference_golden(gold):
@@ -251,3 +251,77 @@ def test_fast_and_generic_kernels_agree():
         assert (a[k][ok] == b[k][ok]).all(), k
     np.testing.assert_allclose(a["xtraj"][ok], b["xtraj"][ok], rtol=0, atol=1e-8)
     np.testing.assert_allclose(a["pobj"][ok], b["pobj"][ok], rtol=1e-9)
+
+
+# ---- slack model: BASELINE configs 3 (rosnavigation T-MPC: guidance + ellipsoids + decomp rows) and 5 (SH-MPC) --------
+SLACK_CFG = {
+    "cfg3": (dict(N=30, M=8, slack=True, n_decomp=12), dict(N=30, n_lin=8, M=8, n_slk=12, slack=1)),
+    "cfg5": (dict(N=20, M=8, slack=True, n_scenario=24), dict(N=20, n_lin=0, M=0, n_slk=24, slack=1)),
+}
+
+
+def test_slack_stage_functions_match_reference_golden():
+    """Device stage functions of the slack-model configurations vs the reference's own python (make_golden_slack.py).
+    The kernels carry 7 variables and treat slack as a per-trajectory constant, so the 7x7 blocks are compared and the
+    slack column of the reference derivatives is checked to be what that treatment assumes (-1 / diagonal)."""
+    with open(os.path.join(HERE, "golden", "stage_functions_slack.json")) as fh:
+        cases = json.load(fh)["cases"]
+    for case in cases:
+        s = _solver(N=case["N"], n_lin=case["n_lin"], M=case["M"], n_slk=case["n_scen"] + case["n_dec"], slack=1, B_max=4)
+        assert s.npar == case["npar"]
+        o = s.debug_eval_stage(case["z"], case["p"])
+        J = np.array(case["h_jac"]); H = np.array(case["cost_hess"]); nl, M = case["n_lin"], case["M"]
+        assert np.all(J[nl + M:, 7] == -1.0) and np.all(J[:nl + M, 7] == 0.0) and np.all(H[7, :7] == 0.0)
+        np.testing.assert_allclose(o["cost"][0], case["cost"], rtol=1e-11)
+        np.testing.assert_allclose(o["cost_grad"][0], case["cost_grad"][:7], rtol=1e-10, atol=1e-11)
+        np.testing.assert_allclose(o["cost_hess"][0], H[:7, :7], rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(o["h"][0], case["h"], rtol=1e-11, atol=1e-12)
+        np.testing.assert_allclose(o["h_jac"][0], J[:, :7], rtol=1e-10, atol=1e-11)
+        np.testing.assert_allclose(o["x_next"][0], case["x_next"][:5], rtol=1e-13, atol=1e-14)
+        np.testing.assert_allclose(o["x_jac"][0], np.array(case["x_next_jac"])[:5, :7], rtol=1e-11, atol=1e-13)
+        rng = np.random.default_rng(6)
+        pi = rng.normal(size=5); lam = rng.normal(size=case["nh"])
+        o2 = s.debug_eval_stage(case["z"], case["p"], pi=pi, lamh=lam)
+        ref = 0.2 * H + np.tensordot(pi, np.array(case["x_next_hess"])[:5], 1) + np.tensordot(lam, np.array(case["h_hess"]), 1)
+        np.testing.assert_allclose(o2["lag_hess"][0], ref[:7, :7], rtol=1e-9, atol=1e-10)
+        s.close()
+
+
+@pytest.mark.parametrize("cfg,scenes_,B", [("cfg5", (1, 2, 3, 5), 32), ("cfg3", (1, 2), 16)])
+def test_slack_model_solve_matches_oracle(cfg, scenes_, B):
+    """cfg 5: SH-MPC, 24 scenario halfspaces from 8 obstacles x 256 scenarios per stage, 32 guidance trajectories
+    (fast kernel <24,0,3>); cfg 3: slack model + guidance + ellipsoids + 12 decomp rows, N = 30 (generic kernel)."""
+    import oracle_lib as O
+    from mpc_planner_amd import scenes
+    skw, pkw = SLACK_CFG[cfg]
+    s = _solver(S=5, B_max=B, **pkw)
+    pb = O.problem(S=5, **pkw)
+    n_ok = 0
+    for scene in scenes_:
+        sc = scenes.make_scene(scene, B=B, **skw)
+        s.set_batch(sc["xinit"], sc["x0"], sc["params"]); s.solve(); got = s.get()
+        xt, ut, info = O.solve_batch(pb, sc["xinit"], sc["x0"].reshape(B, -1), sc["params"].reshape(B, -1))
+        _compare(got, xt, ut, info)
+        assert np.all(got["xtraj"][:, :, 5] == 0.0)                 # the pinned slack state
+        assert s.select_best() == O.find_best(info["pobj"], info["exit_code"])
+        n_ok += int((info["exit_code"] == 1).sum())
+    assert n_ok >= B
+    s.close()
+
+
+def test_slack_value_comes_from_xinit():
+    """xinit's slack entry relaxes the scenario rows and is what xtraj reports; the slack warm start is irrelevant."""
+    import oracle_lib as O
+    from mpc_planner_amd import scenes
+    skw, pkw = SLACK_CFG["cfg5"]
+    B = 16
+    sc = scenes.make_scene(3, B=B, **skw)
+    xinit = sc["xinit"].copy(); xinit[:, 5] = np.linspace(0.0, 0.02, B)
+    x0 = sc["x0"].copy(); x0[:, :, 7] = 0.3
+    s = _solver(S=5, B_max=B, **pkw)
+    s.set_batch(xinit, x0, sc["params"]); s.solve(); got = s.get()
+    pb = O.problem(S=5, **pkw)
+    xt, ut, info = O.solve_batch(pb, xinit, x0.reshape(B, -1), sc["params"].reshape(B, -1))
+    _compare(got, xt, ut, info)
+    assert np.all(got["xtraj"][:, :, 5] == xinit[:, None, 5])
+    s.close()
