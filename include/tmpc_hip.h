@@ -154,6 +154,18 @@ int tmpc_time_solve(tmpc_handle *h, int32_t reps, float *ms_each);
 int tmpc_linearize_topology(tmpc_handle *h, const void *d_obstacle_pos, const void *d_scene_of, const void *d_state_x,
                             double robot_radius, const void *d_is_original);
 
+/* ---- scenario -> halfspace reduction of SH-MPC on device.  Replaces what the reference gets from the
+ * external scenario_module (scenario_constraints.cpp:47 update, :76-79 setParameters; source absent -> restated, see
+ * mpc_planner_amd/modules.py::scenario_halfspaces): for every trajectory b and stage k >= 1, the n_pts sampled obstacle
+ * positions of prediction step k-1 are reduced to n_rows halfspaces a.x <= b around the guess x0[b][k] (closest sample
+ * per angular sector of a; empty sectors / stage 0 = dummy rows), written into the first n_rows decomp/scenario rows of
+ * the batch's parameter tensor together with ego_disc_0_offset.  Device pointers:
+ *   d_samples  : f64 [n_scenes][N][n_pts][2]   sampled positions, n_pts = obstacles x scenarios (index i = step k-1)
+ *   d_scene_of : i32 [B];  d_state_x : f64 [n_scenes]  (dummy b = x + 100)
+ * Operates in place on the parameter tensor of the last tmpc_set_batch / tmpc_set_batch_device call. */
+int tmpc_scenario_halfspaces(tmpc_handle *h, const void *d_samples, int32_t n_pts, int32_t n_rows, const void *d_scene_of,
+                             const void *d_state_x, double radius, double disc_offset);
+
 /* ---- test/debug entry points (used by tests/ to diff per-phase tensors against the oracle) -------- */
 /* Evaluate the stage functions on device for n points: z[n][7], p[n][npar] (host pointers).
  * Outputs (host, may be NULL): cost[n], cost_grad[n][7], cost_hess[n][49], h[n][nh], h_jac[n][nh][7],

@@ -909,6 +909,73 @@ __global__ void tmpc_linearize_topology_kernel(Dims d, int B, const double *x0, 
     }
 }
 
+
+// ---- f-3: scenario -> halfspace reduction on device (SH-MPC, BASELINE config 5) -----------------------------------
+// The reference delegates this to the external scenario_module (scenario_constraints.cpp:47,76-79; source absent), so
+// this restates the host mirror mpc_planner_amd/modules.py::scenario_halfspaces: for stage k >= 1 of trajectory b every
+// sampled obstacle position o (n_pts = obstacles x scenarios of the trajectory's scene, prediction step k-1) gives the
+// halfspace a = (o - p)/|o - p|, b = a.o - radius around the guess p = x0[b][k](x, y); the n_rows angular sectors of a
+// each keep their closest sample (lowest sample index on ties); empty sectors and stage 0 get the dummy row
+// (1, 0, x + 100) (decomp_constraints.cpp:153-169 pattern).  One workgroup per (trajectory, stage); the samples of a
+// stage are contiguous ([scene][N][n_pts][2]) so the scan is a coalesced HBM/L2 stream shared by the scene's
+// trajectories.  Arithmetic is written without FMA contraction so the rows equal the host mirror's bit for bit.
+__global__ __launch_bounds__(256) void tmpc_scenario_halfspaces_kernel(Dims d, int B, const double *x0, double *params,
+                                                                       const double *samples, int n_pts, int n_rows,
+                                                                       const int *scene_of, const double *state_x,
+                                                                       double radius, double disc_offset)
+{
+#pragma clang fp contract(off)
+    __shared__ unsigned long long s_best[64];
+    __shared__ int s_idx[64];
+    const int N = d.N;
+    const int b = blockIdx.x / N, k = blockIdx.x - b * N;
+    if (b >= B) return;
+    const int sc = scene_of[b];
+    double *p = params + ((size_t)b * N + k) * d.npar;
+    const int tid = threadIdx.x;
+    if (tid == 0) p[ip_disc_offset(d)] = disc_offset;
+    if (k == 0) {
+        if (tid < n_rows) { p[ip_slk(d, tid, 0)] = 1.0; p[ip_slk(d, tid, 1)] = 0.0; p[ip_slk(d, tid, 2)] = state_x[sc] + 100.0; }
+        return;
+    }
+    if (tid < n_rows) { s_best[tid] = ~0ull; s_idx[tid] = 0x7fffffff; }
+    __syncthreads();
+    const double px = x0[((size_t)b * (N + 1) + k) * ext_nv(d) + ZX], py = x0[((size_t)b * (N + 1) + k) * ext_nv(d) + ZY];
+    const double2 *o = reinterpret_cast<const double2 *>(samples) + ((size_t)sc * N + (k - 1)) * n_pts;
+    const double scale = (double)n_rows / (2.0 * M_PI);
+    auto classify = [&](int i, double &dist, double &ax, double &ay) {
+        const double2 q = o[i];
+        const double dx = q.x - px, dy = q.y - py;
+        dist = sqrt(dx * dx + dy * dy);
+        ax = dx / dist; ay = dy / dist;
+        int sec = (int)((atan2(ay, ax) + M_PI) * scale);
+        return sec < n_rows - 1 ? sec : n_rows - 1;
+    };
+    for (int i = tid; i < n_pts; i += blockDim.x) {
+        double dist, ax, ay;
+        const int sec = classify(i, dist, ax, ay);
+        atomicMin(&s_best[sec], (unsigned long long)__double_as_longlong(dist));      // dist > 0: bit pattern is monotone
+    }
+    __syncthreads();
+    for (int i = tid; i < n_pts; i += blockDim.x) {
+        double dist, ax, ay;
+        const int sec = classify(i, dist, ax, ay);
+        if ((unsigned long long)__double_as_longlong(dist) == s_best[sec]) atomicMin(&s_idx[sec], i);
+    }
+    __syncthreads();
+    if (tid < n_rows) {
+        double a1 = 1.0, a2 = 0.0, bb = state_x[sc] + 100.0;
+        const int i = s_idx[tid];
+        if (i != 0x7fffffff) {
+            double dist;
+            classify(i, dist, a1, a2);
+            const double2 q = o[i];
+            bb = a1 * q.x + a2 * q.y - radius;
+        }
+        p[ip_slk(d, tid, 0)] = a1; p[ip_slk(d, tid, 1)] = a2; p[ip_slk(d, tid, 2)] = bb;
+    }
+}
+
 // ---- debug: stage functions on device -----------------------------------------------------------
 __global__ void tmpc_debug_eval_kernel(Dims d, int n, const double *z, const double *p, const double *pi, const double *lamh,
                                        double *cost, double *cgrad, double *chess, double *hval, double *hjac,
@@ -1211,6 +1278,22 @@ int tmpc_linearize_topology(tmpc_handle *h, const void *d_obstacle_pos, const vo
     hipLaunchKernelGGL(tmpc::tmpc_linearize_topology_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->d, h->B,
                        h->x0, const_cast<double *>(h->params), (const double *)d_obstacle_pos, (const int *)d_scene_of,
                        (const double *)d_state_x, robot_radius, (const uint8_t *)d_is_original);
+    TMPC_HIP_CHECK(h, hipGetLastError());
+    return TMPC_OK;
+}
+
+int tmpc_scenario_halfspaces(tmpc_handle *h, const void *d_samples, int32_t n_pts, int32_t n_rows, const void *d_scene_of,
+                             const void *d_state_x, double radius, double disc_offset)
+{
+    if (!h || h->B <= 0 || !h->params || !d_samples || !d_scene_of || !d_state_x || n_pts <= 0 || n_rows <= 0 || n_rows > 64 ||
+        n_rows > h->d.n_slk) {
+        if (h) h->err = "tmpc_scenario_halfspaces: bad argument / no batch / more rows than the problem's slack rows";
+        return TMPC_ERR_INVALID;
+    }
+    TMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    hipLaunchKernelGGL(tmpc::tmpc_scenario_halfspaces_kernel, dim3(h->B * h->d.N), dim3(256), 0, h->stream, h->d, h->B, h->x0,
+                       const_cast<double *>(h->params), (const double *)d_samples, n_pts, n_rows, (const int *)d_scene_of,
+                       (const double *)d_state_x, radius, disc_offset);
     TMPC_HIP_CHECK(h, hipGetLastError());
     return TMPC_OK;
 }

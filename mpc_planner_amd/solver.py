@@ -39,7 +39,7 @@ EXPORTS = ["tmpc_default_dims", "tmpc_default_dims_ex", "tmpc_create", "tmpc_des
            "tmpc_set_batch_device", "tmpc_solve", "tmpc_synchronize", "tmpc_get", "tmpc_select_best",
            "tmpc_result_device_ptrs", "tmpc_time_solve", "tmpc_debug_eval_stage", "tmpc_pack_records",
            "tmpc_select_best_records", "tmpc_enable_timing", "tmpc_get_timings", "tmpc_debug_profile",
-           "tmpc_linearize_topology", "tmpc_debug_get_params"]
+           "tmpc_linearize_topology", "tmpc_scenario_halfspaces", "tmpc_debug_get_params"]
 
 _lib = None
 
@@ -78,6 +78,7 @@ def load_library():
         lib.tmpc_get_timings.argtypes = [vp, vp, C.c_int32, C.POINTER(C.c_int32)]
         lib.tmpc_debug_profile.argtypes = [vp, vp, C.c_int32]
         lib.tmpc_linearize_topology.argtypes = [vp, vp, vp, vp, C.c_double, vp]
+        lib.tmpc_scenario_halfspaces.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, vp, C.c_double, C.c_double]
         lib.tmpc_debug_get_params.argtypes = [vp, vp]
         _lib = lib
     return _lib
@@ -201,6 +202,13 @@ class BatchedSolver:
                                                      C.c_void_p(d_state_x), float(robot_radius),
                                                      C.c_void_p(d_is_original) if d_is_original else None),
                     "tmpc_linearize_topology")
+
+    def scenario_halfspaces(self, d_samples, n_pts, n_rows, d_scene_of, d_state_x, radius, disc_offset=0.0):
+        """Device scenario -> halfspace reduction of SH-MPC (raw device pointers; samples [n_scenes][N][n_pts][2]);
+        modifies the batch params in place."""
+        self._check(self.lib.tmpc_scenario_halfspaces(self._h, C.c_void_p(d_samples), int(n_pts), int(n_rows),
+                                                      C.c_void_p(d_scene_of), C.c_void_p(d_state_x), float(radius),
+                                                      float(disc_offset)), "tmpc_scenario_halfspaces")
 
     def debug_get_params(self):
         out = np.zeros((self.B, self.N, self.npar))

@@ -325,3 +325,37 @@ def test_slack_value_comes_from_xinit():
     _compare(got, xt, ut, info)
     assert np.all(got["xtraj"][:, :, 5] == xinit[:, None, 5])
     s.close()
+
+
+def test_device_scenario_halfspaces_match_host_mirror():
+    """the SH-MPC scenario -> 24-halfspace reduction on device (8 obstacles x 256 scenarios per stage)
+    vs the host mirror mpc_planner_amd/modules.py::scenario_halfspaces: identical rows (bit for bit), and the solve on
+    device-built rows equals the solve on host-built rows."""
+    import torch
+    from mpc_planner_amd import scenes
+    skw, pkw = SLACK_CFG["cfg5"]
+    scs = [scenes.make_scene(2 + i, B=16, **skw) for i in range(3)]
+    B = 48; N = 20
+    xinit = np.concatenate([s["xinit"] for s in scs]); x0 = np.concatenate([s["x0"] for s in scs])
+    want = np.concatenate([s["params"] for s in scs])
+    scene_of = np.repeat(np.arange(3, dtype=np.int32), 16)
+    state_x = np.array([s["xinit"][0, 0] for s in scs])
+    # [scene][M][S_cen][N][2] -> [scene][N][M*S_cen][2]
+    smp = np.stack([np.ascontiguousarray(s["samples"].transpose(2, 0, 1, 3)).reshape(N, -1, 2) for s in scs])
+    pm = scs[0]["pm"]
+    start = want.copy()
+    for j in range(24):
+        for f in ("a1", "a2", "b"):
+            start[:, :, pm.index(f"disc_0_scenario_constraint_{j}_{f}")] = -7.0
+    start[:, :, pm.index("ego_disc_0_offset")] = -7.0
+    s = _solver(S=5, B_max=B, **pkw)
+    s.set_batch(xinit, x0, start)
+    dev = torch.device("cuda")
+    t_s = torch.from_numpy(smp).to(dev); t_sc = torch.from_numpy(scene_of).to(dev); t_sx = torch.from_numpy(state_x).to(dev)
+    s.scenario_halfspaces(t_s.data_ptr(), smp.shape[2], 24, t_sc.data_ptr(), t_sx.data_ptr(), 0.4 + 0.325)
+    got = s.debug_get_params()
+    assert np.array_equal(got, want)
+    s.solve(); a = s.get()
+    s.set_batch(xinit, x0, want); s.solve(); b = s.get()
+    assert (a["exit_code"] == b["exit_code"]).all() and np.array_equal(a["xtraj"], b["xtraj"])
+    s.close()
