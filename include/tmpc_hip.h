@@ -166,7 +166,23 @@ int tmpc_linearize_topology(tmpc_handle *h, const void *d_obstacle_pos, const vo
 int tmpc_scenario_halfspaces(tmpc_handle *h, const void *d_samples, int32_t n_pts, int32_t n_rows, const void *d_scene_of,
                              const void *d_state_x, double radius, double disc_offset);
 
+/* ---- cross-tick state on device, so a closed loop runs without host round trips --------------------
+ * tmpc_warmstart builds the next tick's warm start x0 and xinit of every trajectory of the current batch from the
+ * solution the handle holds (last tmpc_solve) and the new state.  Device pointers:
+ *   d_state : f64 [B][nx]   the new initial state of each trajectory (Solver::setXinit(State))
+ *   d_mode  : i32 [B] or NULL (= all 1):  0 leave x0 alone; 1 Solver::initializeWarmstart(state, true)
+ *             (acados_solver_interface.cpp:344-364); 2 initializeWarmstart(state, false) (:365-375);
+ *             3 Solver::initializeWithBraking(state) (:303-342) with |deceleration| (CONFIG deceleration_at_infeasible)
+ *   d_src   : i32 [B] or NULL (= identity): trajectory whose previous solution is shifted into b.
+ * Mode 1 writes 0 into the inputs of node 0, where the reference reads State::get(<input>) out of bounds (state.cpp:21-24). */
+int tmpc_warmstart(tmpc_handle *h, const void *d_state, const void *d_mode, const void *d_src, double deceleration);
+/* GuidanceConstraints::initializeSolverWithGuidance (guidance_constraints.cpp:390-414) for every enabled trajectory:
+ * d_gpos, d_gvel f64 [B][N+1][2] (guidance position / velocity at t = k dt), d_enabled u8 [B] or NULL. */
+int tmpc_init_with_guidance(tmpc_handle *h, const void *d_gpos, const void *d_gvel, const void *d_enabled);
+
 /* ---- test/debug entry points (used by tests/ to diff per-phase tensors against the oracle) -------- */
+/* Copy the batch's (possibly device-built) warm start and xinit back: x0[B][(N+1)*nvar], xinit[B][nx]; either may be NULL. */
+int tmpc_debug_get_x0(tmpc_handle *h, double *x0, double *xinit);
 /* Evaluate the stage functions on device for n points: z[n][7], p[n][npar] (host pointers).
  * Outputs (host, may be NULL): cost[n], cost_grad[n][7], cost_hess[n][49], h[n][nh], h_jac[n][nh][7],
  * x_next[n][5], x_jac[n][5][7]; lag_hess[n][49] = dt*hess(l) + sum_j pi[j] hess(x_next_j) +

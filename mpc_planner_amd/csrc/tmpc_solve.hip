@@ -976,6 +976,78 @@ __global__ __launch_bounds__(256) void tmpc_scenario_halfspaces_kernel(Dims d, i
     }
 }
 
+
+// ---- f-2: cross-tick state on device ------------------------------------------------------------------------------
+// Warm start of the next tick from the previous tick's solution, without a host round trip.  One thread per
+// (trajectory, node).  mode[b]:
+//   0  leave x0[b] alone (the caller loads a guidance trajectory, tmpc_init_with_guidance)
+//   1  Solver::initializeWarmstart(state, shift = true)   (acados_solver_interface.cpp:344-364):
+//        [state, out_2, ..., out_{N-1}, out_{N-1}, out_{N-1}]
+//   2  Solver::initializeWarmstart(state, shift = false)  (:365-375): x0[k] = out_k for k < N
+//   3  Solver::initializeWithBraking(state)               (:303-342): constant deceleration roll-out
+// out_k is the previous solution of trajectory src[b] (src = NULL: b itself -- a planner re-uses its own last output,
+// guidance_constraints.cpp:310-311).  xinit[b] <- state[b] (Solver::setXinit).
+// In mode 1 the reference fills the INPUT entries of node 0 from State::get(<input name>), which indexes the state
+// vector at -2 / -1 (state.cpp:21-24: index - nu) -- an out-of-bounds read; this restatement writes 0 there.
+__global__ void tmpc_warmstart_kernel(Dims d, int B, const double *state, const int *mode, const int *src, const double *xtraj,
+                                      const double *utraj, double *x0, double *xinit, double decel)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int N = d.N, nxe = ext_nx(d), nve = ext_nv(d);
+    if (e >= B * (N + 1)) return;
+    const int b = e / (N + 1), k = e - b * (N + 1);
+    const double *st = state + (size_t)b * nxe;
+    if (k == 0) for (int i = 0; i < nxe; i++) xinit[(size_t)b * nxe + i] = st[i];
+    const int m = mode ? mode[b] : 1;
+    if (m == 0) return;
+    double *z = x0 + ((size_t)b * (N + 1) + k) * nve;
+    const int sb = src ? src[b] : b;
+    const double *xo = xtraj + (size_t)sb * (N + 1) * nxe, *uo = utraj + (size_t)sb * N * NU;
+    if (m == 1) {
+        if (k == 0) {
+            for (int i = 0; i < NU; i++) z[i] = 0.0;
+            for (int i = 0; i < nxe; i++) z[NU + i] = st[i];
+        } else {
+            const int ko = (k >= N - 1) ? N - 1 : k + 1;
+            for (int i = 0; i < NU; i++) z[i] = uo[ko * NU + i];
+            for (int i = 0; i < nxe; i++) z[NU + i] = xo[ko * nxe + i];
+        }
+    } else if (m == 2) {
+        if (k < N) {
+            for (int i = 0; i < NU; i++) z[i] = uo[k * NU + i];
+            for (int i = 0; i < nxe; i++) z[NU + i] = xo[k * nxe + i];
+        }
+    } else if (m == 3) {
+        double x = st[0], y = st[1], v = st[3], spline = st[4];
+        const double psi = st[2], a = -fabs(decel);
+        double sn, cs;
+        sincos(psi, &sn, &cs);
+        for (int j = 1; j <= k; j++) {                       // same recursion order as the reference's loop (:322-331)
+            x += v * d.dt * cs; y += v * d.dt * sn; spline += v * d.dt;
+            v += a * d.dt; v = fmax(v, 0.0);
+        }
+        z[ZA] = a; z[ZW] = 0.0; z[ZX] = x; z[ZY] = y; z[ZPSI] = psi; z[ZV] = v; z[ZS] = spline;
+        for (int i = NX; i < nxe; i++) z[NU + i] = st[i];    // initializeWithState: remaining states = initial state
+    }
+}
+
+// GuidanceConstraints::initializeSolverWithGuidance (guidance_constraints.cpp:390-414): k = 1..N-1: x, y from the guidance
+// trajectory at t = k dt, psi = atan2(vy, vx), v = |vel|.  gpos / gvel: [B][N+1][2]; enabled[b] == 0 skips b.
+__global__ void tmpc_init_with_guidance_kernel(Dims d, int B, const double *gpos, const double *gvel, const uint8_t *enabled, double *x0)
+{
+#pragma clang fp contract(off)
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int N = d.N;
+    if (e >= B * (N + 1)) return;
+    const int b = e / (N + 1), k = e - b * (N + 1);
+    if (k < 1 || k > N - 1 || (enabled && !enabled[b])) return;
+    double *z = x0 + ((size_t)b * (N + 1) + k) * ext_nv(d);
+    const double vx = gvel[(size_t)e * 2], vy = gvel[(size_t)e * 2 + 1];
+    z[ZX] = gpos[(size_t)e * 2]; z[ZY] = gpos[(size_t)e * 2 + 1];
+    z[ZPSI] = atan2(vy, vx);
+    z[ZV] = sqrt(vx * vx + vy * vy);
+}
+
 // ---- debug: stage functions on device -----------------------------------------------------------
 __global__ void tmpc_debug_eval_kernel(Dims d, int n, const double *z, const double *p, const double *pi, const double *lamh,
                                        double *cost, double *cgrad, double *chess, double *hval, double *hjac,
@@ -1295,6 +1367,39 @@ int tmpc_scenario_halfspaces(tmpc_handle *h, const void *d_samples, int32_t n_pt
                        const_cast<double *>(h->params), (const double *)d_samples, n_pts, n_rows, (const int *)d_scene_of,
                        (const double *)d_state_x, radius, disc_offset);
     TMPC_HIP_CHECK(h, hipGetLastError());
+    return TMPC_OK;
+}
+
+int tmpc_warmstart(tmpc_handle *h, const void *d_state, const void *d_mode, const void *d_src, double deceleration)
+{
+    if (!h || h->B <= 0 || !h->x0 || !h->xinit || !d_state) { if (h) h->err = "tmpc_warmstart: bad argument / no batch"; return TMPC_ERR_INVALID; }
+    TMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    const int n = h->B * (h->d.N + 1);
+    hipLaunchKernelGGL(tmpc::tmpc_warmstart_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->d, h->B, (const double *)d_state,
+                       (const int *)d_mode, (const int *)d_src, h->xtraj, h->utraj, const_cast<double *>(h->x0),
+                       const_cast<double *>(h->xinit), deceleration);
+    TMPC_HIP_CHECK(h, hipGetLastError());
+    return TMPC_OK;
+}
+
+int tmpc_init_with_guidance(tmpc_handle *h, const void *d_gpos, const void *d_gvel, const void *d_enabled)
+{
+    if (!h || h->B <= 0 || !h->x0 || !d_gpos || !d_gvel) { if (h) h->err = "tmpc_init_with_guidance: bad argument / no batch"; return TMPC_ERR_INVALID; }
+    TMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    const int n = h->B * (h->d.N + 1);
+    hipLaunchKernelGGL(tmpc::tmpc_init_with_guidance_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->d, h->B,
+                       (const double *)d_gpos, (const double *)d_gvel, (const uint8_t *)d_enabled, const_cast<double *>(h->x0));
+    TMPC_HIP_CHECK(h, hipGetLastError());
+    return TMPC_OK;
+}
+
+int tmpc_debug_get_x0(tmpc_handle *h, double *x0, double *xinit)
+{
+    if (!h || h->B <= 0 || !h->x0) return TMPC_ERR_INVALID;
+    TMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    TMPC_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    if (x0) TMPC_HIP_CHECK(h, hipMemcpy(x0, h->x0, (size_t)h->B * (h->d.N + 1) * tmpc::ext_nv(h->d) * 8, hipMemcpyDeviceToHost));
+    if (xinit) TMPC_HIP_CHECK(h, hipMemcpy(xinit, h->xinit, (size_t)h->B * tmpc::ext_nx(h->d) * 8, hipMemcpyDeviceToHost));
     return TMPC_OK;
 }
 

@@ -153,3 +153,61 @@ def initialize_solver_with_guidance(x0, guidance_pos, guidance_vel):
         x0[k, IDX["psi"]] = np.arctan2(guidance_vel[k, 1], guidance_vel[k, 0])
         x0[k, IDX["v"]] = np.sqrt(guidance_vel[k, 0] ** 2 + guidance_vel[k, 1] ** 2)
     return x0
+
+
+def initialize_warmstart(x0, state, xtraj_prev, utraj_prev, shift_previous_solution_forward=True):
+    """Solver::initializeWarmstart (acados_solver_interface.cpp:344-376) on one solver's warm start x0 [N+1][nvar],
+    in place, from its previous output (xtraj_prev [N+1][nx], utraj_prev [N][nu]).  shift = True:
+    [state, out_2, ..., out_{N-1}, out_{N-1}, out_{N-1}]; the inputs of node 0 are written as 0 (the reference reads
+    State::get(<input name>) there, an out-of-bounds index: state.cpp:21-24).  shift = False: x0[k] = out_k, k < N."""
+    N = x0.shape[0] - 1
+    nx = xtraj_prev.shape[1]
+    if shift_previous_solution_forward:
+        x0[0, :NU] = 0.0
+        x0[0, NU:NU + nx] = state[:nx]
+        for k in range(1, N + 1):
+            ko = N - 1 if k >= N - 1 else k + 1
+            x0[k, :NU] = utraj_prev[ko]
+            x0[k, NU:NU + nx] = xtraj_prev[ko]
+    else:
+        for k in range(N):
+            x0[k, :NU] = utraj_prev[k]
+            x0[k, NU:NU + nx] = xtraj_prev[k]
+    return x0
+
+
+def initialize_with_braking(state, N, dt, deceleration, nv=NV):
+    """Solver::initializeWithBraking (acados_solver_interface.cpp:303-342)."""
+    x0 = np.zeros((N + 1, nv))
+    x, y, psi, v, spline = state[:5]
+    a = -abs(deceleration)
+    for k in range(N + 1):
+        if k >= 1:
+            x += v * dt * np.cos(psi); y += v * dt * np.sin(psi); spline += v * dt
+            v += a * dt; v = max(v, 0.0)
+        x0[k, :NV] = [a, 0.0, x, y, psi, v, spline]
+        x0[k, NV:] = state[5:]
+    return x0
+
+
+def map_guidance_trajectories_to_planners(planner_guidance_ids, topology_classes):
+    """GuidanceConstraints::mapGuidanceTrajectoriesToPlanners (guidance_constraints.cpp:192-250), integer bookkeeping
+    restated literally.  planner_guidance_ids[p] = result.guidance_ID of planner p's last solve; topology_classes[i] =
+    class of guidance trajectory i.  Returns (mapping {i: p}, taken [P], existing_guidance [P]).  Note the reference's
+    second loop has no `break`: the first unmatched trajectory claims every free planner (its mapping ends at the last
+    one) and later unmatched trajectories get none."""
+    P = len(planner_guidance_ids)
+    taken = [False] * P; existing = [False] * P; mapping = {}; remaining = []
+    for i, cls in enumerate(topology_classes):
+        found = False
+        for p in range(P):
+            if planner_guidance_ids[p] == cls and not taken[p]:
+                mapping[i] = p; taken[p] = True; existing[p] = True; found = True
+                break
+        if not found:
+            remaining.append(i)
+    for i in remaining:
+        for p in range(P):
+            if not taken[p]:
+                mapping[i] = p; taken[p] = True; existing[p] = False
+    return mapping, taken, existing

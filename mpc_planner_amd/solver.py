@@ -39,7 +39,8 @@ EXPORTS = ["tmpc_default_dims", "tmpc_default_dims_ex", "tmpc_create", "tmpc_des
            "tmpc_set_batch_device", "tmpc_solve", "tmpc_synchronize", "tmpc_get", "tmpc_select_best",
            "tmpc_result_device_ptrs", "tmpc_time_solve", "tmpc_debug_eval_stage", "tmpc_pack_records",
            "tmpc_select_best_records", "tmpc_enable_timing", "tmpc_get_timings", "tmpc_debug_profile",
-           "tmpc_linearize_topology", "tmpc_scenario_halfspaces", "tmpc_debug_get_params"]
+           "tmpc_linearize_topology", "tmpc_scenario_halfspaces", "tmpc_warmstart", "tmpc_init_with_guidance",
+           "tmpc_debug_get_x0", "tmpc_debug_get_params"]
 
 _lib = None
 
@@ -78,6 +79,9 @@ def load_library():
         lib.tmpc_get_timings.argtypes = [vp, vp, C.c_int32, C.POINTER(C.c_int32)]
         lib.tmpc_debug_profile.argtypes = [vp, vp, C.c_int32]
         lib.tmpc_linearize_topology.argtypes = [vp, vp, vp, vp, C.c_double, vp]
+        lib.tmpc_warmstart.argtypes = [vp, vp, vp, vp, C.c_double]
+        lib.tmpc_init_with_guidance.argtypes = [vp, vp, vp, vp]
+        lib.tmpc_debug_get_x0.argtypes = [vp, vp, vp]
         lib.tmpc_scenario_halfspaces.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, vp, C.c_double, C.c_double]
         lib.tmpc_debug_get_params.argtypes = [vp, vp]
         _lib = lib
@@ -209,6 +213,20 @@ class BatchedSolver:
         self._check(self.lib.tmpc_scenario_halfspaces(self._h, C.c_void_p(d_samples), int(n_pts), int(n_rows),
                                                       C.c_void_p(d_scene_of), C.c_void_p(d_state_x), float(radius),
                                                       float(disc_offset)), "tmpc_scenario_halfspaces")
+
+    def warmstart(self, d_state, d_mode=None, d_src=None, deceleration=3.0):
+        """Device warm start of the next tick from the solution held by the handle (raw device pointers)."""
+        self._check(self.lib.tmpc_warmstart(self._h, C.c_void_p(d_state), C.c_void_p(d_mode) if d_mode else None,
+                                            C.c_void_p(d_src) if d_src else None, float(deceleration)), "tmpc_warmstart")
+
+    def init_with_guidance(self, d_gpos, d_gvel, d_enabled=None):
+        self._check(self.lib.tmpc_init_with_guidance(self._h, C.c_void_p(d_gpos), C.c_void_p(d_gvel),
+                                                     C.c_void_p(d_enabled) if d_enabled else None), "tmpc_init_with_guidance")
+
+    def debug_get_x0(self):
+        x0 = np.zeros((self.B, self.N + 1, self.dims.nvar)); xinit = np.zeros((self.B, self.dims.nx))
+        self._check(self.lib.tmpc_debug_get_x0(self._h, _p(x0), _p(xinit)), "tmpc_debug_get_x0")
+        return x0, xinit
 
     def debug_get_params(self):
         out = np.zeros((self.B, self.N, self.npar))

@@ -359,3 +359,61 @@ def test_device_scenario_halfspaces_match_host_mirror():
     s.set_batch(xinit, x0, want); s.solve(); b = s.get()
     assert (a["exit_code"] == b["exit_code"]).all() and np.array_equal(a["xtraj"], b["xtraj"])
     s.close()
+
+
+def test_device_cross_tick_warmstart_matches_host_mirror():
+    """next tick's warm start built on device from the solution the handle holds (shift / maintain /
+    braking / guidance) vs the host mirrors written after acados_solver_interface.cpp:303-376 and
+    guidance_constraints.cpp:390-414; then a second tick solved from it equals the host-driven second tick."""
+    import torch
+    from mpc_planner_amd import scenes, modules as md
+    N, B = 20, 32
+    sc = scenes.make_scene(4, N=N, M=8, B=B)
+    s = _solver(B_max=B)
+    s.set_batch(sc["xinit"], sc["x0"], sc["params"]); s.solve(); t0 = s.get()
+    best = s.select_best()
+    assert best >= 0
+    state = t0["xtraj"][best, 1].copy()                        # the robot moved one step along the chosen plan
+    states = np.tile(state, (B, 1))
+    mode = np.array([1, 2, 3, 0] * (B // 4), np.int32)
+    src = np.arange(B, dtype=np.int32); src[8] = best           # one planner warm-started from the chosen plan
+    rng = np.random.default_rng(3)
+    gpos = rng.normal(size=(B, N + 1, 2)); gvel = rng.normal(size=(B, N + 1, 2))
+    enabled = (mode == 0).astype(np.uint8)
+    dev = torch.device("cuda")
+    t = {k: torch.from_numpy(v).to(dev) for k, v in dict(st=states, mode=mode, src=src, gp=gpos, gv=gvel, en=enabled).items()}
+    s.warmstart(t["st"].data_ptr(), t["mode"].data_ptr(), t["src"].data_ptr(), deceleration=3.0)
+    s.init_with_guidance(t["gp"].data_ptr(), t["gv"].data_ptr(), t["en"].data_ptr())
+    x0_dev, xinit_dev = s.debug_get_x0()
+    want = sc["x0"].copy()
+    for b in range(B):
+        if mode[b] == 1:
+            md.initialize_warmstart(want[b], state, t0["xtraj"][src[b]], t0["utraj"][src[b]], True)
+        elif mode[b] == 2:
+            md.initialize_warmstart(want[b], state, t0["xtraj"][src[b]], t0["utraj"][src[b]], False)
+        elif mode[b] == 3:
+            want[b] = md.initialize_with_braking(state, N, 0.2, 3.0)
+        else:
+            md.initialize_solver_with_guidance(want[b], gpos[b], gvel[b])
+    assert np.array_equal(xinit_dev, states)
+    exact = mode != 3
+    assert np.array_equal(x0_dev[exact][:, :, [0, 1, 2, 3, 5, 6]], want[exact][:, :, [0, 1, 2, 3, 5, 6]])
+    np.testing.assert_allclose(x0_dev, want, rtol=4e-16, atol=4e-16)          # atan2 / sincos: last-ulp differences only
+    # second tick: shift-warm-started planners re-linearise their topology rows on device and solve
+    obst = sc["obstacles"]["pos"][None]
+    mode2 = np.ones(B, np.int32)
+    s.warmstart(t["st"].data_ptr(), torch.from_numpy(mode2).to(dev).data_ptr(), None)
+    t_ob = torch.from_numpy(np.ascontiguousarray(obst)).to(dev); t_sc = torch.zeros(B, dtype=torch.int32, device=dev)
+    t_sx = torch.from_numpy(states[:1, 0].copy()).to(dev)
+    s.linearize_topology(t_ob.data_ptr(), t_sc.data_ptr(), t_sx.data_ptr(), 0.325, None)
+    s.solve(); a = s.get()
+    x0h = sc["x0"].copy(); ph = sc["params"].copy()
+    for b in range(B):
+        md.initialize_warmstart(x0h[b], state, t0["xtraj"][b], t0["utraj"][b], True)
+    s2 = _solver(B_max=B)
+    s2.set_batch(states, x0h, ph)
+    s2.linearize_topology(t_ob.data_ptr(), t_sc.data_ptr(), t_sx.data_ptr(), 0.325, None)
+    s2.solve(); bb = s2.get()
+    assert np.array_equal(a["exit_code"], bb["exit_code"]) and np.array_equal(a["xtraj"], bb["xtraj"])
+    assert (a["exit_code"] == 1).sum() >= B // 2
+    s.close(); s2.close()

@@ -1,0 +1,49 @@
+"""Host mirrors of the cross-tick bookkeeping: mapGuidanceTrajectoriesToPlanners (integer work, restated
+literally incl. its missing `break`), initializeWarmstart, initializeWithBraking."""
+import numpy as np
+
+from mpc_planner_amd import modules as md
+
+
+def test_map_guidance_trajectories_to_planners_semantics():
+    # planners 0..3 solved classes [7, 3, 7, -1] last tick; guidance now offers classes [3, 7, 7, 9]
+    m, taken, existing = md.map_guidance_trajectories_to_planners([7, 3, 7, -1], [3, 7, 7, 9])
+    assert m == {0: 1, 1: 0, 2: 2, 3: 3}
+    assert taken == [True] * 4 and existing == [True, True, True, False]
+    # two unmatched trajectories, three free planners: the first one claims ALL free planners (no `break` in the
+    # reference's second loop, guidance_constraints.cpp:232-243) and ends mapped to the last; the second gets nothing
+    m, taken, existing = md.map_guidance_trajectories_to_planners([5, -1, -1, -1], [5, 8, 9])
+    assert m == {0: 0, 1: 3} and 2 not in m
+    assert taken == [True] * 4 and existing == [True, False, False, False]
+    # a class matched twice maps to two different planners only if two planners carried it
+    m, taken, existing = md.map_guidance_trajectories_to_planners([4, 2], [4, 4])
+    assert m == {0: 0, 1: 1} and existing == [True, False]
+    # nothing offered
+    m, taken, existing = md.map_guidance_trajectories_to_planners([1, 2], [])
+    assert m == {} and taken == [False, False]
+
+
+def test_initialize_warmstart_shift_and_maintain():
+    N = 6
+    xt = np.arange((N + 1) * 5, dtype=float).reshape(N + 1, 5) + 100.0
+    ut = np.arange(N * 2, dtype=float).reshape(N, 2) + 1.0
+    state = np.array([9.0, 8.0, 7.0, 6.0, 5.0])
+    x0 = np.full((N + 1, 7), -1.0)
+    md.initialize_warmstart(x0, state, xt, ut, True)
+    assert np.all(x0[0] == [0, 0, 9, 8, 7, 6, 5])
+    for k in range(1, N - 1):
+        assert np.all(x0[k, 2:] == xt[k + 1]) and np.all(x0[k, :2] == ut[k + 1])
+    for k in (N - 1, N):
+        assert np.all(x0[k, 2:] == xt[N - 1]) and np.all(x0[k, :2] == ut[N - 1])
+    x0 = np.full((N + 1, 7), -1.0)
+    md.initialize_warmstart(x0, state, xt, ut, False)
+    assert np.all(x0[:N, 2:] == xt[:N]) and np.all(x0[:N, :2] == ut) and np.all(x0[N] == -1.0)
+
+
+def test_initialize_with_braking_stops_and_stays():
+    x0 = md.initialize_with_braking(np.array([1.0, 2.0, 0.5, 1.2, 3.0]), 20, 0.2, 3.0)
+    assert np.all(x0[:, 0] == -3.0) and np.all(x0[:, 1] == 0.0) and np.all(x0[:, 4] == 0.5)
+    assert x0[0, 5] == 1.2 and np.all(np.diff(x0[:, 5]) <= 0) and x0[-1, 5] == 0.0
+    stopped = np.nonzero(x0[:, 5] == 0.0)[0][0]
+    assert np.all(x0[stopped + 1:, 2] == x0[stopped + 1, 2])            # no motion after standstill
+    assert abs((x0[1, 2] - 1.0) - 1.2 * 0.2 * np.cos(0.5)) < 1e-15 and abs((x0[1, 6] - 3.0) - 0.24) < 1e-15
