@@ -951,13 +951,30 @@ __global__ __launch_bounds__(256) void tmpc_scenario_halfspaces_kernel(Dims d, i
         int sec = (int)((atan2(ay, ax) + M_PI) * scale);
         return sec < n_rows - 1 ? sec : n_rows - 1;
     };
-    for (int i = tid; i < n_pts; i += blockDim.x) {
+    // pass 1: per-sector minimum distance; the first CACHE classifications of a thread stay in registers for pass 2
+    constexpr int CACHE = 8;
+    double c_dist[CACHE]; int c_sec[CACHE];
+#pragma unroll
+    for (int c = 0; c < CACHE; c++) {
+        const int i = tid + c * 256;
+        c_sec[c] = -1; c_dist[c] = 0.0;
+        if (i < n_pts) {
+            double ax, ay;
+            c_sec[c] = classify(i, c_dist[c], ax, ay);
+            atomicMin(&s_best[c_sec[c]], (unsigned long long)__double_as_longlong(c_dist[c]));   // dist > 0: bit pattern is monotone
+        }
+    }
+    for (int i = tid + CACHE * 256; i < n_pts; i += 256) {
         double dist, ax, ay;
         const int sec = classify(i, dist, ax, ay);
-        atomicMin(&s_best[sec], (unsigned long long)__double_as_longlong(dist));      // dist > 0: bit pattern is monotone
+        atomicMin(&s_best[sec], (unsigned long long)__double_as_longlong(dist));
     }
     __syncthreads();
-    for (int i = tid; i < n_pts; i += blockDim.x) {
+    // pass 2: lowest sample index among the samples at the minimum
+#pragma unroll
+    for (int c = 0; c < CACHE; c++)
+        if (c_sec[c] >= 0 && (unsigned long long)__double_as_longlong(c_dist[c]) == s_best[c_sec[c]]) atomicMin(&s_idx[c_sec[c]], tid + c * 256);
+    for (int i = tid + CACHE * 256; i < n_pts; i += 256) {
         double dist, ax, ay;
         const int sec = classify(i, dist, ax, ay);
         if ((unsigned long long)__double_as_longlong(dist) == s_best[sec]) atomicMin(&s_idx[sec], i);
