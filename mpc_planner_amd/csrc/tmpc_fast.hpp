@@ -58,10 +58,11 @@ __device__ __forceinline__ double rcp_nr(double x)
 
 __device__ __forceinline__ void lds_add(double *p, double v) { atomicAdd(p, v); }   // ds_add_f64
 
-template <int NLIN, int MM, int LPS>
+template <int NLIN, int MM, int LPS, int NTH>
 __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, int *iters_out, Prof &pf,
                         double (&lam)[FastCfg<NLIN, MM, LPS>::RPL])
 {
+    constexpr int NT = NTH;                         // threads per trajectory: 64 (one wave) or 128 (two waves; N > 21)
     using C = FastCfg<NLIN, MM, LPS>;
     constexpr int NH = C::NH, NR = C::NR, RPL = C::RPL;
     const int N = d.N;
@@ -215,19 +216,20 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
         double res_g = 0.0;
         for (int e = tl; e < (N + 1) * NV; e += NT)
             if (!(e >= NU && e < NV)) res_g = fmax(res_g, fabs(L.rg[e]));      // dx_0 is fixed: its stationarity row is not a residual
-        res_g = wave_max(res_g); res_b = wave_max(res_b); res_d = wave_max(res_d); res_m = wave_max(res_m);
-        mu = wave_sum(mu) / m_rows;
+        res_g = blk_max<NTH>(res_g, L.scr, tl, 0); res_b = blk_max<NTH>(res_b, L.scr, tl, 1);
+        res_d = blk_max<NTH>(res_d, L.scr, tl, 2); res_m = blk_max<NTH>(res_m, L.scr, tl, 3);
+        mu = blk_sum<NTH>(mu, L.scr, tl, 4) / m_rows;
         pf.stop(PH_RES);
         if (!(isfinite(res_g) && isfinite(res_b) && isfinite(res_d) && isfinite(res_m))) { status = 4; break; }
         if (res_g <= d.qp_tol && res_b <= d.qp_tol && res_d <= d.qp_tol && res_m <= d.qp_tol) { status = 0; break; }
         if (it >= d.qp_iter_max) { status = 2; break; }
         iters = it + 1;
 
-        const bool fbad = riccati_factor(L, d, tl);
+        const bool fbad = riccati_factor<NTH>(L, d, tl);
         pf.stop(PH_FACTOR);
         if (fbad) { status = 4; break; }
         // ---- predictor: rhs = rg + sum c (lam + d rd)  (q/t = lam) ----
-        riccati_solve(L, d, tl);
+        riccati_solve<NTH>(L, d, tl);
         pf.stop(PH_SOLVE);
         double dt_[RPL];                                                  // dlam is recomputed from dt where needed
         double amax = 1e300;
@@ -250,7 +252,7 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        const double a_aff = fmin(1.0, wave_min(amax));
+        const double a_aff = fmin(1.0, blk_min<NTH>(amax, L.scr, tl, 5));
         double mu_aff = 0.0;
 #pragma unroll
         for (int s = 0; s < RPL; s++)
@@ -258,7 +260,7 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
                 const double dl = -lam[s] - lam[s] * INVT(s) * dt_[s];
                 mu_aff += (lam[s] + a_aff * dl) * (t[s] + a_aff * dt_[s]);
             }
-        mu_aff = wave_sum(mu_aff) / m_rows;
+        mu_aff = blk_sum<NTH>(mu_aff, L.scr, tl, 6) / m_rows;
         double sigma = mu > 0.0 ? mu_aff / mu : 0.0;
         sigma = sigma * sigma * sigma;
         // ---- corrector rhs: gh = rg + sum c (qt + d rd) ----
@@ -283,7 +285,7 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
         }
         __syncthreads();
         pf.stop(PH_RHS);
-        riccati_solve(L, d, tl);
+        riccati_solve<NTH>(L, d, tl);
         pf.stop(PH_SOLVE);
         amax = 1e300;
         {
@@ -305,7 +307,7 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        const double alpha = fmin(1.0, 0.995 * wave_min(amax));
+        const double alpha = fmin(1.0, 0.995 * blk_min<NTH>(amax, L.scr, tl, 7));
         pf.stop(PH_ROWS);
         if (!isfinite(alpha)) { status = 4; break; }
         if (alpha < 1e-12) { status = 3; break; }
@@ -326,8 +328,8 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
     return status;
 }
 
-template <int NLIN, int MM, int LPS>
-__global__ __launch_bounds__(NT) void tmpc_solve_fast_kernel(Dims d, int B, const double *__restrict__ xinit,
+template <int NLIN, int MM, int LPS, int NTH = 64>
+__global__ __launch_bounds__(NTH) void tmpc_solve_fast_kernel(Dims d, int B, const double *__restrict__ xinit,
                                                              const double *__restrict__ x0, const double *__restrict__ params,
                                                              double *__restrict__ xtraj, double *__restrict__ utraj,
                                                              double *__restrict__ pobj, int *__restrict__ exit_code,
@@ -336,6 +338,7 @@ __global__ __launch_bounds__(NT) void tmpc_solve_fast_kernel(Dims d, int B, cons
                                                              long long *__restrict__ prof_out)
 {
     using C = FastCfg<NLIN, MM, LPS>;
+    constexpr int NT = NTH;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int b = blockIdx.x, tid = threadIdx.x;
     if (b >= B) return;
@@ -367,7 +370,7 @@ __global__ __launch_bounds__(NT) void tmpc_solve_fast_kernel(Dims d, int B, cons
         __syncthreads();
         pf.stop(PH_LIN);
         int iters = 0;
-        qp_status = ipm_fast<NLIN, MM, LPS>(L, d, tid, xi, &iters, pf, lam);
+        qp_status = ipm_fast<NLIN, MM, LPS, NTH>(L, d, tid, xi, &iters, pf, lam);
         sqp_iter = it + 1; qp_iter_total += iters;
         if (qp_status != 0 && qp_status != 2) { status = 4; break; }
         status = 0;
@@ -393,7 +396,7 @@ __global__ __launch_bounds__(NT) void tmpc_solve_fast_kernel(Dims d, int B, cons
         if (qp_status != 0) break;
     }
     solve_epilogue(L, d, tid, b, xi, pb, slack, status, qp_status, sqp_iter, qp_iter_total, xtraj, utraj, pobj, exit_code,
-                   qp_status_out, sqp_iter_out, res_eq_out, qp_iter_out, prof_out, pf, t_begin);
+                   qp_status_out, sqp_iter_out, res_eq_out, qp_iter_out, prof_out, pf, t_begin, NTH);
 }
 
 }  // namespace tmpc

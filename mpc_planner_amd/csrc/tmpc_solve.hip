@@ -92,6 +92,31 @@ __device__ __forceinline__ double wave_sum(double x)
     return x;
 }
 
+// Workgroup reductions for the two-wave (128-thread) variant of the fast kernel: wave reduction, then one LDS exchange.
+// `scr` = L.scr (64 doubles); slots [base, base + 2 * n) are used.  NTH == 64 reduces to the wave reduction.
+template <int NTH, typename Op>
+__device__ __forceinline__ double blk_combine(double x, double *scr, int tid, int slot, Op op)
+{
+    if constexpr (NTH == 64) return x;
+    // every call site has its own slot and is reached once per interior-point iteration, with barriers in between:
+    // the previous readers of the slot are long done
+    if ((tid & 63) == 0) scr[slot * 2 + (tid >> 6)] = x;
+    __syncthreads();
+    return op(scr[slot * 2], scr[slot * 2 + 1]);
+}
+template <int NTH> __device__ __forceinline__ double blk_max(double x, double *scr, int tid, int slot = 0)
+{
+    return blk_combine<NTH>(wave_max(x), scr, tid, slot, [](double a, double b) { return fmax(a, b); });
+}
+template <int NTH> __device__ __forceinline__ double blk_min(double x, double *scr, int tid, int slot = 0)
+{
+    return blk_combine<NTH>(wave_min(x), scr, tid, slot, [](double a, double b) { return fmin(a, b); });
+}
+template <int NTH> __device__ __forceinline__ double blk_sum(double x, double *scr, int tid, int slot = 0)
+{
+    return blk_combine<NTH>(wave_sum(x), scr, tid, slot, [](double a, double b) { return a + b; });
+}
+
 // ---- interior-point row access --------------------------------------------------------------------
 struct Row { int k, var, general; double sgn; };   // general: index into D/beta; box: var = z index
 
@@ -183,9 +208,14 @@ enum { D8_XA = 0, D8_XW, D8_XP, D8_XV, D8_YA, D8_YW, D8_YP, D8_YV };
 // The sweeps below are strictly sequential over stages; to keep LDS latency off the critical path every
 // operand of stage k-1 is (re)loaded into the same registers right after its last use in stage k, so the loads
 // complete underneath the dependent Cholesky / readlane chain of stage k.
+// NTH = threads per trajectory: 64, or 128 for the two-wave variant, in which the sweeps run on wave 0 alone (wave 1
+// waits at the closing barrier) and only the stage-parallel loops use all threads.
+template <int NTH>
 __device__ bool riccati_factor(const Lds &L, const Dims &d, int tid)
 {
     const int N = d.N;
+    bool anybad = false;
+    if (NTH == 64 || tid < 64) {
     const int lane = tid;
     const bool rowl = lane < NV;
     const int ls = rowl ? lane : 0;
@@ -277,22 +307,28 @@ __device__ bool riccati_factor(const Lds &L, const Dims &d, int tid)
             if (lane == 1) { Fb[FB_L10] = f[0]; Fb[FB_R0] = r0; Fb[FB_R1] = r1; }
         }
     }
+    anybad = __any(bad);
+    if (NTH > 64 && tid == 0) L.scr[63] = anybad ? 1.0 : 0.0;
+    }
     __syncthreads();
-    return __any(bad);
+    if (NTH > 64) anybad = L.scr[63] != 0.0;
+    return anybad;
 }
 
 // ---- square-root Riccati: vector solve (backward + forward), rhs gh / rb -> dv, dpi ------------------
 // Lane j (< 7) = component j of the stage vector [u; x]; the cost-to-go gradient p lives in lanes 2..6.
+template <int NTH>
 __device__ void riccati_solve(const Lds &L, const Dims &d, int tid)
 {
     const int N = d.N;
+    const bool sweeper = NTH == 64 || tid < 64;          // wave 0 runs the sequential sweeps
     const int lane = tid;
     const bool rowl = lane < NV, xl = rowl && lane >= NU;
     const int ls = rowl ? lane : 0;
     const int i5 = xl ? lane - NU : 0;
     // q_k = P_{k+1} rb_k = Lxx (Lxx^T rb_k) for all stages at once (off the sequential chain); parked in dpi[k+1].
     // One lane per stage, fully unrolled (30 FMAs for the 5 components).
-    for (int k = tid; k < N; k += NT) {
+    for (int k = tid; k < N; k += NTH) {
         const double *Ln = L.Hh + (k + 1) * NP28 + FB_P;
         const double *r = L.rb + k * NX;
         double ll[15], rr[NX], tl[NX];
@@ -316,6 +352,7 @@ __device__ void riccati_solve(const Lds &L, const Dims &d, int tid)
         }
     }
     __syncthreads();
+    if (sweeper) {
     double p = L.gh[N * NV + ls];                       // p_N (lanes 2..6 meaningful)
     if (xl) L.pr[N * NX + i5] = p;
     {
@@ -344,9 +381,10 @@ __device__ void riccati_solve(const Lds &L, const Dims &d, int tid)
             if (k > 0) load_stage(k - 1);
         }
     }
+    }
     __syncthreads();
     // forward sweep; dx_0 = 0 (dx lives in lanes 2..6).  dx+ = A dx + B du + rb with A = I + E (E: columns psi, v).
-    {
+    if (sweeper) {
         double dx = 0.0;
         double lx0, lx1, y0, y1, r0, l10, r1, e_psi, e_v, b_a, b_w, rbi;
         auto load_stage = [&](int k) {
@@ -378,7 +416,7 @@ __device__ void riccati_solve(const Lds &L, const Dims &d, int tid)
     }
     __syncthreads();
     // dpi_k = P_k dx_k + p_k = Lxx (Lxx^T dx_k) + p_k, k = 1..N  (one lane per stage, unrolled)
-    for (int kk = tid; kk < N; kk += NT) {
+    for (int kk = tid; kk < N; kk += NTH) {
         const int k = kk + 1;
         const double *Lk = L.Hh + k * NP28 + FB_P;
         const double *dxk = L.dv + k * NV + NU;
@@ -555,14 +593,14 @@ __device__ int ipm_solve(const Lds &L, const Dims &d, int tid, int *iters_out, P
         }
         __syncthreads();
         pf.stop(PH_HH);
-        const bool fbad = riccati_factor(L, d, tid);
+        const bool fbad = riccati_factor<NT>(L, d, tid);
         pf.stop(PH_FACTOR);
         if (fbad) { status = 4; break; }
 
         // ---------------- predictor ----------------
         build_rhs(L, d, tid, true);
         pf.stop(PH_RHS);
-        riccati_solve(L, d, tid);
+        riccati_solve<NT>(L, d, tid);
         pf.stop(PH_SOLVE);
         double amax = 1e300;
         for (int r = tid; r < L.nrows; r += NT) {
@@ -593,7 +631,7 @@ __device__ int ipm_solve(const Lds &L, const Dims &d, int tid, int *iters_out, P
         pf.stop(PH_ROWS);
         build_rhs(L, d, tid, false);
         pf.stop(PH_RHS);
-        riccati_solve(L, d, tid);
+        riccati_solve<NT>(L, d, tid);
         pf.stop(PH_SOLVE);
         amax = 1e300;
         for (int r = tid; r < L.nrows; r += NT) {
@@ -691,7 +729,7 @@ __device__ void linearise(const Lds &L, const Dims &d, int tid, const double *pa
 __device__ void solve_epilogue(const Lds &L, const Dims &d, int tid, int b, const double *xi, const double *pb, double slack, int status,
                                int qp_status, int sqp_iter, int qp_iter_total, double *xtraj, double *utraj, double *pobj,
                                int *exit_code, int *qp_status_out, int *sqp_iter_out, double *res_eq_out, int *qp_iter_out,
-                               long long *prof_out, Prof &pf, long long t_begin)
+                               long long *prof_out, Prof &pf, long long t_begin, int nth = NT)
 {
     const int N = d.N;
     pf.start();
@@ -715,13 +753,13 @@ __device__ void solve_epilogue(const Lds &L, const Dims &d, int tid, int b, cons
     int tid_o = tid;
     asm volatile("" : "+v"(tid_o));
     if (tid_o < NX) res = fmax(res, fabs(L.z[NU + tid_o] - xi[tid_o]));
-    cost = wave_sum(cost); res = wave_max(res);
+    cost = wave_sum(cost); res = wave_max(res);              // contributions live in lanes < N + NX <= 64: wave 0 holds the totals
     const int nxe = ext_nx(d);
-    for (int e = tid_o; e < (N + 1) * nxe; e += NT) {
+    for (int e = tid_o; e < (N + 1) * nxe; e += nth) {
         const int k = e / nxe, i = e - k * nxe;
         xtraj[(size_t)b * (N + 1) * nxe + e] = i < NX ? L.z[k * NV + NU + i] : slack;      // the pinned slack state
     }
-    for (int e = tid_o; e < N * NU; e += NT) {
+    for (int e = tid_o; e < N * NU; e += nth) {
         const int k = e / NU, i = e - k * NU;
         utraj[(size_t)b * N * NU + e] = L.z[k * NV + i];
     }
@@ -1119,10 +1157,19 @@ typedef void (*SolveKernel)(Dims, int, const double *, const double *, const dou
 // return wrong iterates (spill/reload around partially-masked regions), see DESIGN.md section 5.  Shapes with more rows
 // per lane ((8,8) at 2 lanes/stage for N > 21, (12,12) at 2 lanes/stage) therefore use the generic kernel for now.  The library is
 // built with -mllvm -disable-machine-licm: hoisted constant materialisations were what pushed (12,12,3) into scratch.
-static SolveKernel pick_fast_kernel(const Dims &d)
+static SolveKernel pick_fast_kernel(const Dims &d, int *threads)
 {
+    *threads = NT;
     if (getenv("TMPC_FORCE_GENERIC")) return nullptr;
     const int lps = (3 * d.N <= NT) ? 3 : ((2 * d.N <= NT) ? 2 : 0);
+    if (lps != 3 && 4 * d.N <= 128 && !getenv("TMPC_NO_TWO_WAVE")) {
+        // two waves per trajectory, 4 lanes per stage (22 <= N <= 32: the reference's default N = 30 and BASELINE cfg 3)
+        SolveKernel k2 = nullptr;
+        if (d.n_up == 8 && d.M == 8) k2 = tmpc_solve_fast_kernel<8, 8, 4, 128>;
+        if (d.n_up == 12 && d.M == 12) k2 = tmpc_solve_fast_kernel<12, 12, 4, 128>;
+        if (d.n_up == 20 && d.M == 8) k2 = tmpc_solve_fast_kernel<20, 8, 4, 128>;      // cfg 3: 8 topology + 12 decomp rows + 8 ellipsoids
+        if (k2) { *threads = 128; return k2; }
+    }
     if (lps == 3) {
         if (d.n_up == 0 && d.M == 4) return tmpc_solve_fast_kernel<0, 4, 3>;
         if (d.n_up == 8 && d.M == 8) return tmpc_solve_fast_kernel<8, 8, 3>;
@@ -1151,6 +1198,7 @@ struct tmpc_handle {
     uint8_t *d_disabled = nullptr;
     size_t lds_bytes = 0;
     tmpc::SolveKernel kernel = nullptr;
+    int threads = tmpc::NT;          // threads per trajectory (64, or 128 for the two-wave fast variant)
     bool fast = false;
     std::vector<hipEvent_t> ev;      // per-launch timing events (pairs)
     int ev_used = 0;
@@ -1206,7 +1254,7 @@ int tmpc_create(tmpc_handle **out, const tmpc_dims *dims, int32_t B_max, int32_t
     d.n_sqp = dims->n_sqp; d.qp_iter_max = dims->qp_iter_max; d.erk_steps = dims->erk_steps;
     d.dt = dims->dt; d.qp_tol = dims->qp_tol; d.reg_eps = dims->reg_eps; d.mu0 = dims->ipm_mu0; d.thr0 = dims->ipm_thr0;
     for (int i = 0; i < TMPC_NV; i++) { d.lb[i] = dims->lb[i]; d.ub[i] = dims->ub[i]; }
-    h->kernel = tmpc::pick_fast_kernel(d);
+    h->kernel = tmpc::pick_fast_kernel(d, &h->threads);
     h->fast = h->kernel != nullptr;
     if (h->fast) h->lds_bytes = sizeof(double) * (size_t)tmpc::lds_doubles_fast(d.N, d.n_up + d.M);
     else { h->kernel = tmpc::tmpc_solve_kernel; h->lds_bytes = sizeof(double) * (size_t)tmpc::lds_doubles(d.N, d.n_up + d.M); }
@@ -1279,7 +1327,7 @@ int tmpc_solve(tmpc_handle *h)
     TMPC_HIP_CHECK(h, hipSetDevice(h->device));
     const bool rec = h->timing && h->ev_used + 2 <= (int)h->ev.size();
     if (rec) TMPC_HIP_CHECK(h, hipEventRecord(h->ev[h->ev_used], h->stream));
-    hipLaunchKernelGGL(h->kernel, dim3(h->B), dim3(tmpc::NT), h->lds_bytes, h->stream, h->d, h->B,
+    hipLaunchKernelGGL(h->kernel, dim3(h->B), dim3(h->threads), h->lds_bytes, h->stream, h->d, h->B,
                        h->xinit, h->x0, h->params, h->xtraj, h->utraj, h->pobj, h->exit_code, h->qp_status,
                        h->sqp_iter, h->res_eq, h->qp_iter, (long long *)nullptr);
     TMPC_HIP_CHECK(h, hipGetLastError());
@@ -1480,7 +1528,7 @@ int tmpc_debug_profile(tmpc_handle *h, int64_t *cycles, int32_t n_phases)
 #endif
     TMPC_HIP_CHECK(h, hipMalloc(&dp, n * 8));
     TMPC_HIP_CHECK(h, hipMemset(dp, 0, n * 8));
-    hipLaunchKernelGGL(h->kernel, dim3(h->B), dim3(tmpc::NT), h->lds_bytes, h->stream, h->d, h->B,
+    hipLaunchKernelGGL(h->kernel, dim3(h->B), dim3(h->threads), h->lds_bytes, h->stream, h->d, h->B,
                        h->xinit, h->x0, h->params, h->xtraj, h->utraj, h->pobj, h->exit_code, h->qp_status,
                        h->sqp_iter, h->res_eq, h->qp_iter, dp);
     TMPC_HIP_CHECK(h, hipGetLastError());

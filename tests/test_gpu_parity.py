@@ -226,16 +226,17 @@ def test_device_linearize_topology_matches_host_mirror():
     s.close()
 
 
-def test_fast_and_generic_kernels_agree():
-    """A/B: the registered fast kernel (rows in registers) against the generic kernel (TMPC_FORCE_GENERIC=1) on the bench
-    shape -- same integer outcomes, trajectories equal to rounding."""
+@pytest.mark.parametrize("N", [20, 30])
+def test_fast_and_generic_kernels_agree(N):
+    """A/B: the registered fast kernel (rows in registers; N = 20: one wave per trajectory, N = 30: the two-wave variant)
+    against the generic kernel (TMPC_FORCE_GENERIC=1) -- same integer outcomes, trajectories equal to rounding."""
     import subprocess, sys, tempfile
     code = (
         "import sys, numpy as np; sys.path.insert(0, %r)\n"
         "from mpc_planner_amd import scenes, solver\n"
-        "b = scenes.make_batch(range(300, 304), N=20, M=8, B=64)\n"
-        "s = solver.BatchedSolver(solver.default_dims(), B_max=256); s.set_batch(b['xinit'], b['x0'], b['params']); s.solve(); g = s.get()\n"
-        "np.savez(sys.argv[1], **g)\n" % os.path.dirname(HERE))
+        "b = scenes.make_batch(range(300, 304), N=%d, M=8, B=64)\n"
+        "s = solver.BatchedSolver(solver.default_dims(N=%d), B_max=256); s.set_batch(b['xinit'], b['x0'], b['params']); s.solve(); g = s.get()\n"
+        "np.savez(sys.argv[1], **g)\n" % (os.path.dirname(HERE), N, N))
     outs = []
     for env in ({}, {"TMPC_FORCE_GENERIC": "1"}):
         f = tempfile.NamedTemporaryFile(suffix=".npz", delete=False).name

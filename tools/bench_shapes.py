@@ -10,8 +10,8 @@ for name, kw, dims_kw, per_scene in (
         ("cfg1 MPCC+4 ellipsoids (no guidance), N=20", dict(N=20, M=4, B=64, guidance=False), dict(N=20, S=5, n_lin=0, M=4), 64),
         ("cfg2 T-MPC 8 obstacles, N=20", dict(N=20, M=8, B=64), dict(N=20, S=5, n_lin=8, M=8), 64),
         ("cfg4 T-MPC++ 12 obstacles, N=20", dict(N=20, M=12, B=63, tmpc_pp=True), dict(N=20, S=5, n_lin=12, M=12), 64),
-        ("reference default N=30, 8 obstacles (generic kernel)", dict(N=30, M=8, B=64), dict(N=30, S=5, n_lin=8, M=8), 64),
-        ("cfg3 slack model + guidance + ellipsoids + 12 decomp rows, N=30 (generic kernel)",
+        ("reference default N=30, 8 obstacles (two-wave fast kernel)", dict(N=30, M=8, B=64), dict(N=30, S=5, n_lin=8, M=8), 64),
+        ("cfg3 slack model + guidance + ellipsoids + 12 decomp rows, N=30 (two-wave fast kernel)",
          dict(N=30, M=8, B=64, slack=True, n_decomp=12), dict(N=30, S=5, n_lin=8, M=8, n_slk=12, slack=1), 64),
         ("cfg5 SH-MPC 24 scenario halfspaces, slack model, N=20, 32 guidance/scene",
          dict(N=20, M=8, B=32, slack=True, n_scenario=24), dict(N=20, S=5, n_lin=0, M=0, n_slk=24, slack=1), 32)):
