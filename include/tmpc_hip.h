@@ -95,6 +95,11 @@ int tmpc_set_batch_device(tmpc_handle *h, int32_t B, const void *d_xinit, const 
  * (:86-204) for all B trajectories: one kernel launch, asynchronous on the handle's stream. */
 int tmpc_solve(tmpc_handle *h);
 int tmpc_synchronize(tmpc_handle *h);
+/* Kernel variant for the following tmpc_solve calls: 0 (default) = throughput variant, 1 = latency variant (two waves per
+ * trajectory; for control ticks of a few planners, like the 8 OpenMP threads of guidance_constraints.cpp:279).  Returns
+ * 0, or 1 if the handle's shape has no separate latency variant (the default kernel is used).  A trajectory's result
+ * is bitwise independent of the batch it is solved in; the two variants agree to rounding (1e-11), not bitwise. */
+int tmpc_set_latency_mode(tmpc_handle *h, int32_t on);
 
 /* Replaces ocp_nlp_out_get / ocp_nlp_get / ocp_nlp_eval_cost of completeOneIteration (:162-204).
  * Any pointer may be NULL.  Synchronises the stream.  Host pointers. */

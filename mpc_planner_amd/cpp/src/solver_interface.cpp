@@ -96,6 +96,7 @@ namespace MPCPlanner
             std::printf("tmpc_create() returned status %d (no MI355X / library not built). Exiting.\n", status);
             std::exit(1);
         }
+        tmpc_set_latency_mode(_handle, 1);              // a Solver serves control ticks of a few planners: latency variant
     }
 
     Solver &Solver::operator=(const Solver &rhs) { _params = rhs._params; return *this; }      // (:67-77)
@@ -146,6 +147,7 @@ namespace MPCPlanner
             d.n_sqp = s0->_num_iterations; d.dt = s0->dt;
             for (auto &e : s0->_model_map) { d.lb[e.second.index] = e.second.lb; d.ub[e.second.index] = e.second.ub; }
             if (tmpc_create(&batch_handle, &d, B, 0)) { std::printf("tmpc_create() failed. Exiting.\n"); std::exit(1); }
+            tmpc_set_latency_mode(batch_handle, 1);     // same variant as solve(): solve() and solveBatch() stay bitwise equal
             batch_cap = B;
         }
         const size_t n0 = (SOLVER_NU + SOLVER_NX) * (SOLVER_N + 1), np = (size_t)SOLVER_NP * SOLVER_N;

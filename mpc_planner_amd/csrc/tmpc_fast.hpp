@@ -58,37 +58,42 @@ __device__ __forceinline__ double rcp_nr(double x)
 
 __device__ __forceinline__ void lds_add(double *p, double v) { atomicAdd(p, v); }   // ds_add_f64
 
-template <int NLIN, int MM, int LPS, int NTH>
-__device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, int *iters_out, Prof &pf,
+template <int NLIN, int MM, int LPS, int NTH, typename PF>
+__device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, int *iters_out, PF &pf,
                         double (&lam)[FastCfg<NLIN, MM, LPS>::RPL])
 {
     constexpr int NT = NTH;                         // threads per trajectory: 64 (one wave) or 128 (two waves; N > 21)
     using C = FastCfg<NLIN, MM, LPS>;
     constexpr int NH = C::NH, NR = C::NR, RPL = C::RPL;
+    constexpr bool DIET = LPS == 6;                 // 256-register budget (two waves per SIMD): recompute per-row values instead of storing them
     const int N = d.N;
     // Opaque copy of the lane id: keeps the compiler from hoisting this QP's per-row setup (masks, LDS addresses) out of
     // the RTI loop of the caller, where it would stay live across the register-hungry linearisation and be spilled.
     int tid_q = tid;
     asm volatile("" : "+v"(tid_q));
-    const int k = tid_q / LPS, c = tid_q - k * LPS;
-    const bool stage_lane = k < N;
+    // lane -> (stage, sub-lane): a stage never straddles the two waves, so the ds_add_f64 accumulations of a stage all
+    // come from one wave in lane order -- results do not depend on how the two waves happen to interleave
+    constexpr int SPW = 64 / LPS;                   // stages per wave
+    const int wl = tid_q & 63;
+    const int k = (tid_q >> 6) * SPW + wl / LPS, c = wl % LPS;
+    const bool stage_lane = wl < SPW * LPS && k < N;
     const int kk = stage_lane ? k : 0;
     const double m_rows = (double)(N * NH + 4 * N + 10 * (N - 1));
 
     // ---- load this lane's rows (signed coefficients) from the staging area into registers ----
     // per row: signed coefficients on (x, y, psi), signed rhs; box rows: sign in `upper`, variable index packed 3 bits/slot
     double sb[RPL];
-    int didx[RPL];                                  // row's Jacobian triple in L.D (box rows: the zero triple)
+    int didx_[DIET ? 1 : RPL];                      // row's Jacobian triple in L.D (box rows: the zero triple)
     unsigned act = 0, box = 0, upper = 0, neg = 0;  // neg: row sign is -1 (upper-bounded rows)
     unsigned long long varpack = 0;
 #pragma unroll
     for (int s = 0; s < RPL; s++) {
         const int r = c + LPS * s;
-        sb[s] = 0.0; didx[s] = N * NH * 3;
+        sb[s] = 0.0; if constexpr (!DIET) didx_[s] = N * NH * 3;
         if (stage_lane && r < NR) {
             if (r < NH) {
                 const double sgn = (r < NLIN) ? -1.0 : 1.0;     // topology / slack rows: upper bound 0; ellipsoids: lower bound 1
-                didx[s] = (k * NH + r) * 3;
+                if constexpr (!DIET) didx_[s] = (k * NH + r) * 3;
                 if (r < NLIN) neg |= 1u << s;
                 sb[s] = sgn * L.beta[k * NH + r];
                 act |= 1u << s;
@@ -109,7 +114,12 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
     }
     auto VAR = [&](int s) { return (int)((varpack >> (3 * s)) & 7ull); };
     // signed Jacobian of row s (general rows: +-D from LDS; box rows: zero triple)
-#define ROW_C(s) const double sg_ = (neg >> (s) & 1) ? -1.0 : 1.0; const double *Dr_ = L.D + didx[s]; \
+    // row's Jacobian triple in L.D (box rows and idle lanes: the zero triple behind the last row); recomputed, not stored
+    auto DIDX = [&](int s) {
+        if constexpr (!DIET) return didx_[DIET ? 0 : s];
+        const int r = c + LPS * s; return (stage_lane && r < NH) ? (k * NH + r) * 3 : N * NH * 3;
+    };
+#define ROW_C(s) const double sg_ = (neg >> (s) & 1) ? -1.0 : 1.0; const double *Dr_ = L.D + DIDX(s); \
     const double c0s = sg_ * Dr_[0], c1s = sg_ * Dr_[1], c2s = sg_ * Dr_[2];
 #define INVT(s) (LEAN ? rcp_nr(t[s]) : invt_[(LEAN ? 0 : (s))])
     auto CU = [&](int s) { return (box >> s & 1) ? ((upper >> s & 1) ? -1.0 : 1.0) : 0.0; };   // signed unit coefficient
@@ -122,7 +132,8 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
     __syncthreads();
 
     double t[RPL], qt[RPL];
-    constexpr bool LEAN = RPL > 10;                 // many rows per lane: recompute 1/t instead of keeping it (register budget)
+    constexpr bool LEAN = RPL > 10 || LPS == 6;     // recompute 1/t instead of keeping it: many rows per lane, or the 256-register
+                                                    // budget of the two-waves-per-SIMD instantiations
     double invt_[LEAN ? 1 : RPL];               // the row residual r_d = c.v - sb - t is recomputed where needed
     {
         const double vx = L.v[kk * NV + ZX], vy = L.v[kk * NV + ZY], vp = L.v[kk * NV + ZPSI];
@@ -231,35 +242,43 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
         // ---- predictor: rhs = rg + sum c (lam + d rd)  (q/t = lam) ----
         riccati_solve<NTH>(L, d, tl);
         pf.stop(PH_SOLVE);
-        double dt_[RPL];                                                  // dlam is recomputed from dt where needed
+        // Row step dt = c.dv + r_d is recomputed from the direction in LDS wherever it is needed (no per-row storage:
+        // the register budget decides how many waves a SIMD holds)
+        auto row_dt = [&](int s, double dx, double dy, double dp, double vx, double vy, double vp) {
+            const bool a = act >> s & 1;
+            const double dvv = L.dv[kk * NV + VAR(s)], vv = L.v[kk * NV + VAR(s)];
+            ROW_C(s)
+            const double cus = CU(s);
+            const double rds = c0s * vx + c1s * vy + c2s * vp + cus * vv - sb[s] - t[s];
+            const double ddot = c0s * dx + c1s * dy + c2s * dp + cus * dvv;
+            return a ? ddot + rds : 0.0;
+        };
+        double dt_[DIET ? 1 : RPL];                      // row steps (stored unless DIET)
         double amax = 1e300;
+        double mu_aff = 0.0;
+        double a_aff;
         {
             const double dx = L.dv[kk * NV + ZX], dy = L.dv[kk * NV + ZY], dp = L.dv[kk * NV + ZPSI];
             const double vx = L.v[kk * NV + ZX], vy = L.v[kk * NV + ZY], vp = L.v[kk * NV + ZPSI];
 #pragma unroll
             for (int s = 0; s < RPL; s++) {
                 const bool a = act >> s & 1;
-                const double dvv = L.dv[kk * NV + VAR(s)], vv = L.v[kk * NV + VAR(s)];
-                ROW_C(s)
-                const double cus = CU(s);
-                const double rds = c0s * vx + c1s * vy + c2s * vp + cus * vv - sb[s] - t[s];
-                const double ddot = c0s * dx + c1s * dy + c2s * dp + cus * dvv;
-                const double dt = a ? ddot + rds : 0.0;
+                const double dt = row_dt(s, dx, dy, dp, vx, vy, vp);
+                if constexpr (!DIET) dt_[DIET ? 0 : s] = dt;
                 const double dl = a ? -lam[s] - lam[s] * INVT(s) * dt : 0.0;
-                dt_[s] = dt;
                 if (dt < 0.0) amax = fmin(amax, -t[s] / dt);
                 if (dl < 0.0) amax = fmin(amax, -lam[s] / dl);
                 __builtin_amdgcn_sched_barrier(0);
             }
-        }
-        const double a_aff = fmin(1.0, blk_min<NTH>(amax, L.scr, tl, 5));
-        double mu_aff = 0.0;
+            a_aff = fmin(1.0, blk_min<NTH>(amax, L.scr, tl, 5));
 #pragma unroll
-        for (int s = 0; s < RPL; s++)
-            if (act >> s & 1) {
-                const double dl = -lam[s] - lam[s] * INVT(s) * dt_[s];
-                mu_aff += (lam[s] + a_aff * dl) * (t[s] + a_aff * dt_[s]);
-            }
+            for (int s = 0; s < RPL; s++)
+                if (act >> s & 1) {
+                    const double dt = DIET ? row_dt(s, dx, dy, dp, vx, vy, vp) : dt_[DIET ? 0 : s];
+                    const double dl = -lam[s] - lam[s] * INVT(s) * dt;
+                    mu_aff += (lam[s] + a_aff * dl) * (t[s] + a_aff * dt);
+                }
+        }
         mu_aff = blk_sum<NTH>(mu_aff, L.scr, tl, 6) / m_rows;
         double sigma = mu > 0.0 ? mu_aff / mu : 0.0;
         sigma = sigma * sigma * sigma;
@@ -268,12 +287,14 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
         __syncthreads();
         {
             double cs0 = 0, cs1 = 0, cs2 = 0;
+            const double dx = L.dv[kk * NV + ZX], dy = L.dv[kk * NV + ZY], dp = L.dv[kk * NV + ZPSI];   // predictor direction
             const double vx = L.v[kk * NV + ZX], vy = L.v[kk * NV + ZY], vp = L.v[kk * NV + ZPSI];
 #pragma unroll
             for (int s = 0; s < RPL; s++) {
                 const bool a = act >> s & 1;
-                const double dl = -lam[s] - lam[s] * INVT(s) * dt_[s];
-                qt[s] = a ? lam[s] + (dt_[s] * dl - sigma * mu) * INVT(s) : 0.0;
+                const double dta = DIET ? row_dt(s, dx, dy, dp, vx, vy, vp) : dt_[DIET ? 0 : s];
+                const double dl = -lam[s] - lam[s] * INVT(s) * dta;
+                qt[s] = a ? lam[s] + (dta * dl - sigma * mu) * INVT(s) : 0.0;
                 ROW_C(s)
                 const double rr = c0s * vx + c1s * vy + c2s * vp + CU(s) * L.v[kk * NV + VAR(s)] - sb[s] - t[s];
                 const double w = qt[s] + lam[s] * INVT(s) * (a ? rr : 0.0);
@@ -288,24 +309,17 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
         riccati_solve<NTH>(L, d, tl);
         pf.stop(PH_SOLVE);
         amax = 1e300;
-        {
-            const double dx = L.dv[kk * NV + ZX], dy = L.dv[kk * NV + ZY], dp = L.dv[kk * NV + ZPSI];
-            const double vx = L.v[kk * NV + ZX], vy = L.v[kk * NV + ZY], vp = L.v[kk * NV + ZPSI];
+        const double dxc = L.dv[kk * NV + ZX], dyc = L.dv[kk * NV + ZY], dpc = L.dv[kk * NV + ZPSI];
+        const double vxc = L.v[kk * NV + ZX], vyc = L.v[kk * NV + ZY], vpc = L.v[kk * NV + ZPSI];
 #pragma unroll
-            for (int s = 0; s < RPL; s++) {
-                const bool a = act >> s & 1;
-                const double dvv = L.dv[kk * NV + VAR(s)], vv = L.v[kk * NV + VAR(s)];
-                ROW_C(s)
-                const double cus = CU(s);
-                const double rds = c0s * vx + c1s * vy + c2s * vp + cus * vv - sb[s] - t[s];
-                const double ddot = c0s * dx + c1s * dy + c2s * dp + cus * dvv;
-                const double dt = a ? ddot + rds : 0.0;
-                const double dl = a ? -qt[s] - lam[s] * INVT(s) * dt : 0.0;
-                dt_[s] = dt;
-                if (dt < 0.0) amax = fmin(amax, -t[s] / dt);
-                if (dl < 0.0) amax = fmin(amax, -lam[s] / dl);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+        for (int s = 0; s < RPL; s++) {
+            const bool a = act >> s & 1;
+            const double dt = row_dt(s, dxc, dyc, dpc, vxc, vyc, vpc);
+            if constexpr (!DIET) dt_[DIET ? 0 : s] = dt;
+            const double dl = a ? -qt[s] - lam[s] * INVT(s) * dt : 0.0;
+            if (dt < 0.0) amax = fmin(amax, -t[s] / dt);
+            if (dl < 0.0) amax = fmin(amax, -lam[s] / dl);
+            __builtin_amdgcn_sched_barrier(0);
         }
         const double alpha = fmin(1.0, 0.995 * blk_min<NTH>(amax, L.scr, tl, 7));
         pf.stop(PH_ROWS);
@@ -314,11 +328,13 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
 #pragma unroll
         for (int s = 0; s < RPL; s++) {
             if (act >> s & 1) {
-                const double dl = -qt[s] - lam[s] * INVT(s) * dt_[s];
-                t[s] += alpha * dt_[s]; lam[s] += alpha * dl;
+                const double dt = DIET ? row_dt(s, dxc, dyc, dpc, vxc, vyc, vpc) : dt_[DIET ? 0 : s];
+                const double dl = -qt[s] - lam[s] * INVT(s) * dt;
+                t[s] += alpha * dt; lam[s] += alpha * dl;
                 if constexpr (!LEAN) invt_[s] = 1.0 / t[s];
             }
         }
+        __syncthreads();                                 // the rows read v / dv above; v changes below
         for (int e = tl; e < (N + 1) * NV; e += NT) L.v[e] += alpha * L.dv[e];
         for (int e = tl; e < N * NX; e += NT) L.pq[NX + e] += alpha * L.dpi[NX + e];
         __syncthreads();
@@ -328,8 +344,11 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
     return status;
 }
 
-template <int NLIN, int MM, int LPS, int NTH = 64>
-__global__ __launch_bounds__(NTH) void tmpc_solve_fast_kernel(Dims d, int B, const double *__restrict__ xinit,
+// Two-wave instantiations with 6 lanes per stage are built for two waves per SIMD (<= 256 registers): four trajectories
+// per CU stay resident with two waves each.  The build refuses any instantiation that needs scratch.
+template <int NLIN, int MM, int LPS, int NTH = 64, bool PROF = false>
+__global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu((NTH == 128 && LPS == 6 && !PROF) ? 2 : 1, (NTH == 128 && LPS == 6 && !PROF) ? 2 : 1)))
+void tmpc_solve_fast_kernel(Dims d, int B, const double *__restrict__ xinit,
                                                              const double *__restrict__ x0, const double *__restrict__ params,
                                                              double *__restrict__ xtraj, double *__restrict__ utraj,
                                                              double *__restrict__ pobj, int *__restrict__ exit_code,
@@ -346,7 +365,9 @@ __global__ __launch_bounds__(NTH) void tmpc_solve_fast_kernel(Dims d, int B, con
     const int N = d.N;
     const double *xi = xinit + (size_t)b * ext_nx(d);
     const double *pb = params + (size_t)b * N * d.npar;
-    const double slack = d.slack ? xi[NX] : 0.0;              // pinned by x_0 = xinit and slack' = 0 (tmpc_stage.hpp)
+    // slack value: pinned by x_0 = xinit and slack' = 0 (tmpc_stage.hpp).  Re-read where it is used instead of being kept
+    // in registers across the whole solve.
+    auto slack_of = [&]() { return d.slack ? __builtin_nontemporal_load(xi + NX) : 0.0; };
 
     for (int e = tid; e < (N + 1) * NV; e += NT) {
         const int k = e / NV, i = e - k * NV;
@@ -359,14 +380,14 @@ __global__ __launch_bounds__(NTH) void tmpc_solve_fast_kernel(Dims d, int B, con
     if (tid < NU) L.z[N * NV + tid] = 0.0;
     __syncthreads();
 
-    Prof pf; pf.out = prof_out;
-    for (int i = 0; i < PH_COUNT; i++) pf.acc[i] = 0;
-    const long long t_begin = prof_out ? clock64() : 0;
+    typename std::conditional<PROF, Prof, NoProf>::type pf;
+    pf.init(prof_out);
+    const long long t_begin = (PROF && prof_out) ? clock64() : 0;
     int status = 0, qp_status = 0, sqp_iter = 0, qp_iter_total = 0;
     double lam[C::RPL];
     for (int it = 0; it < d.n_sqp; it++) {
         pf.start();
-        linearise<true>(L, d, tid, pb, slack);
+        linearise<true>(L, d, tid, pb, slack_of());
         __syncthreads();
         pf.stop(PH_LIN);
         int iters = 0;
@@ -384,8 +405,10 @@ __global__ __launch_bounds__(NTH) void tmpc_solve_fast_kernel(Dims d, int B, con
         for (int e = tid_w; e < N * NX; e += NT) L.pi[NX + e] = L.pq[NX + e];
         __syncthreads();
         // multipliers of the general rows for the next linearisation: (lam_upper - lam_lower) = -sgn lam
-        const int k = tid_w / LPS, c = tid_w - k * LPS;
-        if (k < N) {
+        constexpr int SPW = 64 / LPS;
+        const int wl = tid_w & 63;
+        const int k = (tid_w >> 6) * SPW + wl / LPS, c = wl % LPS;
+        if (wl < SPW * LPS && k < N) {
 #pragma unroll
             for (int s = 0; s < C::RPL; s++) {
                 const int r = c + LPS * s;
@@ -395,7 +418,7 @@ __global__ __launch_bounds__(NTH) void tmpc_solve_fast_kernel(Dims d, int B, con
         __syncthreads();
         if (qp_status != 0) break;
     }
-    solve_epilogue(L, d, tid, b, xi, pb, slack, status, qp_status, sqp_iter, qp_iter_total, xtraj, utraj, pobj, exit_code,
+    solve_epilogue(L, d, tid, b, xi, pb, slack_of(), status, qp_status, sqp_iter, qp_iter_total, xtraj, utraj, pobj, exit_code,
                    qp_status_out, sqp_iter_out, res_eq_out, qp_iter_out, prof_out, pf, t_begin, NTH);
 }
 

@@ -21,6 +21,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/tmpc_hip.h"
@@ -220,7 +221,7 @@ __device__ bool riccati_factor(const Lds &L, const Dims &d, int tid)
     const bool rowl = lane < NV;
     const int ls = rowl ? lane : 0;
     const int i5 = lane - NU;                        // state index of lanes 2..6
-    const double dt = d.dt, hdt2 = 0.5 * d.dt * d.dt;
+    const double dt = d.dt, hdt2 = d.hdt2;
     bool bad = false;
     double f[NV], hk[NV], ba[NX], dn[8];
     auto load_stage = [&](int k) {
@@ -321,8 +322,10 @@ template <int NTH>
 __device__ void riccati_solve(const Lds &L, const Dims &d, int tid)
 {
     const int N = d.N;
-    const bool sweeper = NTH == 64 || tid < 64;          // wave 0 runs the sequential sweeps
-    const int lane = tid;
+    // two-wave variant: the vector sweeps run on wave 1 (the factorisation on wave 0), so that with two trajectories'
+    // waves sharing a SIMD pair the sequential work is spread over both SIMDs
+    const bool sweeper = NTH == 64 || tid >= 64;
+    const int lane = NTH == 64 ? tid : (tid >= 64 ? tid - 64 : 64);
     const bool rowl = lane < NV, xl = rowl && lane >= NU;
     const int ls = rowl ? lane : 0;
     const int i5 = xl ? lane - NU : 0;
@@ -492,8 +495,23 @@ __device__ void build_rhs(const Lds &L, const Dims &d, int tid, bool predictor)
 enum { PH_LIN = 0, PH_RES, PH_HH, PH_FACTOR, PH_RHS, PH_SOLVE, PH_ROWS, PH_UPDATE, PH_FINAL, PH_TOTAL, PH_COUNT };
 struct Prof {
     long long *out; long long acc[PH_COUNT]; long long t0;
+    __device__ __forceinline__ void init(long long *o) { out = o; for (int i = 0; i < PH_COUNT; i++) acc[i] = 0; }
     __device__ __forceinline__ void start() { if (out) t0 = clock64(); }
     __device__ __forceinline__ void stop(int ph) { if (out) { const long long t1 = clock64(); acc[ph] += t1 - t0; t0 = t1; } }
+    __device__ __forceinline__ void finish(int tid, int b, long long t_begin)
+    {
+        if (!out) return;
+        stop(PH_FINAL);
+        acc[PH_TOTAL] = clock64() - t_begin;
+        if (tid == 0) for (int i = 0; i < PH_COUNT; i++) out[(size_t)b * PH_COUNT + i] = acc[i];
+    }
+};
+// Production instantiations of the fast kernel carry no profiling state (the 10 phase accumulators cost ~20 registers).
+struct NoProf {
+    __device__ __forceinline__ void init(long long *) {}
+    __device__ __forceinline__ void start() {}
+    __device__ __forceinline__ void stop(int) {}
+    __device__ __forceinline__ void finish(int, int, long long) {}
 };
 
 // One QP solve.  Returns status (0 ok, 2 max iter, 3 min step, 4 NaN); *iters = IPM iterations.
@@ -726,10 +744,11 @@ __device__ void linearise(const Lds &L, const Dims &d, int tid, const double *pa
 }
 
 // ---- completeOneIteration (acados_solver_interface.cpp:162-204): cost, trajectories, res_eq, exit-code mapping ----
+template <typename PF>
 __device__ void solve_epilogue(const Lds &L, const Dims &d, int tid, int b, const double *xi, const double *pb, double slack, int status,
                                int qp_status, int sqp_iter, int qp_iter_total, double *xtraj, double *utraj, double *pobj,
                                int *exit_code, int *qp_status_out, int *sqp_iter_out, double *res_eq_out, int *qp_iter_out,
-                               long long *prof_out, Prof &pf, long long t_begin, int nth = NT)
+                               long long *prof_out, PF &pf, long long t_begin, int nth = NT)
 {
     const int N = d.N;
     pf.start();
@@ -770,11 +789,8 @@ __device__ void solve_epilogue(const Lds &L, const Dims &d, int tid, int b, cons
         exit_code[b] = status == 0 ? 1 : (status == 1 ? 0 : status);      // Forces-style mapping (:197-201)
         qp_status_out[b] = qp_status; sqp_iter_out[b] = sqp_iter; qp_iter_out[b] = qp_iter_total;
     }
-    if (prof_out) {
-        pf.stop(PH_FINAL);
-        pf.acc[PH_TOTAL] = clock64() - t_begin;
-        if (tid == 0) for (int i = 0; i < PH_COUNT; i++) prof_out[(size_t)b * PH_COUNT + i] = pf.acc[i];
-    }
+    (void)prof_out;
+    pf.finish(tid, b, t_begin);
 }
 
 // ---- the solve kernel ---------------------------------------------------------------------------
@@ -806,8 +822,7 @@ __global__ __launch_bounds__(NT) void tmpc_solve_kernel(Dims d, int B, const dou
     if (tid < NU) L.z[N * NV + tid] = 0.0;
     __syncthreads();
 
-    Prof pf; pf.out = prof_out;
-    for (int i = 0; i < PH_COUNT; i++) pf.acc[i] = 0;
+    Prof pf; pf.init(prof_out);
     const long long t_begin = prof_out ? clock64() : 0;
     int status = 0, qp_status = 0, sqp_iter = 0, qp_iter_total = 0;
     for (int it = 0; it < d.n_sqp; it++) {
@@ -1157,7 +1172,9 @@ typedef void (*SolveKernel)(Dims, int, const double *, const double *, const dou
 // return wrong iterates (spill/reload around partially-masked regions), see DESIGN.md section 5.  Shapes with more rows
 // per lane ((8,8) at 2 lanes/stage for N > 21, (12,12) at 2 lanes/stage) therefore use the generic kernel for now.  The library is
 // built with -mllvm -disable-machine-licm: hoisted constant materialisations were what pushed (12,12,3) into scratch.
-static SolveKernel pick_fast_kernel(const Dims &d, int *threads)
+// prof: the instrumented instantiation (tmpc_debug_profile) instead of the production one.
+#define TMPC_FAST(...) (prof ? (SolveKernel)tmpc_solve_fast_kernel<__VA_ARGS__, true> : (SolveKernel)tmpc_solve_fast_kernel<__VA_ARGS__, false>)
+static SolveKernel pick_fast_kernel(const Dims &d, int *threads, bool prof)
 {
     *threads = NT;
     if (getenv("TMPC_FORCE_GENERIC")) return nullptr;
@@ -1165,23 +1182,30 @@ static SolveKernel pick_fast_kernel(const Dims &d, int *threads)
     if (lps != 3 && 4 * d.N <= 128 && !getenv("TMPC_NO_TWO_WAVE")) {
         // two waves per trajectory, 4 lanes per stage (22 <= N <= 32: the reference's default N = 30 and BASELINE cfg 3)
         SolveKernel k2 = nullptr;
-        if (d.n_up == 8 && d.M == 8) k2 = tmpc_solve_fast_kernel<8, 8, 4, 128>;
-        if (d.n_up == 12 && d.M == 12) k2 = tmpc_solve_fast_kernel<12, 12, 4, 128>;
-        if (d.n_up == 20 && d.M == 8) k2 = tmpc_solve_fast_kernel<20, 8, 4, 128>;      // cfg 3: 8 topology + 12 decomp rows + 8 ellipsoids
+        if (d.n_up == 8 && d.M == 8) k2 = TMPC_FAST(8, 8, 4, 128);
+        if (d.n_up == 12 && d.M == 12) k2 = TMPC_FAST(12, 12, 4, 128);
+        if (d.n_up == 20 && d.M == 8) k2 = TMPC_FAST(20, 8, 4, 128);      // cfg 3: 8 topology + 12 decomp rows + 8 ellipsoids
         if (k2) { *threads = 128; return k2; }
     }
     if (lps == 3) {
-        if (d.n_up == 0 && d.M == 4) return tmpc_solve_fast_kernel<0, 4, 3>;
-        if (d.n_up == 8 && d.M == 8) return tmpc_solve_fast_kernel<8, 8, 3>;
-        if (d.n_up == 12 && d.M == 12) return tmpc_solve_fast_kernel<12, 12, 3>;      // zero scratch only with machine-LICM off (build flag)
-        if (d.n_up == 24 && d.M == 0) return tmpc_solve_fast_kernel<24, 0, 3>;        // SH-MPC: 24 scenario halfspaces (cfg 5)
+        if (d.n_up == 0 && d.M == 4) return TMPC_FAST(0, 4, 3, 64);
+        if (d.n_up == 8 && d.M == 8) return TMPC_FAST(8, 8, 3, 64);
+        if (d.n_up == 12 && d.M == 12) return TMPC_FAST(12, 12, 3, 64);      // zero scratch only with machine-LICM off (build flag)
+        if (d.n_up == 24 && d.M == 0) return TMPC_FAST(24, 0, 3, 64);        // SH-MPC: 24 scenario halfspaces (cfg 5)
     } else if (lps == 2) {
-        if (d.n_up == 0 && d.M == 4) return tmpc_solve_fast_kernel<0, 4, 2>;
+        if (d.n_up == 0 && d.M == 4) return TMPC_FAST(0, 4, 2, 64);
     }
-#ifdef TMPC_TRY_ALL      // compile-only probe of candidate shapes (resource remarks); never dispatched in the shipped build
-    if (d.n_up == 8 && d.M == 8 && lps == 2) return tmpc_solve_fast_kernel<8, 8, 2>;
-    if (d.n_up == 12 && d.M == 12 && lps == 2) return tmpc_solve_fast_kernel<12, 12, 2>;
-#endif
+    return nullptr;
+}
+// Latency variant (tmpc_set_latency_mode): two waves per trajectory at 6 lanes per stage, built for two waves per SIMD
+// (<= 256 registers, so four trajectories per CU stay resident).  The stage-parallel phases run on twice the lanes:
+// -8 % kernel time on a 64-trajectory control tick; on a saturated GPU the one-wave kernel is as fast or faster, which is
+// why it stays the default.  The variant is chosen by the caller, never by the batch size: a trajectory's result does
+// not depend on what else is in the launch.
+static SolveKernel pick_latency_kernel(const Dims &d, bool prof)
+{
+    if (getenv("TMPC_FORCE_GENERIC") || getenv("TMPC_NO_TWO_WAVE") || d.N > 2 * (64 / 6)) return nullptr;
+    if (d.n_up == 8 && d.M == 8) return TMPC_FAST(8, 8, 6, 128);
     return nullptr;
 }
 }  // namespace tmpc
@@ -1199,6 +1223,8 @@ struct tmpc_handle {
     size_t lds_bytes = 0;
     tmpc::SolveKernel kernel = nullptr;
     int threads = tmpc::NT;          // threads per trajectory (64, or 128 for the two-wave fast variant)
+    tmpc::SolveKernel kernel_lat = nullptr;   // optional latency variant (128 threads), used when latency_mode is on
+    bool latency_mode = false;
     bool fast = false;
     std::vector<hipEvent_t> ev;      // per-launch timing events (pairs)
     int ev_used = 0;
@@ -1250,11 +1276,12 @@ int tmpc_create(tmpc_handle **out, const tmpc_dims *dims, int32_t B_max, int32_t
     h->device = device; h->B_max = B_max;
     tmpc::Dims &d = h->d;
     d.N = dims->N; d.S = dims->S; d.n_lin = dims->n_lin; d.M = dims->M; d.npar = dims->npar;
-    d.n_slk = dims->n_slk; d.slack = dims->slack; d.n_up = d.n_lin + d.n_slk;
+    d.n_slk = dims->n_slk; d.slack = dims->slack;
     d.n_sqp = dims->n_sqp; d.qp_iter_max = dims->qp_iter_max; d.erk_steps = dims->erk_steps;
     d.dt = dims->dt; d.qp_tol = dims->qp_tol; d.reg_eps = dims->reg_eps; d.mu0 = dims->ipm_mu0; d.thr0 = dims->ipm_thr0;
     for (int i = 0; i < TMPC_NV; i++) { d.lb[i] = dims->lb[i]; d.ub[i] = dims->ub[i]; }
-    h->kernel = tmpc::pick_fast_kernel(d, &h->threads);
+    tmpc::derive_dims(d);
+    h->kernel = tmpc::pick_fast_kernel(d, &h->threads, false);
     h->fast = h->kernel != nullptr;
     if (h->fast) h->lds_bytes = sizeof(double) * (size_t)tmpc::lds_doubles_fast(d.N, d.n_up + d.M);
     else { h->kernel = tmpc::tmpc_solve_kernel; h->lds_bytes = sizeof(double) * (size_t)tmpc::lds_doubles(d.N, d.n_up + d.M); }
@@ -1264,6 +1291,10 @@ int tmpc_create(tmpc_handle **out, const tmpc_dims *dims, int32_t B_max, int32_t
     if (hipFuncSetAttribute((const void *)h->kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)h->lds_bytes) != hipSuccess)
         return fail(TMPC_ERR_NO_DEVICE);
+    if (h->fast && h->threads == tmpc::NT && (h->kernel_lat = tmpc::pick_latency_kernel(d, false)) != nullptr) {
+        if (hipFuncSetAttribute((const void *)h->kernel_lat, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes) != hipSuccess)
+            h->kernel_lat = nullptr;
+    }
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return fail(TMPC_ERR_HIP);
     const size_t N = d.N, B = B_max;
     bool ok = true;
@@ -1327,12 +1358,20 @@ int tmpc_solve(tmpc_handle *h)
     TMPC_HIP_CHECK(h, hipSetDevice(h->device));
     const bool rec = h->timing && h->ev_used + 2 <= (int)h->ev.size();
     if (rec) TMPC_HIP_CHECK(h, hipEventRecord(h->ev[h->ev_used], h->stream));
-    hipLaunchKernelGGL(h->kernel, dim3(h->B), dim3(h->threads), h->lds_bytes, h->stream, h->d, h->B,
+    const bool lat = h->kernel_lat && h->latency_mode;
+    hipLaunchKernelGGL(lat ? h->kernel_lat : h->kernel, dim3(h->B), dim3(lat ? 128 : h->threads), h->lds_bytes, h->stream, h->d, h->B,
                        h->xinit, h->x0, h->params, h->xtraj, h->utraj, h->pobj, h->exit_code, h->qp_status,
                        h->sqp_iter, h->res_eq, h->qp_iter, (long long *)nullptr);
     TMPC_HIP_CHECK(h, hipGetLastError());
     if (rec) { TMPC_HIP_CHECK(h, hipEventRecord(h->ev[h->ev_used + 1], h->stream)); h->ev_used += 2; }
     return TMPC_OK;
+}
+
+int tmpc_set_latency_mode(tmpc_handle *h, int32_t on)
+{
+    if (!h) return TMPC_ERR_INVALID;
+    h->latency_mode = on != 0;
+    return (h->latency_mode && !h->kernel_lat) ? 1 : TMPC_OK;      // 1: accepted, but this shape has no latency variant
 }
 
 int tmpc_synchronize(tmpc_handle *h)
@@ -1528,7 +1567,13 @@ int tmpc_debug_profile(tmpc_handle *h, int64_t *cycles, int32_t n_phases)
 #endif
     TMPC_HIP_CHECK(h, hipMalloc(&dp, n * 8));
     TMPC_HIP_CHECK(h, hipMemset(dp, 0, n * 8));
-    hipLaunchKernelGGL(h->kernel, dim3(h->B), dim3(h->threads), h->lds_bytes, h->stream, h->d, h->B,
+    tmpc::SolveKernel pk = h->kernel;                   // the generic kernel profiles itself; fast shapes have an instrumented twin
+    if (h->fast) {
+        int thr = 0;
+        pk = tmpc::pick_fast_kernel(h->d, &thr, true);
+        TMPC_HIP_CHECK(h, hipFuncSetAttribute((const void *)pk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
+    }
+    hipLaunchKernelGGL(pk, dim3(h->B), dim3(h->threads), h->lds_bytes, h->stream, h->d, h->B,
                        h->xinit, h->x0, h->params, h->xtraj, h->utraj, h->pobj, h->exit_code, h->qp_status,
                        h->sqp_iter, h->res_eq, h->qp_iter, dp);
     TMPC_HIP_CHECK(h, hipGetLastError());

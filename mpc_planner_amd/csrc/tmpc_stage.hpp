@@ -34,7 +34,17 @@ struct Dims {
     int n_slk;      // decomp / scenario halfspace rows  a1 x + a2 y - (b + slack) <= 0
     int slack;      // 1: slack model (nx = 6, nvar = 8 in the external layouts; MPCBase weighs the slack)
     int n_up;       // upper-bounded general rows = n_lin + n_slk.  Internal row order: [topology | slack rows | ellipsoids]
+    // derived on the host (tmpc_create) so that the kernels read them as scalar kernel arguments instead of keeping
+    // loop-invariant VGPR copies alive across the whole solve:
+    double erk_h, erk_eta, erk_w6;   // dt / erk_steps, its half, its sixth
+    double hdt2;                     // dt^2 / 2
 };
+__host__ inline void derive_dims(Dims &d)
+{
+    d.n_up = d.n_lin + d.n_slk;
+    d.erk_h = d.dt / d.erk_steps; d.erk_eta = 0.5 * d.erk_h; d.erk_w6 = d.erk_h / 6.0;
+    d.hdt2 = 0.5 * d.dt * d.dt;
+}
 __host__ __device__ __forceinline__ int ext_nx(const Dims &d) { return NX + d.slack; }   // strides of xinit / xtraj
 __host__ __device__ __forceinline__ int ext_nv(const Dims &d) { return NV + d.slack; }   // stride of x0
 
@@ -77,13 +87,13 @@ struct DynOut {
 __device__ __forceinline__ void dyn_eval(const Dims &d, const double *z, DynOut &o, bool second_order)
 {
     const double a = z[ZA], w = z[ZW], psi = z[ZPSI], v = z[ZV];
-    const double h = d.dt / d.erk_steps, eta = 0.5 * h, w6 = h / 6.0;
+    const double eta = d.erk_eta, w6 = d.erk_w6;
     const int last = 2 * d.erk_steps;
     double C0 = 0, C1 = 0, C2 = 0, S0 = 0, S1 = 0, S2 = 0;
     double nC0 = 0, nC1 = 0, nC2 = 0, nS0 = 0, nS1 = 0, nS2 = 0;
     for (int m = 0; m <= last; m++) {
         const double om = w6 * ((m == 0 || m == last) ? 1.0 : ((m & 1) ? 4.0 : 2.0));
-        const double tau = m * eta;
+        const double tau = m == 0 ? 0.0 : m * eta;          // (literal 0 for the first node: nothing loop-invariant to keep in a VGPR)
         double sn, cs;
         sincos(psi + tau * w, &sn, &cs);
         const double nu = v + tau * a;
@@ -97,7 +107,7 @@ __device__ __forceinline__ void dyn_eval(const Dims &d, const double *z, DynOut 
     o.xn[1] = z[ZY] + nS0;
     o.xn[2] = psi + d.dt * w;
     o.xn[3] = v + d.dt * a;
-    o.xn[4] = z[ZS] + d.dt * v + 0.5 * d.dt * d.dt * a;
+    o.xn[4] = z[ZS] + d.dt * v + d.hdt2 * a;
     o.Xa = C1; o.Xw = -nS1; o.Xp = -nS0; o.Xv = C0;
     o.Ya = S1; o.Yw = nC1; o.Yp = nC0; o.Yv = S0;
     if (second_order) {
@@ -115,7 +125,7 @@ __device__ __forceinline__ void dyn_jacobian(const Dims &d, const DynOut &o, dou
     BA[1 * NV + ZA] = o.Ya; BA[1 * NV + ZW] = o.Yw; BA[1 * NV + ZY] = 1.0; BA[1 * NV + ZPSI] = o.Yp; BA[1 * NV + ZV] = o.Yv;
     BA[2 * NV + ZW] = d.dt; BA[2 * NV + ZPSI] = 1.0;
     BA[3 * NV + ZA] = d.dt; BA[3 * NV + ZV] = 1.0;
-    BA[4 * NV + ZA] = 0.5 * d.dt * d.dt; BA[4 * NV + ZV] = d.dt; BA[4 * NV + ZS] = 1.0;
+    BA[4 * NV + ZA] = d.hdt2; BA[4 * NV + ZV] = d.dt; BA[4 * NV + ZS] = 1.0;
 }
 
 // W += pix * hess(x+) + piy * hess(y+)   (W full symmetric 7x7)
@@ -461,7 +471,8 @@ __device__ __forceinline__ void stage_linearise(const Dims &d, const double *z, 
     CostOut co;
     cost_eval(d, z, p, pstride, co, true, slack);
 #pragma unroll
-    for (int i = 0; i < NV; i++) g[i] = d.dt * co.g[i];          // stage cost scaled by the shooting interval
+    for (int i = 0; i < NV; i++) g[i] = (i == ZPSI) ? 0.0 : d.dt * co.g[i];   // stage cost scaled by the shooting interval (the cost
+                                                                        // does not depend on psi: literal 0, not a hoisted dt * 0)
     cost_add_hessian(co, d.dt, W);
     RowOut ro;
     for (int j = 0; j < d.n_lin; j++) {

@@ -36,7 +36,7 @@ class TmpcDims(C.Structure):
 
 
 EXPORTS = ["tmpc_default_dims", "tmpc_default_dims_ex", "tmpc_create", "tmpc_destroy", "tmpc_last_error", "tmpc_set_batch",
-           "tmpc_set_batch_device", "tmpc_solve", "tmpc_synchronize", "tmpc_get", "tmpc_select_best",
+           "tmpc_set_batch_device", "tmpc_solve", "tmpc_set_latency_mode", "tmpc_synchronize", "tmpc_get", "tmpc_select_best",
            "tmpc_result_device_ptrs", "tmpc_time_solve", "tmpc_debug_eval_stage", "tmpc_pack_records",
            "tmpc_select_best_records", "tmpc_enable_timing", "tmpc_get_timings", "tmpc_debug_profile",
            "tmpc_linearize_topology", "tmpc_scenario_halfspaces", "tmpc_warmstart", "tmpc_init_with_guidance",
@@ -67,6 +67,7 @@ def load_library():
         lib.tmpc_set_batch.argtypes = [vp, C.c_int32, vp, vp, vp]
         lib.tmpc_set_batch_device.argtypes = [vp, C.c_int32, vp, vp, vp]
         lib.tmpc_solve.argtypes = [vp]
+        lib.tmpc_set_latency_mode.argtypes = [vp, C.c_int32]
         lib.tmpc_synchronize.argtypes = [vp]
         lib.tmpc_get.argtypes = [vp] + [vp] * 8
         lib.tmpc_select_best.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, C.POINTER(C.c_int32)]
@@ -153,6 +154,13 @@ class BatchedSolver:
         self._check(self.lib.tmpc_solve(self._h), "tmpc_solve")
         if sync:
             self._check(self.lib.tmpc_synchronize(self._h), "tmpc_synchronize")
+
+    def set_latency_mode(self, on=True):
+        """Two-waves-per-trajectory kernel variant for small control ticks; returns False if the shape has none."""
+        rc = self.lib.tmpc_set_latency_mode(self._h, int(bool(on)))
+        if rc < 0:
+            self._check(rc, "tmpc_set_latency_mode")
+        return rc == 0
 
     def synchronize(self):
         self._check(self.lib.tmpc_synchronize(self._h), "tmpc_synchronize")

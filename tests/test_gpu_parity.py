@@ -418,3 +418,29 @@ def test_device_cross_tick_warmstart_matches_host_mirror():
     assert np.array_equal(a["exit_code"], bb["exit_code"]) and np.array_equal(a["xtraj"], bb["xtraj"])
     assert (a["exit_code"] == 1).sum() >= B // 2
     s.close(); s2.close()
+
+
+def test_latency_variant_matches_oracle_and_default_kernel():
+    """tmpc_set_latency_mode: the two-waves-per-trajectory variant of the cfg 2 kernel against the oracle (same assertions as
+    the default kernel) and against the default kernel (equal to rounding); its result for a trajectory is bitwise the
+    same whether it is solved alone or inside a batch."""
+    import oracle_lib as O
+    from mpc_planner_amd import scenes
+    sc = scenes.make_scene(1, N=20, M=8, B=64)
+    s = _solver()
+    assert s.set_latency_mode(True)
+    s.set_batch(sc["xinit"], sc["x0"], sc["params"]); s.solve(); lat = s.get()
+    pb = O.problem(N=20, S=5, n_lin=8, M=8)
+    xt, ut, info = O.solve_batch(pb, sc["xinit"], sc["x0"].reshape(64, -1), sc["params"].reshape(64, -1))
+    _compare(lat, xt, ut, info)
+    s.set_batch(sc["xinit"][7:8], sc["x0"][7:8], sc["params"][7:8]); s.solve(); one = s.get()
+    assert np.array_equal(one["xtraj"][0], lat["xtraj"][7]) and one["pobj"][0] == lat["pobj"][7]
+    s.set_latency_mode(False)
+    s.set_batch(sc["xinit"], sc["x0"], sc["params"]); s.solve(); dflt = s.get()
+    assert np.array_equal(dflt["exit_code"], lat["exit_code"]) and np.array_equal(dflt["sqp_iter"], lat["sqp_iter"])
+    ok = dflt["exit_code"] == 1
+    np.testing.assert_allclose(lat["xtraj"][ok], dflt["xtraj"][ok], rtol=0, atol=1e-8)
+    s.close()
+    s5 = _solver(n_lin=0, M=0, n_slk=24, slack=1, B_max=4)        # a shape without a latency variant: accepted, default kernel
+    assert s5.set_latency_mode(True) is False
+    s5.close()
