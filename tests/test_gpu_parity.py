@@ -444,3 +444,33 @@ def test_latency_variant_matches_oracle_and_default_kernel():
     s5 = _solver(n_lin=0, M=0, n_slk=24, slack=1, B_max=4)        # a shape without a latency variant: accepted, default kernel
     assert s5.set_latency_mode(True) is False
     s5.close()
+
+
+@pytest.mark.parametrize("N", [2, 5, 21, 22, 32])
+def test_horizon_edges_match_oracle(N):
+    """Horizon edge cases of the kernel dispatch: N = 2 (minimum), 21 (last one-wave shape: 63 of 64 lanes), 22 (first
+    two-wave shape), 32 (all 128 lanes of the two-wave kernel; the oracle's maximum)."""
+    import oracle_lib as O
+    from mpc_planner_amd import scenes
+    B = 16
+    sc = scenes.make_scene(40 + N, N=N, M=8, B=B)
+    s = _solver(N=N, B_max=B)
+    s.set_batch(sc["xinit"], sc["x0"], sc["params"]); s.solve(); got = s.get()
+    pb = O.problem(N=N, S=5, n_lin=8, M=8)
+    xt, ut, info = O.solve_batch(pb, sc["xinit"], sc["x0"].reshape(B, -1), sc["params"].reshape(B, -1))
+    _compare(got, xt, ut, info)
+    s.close()
+
+
+def test_create_rejects_unsupported_dimensions():
+    from mpc_planner_amd import solver
+    for kw in (dict(N=1), dict(N=63), dict(N=20, npar=7), dict(N=20, erk_steps=0)):
+        d = solver.default_dims(**{k: v for k, v in kw.items() if k == "N"})
+        for k, v in kw.items():
+            if k != "N":
+                setattr(d, k, v)
+        with pytest.raises(solver.TmpcError):
+            solver.BatchedSolver(d, B_max=4)
+    d = solver.default_dims(N=60, n_lin=12, M=12)              # valid sizes whose generic-kernel LDS footprint exceeds a CU's 160 KB
+    with pytest.raises(solver.TmpcError):
+        solver.BatchedSolver(d, B_max=4)
