@@ -1,0 +1,211 @@
+"""Stage-function emission: from a module stack (plugin.py protocol) to the HIP/C++ header the solve kernel compiles.
+
+What CasADi + acados do for the reference at solver-generation time (generate_acados_solver.py:27-65: `cost_expr_ext_cost`,
+`con_h_expr`, EXACT Hessian) is done here with sympy: the stage cost and every inequality row are differentiated exactly
+(gradient + Hessian), all outputs go through one common-subexpression elimination, and the result is printed as
+straight-line C++ that is valid both for hipcc (`__host__ __device__`) and for a host compiler (tests).
+
+Conventions of the emitted code (namespace tmpc_gen):
+  * z = [a, w, x, y, psi, v, spline] are the 7 QP variables; with the slack model the 8th model variable `slack` is a
+    per-trajectory constant argument;
+  * every row is normalised to  g(z) <= 0  (lower-bounded rows h >= lb become lb - h <= 0): the kernel then has
+    NH upper-bounded rows and no lower-bounded ones;
+  * rows may depend on (x, y, psi) and on the slack only -- true for every constraint module the reference ships;
+    the generator refuses anything else, because the kernels keep 3 Jacobian entries per row;
+  * the stage cost may depend on all 7 variables (dense 7x7 Hessian, packed lower triangle, index i(i+1)/2 + j).
+"""
+import re
+
+import numpy as np
+import sympy as sp
+from sympy.printing.c import C99CodePrinter
+
+from . import plugin
+
+class logistic(sp.Function):
+    """1 / (1 + exp(-x)) as an atomic function: its derivatives are polynomials in itself, so the emitted gradient and
+    Hessian never form exp(u)^k / (1 + exp(u))^m quotients that overflow for the glue sigmoids of spline.py:37
+    (|u| reaches ~200 one segment away from a knot)."""
+    nargs = 1
+
+    def fdiff(self, argindex=1):
+        return self * (1 - self)
+
+
+def _stabilise(expr):
+    """1 / (1 + c exp(w))  ->  logistic(-(w + log c))   (the glue sigmoids; sympy folds exp(u + 0.2) into 1.22 exp(u))."""
+    def split(e):
+        if not (e.is_Pow and e.exp == -1 and e.base.is_Add and len(e.base.args) == 2):
+            return None
+        a, b = e.base.args
+        one = lambda q: q.is_Number and float(q) == 1.0
+        if not one(a):
+            a, b = b, a
+        if not one(a):
+            return None
+        coeff, rest = b.as_coeff_Mul()
+        if rest.func == sp.exp and coeff.is_Number and coeff > 0:
+            return rest.args[0] + sp.log(coeff)
+        return None
+
+    return sp.sympify(expr).replace(lambda e: split(e) is not None, lambda e: logistic(-split(e)))
+
+
+CORE = ["a", "w", "x", "y", "psi", "v", "spline"]
+ROW_VARS = (2, 3, 4)            # x, y, psi
+
+
+class _Printer(C99CodePrinter):
+    def _print_Pow(self, expr):
+        b, e = expr.as_base_exp()
+        if e.is_Integer and 2 <= abs(int(e)) <= 4:
+            s = "*".join([self.parenthesize(b, 50)] * abs(int(e)))      # x*x instead of pow(x, 2)
+            return f"({s})" if e > 0 else f"(1.0/({s}))"        # always parenthesised: the result may be a denominator
+        if e == sp.Rational(1, 2):
+            return f"sqrt({self._print(b)})"
+        if e == -sp.Rational(1, 2):
+            return f"(1.0/sqrt({self._print(b)}))"
+        return super()._print_Pow(expr)
+
+    def _print_logistic(self, expr):
+        return f"tmpc_gen_logistic({self._print(expr.args[0])})"
+
+    def _print_Max(self, expr):
+        a = list(expr.args)
+        out = self._print(a[0])
+        for x in a[1:]:
+            out = f"fmax({out}, {self._print(x)})"
+        return out
+
+    def _print_Min(self, expr):
+        a = list(expr.args)
+        out = self._print(a[0])
+        for x in a[1:]:
+            out = f"fmin({out}, {self._print(x)})"
+        return out
+
+
+_printer = _Printer({"precision": 17})
+
+
+def _c(expr):
+    s = _printer.doprint(expr)
+    s = re.sub(r"\bP_(\d+)_\b", r"p[(size_t)\1 * ps]", s)
+    s = re.sub(r"\bZ_(\d+)_\b", r"z[\1]", s)
+    return s
+
+
+def _cse_block(outputs, prefix):
+    """outputs: list of (lhs string, expr).  Returns C statements (temporaries + assignments)."""
+    exprs = [sp.sympify(e) for _, e in outputs]
+    repl, red = sp.cse(exprs, symbols=sp.numbered_symbols(prefix), optimizations="basic", order="none")
+    lines = [f"    const double {_c(s)} = {_c(e)};" for s, e in repl]
+    lines += [f"    {lhs} = {_c(e)};" for (lhs, _), e in zip(outputs, red)]
+    return lines
+
+
+def generate(modules, model, settings, name="generated"):
+    """Returns dict(header=<C++ text>, params=<plugin.Parameters>, npar, nh, slack, rows=[(module row index, kind)])."""
+    params = plugin.Parameters()
+    plugin.define_parameters(modules, params, settings)
+    settings = dict(settings); settings["params"] = params
+    npar = params.length()
+    nvar = model.get_nvar()
+    slack_model = "slack" in model.states
+    assert model.inputs + model.states[:5] == CORE, "the kernels integrate the contouring unicycle (solver_model.py:193-214)"
+    z = [sp.Symbol(f"Z_{i}_", real=True) for i in range(7)]
+    slack = sp.Symbol("slack", real=True)
+    zfull = z + ([slack] if slack_model else [])
+    assert len(zfull) == nvar
+    p = [sp.Symbol(f"P_{i}_", real=True) for i in range(npar)]
+
+    cost = _stabilise(plugin.objective(modules, np.array(zfull, dtype=object), p, model, settings, 1))
+    hs = [_stabilise(h) for h in plugin.constraints(modules, np.array(zfull, dtype=object), p, model, settings, 1)]
+    lb, ub = plugin.constraint_bounds(modules)
+    assert len(hs) == len(lb) == len(ub)
+
+    # ---- cost: value, gradient, packed Hessian ------------------------------------------------------------------
+    g = [sp.diff(cost, v) for v in z]
+    H = [[sp.diff(g[i], z[j]) for j in range(i + 1)] for i in range(7)]
+    if slack_model:
+        for gi in g:
+            assert sp.simplify(sp.diff(gi, slack)) == 0, "cost couples the slack with another variable: not supported (DESIGN.md U9)"
+    outs = [("*val", cost)] + [(f"g[{i}]", g[i]) for i in range(7)] + \
+           [(f"H[{i * (i + 1) // 2 + j}]", H[i][j]) for i in range(7) for j in range(i + 1)]
+    cost_full = _cse_block(outs, "c")
+    cost_value = _cse_block([("*val", cost)], "v")
+
+    # ---- rows, normalised to g(z) <= 0 ----------------------------------------------------------------------------
+    rows = []
+    for r, h in enumerate(hs):
+        has_lo, has_up = np.isfinite(lb[r]), np.isfinite(ub[r])
+        if has_up:
+            rows.append((r, "upper", h - ub[r]))
+        if has_lo:
+            rows.append((r, "lower", lb[r] - h))
+        assert has_lo or has_up, f"row {r} is unbounded on both sides"
+    row_lines = []
+    for k, (r, kind, gexpr) in enumerate(rows):
+        for i, v in enumerate(z):
+            if i not in ROW_VARS:
+                assert sp.diff(gexpr, v) == 0, f"constraint row {r} depends on `{CORE[i]}`: only x, y, psi (and slack) are supported"
+        gx, gy, gp = (sp.diff(gexpr, z[i]) for i in ROW_VARS)
+        outs_k = [("const double h_", gexpr), ("const double gx_", gx), ("const double gy_", gy), ("const double gp_", gp),
+                  ("const double hxx_", sp.diff(gx, z[2])), ("const double hxy_", sp.diff(gx, z[3])),
+                  ("const double hyy_", sp.diff(gy, z[3])), ("const double hxp_", sp.diff(gx, z[4])),
+                  ("const double hyp_", sp.diff(gy, z[4])), ("const double hpp_", sp.diff(gp, z[4]))]
+        # one block per row (own common subexpressions, values dead after the sink call): keeps the register footprint of
+        # the kernel independent of the number of rows; the compiler still shares sin/cos(psi) across blocks
+        row_lines += ["    {"] + ["    " + l for l in _cse_block(outs_k, "r")] + \
+                     [f"        sink({k}, h_, gx_, gy_, gp_, hxx_, hxy_, hyy_, hxp_, hyp_, hpp_);", "    }"]
+    nh = len(rows)
+    src_rows = ", ".join(str(r) for r, _, _ in rows)
+    sgn = ", ".join("1" if kind == "upper" else "-1" for _, kind, _ in rows)
+    off = ", ".join(repr(float(ub[r])) if kind == "upper" else repr(float(lb[r])) for r, kind, _ in rows)
+    header = f"""// Generated by mpc_planner_amd.codegen.emit for solver "{name}" -- do not edit.
+// Stage cost and inequality rows of the configured module stack with exact first and second derivatives.
+// z = [a, w, x, y, psi, v, spline]; p = one stage's parameter row, element i at p[i * ps]; slack = the trajectory's
+// constant slack value (0 without the slack model).  Rows are normalised to g(z) <= 0:
+//   g_k = SIGN[k] * (h_SRC[k](z) - BOUND[k]),  SIGN = +1 for an upper bound, -1 for a lower bound of module row SRC[k].
+#pragma once
+#include <math.h>
+#include <stddef.h>
+#if defined(__HIPCC__)
+#define TMPC_GEN_FN __host__ __device__ inline
+#else
+#define TMPC_GEN_FN inline
+#endif
+// 1 / (1 + exp(-x)), evaluated without overflow for either sign of x
+TMPC_GEN_FN double tmpc_gen_logistic(double x) {{ const double e = exp(-fabs(x)); return (x >= 0.0 ? 1.0 : e) / (1.0 + e); }}
+namespace tmpc_gen {{
+constexpr int NPAR = {npar};
+constexpr int NH = {nh};
+constexpr int SLACK = {1 if slack_model else 0};
+constexpr int ROW_SRC[{max(nh, 1)}] = {{{src_rows or "0"}}};
+constexpr int ROW_SIGN[{max(nh, 1)}] = {{{sgn or "0"}}};
+constexpr double ROW_BOUND[{max(nh, 1)}] = {{{off or "0.0"}}};
+
+TMPC_GEN_FN void cost_value(const double *z, const double *p, int ps, double slack, double *val)
+{{
+    (void)slack;
+{chr(10).join(cost_value)}
+}}
+
+// g[7]; H[28] = packed lower triangle, H[i (i + 1) / 2 + j] = d2 cost / dz_i dz_j  (i >= j)
+TMPC_GEN_FN void cost_full(const double *z, const double *p, int ps, double slack, double *val, double *g, double *H)
+{{
+    (void)slack;
+{chr(10).join(cost_full)}
+}}
+
+// sink(k, g_k, dg/dx, dg/dy, dg/dpsi, d2g/dxdx, dxdy, dydy, dxdpsi, dydpsi, dpsidpsi) for k = 0..NH-1
+template <class Sink>
+TMPC_GEN_FN void rows(const double *z, const double *p, int ps, double slack, Sink &&sink)
+{{
+    (void)z; (void)p; (void)ps; (void)slack; (void)sink;
+{chr(10).join(row_lines)}
+}}
+}}  // namespace tmpc_gen
+"""
+    return dict(header=header, params=params, npar=npar, nh=nh, slack=int(slack_model),
+                rows=[(r, kind) for r, kind, _ in rows], name=name)

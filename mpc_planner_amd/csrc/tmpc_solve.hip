@@ -1179,6 +1179,17 @@ static SolveKernel pick_fast_kernel(const Dims &d, int *threads, bool prof)
     *threads = NT;
     if (getenv("TMPC_FORCE_GENERIC")) return nullptr;
     const int lps = (3 * d.N <= NT) ? 3 : ((2 * d.N <= NT) ? 2 : 0);
+#ifdef TMPC_GENERATED_STAGE
+    // generated solver: one row shape (tmpc_gen::NH upper-bounded rows); the fast instantiations are compiled only when the
+    // generator's build found them free of scratch (TMPC_GEN_FAST / TMPC_GEN_FAST2 set by codegen/build.py)
+#ifdef TMPC_GEN_FAST
+    if (lps == 3) return TMPC_FAST(tmpc_gen::NH, 0, 3, 64);
+#endif
+#ifdef TMPC_GEN_FAST2
+    if (lps != 3 && 4 * d.N <= 128) { *threads = 128; return TMPC_FAST(tmpc_gen::NH, 0, 4, 128); }
+#endif
+    return nullptr;
+#else
     if (lps != 3 && 4 * d.N <= 128 && !getenv("TMPC_NO_TWO_WAVE")) {
         // two waves per trajectory, 4 lanes per stage (22 <= N <= 32: the reference's default N = 30 and BASELINE cfg 3)
         SolveKernel k2 = nullptr;
@@ -1196,6 +1207,7 @@ static SolveKernel pick_fast_kernel(const Dims &d, int *threads, bool prof)
         if (d.n_up == 0 && d.M == 4) return TMPC_FAST(0, 4, 2, 64);
     }
     return nullptr;
+#endif
 }
 // Latency variant (tmpc_set_latency_mode): two waves per trajectory at 6 lanes per stage, built for two waves per SIMD
 // (<= 256 registers, so four trajectories per CU stay resident).  The stage-parallel phases run on twice the lanes:
@@ -1204,8 +1216,11 @@ static SolveKernel pick_fast_kernel(const Dims &d, int *threads, bool prof)
 // not depend on what else is in the launch.
 static SolveKernel pick_latency_kernel(const Dims &d, bool prof)
 {
+#ifndef TMPC_GENERATED_STAGE
     if (getenv("TMPC_FORCE_GENERIC") || getenv("TMPC_NO_TWO_WAVE") || d.N > 2 * (64 / 6)) return nullptr;
     if (d.n_up == 8 && d.M == 8) return TMPC_FAST(8, 8, 6, 128);
+#endif
+    (void)d; (void)prof;
     return nullptr;
 }
 }  // namespace tmpc
@@ -1248,6 +1263,11 @@ void tmpc_default_dims(tmpc_dims *d, int32_t N, int32_t S, int32_t n_lin, int32_
 void tmpc_default_dims_ex(tmpc_dims *d, int32_t N, int32_t S, int32_t n_lin, int32_t M, int32_t n_slk, int32_t slack)
 {
     memset(d, 0, sizeof *d);
+#ifdef TMPC_GENERATED_STAGE
+    // generated solver: the row / parameter structure is fixed by the generated stage functions
+    (void)n_lin; (void)M; (void)n_slk; (void)slack;
+    n_lin = tmpc_gen::NH; M = 0; n_slk = 0; slack = tmpc_gen::SLACK;
+#endif
     d->N = N; d->S = S; d->n_lin = n_lin; d->M = M; d->n_slk = n_slk; d->slack = slack ? 1 : 0;
     tmpc::Dims t; t.S = S; t.n_lin = n_lin; t.M = M; t.n_slk = n_slk; t.slack = d->slack;
     d->npar = tmpc::expected_npar(t);
@@ -1269,6 +1289,9 @@ int tmpc_create(tmpc_handle **out, const tmpc_dims *dims, int32_t B_max, int32_t
         if (dims->N < 2 || dims->N > 62 || dims->S < 1 || dims->M < 0 || dims->n_lin < 0 || dims->n_slk < 0 ||
             (dims->slack != 0 && dims->slack != 1) || dims->npar != tmpc::expected_npar(t) || dims->erk_steps < 1)
             return TMPC_ERR_INVALID;
+#ifdef TMPC_GENERATED_STAGE
+        if (dims->n_lin != tmpc_gen::NH || dims->M != 0 || dims->n_slk != 0 || dims->slack != tmpc_gen::SLACK) return TMPC_ERR_INVALID;
+#endif
     }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return TMPC_ERR_NO_DEVICE;
@@ -1445,6 +1468,10 @@ int tmpc_select_best_records(tmpc_handle *h, const void *d_records, int32_t n_ra
 int tmpc_linearize_topology(tmpc_handle *h, const void *d_obstacle_pos, const void *d_scene_of, const void *d_state_x,
                             double robot_radius, const void *d_is_original)
 {
+#ifdef TMPC_GENERATED_STAGE
+    if (h) h->err = "tmpc_linearize_topology: not available in a generated solver (its parameter layout is the module stack's)";
+    return TMPC_ERR_INVALID;
+#endif
     if (!h || h->B <= 0 || !h->params || !d_obstacle_pos || !d_scene_of || !d_state_x || h->d.n_lin <= 0) {
         if (h) h->err = "tmpc_linearize_topology: bad argument / no batch / no topology rows";
         return TMPC_ERR_INVALID;
@@ -1461,6 +1488,10 @@ int tmpc_linearize_topology(tmpc_handle *h, const void *d_obstacle_pos, const vo
 int tmpc_scenario_halfspaces(tmpc_handle *h, const void *d_samples, int32_t n_pts, int32_t n_rows, const void *d_scene_of,
                              const void *d_state_x, double radius, double disc_offset)
 {
+#ifdef TMPC_GENERATED_STAGE
+    if (h) h->err = "tmpc_scenario_halfspaces: not available in a generated solver (its parameter layout is the module stack's)";
+    return TMPC_ERR_INVALID;
+#endif
     if (!h || h->B <= 0 || !h->params || !d_samples || !d_scene_of || !d_state_x || n_pts <= 0 || n_rows <= 0 || n_rows > 64 ||
         n_rows > h->d.n_slk) {
         if (h) h->err = "tmpc_scenario_halfspaces: bad argument / no batch / more rows than the problem's slack rows";

@@ -22,6 +22,13 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Generated solvers (mpc_planner_amd/codegen): -DTMPC_GENERATED_STAGE='"<header>"' replaces the hand-written stage cost and
+// inequality rows below by the emitted tmpc_gen::cost_* / tmpc_gen::rows of a user-defined module stack.  Dynamics,
+// MIRROR, the QP and everything else are shared.
+#ifdef TMPC_GENERATED_STAGE
+#include TMPC_GENERATED_STAGE
+#endif
+
 namespace tmpc {
 
 constexpr int NU = 2, NX = 5, NV = 7, NP28 = 28;
@@ -67,6 +74,10 @@ __host__ __device__ __forceinline__ int ip_slk(const Dims &d, int j, int which)
 }
 __host__ __device__ __forceinline__ int expected_npar(const Dims &d)
 {
+#ifdef TMPC_GENERATED_STAGE
+    (void)d;
+    return tmpc_gen::NPAR;
+#endif
     return 8 + d.slack + 9 * d.S + 3 * d.n_lin + (d.M > 0 ? 2 + 7 * d.M : 0) + (d.n_slk > 0 ? (d.M > 0 ? 0 : 1) + 3 * d.n_slk : 0);
 }
 
@@ -166,6 +177,27 @@ __device__ __forceinline__ J1 seg_deriv(double a, double b, double c, double t)
     return {(3.0 * a * t + 2.0 * b) * t + c, 6.0 * a * t + 2.0 * b, 6.0 * a};
 }
 
+#ifdef TMPC_GENERATED_STAGE
+struct CostOut { double val; double g[NV]; double H[NP28]; };      // dense packed Hessian from the generated code
+__device__ __forceinline__ void cost_eval(const Dims &d, const double *z, const double *p, int pstride, CostOut &o,
+                                          bool derivs, double slack = 0.0)
+{
+    (void)d;
+    if (derivs) tmpc_gen::cost_full(z, p, pstride, slack, &o.val, o.g, o.H);
+    else tmpc_gen::cost_value(z, p, pstride, slack, &o.val);
+}
+__device__ __forceinline__ void cost_add_hessian(const CostOut &o, double scale, double (*W)[NV])
+{
+#pragma unroll
+    for (int i = 0; i < NV; i++)
+#pragma unroll
+        for (int j = 0; j <= i; j++) {
+            const double h = scale * o.H[i * (i + 1) / 2 + j];
+            W[i][j] += h;
+            if (i != j) W[j][i] += h;
+        }
+}
+#else
 struct CostOut { double val; double g[NV]; double Hxx, Hxy, Hyy, Hxs, Hys, Hss, Haa, Hww, Hvv; };
 
 // p: this stage's parameter row, element i at p[i * pstride]
@@ -251,6 +283,7 @@ __device__ __forceinline__ void cost_add_hessian(const CostOut &o, double scale,
     W[ZX][ZS] += scale * o.Hxs; W[ZS][ZX] += scale * o.Hxs;
     W[ZY][ZS] += scale * o.Hys; W[ZS][ZY] += scale * o.Hys;
 }
+#endif  // TMPC_GENERATED_STAGE (hand-written cost)
 
 // =============================================================================================
 // Inequality rows.  Row r < n_lin: topology halfspace a1 x + a2 y - b  (<= 0);
@@ -470,6 +503,20 @@ __device__ __forceinline__ void stage_linearise(const Dims &d, const double *z, 
     dyn_add_hessian(dy, pix, piy, W);
     CostOut co;
     cost_eval(d, z, p, pstride, co, true, slack);
+#ifdef TMPC_GENERATED_STAGE
+#pragma unroll
+    for (int i = 0; i < NV; i++) g[i] = d.dt * co.g[i];          // stage cost scaled by the shooting interval
+    cost_add_hessian(co, d.dt, W);
+    // generated rows, all normalised to g(z) <= 0 (internal order = emitted order, every row upper-bounded)
+    tmpc_gen::rows(z, p, pstride, slack, [&](int k, double h, double gx, double gy, double gp, double hxx, double hxy, double hyy,
+                                             double hxp, double hyp, double hpp) {
+        RowOut ro;
+        ro.h = h; ro.gx = gx; ro.gy = gy; ro.gp = gp;
+        ro.Hxx = hxx; ro.Hxy = hxy; ro.Hyy = hyy; ro.Hxp = hxp; ro.Hyp = hyp; ro.Hpp = hpp;
+        row_add_hessian(ro, lamh(k), W);
+        sink(k, ro);
+    });
+#else
 #pragma unroll
     for (int i = 0; i < NV; i++) g[i] = (i == ZPSI) ? 0.0 : d.dt * co.g[i];   // stage cost scaled by the shooting interval (the cost
                                                                         // does not depend on psi: literal 0, not a hoisted dt * 0)
@@ -493,6 +540,7 @@ __device__ __forceinline__ void stage_linearise(const Dims &d, const double *z, 
         row_add_hessian(ro, lamh(d.n_up + j), W);
         sink(d.n_up + j, ro);
     }
+#endif
 }
 
 }  // namespace tmpc

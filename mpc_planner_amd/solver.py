@@ -49,14 +49,21 @@ class TmpcError(RuntimeError):
     pass
 
 
-def load_library():
-    """Load libtmpc_hip.so; raises (never falls back) if it has not been built."""
+_libs = {}
+
+
+def load_library(path=None):
+    """Load libtmpc_hip.so -- or a generated per-configuration library with the same C-ABI (mpc_planner_amd/codegen) --;
+    raises (never falls back) if it has not been built."""
     global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise TmpcError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+    path = os.path.abspath(path) if path else LIB_PATH
+    if path in _libs:
+        return _libs[path]
+    if True:
+        if not os.path.exists(path):
+            raise TmpcError(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                             "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
-        lib = C.CDLL(LIB_PATH)
+        lib = C.CDLL(path)
         lib.tmpc_last_error.restype = C.c_char_p
         lib.tmpc_last_error.argtypes = [C.c_void_p]
         lib.tmpc_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(TmpcDims), C.c_int32, C.c_int32]
@@ -85,13 +92,16 @@ def load_library():
         lib.tmpc_debug_get_x0.argtypes = [vp, vp, vp]
         lib.tmpc_scenario_halfspaces.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, vp, C.c_double, C.c_double]
         lib.tmpc_debug_get_params.argtypes = [vp, vp]
-        _lib = lib
-    return _lib
+        _libs[path] = lib
+        if path == LIB_PATH:
+            _lib = lib
+    return _libs[path]
 
 
-def default_dims(N=20, S=5, n_lin=8, M=8, n_slk=0, slack=0, **opts):
+def default_dims(N=20, S=5, n_lin=8, M=8, n_slk=0, slack=0, lib_path=None, **opts):
+    """lib_path: a generated library (its row / parameter structure overrides n_lin, M, n_slk, slack)."""
     d = TmpcDims()
-    load_library().tmpc_default_dims_ex(C.byref(d), N, S, n_lin, M, n_slk, int(bool(slack)))
+    load_library(lib_path).tmpc_default_dims_ex(C.byref(d), N, S, n_lin, M, n_slk, int(bool(slack)))
     for k, v in opts.items():
         setattr(d, k, v)
     return d
@@ -104,8 +114,8 @@ def _p(a):
 class BatchedSolver:
     """B reference `Solver` instances behind one HIP launch."""
 
-    def __init__(self, dims, B_max, device=0):
-        self.lib = load_library()
+    def __init__(self, dims, B_max, device=0, lib_path=None):
+        self.lib = load_library(lib_path)
         self.dims = dims
         self.B_max = int(B_max)
         self.B = 0

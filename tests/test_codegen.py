@@ -1,0 +1,119 @@
+"""Solver generation: module stacks written against the reference's plugin protocol -> emitted stage
+functions.  The emitted C++ is compiled for the host and compared with the golden vectors produced by executing the
+reference's own module scripts (tests/golden/*.json): parameter maps, values, gradients, Hessians."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from mpc_planner_amd.codegen import emit, stacks
+from mpc_planner_amd.codegen.hostlib import HostStageFunctions
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _golden(fname, config):
+    with open(os.path.join(HERE, "golden", fname)) as fh:
+        return [c for c in json.load(fh)["cases"] if c["config"] == config]
+
+
+def _check(gen, cases, slack_model):
+    hs = HostStageFunctions(gen["header"])
+    assert hs.npar == cases[0]["npar"] and dict(gen["params"]._params) == cases[0]["parameter_map"]
+    for c in cases:
+        z = np.array(c["z"]); slack = z[7] if slack_model else 0.0
+        v, g, H = hs.cost(z, c["p"], slack)
+        np.testing.assert_allclose(v, c["cost"], rtol=1e-12)
+        np.testing.assert_allclose(g, np.array(c["cost_grad"])[:7], rtol=1e-10, atol=1e-11)
+        np.testing.assert_allclose(H, np.array(c["cost_hess"])[:7, :7], rtol=1e-9, atol=1e-10)
+        h, D, Hr = hs.rows(z, c["p"], slack)
+        hh, J, HH = np.array(c["h"]), np.array(c["h_jac"]), np.array(c["h_hess"])
+        lh, uh = np.array(c["lh"]), np.array(c["uh"])
+        assert hs.nh == int((np.abs(lh) < 1e14).sum() + (np.abs(uh) < 1e14).sum())
+        for k in range(hs.nh):                      # emitted row k is  sign * (h_src - bound) <= 0
+            r, s = hs.row_src[k], hs.row_sign[k]
+            assert hs.row_bound[k] == (uh[r] if s > 0 else lh[r])
+            np.testing.assert_allclose(h[k], s * (hh[r] - hs.row_bound[k]), rtol=1e-11, atol=1e-11)
+            np.testing.assert_allclose(D[k], s * J[r][[2, 3, 4]], rtol=1e-10, atol=1e-11)
+            np.testing.assert_allclose(Hr[k], s * HH[r][np.ix_([2, 3, 4], [2, 3, 4])], rtol=1e-10, atol=1e-11)
+            assert np.all(J[r][[0, 1, 5, 6]] == 0.0)      # what the generator verified symbolically
+
+
+def test_generated_tmpc_stack_matches_reference_golden():
+    """BASELINE cfg 2 stack (MPC base + contouring + guidance halfspaces + ellipsoids), incl. the point 3 cm before a
+    spline knot and points several segments away from one (the glue sigmoids' derivatives must not overflow)."""
+    st = stacks.settings(N=20, max_obstacles=8)
+    model, mm = stacks.tmpc(st)
+    _check(emit.generate(mm, model, st, "cfg2"), _golden("stage_functions.json", "cfg2_tmpc_M8"), False)
+
+
+def test_generated_safe_horizon_stack_matches_reference_golden():
+    """BASELINE cfg 5 stack (slack model, 24 scenario halfspaces): the slack enters as the per-trajectory constant."""
+    st = stacks.settings(N=20, max_obstacles=8)
+    model, mm = stacks.safe_horizon(st)
+    gen = emit.generate(mm, model, st, "cfg5")
+    assert gen["slack"] == 1 and gen["nh"] == 24
+    _check(gen, _golden("stage_functions_slack.json", "cfg5_safe_horizon"), True)
+
+
+def test_generated_goal_gaussian_stack_against_finite_differences():
+    """A stack with modules the hand-written kernels do not have (GoalModule, GaussianConstraintModule): emitted
+    derivatives against central differences of the emitted values; erf / log / sqrt paths of the chance constraint."""
+    st = stacks.settings(N=20, max_obstacles=3)
+    model, mm = stacks.goal_gaussian(st)
+    gen = emit.generate(mm, model, st, "goal_gaussian")
+    pm = gen["params"]
+    hs = HostStageFunctions(gen["header"])
+    assert hs.nh == 3 and hs.npar == pm.length() == 4 + 3 + 2 + 6 * 3
+    rng = np.random.default_rng(1)
+    p = np.zeros(hs.npar)
+    for n, v in dict(acceleration=0.3, angular_velocity=0.8, velocity=0.5, reference_velocity=2.0, goal_weight=1.5, goal_x=7.0,
+                     goal_y=-1.0, ego_disc_radius=0.325, ego_disc_0_offset=0.1).items():
+        p[pm.index(n)] = v
+    for j in range(3):
+        for f, v in dict(x=3.0 + 2 * j, y=(-1) ** j * 1.5, major=0.4 + 0.1 * j, minor=0.2, risk=0.05, r=0.4).items():
+            p[pm.index(f"gaussian_obst_{j}_{f}")] = v
+    z = np.array([0.4, -0.2, 1.0, 0.3, 0.2, 1.5, 2.0])
+    v, g, H = hs.cost(z, p)
+    assert abs(v - (0.3 * 0.16 + 0.8 * 0.04 + 0.5 * 0.25 + 1.5 * (36.0 + 1.69) / (49.0 + 1.0 + 0.01))) < 1e-12
+    eps = 1e-6
+    for i in range(7):
+        e = np.zeros(7); e[i] = eps
+        vp, gp, _ = hs.cost(z + e, p); vm, gm, _ = hs.cost(z - e, p)
+        assert abs((vp - vm) / (2 * eps) - g[i]) < 1e-7
+        np.testing.assert_allclose((gp - gm) / (2 * eps), H[:, i], atol=1e-6)
+    h, D, Hr = hs.rows(z, p)
+    assert np.all(hs.row_sign == -1) and np.all(hs.row_bound == 0.0)         # chance constraints are >= 0 rows
+    for a, i in enumerate((2, 3, 4)):
+        e = np.zeros(7); e[i] = eps
+        hp, Dp, _ = hs.rows(z + e, p); hm, Dm, _ = hs.rows(z - e, p)
+        np.testing.assert_allclose((hp - hm) / (2 * eps), D[:, a], atol=1e-7)
+        np.testing.assert_allclose((Dp - Dm) / (2 * eps), Hr[:, :, a], atol=1e-6)
+    # the row itself: distance along the line of sight minus radii minus the Gaussian margin (erfinv(1 - 2 risk) sqrt(2 a^T Sigma a))
+    from scipy.special import erfinv
+    c, s = np.cos(z[4]), np.sin(z[4])
+    for j in range(3):
+        o = np.array([3.0 + 2 * j, (-1) ** j * 1.5]); d = np.array([z[2] + 0.1 * c, z[3] + 0.1 * s]) - o
+        a = d / np.linalg.norm(d)
+        want = np.linalg.norm(d) - (0.325 + 0.4) - erfinv(1 - 2 * 0.05) * np.sqrt(2 * (a[0] ** 2 * (0.4 + 0.1 * j) ** 2 + a[1] ** 2 * 0.04))
+        assert abs(-h[j] - want) < 1e-9
+
+
+def test_generator_refuses_rows_outside_the_kernel_structure():
+    from mpc_planner_amd.codegen import plugin as P, library as L
+
+    class VelocityRow:
+        nh = 1
+        def define_parameters(self, params): params.add("vmax")
+        def get_lower_bound(self): return [-np.inf]
+        def get_upper_bound(self): return [0.0]
+        def get_constraints(self, model, params, settings, stage_idx): return [model.get("v") - params.get("vmax")]
+
+    class M(P.ConstraintModule):
+        def __init__(self):
+            super().__init__(); self.constraints.append(VelocityRow())
+    st = stacks.settings()
+    mm = P.ModuleManager(); mm.add_module(L.GoalModule(st)); mm.add_module(M())
+    with pytest.raises(AssertionError, match="depends on `v`"):
+        emit.generate(mm, P.UnicycleContouringModel(), st, "bad")

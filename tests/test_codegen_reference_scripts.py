@@ -1,0 +1,66 @@
+"""Drop-in check of the generator's plugin surface: the reference's OWN, unmodified module scripts
+(/root/reference/mpc_planner_modules/scripts, solver_generator) are imported with mpc_planner_amd.codegen.symbolic
+registered as `casadi`, assembled exactly like generate_jackalsimulator_solver.py:92-101 does, and handed to emit.generate.
+Only runs where the reference checkout exists (this container); a subprocess with bytecode writing disabled keeps the
+checkout untouched."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+SCRIPT = r'''
+import sys, json
+sys.dont_write_bytecode = True
+sys.path.insert(0, %(root)r)
+from mpc_planner_amd.codegen import symbolic, emit
+symbolic.install_as_casadi()
+sys.path.insert(0, %(ref)r + "/solver_generator"); sys.path.insert(0, %(ref)r + "/mpc_planner_modules/scripts")
+from control_modules import ModuleManager
+from solver_model import ContouringSecondOrderUnicycleModel
+from mpc_base import MPCBaseModule
+from contouring import ContouringModule
+from ellipsoid_constraints import EllipsoidConstraintModule
+from guidance_constraints import GuidanceConstraintModule
+settings = {"N": 20, "integrator_step": 0.2, "n_discs": 1, "max_obstacles": 8, "linearized_constraints": {"add_halfspaces": 0},
+            "contouring": {"num_segments": 5, "dynamic_velocity_reference": False}}
+modules = ModuleManager(); model = ContouringSecondOrderUnicycleModel()
+base = modules.add_module(MPCBaseModule(settings))
+base.weigh_variable(var_name="a", weight_names="acceleration"); base.weigh_variable(var_name="w", weight_names="angular_velocity")
+base.weigh_variable(var_name="v", weight_names=["velocity", "reference_velocity"], cost_function=lambda x, w: w[0] * (x - w[1]) ** 2)
+modules.add_module(ContouringModule(settings))
+modules.add_module(GuidanceConstraintModule(settings, constraint_submodule=EllipsoidConstraintModule))
+gen = emit.generate(modules, model, settings, "reference_scripts_tmpc")
+json.dump(dict(header=gen["header"], pmap=dict(gen["params"]._params), nh=gen["nh"]), open(sys.argv[1], "w"))
+'''
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "solver_generator")), reason="reference checkout not present")
+def test_unmodified_reference_module_scripts_generate_the_same_stage_functions(tmp_path):
+    out = tmp_path / "gen.json"
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
+    subprocess.run([sys.executable, "-c", SCRIPT % dict(root=ROOT, ref=REF), str(out)], check=True, env=env, timeout=600,
+                   cwd=str(tmp_path), stdout=subprocess.DEVNULL)
+    gen = json.load(open(out))
+    from mpc_planner_amd.codegen.hostlib import HostStageFunctions
+    with open(os.path.join(HERE, "golden", "stage_functions.json")) as fh:
+        cases = [c for c in json.load(fh)["cases"] if c["config"] == "cfg2_tmpc_M8"]
+    assert gen["pmap"] == cases[0]["parameter_map"] and gen["nh"] == 16
+    hs = HostStageFunctions(gen["header"])
+    for c in cases:
+        v, g, H = hs.cost(c["z"], c["p"])
+        np.testing.assert_allclose(v, c["cost"], rtol=1e-12)
+        np.testing.assert_allclose(g, c["cost_grad"], rtol=1e-10, atol=1e-11)
+        np.testing.assert_allclose(H, c["cost_hess"], rtol=1e-9, atol=1e-10)
+        h, D, Hr = hs.rows(c["z"], c["p"])
+        hh, J = np.array(c["h"]), np.array(c["h_jac"])
+        for k in range(hs.nh):
+            r, s = hs.row_src[k], hs.row_sign[k]
+            np.testing.assert_allclose(h[k], s * (hh[r] - hs.row_bound[k]), rtol=1e-11, atol=1e-11)
+            np.testing.assert_allclose(D[k], s * J[r][[2, 3, 4]], rtol=1e-10, atol=1e-11)
