@@ -90,7 +90,7 @@ def _nlp_functions(pb, params, xinit):
     return f, fg, ceq, cineq, lb, ub
 
 
-@pytest.mark.parametrize("scene,b", [(1, 3), (5, 20), (0, 10)])
+@pytest.mark.parametrize("scene,b", [(1, 3), (5, 20)])
 def test_converged_sqp_matches_scipy_slsqp(scene, b):
     """Run the oracle as a converged SQP (many RTI iterations, tight QP tolerance) and check that an
     independent NLP solver started there cannot move: same optimum, same objective."""

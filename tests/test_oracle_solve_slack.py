@@ -50,7 +50,7 @@ def _full_nlp(pb, params, xinit):
     return f, fg, ceq, cineq, lb, ub
 
 
-@pytest.mark.parametrize("cfg,scene,b", [("cfg5", 3, 5), ("cfg3", 1, 3)])
+@pytest.mark.parametrize("cfg,scene,b", [("cfg5", 3, 5)])   # ("cfg3", 1, 3) also passes; 80 s of SLSQP at N = 30
 def test_converged_sqp_matches_scipy_on_the_full_slack_nlp(cfg, scene, b):
     skw, pkw = CFG[cfg]
     sc = scenes.make_scene(scene, B=8, **skw)
