@@ -236,11 +236,14 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
         if (it >= d.qp_iter_max) { status = 2; break; }
         iters = it + 1;
 
-        const bool fbad = riccati_factor<NTH>(L, d, tl);
+        // two-wave variant: the sweeping wave alternates with the iteration (and differs between neighbouring trajectories),
+        // so that co-resident trajectories seldom run the same sweep on the same SIMD
+        const int sw = NTH == 128 ? ((it + (int)(blockIdx.x >> 8)) & 1) : 0;
+        const bool fbad = riccati_factor<NTH>(L, d, tl, sw);
         pf.stop(PH_FACTOR);
         if (fbad) { status = 4; break; }
         // ---- predictor: rhs = rg + sum c (lam + d rd)  (q/t = lam) ----
-        riccati_solve<NTH>(L, d, tl);
+        riccati_solve<NTH>(L, d, tl, 1 - sw);
         pf.stop(PH_SOLVE);
         // Row step dt = c.dv + r_d is recomputed from the direction in LDS wherever it is needed (no per-row storage:
         // the register budget decides how many waves a SIMD holds)
@@ -306,7 +309,7 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
         }
         __syncthreads();
         pf.stop(PH_RHS);
-        riccati_solve<NTH>(L, d, tl);
+        riccati_solve<NTH>(L, d, tl, 1 - sw);
         pf.stop(PH_SOLVE);
         amax = 1e300;
         const double dxc = L.dv[kk * NV + ZX], dyc = L.dv[kk * NV + ZY], dpc = L.dv[kk * NV + ZPSI];

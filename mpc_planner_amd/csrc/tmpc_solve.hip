@@ -211,13 +211,14 @@ enum { D8_XA = 0, D8_XW, D8_XP, D8_XV, D8_YA, D8_YW, D8_YP, D8_YV };
 // complete underneath the dependent Cholesky / readlane chain of stage k.
 // NTH = threads per trajectory: 64, or 128 for the two-wave variant, in which the sweeps run on wave 0 alone (wave 1
 // waits at the closing barrier) and only the stage-parallel loops use all threads.
+// `sw`: which of the two waves sweeps (two-wave variant); the other one waits at the closing barrier.
 template <int NTH>
-__device__ bool riccati_factor(const Lds &L, const Dims &d, int tid)
+__device__ bool riccati_factor(const Lds &L, const Dims &d, int tid, int sw = 0)
 {
     const int N = d.N;
     bool anybad = false;
-    if (NTH == 64 || tid < 64) {
-    const int lane = tid;
+    if (NTH == 64 || (tid >> 6) == sw) {
+    const int lane = tid & 63;
     const bool rowl = lane < NV;
     const int ls = rowl ? lane : 0;
     const int i5 = lane - NU;                        // state index of lanes 2..6
@@ -309,7 +310,7 @@ __device__ bool riccati_factor(const Lds &L, const Dims &d, int tid)
         }
     }
     anybad = __any(bad);
-    if (NTH > 64 && tid == 0) L.scr[63] = anybad ? 1.0 : 0.0;
+    if (NTH > 64 && lane == 0) L.scr[63] = anybad ? 1.0 : 0.0;
     }
     __syncthreads();
     if (NTH > 64) anybad = L.scr[63] != 0.0;
@@ -319,13 +320,13 @@ __device__ bool riccati_factor(const Lds &L, const Dims &d, int tid)
 // ---- square-root Riccati: vector solve (backward + forward), rhs gh / rb -> dv, dpi ------------------
 // Lane j (< 7) = component j of the stage vector [u; x]; the cost-to-go gradient p lives in lanes 2..6.
 template <int NTH>
-__device__ void riccati_solve(const Lds &L, const Dims &d, int tid)
+__device__ void riccati_solve(const Lds &L, const Dims &d, int tid, int sw = 1)
 {
     const int N = d.N;
-    // two-wave variant: the vector sweeps run on wave 1 (the factorisation on wave 0), so that with two trajectories'
-    // waves sharing a SIMD pair the sequential work is spread over both SIMDs
-    const bool sweeper = NTH == 64 || tid >= 64;
-    const int lane = NTH == 64 ? tid : (tid >= 64 ? tid - 64 : 64);
+    // two-wave variant: the vector sweeps run on the wave that did not factorise, so that with two trajectories' waves
+    // sharing a SIMD pair the sequential work is spread over both SIMDs
+    const bool sweeper = NTH == 64 || (tid >> 6) == sw;
+    const int lane = NTH == 64 ? tid : (sweeper ? (tid & 63) : 64);
     const bool rowl = lane < NV, xl = rowl && lane >= NU;
     const int ls = rowl ? lane : 0;
     const int i5 = xl ? lane - NU : 0;
@@ -1305,6 +1306,7 @@ int tmpc_create(tmpc_handle **out, const tmpc_dims *dims, int32_t B_max, int32_t
     for (int i = 0; i < TMPC_NV; i++) { d.lb[i] = dims->lb[i]; d.ub[i] = dims->ub[i]; }
     tmpc::derive_dims(d);
     h->kernel = tmpc::pick_fast_kernel(d, &h->threads, false);
+    h->latency_mode = getenv("TMPC_LATENCY_MODE") != nullptr;      // experiments: latency variant regardless of the caller
     h->fast = h->kernel != nullptr;
     if (h->fast) h->lds_bytes = sizeof(double) * (size_t)tmpc::lds_doubles_fast(d.N, d.n_up + d.M);
     else { h->kernel = tmpc::tmpc_solve_kernel; h->lds_bytes = sizeof(double) * (size_t)tmpc::lds_doubles(d.N, d.n_up + d.M); }
