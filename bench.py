@@ -212,7 +212,7 @@ def main():
             "latency_b64": lat,
             "best_index_sample": best[:4].tolist(),
         }
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:                      # reported baseline: rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(a.cpu_scenes)
         print(json.dumps(out))
     sv.close()

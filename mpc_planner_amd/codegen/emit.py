@@ -96,11 +96,26 @@ def _c(expr):
 
 
 def _cse_block(outputs, prefix):
-    """outputs: list of (lhs string, expr).  Returns C statements (temporaries + assignments)."""
+    """outputs: list of (lhs string, expr).  Returns C statements (temporaries + assignments).
+
+    Statement order: every output is followed back through the temporaries it needs (depth first), and a temporary is
+    emitted right before its first consumer -- values are born late and die early, which is what keeps the kernels'
+    linearisation phase inside the register file (sympy's own order defines all temporaries up front)."""
     exprs = [sp.sympify(e) for _, e in outputs]
     repl, red = sp.cse(exprs, symbols=sp.numbered_symbols(prefix), optimizations="basic", order="none")
-    lines = [f"    const double {_c(s)} = {_c(e)};" for s, e in repl]
-    lines += [f"    {lhs} = {_c(e)};" for (lhs, _), e in zip(outputs, red)]
+    defs = {s_: e for s_, e in repl}
+    emitted, lines = set(), []
+
+    def need(expr):
+        for s_ in sorted(expr.free_symbols & defs.keys(), key=lambda q: int(str(q)[len(prefix):])):
+            if s_ not in emitted:
+                need(defs[s_])
+                emitted.add(s_)
+                lines.append(f"    const double {_c(s_)} = {_c(defs[s_])};")
+
+    for (lhs, _), e in zip(outputs, red):
+        need(e)
+        lines.append(f"    {lhs} = {_c(e)};")
     return lines
 
 
