@@ -11,11 +11,14 @@
 
 namespace tmpc {
 
+// NLIN >= 0: row counts fixed at compile time (tuned shapes).  NLIN < 0: "runtime shape" -- MM is the number of rows per
+// lane the instantiation provides and the actual counts come from Dims (any n_up, M with n_up + M + 14 <= LPS * MM).
 template <int NLIN, int MM, int LPS>
 struct FastCfg {
-    static constexpr int NH = NLIN + MM;
+    static constexpr bool RT = NLIN < 0;
+    static constexpr int NH = RT ? 0 : NLIN + MM;
     static constexpr int NR = NH + 14;                 // general rows + 4 input-box rows + 10 state-box rows
-    static constexpr int RPL = (NR + LPS - 1) / LPS;   // rows per lane
+    static constexpr int RPL = RT ? MM : (NR + LPS - 1) / LPS;   // rows per lane
 };
 
 __host__ __device__ inline int lds_doubles_fast(int N, int nh)
@@ -64,8 +67,10 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
 {
     constexpr int NT = NTH;                         // threads per trajectory: 64 (one wave) or 128 (two waves; N > 21)
     using C = FastCfg<NLIN, MM, LPS>;
-    constexpr int NH = C::NH, NR = C::NR, RPL = C::RPL;
-    constexpr bool DIET = LPS == 6;                 // 256-register budget (two waves per SIMD): recompute per-row values instead of storing them
+    constexpr int RPL = C::RPL;
+    // compile-time constants for the tuned shapes, kernel arguments for runtime-shape instantiations
+    const int NH = C::RT ? L.nh : C::NH, NR = NH + 14, NLIN_ = C::RT ? d.n_up : NLIN;
+    constexpr bool DIET = LPS == 6 && NLIN == 8;                 // 256-register budget (two waves per SIMD): recompute per-row values instead of storing them
     const int N = d.N;
     // Opaque copy of the lane id: keeps the compiler from hoisting this QP's per-row setup (masks, LDS addresses) out of
     // the RTI loop of the caller, where it would stay live across the register-hungry linearisation and be spilled.
@@ -92,9 +97,9 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
         sb[s] = 0.0; if constexpr (!DIET) didx_[s] = N * NH * 3;
         if (stage_lane && r < NR) {
             if (r < NH) {
-                const double sgn = (r < NLIN) ? -1.0 : 1.0;     // topology / slack rows: upper bound 0; ellipsoids: lower bound 1
+                const double sgn = (r < NLIN_) ? -1.0 : 1.0;    // topology / slack rows: upper bound 0; ellipsoids: lower bound 1
                 if constexpr (!DIET) didx_[s] = (k * NH + r) * 3;
-                if (r < NLIN) neg |= 1u << s;
+                if (r < NLIN_) neg |= 1u << s;
                 sb[s] = sgn * L.beta[k * NH + r];
                 act |= 1u << s;
             } else {
@@ -132,7 +137,7 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
     __syncthreads();
 
     double t[RPL], qt[RPL];
-    constexpr bool LEAN = RPL > 10 || LPS == 6;     // recompute 1/t instead of keeping it: many rows per lane, or the 256-register
+    constexpr bool LEAN = RPL > 10 || (LPS == 6 && NLIN == 8);     // recompute 1/t instead of keeping it: many rows per lane, or the 256-register
                                                     // budget of the two-waves-per-SIMD instantiations
     double invt_[LEAN ? 1 : RPL];               // the row residual r_d = c.v - sb - t is recomputed where needed
     {
@@ -350,7 +355,7 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
 // Two-wave instantiations with 6 lanes per stage are built for two waves per SIMD (<= 256 registers): four trajectories
 // per CU stay resident with two waves each.  The build refuses any instantiation that needs scratch.
 template <int NLIN, int MM, int LPS, int NTH = 64, bool PROF = false>
-__global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu((NTH == 128 && LPS == 6 && !PROF) ? 2 : 1, (NTH == 128 && LPS == 6 && !PROF) ? 2 : 1)))
+__global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu((NTH == 128 && LPS == 6 && NLIN == 8 && !PROF) ? 2 : 1, (NTH == 128 && LPS == 6 && NLIN == 8 && !PROF) ? 2 : 1)))
 void tmpc_solve_fast_kernel(Dims d, int B, const double *__restrict__ xinit,
                                                              const double *__restrict__ x0, const double *__restrict__ params,
                                                              double *__restrict__ xtraj, double *__restrict__ utraj,
@@ -361,6 +366,7 @@ void tmpc_solve_fast_kernel(Dims d, int B, const double *__restrict__ xinit,
 {
     using C = FastCfg<NLIN, MM, LPS>;
     constexpr int NT = NTH;
+    const int NHk = C::RT ? d.n_up + d.M : C::NH, NLINk = C::RT ? d.n_up : NLIN;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int b = blockIdx.x, tid = threadIdx.x;
     if (b >= B) return;
@@ -377,8 +383,8 @@ void tmpc_solve_fast_kernel(Dims d, int B, const double *__restrict__ xinit,
         L.z[e] = x0[((size_t)b * (N + 1) + k) * ext_nv(d) + i];
     }
     for (int e = tid; e < (N + 1) * NX; e += NT) L.pi[e] = 0.0;
-    for (int e = tid; e < N * C::NH; e += NT) L.lamh[e] = 0.0;
-    if (tid < 3) L.D[N * C::NH * 3 + tid] = 0.0;      // zero triple read by box rows
+    for (int e = tid; e < N * NHk; e += NT) L.lamh[e] = 0.0;
+    if (tid < 3) L.D[N * NHk * 3 + tid] = 0.0;      // zero triple read by box rows
     __syncthreads();
     if (tid < NU) L.z[N * NV + tid] = 0.0;
     __syncthreads();
@@ -415,7 +421,7 @@ void tmpc_solve_fast_kernel(Dims d, int B, const double *__restrict__ xinit,
 #pragma unroll
             for (int s = 0; s < C::RPL; s++) {
                 const int r = c + LPS * s;
-                if (r < C::NH) L.lamh[k * C::NH + r] = (r < NLIN) ? lam[s] : -lam[s];
+                if (r < NHk) L.lamh[k * NHk + r] = (r < NLINk) ? lam[s] : -lam[s];
             }
         }
         __syncthreads();

@@ -1191,12 +1191,16 @@ static SolveKernel pick_fast_kernel(const Dims &d, int *threads, bool prof)
 #endif
     return nullptr;
 #else
+    const int nr = d.n_up + d.M + 14;                    // interior-point rows per stage
     if (lps != 3 && 4 * d.N <= 128 && !getenv("TMPC_NO_TWO_WAVE")) {
         // two waves per trajectory, 4 lanes per stage (22 <= N <= 32: the reference's default N = 30 and BASELINE cfg 3)
         SolveKernel k2 = nullptr;
         if (d.n_up == 8 && d.M == 8) k2 = TMPC_FAST(8, 8, 4, 128);
-        if (d.n_up == 12 && d.M == 12) k2 = TMPC_FAST(12, 12, 4, 128);
-        if (d.n_up == 20 && d.M == 8) k2 = TMPC_FAST(20, 8, 4, 128);      // cfg 3: 8 topology + 12 decomp rows + 8 ellipsoids
+        else if (d.n_up == 12 && d.M == 12) k2 = TMPC_FAST(12, 12, 4, 128);  // mpc_planner_jackalsimulator defaults (N = 30, 12 obstacles)
+        else if (d.n_up == 20 && d.M == 8) k2 = TMPC_FAST(20, 8, 4, 128);    // cfg 3: 8 topology + 12 decomp rows + 8 ellipsoids
+        else if (nr <= 4 * 6) k2 = TMPC_FAST(-1, 6, 4, 128);                 // any other row mix: runtime-shape instantiations
+        else if (nr <= 4 * 9) k2 = TMPC_FAST(-1, 9, 4, 128);                 //   (e.g. mpc_planner_jackal: N = 30, 5 obstacles)
+        else if (nr <= 4 * 12) k2 = TMPC_FAST(-1, 12, 4, 128);
         if (k2) { *threads = 128; return k2; }
     }
     if (lps == 3) {
@@ -1204,6 +1208,13 @@ static SolveKernel pick_fast_kernel(const Dims &d, int *threads, bool prof)
         if (d.n_up == 8 && d.M == 8) return TMPC_FAST(8, 8, 3, 64);
         if (d.n_up == 12 && d.M == 12) return TMPC_FAST(12, 12, 3, 64);      // zero scratch only with machine-LICM off (build flag)
         if (d.n_up == 24 && d.M == 0) return TMPC_FAST(24, 0, 3, 64);        // SH-MPC: 24 scenario halfspaces (cfg 5)
+        if (nr <= 3 * 7) return TMPC_FAST(-1, 7, 3, 64);                     // runtime-shape instantiations
+        if (nr <= 3 * 10) return TMPC_FAST(-1, 10, 3, 64);
+        if (nr <= 3 * 13) return TMPC_FAST(-1, 13, 3, 64);
+        if (d.N <= 2 * (64 / 6) && nr <= 6 * 9 && !getenv("TMPC_NO_TWO_WAVE")) {   // more rows: two waves, 6 lanes per stage
+            *threads = 128;                                                  //   (mpc_planner_rosnavigation T-MPC: 24 + 12 rows)
+            return TMPC_FAST(-1, 9, 6, 128);
+        }
     } else if (lps == 2) {
         if (d.n_up == 0 && d.M == 4) return TMPC_FAST(0, 4, 2, 64);
     }

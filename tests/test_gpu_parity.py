@@ -555,3 +555,37 @@ def test_generated_goal_gaussian_solver_solves_a_stack_without_hand_written_kern
         d0 = np.hypot(9.0 - x0[b, N, 2], 0.5 - x0[b, N, 3]); d1 = np.hypot(9.0 - r["xtraj"][b, N, 0], 0.5 - r["xtraj"][b, N, 1])
         assert d1 < d0
     s.close()
+
+
+@pytest.mark.parametrize("name,skw,pkw,B", [
+    # mpc_planner_rosnavigation defaults (settings.yaml: N 20, 12 obstacles, 8 segments, 12 decomp rows; configuration_tmpc)
+    ("rosnavigation T-MPC", dict(N=20, M=12, S=8, slack=True, n_decomp=12), dict(N=20, S=8, n_lin=12, M=12, n_slk=12, slack=1), 16),
+    # mpc_planner_jackal defaults (N 30, 5 obstacles, 3 segments)
+    ("jackal T-MPC", dict(N=30, M=5, S=3), dict(N=30, S=3, n_lin=5, M=5), 16),
+    # an arbitrary mix on the one-wave runtime-shape kernel
+    ("3 topology + 6 ellipsoid rows", None, dict(N=20, S=5, n_lin=3, M=6), 16),
+])
+def test_runtime_shape_fast_kernels_match_oracle(name, skw, pkw, B):
+    """Row counts without a tuned instantiation run on the runtime-shape instantiations of the fast kernel (rows per lane
+    fixed at compile time, row counts kernel arguments) instead of the generic kernel."""
+    import oracle_lib as O
+    from mpc_planner_amd import scenes
+    s = _solver(B_max=B, **pkw)
+    pb = O.problem(**pkw)
+    n_ok = 0
+    for scene in (1, 2, 3):
+        if skw is None:             # 6 obstacles, topology rows for the first 3 only: cut a 6-obstacle scene's parameter rows
+            full = scenes.make_scene(scene, N=20, M=6, B=B)
+            pm6 = full["pm"]
+            from mpc_planner_amd.parameters import ParameterMap
+            keep = [i for n, i in pm6._params.items() if not any(n.startswith(f"lin_constraint_{j}_") for j in (3, 4, 5))]
+            sc = dict(full); sc["params"] = np.ascontiguousarray(full["params"][:, :, keep])
+        else:
+            sc = scenes.make_scene(scene, B=B, **skw)
+        assert sc["params"].shape[2] == pb.npar == s.npar
+        s.set_batch(sc["xinit"], sc["x0"], sc["params"]); s.solve(); got = s.get()
+        xt, ut, info = O.solve_batch(pb, sc["xinit"], sc["x0"].reshape(B, -1), sc["params"].reshape(B, -1))
+        _compare(got, xt, ut, info)
+        n_ok += int((info["exit_code"] == 1).sum())
+    assert n_ok >= B
+    s.close()
