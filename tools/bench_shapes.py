@@ -13,6 +13,10 @@ for name, kw, dims_kw, per_scene in (
         ("reference default N=30, 8 obstacles (two-wave fast kernel)", dict(N=30, M=8, B=64), dict(N=30, S=5, n_lin=8, M=8), 64),
         ("cfg3 slack model + guidance + ellipsoids + 12 decomp rows, N=30 (two-wave fast kernel)",
          dict(N=30, M=8, B=64, slack=True, n_decomp=12), dict(N=30, S=5, n_lin=8, M=8, n_slk=12, slack=1), 64),
+        ("rosnavigation defaults: slack model, 12 topology + 12 decomp rows + 12 ellipsoids, 8 segments, N=20 (runtime-shape two-wave kernel)",
+         dict(N=20, M=12, S=8, B=64, slack=True, n_decomp=12), dict(N=20, S=8, n_lin=12, M=12, n_slk=12, slack=1), 64),
+        ("jackal defaults: 5 obstacles, 3 segments, N=30 (runtime-shape two-wave kernel)",
+         dict(N=30, M=5, S=3, B=64), dict(N=30, S=3, n_lin=5, M=5), 64),
         ("cfg5 SH-MPC 24 scenario halfspaces, slack model, N=20, 32 guidance/scene",
          dict(N=20, M=8, B=32, slack=True, n_scenario=24), dict(N=20, S=5, n_lin=0, M=0, n_slk=24, slack=1), 32)):
     if len(sys.argv) > 1 and not any(a in name for a in sys.argv[1:]):
