@@ -45,6 +45,13 @@ def rosnav_tmpc(st):
     return P.UnicycleContouringSlackModel(), mm
 
 
+def jackal_tmpc(st):
+    """generate_jackal_solver.py:53-73 configuration_tmpc -- mpc_planner_jackal's default: T-MPC whose collision-avoidance
+    submodule is the Gaussian chance constraint."""
+    mm = _base(st); mm.add_module(L.GuidanceConstraintModule(st, constraint_submodule=L.GaussianConstraintModule))
+    return P.UnicycleContouringModel(), mm
+
+
 def goal_gaussian(st):
     """A stack the hand-written kernels do not cover: goal tracking + Gaussian chance constraints (CC-MPC)."""
     mm = P.ModuleManager()

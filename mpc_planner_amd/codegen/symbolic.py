@@ -80,6 +80,8 @@ MX = SX
 
 def install_as_casadi():
     """Make `import casadi` resolve to this facade (for unmodified module scripts)."""
+    if not hasattr(np, "Inf"):
+        np.Inf = np.inf             # module scripts written for NumPy 1.x (gaussian_constraints.py:65) keep working under NumPy 2
     mod = types.ModuleType("casadi")
     for k, v in globals().items():
         if not k.startswith("_") and k not in ("sys", "types", "np", "sp"):

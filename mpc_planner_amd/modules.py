@@ -51,6 +51,24 @@ def ellipsoid_set_parameters(pm, params, state_xy, obstacles, robot_radius, disc
         params[1:, ix[6]] = obstacles["radius"][j]
 
 
+def gaussian_set_parameters(pm, params, state_xy, obstacles, robot_radius, risk, disc_offset=0.0):
+    """GaussianConstraints::update/setParameters (gaussian_constraints.cpp:22-79): stage 0 dummies (x + 100, y + 100,
+    0.1, 0.1, 0.05, 0.1), stages k >= 1 the Gaussian prediction step k-1 with CONFIG probabilistic/risk and obstacle_radius."""
+    N = params.shape[0]
+    M = obstacles["pos"].shape[0]
+    params[:, pm.index("ego_disc_radius")] = robot_radius
+    params[:, pm.index("ego_disc_0_offset")] = disc_offset
+    for j in range(M):
+        ix = [pm.index(f"gaussian_obst_{j}_{f}") for f in ("x", "y", "major", "minor", "risk", "r")]
+        params[0, ix] = [state_xy[0] + 100.0, state_xy[1] + 100.0, 0.1, 0.1, 0.05, 0.1]
+        params[1:, ix[0]] = obstacles["pos"][j, :N - 1, 0]
+        params[1:, ix[1]] = obstacles["pos"][j, :N - 1, 1]
+        params[1:, ix[2]] = obstacles["major"][j, :N - 1]
+        params[1:, ix[3]] = obstacles["minor"][j, :N - 1]
+        params[1:, ix[4]] = risk
+        params[1:, ix[5]] = obstacles["radius"][j]
+
+
 def linearized_update(x0, obstacle_pos, robot_radius):
     """LinearizedConstraints::update in guidance mode (linearized_constraints.cpp:49-105).
     x0: warm start [N+1][nvar]; obstacle_pos [M][N][2].  Returns a1,a2,b [N][M] (row k=0 unused).

@@ -44,7 +44,7 @@ class ParameterMap:
 
 
 def define_parameters(num_segments, max_obstacles, guidance=True, add_halfspaces=0, n_discs=1, slack=False,
-                      ellipsoids=True, n_scenario=0, n_decomp=0):
+                      ellipsoids=True, n_scenario=0, n_decomp=0, gaussian=False):
     """T-MPC (guidance=True, cfg 2/4) or LMPCC-style basic (guidance=False, cfg 1) Jackal parameter map; with
     slack=True the slack-model maps: rosnavigation T-MPC (guidance + ellipsoids + n_decomp=12, cfg 3) and SH-MPC
     (guidance=False, ellipsoids=False, n_scenario=24, cfg 5)."""
@@ -74,6 +74,13 @@ def define_parameters(num_segments, max_obstacles, guidance=True, add_halfspaces
         for j in range(max_obstacles):
             for f in ("x", "y", "psi", "major", "minor", "chi", "r"):
                 p.add(f"ellipsoid_obst_{j}_{f}", bundle_name=f"ellipsoid_obst_{f}")
+    if gaussian:                                                                        # GaussianConstraint (gaussian_constraints.py:40-52)
+        p.add("ego_disc_radius")
+        for d in range(n_discs):
+            p.add(f"ego_disc_{d}_offset", bundle_name="ego_disc_offset")
+        for j in range(max_obstacles):
+            for f in ("x", "y", "major", "minor", "risk", "r"):
+                p.add(f"gaussian_obst_{j}_{f}", bundle_name=f"gaussian_obst_{f}")
     if n_scenario:                                                                      # scenario LinearConstraints
         for d in range(n_discs):
             p.add(f"ego_disc_{d}_offset", bundle_name="ego_disc_offset")

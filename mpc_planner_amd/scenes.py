@@ -80,16 +80,18 @@ def scenario_samples(rng, pos0, vel, N, n_samples):
 
 
 def make_scene(scene_idx, N=20, M=8, B=64, S=5, tmpc_pp=False, gaussian=False, guidance=True, slack=False,
-               n_decomp=0, n_scenario=0, n_samples=256):
+               n_decomp=0, n_scenario=0, n_samples=256, chance=False):
     """Returns dict(xinit [Bt][nx], x0 [Bt][N+1][nv], params [Bt][N][npar], pm, guidance_id [Bt]); nx = 5, nv = 7, or
     6 / 8 with the slack model.  n_scenario > 0 builds the SH-MPC problem (cfg 5): no ellipsoid / topology rows, 24
     scenario halfspaces per stage from M obstacles x n_samples scenarios, one set per guidance trajectory."""
     rng = np.random.Generator(np.random.PCG64(1000 + scene_idx))
-    ellipsoids = n_scenario == 0
-    if not ellipsoids:
+    ellipsoids = n_scenario == 0 and not chance         # chance: GaussianConstraintModule instead of the ellipsoids (jackal default)
+    if chance:
+        gaussian = True
+    if n_scenario:
         guidance = False
     pm = define_parameters(S, M, guidance=guidance, slack=slack, ellipsoids=ellipsoids, n_scenario=n_scenario,
-                           n_decomp=n_decomp)
+                           n_decomp=n_decomp, gaussian=chance)
     npar = pm.length()
     nx, nv = 5 + int(slack), 7 + int(slack)
     state = np.array([0.0, 0.0, 0.0, rng.uniform(0.5, 2.0), 0.0] + [0.0] * int(slack))   # x,y,psi,v,spline(,slack)
@@ -123,6 +125,8 @@ def make_scene(scene_idx, N=20, M=8, B=64, S=5, tmpc_pp=False, gaussian=False, g
     md.contouring_set_parameters(pm, base, WEIGHTS, segs)
     if ellipsoids:
         md.ellipsoid_set_parameters(pm, base, state[:2], obs, ROBOT_RADIUS)
+    if chance:
+        md.gaussian_set_parameters(pm, base, state[:2], obs, ROBOT_RADIUS, risk=0.05)    # settings.yaml probabilistic/risk
     if n_decomp:
         md.halfspace_rows_set_parameters(pm, base, state[0], decomp_corridor(rng, segs, state, N, n_decomp),
                                          "disc_0_decomp", n_decomp)
@@ -201,7 +205,7 @@ def make_scene(scene_idx, N=20, M=8, B=64, S=5, tmpc_pp=False, gaussian=False, g
         md.linearized_set_parameters(pm, params[B], state[0], None, n_rows=M)
         guidance_id[B] = 2 * B                                              # guidance_constraints.cpp:349
     return dict(xinit=xinit, x0=x0, params=params, pm=pm, guidance_id=guidance_id, obstacles=obs,
-                segments=segs, N=N, M=(M if ellipsoids else 0), S=S, n_lin=(M if guidance else 0),
+                segments=segs, N=N, M=(M if ellipsoids else 0), S=S, n_lin=(M if guidance else 0), n_gauss=(M if chance else 0),
                 n_slk=n_scenario + n_decomp, slack=int(slack), samples=samples)
 
 

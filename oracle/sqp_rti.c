@@ -38,7 +38,7 @@ typedef struct {
 static void build_qp(const orc_problem *pb, const nlp_state *st, const double *xinit, const double *params,
                      orc_qp *qp, int (*row_lo)[ORC_MAX_NH], int (*row_hi)[ORC_MAX_NH], orc_debug *dbg, double *dslack)
 {
-    const int N = pb->N, nh = pb->n_lin + pb->M + pb->n_slk;
+    const int N = pb->N, nh = pb->n_lin + pb->M + pb->n_gauss + pb->n_slk;
     const int E = ORC_NVE;                                   /* stride of the model's derivative arrays */
 #if ORC_SLACK
     dslack[0] = xinit[ORC_NX] - st->z[0][ORC_NV];            /* U9 */
@@ -142,7 +142,7 @@ static void build_qp(const orc_problem *pb, const nlp_state *st, const double *x
 void orc_solve_debug(const orc_problem *pb, const double *xinit, const double *x0, const double *params,
                      double *xtraj, double *utraj, orc_info *info, orc_debug *dbg, int capture_sqp_iter)
 {
-    const int N = pb->N, nh = pb->n_lin + pb->M + pb->n_slk;
+    const int N = pb->N, nh = pb->n_lin + pb->M + pb->n_gauss + pb->n_slk;
     double dslack[ORC_MAX_N + 1];
     nlp_state *st = (nlp_state *)calloc(1, sizeof(nlp_state));
     orc_qp *qp = (orc_qp *)calloc(1, sizeof(orc_qp));

@@ -43,12 +43,21 @@ int orc_idx_slk(const orc_problem *pb, int j, int which)
     return base + 3 * j + which;
 }
 int orc_model_nx(void) { return ORC_NXE; }
+/* GaussianConstraint.define_parameters (gaussian_constraints.py:40-52): ego_disc_radius, ego_disc_0_offset, then
+ * x, y, major, minor, risk, r per obstacle */
+int orc_idx_gaussian(const orc_problem *pb, int j, int which) { return orc_idx_disc_radius(pb) + 2 + 6 * j + which; }
+void orc_problem_set_gaussian(orc_problem *pb, int n_gauss)
+{
+    if (pb->M != 0 || pb->n_slk != 0) abort();
+    pb->n_gauss = n_gauss;
+    pb->npar = 8 + ORC_SLACK + 9 * pb->S + 3 * pb->n_lin + (n_gauss > 0 ? 2 + 6 * n_gauss : 0);
+}
 
 void orc_problem_init(orc_problem *pb, int N, int S, int n_lin, int M) { orc_problem_init_ex(pb, N, S, n_lin, M, 0); }
 
 void orc_problem_init_ex(orc_problem *pb, int N, int S, int n_lin, int M, int n_slk)
 {
-    pb->N = N; pb->S = S; pb->n_lin = n_lin; pb->M = M; pb->n_slk = n_slk; pb->slack = ORC_SLACK;
+    pb->N = N; pb->S = S; pb->n_lin = n_lin; pb->M = M; pb->n_slk = n_slk; pb->slack = ORC_SLACK; pb->n_gauss = 0;
     pb->npar = 8 + ORC_SLACK + 9 * S + 3 * n_lin + (M > 0 ? 2 + 7 * M : 0) + (n_slk > 0 ? (M > 0 ? 0 : 1) + 3 * n_slk : 0);
     pb->lb_slack = 0.0; pb->ub_slack = 5000.0;     /* solver_model.py:285-286 */
     pb->dt = 0.2;                 /* settings.yaml:3 integrator_step */
@@ -187,9 +196,9 @@ void orc_stage_constraints(const orc_problem *pb, const double *z, const double 
         jet c = jet_addc(jet_add(jet_scale(x, a1), jet_scale(y, a2)), -b);
         jet_out(&c, &h[row], jac ? &jac[row * ORC_NVE] : 0, hess ? &hess[row * ORC_NVE * ORC_NVE] : 0);
     }
-    if (pb->M == 0 && pb->n_slk == 0) return;
-    const double r_disc = pb->M > 0 ? p[orc_idx_disc_radius(pb)] : 0.0;
-    const double disc_x = p[orc_idx_disc_offset(pb)];
+    if (pb->M == 0 && pb->n_slk == 0 && pb->n_gauss == 0) return;
+    const double r_disc = (pb->M > 0 || pb->n_gauss > 0) ? p[orc_idx_disc_radius(pb)] : 0.0;
+    const double disc_x = p[orc_idx_disc_radius(pb) + ((pb->M > 0 || pb->n_gauss > 0) ? 1 : 0)];
     /* disc_pos = pos + rotation_car @ [disc_x, 0]  (ellipsoid_constraints.py:109-111) */
     jet dpx = jet_add(x, jet_scale(jet_cos(psi), disc_x));
     jet dpy = jet_add(y, jet_scale(jet_sin(psi), disc_x));
@@ -210,6 +219,25 @@ void orc_stage_constraints(const orc_problem *pb, const double *z, const double 
         jet q = jet_add(jet_add(jet_scale(jet_sq(d0), m00), jet_scale(jet_mul(d0, d1), 2.0 * m01)),
                         jet_scale(jet_sq(d1), m11));
         jet_out(&q, &h[row], jac ? &jac[row * ORC_NVE] : 0, hess ? &hess[row * ORC_NVE * ORC_NVE] : 0);
+    }
+    /* GaussianConstraint.get_constraints (gaussian_constraints.py:66-113):
+     *   a = diff/|diff|,  a.diff - (r_disc + r) - erfinv(1 - 2 risk) * sqrt(2 a^T diag(major^2, minor^2) a)   (>= 0)
+     * erfinv by the rational start + two Newton steps of :103-111; it depends on the parameters only. */
+    for (int j = 0; j < pb->n_gauss; j++, row++) {
+        double ox = p[orc_idx_gaussian(pb, j, 0)], oy = p[orc_idx_gaussian(pb, j, 1)];
+        double sx = p[orc_idx_gaussian(pb, j, 2)], sy = p[orc_idx_gaussian(pb, j, 3)];
+        double risk = p[orc_idx_gaussian(pb, j, 4)], r = p[orc_idx_gaussian(pb, j, 5)];
+        double xe = 1.0 - 2.0 * risk;
+        double zz = sqrt(-log((1.0 - xe) / 2.0));
+        double ye = (((1.641345311 * zz + 3.429567803) * zz - 1.624906493) * zz - 1.970840454) / ((1.637067800 * zz + 3.543889200) * zz + 1.0);
+        for (int it = 0; it < 2; it++) ye = ye - (erf(ye) - xe) / (2.0 / sqrt(M_PI) * exp(-ye * ye));
+        jet d0 = jet_addc(dpx, -ox), d1 = jet_addc(dpy, -oy);
+        jet nrm = jet_sqrt(jet_add(jet_sq(d0), jet_sq(d1)));
+        jet a0 = jet_div(d0, nrm), a1 = jet_div(d1, nrm);
+        jet along = jet_add(jet_mul(a0, d0), jet_mul(a1, d1));                       /* a_ij.T @ diff_pos */
+        jet quad = jet_add(jet_scale(jet_sq(a0), sx * sx), jet_scale(jet_sq(a1), sy * sy));
+        jet c = jet_sub(jet_addc(along, -(r_disc + r)), jet_scale(jet_sqrt(jet_scale(quad, 2.0)), ye));
+        jet_out(&c, &h[row], jac ? &jac[row * ORC_NVE] : 0, hess ? &hess[row * ORC_NVE * ORC_NVE] : 0);
     }
     /* Scenario / Decomp LinearConstraints.get_constraints (scenario_constraints.py:64-94, decomp_constraints.py:68-98):
      * a1*disc_pos[0] + a2*disc_pos[1] - (b + slack); slack = 0.0 when the model has no slack state
@@ -233,6 +261,7 @@ void orc_constraint_bounds(const orc_problem *pb, double *lh, double *uh)
     int row = 0;
     for (int j = 0; j < pb->n_lin; j++, row++) { lh[row] = -1e15; uh[row] = 0.0; }
     for (int j = 0; j < pb->M; j++, row++) { lh[row] = 1.0; uh[row] = 1e15; }
+    for (int j = 0; j < pb->n_gauss; j++, row++) { lh[row] = 0.0; uh[row] = 1e15; }   /* gaussian_constraints.py:54-64 */
     for (int j = 0; j < pb->n_slk; j++, row++) { lh[row] = -1e15; uh[row] = 0.0; }   /* scenario_constraints.py:52-62 */
 }
 

@@ -72,12 +72,19 @@ typedef struct {
     int n_slk;
     int slack;          /* = ORC_SLACK: the model has the slack state (and MPCBase weighs it) */
     double lb_slack, ub_slack;   /* solver_model.py:285-286: [0, 5000] */
+    /* Gaussian chance-constraint rows (gaussian_constraints.py:33-113; mpc_planner_jackal's default T-MPC uses them as the
+     * guidance submodule instead of the ellipsoids, generate_jackal_solver.py:53-73): rows >= 0, after the topology rows.
+     * Only with M == 0 and n_slk == 0. */
+    int n_gauss;
 } orc_problem;
 
 /* Fill sizes, default options and bounds for the Jackal contouring unicycle. */
 void orc_problem_init(orc_problem *pb, int N, int S, int n_lin, int M);
 void orc_problem_init_ex(orc_problem *pb, int N, int S, int n_lin, int M, int n_slk);
 int orc_model_nx(void);   /* ORC_NXE of this build */
+/* Replace the (absent) ellipsoid module by n_gauss Gaussian chance-constraint rows; recomputes npar. */
+void orc_problem_set_gaussian(orc_problem *pb, int n_gauss);
+int orc_idx_gaussian(const orc_problem *pb, int j, int which);  /* which: 0..5 = x,y,major,minor,risk,r */
 
 /* parameter index helpers (index into one stage's parameter row) */
 int orc_idx_weight(const orc_problem *pb, int which);           /* 0..7: acceleration, angular_velocity, velocity,
@@ -94,7 +101,7 @@ int orc_idx_slk(const orc_problem *pb, int j, int which);       /* which: 0..2 =
 /* z = [a,w,x,y,psi,v,spline(,slack)] (ORC_NVE entries); p = one stage's parameter row. */
 void orc_stage_cost(const orc_problem *pb, const double *z, const double *p,
                     double *val, double grad[ORC_NVE], double hess[ORC_NVE * ORC_NVE]);
-/* h[0..n_lin) topology rows (<= 0), h[n_lin..n_lin+M) ellipsoid rows (>= 1), then n_slk rows (<= 0) */
+/* h[0..n_lin) topology rows (<= 0), h[n_lin..n_lin+M) ellipsoid rows (>= 1) or n_gauss chance rows (>= 0), then n_slk rows (<= 0) */
 void orc_stage_constraints(const orc_problem *pb, const double *z, const double *p,
                            double *h, double *jac /* nh x NVE */, double *hess /* nh x NVE x NVE */);
 void orc_continuous_dynamics(const double *z, double f[ORC_NXE]);

@@ -17,7 +17,8 @@ class Problem(C.Structure):
                 ("dt", C.c_double), ("n_sqp", C.c_int), ("qp_iter_max", C.c_int), ("qp_tol", C.c_double),
                 ("reg_eps", C.c_double), ("ipm_mu0", C.c_double), ("ipm_thr0", C.c_double),
                 ("erk_steps", C.c_int), ("lb", C.c_double * NV), ("ub", C.c_double * NV),
-                ("n_slk", C.c_int), ("slack", C.c_int), ("lb_slack", C.c_double), ("ub_slack", C.c_double)]
+                ("n_slk", C.c_int), ("slack", C.c_int), ("lb_slack", C.c_double), ("ub_slack", C.c_double),
+                ("n_gauss", C.c_int)]
 
     @property
     def nxe(self):          # model dimensions (array strides): the slack build has one more state
@@ -29,7 +30,7 @@ class Problem(C.Structure):
 
     @property
     def nh(self):
-        return self.n_lin + self.M + self.n_slk
+        return self.n_lin + self.M + self.n_gauss + self.n_slk
 
 
 class Info(C.Structure):
@@ -72,10 +73,12 @@ def dptr(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 
 
-def problem(N=20, S=5, n_lin=8, M=8, n_slk=0, slack=0, **opts):
+def problem(N=20, S=5, n_lin=8, M=8, n_slk=0, slack=0, n_gauss=0, **opts):
     pb = Problem()
     lib(slack).orc_problem_init_ex(C.byref(pb), N, S, n_lin, M, n_slk)
     assert pb.slack == int(bool(slack))
+    if n_gauss:
+        lib(slack).orc_problem_set_gaussian(C.byref(pb), n_gauss)
     for k, v in opts.items():
         setattr(pb, k, v)
     return pb

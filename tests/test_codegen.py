@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 def _golden(fname, config):
     with open(os.path.join(HERE, "golden", fname)) as fh:
-        return [c for c in json.load(fh)["cases"] if c["config"] == config]
+        return [c for c in json.load(fh)["cases"] if config is None or c["config"] == config]
 
 
 def _check(gen, cases, slack_model):
@@ -55,6 +55,16 @@ def test_generated_safe_horizon_stack_matches_reference_golden():
     gen = emit.generate(mm, model, st, "cfg5")
     assert gen["slack"] == 1 and gen["nh"] == 24
     _check(gen, _golden("stage_functions_slack.json", "cfg5_safe_horizon"), True)
+
+
+def test_generated_jackal_gaussian_tmpc_stack_matches_reference_golden():
+    """mpc_planner_jackal's default stack (guidance halfspaces + Gaussian chance constraints as the submodule)."""
+    st = stacks.settings(N=30, max_obstacles=5, num_segments=3)
+    model, mm = stacks.jackal_tmpc(st)
+    gen = emit.generate(mm, model, st, "jackal_tmpc")
+    assert gen["npar"] == 82 and gen["nh"] == 10
+    cases = _golden("stage_functions_gaussian.json", None)
+    _check(gen, cases, False)
 
 
 def test_generated_goal_gaussian_stack_against_finite_differences():

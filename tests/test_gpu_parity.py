@@ -589,3 +589,28 @@ def test_runtime_shape_fast_kernels_match_oracle(name, skw, pkw, B):
         n_ok += int((info["exit_code"] == 1).sum())
     assert n_ok >= B
     s.close()
+
+
+def test_generated_jackal_default_solver_matches_oracle():
+    """mpc_planner_jackal's default configuration (generate_jackal_solver.py:53-73: T-MPC with the GaussianConstraintModule as
+    collision-avoidance submodule, N = 30, 5 obstacles, 3 spline segments) exists only as a generated solver here; the CPU
+    oracle has the chance-constraint rows (pinned to the reference's scripts by tests/golden/stage_functions_gaussian.json),
+    so the generated library is held to the same parity assertions as the hand-written kernels."""
+    import oracle_lib as O
+    from mpc_planner_amd import scenes, solver
+    path, meta = _generated_lib("jackal_tmpc")
+    assert meta["npar"] == 82 and meta["nh"] == 10
+    B = 16
+    d = solver.default_dims(N=30, S=3, lib_path=path)
+    s = solver.BatchedSolver(d, B_max=B, lib_path=path)
+    pb = O.problem(N=30, S=3, n_lin=5, M=0, n_gauss=5)
+    n_ok = 0
+    for scene in (1, 2, 3, 4):
+        sc = scenes.make_scene(scene, N=30, M=5, S=3, B=B, chance=True)
+        assert dict(sc["pm"]._params) == meta["parameter_map"]
+        s.set_batch(sc["xinit"], sc["x0"], sc["params"]); s.solve(); got = s.get()
+        xt, ut, info = O.solve_batch(pb, sc["xinit"], sc["x0"].reshape(B, -1), sc["params"].reshape(B, -1))
+        _compare(got, xt, ut, info)
+        n_ok += int((info["exit_code"] == 1).sum())
+    assert n_ok >= 2 * B
+    s.close()

@@ -146,3 +146,26 @@ def test_mirror_matches_eigh():
             e2 = np.where(np.abs(e) <= 1e-4, 1e-4, np.abs(e))
             close(O.mirror(A), (V * e2) @ V.T, rtol=1e-10, atol=1e-12)
     close(O.mirror(np.zeros((5, 5))), 1e-4 * np.eye(5))
+
+
+def test_gaussian_chance_rows_match_reference_golden():
+    """mpc_planner_jackal's default stack (guidance + GaussianConstraintModule, generate_jackal_solver.py:53-73): oracle rows,
+    parameter map and bounds against the reference's own scripts (tests/golden/make_golden_gaussian.py)."""
+    import ctypes as C
+    with open(os.path.join(HERE, "golden", "stage_functions_gaussian.json")) as fh:
+        cases = json.load(fh)["cases"]
+    for case in cases:
+        pb = O.problem(N=case["N"], S=case["S"], n_lin=case["M"], M=0, n_gauss=case["M"])
+        assert pb.npar == case["npar"] == 82 and pb.nh == case["nh"] == 10
+        pm = case["parameter_map"]; L = O.lib()
+        assert L.orc_idx_disc_radius(C.byref(pb)) == pm["ego_disc_radius"]
+        for j in range(case["M"]):
+            for w, n in enumerate(["x", "y", "major", "minor", "risk", "r"]):
+                assert L.orc_idx_gaussian(C.byref(pb), j, w) == pm[f"gaussian_obst_{j}_{n}"]
+        v, g, H = O.stage_cost(pb, case["z"], case["p"])
+        close(v, case["cost"]); close(H, case["cost_hess"], atol=1e-10)
+        h, J, Hh = O.stage_constraints(pb, case["z"], case["p"])
+        close(h, case["h"], rtol=1e-10); close(J, case["h_jac"], rtol=1e-9, atol=1e-11); close(Hh, case["h_hess"], rtol=1e-8, atol=1e-10)
+        lh = np.zeros(10); uh = np.zeros(10)
+        L.orc_constraint_bounds(C.byref(pb), O.dptr(lh), O.dptr(uh))
+        close(lh, case["lh"]); close(uh, case["uh"])
