@@ -715,7 +715,8 @@ __device__ void linearise(const Lds &L, const Dims &d, int tid, const double *pa
                 L.beta[k * nh + r] = bound - ro.h;
             }
         };
-        stage_linearise(d, z, p, 1, L.pi[(k + 1) * NX + 0], L.pi[(k + 1) * NX + 1], lamh, sink, W, g, BA, xn, slack);
+        stage_linearise(d, z, p, 1, L.pi[(k + 1) * NX + 0], L.pi[(k + 1) * NX + 1], lamh, sink, W, g, BA, xn, slack,
+                        L.W + k * NP28);                    // (generated solvers park the cost Hessian in the stage's W slot)
         // everything but W leaves the registers BEFORE the register-hungry MIRROR
         if (owner) {
 #pragma unroll

@@ -489,8 +489,21 @@ __device__ __forceinline__ void mirror7(double (*A)[NV], double eps)
 template <typename LamH, typename RowSink>
 __device__ __forceinline__ void stage_linearise(const Dims &d, const double *z, const double *p, int pstride,
                                                 double pix, double piy, LamH lamh, RowSink sink,
-                                                double (*W)[NV], double *g, double *BA, double *xn, double slack = 0.0)
+                                                double (*W)[NV], double *g, double *BA, double *xn, double slack = 0.0,
+                                                double *stash = nullptr)
 {
+#ifdef TMPC_GENERATED_STAGE
+    // The emitted cost is long straight-line code: evaluate it first and park dt * Hessian in `stash` (28 doubles of LDS, the
+    // stage's own W slot), so that its temporaries are dead before the dynamics / rows / W accumulation start.
+    CostOut co;
+    cost_eval(d, z, p, pstride, co, true, slack);
+#pragma unroll
+    for (int i = 0; i < NV; i++) g[i] = d.dt * co.g[i];          // stage cost scaled by the shooting interval
+    if (stash) {
+#pragma unroll
+        for (int e = 0; e < NP28; e++) stash[e] = d.dt * co.H[e];
+    }
+#endif
 #pragma unroll
     for (int i = 0; i < NV; i++)
 #pragma unroll
@@ -501,12 +514,19 @@ __device__ __forceinline__ void stage_linearise(const Dims &d, const double *z, 
 #pragma unroll
     for (int i = 0; i < NX; i++) xn[i] = dy.xn[i];
     dyn_add_hessian(dy, pix, piy, W);
-    CostOut co;
-    cost_eval(d, z, p, pstride, co, true, slack);
 #ifdef TMPC_GENERATED_STAGE
+    if (stash) {
 #pragma unroll
-    for (int i = 0; i < NV; i++) g[i] = d.dt * co.g[i];          // stage cost scaled by the shooting interval
-    cost_add_hessian(co, d.dt, W);
+        for (int i = 0; i < NV; i++)
+#pragma unroll
+            for (int j = 0; j <= i; j++) {
+                const double h = stash[i * (i + 1) / 2 + j];
+                W[i][j] += h;
+                if (i != j) W[j][i] += h;
+            }
+    } else {
+        cost_add_hessian(co, d.dt, W);
+    }
     // generated rows, all normalised to g(z) <= 0 (internal order = emitted order, every row upper-bounded)
     tmpc_gen::rows(z, p, pstride, slack, [&](int k, double h, double gx, double gy, double gp, double hxx, double hxy, double hyy,
                                              double hxp, double hyp, double hpp) {
@@ -517,6 +537,8 @@ __device__ __forceinline__ void stage_linearise(const Dims &d, const double *z, 
         sink(k, ro);
     });
 #else
+    CostOut co;
+    cost_eval(d, z, p, pstride, co, true, slack);
 #pragma unroll
     for (int i = 0; i < NV; i++) g[i] = (i == ZPSI) ? 0.0 : d.dt * co.g[i];   // stage cost scaled by the shooting interval (the cost
                                                                         // does not depend on psi: literal 0, not a hoisted dt * 0)
