@@ -51,6 +51,21 @@ def test_stage_functions_match_reference_golden(gold):
         s.close()
 
 
+def _check_selection(best, got, info, weight=None, disabled=None):
+    """FindBestPlanner on device: bit-exact against the reference rule (oracle's orc_find_best: strict '<', lowest index,
+    init 1e10) applied to the SAME objectives the device holds; and equivalent to the oracle's own choice -- when several
+    guidance trajectories converge to the same optimum their objectives tie to rounding, so the index may differ but the
+    selected objective may not."""
+    import oracle_lib as O
+    w = 1.0 if weight is None else weight
+    assert best == O.find_best(got["pobj"] * w, got["exit_code"], disabled)
+    ref = O.find_best(info["pobj"] * w, info["exit_code"], disabled)
+    assert (best < 0) == (ref < 0)
+    if best >= 0:
+        a, b = (got["pobj"] * w)[best], (info["pobj"] * w)[ref]
+        assert abs(a - b) <= 1e-6 * max(1.0, abs(b))
+
+
 def _compare(got, xt, ut, info, tol=1e-4, tight=2e-5):
     assert (got["exit_code"] == info["exit_code"]).all()
     assert (got["sqp_iter"] == info["sqp_iter"]).all()
@@ -79,7 +94,7 @@ def test_cfg2_solve_matches_oracle(scene):
     pb = O.problem(N=20, S=5, n_lin=8, M=8)
     xt, ut, info = O.solve_batch(pb, sc["xinit"], sc["x0"].reshape(64, -1), sc["params"].reshape(64, -1))
     _compare(got, xt, ut, info)
-    assert s.select_best() == O.find_best(info["pobj"], info["exit_code"])
+    _check_selection(s.select_best(), got, info)
     s.close()
 
 
@@ -110,7 +125,7 @@ def test_cfg4_tmpcpp_12_obstacles():
     _compare(got, xt, ut, info)
     w = np.ones(B); w[3] = 0.75                     # selection_weight_consistency_ (guidance_constraints.cpp:358-359)
     dis = np.zeros(B, np.uint8); dis[5] = 1
-    assert s.select_best(weight=w, disabled=dis) == O.find_best(info["pobj"] * w, info["exit_code"], dis)
+    _check_selection(s.select_best(weight=w, disabled=dis), got, info, w, dis)
     s.close()
 
 
@@ -304,7 +319,7 @@ def test_slack_model_solve_matches_oracle(cfg, scenes_, B):
         xt, ut, info = O.solve_batch(pb, sc["xinit"], sc["x0"].reshape(B, -1), sc["params"].reshape(B, -1))
         _compare(got, xt, ut, info)
         assert np.all(got["xtraj"][:, :, 5] == 0.0)                 # the pinned slack state
-        assert s.select_best() == O.find_best(info["pobj"], info["exit_code"])
+        _check_selection(s.select_best(), got, info)
         n_ok += int((info["exit_code"] == 1).sum())
     assert n_ok >= B
     s.close()
