@@ -80,7 +80,7 @@ int main(int argc, char **argv)
             for (int i = 0; i < 6; i++) s.setParameter(k, std::string(w[i]), wv[i]);
             for (int i = 0; i < SOLVER_S; i++) { setSolverParameterSplineXC(k, s._params, 1.0, i); setSolverParameterSplineXD(k, s._params, 6.0 * i, i); setSolverParameterSplineStart(k, s._params, 6.0 * i, i); }
             setSolverParameterEgoDiscRadius(k, s._params, 0.325);
-            for (int j = 0; j < SOLVER_M; j++) {
+            for (int j = 0; j < SOLVER_MAX_OBSTACLES; j++) {     // (SOLVER_M is 0 in generated libraries: rows are not typed there)
                 setSolverParameterLinConstraintA1(k, s._params, 1.0, j); setSolverParameterLinConstraintB(k, s._params, 100.0, j);
                 setSolverParameterEllipsoidObstX(k, s._params, 50.0, j); setSolverParameterEllipsoidObstY(k, s._params, 50.0 + j, j);
                 setSolverParameterEllipsoidObstChi(k, s._params, 1.0, j); setSolverParameterEllipsoidObstR(k, s._params, 0.4, j);

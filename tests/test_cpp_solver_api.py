@@ -57,3 +57,26 @@ def test_cpp_solver_solve_and_batch():
         _build()
     out = subprocess.run([BIN, os.path.join(GEN, "config"), "--solve"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "solve ok" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.gpu
+def test_cpp_solver_over_a_generated_library():
+    """The C++ Solver mirror linked against a per-configuration library produced by generate_solver_from_modules (T-MPC stack
+    from plugin modules): same test program, same parameter names, plumbing + solve + batch."""
+    from mpc_planner_amd.generate_solver import generate_solver_from_modules
+    from mpc_planner_amd.codegen import stacks
+    out = os.path.join(ROOT, "build", "generated_from_modules")
+    st = stacks.settings(N=20, max_obstacles=8); st["integrator_step"] = 0.2
+    lib = os.path.join(out, "lib", "libtmpc_hip_cpp_tmpc.so")
+    if not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(os.path.join(ROOT, "mpc_planner_amd", "csrc", "tmpc_solve.hip")):
+        model, mm = stacks.tmpc(st)
+        lib, meta = generate_solver_from_modules(out, "cpp_tmpc", mm, model, st)
+        assert meta["npar"] == 135
+    cpp = os.path.join(ROOT, "mpc_planner_amd", "cpp")
+    exe = os.path.join(out, "test_solver_generated")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(cpp, "include"), "-I", os.path.join(out, "include"),
+                           "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "test_solver.cpp"),
+                           os.path.join(cpp, "src", "solver_interface.cpp"), os.path.join(out, "src", "mpc_planner_parameters.cpp"),
+                           lib, "-Wl,-rpath," + os.path.dirname(lib), "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-lamdhip64", "-o", exe])
+    res = subprocess.run([exe, os.path.join(out, "config"), "--solve"], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and "solve ok" in res.stdout, res.stdout + res.stderr
