@@ -368,8 +368,9 @@ void tmpc_solve_fast_kernel(Dims d, int B, const double *__restrict__ xinit,
     constexpr int NT = NTH;
     const int NHk = C::RT ? d.n_up + d.M : C::NH, NLINk = C::RT ? d.n_up : NLIN;
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    if (b >= B) return;
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x >= B) return;
+    const int b = trajectory_of_block(blockIdx.x, B);
     const Lds L = carve_fast(smem, d);
     const int N = d.N;
     const double *xi = xinit + (size_t)b * ext_nx(d);

@@ -73,6 +73,18 @@ __device__ __forceinline__ Lds carve(double *s, const Dims &d)
     return L;
 }
 
+// ---- workgroup -> trajectory ------------------------------------------------------------------------
+// The dispatcher deals consecutive workgroups round-robin to the 8 XCDs (each with its own L2), and trajectories of one scene
+// (adjacent in the batch) share 92 % of their parameter rows.  Giving every XCD a contiguous range of trajectories was
+// measured (round 1): HBM fetch per launch 127 -> 99 MB, but kernel time 10.5 -> 11.3 ms -- a scene's trajectories need
+// similar iteration counts, so whole slow scenes pile up on one XCD while others drain.  The kernel is compute-bound
+// (0.15 % of HBM peak), so the identity mapping, which interleaves every scene over all XCDs, stays.
+__device__ __forceinline__ int trajectory_of_block(int blk, int B)
+{
+    (void)B;
+    return blk;
+}
+
 // ---- wave reductions (one wavefront per workgroup) -----------------------------------------------
 __device__ __forceinline__ double wave_max(double x)
 {
@@ -805,8 +817,9 @@ __global__ __launch_bounds__(NT) void tmpc_solve_kernel(Dims d, int B, const dou
                                                         long long *__restrict__ prof_out)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    if (b >= B) return;
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x >= B) return;
+    const int b = trajectory_of_block(blockIdx.x, B);
     const Lds L = carve(smem, d);
     const int N = d.N;
     const double *xi = xinit + (size_t)b * ext_nx(d);
