@@ -36,7 +36,7 @@ def rows(d, suffix):
     return out
 
 
-summary = {"command": "rocprofv3 --kernel-trace --stats -- " + " ".join(BENCH[1:]) + "   (cfg2, 64 scenes x 64 = 4096 trajectories per launch); "
+summary = {"command": "rocprofv3 --kernel-trace --stats -- " + " ".join(BENCH[1:]) + "   (cfg2, 256 scenes x 64 = 16384 trajectories per launch); "
            "PMC in separate --pmc passes", "tag": tag}
 d = rocprof("kt", ["--kernel-trace", "--stats"], BENCH)
 ks = rows(d, "kernel_stats")
