@@ -86,23 +86,44 @@ __device__ __forceinline__ int trajectory_of_block(int blk, int B)
 }
 
 // ---- wave reductions (one wavefront per workgroup) -----------------------------------------------
+// DPP row shifts / row broadcasts on the two 32-bit halves (pure VALU, no LDS round trips as with ds_bpermute): after
+// row_shr 1,2,4,8 lane 15 of every 16-lane row holds the row's result, row_bcast:15 folds rows 0->1 and 2->3, row_bcast:31
+// folds the lower half into the upper one; lane 63 then holds the wave's result and is broadcast with v_readlane.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_move(double x, double identity)
+{
+    union { double d; int i[2]; } u, o;
+    u.d = x; o.d = identity;
+    o.i[0] = __builtin_amdgcn_update_dpp(o.i[0], u.i[0], CTRL, ROW_MASK, 0xf, false);
+    o.i[1] = __builtin_amdgcn_update_dpp(o.i[1], u.i[1], CTRL, ROW_MASK, 0xf, false);
+    return o.d;
+}
+template <typename Op>
+__device__ __forceinline__ double wave_reduce(double x, double identity, Op op)
+{
+    x = op(x, dpp_move<0x111, 0xf>(x, identity));      // row_shr:1
+    x = op(x, dpp_move<0x112, 0xf>(x, identity));      // row_shr:2
+    x = op(x, dpp_move<0x114, 0xf>(x, identity));      // row_shr:4
+    x = op(x, dpp_move<0x118, 0xf>(x, identity));      // row_shr:8
+    x = op(x, dpp_move<0x142, 0xa>(x, identity));      // row_bcast:15 into rows 1 and 3
+    x = op(x, dpp_move<0x143, 0xc>(x, identity));      // row_bcast:31 into rows 2 and 3
+    union { double d; int i[2]; } u;
+    u.d = x;
+    u.i[0] = __builtin_amdgcn_readlane(u.i[0], 63);
+    u.i[1] = __builtin_amdgcn_readlane(u.i[1], 63);
+    return u.d;
+}
 __device__ __forceinline__ double wave_max(double x)
 {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) x = fmax(x, __shfl_xor(x, o, 64));
-    return x;
+    return wave_reduce(x, -__builtin_huge_val(), [](double a, double b) { return fmax(a, b); });
 }
 __device__ __forceinline__ double wave_min(double x)
 {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) x = fmin(x, __shfl_xor(x, o, 64));
-    return x;
+    return wave_reduce(x, __builtin_huge_val(), [](double a, double b) { return fmin(a, b); });
 }
 __device__ __forceinline__ double wave_sum(double x)
 {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) x += __shfl_xor(x, o, 64);
-    return x;
+    return wave_reduce(x, 0.0, [](double a, double b) { return a + b; });
 }
 
 // Workgroup reductions for the two-wave (128-thread) variant of the fast kernel: wave reduction, then one LDS exchange.
