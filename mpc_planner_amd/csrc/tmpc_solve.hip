@@ -438,10 +438,13 @@ __device__ void riccati_solve(const Lds &L, const Dims &d, int tid, int sw = 1)
         load_stage(0);
         for (int k = 0; k < N; k++) {
             // du = -Luu^-T (Lxu^T dx + y): the dot products over lanes 2..6 are reduced with readlanes
-            const double p0 = lx0 * dx, p1 = lx1 * dx;
-            double s0 = y0, s1 = y1;
-#pragma unroll
-            for (int j = 0; j < NX; j++) { s0 += readlane_d(p0, NU + j); s1 += readlane_d(p1, NU + j); }
+            // (Lxu^T dx)_{0,1}: sums over lanes 2..6, folded with DPP row shifts (lanes 0, 1 contribute zeros; lane 6 ends up
+            // with the total) instead of five dependent readlane + add pairs each
+            double q0 = xl ? lx0 * dx : 0.0, q1 = xl ? lx1 * dx : 0.0;
+            q0 += dpp_move<0x111, 0xf>(q0, 0.0); q1 += dpp_move<0x111, 0xf>(q1, 0.0);
+            q0 += dpp_move<0x112, 0xf>(q0, 0.0); q1 += dpp_move<0x112, 0xf>(q1, 0.0);
+            q0 += dpp_move<0x114, 0xf>(q0, 0.0); q1 += dpp_move<0x114, 0xf>(q1, 0.0);
+            const double s0 = y0 + readlane_d(q0, NV - 1), s1 = y1 + readlane_d(q1, NV - 1);
             const double u1 = -s1 * r1;
             const double u0 = (-s0 - l10 * u1) * r0;
             if (rowl) L.dv[k * NV + lane] = lane == 0 ? u0 : (lane == 1 ? u1 : dx);
