@@ -37,9 +37,10 @@ def _compile(header, out, extra):
     return usage
 
 
-def build_generated_solver(name, modules, model, settings, out_dir):
+def build_generated_solver(name, modules, model, settings, out_dir, method="symbolic"):
+    """method: see emit.generate ("symbolic": best kernels, slow generation; "jets": instant generation)."""
     os.makedirs(out_dir, exist_ok=True)
-    gen = emit.generate(modules, model, settings, name)
+    gen = emit.generate(modules, model, settings, name, method=method)
     header = os.path.join(os.path.abspath(out_dir), f"stage_{name}.h")
     with open(header, "w") as fh:
         fh.write(gen["header"])

@@ -1642,11 +1642,7 @@ int tmpc_debug_profile(tmpc_handle *h, int64_t *cycles, int32_t n_phases)
     if (!h || h->B <= 0 || !cycles || n_phases < tmpc::PH_COUNT) return TMPC_ERR_INVALID;
     TMPC_HIP_CHECK(h, hipSetDevice(h->device));
     long long *dp = nullptr;
-#ifdef TMPC_DEBUG_DUMP
-    const size_t n = (size_t)h->B * tmpc::PH_COUNT + 2048;
-#else
     const size_t n = (size_t)h->B * tmpc::PH_COUNT;
-#endif
     TMPC_HIP_CHECK(h, hipMalloc(&dp, n * 8));
     TMPC_HIP_CHECK(h, hipMemset(dp, 0, n * 8));
     tmpc::SolveKernel pk = h->kernel;                   // the generic kernel profiles itself; fast shapes have an instrumented twin
@@ -1668,9 +1664,6 @@ int tmpc_debug_profile(tmpc_handle *h, int64_t *cycles, int32_t n_phases)
         for (int b = 0; b < h->B; b++) acc += (double)host[(size_t)b * tmpc::PH_COUNT + i];
         cycles[i] = (int64_t)(acc / h->B);
     }
-#ifdef TMPC_DEBUG_DUMP
-    if (getenv("TMPC_DUMP_FILE")) { FILE *fp = fopen(getenv("TMPC_DUMP_FILE"), "wb"); fwrite(host.data() + 16, 8, 1800, fp); fclose(fp); }
-#endif
     return TMPC_OK;
 }
 

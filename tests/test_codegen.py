@@ -45,14 +45,14 @@ def test_generated_tmpc_stack_matches_reference_golden():
     spline knot and points several segments away from one (the glue sigmoids' derivatives must not overflow)."""
     st = stacks.settings(N=20, max_obstacles=8)
     model, mm = stacks.tmpc(st)
-    _check(emit.generate(mm, model, st, "cfg2"), _golden("stage_functions.json", "cfg2_tmpc_M8"), False)
+    _check(emit.generate(mm, model, st, "cfg2", method="jets"), _golden("stage_functions.json", "cfg2_tmpc_M8"), False)
 
 
 def test_generated_safe_horizon_stack_matches_reference_golden():
     """BASELINE cfg 5 stack (slack model, 24 scenario halfspaces): the slack enters as the per-trajectory constant."""
     st = stacks.settings(N=20, max_obstacles=8)
     model, mm = stacks.safe_horizon(st)
-    gen = emit.generate(mm, model, st, "cfg5")
+    gen = emit.generate(mm, model, st, "cfg5", method="jets")
     assert gen["slack"] == 1 and gen["nh"] == 24
     _check(gen, _golden("stage_functions_slack.json", "cfg5_safe_horizon"), True)
 
@@ -61,7 +61,7 @@ def test_generated_jackal_gaussian_tmpc_stack_matches_reference_golden():
     """mpc_planner_jackal's default stack (guidance halfspaces + Gaussian chance constraints as the submodule)."""
     st = stacks.settings(N=30, max_obstacles=5, num_segments=3)
     model, mm = stacks.jackal_tmpc(st)
-    gen = emit.generate(mm, model, st, "jackal_tmpc")
+    gen = emit.generate(mm, model, st, "jackal_tmpc", method="jets")
     assert gen["npar"] == 82 and gen["nh"] == 10
     cases = _golden("stage_functions_gaussian.json", None)
     _check(gen, cases, False)
@@ -72,7 +72,7 @@ def test_generated_goal_gaussian_stack_against_finite_differences():
     derivatives against central differences of the emitted values; erf / log / sqrt paths of the chance constraint."""
     st = stacks.settings(N=20, max_obstacles=3)
     model, mm = stacks.goal_gaussian(st)
-    gen = emit.generate(mm, model, st, "goal_gaussian")
+    gen = emit.generate(mm, model, st, "goal_gaussian", method="jets")
     pm = gen["params"]
     hs = HostStageFunctions(gen["header"])
     assert hs.nh == 3 and hs.npar == pm.length() == 4 + 3 + 2 + 6 * 3
@@ -108,6 +108,26 @@ def test_generated_goal_gaussian_stack_against_finite_differences():
         a = d / np.linalg.norm(d)
         want = np.linalg.norm(d) - (0.325 + 0.4) - erfinv(1 - 2 * 0.05) * np.sqrt(2 * (a[0] ** 2 * (0.4 + 0.1 * j) ** 2 + a[1] ** 2 * 0.04))
         assert abs(-h[j] - want) < 1e-9
+
+
+def test_jet_and_symbolic_differentiation_agree():
+    """The two differentiation back ends of emit.py (sparse forward-mode jets at code level -- the default -- and sympy
+    derivatives + CSE) are independent implementations: same values, gradients and Hessians on a stack with sqrt, log, erf,
+    exp, sin / cos and rational functions."""
+    st = stacks.settings(N=20, max_obstacles=2)
+    model, mm = stacks.goal_gaussian(st)
+    a = HostStageFunctions(emit.generate(mm, model, st, "a", method="jets")["header"])
+    model, mm = stacks.goal_gaussian(st)
+    b = HostStageFunctions(emit.generate(mm, model, st, "b", method="symbolic")["header"])
+    rng = np.random.default_rng(2)
+    for _ in range(5):
+        p = rng.uniform(0.2, 1.5, a.npar); z = rng.uniform(-1.0, 2.0, 7)
+        for j in range(2):
+            p[a.npar - 6 * (2 - j) + 4] = rng.uniform(0.01, 0.3)       # risk in (0, 0.5)
+        for fa, fb in zip(a.cost(z, p), b.cost(z, p)):
+            np.testing.assert_allclose(fa, fb, rtol=1e-11, atol=1e-12)
+        for fa, fb in zip(a.rows(z, p), b.rows(z, p)):
+            np.testing.assert_allclose(fa, fb, rtol=1e-10, atol=1e-11)
 
 
 def test_generator_refuses_rows_outside_the_kernel_structure():

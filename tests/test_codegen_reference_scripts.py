@@ -36,7 +36,7 @@ base.weigh_variable(var_name="a", weight_names="acceleration"); base.weigh_varia
 base.weigh_variable(var_name="v", weight_names=["velocity", "reference_velocity"], cost_function=lambda x, w: w[0] * (x - w[1]) ** 2)
 modules.add_module(ContouringModule(settings))
 modules.add_module(GuidanceConstraintModule(settings, constraint_submodule=EllipsoidConstraintModule))
-gen = emit.generate(modules, model, settings, "reference_scripts_tmpc")
+gen = emit.generate(modules, model, settings, "reference_scripts_tmpc", method="jets")
 json.dump(dict(header=gen["header"], pmap=dict(gen["params"]._params), nh=gen["nh"]), open(sys.argv[1], "w"))
 '''
 

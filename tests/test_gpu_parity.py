@@ -542,7 +542,7 @@ def test_generated_goal_gaussian_solver_solves_a_stack_without_hand_written_kern
     path, meta = _generated_lib("goal_gaussian")
     st = stacks.settings(N=20, max_obstacles=4)
     model, mm = stacks.goal_gaussian(st)
-    hs = HostStageFunctions(emit.generate(mm, model, st, "goal_gaussian")["header"])
+    hs = HostStageFunctions(emit.generate(mm, model, st, "goal_gaussian", method="jets")["header"])
     pm = meta["parameter_map"]; N, B = 20, 8
     params = np.zeros((B, N, meta["npar"]))
     for n, v in dict(acceleration=0.34, angular_velocity=0.85, velocity=0.55, reference_velocity=2.0, goal_weight=4.0,
