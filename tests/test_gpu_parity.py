@@ -629,3 +629,69 @@ def test_generated_jackal_default_solver_matches_oracle():
         n_ok += int((info["exit_code"] == 1).sum())
     assert n_ok >= 2 * B
     s.close()
+
+
+def test_closed_loop_replay_device_state_equals_host_driven_loop():
+    """Ten control ticks of one scene: every tick the robot moves to node 1 of the selected plan, all planners
+    are warm-started by shifting their own previous solution (initializeWarmstart), the obstacle predictions advance one
+    step, the topology rows are re-linearised around the shifted plans and everything is solved again.  Loop A keeps the plans
+    on the device (tmpc_warmstart + tmpc_linearize_topology); loop B does the same on the host with the numpy mirrors and
+    re-uploads: the same selected objective and the same trajectories tick by tick, and the robot makes progress along the path."""
+    import torch
+    from mpc_planner_amd import scenes, modules as md
+    N, M, B, TICKS = 20, 8, 32, 10
+    sc = scenes.make_scene(9, N=N, M=M, B=B)
+    pm = sc["pm"]
+    dev = torch.device("cuda")
+    obs0 = sc["obstacles"]
+
+    def params_for_tick(t, state_xy):                         # host side of a tick: obstacle predictions shifted by t steps
+        obs = dict(obs0)
+        vel = (obs0["pos"][:, 1] - obs0["pos"][:, 0]) / scenes.DT
+        obs["pos"] = obs0["pos"] + vel[:, None, :] * scenes.DT * t
+        base = sc["params"][0].copy()
+        md.ellipsoid_set_parameters(pm, base, state_xy, obs, scenes.ROBOT_RADIUS)
+        return obs, base
+
+    sA, sB = _solver(B_max=B), _solver(B_max=B)
+    xinit, x0, params = sc["xinit"].copy(), sc["x0"].copy(), sc["params"].copy()
+    sA.set_batch(xinit, x0, params); sA.solve(); rA = sA.get(); bestA = sA.select_best()
+    sB.set_batch(xinit, x0, params); sB.solve(); rB = sB.get(); bestB = sB.select_best()
+    progress = []
+    for t in range(1, TICKS + 1):
+        # planners that reach the same optimum tie to rounding: the two loops must agree on the selected objective, not on
+        # which of the tied planners carries it
+        assert bestA >= 0 and bestB >= 0 and abs(rA["pobj"][bestA] - rB["pobj"][bestB]) <= 1e-8 * max(1.0, abs(rB["pobj"][bestB]))
+        state = rB["xtraj"][bestB, 1].copy()
+        progress.append(state[4])
+        obs, base = params_for_tick(t, state[:2])
+        states = np.tile(state, (B, 1))
+        # ---- loop B: host mirrors ----
+        x0B = x0.copy(); pB = np.tile(base, (B, 1, 1))
+        for b in range(B):
+            md.initialize_warmstart(x0B[b], state, rB["xtraj"][b], rB["utraj"][b], True)
+        x0B_lin = x0B.copy()
+        r = 1e-3 + scenes.ROBOT_RADIUS
+        for b in range(B):                                    # projectToSafety stand-in (same rule as the device kernel)
+            for k in range(1, N):
+                for _ in range(3):
+                    for j in range(M):
+                        o = obs["pos"][j, k - 1]; dv = x0B_lin[b, k, 2:4] - o; dist = np.sqrt(dv[0] * dv[0] + dv[1] * dv[1])
+                        if dist < r:
+                            x0B_lin[b, k, 2:4] = o + dv * (r * 1.001 / dist)
+            md.linearized_set_parameters(pm, pB[b], state[0], md.linearized_update(x0B_lin[b], obs["pos"], scenes.ROBOT_RADIUS), n_rows=M)
+        sB.set_batch(states, x0B, pB); sB.solve(); rB = sB.get(); bestB = sB.select_best()
+        # ---- loop A: plans stay on the device; only the (scene-level) parameter rows are uploaded ----
+        sA.set_batch(states, x0, np.tile(base, (B, 1, 1)))    # x0 content is irrelevant: overwritten by the device warm start
+        t_state = torch.from_numpy(states).to(dev)
+        sA.warmstart(t_state.data_ptr())                      # NB: shifts the solution of the previous tick held by sA
+        t_ob = torch.from_numpy(np.ascontiguousarray(obs["pos"][None])).to(dev)
+        t_sc = torch.zeros(B, dtype=torch.int32, device=dev); t_sx = torch.from_numpy(states[:1, 0].copy()).to(dev)
+        sA.linearize_topology(t_ob.data_ptr(), t_sc.data_ptr(), t_sx.data_ptr(), scenes.ROBOT_RADIUS)
+        sA.solve(); rA = sA.get(); bestA = sA.select_best()
+        assert np.array_equal(rA["exit_code"], rB["exit_code"])
+        ok = rB["exit_code"] == 1
+        assert ok.sum() >= 1
+        np.testing.assert_allclose(rA["xtraj"][ok], rB["xtraj"][ok], rtol=0, atol=1e-9)
+    assert progress[-1] > progress[0] + 2.0                  # the robot advanced > 2 m along the reference path in 2 s
+    sA.close(); sB.close()
