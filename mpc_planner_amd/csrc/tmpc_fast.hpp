@@ -188,6 +188,7 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
         }
         for (int e = tl; e < (N + 1) * NP28; e += NT) L.Hh[e] = L.W[e];
         __syncthreads();
+        pf.stop(PH_HH);                                   // (profile: stage-vector part of the residuals)
         // ---- row pass R (registers): residuals, rg -= lam c, Hh += d c c^T, gh += d rd c ----
         double res_d = 0.0, res_m = 0.0, mu = 0.0;
         {
@@ -217,7 +218,6 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
                     lds_add(&L.gh[k * NV + vr], w * cus);
                     lds_add(&L.Hh[k * NP28 + pidx(vr, vr)], dd);
                 }
-                __builtin_amdgcn_sched_barrier(0);             // one row at a time: keeps the unrolled pass from piling up live values
             }
             if (stage_lane) {
                 lds_add(&L.rg[k * NV + ZX], -gs0); lds_add(&L.rg[k * NV + ZY], -gs1); lds_add(&L.rg[k * NV + ZPSI], -gs2);
@@ -276,7 +276,6 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
                 const double dl = a ? -lam[s] - lam[s] * INVT(s) * dt : 0.0;
                 if (dt < 0.0) amax = fmin(amax, -t[s] / dt);
                 if (dl < 0.0) amax = fmin(amax, -lam[s] / dl);
-                __builtin_amdgcn_sched_barrier(0);
             }
             a_aff = fmin(1.0, blk_min<NTH>(amax, L.scr, tl, 5));
 #pragma unroll
@@ -308,7 +307,6 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
                 const double w = qt[s] + lam[s] * INVT(s) * (a ? rr : 0.0);
                 cs0 += w * c0s; cs1 += w * c1s; cs2 += w * c2s;
                 if (a && (box >> s & 1)) lds_add(&L.gh[k * NV + VAR(s)], w * CU(s));
-                __builtin_amdgcn_sched_barrier(0);
             }
             if (stage_lane) { lds_add(&L.gh[k * NV + ZX], cs0); lds_add(&L.gh[k * NV + ZY], cs1); lds_add(&L.gh[k * NV + ZPSI], cs2); }
         }
@@ -327,7 +325,6 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
             const double dl = a ? -qt[s] - lam[s] * INVT(s) * dt : 0.0;
             if (dt < 0.0) amax = fmin(amax, -t[s] / dt);
             if (dl < 0.0) amax = fmin(amax, -lam[s] / dl);
-            __builtin_amdgcn_sched_barrier(0);
         }
         const double alpha = fmin(1.0, 0.995 * blk_min<NTH>(amax, L.scr, tl, 7));
         pf.stop(PH_ROWS);
