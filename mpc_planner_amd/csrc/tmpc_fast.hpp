@@ -326,7 +326,7 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
             if (dt < 0.0) amax = fmin(amax, -t[s] / dt);
             if (dl < 0.0) amax = fmin(amax, -lam[s] / dl);
         }
-        const double alpha = fmin(1.0, 0.995 * blk_min<NTH>(amax, L.scr, tl, 7));
+        const double alpha = fmin(1.0, 0.999 * blk_min<NTH>(amax, L.scr, tl, 7));
         pf.stop(PH_ROWS);
         if (!isfinite(alpha)) { status = 4; break; }
         if (alpha < 1e-12) { status = 3; break; }

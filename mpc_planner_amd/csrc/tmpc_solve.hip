@@ -697,7 +697,7 @@ __device__ int ipm_solve(const Lds &L, const Dims &d, int tid, int *iters_out, P
             if (dt < 0.0) amax = fmin(amax, -L.t[r] / dt);
             if (dl < 0.0) amax = fmin(amax, -L.lam[r] / dl);
         }
-        const double alpha = fmin(1.0, 0.995 * wave_min(amax));
+        const double alpha = fmin(1.0, 0.999 * wave_min(amax));
         pf.stop(PH_ROWS);
         if (!isfinite(alpha)) { status = 4; break; }
         if (alpha < 1e-12) { status = 3; break; }
