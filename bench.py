@@ -43,6 +43,26 @@ def bytes_per_solve(N=N_H, npar=135, nv=NV, nx=NX, nu=NU):
     return 8 * (N * npar + (N + 1) * nv + nx + (N + 1) * nx + N * nu)
 
 
+def usable_cpus():
+    """CPUs this process can actually run on: scheduler affinity capped by the cgroup CPU quota (the bench box shows 256
+    logical CPUs to a container whose quota is 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:                         # cgroup v2: "<quota> <period>" or "max <period>"
+            q, per = fh.read().split()
+            if q != "max":
+                n = min(n, max(1, int(float(q) / float(per))))
+    except OSError:
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fq, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fp:
+                q, per = int(fq.read()), int(fp.read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+        except OSError:
+            pass
+    return n
+
+
 def cpu_baseline(n_scenes):
     """Reported baseline (NOT the target): the restated acados-equivalent CPU path (oracle/, kind 'port'),
     OpenMP over trajectories like guidance_constraints.cpp:279, on all host cores, bounded sample."""
@@ -50,21 +70,26 @@ def cpu_baseline(n_scenes):
     import oracle_lib as O
     from mpc_planner_amd import scenes
     pb = O.problem(N=N_H, S=S_SEG, n_lin=M_OBS, M=M_OBS)
-    cores = os.cpu_count()
+    cores = usable_cpus()
     batch = scenes.make_batch(range(n_scenes), N=N_H, M=M_OBS, B=TRAJ)
-    # bounded sample: tile the scenes so that every core gets >= ~16 solves (about 10-30 s of CPU work)
-    reps = max(1, int(np.ceil(16 * cores / batch["xinit"].shape[0])))
+    # bounded sample: tile the scenes so that every core gets >= ~128 solves (about 10-30 s of CPU work)
+    reps = max(1, int(np.ceil(128 * cores / batch["xinit"].shape[0])))
     for key in ("xinit", "x0", "params"):
         batch[key] = np.concatenate([batch[key]] * reps, 0)
     B = batch["xinit"].shape[0]
     args = (pb, batch["xinit"], batch["x0"].reshape(B, -1), batch["params"].reshape(B, -1))
     O.solve_batch(*args[:1], args[1][:cores], args[2][:cores], args[3][:cores], num_threads=cores)   # warm-up
-    t0 = time.perf_counter()
-    _, _, info = O.solve_batch(*args, num_threads=cores)
-    dt = time.perf_counter() - t0
-    return {"value": B / dt, "unit": "solves/s", "cores": cores, "kind": "port",
-            "sample": f"{n_scenes} scenes x {TRAJ} trajectories tiled x{reps} = {B} solves of the same workload in {dt:.2f} s, "
-                      f"restated acados-equivalent C oracle (oracle/), OpenMP over trajectories"}
+    t0 = time.perf_counter(); passes = 0
+    while True:                                                      # bounded sample: >= 10 s of CPU work
+        _, _, info = O.solve_batch(*args, num_threads=cores)
+        passes += 1
+        dt = time.perf_counter() - t0
+        if dt >= 10.0 or passes >= 200:
+            break
+    return {"value": passes * B / dt, "unit": "solves/s", "cores": cores, "kind": "port",
+            "sample": f"{n_scenes} scenes x {TRAJ} trajectories tiled x{reps} = {B} solves of the same workload, {passes} passes in {dt:.2f} s, "
+                      f"restated acados-equivalent C oracle (oracle/), OpenMP over trajectories on the {cores} CPUs usable by this "
+                      f"process (affinity / cgroup quota; {os.cpu_count()} logical CPUs visible)"}
 
 
 def main():

@@ -184,7 +184,12 @@ static double max_step(const orc_qp *qp, const orc_qp_sol *s, const ipm_ws *w)
 void orc_qp_solve(const orc_qp *qp, orc_qp_sol *s, int iter_max, double tol, double mu0, double thr0)
 {
     const int N = qp->N;
-    ipm_ws *w = (ipm_ws *)calloc(1, sizeof(ipm_ws));
+    /* per-thread workspace, reused across solves (a calloc/free pair per QP makes hundreds of OpenMP threads fight over
+     * the kernel's page-fault path and says nothing about the algorithm) */
+    static __thread ipm_ws *tls_w = NULL;
+    if (!tls_w) tls_w = (ipm_ws *)malloc(sizeof(ipm_ws));
+    ipm_ws *w = tls_w;
+    memset(w, 0, sizeof(ipm_ws));
     int m = 0;
     /* cold start: v = 0 (dx_0 = given), pi = 0, t = max(residual, thr0), lam = mu0 / t */
     memset(s->v, 0, sizeof s->v); memset(s->pi, 0, sizeof s->pi);
@@ -280,5 +285,4 @@ void orc_qp_solve(const orc_qp *qp, orc_qp_sol *s, int iter_max, double tol, dou
             }
         }
     }
-    free(w);
 }

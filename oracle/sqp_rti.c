@@ -57,7 +57,9 @@ static void build_qp(const orc_problem *pb, const nlp_state *st, const double *x
         double l, gl[ORC_NVE], Hl[ORC_NVE * ORC_NVE];
         orc_stage_cost(pb, z, p, &l, gl, Hl);
         double h[ORC_MAX_NH], D[ORC_MAX_NH * ORC_NVE];
-        double *Hh = (double *)malloc(sizeof(double) * ORC_MAX_NH * ORC_NVE * ORC_NVE);
+        static __thread double *tls_Hh = NULL;                 /* per-thread scratch, reused (see qp_ipm.c) */
+        if (!tls_Hh) tls_Hh = (double *)malloc(sizeof(double) * ORC_MAX_NH * ORC_NVE * ORC_NVE);
+        double *Hh = tls_Hh;
         orc_stage_constraints(pb, z, p, h, D, Hh);
 
         /* Lagrangian Hessian on the QP's 7 variables (the slack row/column of the model's Hessian is diagonal:
@@ -70,7 +72,6 @@ static void build_qp(const orc_problem *pb, const nlp_state *st, const double *x
                 for (int r = 0; r < nh; r++) acc += st->lam_h[k][r] * Hh[r * E * E + a * E + c];
                 W[a * ORC_NV + c] = acc;
             }
-        free(Hh);
         if (dbg) {
             memcpy(&dbg->W_raw[k * ORC_NV * ORC_NV], W, sizeof W);
             for (int j = 0; j < ORC_NV; j++) dbg->z_in[k * ORC_NV + j] = z[j];
@@ -144,11 +145,18 @@ void orc_solve_debug(const orc_problem *pb, const double *xinit, const double *x
 {
     const int N = pb->N, nh = pb->n_lin + pb->M + pb->n_gauss + pb->n_slk;
     double dslack[ORC_MAX_N + 1];
-    nlp_state *st = (nlp_state *)calloc(1, sizeof(nlp_state));
-    orc_qp *qp = (orc_qp *)calloc(1, sizeof(orc_qp));
-    orc_qp_sol *sol = (orc_qp_sol *)calloc(1, sizeof(orc_qp_sol));
-    int (*row_lo)[ORC_MAX_NH] = calloc(ORC_MAX_N, sizeof *row_lo);
-    int (*row_hi)[ORC_MAX_NH] = calloc(ORC_MAX_N, sizeof *row_hi);
+    /* per-thread workspaces, zeroed per solve (fresh solver state) but allocated once */
+    static __thread nlp_state *tls_st = NULL; static __thread orc_qp *tls_qp = NULL; static __thread orc_qp_sol *tls_sol = NULL;
+    static __thread int (*tls_lo)[ORC_MAX_NH] = NULL; static __thread int (*tls_hi)[ORC_MAX_NH] = NULL;
+    if (!tls_st) {
+        tls_st = (nlp_state *)malloc(sizeof(nlp_state)); tls_qp = (orc_qp *)malloc(sizeof(orc_qp));
+        tls_sol = (orc_qp_sol *)malloc(sizeof(orc_qp_sol));
+        tls_lo = malloc(ORC_MAX_N * sizeof *tls_lo); tls_hi = malloc(ORC_MAX_N * sizeof *tls_hi);
+    }
+    nlp_state *st = tls_st; orc_qp *qp = tls_qp; orc_qp_sol *sol = tls_sol;
+    int (*row_lo)[ORC_MAX_NH] = tls_lo; int (*row_hi)[ORC_MAX_NH] = tls_hi;
+    memset(st, 0, sizeof *st); memset(qp, 0, sizeof *qp); memset(sol, 0, sizeof *sol);
+    memset(row_lo, 0, ORC_MAX_N * sizeof *row_lo); memset(row_hi, 0, ORC_MAX_N * sizeof *row_hi);
 
     /* loadWarmstart (:274-284): x_k = x0[nvar*k + nu ..], u_k = x0[nvar*k ..], k<N; x_N */
     for (int k = 0; k <= N; k++)
@@ -204,7 +212,6 @@ void orc_solve_debug(const orc_problem *pb, const double *xinit, const double *x
     /* map to Forces codes (:197-201): 0 -> 1, 1 -> 0 */
     int exit_code = status == 0 ? 1 : (status == 1 ? 0 : status);
     info->pobj = pobj; info->res_eq = res_eq; info->exit_code = exit_code;
-    free(st); free(qp); free(sol); free(row_lo); free(row_hi);
 }
 
 void orc_solve(const orc_problem *pb, const double *xinit, const double *x0, const double *params,
