@@ -179,7 +179,9 @@ int tmpc_scenario_halfspaces(tmpc_handle *h, const void *d_samples, int32_t n_pt
  *             (acados_solver_interface.cpp:344-364); 2 initializeWarmstart(state, false) (:365-375);
  *             3 Solver::initializeWithBraking(state) (:303-342) with |deceleration| (CONFIG deceleration_at_infeasible)
  *   d_src   : i32 [B] or NULL (= identity): trajectory whose previous solution is shifted into b.
- * Mode 1 writes 0 into the inputs of node 0, where the reference reads State::get(<input>) out of bounds (state.cpp:21-24). */
+ * Mode 1 writes 0 into the inputs of node 0, where the reference reads State::get(<input>) out of bounds (state.cpp:21-24).
+ * The warm start / xinit buffers of the current batch are rewritten in place: the handle's own copies after tmpc_set_batch,
+ * the caller's device buffers after tmpc_set_batch_device (they must be writable). */
 int tmpc_warmstart(tmpc_handle *h, const void *d_state, const void *d_mode, const void *d_src, double deceleration);
 /* GuidanceConstraints::initializeSolverWithGuidance (guidance_constraints.cpp:390-414) for every enabled trajectory:
  * d_gpos, d_gvel f64 [B][N+1][2] (guidance position / velocity at t = k dt), d_enabled u8 [B] or NULL. */
