@@ -23,6 +23,10 @@ from sympy.printing.c import C99CodePrinter
 from . import plugin
 from .jets import JetEmitter, _lit
 
+class UnsupportedStack(ValueError):
+    """The module stack / model asks for something the solve kernels do not implement (message says what)."""
+
+
 class logistic(sp.Function):
     """1 / (1 + exp(-x)) as an atomic function: its derivatives are polynomials in itself, so the emitted gradient and
     Hessian never form exp(u)^k / (1 + exp(u))^m quotients that overflow for the glue sigmoids of spline.py:37
@@ -132,22 +136,27 @@ def generate(modules, model, settings, name="generated", method="symbolic"):
     npar = params.length()
     nvar = model.get_nvar()
     slack_model = "slack" in model.states
-    assert model.inputs + model.states[:5] == CORE, "the kernels integrate the contouring unicycle (solver_model.py:193-214)"
+    if model.inputs + model.states[:5] != CORE:
+        raise UnsupportedStack("the kernels integrate the contouring unicycle (solver_model.py:193-214); got "
+                               f"inputs {model.inputs}, states {model.states}")
     z = [sp.Symbol(f"Z_{i}_", real=True) for i in range(7)]
     slack = sp.Symbol("slack", real=True)
     zfull = z + ([slack] if slack_model else [])
-    assert len(zfull) == nvar
+    if len(zfull) != nvar:
+        raise UnsupportedStack(f"model has {nvar} variables; the kernels support the unicycle (7) and its slack variant (8)")
     p = [sp.Symbol(f"P_{i}_", real=True) for i in range(npar)]
 
     cost = _stabilise(plugin.objective(modules, np.array(zfull, dtype=object), p, model, settings, 1))
     hs = [_stabilise(h) for h in plugin.constraints(modules, np.array(zfull, dtype=object), p, model, settings, 1)]
     lb, ub = plugin.constraint_bounds(modules)
-    assert len(hs) == len(lb) == len(ub)
+    if not len(hs) == len(lb) == len(ub):
+        raise UnsupportedStack(f"{len(hs)} constraint rows but {len(lb)} lower / {len(ub)} upper bounds")
 
     # ---- cost: value, gradient, packed Hessian ------------------------------------------------------------------
     if slack_model:
         for v in z:
-            assert sp.simplify(sp.diff(cost, v, slack)) == 0, "cost couples the slack with another variable: not supported (DESIGN.md U9)"
+            if sp.simplify(sp.diff(cost, v, slack)) != 0:
+                raise UnsupportedStack("cost couples the slack with another variable: not supported (DESIGN.md U9)")
     if method == "jets":
         em = JetEmitter(z, _c, "c")
         j = em.jet(cost)
@@ -169,12 +178,14 @@ def generate(modules, model, settings, name="generated", method="symbolic"):
             rows.append((r, "upper", h - ub[r]))
         if has_lo:
             rows.append((r, "lower", lb[r] - h))
-        assert has_lo or has_up, f"row {r} is unbounded on both sides"
+        if not (has_lo or has_up):
+            raise UnsupportedStack(f"row {r} is unbounded on both sides")
     row_lines = []
     for k, (r, kind, gexpr) in enumerate(rows):
         for i, v in enumerate(z):
             if i not in ROW_VARS:
-                assert sp.diff(gexpr, v) == 0, f"constraint row {r} depends on `{CORE[i]}`: only x, y, psi (and slack) are supported"
+                if sp.diff(gexpr, v) != 0:
+                    raise UnsupportedStack(f"constraint row {r} depends on `{CORE[i]}`: only x, y, psi (and slack) are supported")
         if method == "jets":
             em = JetEmitter([z[i] for i in ROW_VARS], _c, "r")
             j = em.jet(gexpr)

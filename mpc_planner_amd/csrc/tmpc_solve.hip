@@ -1306,6 +1306,19 @@ struct tmpc_handle {
         }                                                                                           \
     } while (0)
 
+namespace {
+// Scratch device buffers / events of the diagnostic entry points: released on every return path.
+struct DevBufs {
+    std::vector<void *> p;
+    ~DevBufs() { for (void *q : p) if (q) (void)hipFree(q); }
+    hipError_t alloc(double **out, size_t bytes) { hipError_t e = hipMalloc(out, bytes ? bytes : 8); if (e == hipSuccess) p.push_back(*out); return e; }
+};
+struct Events {
+    std::vector<hipEvent_t> ev;
+    ~Events() { for (auto &e : ev) if (e) (void)hipEventDestroy(e); }
+};
+}  // namespace
+
 extern "C" {
 
 void tmpc_default_dims(tmpc_dims *d, int32_t N, int32_t S, int32_t n_lin, int32_t M) { tmpc_default_dims_ex(d, N, S, n_lin, M, 0, 0); }
@@ -1327,8 +1340,6 @@ void tmpc_default_dims_ex(tmpc_dims *d, int32_t N, int32_t S, int32_t n_lin, int
     const double ub[TMPC_NV] = {2.0, 0.8, 2000.0, 2000.0, M_PI * 4, 3.0, 10000.0};
     for (int i = 0; i < TMPC_NV; i++) { d->lb[i] = lb[i]; d->ub[i] = ub[i]; }
 }
-
-static thread_local std::string g_create_err;
 
 int tmpc_create(tmpc_handle **out, const tmpc_dims *dims, int32_t B_max, int32_t device)
 {
@@ -1614,7 +1625,8 @@ int tmpc_time_solve(tmpc_handle *h, int32_t reps, float *ms_each)
 {
     if (!h || reps <= 0 || !ms_each) return TMPC_ERR_INVALID;
     TMPC_HIP_CHECK(h, hipSetDevice(h->device));
-    std::vector<hipEvent_t> ev(2 * (size_t)reps);
+    Events evs; evs.ev.assign(2 * (size_t)reps, nullptr);
+    std::vector<hipEvent_t> &ev = evs.ev;
     for (auto &e : ev) TMPC_HIP_CHECK(h, hipEventCreate(&e));
     for (int i = 0; i < reps; i++) {
         TMPC_HIP_CHECK(h, hipEventRecord(ev[2 * i], h->stream));
@@ -1624,7 +1636,6 @@ int tmpc_time_solve(tmpc_handle *h, int32_t reps, float *ms_each)
     }
     TMPC_HIP_CHECK(h, hipStreamSynchronize(h->stream));
     for (int i = 0; i < reps; i++) TMPC_HIP_CHECK(h, hipEventElapsedTime(&ms_each[i], ev[2 * i], ev[2 * i + 1]));
-    for (auto &e : ev) (void)hipEventDestroy(e);
     return TMPC_OK;
 }
 
@@ -1641,9 +1652,11 @@ int tmpc_debug_profile(tmpc_handle *h, int64_t *cycles, int32_t n_phases)
 {
     if (!h || h->B <= 0 || !cycles || n_phases < tmpc::PH_COUNT) return TMPC_ERR_INVALID;
     TMPC_HIP_CHECK(h, hipSetDevice(h->device));
-    long long *dp = nullptr;
+    DevBufs bufs;
+    double *dp_ = nullptr;
     const size_t n = (size_t)h->B * tmpc::PH_COUNT;
-    TMPC_HIP_CHECK(h, hipMalloc(&dp, n * 8));
+    TMPC_HIP_CHECK(h, bufs.alloc(&dp_, n * 8));
+    long long *dp = (long long *)dp_;
     TMPC_HIP_CHECK(h, hipMemset(dp, 0, n * 8));
     tmpc::SolveKernel pk = h->kernel;                   // the generic kernel profiles itself; fast shapes have an instrumented twin
     if (h->fast) {
@@ -1658,7 +1671,6 @@ int tmpc_debug_profile(tmpc_handle *h, int64_t *cycles, int32_t n_phases)
     TMPC_HIP_CHECK(h, hipStreamSynchronize(h->stream));
     std::vector<long long> host(n);
     TMPC_HIP_CHECK(h, hipMemcpy(host.data(), dp, n * 8, hipMemcpyDeviceToHost));
-    (void)hipFree(dp);
     for (int i = 0; i < tmpc::PH_COUNT; i++) {
         double acc = 0.0;
         for (int b = 0; b < h->B; b++) acc += (double)host[(size_t)b * tmpc::PH_COUNT + i];
@@ -1676,25 +1688,23 @@ int tmpc_debug_eval_stage(tmpc_handle *h, int32_t n, const double *z, const doub
     const int nh = h->d.n_up + h->d.M;
     const size_t sz_in[4] = {(size_t)n * tmpc::ext_nv(h->d) * 8, (size_t)n * h->d.npar * 8, (size_t)n * 5 * 8, (size_t)n * nh * 8};
     const void *src[4] = {z, p, pi, lamh};
+    DevBufs bufs;
     double *din[4] = {nullptr, nullptr, nullptr, nullptr};
     for (int i = 0; i < 4; i++) {
         if (!src[i]) continue;
-        TMPC_HIP_CHECK(h, hipMalloc(&din[i], sz_in[i]));
+        TMPC_HIP_CHECK(h, bufs.alloc(&din[i], sz_in[i]));
         TMPC_HIP_CHECK(h, hipMemcpy(din[i], src[i], sz_in[i], hipMemcpyHostToDevice));
     }
     const size_t sz_out[9] = {(size_t)n * 8, (size_t)n * 7 * 8, (size_t)n * 49 * 8, (size_t)n * nh * 8, (size_t)n * nh * 7 * 8,
                               (size_t)n * 5 * 8, (size_t)n * 35 * 8, (size_t)n * 49 * 8, (size_t)n * 49 * 8};
     double *dout[9]; void *dst[9] = {cost, cost_grad, cost_hess, hval, h_jac, x_next, x_jac, lag_hess, mirror};
-    for (int i = 0; i < 9; i++) TMPC_HIP_CHECK(h, hipMalloc(&dout[i], sz_out[i] ? sz_out[i] : 8));
+    for (int i = 0; i < 9; i++) TMPC_HIP_CHECK(h, bufs.alloc(&dout[i], sz_out[i]));
     hipLaunchKernelGGL(tmpc::tmpc_debug_eval_kernel, dim3((n + 63) / 64), dim3(64), 0, h->stream, h->d, n, din[0], din[1], din[2], din[3],
                        dout[0], dout[1], dout[2], dout[3], dout[4], dout[5], dout[6], dout[7], dout[8]);
     TMPC_HIP_CHECK(h, hipGetLastError());
     TMPC_HIP_CHECK(h, hipStreamSynchronize(h->stream));
-    for (int i = 0; i < 9; i++) {
+    for (int i = 0; i < 9; i++)
         if (dst[i]) TMPC_HIP_CHECK(h, hipMemcpy(dst[i], dout[i], sz_out[i], hipMemcpyDeviceToHost));
-        (void)hipFree(dout[i]);
-    }
-    for (int i = 0; i < 4; i++) if (din[i]) (void)hipFree(din[i]);
     return TMPC_OK;
 }
 

@@ -69,22 +69,38 @@ def gaussian_set_parameters(pm, params, state_xy, obstacles, robot_radius, risk,
         params[1:, ix[5]] = obstacles["radius"][j]
 
 
+def project_to_safety(pos, obstacles_k, r):
+    """Stand-in for LinearizedConstraints::projectToSafety (linearized_constraints.cpp:130-148: at most 3 sweeps of
+    ros_tools' Douglas-Rachford projection over the obstacles; the ros_tools source is absent -- DESIGN.md [UPSTREAM]):
+    a guess closer than r to an obstacle is moved radially to 1.001 r from it.  The identity whenever the guess is
+    already clear of every obstacle, which is the only case the parity claims rest on.  Same arithmetic as
+    tmpc_linearize_topology_kernel (csrc/tmpc_solve.hip)."""
+    px, py = float(pos[0]), float(pos[1])
+    for _ in range(3):
+        for o in obstacles_k:
+            dx, dy = px - o[0], py - o[1]
+            dist = np.sqrt(dx * dx + dy * dy)
+            if dist < r:
+                if dist > 1e-12:
+                    s = r * 1.001 / dist
+                    px, py = o[0] + dx * s, o[1] + dy * s
+                else:
+                    px, py = o[0], o[1] + r * 1.001
+    return np.array([px, py])
+
+
 def linearized_update(x0, obstacle_pos, robot_radius):
     """LinearizedConstraints::update in guidance mode (linearized_constraints.cpp:49-105).
-    x0: warm start [N+1][nvar]; obstacle_pos [M][N][2].  Returns a1,a2,b [N][M] (row k=0 unused).
-    The Douglas-Rachford projection (projectToSafety :130-148, ros_tools source absent) is the identity
-    whenever the guess is already >= r+robot_radius away from every obstacle; synthetic scenes guarantee
-    that, and this mirror asserts it."""
+    x0: warm start [N+1][nvar]; obstacle_pos [M][N][2].  Returns a1,a2,b [N][M] (row k=0 unused)."""
     Np1 = x0.shape[0]; N = Np1 - 1; M = obstacle_pos.shape[0]
     a1 = np.zeros((N, M)); a2 = np.zeros((N, M)); b = np.zeros((N, M))
     radius = 1e-3                                             # _use_guidance (:99)
     for k in range(1, N):
-        pos = x0[k, [IDX["x"], IDX["y"]]]
+        pos = project_to_safety(x0[k, [IDX["x"], IDX["y"]]], obstacle_pos[:, k - 1], radius + robot_radius)
         for j in range(M):
             o = obstacle_pos[j, k - 1]
             diff = o - pos
             dist = np.sqrt(diff[0] * diff[0] + diff[1] * diff[1])
-            assert dist >= radius + robot_radius, "guess inside the projection radius: DR projection not restated"
             a1[k, j] = diff[0] / dist
             a2[k, j] = diff[1] / dist
             b[k, j] = a1[k, j] * o[0] + a2[k, j] * o[1] - (radius + robot_radius)

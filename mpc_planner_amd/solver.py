@@ -42,9 +42,6 @@ EXPORTS = ["tmpc_default_dims", "tmpc_default_dims_ex", "tmpc_create", "tmpc_des
            "tmpc_linearize_topology", "tmpc_scenario_halfspaces", "tmpc_warmstart", "tmpc_init_with_guidance",
            "tmpc_debug_get_x0", "tmpc_debug_get_params"]
 
-_lib = None
-
-
 class TmpcError(RuntimeError):
     pass
 
@@ -55,47 +52,43 @@ _libs = {}
 def load_library(path=None):
     """Load libtmpc_hip.so -- or a generated per-configuration library with the same C-ABI (mpc_planner_amd/codegen) --;
     raises (never falls back) if it has not been built."""
-    global _lib
     path = os.path.abspath(path) if path else LIB_PATH
     if path in _libs:
         return _libs[path]
-    if True:
-        if not os.path.exists(path):
-            raise TmpcError(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-                            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
-        lib = C.CDLL(path)
-        lib.tmpc_last_error.restype = C.c_char_p
-        lib.tmpc_last_error.argtypes = [C.c_void_p]
-        lib.tmpc_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(TmpcDims), C.c_int32, C.c_int32]
-        lib.tmpc_destroy.argtypes = [C.c_void_p]
-        lib.tmpc_default_dims.argtypes = [C.POINTER(TmpcDims), C.c_int32, C.c_int32, C.c_int32, C.c_int32]
-        lib.tmpc_default_dims_ex.argtypes = [C.POINTER(TmpcDims)] + [C.c_int32] * 6
-        vp = C.c_void_p
-        lib.tmpc_set_batch.argtypes = [vp, C.c_int32, vp, vp, vp]
-        lib.tmpc_set_batch_device.argtypes = [vp, C.c_int32, vp, vp, vp]
-        lib.tmpc_solve.argtypes = [vp]
-        lib.tmpc_set_latency_mode.argtypes = [vp, C.c_int32]
-        lib.tmpc_synchronize.argtypes = [vp]
-        lib.tmpc_get.argtypes = [vp] + [vp] * 8
-        lib.tmpc_select_best.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, C.POINTER(C.c_int32)]
-        lib.tmpc_result_device_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
-        lib.tmpc_time_solve.argtypes = [vp, C.c_int32, vp]
-        lib.tmpc_debug_eval_stage.argtypes = [vp, C.c_int32] + [vp] * 13
-        lib.tmpc_pack_records.argtypes = [vp, vp, vp, vp]
-        lib.tmpc_select_best_records.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int32, vp]
-        lib.tmpc_enable_timing.argtypes = [vp, C.c_int32]
-        lib.tmpc_get_timings.argtypes = [vp, vp, C.c_int32, C.POINTER(C.c_int32)]
-        lib.tmpc_debug_profile.argtypes = [vp, vp, C.c_int32]
-        lib.tmpc_linearize_topology.argtypes = [vp, vp, vp, vp, C.c_double, vp]
-        lib.tmpc_warmstart.argtypes = [vp, vp, vp, vp, C.c_double]
-        lib.tmpc_init_with_guidance.argtypes = [vp, vp, vp, vp]
-        lib.tmpc_debug_get_x0.argtypes = [vp, vp, vp]
-        lib.tmpc_scenario_halfspaces.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, vp, C.c_double, C.c_double]
-        lib.tmpc_debug_get_params.argtypes = [vp, vp]
-        _libs[path] = lib
-        if path == LIB_PATH:
-            _lib = lib
-    return _libs[path]
+    if not os.path.exists(path):
+        raise TmpcError(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(path)
+    lib.tmpc_last_error.restype = C.c_char_p
+    lib.tmpc_last_error.argtypes = [C.c_void_p]
+    lib.tmpc_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(TmpcDims), C.c_int32, C.c_int32]
+    lib.tmpc_destroy.argtypes = [C.c_void_p]
+    lib.tmpc_default_dims.argtypes = [C.POINTER(TmpcDims), C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+    lib.tmpc_default_dims_ex.argtypes = [C.POINTER(TmpcDims)] + [C.c_int32] * 6
+    vp = C.c_void_p
+    lib.tmpc_set_batch.argtypes = [vp, C.c_int32, vp, vp, vp]
+    lib.tmpc_set_batch_device.argtypes = [vp, C.c_int32, vp, vp, vp]
+    lib.tmpc_solve.argtypes = [vp]
+    lib.tmpc_set_latency_mode.argtypes = [vp, C.c_int32]
+    lib.tmpc_synchronize.argtypes = [vp]
+    lib.tmpc_get.argtypes = [vp] + [vp] * 8
+    lib.tmpc_select_best.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, C.POINTER(C.c_int32)]
+    lib.tmpc_result_device_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
+    lib.tmpc_time_solve.argtypes = [vp, C.c_int32, vp]
+    lib.tmpc_debug_eval_stage.argtypes = [vp, C.c_int32] + [vp] * 13
+    lib.tmpc_pack_records.argtypes = [vp, vp, vp, vp]
+    lib.tmpc_select_best_records.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int32, vp]
+    lib.tmpc_enable_timing.argtypes = [vp, C.c_int32]
+    lib.tmpc_get_timings.argtypes = [vp, vp, C.c_int32, C.POINTER(C.c_int32)]
+    lib.tmpc_debug_profile.argtypes = [vp, vp, C.c_int32]
+    lib.tmpc_linearize_topology.argtypes = [vp, vp, vp, vp, C.c_double, vp]
+    lib.tmpc_warmstart.argtypes = [vp, vp, vp, vp, C.c_double]
+    lib.tmpc_init_with_guidance.argtypes = [vp, vp, vp, vp]
+    lib.tmpc_debug_get_x0.argtypes = [vp, vp, vp]
+    lib.tmpc_scenario_halfspaces.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, vp, C.c_double, C.c_double]
+    lib.tmpc_debug_get_params.argtypes = [vp, vp]
+    _libs[path] = lib
+    return lib
 
 
 def default_dims(N=20, S=5, n_lin=8, M=8, n_slk=0, slack=0, lib_path=None, **opts):
@@ -147,8 +140,10 @@ class BatchedSolver:
         xinit = np.ascontiguousarray(xinit, np.float64); x0 = np.ascontiguousarray(x0, np.float64)
         params = np.ascontiguousarray(params, np.float64)
         B = xinit.shape[0]
-        assert xinit.shape == (B, self.dims.nx) and x0.size == B * (self.N + 1) * self.dims.nvar \
-            and params.size == B * self.N * self.npar
+        if xinit.shape != (B, self.dims.nx) or x0.size != B * (self.N + 1) * self.dims.nvar \
+                or params.size != B * self.N * self.npar:
+            raise ValueError(f"set_batch: expected xinit [{B}][{self.dims.nx}], x0 [{B}][{self.N + 1}][{self.dims.nvar}], "
+                             f"params [{B}][{self.N}][{self.npar}]; got {xinit.shape}, {x0.shape}, {params.shape}")
         self._keep = (xinit, x0, params)
         self._check(self.lib.tmpc_set_batch(self._h, B, _p(xinit), _p(x0), _p(params)), "tmpc_set_batch")
         self.B = B

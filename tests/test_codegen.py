@@ -145,5 +145,5 @@ def test_generator_refuses_rows_outside_the_kernel_structure():
             super().__init__(); self.constraints.append(VelocityRow())
     st = stacks.settings()
     mm = P.ModuleManager(); mm.add_module(L.GoalModule(st)); mm.add_module(M())
-    with pytest.raises(AssertionError, match="depends on `v`"):
+    with pytest.raises(emit.UnsupportedStack, match="depends on `v`"):
         emit.generate(mm, P.UnicycleContouringModel(), st, "bad")

@@ -209,16 +209,11 @@ def test_device_linearize_topology_matches_host_mirror():
     is_orig = np.concatenate([(np.arange(len(s["xinit"])) == len(s["xinit"]) - 1).astype(np.uint8) for s in scs])
     obst = np.stack([s["obstacles"]["pos"] for s in scs])                       # [3][8][20][2]
     state_x = np.array([s["xinit"][0, 0] for s in scs])
-    # put one guess inside an obstacle's projection disc: the host mirror gets the same radial projection first
+    # put one guess inside an obstacle's projection disc
     x0[5, 7, 2:4] = obst[0, 3, 6] + np.array([0.05, 0.02])
     pm = scs[0]["pm"]
     ref = want.copy()
-    g = x0[5].copy(); r = 1e-3 + 0.325
-    for _ in range(3):
-        for j in range(8):
-            o = obst[0, j, 6]; dv = g[7, 2:4] - o; dist = np.sqrt(dv[0] * dv[0] + dv[1] * dv[1])
-            if dist < r: g[7, 2:4] = o + dv * (r * 1.001 / dist)
-    lin = md.linearized_update(g, obst[0], 0.325)
+    lin = md.linearized_update(x0[5], obst[0], 0.325)              # applies the same radial projection (project_to_safety)
     md.linearized_set_parameters(pm, ref[5], state_x[0], lin, n_rows=8)
     start = want.copy()
     for j in range(8):                                                          # wipe the lin rows: the device must rebuild them

@@ -47,3 +47,25 @@ def test_initialize_with_braking_stops_and_stays():
     stopped = np.nonzero(x0[:, 5] == 0.0)[0][0]
     assert np.all(x0[stopped + 1:, 2] == x0[stopped + 1, 2])            # no motion after standstill
     assert abs((x0[1, 2] - 1.0) - 1.2 * 0.2 * np.cos(0.5)) < 1e-15 and abs((x0[1, 6] - 3.0) - 0.24) < 1e-15
+
+
+def test_project_to_safety_is_identity_when_clear_and_pushes_out_otherwise():
+    """The stand-in of projectToSafety (linearized_constraints.cpp:130-148): untouched when the guess is clear of every
+    obstacle, moved radially to just outside the disc otherwise, and the halfspace rows built from it stay finite."""
+    rng = np.random.default_rng(3)
+    obst = rng.uniform(-3.0, 3.0, (8, 2))
+    r = 1e-3 + 0.325
+    far = np.array([10.0, -7.0])
+    assert (md.project_to_safety(far, obst, r) == far).all()                    # bit-identical: no arithmetic applied
+    inside = obst[3] + np.array([0.05, 0.02])
+    out = md.project_to_safety(inside, obst[3:4], r)
+    assert np.hypot(*(out - obst[3])) >= r
+    np.testing.assert_allclose((out - obst[3]) / np.hypot(*(out - obst[3])), np.array([0.05, 0.02]) / np.hypot(0.05, 0.02), atol=1e-12)
+    centre = md.project_to_safety(obst[5], obst[5:6], r)                        # degenerate: exactly on the obstacle centre
+    assert np.isfinite(centre).all() and np.hypot(*(centre - obst[5])) >= r
+    # linearized_update on a guess inside a disc: unit normals, no NaN
+    x0 = np.zeros((5, 7)); x0[:, 2:4] = far; x0[2, 2:4] = inside
+    pos = np.repeat(obst[:, None, :], 4, axis=1)
+    a1, a2, b = md.linearized_update(x0, pos, 0.325)
+    assert np.isfinite(a1).all() and np.isfinite(a2).all() and np.isfinite(b).all()
+    np.testing.assert_allclose(a1[1:] ** 2 + a2[1:] ** 2, 1.0, atol=1e-12)
