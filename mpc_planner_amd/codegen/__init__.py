@@ -13,4 +13,5 @@ over `solver_generator/control_modules.py`) and lets CasADi + acados generate C 
   emit.py       exact first / second derivatives, common-subexpression elimination and emission of the HIP stage
                 functions (`tmpc_gen::cost`, `tmpc_gen::rows`) that `csrc/tmpc_stage.hpp` compiles into the solve kernel
   build.py      hipcc build of a per-configuration `libtmpc_hip_<name>.so` with the same C-ABI
+  cpp_glue.py   modules.h / definitions.h / modules.cmake for the reference's C++ module classes (generate_cpp_files.py:11-95)
 """

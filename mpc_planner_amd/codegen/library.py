@@ -35,8 +35,13 @@ class MPCBaseModule(ObjectiveModule):
 
     def __init__(self, settings=None):
         super().__init__()
-        self.module_name = "MPCBaseModule"
+        self.module_name, self.import_name = "MPCBaseModule", "mpc_base.h"
         self.objectives.append(_Weights())
+
+    def add_definitions(self, header_file):
+        """mpc_base.py:83-92: the weight names the C++ module reads from CONFIG["weights"]."""
+        names = [n for _, ns, _ in self.objectives[0]._terms for n in ns]
+        header_file.write("#define WEIGHT_PARAMS {" + ", ".join(f'"{n}"' for n in names) + "}\n")
 
     def weigh_variable(self, var_name, weight_names, cost_function=lambda x, w: w[0] * x ** 2, **_):
         names = [weight_names] if isinstance(weight_names, str) else list(weight_names)
@@ -109,7 +114,7 @@ class ContouringModule(ObjectiveModule):
 
     def __init__(self, settings):
         super().__init__()
-        self.module_name = "Contouring"
+        self.module_name, self.import_name = "Contouring", "contouring.h"
         self.objectives.append(_Contouring(settings["contouring"]["num_segments"]))
 
 
@@ -128,7 +133,7 @@ class GoalModule(ObjectiveModule):
 
     def __init__(self, settings=None):
         super().__init__()
-        self.module_name = "GoalModule"
+        self.module_name, self.import_name = "GoalModule", "goal_module.h"
         self.objectives.append(_Goal())
 
 
@@ -178,7 +183,7 @@ class EllipsoidConstraintModule(ConstraintModule):
 
     def __init__(self, settings):
         super().__init__()
-        self.module_name = "EllipsoidConstraints"
+        self.module_name, self.import_name = "EllipsoidConstraints", "ellipsoid_constraints.h"
         self.constraints.append(_Ellipsoids(settings["n_discs"], settings["max_obstacles"]))
 
 
@@ -216,16 +221,26 @@ class GuidanceConstraintModule(ConstraintModule):
 
     def __init__(self, settings, constraint_submodule=EllipsoidConstraintModule):
         super().__init__()
-        self.module_name = "GuidanceConstraints"
+        self.module_name, self.import_name = "GuidanceConstraints", "guidance_constraints.h"
+        self.dependencies.append("guidance_planner")
         n = settings["max_obstacles"] + settings["linearized_constraints"]["add_halfspaces"]
         self.constraints.append(_Halfspaces([f"lin_constraint_{i}" for i in range(n)], bundle="lin_constraint"))
-        self.constraints += constraint_submodule(settings).constraints
+        self.sources.append("linearized_constraints.h")
+        self.constraint_submodule = constraint_submodule(settings)
+        self.constraints += self.constraint_submodule.constraints
+        self.sources.append(self.constraint_submodule.import_name)
+
+    def add_definitions(self, header_file):
+        """guidance_constraints.py:56-62: which C++ module solves the per-topology problems."""
+        header_file.write(f"#include <mpc_planner_modules/{self.constraint_submodule.import_name}>\n")
+        header_file.write(f"#define GUIDANCE_CONSTRAINTS_TYPE {self.constraint_submodule.module_name}\n")
 
 
 class DecompConstraintModule(ConstraintModule):
     def __init__(self, settings):
         super().__init__()
-        self.module_name = "DecompConstraints"
+        self.module_name, self.import_name = "DecompConstraints", "decomp_constraints.h"
+        self.dependencies.append("decomp_util")
         n = settings["decomp"]["max_constraints"]
         self.constraints.append(_Halfspaces([f"disc_0_decomp_{i}" for i in range(n)], disc=0, use_slack=True, bundle="decomp"))
 
@@ -233,7 +248,8 @@ class DecompConstraintModule(ConstraintModule):
 class ScenarioConstraintModule(ConstraintModule):
     def __init__(self, settings):
         super().__init__()
-        self.module_name = "ScenarioConstraints"
+        self.module_name, self.import_name = "ScenarioConstraints", "scenario_constraints.h"
+        self.dependencies.append("scenario_module")
         self.constraints.append(_Halfspaces([f"disc_0_scenario_constraint_{i}" for i in range(24)], disc=0, use_slack=True))
 
 
@@ -279,5 +295,5 @@ class GaussianConstraintModule(ConstraintModule):
 
     def __init__(self, settings):
         super().__init__()
-        self.module_name = "GaussianConstraints"
+        self.module_name, self.import_name = "GaussianConstraints", "gaussian_constraints.h"
         self.constraints.append(_GaussianChance(settings["n_discs"], settings["max_obstacles"]))

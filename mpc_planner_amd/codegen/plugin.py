@@ -49,9 +49,19 @@ class ModuleManager:
 
 
 class Module:
+    """control_modules.py:39-56.  module_name / import_name name the C++ class and header of the module in
+    mpc_planner_modules (cpp_glue.py writes modules.h / definitions.h / modules.cmake from them)."""
+
     def __init__(self):
         self.module_name = "UNDEFINED"
+        self.import_name = None
         self.description = ""
+        self.submodules = []
+        self.dependencies = []
+        self.sources = []
+
+    def add_definitions(self, header_file):
+        pass
 
 
 class ObjectiveModule(Module):

@@ -147,3 +147,31 @@ def test_generator_refuses_rows_outside_the_kernel_structure():
     mm = P.ModuleManager(); mm.add_module(L.GoalModule(st)); mm.add_module(M())
     with pytest.raises(emit.UnsupportedStack, match="depends on `v`"):
         emit.generate(mm, P.UnicycleContouringModel(), st, "bad")
+
+
+def test_cpp_glue_files_for_the_tmpc_stack(tmp_path):
+    """modules.h / definitions.h / modules.cmake (generate_cpp_files.py:11-95): factory in stack order, the guidance module's
+    extra headers, WEIGHT_PARAMS and GUIDANCE_CONSTRAINTS_TYPE, dependency / source lists without duplicates."""
+    from mpc_planner_amd.codegen import cpp_glue, plugin as P
+    st = stacks.settings()
+    _, mm = stacks.rosnav_tmpc(st)
+    files = cpp_glue.write_module_glue(str(tmp_path), mm)
+    assert [os.path.basename(f) for f in files] == ["definitions.h", "modules.h", "modules.cmake"]
+    mh = open(tmp_path / "include" / "mpc_planner_modules" / "modules.h").read()
+    order = [mh.index(f"std::make_shared<{n}>(solver)") for n in ("MPCBaseModule", "Contouring", "GuidanceConstraints", "DecompConstraints")]
+    assert order == sorted(order)
+    for inc in ("mpc_base.h", "contouring.h", "guidance_constraints.h", "linearized_constraints.h", "ellipsoid_constraints.h", "decomp_constraints.h"):
+        assert f"#include <mpc_planner_modules/{inc}>" in mh
+    assert "inline void initializeModules(std::vector<std::shared_ptr<ControllerModule>> &modules, std::shared_ptr<Solver> solver)" in mh
+    dh = open(tmp_path / "include" / "mpc_planner_modules" / "definitions.h").read()
+    assert '#define WEIGHT_PARAMS {"acceleration", "angular_velocity", "slack", "velocity", "reference_velocity"}' in dh
+    assert "#define GUIDANCE_CONSTRAINTS_TYPE EllipsoidConstraints" in dh
+    cm = open(tmp_path / "modules.cmake").read()
+    assert cm.count("guidance_planner") == 2 and cm.count("decomp_util") == 2          # find_package + dependency list
+    for src in ("mpc_base", "contouring", "guidance_constraints", "linearized_constraints", "ellipsoid_constraints", "decomp_constraints"):
+        assert f"\tsrc/{src}.cpp\n" in cm
+    # a python-only module (no C++ counterpart) is left out of the factory
+    class PyOnly(P.ObjectiveModule):
+        pass
+    mm.add_module(PyOnly())
+    assert "UNDEFINED" not in cpp_glue.modules_header(mm)

@@ -19,7 +19,7 @@ SCRIPT = r'''
 import sys, json
 sys.dont_write_bytecode = True
 sys.path.insert(0, %(root)r)
-from mpc_planner_amd.codegen import symbolic, emit
+from mpc_planner_amd.codegen import symbolic, emit, cpp_glue
 symbolic.install_as_casadi()
 sys.path.insert(0, %(ref)r + "/solver_generator"); sys.path.insert(0, %(ref)r + "/mpc_planner_modules/scripts")
 from control_modules import ModuleManager
@@ -37,7 +37,8 @@ base.weigh_variable(var_name="v", weight_names=["velocity", "reference_velocity"
 modules.add_module(ContouringModule(settings))
 modules.add_module(GuidanceConstraintModule(settings, constraint_submodule=EllipsoidConstraintModule))
 gen = emit.generate(modules, model, settings, "reference_scripts_tmpc", method="jets")
-json.dump(dict(header=gen["header"], pmap=dict(gen["params"]._params), nh=gen["nh"]), open(sys.argv[1], "w"))
+json.dump(dict(header=gen["header"], pmap=dict(gen["params"]._params), nh=gen["nh"], modules_h=cpp_glue.modules_header(modules),
+               definitions_h=cpp_glue.definitions_header(modules), modules_cmake=cpp_glue.modules_cmake(modules)), open(sys.argv[1], "w"))
 '''
 
 
@@ -64,3 +65,10 @@ def test_unmodified_reference_module_scripts_generate_the_same_stage_functions(t
             r, s = hs.row_src[k], hs.row_sign[k]
             np.testing.assert_allclose(h[k], s * (hh[r] - hs.row_bound[k]), rtol=1e-11, atol=1e-11)
             np.testing.assert_allclose(D[k], s * J[r][[2, 3, 4]], rtol=1e-10, atol=1e-11)
+    # the C++ wiring files (modules.h / definitions.h / modules.cmake) written for the reference's own module objects are
+    # identical to those written for this repo's library stack of the same configuration
+    from mpc_planner_amd.codegen import cpp_glue, stacks
+    _, mm = stacks.tmpc(stacks.settings())
+    assert gen["modules_h"] == cpp_glue.modules_header(mm)
+    assert gen["definitions_h"] == cpp_glue.definitions_header(mm)
+    assert gen["modules_cmake"] == cpp_glue.modules_cmake(mm)
