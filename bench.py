@@ -86,7 +86,12 @@ def cpu_baseline(n_scenes):
         dt = time.perf_counter() - t0
         if dt >= 10.0 or passes >= 200:
             break
+    one = []                                                         # single-thread latency of ONE Solver::solve()
+    for i in range(64):
+        sl = slice(i, i + 1)
+        t1 = time.perf_counter(); O.solve_batch(pb, args[1][sl], args[2][sl], args[3][sl], num_threads=1); one.append(time.perf_counter() - t1)
     return {"value": passes * B / dt, "unit": "solves/s", "cores": cores, "kind": "port",
+            "single_thread_solve_ms_p50": float(np.percentile(one, 50) * 1e3),
             "sample": f"{n_scenes} scenes x {TRAJ} trajectories tiled x{reps} = {B} solves of the same workload, {passes} passes in {dt:.2f} s, "
                       f"restated acados-equivalent C oracle (oracle/), OpenMP over trajectories on the {cores} CPUs usable by this "
                       f"process (affinity / cgroup quota; {os.cpu_count()} logical CPUs visible)"}
