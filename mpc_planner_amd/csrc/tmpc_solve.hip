@@ -98,6 +98,16 @@ __device__ __forceinline__ double dpp_move(double x, double identity)
     o.i[1] = __builtin_amdgcn_update_dpp(o.i[1], u.i[1], CTRL, ROW_MASK, 0xf, false);
     return o.d;
 }
+// row shift whose vacated lanes read 0 (bound_ctrl:0): for sums no identity value has to be materialised first
+template <int CTRL>
+__device__ __forceinline__ double dpp_shift_zero(double x)
+{
+    union { double d; int i[2]; } u, o;
+    u.d = x;
+    o.i[0] = __builtin_amdgcn_mov_dpp(u.i[0], CTRL, 0xf, 0xf, true);
+    o.i[1] = __builtin_amdgcn_mov_dpp(u.i[1], CTRL, 0xf, 0xf, true);
+    return o.d;
+}
 template <typename Op>
 __device__ __forceinline__ double wave_reduce(double x, double identity, Op op)
 {
@@ -205,6 +215,20 @@ __device__ __forceinline__ double rsqrt_nr(double d)
     return y;
 }
 
+// ---- optional coarse clock split of the sweeps (tools/profile_sweeps.py builds a separate library with this macro;
+// the product library never defines it) ---------------------------------------------------------------------------
+#ifdef TMPC_SWEEP_PROFILE
+enum { SP_FACTOR_TERM = 0, SP_FACTOR_LOOP, SP_SOLVE_PRE, SP_SOLVE_BWD, SP_SOLVE_FWD, SP_SOLVE_POST, SP_CALLS_FACTOR, SP_CALLS_SOLVE, SP_COUNT };
+__device__ unsigned long long g_sweep_prof[SP_COUNT];
+#define SWEEP_T0() long long sp_t = clock64()
+#define SWEEP_T(i) do { const long long sp_n = clock64(); if (tid == 0) atomicAdd(&g_sweep_prof[i], (unsigned long long)(sp_n - sp_t)); sp_t = sp_n; } while (0)
+#define SWEEP_COUNT(i) do { if (tid == 0) atomicAdd(&g_sweep_prof[i], 1ull); } while (0)
+#else
+#define SWEEP_T0()
+#define SWEEP_T(i)
+#define SWEEP_COUNT(i)
+#endif
+
 // ---- square-root Riccati: factorisation --------------------------------------------------------
 // Lane i (< 7) owns ROW i of the stage matrix F_k = Hh_k + G^T G (G = Lp^T [B A], Lp = trailing 5x5 of the
 // next stage's Cholesky factor) in registers f[0..i].  The 7x7 Cholesky runs entirely in registers: pivots
@@ -250,6 +274,7 @@ __device__ bool riccati_factor(const Lds &L, const Dims &d, int tid, int sw = 0)
 {
     const int N = d.N;
     bool anybad = false;
+    SWEEP_T0(); SWEEP_COUNT(SP_CALLS_FACTOR);
     if (NTH == 64 || (tid >> 6) == sw) {
     const int lane = tid & 63;
     const bool rowl = lane < NV;
@@ -274,6 +299,7 @@ __device__ bool riccati_factor(const Lds &L, const Dims &d, int tid, int sw = 0)
     for (int j = 0; j < NV; j++) f[j] = (j >= NU) ? L.Hh[N * NP28 + pidx(ls, j <= ls ? j : ls)] : 0.0;
     load_stage(N - 1);
     bad |= chol_rows<NU>(f, lane, nullptr, nullptr);
+    SWEEP_T(SP_FACTOR_TERM);
     for (int k = N - 1; k >= 0; k--) {
         // broadcast Lp (lower 5x5 of the factor of stage k+1) to every lane
         double Lp[NX][NX];
@@ -346,6 +372,7 @@ __device__ bool riccati_factor(const Lds &L, const Dims &d, int tid, int sw = 0)
     if (NTH > 64 && lane == 0) L.scr[63] = anybad ? 1.0 : 0.0;
     }
     __syncthreads();
+    SWEEP_T(SP_FACTOR_LOOP);
     if (NTH > 64) anybad = L.scr[63] != 0.0;
     return anybad;
 }
@@ -363,6 +390,7 @@ __device__ void riccati_solve(const Lds &L, const Dims &d, int tid, int sw = 1)
     const bool rowl = lane < NV, xl = rowl && lane >= NU;
     const int ls = rowl ? lane : 0;
     const int i5 = xl ? lane - NU : 0;
+    SWEEP_T0(); SWEEP_COUNT(SP_CALLS_SOLVE);
     // q_k = P_{k+1} rb_k = Lxx (Lxx^T rb_k) for all stages at once (off the sequential chain); parked in dpi[k+1].
     // One lane per stage, fully unrolled (30 FMAs for the 5 components).
     for (int k = tid; k < N; k += NTH) {
@@ -389,72 +417,97 @@ __device__ void riccati_solve(const Lds &L, const Dims &d, int tid, int sw = 1)
         }
     }
     __syncthreads();
+    SWEEP_T(SP_SOLVE_PRE);
     if (sweeper) {
     double p = L.gh[N * NV + ls];                       // p_N (lanes 2..6 meaningful)
     if (xl) L.pr[N * NX + i5] = p;
     {
-        double ghj, ba[NX], r0, l10, r1, lx0, lx1, q;
-        auto load_stage = [&](int k) {
+        // Two operand sets, filled alternately two stages ahead: a set is (re)loaded right after the stage that used it, so
+        // its LDS latency passes underneath the other set's stage (with a single set the loads were issued at the end of
+        // stage k and awaited at the top of stage k-1: ~120 exposed cycles per stage).
+        struct Ops { double ghj, ba[NX], r0, l10, r1, lx0, lx1, q; };
+        auto load_stage = [&](Ops &o, int k) {
             const double *Fb = L.Hh + k * NP28;
             const double *BA = L.BA + k * NX * NV;
-            ghj = L.gh[k * NV + ls];
+            o.ghj = L.gh[k * NV + ls];
 #pragma unroll
-            for (int l = 0; l < NX; l++) ba[l] = BA[l * NV + ls];
-            r0 = Fb[FB_R0]; l10 = Fb[FB_L10]; r1 = Fb[FB_R1];
-            lx0 = Fb[FB_LXU + 2 * i5]; lx1 = Fb[FB_LXU + 2 * i5 + 1];
-            q = L.dpi[(k + 1) * NX + i5];
+            for (int l = 0; l < NX; l++) o.ba[l] = BA[l * NV + ls];
+            o.r0 = Fb[FB_R0]; o.l10 = Fb[FB_L10]; o.r1 = Fb[FB_R1];
+            o.lx0 = Fb[FB_LXU + 2 * i5]; o.lx1 = Fb[FB_LXU + 2 * i5 + 1];
+            o.q = L.dpi[(k + 1) * NX + i5];
         };
-        load_stage(N - 1);
-        for (int k = N - 1; k >= 0; k--) {
-            const double Pb = p + q;                                       // (P_{k+1} rb_k + p_{k+1}), lane 2+i
-            double fj = ghj;
+        auto stage = [&](const Ops &o, int k) {
+            const double Pb = p + o.q;                                     // (P_{k+1} rb_k + p_{k+1}), lane 2+i
+            double fj = o.ghj;
 #pragma unroll
-            for (int l = 0; l < NX; l++) fj += ba[l] * readlane_d(Pb, NU + l);
-            const double y0 = readlane_d(fj, 0) * r0;
-            const double y1 = (readlane_d(fj, 1) - l10 * y0) * r1;
-            p = fj - lx0 * y0 - lx1 * y1;
+            for (int l = 0; l < NX; l++) fj += o.ba[l] * readlane_d(Pb, NU + l);
+            const double y0 = readlane_d(fj, 0) * o.r0;
+            const double y1 = (readlane_d(fj, 1) - o.l10 * y0) * o.r1;
+            p = fj - o.lx0 * y0 - o.lx1 * y1;
             if (lane == 0) { L.y[k * NU] = y0; L.y[k * NU + 1] = y1; }
             if (xl) L.pr[k * NX + i5] = p;
-            if (k > 0) load_stage(k - 1);
+        };
+        Ops oa, ob;
+        load_stage(oa, N - 1);
+        int k = N - 1;
+        for (; k >= 1; k -= 2) {
+            load_stage(ob, k - 1);
+            stage(oa, k);
+            load_stage(oa, k >= 2 ? k - 2 : 0);                           // unconditional (clamped): a branch here makes the
+                                                                          // compiler wait for ALL outstanding LDS loads at the join
+            stage(ob, k - 1);
         }
+        if (k == 0) stage(oa, 0);
     }
     }
     __syncthreads();
+    SWEEP_T(SP_SOLVE_BWD);
     // forward sweep; dx_0 = 0 (dx lives in lanes 2..6).  dx+ = A dx + B du + rb with A = I + E (E: columns psi, v).
     if (sweeper) {
         double dx = 0.0;
-        double lx0, lx1, y0, y1, r0, l10, r1, e_psi, e_v, b_a, b_w, rbi;
-        auto load_stage = [&](int k) {
+        struct Ops { double lx0, lx1, y0, y1, r0, l10, r1, a_psi, a_v, b_a, b_w, rbi; };
+        const double i_psi = lane == ZPSI ? 1.0 : 0.0, i_v = lane == ZV ? 1.0 : 0.0;
+        double *dv_own = L.dv + (rowl ? lane : 0);
+        auto load_stage = [&](Ops &o, int k) {
             const double *Fb = L.Hh + k * NP28;
             const double *BAr = L.BA + k * NX * NV + i5 * NV;              // own row of [B A]
-            lx0 = Fb[FB_LXU + 2 * i5]; lx1 = Fb[FB_LXU + 2 * i5 + 1];
-            y0 = L.y[k * NU]; y1 = L.y[k * NU + 1];
-            r0 = Fb[FB_R0]; l10 = Fb[FB_L10]; r1 = Fb[FB_R1];
-            e_psi = BAr[ZPSI] - (lane == ZPSI ? 1.0 : 0.0);
-            e_v = BAr[ZV] - (lane == ZV ? 1.0 : 0.0);
-            b_a = BAr[ZA]; b_w = BAr[ZW];
-            rbi = L.rb[k * NX + i5];
+            o.lx0 = Fb[FB_LXU + 2 * i5]; o.lx1 = Fb[FB_LXU + 2 * i5 + 1];
+            o.y0 = L.y[k * NU]; o.y1 = L.y[k * NU + 1];
+            o.r0 = Fb[FB_R0]; o.l10 = Fb[FB_L10]; o.r1 = Fb[FB_R1];
+            o.a_psi = BAr[ZPSI]; o.a_v = BAr[ZV];                          // loads only: arithmetic here would wait for them
+            o.b_a = BAr[ZA]; o.b_w = BAr[ZW];
+            o.rbi = L.rb[k * NX + i5];
         };
-        load_stage(0);
-        for (int k = 0; k < N; k++) {
-            // du = -Luu^-T (Lxu^T dx + y): the dot products over lanes 2..6 are reduced with readlanes
-            // (Lxu^T dx)_{0,1}: sums over lanes 2..6, folded with DPP row shifts (lanes 0, 1 contribute zeros; lane 6 ends up
-            // with the total) instead of five dependent readlane + add pairs each
-            double q0 = xl ? lx0 * dx : 0.0, q1 = xl ? lx1 * dx : 0.0;
-            q0 += dpp_move<0x111, 0xf>(q0, 0.0); q1 += dpp_move<0x111, 0xf>(q1, 0.0);
-            q0 += dpp_move<0x112, 0xf>(q0, 0.0); q1 += dpp_move<0x112, 0xf>(q1, 0.0);
-            q0 += dpp_move<0x114, 0xf>(q0, 0.0); q1 += dpp_move<0x114, 0xf>(q1, 0.0);
-            const double s0 = y0 + readlane_d(q0, NV - 1), s1 = y1 + readlane_d(q1, NV - 1);
-            const double u1 = -s1 * r1;
-            const double u0 = (-s0 - l10 * u1) * r0;
-            if (rowl) L.dv[k * NV + lane] = lane == 0 ? u0 : (lane == 1 ? u1 : dx);
+        auto stage = [&](const Ops &o, int k) {
+            // du = -Luu^-T (Lxu^T dx + y).  (Lxu^T dx)_{0,1}: sums over lanes 2..6, folded with DPP row shifts (lanes 0, 1
+            // contribute zeros, vacated lanes read zeros; lane 6 ends up with the total)
+            double q0 = xl ? o.lx0 * dx : 0.0, q1 = xl ? o.lx1 * dx : 0.0;
+            q0 += dpp_shift_zero<0x111>(q0); q1 += dpp_shift_zero<0x111>(q1);
+            q0 += dpp_shift_zero<0x112>(q0); q1 += dpp_shift_zero<0x112>(q1);
+            q0 += dpp_shift_zero<0x114>(q0); q1 += dpp_shift_zero<0x114>(q1);
+            const double s0 = o.y0 + readlane_d(q0, NV - 1), s1 = o.y1 + readlane_d(q1, NV - 1);
+            const double u1 = -s1 * o.r1;
+            const double u0 = (-s0 - o.l10 * u1) * o.r0;
+            if (lane == 0) { L.dv[k * NV] = u0; L.dv[k * NV + 1] = u1; }
+            if (xl) dv_own[k * NV] = dx;
             const double dpsi = readlane_d(dx, ZPSI), dvv = readlane_d(dx, ZV);
-            dx = dx + e_psi * dpsi + e_v * dvv + b_a * u0 + b_w * u1 + rbi;   // lanes 2..6 meaningful
-            if (k + 1 < N) load_stage(k + 1);
+            const double e_psi = o.a_psi - i_psi, e_v = o.a_v - i_v;
+            dx = dx + e_psi * dpsi + e_v * dvv + o.b_a * u0 + o.b_w * u1 + o.rbi;   // lanes 2..6 meaningful
+        };
+        Ops oa, ob;
+        load_stage(oa, 0);
+        int k = 0;
+        for (; k + 1 < N; k += 2) {
+            load_stage(ob, k + 1);
+            stage(oa, k);
+            load_stage(oa, k + 2 < N ? k + 2 : N - 1);                    // unconditional (clamped), see the backward sweep
+            stage(ob, k + 1);
         }
+        if (k < N) stage(oa, k);
         if (rowl) L.dv[N * NV + lane] = xl ? dx : 0.0;
     }
     __syncthreads();
+    SWEEP_T(SP_SOLVE_FWD);
     // dpi_k = P_k dx_k + p_k = Lxx (Lxx^T dx_k) + p_k, k = 1..N  (one lane per stage, unrolled)
     for (int kk = tid; kk < N; kk += NTH) {
         const int k = kk + 1;
@@ -481,6 +534,7 @@ __device__ void riccati_solve(const Lds &L, const Dims &d, int tid, int sw = 1)
         }
     }
     __syncthreads();
+    SWEEP_T(SP_SOLVE_POST);
 }
 
 // gh = rg + sum_rows sgn c (qt + d rd),  d = lam/t, rd = sgn (c.v - beta) - t ; predictor: qt = lam
@@ -1707,5 +1761,21 @@ int tmpc_debug_eval_stage(tmpc_handle *h, int32_t n, const double *z, const doub
         if (dst[i]) TMPC_HIP_CHECK(h, hipMemcpy(dst[i], dout[i], sz_out[i], hipMemcpyDeviceToHost));
     return TMPC_OK;
 }
+
+#ifdef TMPC_SWEEP_PROFILE
+// Profiling build only (not declared in tmpc_hip.h): read and reset the sweep clock accumulators.
+int tmpc_debug_sweep_profile(tmpc_handle *h, uint64_t *out, int32_t n)
+{
+    if (!h || !out || n < tmpc::SP_COUNT) return TMPC_ERR_INVALID;
+    TMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    TMPC_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    unsigned long long host[tmpc::SP_COUNT];
+    TMPC_HIP_CHECK(h, hipMemcpyFromSymbol(host, HIP_SYMBOL(tmpc::g_sweep_prof), sizeof host));
+    for (int i = 0; i < tmpc::SP_COUNT; i++) out[i] = host[i];
+    memset(host, 0, sizeof host);
+    TMPC_HIP_CHECK(h, hipMemcpyToSymbol(HIP_SYMBOL(tmpc::g_sweep_prof), host, sizeof host));
+    return TMPC_OK;
+}
+#endif
 
 }  // extern "C"
