@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <mutex>
 #include <sstream>
 
 namespace MPCPlanner
@@ -57,9 +58,19 @@ namespace MPCPlanner
         _state = std::vector<double>((int)cfg["nx"], 0.0);
     }
     void State::initialize() { std::fill(_state.begin(), _state.end(), 0.0); }
-    double State::get(std::string &&var_name) const { return _state[_model_map.at(var_name).index - _nu]; }
+    // The reference indexes _state[index - nu] for any name, i.e. out of bounds for an input (state.cpp:21-24; reached from
+    // initializeWarmstart's k == 0 branch).  Inputs read as 0 here -- the same value tmpc_warmstart writes on the device.
+    double State::get(std::string &&var_name) const
+    {
+        const ModelEntry &m = _model_map.at(var_name);
+        return m.type == "x" ? _state[m.index - _nu] : 0.0;
+    }
     Vector2d State::getPos() const { return Vector2d(get("x"), get("y")); }
-    void State::set(std::string &&var_name, double value) { _state[_model_map.at(var_name).index - _nu] = value; }
+    void State::set(std::string &&var_name, double value)
+    {
+        const ModelEntry &m = _model_map.at(var_name);
+        if (m.type == "x") _state[m.index - _nu] = value;
+    }
 
     AcadosParameters::AcadosParameters()
     {
@@ -139,16 +150,21 @@ namespace MPCPlanner
         const int B = (int)solvers.size();
         std::vector<int> codes(B, 0);
         if (B == 0) return codes;
-        static tmpc_handle *batch_handle = nullptr; static int batch_cap = 0;
+        // one shared batch handle, (re)created when the batch outgrows it or the solver settings change; calls are serialised
+        static std::mutex batch_mutex;
+        static tmpc_handle *batch_handle = nullptr;
+        static int batch_cap = 0, batch_device = -1, batch_iterations = -1; static double batch_dt = 0.0;
+        std::lock_guard<std::mutex> lock(batch_mutex);
         Solver *s0 = solvers[0];
-        if (!batch_handle || batch_cap < B) {
+        if (!batch_handle || batch_cap < B || batch_device != s0->_device || batch_iterations != s0->_num_iterations || batch_dt != s0->dt) {
             if (batch_handle) tmpc_destroy(batch_handle);
+            batch_handle = nullptr;
             tmpc_dims d; tmpc_default_dims_ex(&d, SOLVER_N, SOLVER_S, SOLVER_NLIN, SOLVER_M, SOLVER_NSLK, SOLVER_SLACK);
             d.n_sqp = s0->_num_iterations; d.dt = s0->dt;
             for (auto &e : s0->_model_map) { d.lb[e.second.index] = e.second.lb; d.ub[e.second.index] = e.second.ub; }
-            if (tmpc_create(&batch_handle, &d, B, 0)) { std::printf("tmpc_create() failed. Exiting.\n"); std::exit(1); }
+            if (tmpc_create(&batch_handle, &d, B, s0->_device)) { std::printf("tmpc_create() failed. Exiting.\n"); std::exit(1); }
             tmpc_set_latency_mode(batch_handle, 1);     // same variant as solve(): solve() and solveBatch() stay bitwise equal
-            batch_cap = B;
+            batch_cap = B; batch_device = s0->_device; batch_iterations = s0->_num_iterations; batch_dt = s0->dt;
         }
         const size_t n0 = (SOLVER_NU + SOLVER_NX) * (SOLVER_N + 1), np = (size_t)SOLVER_NP * SOLVER_N;
         std::vector<double> xinit((size_t)B * SOLVER_NX), x0(B * n0), par(B * np);

@@ -53,6 +53,13 @@ int main(int argc, char **argv)
     solver.initializeWarmstart(state, true);
     ASSERT_TRUE(solver.getEgoPrediction(0, "x") == 0.8 && solver.getEgoPrediction(1, "x") == 12.0);
     ASSERT_TRUE(solver.getEgoPrediction(solver.N, "x") == 10. + solver.N - 1);
+    // node 0 of the shifted warm start: states from `state`, inputs 0 (the reference reads State::get(<input>) out of bounds)
+    solver.setEgoPrediction(0, "a", 123.); solver.setEgoPrediction(0, "w", -4.);
+    solver.initializeWarmstart(state, true);
+    ASSERT_TRUE(solver.getEgoPrediction(0, "a") == 0.0 && solver.getEgoPrediction(0, "w") == 0.0);
+    ASSERT_TRUE(state.get("a") == 0.0);
+    state.set("w", 5.0);                                                  // not a state: ignored, nothing overwritten
+    ASSERT_TRUE(state.get("x") == 0.8 && state.get("w") == 0.0);
     // generated fast setters hit the same slots as the string interface
     setSolverParameterEllipsoidObstX(3, solver._params, 7.25, 2);
     ASSERT_TRUE(solver.getParameter(3, "ellipsoid_obst_2_x") == 7.25);
