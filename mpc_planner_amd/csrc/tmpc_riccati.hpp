@@ -1,0 +1,330 @@
+// Square-root Riccati recursion of the interior-point QP solve: factorisation (matrix recursion) and vector solves
+// (backward / forward sweeps), one wave per trajectory, operands in LDS (struct Lds, tmpc_solve.hip / tmpc_fast.hpp).
+// Included by tmpc_solve.hip after the LDS layout and the cross-lane helpers; shared by the generic and the fast kernels.
+#pragma once
+
+namespace tmpc {
+
+// ---- optional coarse clock split of the sweeps (tools/profile_sweeps.py builds a separate library with this macro;
+// the product library never defines it) ---------------------------------------------------------------------------
+#ifdef TMPC_SWEEP_PROFILE
+enum { SP_FACTOR_TERM = 0, SP_FACTOR_LOOP, SP_SOLVE_PRE, SP_SOLVE_BWD, SP_SOLVE_FWD, SP_SOLVE_POST, SP_CALLS_FACTOR, SP_CALLS_SOLVE, SP_COUNT };
+__device__ unsigned long long g_sweep_prof[SP_COUNT];
+#define SWEEP_T0() long long sp_t = clock64()
+#define SWEEP_T(i) do { const long long sp_n = clock64(); if (tid == 0) atomicAdd(&g_sweep_prof[i], (unsigned long long)(sp_n - sp_t)); sp_t = sp_n; } while (0)
+#define SWEEP_COUNT(i) do { if (tid == 0) atomicAdd(&g_sweep_prof[i], 1ull); } while (0)
+#else
+#define SWEEP_T0()
+#define SWEEP_T(i)
+#define SWEEP_COUNT(i)
+#endif
+
+// ---- square-root Riccati: factorisation --------------------------------------------------------
+// Lane i (< 7) owns ROW i of the stage matrix F_k = Hh_k + G^T G (G = Lp^T [B A], Lp = trailing 5x5 of the
+// next stage's Cholesky factor) in registers f[0..i].  The 7x7 Cholesky runs entirely in registers: pivots
+// and column entries are broadcast with v_readlane, no LDS traffic and no barriers inside the factorisation.
+// In place of Hh_k the "factor block" (28 doubles) is written for the vector solves:
+//   [0..9]  Lxu (5x2, row-major)   [10] L10   [11] 1/L00   [12] 1/L11   [13..27] Lxx (packed lower 5x5; P_k = Lxx Lxx^T)
+constexpr int FB_LXU = 0, FB_L10 = 10, FB_R0 = 11, FB_R1 = 12, FB_P = 13;
+
+template <int C0>
+__device__ __forceinline__ bool chol_rows(double (&f)[NV], int lane, double *r0, double *r1)
+{
+    bool bad = false;
+#pragma unroll
+    for (int c = C0; c < NV; c++) {
+        const double dpiv = readlane_d(f[c], c);
+        if (!(dpiv > 0.0)) bad = true;
+        const double y = rsqrt_nr(dpiv);
+        f[c] *= y;                                  // lane i >= c: L_ic (i == c: sqrt(d))
+        if (c == 0 && r0) *r0 = y;
+        if (c == 1 && r1) *r1 = y;
+#pragma unroll
+        for (int j = c + 1; j < NV; j++) {
+            const double ljc = readlane_d(f[c], j);
+            f[j] -= f[c] * ljc;                     // lane i >= j: F_ij -= L_ic L_jc
+        }
+    }
+    (void)lane;                                       // entries above the diagonal are never read
+    return bad;
+}
+
+// dyn8[k] = (Xa, Xw, Xp, Xv, Ya, Yw, Yp, Yv): the only non-constant entries of [B A] for the unicycle
+// (tmpc_stage.hpp dyn_jacobian); the rest is identity / dt / dt^2/2.
+enum { D8_XA = 0, D8_XW, D8_XP, D8_XV, D8_YA, D8_YW, D8_YP, D8_YV };
+
+// The sweeps below are strictly sequential over stages; to keep LDS latency off the critical path every
+// operand of stage k-1 is (re)loaded into the same registers right after its last use in stage k, so the loads
+// complete underneath the dependent Cholesky / readlane chain of stage k.
+// NTH = threads per trajectory: 64, or 128 for the two-wave variant, in which the sweeps run on wave 0 alone (wave 1
+// waits at the closing barrier) and only the stage-parallel loops use all threads.
+// `sw`: which of the two waves sweeps (two-wave variant); the other one waits at the closing barrier.
+template <int NTH>
+__device__ bool riccati_factor(const Lds &L, const Dims &d, int tid, int sw = 0)
+{
+    const int N = d.N;
+    bool anybad = false;
+    SWEEP_T0(); SWEEP_COUNT(SP_CALLS_FACTOR);
+    if (NTH == 64 || (tid >> 6) == sw) {
+    const int lane = tid & 63;
+    const bool rowl = lane < NV;
+    const int ls = rowl ? lane : 0;
+    const int i5 = lane - NU;                        // state index of lanes 2..6
+    const double dt = d.dt, hdt2 = d.hdt2;
+    bool bad = false;
+    double f[NV], hk[NV], ba[NX], dn[8];
+    auto load_stage = [&](int k) {
+        const double *Hk = L.Hh + k * NP28;
+        const double *BA = L.BA + k * NX * NV;
+        // unconditional loads (clamped indices): entries above the diagonal / of idle lanes are never used
+#pragma unroll
+        for (int j = 0; j < NV; j++) hk[j] = Hk[pidx(ls, j <= ls ? j : ls)];
+#pragma unroll
+        for (int m = 0; m < NX; m++) ba[m] = BA[m * NV + ls];
+#pragma unroll
+        for (int q = 0; q < 8; q++) dn[q] = L.dyn8[k * 8 + q];
+    };
+    // terminal node: Cholesky of the xx-block (rows/cols 2..6)
+#pragma unroll
+    for (int j = 0; j < NV; j++) f[j] = (j >= NU) ? L.Hh[N * NP28 + pidx(ls, j <= ls ? j : ls)] : 0.0;
+    load_stage(N - 1);
+    bad |= chol_rows<NU>(f, lane, nullptr, nullptr);
+    SWEEP_T(SP_FACTOR_TERM);
+    for (int k = N - 1; k >= 0; k--) {
+        // broadcast Lp (lower 5x5 of the factor of stage k+1) to every lane
+        double Lp[NX][NX];
+#pragma unroll
+        for (int m = 0; m < NX; m++)
+#pragma unroll
+            for (int l = 0; l <= m; l++) Lp[m][l] = readlane_d(f[NU + l], NU + m);
+        // Lxx of stage k+1 (own row of lanes 2..6) is kept for the vector solves: P_{k+1} = Lxx Lxx^T is never formed
+        if (rowl && lane >= NU) {
+            double *Ln = L.Hh + (k + 1) * NP28 + FB_P;
+#pragma unroll
+            for (int l = 0; l < NX; l++) if (l <= i5) Ln[i5 * (i5 + 1) / 2 + l] = f[NU + l];
+        }
+        // G = Lp^T [B A] (5 x 7).  Own column densely from ba[]; all columns (wave-uniform) from the sparse [B A]:
+        //   x: e0   y: e1   s: e4   psi: (Xp,Yp,1,0,0)   v: (Xv,Yv,0,1,dt)   a: (Xa,Ya,0,dt,dt^2/2)   w: (Xw,Yw,dt,0,0)
+        // Same operation order as the dense product (zeros skipped, ones exact), i.e. F = Hh + G^T G keeps the
+        // square-root structure (a factor-level perturbation only) -- do not replace by Hh + [B A]^T (P [B A]).
+        double Go[NX];
+#pragma unroll
+        for (int l = 0; l < NX; l++) {
+            double acc = 0.0;
+#pragma unroll
+            for (int m = l; m < NX; m++) acc += Lp[m][l] * ba[m];
+            Go[l] = acc;
+        }
+        const double Xa = dn[D8_XA], Xw = dn[D8_XW], Xp = dn[D8_XP], Xv = dn[D8_XV];
+        const double Ya = dn[D8_YA], Yw = dn[D8_YW], Yp = dn[D8_YP], Yv = dn[D8_YV];
+        double Ga[NX], Gw[NX], Gp[3], Gv[NX];
+        Ga[0] = ((Lp[0][0] * Xa + Lp[1][0] * Ya) + Lp[3][0] * dt) + Lp[4][0] * hdt2;
+        Ga[1] = (Lp[1][1] * Ya + Lp[3][1] * dt) + Lp[4][1] * hdt2;
+        Ga[2] = Lp[3][2] * dt + Lp[4][2] * hdt2;
+        Ga[3] = Lp[3][3] * dt + Lp[4][3] * hdt2;
+        Ga[4] = Lp[4][4] * hdt2;
+        Gw[0] = (Lp[0][0] * Xw + Lp[1][0] * Yw) + Lp[2][0] * dt;
+        Gw[1] = Lp[1][1] * Yw + Lp[2][1] * dt;
+        Gw[2] = Lp[2][2] * dt; Gw[3] = 0.0; Gw[4] = 0.0;
+        Gp[0] = (Lp[0][0] * Xp + Lp[1][0] * Yp) + Lp[2][0];
+        Gp[1] = Lp[1][1] * Yp + Lp[2][1];
+        Gp[2] = Lp[2][2];
+        Gv[0] = ((Lp[0][0] * Xv + Lp[1][0] * Yv) + Lp[3][0]) + Lp[4][0] * dt;
+        Gv[1] = (Lp[1][1] * Yv + Lp[3][1]) + Lp[4][1] * dt;
+        Gv[2] = Lp[3][2] + Lp[4][2] * dt;
+        Gv[3] = Lp[3][3] + Lp[4][3] * dt;
+        Gv[4] = Lp[4][4] * dt;
+        // F row `lane`: F_ij = Hh_ij + sum_l G_l,lane G_l,j
+        {
+            double a0 = hk[ZA], a1 = hk[ZW], a2 = hk[ZX], a3 = hk[ZY], a4 = hk[ZPSI], a5 = hk[ZV], a6 = hk[ZS];
+#pragma unroll
+            for (int l = 0; l < NX; l++) {
+                a0 += Go[l] * Ga[l];
+                if (l < 3) a1 += Go[l] * Gw[l];
+                if (l < 1) a2 += Go[l] * Lp[0][0];
+                if (l < 2) a3 += Go[l] * Lp[1][l];
+                if (l < 3) a4 += Go[l] * Gp[l];
+                a5 += Go[l] * Gv[l];
+                a6 += Go[l] * Lp[4][l];
+            }
+            f[ZA] = a0; f[ZW] = a1; f[ZX] = a2; f[ZY] = a3; f[ZPSI] = a4; f[ZV] = a5; f[ZS] = a6;
+        }
+        if (k > 0) load_stage(k - 1);                 // operands of the next stage, hidden under the Cholesky
+        double r0 = 0.0, r1 = 0.0;
+        bad |= chol_rows<0>(f, lane, &r0, &r1);
+        if (rowl) {
+            double *Fb = L.Hh + k * NP28;
+            if (lane >= NU) { Fb[FB_LXU + 2 * i5] = f[0]; Fb[FB_LXU + 2 * i5 + 1] = f[1]; }
+            if (lane == 1) { Fb[FB_L10] = f[0]; Fb[FB_R0] = r0; Fb[FB_R1] = r1; }
+        }
+    }
+    anybad = __any(bad);
+    if (NTH > 64 && lane == 0) L.scr[63] = anybad ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    SWEEP_T(SP_FACTOR_LOOP);
+    if (NTH > 64) anybad = L.scr[63] != 0.0;
+    return anybad;
+}
+
+// ---- square-root Riccati: vector solve (backward + forward), rhs gh / rb -> dv, dpi ------------------
+// Lane j (< 7) = component j of the stage vector [u; x]; the cost-to-go gradient p lives in lanes 2..6.
+template <int NTH>
+__device__ void riccati_solve(const Lds &L, const Dims &d, int tid, int sw = 1)
+{
+    const int N = d.N;
+    // two-wave variant: the vector sweeps run on the wave that did not factorise, so that with two trajectories' waves
+    // sharing a SIMD pair the sequential work is spread over both SIMDs
+    const bool sweeper = NTH == 64 || (tid >> 6) == sw;
+    const int lane = NTH == 64 ? tid : (sweeper ? (tid & 63) : 64);
+    const bool rowl = lane < NV, xl = rowl && lane >= NU;
+    const int ls = rowl ? lane : 0;
+    const int i5 = xl ? lane - NU : 0;
+    SWEEP_T0(); SWEEP_COUNT(SP_CALLS_SOLVE);
+    // q_k = P_{k+1} rb_k = Lxx (Lxx^T rb_k) for all stages at once (off the sequential chain); parked in dpi[k+1].
+    // One lane per stage, fully unrolled (30 FMAs for the 5 components).
+    for (int k = tid; k < N; k += NTH) {
+        const double *Ln = L.Hh + (k + 1) * NP28 + FB_P;
+        const double *r = L.rb + k * NX;
+        double ll[15], rr[NX], tl[NX];
+#pragma unroll
+        for (int e = 0; e < 15; e++) ll[e] = Ln[e];
+#pragma unroll
+        for (int m = 0; m < NX; m++) rr[m] = r[m];
+#pragma unroll
+        for (int l = 0; l < NX; l++) {
+            double acc = 0.0;
+#pragma unroll
+            for (int m = l; m < NX; m++) acc += ll[m * (m + 1) / 2 + l] * rr[m];
+            tl[l] = acc;
+        }
+#pragma unroll
+        for (int i = 0; i < NX; i++) {
+            double acc = 0.0;
+#pragma unroll
+            for (int l = 0; l <= i; l++) acc += ll[i * (i + 1) / 2 + l] * tl[l];
+            L.dpi[(k + 1) * NX + i] = acc;
+        }
+    }
+    __syncthreads();
+    SWEEP_T(SP_SOLVE_PRE);
+    if (sweeper) {
+    double p = L.gh[N * NV + ls];                       // p_N (lanes 2..6 meaningful)
+    if (xl) L.pr[N * NX + i5] = p;
+    {
+        // Two operand sets, filled alternately two stages ahead: a set is (re)loaded right after the stage that used it, so
+        // its LDS latency passes underneath the other set's stage (with a single set the loads were issued at the end of
+        // stage k and awaited at the top of stage k-1: ~120 exposed cycles per stage).
+        struct Ops { double ghj, ba[NX], r0, l10, r1, lx0, lx1, q; };
+        auto load_stage = [&](Ops &o, int k) {
+            const double *Fb = L.Hh + k * NP28;
+            const double *BA = L.BA + k * NX * NV;
+            o.ghj = L.gh[k * NV + ls];
+#pragma unroll
+            for (int l = 0; l < NX; l++) o.ba[l] = BA[l * NV + ls];
+            o.r0 = Fb[FB_R0]; o.l10 = Fb[FB_L10]; o.r1 = Fb[FB_R1];
+            o.lx0 = Fb[FB_LXU + 2 * i5]; o.lx1 = Fb[FB_LXU + 2 * i5 + 1];
+            o.q = L.dpi[(k + 1) * NX + i5];
+        };
+        auto stage = [&](const Ops &o, int k) {
+            const double Pb = p + o.q;                                     // (P_{k+1} rb_k + p_{k+1}), lane 2+i
+            double fj = o.ghj;
+#pragma unroll
+            for (int l = 0; l < NX; l++) fj += o.ba[l] * readlane_d(Pb, NU + l);
+            const double y0 = readlane_d(fj, 0) * o.r0;
+            const double y1 = (readlane_d(fj, 1) - o.l10 * y0) * o.r1;
+            p = fj - o.lx0 * y0 - o.lx1 * y1;
+            if (lane == 0) { L.y[k * NU] = y0; L.y[k * NU + 1] = y1; }
+            if (xl) L.pr[k * NX + i5] = p;
+        };
+        Ops oa, ob;
+        load_stage(oa, N - 1);
+        int k = N - 1;
+        for (; k >= 1; k -= 2) {
+            load_stage(ob, k - 1);
+            stage(oa, k);
+            load_stage(oa, k >= 2 ? k - 2 : 0);                           // unconditional (clamped): a branch here makes the
+                                                                          // compiler wait for ALL outstanding LDS loads at the join
+            stage(ob, k - 1);
+        }
+        if (k == 0) stage(oa, 0);
+    }
+    }
+    __syncthreads();
+    SWEEP_T(SP_SOLVE_BWD);
+    // forward sweep; dx_0 = 0 (dx lives in lanes 2..6).  dx+ = A dx + B du + rb with A = I + E (E: columns psi, v).
+    if (sweeper) {
+        double dx = 0.0;
+        struct Ops { double lx0, lx1, y0, y1, r0, l10, r1, a_psi, a_v, b_a, b_w, rbi; };
+        const double i_psi = lane == ZPSI ? 1.0 : 0.0, i_v = lane == ZV ? 1.0 : 0.0;
+        double *dv_own = L.dv + (rowl ? lane : 0);
+        auto load_stage = [&](Ops &o, int k) {
+            const double *Fb = L.Hh + k * NP28;
+            const double *BAr = L.BA + k * NX * NV + i5 * NV;              // own row of [B A]
+            o.lx0 = Fb[FB_LXU + 2 * i5]; o.lx1 = Fb[FB_LXU + 2 * i5 + 1];
+            o.y0 = L.y[k * NU]; o.y1 = L.y[k * NU + 1];
+            o.r0 = Fb[FB_R0]; o.l10 = Fb[FB_L10]; o.r1 = Fb[FB_R1];
+            o.a_psi = BAr[ZPSI]; o.a_v = BAr[ZV];                          // loads only: arithmetic here would wait for them
+            o.b_a = BAr[ZA]; o.b_w = BAr[ZW];
+            o.rbi = L.rb[k * NX + i5];
+        };
+        auto stage = [&](const Ops &o, int k) {
+            // du = -Luu^-T (Lxu^T dx + y).  (Lxu^T dx)_{0,1}: sums over lanes 2..6, folded with DPP row shifts (lanes 0, 1
+            // contribute zeros, vacated lanes read zeros; lane 6 ends up with the total)
+            double q0 = xl ? o.lx0 * dx : 0.0, q1 = xl ? o.lx1 * dx : 0.0;
+            q0 += dpp_shift_zero<0x111>(q0); q1 += dpp_shift_zero<0x111>(q1);
+            q0 += dpp_shift_zero<0x112>(q0); q1 += dpp_shift_zero<0x112>(q1);
+            q0 += dpp_shift_zero<0x114>(q0); q1 += dpp_shift_zero<0x114>(q1);
+            const double s0 = o.y0 + readlane_d(q0, NV - 1), s1 = o.y1 + readlane_d(q1, NV - 1);
+            const double u1 = -s1 * o.r1;
+            const double u0 = (-s0 - o.l10 * u1) * o.r0;
+            if (lane == 0) { L.dv[k * NV] = u0; L.dv[k * NV + 1] = u1; }
+            if (xl) dv_own[k * NV] = dx;
+            const double dpsi = readlane_d(dx, ZPSI), dvv = readlane_d(dx, ZV);
+            const double e_psi = o.a_psi - i_psi, e_v = o.a_v - i_v;
+            dx = dx + e_psi * dpsi + e_v * dvv + o.b_a * u0 + o.b_w * u1 + o.rbi;   // lanes 2..6 meaningful
+        };
+        Ops oa, ob;
+        load_stage(oa, 0);
+        int k = 0;
+        for (; k + 1 < N; k += 2) {
+            load_stage(ob, k + 1);
+            stage(oa, k);
+            load_stage(oa, k + 2 < N ? k + 2 : N - 1);                    // unconditional (clamped), see the backward sweep
+            stage(ob, k + 1);
+        }
+        if (k < N) stage(oa, k);
+        if (rowl) L.dv[N * NV + lane] = xl ? dx : 0.0;
+    }
+    __syncthreads();
+    SWEEP_T(SP_SOLVE_FWD);
+    // dpi_k = P_k dx_k + p_k = Lxx (Lxx^T dx_k) + p_k, k = 1..N  (one lane per stage, unrolled)
+    for (int kk = tid; kk < N; kk += NTH) {
+        const int k = kk + 1;
+        const double *Lk = L.Hh + k * NP28 + FB_P;
+        const double *dxk = L.dv + k * NV + NU;
+        double ll[15], rr[NX], tl[NX];
+#pragma unroll
+        for (int e = 0; e < 15; e++) ll[e] = Lk[e];
+#pragma unroll
+        for (int m = 0; m < NX; m++) rr[m] = dxk[m];
+#pragma unroll
+        for (int l = 0; l < NX; l++) {
+            double acc = 0.0;
+#pragma unroll
+            for (int m = l; m < NX; m++) acc += ll[m * (m + 1) / 2 + l] * rr[m];
+            tl[l] = acc;
+        }
+#pragma unroll
+        for (int i = 0; i < NX; i++) {
+            double acc = 0.0;
+#pragma unroll
+            for (int l = 0; l <= i; l++) acc += ll[i * (i + 1) / 2 + l] * tl[l];
+            L.dpi[k * NX + i] = acc + L.pr[k * NX + i];
+        }
+    }
+    __syncthreads();
+    SWEEP_T(SP_SOLVE_POST);
+}
+
+}  // namespace tmpc

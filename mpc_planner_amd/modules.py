@@ -74,7 +74,7 @@ def project_to_safety(pos, obstacles_k, r):
     ros_tools' Douglas-Rachford projection over the obstacles; the ros_tools source is absent -- DESIGN.md [UPSTREAM]):
     a guess closer than r to an obstacle is moved radially to 1.001 r from it.  The identity whenever the guess is
     already clear of every obstacle, which is the only case the parity claims rest on.  Same arithmetic as
-    tmpc_linearize_topology_kernel (csrc/tmpc_solve.hip)."""
+    tmpc_linearize_topology_kernel (csrc/tmpc_aux_kernels.hpp)."""
     px, py = float(pos[0]), float(pos[1])
     for _ in range(3):
         for o in obstacles_k:

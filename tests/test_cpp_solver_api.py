@@ -68,7 +68,8 @@ def test_cpp_solver_over_a_generated_library():
     out = os.path.join(ROOT, "build", "generated_from_modules")
     st = stacks.settings(N=20, max_obstacles=8); st["integrator_step"] = 0.2
     lib = os.path.join(out, "lib", "libtmpc_hip_cpp_tmpc.so")
-    if not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(os.path.join(ROOT, "mpc_planner_amd", "csrc", "tmpc_solve.hip")):
+    if not os.path.exists(lib) or os.path.getmtime(lib) < max(
+            os.path.getmtime(os.path.join(ROOT, "mpc_planner_amd", "csrc", f)) for f in os.listdir(os.path.join(ROOT, "mpc_planner_amd", "csrc"))):
         model, mm = stacks.tmpc(st)
         lib, meta = generate_solver_from_modules(out, "cpp_tmpc", mm, model, st)
         assert meta["npar"] == 135
