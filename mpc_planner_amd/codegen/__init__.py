@@ -8,7 +8,7 @@ over `solver_generator/control_modules.py`) and lets CasADi + acados generate C 
                 against CasADi run unmodified (`install_as_casadi()`)
   plugin.py     the module protocol (ModuleManager / ObjectiveModule / ConstraintModule / Parameters / model) and the
                 assembly rules of solver_definition.py:5-76
-  library.py    a library of modules written against that protocol (MPC base weights, contouring, goal, ellipsoids,
+  library.py    a library of modules written against that protocol (MPC base weights, contouring, path reference velocity, goal, ellipsoids,
                 topology halfspaces, decomp / scenario halfspaces, Gaussian chance constraints)
   emit.py       exact first / second derivatives, common-subexpression elimination and emission of the HIP stage
                 functions (`tmpc_gen::cost`, `tmpc_gen::rows`) that `csrc/tmpc_stage.hpp` compiles into the solve kernel

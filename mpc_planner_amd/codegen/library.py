@@ -84,12 +84,18 @@ class GluedSpline:
 
 
 class _Contouring:
-    def __init__(self, num_segments):
+    def __init__(self, num_segments, dynamic_velocity_reference=False):
         self.num_segments = num_segments
+        self.dynamic_velocity_reference = dynamic_velocity_reference
 
     def define_parameters(self, params):
-        for n in ("contour", "lag", "terminal_angle", "terminal_contouring"):
-            params.add(n, add_to_rqt_reconfigure=True)
+        params.add("contour", add_to_rqt_reconfigure=True)
+        params.add("lag", add_to_rqt_reconfigure=True)
+        if not params.has_parameter("velocity"):        # contouring.py:26-28: only when no MPC base module defined them
+            params.add("velocity", add_to_rqt_reconfigure=True)
+            params.add("reference_velocity", add_to_rqt_reconfigure=True)
+        params.add("terminal_angle", add_to_rqt_reconfigure=True)
+        params.add("terminal_contouring", add_to_rqt_reconfigure=True)
         for i in range(self.num_segments):
             for ax in ("x", "y"):
                 for k in "abcd":
@@ -106,7 +112,13 @@ class _Contouring:
         ex, ey = x - px.at(s), y - py.at(s)
         contour_error = ty * ex - tx * ey
         lag_error = tx * ex + ty * ey
-        return params.get("lag") * lag_error ** 2 + params.get("contour") * contour_error ** 2
+        cost = params.get("lag") * lag_error ** 2 + params.get("contour") * contour_error ** 2
+        if self.dynamic_velocity_reference:             # contouring.py:60-66,80-81: velocity reference from the path spline
+            if not params.has_parameter("spline_v0_a"):
+                raise IOError("contouring/dynamic_velocity_reference is enabled, but there is no PathReferenceVelocity module.")
+            v_ref = GluedSpline(params, "spline_v", self.num_segments, s).at(s)
+            cost += params.get("velocity") * (model.get("v") - v_ref) ** 2
+        return cost
 
 
 class ContouringModule(ObjectiveModule):
@@ -115,7 +127,32 @@ class ContouringModule(ObjectiveModule):
     def __init__(self, settings):
         super().__init__()
         self.module_name, self.import_name = "Contouring", "contouring.h"
-        self.objectives.append(_Contouring(settings["contouring"]["num_segments"]))
+        self.objectives.append(_Contouring(settings["contouring"]["num_segments"],
+                                           settings["contouring"].get("dynamic_velocity_reference", False)))
+
+
+class _PathReferenceVelocity:
+    """Declares the velocity spline's parameters; the cost term itself lives in the contouring objective."""
+
+    def __init__(self, num_segments):
+        self.num_segments = num_segments
+
+    def define_parameters(self, params):
+        for i in range(self.num_segments):
+            for k in "abcd":
+                params.add(f"spline_v{i}_{k}", bundle_name=f"spline_v_{k}")
+
+    def get_value(self, model, params, settings, stage_idx):
+        return 0.0
+
+
+class PathReferenceVelocityModule(ObjectiveModule):
+    """path_reference_velocity.py:11-48."""
+
+    def __init__(self, settings):
+        super().__init__()
+        self.module_name, self.import_name = "PathReferenceVelocity", "path_reference_velocity.h"
+        self.objectives.append(_PathReferenceVelocity(settings["contouring"]["num_segments"]))
 
 
 class _Goal:

@@ -60,3 +60,14 @@ def goal_gaussian(st):
     b.weigh_variable("v", ["velocity", "reference_velocity"], cost_function=lambda x, w: w[0] * (x - w[1]) ** 2)
     mm.add_module(L.GoalModule(st)); mm.add_module(L.GaussianConstraintModule(st))
     return P.UnicycleContouringModel(), mm
+
+
+def contouring_path_velocity_ellipsoids(st):
+    """The stack of the reference's own generation test (solver_generator/test/test_acados.py:30-46): MPC base weights on
+    a, w + contouring + path reference velocity + ellipsoids."""
+    mm = P.ModuleManager()
+    b = mm.add_module(L.MPCBaseModule(st))
+    b.weigh_variable("a", "acceleration"); b.weigh_variable("w", "angular_velocity")
+    mm.add_module(L.ContouringModule(st)); mm.add_module(L.PathReferenceVelocityModule(st))
+    mm.add_module(L.EllipsoidConstraintModule(st))
+    return P.UnicycleContouringModel(), mm

@@ -175,3 +175,49 @@ def test_cpp_glue_files_for_the_tmpc_stack(tmp_path):
         pass
     mm.add_module(PyOnly())
     assert "UNDEFINED" not in cpp_glue.modules_header(mm)
+
+
+def test_reference_generation_test_configurations():
+    """The assertions of the reference's own generator tests, on this generator: parameter count of contouring + path
+    reference velocity (test_control_modules.py:27-53) and the stack of test_acados.py:30-77 (12 ellipsoid rows, nx = 5,
+    nu = 2); with a dynamic velocity reference the cost tracks the path's velocity spline (contouring.py:60-81)."""
+    from mpc_planner_amd.codegen import plugin as P, library as L
+    st = {"N": 20, "contouring": {"num_segments": 10, "dynamic_velocity_reference": False}}
+    mm = P.ModuleManager(); mm.add_module(L.ContouringModule(st)); mm.add_module(L.PathReferenceVelocityModule(st))
+    pm = P.define_parameters(mm, P.Parameters(), st)
+    assert pm.length() == 10 * 9 + 2 + 4 + 10 * 4
+    assert [pm.index(n) for n in ("contour", "lag", "velocity", "reference_velocity", "terminal_angle", "terminal_contouring")] == list(range(6))
+
+    st = stacks.settings(N=20, max_obstacles=12, num_segments=8)
+    model, mm = stacks.contouring_path_velocity_ellipsoids(st)
+    gen = emit.generate(mm, model, st, "test_solver", method="jets")
+    assert gen["nh"] == 12 and model.nx == 5 and model.nu == 2
+    assert gen["npar"] == 2 + 6 + 8 * 9 + 8 * 4 + 2 + 12 * 7
+
+    # dynamic velocity reference: value by hand on a straight path with v_ref(s) = 1.5 + 0.25 s, derivatives by differences
+    st = stacks.settings(N=20, max_obstacles=1, num_segments=2); st["contouring"]["dynamic_velocity_reference"] = True
+    model, mm = stacks.contouring_path_velocity_ellipsoids(st)
+    gen = emit.generate(mm, model, st, "dynvel", method="jets")
+    pm, hs = gen["params"], HostStageFunctions(gen["header"])
+    p = np.zeros(hs.npar)
+    for n, v in dict(acceleration=0.3, angular_velocity=0.8, contour=0.05, lag=0.75, velocity=0.55, ego_disc_radius=0.3,
+                     ellipsoid_obst_0_x=50.0, ellipsoid_obst_0_y=50.0, ellipsoid_obst_0_r=0.1, ellipsoid_obst_0_chi=1.0).items():
+        p[pm.index(n)] = v
+    for i, start in enumerate((0.0, 6.0)):                  # x(s) = s, y(s) = 0, v_ref(s) = 1.5 + 0.25 s on both segments
+        p[pm.index(f"spline_x{i}_c")] = 1.0; p[pm.index(f"spline_x{i}_d")] = start
+        p[pm.index(f"spline_v{i}_c")] = 0.25; p[pm.index(f"spline_v{i}_d")] = 1.5 + 0.25 * start
+        p[pm.index(f"spline{i}_start")] = start
+    z = np.array([0.4, -0.2, 2.3, 0.6, 0.1, 1.2, 2.0])      # a, w, x, y, psi, v, s
+    v, g, H = hs.cost(z, p)
+    want = 0.3 * 0.16 + 0.8 * 0.04 + 0.75 * 0.3 ** 2 + 0.05 * 0.6 ** 2 + 0.55 * (1.2 - 2.0) ** 2
+    assert abs(v - want) < 1e-9
+    eps = 1e-6
+    for i in range(7):
+        e = np.zeros(7); e[i] = eps
+        vp, gp, _ = hs.cost(z + e, p); vm, gm, _ = hs.cost(z - e, p)
+        assert abs((vp - vm) / (2 * eps) - g[i]) < 1e-7
+        np.testing.assert_allclose((gp - gm) / (2 * eps), H[:, i], atol=1e-6)
+    # without the PathReferenceVelocity module the reference refuses (contouring.py:61-62)
+    mm = P.ModuleManager(); mm.add_module(L.ContouringModule(st))
+    with pytest.raises(IOError, match="no PathReferenceVelocity module"):
+        emit.generate(mm, P.UnicycleContouringModel(), st, "bad", method="jets")

@@ -37,7 +37,18 @@ base.weigh_variable(var_name="v", weight_names=["velocity", "reference_velocity"
 modules.add_module(ContouringModule(settings))
 modules.add_module(GuidanceConstraintModule(settings, constraint_submodule=EllipsoidConstraintModule))
 gen = emit.generate(modules, model, settings, "reference_scripts_tmpc", method="jets")
+# second configuration: the reference's own generation test stack (solver_generator/test/test_acados.py:30-46)
+from path_reference_velocity import PathReferenceVelocityModule
+from solver_definition import define_parameters
+from util.parameters import Parameters
+st2 = {"N": 20, "integrator_step": 0.2, "n_discs": 1, "max_obstacles": 12, "contouring": {"num_segments": 8, "dynamic_velocity_reference": False}}
+m2 = ModuleManager()
+b2 = m2.add_module(MPCBaseModule(st2))
+b2.weigh_variable(var_name="a", weight_names="acceleration"); b2.weigh_variable(var_name="w", weight_names="angular_velocity")
+m2.add_module(ContouringModule(st2)); m2.add_module(PathReferenceVelocityModule(st2)); m2.add_module(EllipsoidConstraintModule(st2))
+p2 = define_parameters(m2, Parameters(), st2)
 json.dump(dict(header=gen["header"], pmap=dict(gen["params"]._params), nh=gen["nh"], modules_h=cpp_glue.modules_header(modules),
+               pmap2=dict(p2._params), modules_h2=cpp_glue.modules_header(m2), definitions_h2=cpp_glue.definitions_header(m2),
                definitions_h=cpp_glue.definitions_header(modules), modules_cmake=cpp_glue.modules_cmake(modules)), open(sys.argv[1], "w"))
 '''
 
@@ -72,3 +83,10 @@ def test_unmodified_reference_module_scripts_generate_the_same_stage_functions(t
     assert gen["modules_h"] == cpp_glue.modules_header(mm)
     assert gen["definitions_h"] == cpp_glue.definitions_header(mm)
     assert gen["modules_cmake"] == cpp_glue.modules_cmake(mm)
+    # the stack of the reference's generation test (test_acados.py:30-46): same parameter map and wiring files from the
+    # reference's own Parameters / module objects and from this repo's library
+    from mpc_planner_amd.codegen import plugin as P
+    st2 = stacks.settings(N=20, max_obstacles=12, num_segments=8)
+    _, mm2 = stacks.contouring_path_velocity_ellipsoids(st2)
+    assert gen["pmap2"] == dict(P.define_parameters(mm2, P.Parameters(), st2)._params)
+    assert gen["modules_h2"] == cpp_glue.modules_header(mm2) and gen["definitions_h2"] == cpp_glue.definitions_header(mm2)
