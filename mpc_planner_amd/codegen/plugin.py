@@ -123,6 +123,33 @@ class UnicycleContouringModel:
     def get_u(self):
         return self._z[:self.nu]
 
+    def get_xinit(self):
+        return range(self.nu, self.get_nvar())
+
+    def _index(self, name):
+        if name in self.states:
+            return self.nu + self.states.index(name)
+        if name in self.inputs:
+            return self.inputs.index(name)
+        raise IOError(f"Requested a state or input `{name}' that was neither a state nor an input for the selected model")
+
+    def set_bounds(self, lower_bound, upper_bound):
+        if not len(lower_bound) == len(upper_bound) == len(self.lower_bound):
+            raise ValueError("bounds must cover every input and state")
+        self.lower_bound, self.upper_bound = list(lower_bound), list(upper_bound)
+
+    def get_bounds(self, name):
+        """(lower, upper, range) of an input or state (solver_model.py:151-168)."""
+        i = self._index(name)
+        return self.lower_bound[i], self.upper_bound[i], self.upper_bound[i] - self.lower_bound[i]
+
+    def continuous_model(self, x, u):
+        """xdot = [v cos psi, v sin psi, w, a, v] (solver_model.py:207-214) -- for inspection and tests: the kernels integrate
+        exactly this model in closed form (csrc/tmpc_stage.hpp, ERK4 x 3 per stage)."""
+        a, w = u[0], u[1]
+        psi, v = x[2], x[3]
+        return [v * math.cos(psi), v * math.sin(psi), w, a, v]
+
 
 class UnicycleContouringSlackModel(UnicycleContouringModel):
     """ContouringSecondOrderUnicycleModelWithSlack (solver_model.py:274-298)."""
@@ -133,6 +160,12 @@ class UnicycleContouringSlackModel(UnicycleContouringModel):
         self.states = self.states + ["slack"]
         self.lower_bound = self.lower_bound + [0.0]
         self.upper_bound = self.upper_bound + [5000.0]
+
+    def continuous_model(self, x, u):
+        return super().continuous_model(x, u) + [0.0]                      # slack' = 0 (solver_model.py:287-295)
+
+    def get_xinit(self):
+        return range(self.nu, self.get_nvar() - 1)                          # the slack is not an initial state (:297-298)
 
 
 # ---- assembly (solver_definition.py:5-76) ------------------------------------------------------------------------

@@ -221,3 +221,32 @@ def test_reference_generation_test_configurations():
     mm = P.ModuleManager(); mm.add_module(L.ContouringModule(st))
     with pytest.raises(IOError, match="no PathReferenceVelocity module"):
         emit.generate(mm, P.UnicycleContouringModel(), st, "bad", method="jets")
+
+
+def test_plugin_base_classes_like_the_reference_tests():
+    """solver_generator/test/test_base_classes.py:14-26 (Parameters) and :52-84 (model), on this repo's protocol classes."""
+    from mpc_planner_amd.codegen import plugin as P
+    params = P.Parameters()
+    params.add("var"); params.add("v2"); params.add("long variable name")
+    assert params.length() == 3
+    params.load([3.8, 2.5, -1.0])
+    assert params.get("var") == 3.8 and params.get("v2") == 2.5 and params.get("long variable name") == -1.0
+    assert params.as_dict()["num parameters"] == 3
+
+    for model in (P.UnicycleContouringModel(), P.UnicycleContouringSlackModel()):
+        assert model.nx > 0 and model.nu > 0 and model.get_nvar() == model.nx + model.nu
+        dx = model.continuous_model([0] * model.nx, [0, 0])
+        assert len(dx) == model.nx and dx[0] == 0.0 and dx[1] == 0.0
+        assert "x" in model.states and "y" in model.states
+        model.load([1., 2., 3., 4., 5., 6., 7., 8.][:model.get_nvar()])
+        assert model.get("x") == 3. and model.get("y") == 4. and model.get("a") == 1.
+        with pytest.raises(IOError):
+            model.get("xyz")
+        lb, ub, x_range = model.get_bounds("x")
+        assert ub > lb and x_range > 0
+        assert model.get_bounds("w") == (-0.8, 0.8, 1.6)
+    assert list(P.UnicycleContouringModel().get_xinit()) == [2, 3, 4, 5, 6]
+    assert list(P.UnicycleContouringSlackModel().get_xinit()) == [2, 3, 4, 5, 6]       # slack excluded (solver_model.py:297-298)
+    # unicycle at psi = pi/2, v = 2: moves along +y
+    dx = P.UnicycleContouringModel().continuous_model([0., 0., np.pi / 2, 2.0, 0.], [0.5, -0.1])
+    np.testing.assert_allclose(dx, [0.0, 2.0, -0.1, 0.5, 2.0], atol=1e-15)
