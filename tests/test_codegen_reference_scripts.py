@@ -169,3 +169,63 @@ def test_every_shipped_module_script_and_model_traces_through_the_facade(tmp_pat
         assert n_dx in (nx, nx - 1) and nu >= 2, name       # curvature-aware models integrate all but the last state
     assert r["models"]["ContouringSecondOrderUnicycleModel"] == [5, 2, 5]
     assert r["models"]["ContouringSecondOrderUnicycleModelWithSlack"] == [6, 2, 6]
+
+
+CAC_SCRIPT = r'''
+import sys, json
+sys.dont_write_bytecode = True
+sys.path.insert(0, %(root)r)
+from mpc_planner_amd.codegen import symbolic, emit
+symbolic.install_as_casadi()
+sys.path.insert(0, %(ref)r + "/solver_generator"); sys.path.insert(0, %(ref)r + "/mpc_planner_modules/scripts")
+from control_modules import ModuleManager
+from solver_model import ContouringSecondOrderUnicycleModel
+from mpc_base import MPCBaseModule
+from curvature_aware_contouring import CurvatureAwareContouringModule
+from linearized_constraints import LinearizedConstraintModule
+settings = dict(n_discs=1, max_obstacles=2, N=20, integrator_step=0.2, contouring=dict(num_segments=3, dynamic_velocity_reference=False),
+                linearized_constraints=dict(add_halfspaces=1))
+modules = ModuleManager()
+b = modules.add_module(MPCBaseModule(settings))
+b.weigh_variable(var_name="a", weight_names="acceleration"); b.weigh_variable(var_name="w", weight_names="angular_velocity")
+modules.add_module(CurvatureAwareContouringModule(settings)); modules.add_module(LinearizedConstraintModule(settings))
+gen = emit.generate(modules, ContouringSecondOrderUnicycleModel(), settings, "cac", method="jets")
+json.dump(dict(header=gen["header"], pmap=dict(gen["params"]._params), nh=gen["nh"]), open(sys.argv[1], "w"))
+'''
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "solver_generator")), reason="reference checkout not present")
+def test_modules_without_a_library_counterpart_are_emitted_from_the_reference_scripts(tmp_path):
+    """CurvatureAwareContouringModule and LinearizedConstraintModule exist only as reference scripts (no class in
+    codegen/library.py, no hand-written kernel): the generator differentiates and emits them as they are; emitted
+    gradients / Hessians against central differences of the emitted values."""
+    out = tmp_path / "cac.json"
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
+    subprocess.run([sys.executable, "-c", CAC_SCRIPT % dict(root=ROOT, ref=REF), str(out)], check=True, env=env, timeout=600,
+                   cwd=str(tmp_path), stdout=subprocess.DEVNULL)
+    gen = json.load(open(out))
+    from mpc_planner_amd.codegen.hostlib import HostStageFunctions
+    hs = HostStageFunctions(gen["header"])
+    pm = gen["pmap"]
+    assert hs.npar == len(pm) and hs.nh == gen["nh"] == 2 and "disc_0_lin_constraint_0_a1" in pm and "spline_x0_a" in pm
+    rng = np.random.default_rng(0)
+    p = rng.uniform(0.2, 1.0, hs.npar)
+    for i, start in enumerate((0.0, 4.0, 8.0)):
+        p[pm[f"spline{i}_start"]] = start
+    z = np.array([0.3, -0.1, 1.0, 0.4, 0.2, 1.1, 2.5])
+    v, g, H = hs.cost(z, p)
+    eps = 1e-6
+    for i in range(7):
+        e = np.zeros(7); e[i] = eps
+        vp, gp, _ = hs.cost(z + e, p); vm, gm, _ = hs.cost(z - e, p)
+        assert abs((vp - vm) / (2 * eps) - g[i]) < 1e-6
+        np.testing.assert_allclose((gp - gm) / (2 * eps), H[:, i], atol=1e-5)
+    h, D, Hr = hs.rows(z, p)
+    off = p[pm["ego_disc_0_offset"]]
+    dx, dy = z[2] + off * np.cos(z[4]), z[3] + off * np.sin(z[4])          # disc position (linearized_constraints.py:83-86)
+    for k in range(hs.nh):                                   # halfspaces a1 X_d + a2 Y_d - b <= 0
+        j = hs.row_src[k]
+        a1, a2, b = (p[pm[f"disc_0_lin_constraint_{j}_{f}"]] for f in ("a1", "a2", "b"))
+        assert abs(h[k] - (a1 * dx + a2 * dy - b)) < 1e-12
+        np.testing.assert_allclose(D[k], [a1, a2, off * (-a1 * np.sin(z[4]) + a2 * np.cos(z[4]))], atol=1e-14)
+        np.testing.assert_allclose(Hr[k][2, 2], off * (-a1 * np.cos(z[4]) - a2 * np.sin(z[4])), atol=1e-14)
