@@ -1,4 +1,4 @@
-"""Wide parity sweep (robustness check, not part of the test suite): many scenes per shape, HIP path vs CPU oracle.
+"""Wide parity sweep (robustness check run by hand on the GPU box, not collected by pytest; lives under tests/ because it uses the oracle): many scenes per shape, HIP path vs CPU oracle.
 Prints per shape: trajectories, successes, mismatching exit codes / iteration counts, worst relative trajectory difference."""
 import os, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
