@@ -95,13 +95,25 @@ namespace MPCPlanner
     }
     Solver::~Solver() { if (_handle) tmpc_destroy(_handle); }
 
+    // model_map.yaml -> tmpc_dims bounds.  The slack model's map has one more entry (`slack: [x, 7, 0, 5000]`,
+    // solver_model.py:281-298) than tmpc_dims::lb/ub hold (TMPC_NV = 7): acados pins that state (DESIGN U9), it needs no bounds.
+    template <typename Map>
+    static void applyModelBounds(tmpc_dims &d, const Map &model_map)
+    {
+        for (auto &e : model_map) {
+            const int i = e.second.index;
+            if (i < 0 || i >= TMPC_NV) continue;
+            d.lb[i] = e.second.lb; d.ub[i] = e.second.ub;
+        }
+    }
+
     void Solver::ensureHandle()
     {
         if (_handle) return;
         tmpc_dims d;
         tmpc_default_dims_ex(&d, SOLVER_N, SOLVER_S, SOLVER_NLIN, SOLVER_M, SOLVER_NSLK, SOLVER_SLACK);
         d.n_sqp = _num_iterations; d.dt = dt;
-        for (auto &e : _model_map) { d.lb[e.second.index] = e.second.lb; d.ub[e.second.index] = e.second.ub; }
+        applyModelBounds(d, _model_map);
         int status = tmpc_create(&_handle, &d, 1, _device);
         if (status) {                                   // reference: exit(1) when the capsule cannot be created (:35-39)
             std::printf("tmpc_create() returned status %d (no MI355X / library not built). Exiting.\n", status);
@@ -161,7 +173,7 @@ namespace MPCPlanner
             batch_handle = nullptr;
             tmpc_dims d; tmpc_default_dims_ex(&d, SOLVER_N, SOLVER_S, SOLVER_NLIN, SOLVER_M, SOLVER_NSLK, SOLVER_SLACK);
             d.n_sqp = s0->_num_iterations; d.dt = s0->dt;
-            for (auto &e : s0->_model_map) { d.lb[e.second.index] = e.second.lb; d.ub[e.second.index] = e.second.ub; }
+            applyModelBounds(d, s0->_model_map);
             if (tmpc_create(&batch_handle, &d, B, s0->_device)) { std::printf("tmpc_create() failed. Exiting.\n"); std::exit(1); }
             tmpc_set_latency_mode(batch_handle, 1);     // same variant as solve(): solve() and solveBatch() stay bitwise equal
             batch_cap = B; batch_device = s0->_device; batch_iterations = s0->_num_iterations; batch_dt = s0->dt;

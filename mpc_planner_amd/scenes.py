@@ -16,7 +16,52 @@ WEIGHTS = dict(acceleration=0.34, angular_velocity=0.85, velocity=0.55, referenc
 ROBOT_RADIUS = 0.325
 OBSTACLE_RADIUS = 0.4
 DT = 0.2
-A_MAX = 2.0   # max lateral amplitude of a guidance trajectory [m] (keeps homotopy classes dynamically reachable)
+A_MAX = 4.0   # lateral amplitudes of the guidance set [m] (linspace(-4, 4, B)); candidates that the model cannot
+              # follow (|w| <= 0.8, |a| <= 2, v <= 3: solver_model.py:204-205) or that hit a prediction are re-drawn
+W_LIMIT, A_LIMIT, V_LIMIT = 0.7, 1.8, 2.8     # reachability margins inside the model's input / speed bounds
+
+
+def _smoothstep(tau):
+    """Quintic step 0 -> 1 with zero velocity and acceleration at both ends."""
+    tau = np.clip(tau, 0.0, 1.0)
+    return tau ** 3 * (10.0 - 15.0 * tau + 6.0 * tau * tau)
+
+
+def _smoothstep_d(tau):
+    tau = np.clip(tau, 0.0, 1.0)
+    return 30.0 * tau * tau * (1.0 - tau) ** 2
+
+
+def guidance_candidates(state, t, A, v_cruise, t_acc, shape):
+    """Guidance trajectories (position / velocity at t = k dt; arrays over candidates: A, v_cruise, t_acc, shape [K] ->
+    gpos, gvel [K][N+1][2]) the way a guidance planner's goal grid produces them (guidance_planner is external; SURVEY 8d
+    prescribes lateral profiles of amplitude A): the robot accelerates from its current speed to `v_cruise` within `t_acc` and
+    moves laterally by A with a quintic step (shape 0: ends on a goal offset by A from the path, like the lateral goal grid of
+    guidance_planner.yaml) or leaves and rejoins the path (shape 1).  Tangential to the current heading at t = 0, so it is
+    consistent with xinit."""
+    A = np.atleast_1d(np.asarray(A, float))[:, None]; vc = np.atleast_1d(np.asarray(v_cruise, float))[:, None]
+    shape = np.atleast_1d(np.asarray(shape))[:, None]
+    T = t[-1]; tt = t[None, :]
+    v0 = state[3]
+    ta = np.minimum(np.atleast_1d(np.asarray(t_acc, float))[:, None], T)
+    vx = v0 + (vc - v0) * np.minimum(tt / ta, 1.0)
+    xs = np.where(tt < ta, v0 * tt + 0.5 * (vc - v0) * tt * tt / ta, v0 * ta + 0.5 * (vc - v0) * ta + vc * (tt - ta))
+    tau = tt / T
+    up = tau <= 0.5
+    y = A * np.where(shape == 0, _smoothstep(tau), np.where(up, _smoothstep(2.0 * tau), _smoothstep(2.0 - 2.0 * tau)))
+    vy = A * np.where(shape == 0, _smoothstep_d(tau) / T,
+                      np.where(up, _smoothstep_d(2.0 * tau), -_smoothstep_d(2.0 - 2.0 * tau)) * 2.0 / T)
+    return np.stack([xs, y], 2), np.stack([vx, vy], 2)
+
+
+def guidance_reachable(gpos, gvel, state):
+    """Can the unicycle follow the guidance from `state` within its bounds (solver_model.py:204-205)?  Heading rate, speed and
+    acceleration of the guidance at the nodes, with margins.  gvel [K][N+1][2] -> bool [K]."""
+    psi = np.unwrap(np.arctan2(gvel[..., 1], gvel[..., 0]), axis=-1)
+    v = np.hypot(gvel[..., 0], gvel[..., 1])
+    w = np.diff(psi, axis=-1) / DT; a = np.diff(v, axis=-1) / DT
+    return ((np.abs(w).max(-1) <= W_LIMIT) & (np.abs(a).max(-1) <= A_LIMIT) & (v.max(-1) <= V_LIMIT) & (v.min(-1) >= 0.05)
+            & (np.abs(psi[..., 0] - state[2]) < 0.1))
 
 
 def reference_path_segments(rng, S=5, seg_len=6.0):
@@ -106,11 +151,26 @@ def make_scene(scene_idx, N=20, M=8, B=64, S=5, tmpc_pp=False, gaussian=False, g
     pos0 = np.stack([rng.uniform(3.0, 18.0, M), rng.uniform(-4.0, 4.0, M)], 1)
     n_cross = (M + 1) // 2
     v_nom = 0.5 * (state[3] + WEIGHTS["reference_velocity"])
-    for j in range(n_cross):
-        x_c = rng.uniform(1.5, 7.0)
-        t_c = x_c / v_nom + rng.uniform(-0.5, 0.5)
-        y_c = rng.uniform(-0.3, 0.3)
-        pos0[j] = np.array([x_c, y_c]) - vel[j] * t_c
+
+    def leaves_room(p0, vl):
+        """A tick that starts (almost) in collision has no feasible plan at all: the robot, coasting straight on, must keep
+        r_obstacle + r_robot + 0.3 m from the prediction during the first 1.6 s -- time enough for a guidance trajectory to
+        pass on either side."""
+        i = np.arange(8)
+        robot = np.stack([state[3] * DT * (i + 1), np.zeros(8)], 1)
+        return np.linalg.norm(p0[None, :] + vl[None, :] * DT * i[:, None] - robot, axis=1).min() >= OBSTACLE_RADIUS + ROBOT_RADIUS + 0.3
+
+    for j in range(M):
+        for _try in range(100):
+            if j < n_cross:
+                x_c = rng.uniform(1.5, 7.0)
+                t_c = x_c / v_nom + rng.uniform(-0.5, 0.5)
+                y_c = rng.uniform(-0.3, 0.3)
+                pos0[j] = np.array([x_c, y_c]) - vel[j] * t_c
+            elif _try > 0:
+                pos0[j] = [rng.uniform(3.0, 18.0), rng.uniform(-4.0, 4.0)]
+            if leaves_room(pos0[j], vel[j]):
+                break
     steps = np.arange(N)[None, :, None]
     obs = dict(pos=pos0[:, None, :] + vel[:, None, :] * DT * steps, angle=np.zeros((M, N)),
                radius=np.full(M, OBSTACLE_RADIUS), major=np.zeros((M, N)), minor=np.zeros((M, N)),
@@ -128,8 +188,8 @@ def make_scene(scene_idx, N=20, M=8, B=64, S=5, tmpc_pp=False, gaussian=False, g
     if chance:
         md.gaussian_set_parameters(pm, base, state[:2], obs, ROBOT_RADIUS, risk=0.05)    # settings.yaml probabilistic/risk
     if n_decomp:
-        md.halfspace_rows_set_parameters(pm, base, state[0], decomp_corridor(rng, segs, state, N, n_decomp),
-                                         "disc_0_decomp", n_decomp)
+        corridor = decomp_corridor(rng, segs, state, N, n_decomp)
+        md.halfspace_rows_set_parameters(pm, base, state[0], corridor, "disc_0_decomp", n_decomp)
     samples = scenario_samples(rng, pos0, vel, N, n_samples) if n_scenario else None
     main_x0 = md.initialize_with_forward_propagation(state, N, DT, nv)
 
@@ -139,35 +199,56 @@ def make_scene(scene_idx, N=20, M=8, B=64, S=5, tmpc_pp=False, gaussian=False, g
     guidance_id = np.zeros(Bt, np.int32)
     T = N * DT; t = np.arange(N + 1) * DT
     v_ref = WEIGHTS["reference_velocity"]
-    # longitudinal profile: accelerate from the current speed to v_ref within t_acc, then cruise
-    t_acc = 1.5
-    vx = state[3] + (v_ref - state[3]) * np.minimum(t / t_acc, 1.0)
-    xs = np.where(t < t_acc, state[3] * t + 0.5 * (v_ref - state[3]) * t * t / t_acc,
-                  state[3] * t_acc + 0.5 * (v_ref - state[3]) * t_acc + v_ref * (t - t_acc))
     amps = np.linspace(-A_MAX, A_MAX, B) + rng.normal(0.0, 0.05, B) if B > 1 else np.array([rng.normal(0.0, 0.5)])
-    clearance = OBSTACLE_RADIUS + ROBOT_RADIUS + 0.1
+    # inflated obstacle radius per prediction step (Gaussian predictions: major sqrt(chi), ellipsoid_constraints.py:94-100)
+    rad = obs["major"] * np.sqrt(obs["chi"])[:, None] + OBSTACLE_RADIUS + ROBOT_RADIUS + 0.1          # [M][N]
+    r_samples = OBSTACLE_RADIUS + ROBOT_RADIUS + 0.05
+    # candidate pool of the scene: the B nominal profiles (amplitudes above, cruise at v_ref) followed by K random ones; a
+    # trajectory keeps its nominal profile if the robot can follow it and it clears every prediction, otherwise it takes the
+    # next unused pool member that does (what a guidance planner returns are collision-free, dynamically feasible paths)
+    K = 1024 if samples is None else 384
+    cA = np.concatenate([amps, rng.uniform(-A_MAX, A_MAX, K)])
+    cv = np.concatenate([np.full(B, v_ref), rng.uniform(0.6, 2.6, K)])
+    cta = np.concatenate([np.full(B, 1.5), rng.uniform(1.0, 3.0, K)])
+    csh = np.concatenate([np.zeros(B, int), rng.integers(0, 2, K)])
+    cpos, cvel = guidance_candidates(state, t, cA, cv, cta, csh)
+    reach = guidance_reachable(cpos, cvel, state)
+    if samples is not None:      # SH-MPC: clearance from every sampled scenario, not only from the mean prediction
+        cloud = samples[:, :, :N - 1, :].reshape(-1, N - 1, 2)
+        clear = np.full(B + K, np.inf)
+        for c0 in range(0, B + K, 32):                                   # chunked: [32][points][N-1]
+            dd = cpos[c0:c0 + 32, None, 1:N, :] - cloud[None]
+            clear[c0:c0 + 32] = np.sqrt((dd * dd).sum(-1)).min(axis=(1, 2)) - r_samples
+    else:
+        dd = cpos[:, None, 1:N, :] - obs["pos"][None, :, :N - 1, :]
+        clear = (np.sqrt((dd * dd).sum(-1)) - rad[None, :, :N - 1]).min(axis=(1, 2))
+    if n_decomp:                 # static obstacles: stay inside the free-space polytope of every stage (decomp rows, slack = 0)
+        da1, da2, db = corridor
+        inside = np.ones(B + K, bool)
+        for k in range(1, N):
+            live = ~np.isnan(da1[k])
+            val = cpos[:, k, 0:1] * da1[k][None, live] + cpos[:, k, 1:2] * da2[k][None, live] - db[k][None, live]
+            inside &= (val <= -0.05).all(axis=1)
+        clear = np.where(inside, clear, np.minimum(clear, -1e-3))
+    good = reach & (clear >= 0.0)
+    spare = [int(i) for i in np.nonzero(good[B:])[0] + B]
+    fallback = int(np.argmax(np.where(reach, clear, -np.inf))) if reach.any() else 0
     for b in range(B):
-        best = None
-        for attempt in range(200 if samples is None else 40):
-            A = amps[b] if attempt == 0 else rng.uniform(-A_MAX, A_MAX)
-            # lateral profile A sin^2(pi t/T): leaves and rejoins the path tangentially
-            gpos = np.stack([xs, A * np.sin(np.pi * t / T) ** 2], 1)
-            gvel = np.stack([vx, A * np.pi / T * np.sin(2 * np.pi * t / T)], 1)
-            if samples is not None:      # SH-MPC: clearance from every sampled scenario, not only from the mean prediction
-                d = np.sqrt(((gpos[None, None, 1:N, :] - samples[:, :, :N - 1, :]) ** 2).sum(-1)).min()
-            else:
-                d = np.linalg.norm(gpos[None, 1:N, :] - obs["pos"][:, :N - 1, :], axis=2).min()
-            if best is None or d > best[0]:
-                best = (d, gpos, gvel)
-            if d >= clearance:
-                break
+        if good[b]:
+            pick = b
+        elif spare:
+            pick = spare.pop(0)
+        else:
+            pick = fallback
+        best = (clear[pick], cpos[pick], cvel[pick])
         _, gpos, gvel = best
+        gpos = gpos.copy()
         # stand-in for LinearizedConstraints::projectToSafety (linearized_constraints.cpp:130-148; the
         # Douglas-Rachford projection lives in ros_tools, source absent): if no sampled guidance keeps
         # r + robot_radius from every obstacle prediction, push the offending points radially out so the
         # reference's projection would be the identity on what we hand to the solver.
         r_min = 1e-3 + ROBOT_RADIUS + 1e-6
-        for _sweep in range(50):
+        for _sweep in range(50 if best[0] < 0.0 else 0):           # (a candidate that clears every prediction needs no push-out)
             moved = False
             for k in range(1, N):
                 for j in range(M):
@@ -181,7 +262,7 @@ def make_scene(scene_idx, N=20, M=8, B=64, S=5, tmpc_pp=False, gaussian=False, g
                 break
         if samples is not None:            # same stand-in against every sampled scenario (radius of the scenario rows)
             r_s = OBSTACLE_RADIUS + ROBOT_RADIUS + 1e-3
-            for k in range(1, N):
+            for k in range(1, N if best[0] < 0.0 else 1):
                 cloud = samples[:, :, k - 1, :].reshape(-1, 2)
                 for _sweep in range(60):
                     dvec = gpos[k] - cloud

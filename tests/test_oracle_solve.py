@@ -132,8 +132,14 @@ def test_find_best_planner_semantics():
 
 def test_infeasible_guess_reports_qp_failure():
     sc = scenes.make_scene(2, N=N, M=M, B=64)
+    pm = sc["pm"]
+    for b in (3, 10, 40):               # contradictory topology rows: x <= x_k - 5 and x >= x_k + 5 (no feasible QP point)
+        for j, sg in ((0, 1.0), (1, -1.0)):
+            sc["params"][b, 1:, pm.index(f"lin_constraint_{j}_a1")] = sg
+            sc["params"][b, 1:, pm.index(f"lin_constraint_{j}_a2")] = 0.0
+            sc["params"][b, 1:, pm.index(f"lin_constraint_{j}_b")] = sg * sc["x0"][b, 1:-1, 2] - 5.0
     pb = O.problem(N=N, S=S, n_lin=M, M=M)
     xt, ut, info = O.solve_batch(pb, sc["xinit"], sc["x0"].reshape(64, -1), sc["params"].reshape(64, -1))
-    assert (info["exit_code"] == 4).any() and (info["exit_code"] == 1).any()
+    assert (info["exit_code"][[3, 10, 40]] == 4).all() and (info["exit_code"] == 1).sum() >= 50
     bad = info["exit_code"] == 4
     assert (info["qp_status"][bad] != 0).all() or (info["res_eq"][bad] > 1e-2).all()
