@@ -29,3 +29,20 @@ int orc_find_best(int B, const double *objective, const int *exit_code, const un
     }
     return best_index;
 }
+
+/* Same batch loop, additionally recording the interior-point iterations of every QP: qp_iters[B][n_sqp] (0 = QP not reached). */
+void orc_set_qp_iter_trace(int *per_sqp_iteration);
+void orc_solve_batch_trace(const orc_problem *pb, int B, const double *xinit, const double *x0,
+                           const double *params, double *xtraj, double *utraj, orc_info *info, int num_threads, int *qp_iters)
+{
+    const size_t n_x0 = (size_t)(pb->N + 1) * ORC_NVE, n_par = (size_t)pb->N * pb->npar;
+    const size_t n_xt = (size_t)(pb->N + 1) * ORC_NXE, n_ut = (size_t)pb->N * ORC_NU;
+#pragma omp parallel for num_threads(num_threads) schedule(dynamic, 1)
+    for (int b = 0; b < B; b++) {
+        for (int i = 0; i < pb->n_sqp; i++) qp_iters[(size_t)b * pb->n_sqp + i] = 0;
+        orc_set_qp_iter_trace(&qp_iters[(size_t)b * pb->n_sqp]);
+        orc_solve(pb, &xinit[(size_t)b * ORC_NXE], &x0[b * n_x0], &params[b * n_par],
+                  &xtraj[b * n_xt], &utraj[b * n_ut], &info[b]);
+        orc_set_qp_iter_trace(0);
+    }
+}

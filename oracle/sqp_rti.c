@@ -140,6 +140,10 @@ static void build_qp(const orc_problem *pb, const nlp_state *st, const double *x
     for (int j = 0; j < ORC_NX; j++) qp->dx0[j] = xinit[j] - st->z[0][ORC_NU + j];      /* lbx_0 = ubx_0 = xinit :124-125 */
 }
 
+/* optional per-QP interior-point iteration trace of the calling thread (tests / workload statistics) */
+static __thread int *tls_qp_iter_trace = NULL;
+void orc_set_qp_iter_trace(int *per_sqp_iteration) { tls_qp_iter_trace = per_sqp_iteration; }
+
 void orc_solve_debug(const orc_problem *pb, const double *xinit, const double *x0, const double *params,
                      double *xtraj, double *utraj, orc_info *info, orc_debug *dbg, int capture_sqp_iter)
 {
@@ -169,6 +173,7 @@ void orc_solve_debug(const orc_problem *pb, const double *xinit, const double *x
         build_qp(pb, st, xinit, params, qp, row_lo, row_hi, (dbg && it == capture_sqp_iter) ? dbg : 0, dslack);
         orc_qp_solve(qp, sol, pb->qp_iter_max, pb->qp_tol, pb->ipm_mu0, pb->ipm_thr0);
         info->qp_status = sol->status; info->sqp_iter = it + 1; info->qp_iter_total += sol->iters;
+        if (tls_qp_iter_trace) tls_qp_iter_trace[it] = sol->iters;
         if (dbg && it == capture_sqp_iter) {
             for (int k = 0; k <= N; k++) {
                 for (int j = 0; j < ORC_NV; j++) dbg->dz[k * ORC_NV + j] = sol->v[k][j];

@@ -152,6 +152,10 @@ void orc_solve_debug(const orc_problem *pb, const double *xinit, const double *x
 void orc_solve_batch(const orc_problem *pb, int B, const double *xinit, const double *x0,
                      const double *params, double *xtraj, double *utraj, orc_info *info, int num_threads);
 
+/* Same, recording the interior-point iterations of every QP in qp_iters[B][n_sqp] (workload statistics for DESIGN.md). */
+void orc_solve_batch_trace(const orc_problem *pb, int B, const double *xinit, const double *x0,
+                           const double *params, double *xtraj, double *utraj, orc_info *info, int num_threads, int *qp_iters);
+
 /* FindBestPlanner (guidance_constraints.cpp:416-434): argmin of objective*weight over enabled &
  * success; init 1e10, strict '<' => lowest index wins ties; -1 if none. */
 int orc_find_best(int B, const double *objective, const int *exit_code, const unsigned char *disabled);
