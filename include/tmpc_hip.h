@@ -100,6 +100,14 @@ int tmpc_synchronize(tmpc_handle *h);
  * 0, or 1 if the handle's shape has no separate latency variant (the default kernel is used).  A trajectory's result
  * is bitwise independent of the batch it is solved in; the two variants agree to rounding (1e-11), not bitwise. */
 int tmpc_set_latency_mode(tmpc_handle *h, int32_t on);
+/* Throughput variant for large batches (many control ticks / scenario solvers per launch): one LANE per trajectory instead of
+ * one wavefront -- every lane runs the scalar SQP_RTI program on its own trajectory, the per-trajectory state is streamed from a
+ * lane-major HBM workspace (allocated for B_max trajectories on the first call: about 8 (N+1) (175 + 6 nh) + 8 N npar bytes
+ * each), and the reference-layout inputs are transposed into it at the start of every tmpc_solve.  Same algorithm and stopping
+ * rules as the default kernels: exit codes and iteration counts agree, trajectories agree to rounding (1e-10), and a
+ * trajectory's result does not depend on the rest of the batch.  The default (0) stays the choice for control ticks of a few
+ * planners; the mode is chosen by the caller, never by the batch size.  Returns 0, or <0 if the workspace cannot be allocated. */
+int tmpc_set_throughput_mode(tmpc_handle *h, int32_t on);
 
 /* Replaces ocp_nlp_out_get / ocp_nlp_get / ocp_nlp_eval_cost of completeOneIteration (:162-204).
  * Any pointer may be NULL.  Synchronises the stream.  Host pointers. */

@@ -16,12 +16,13 @@ from . import emit
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(HERE), "csrc", "tmpc_solve.hip")
+CSRC_LANES = os.path.join(os.path.dirname(HERE), "csrc", "tmpc_lanes.hip")      # second translation unit (throughput kernels)
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 
 def _compile(header, out, extra):
     cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-mllvm", "-disable-machine-licm",
-           "-Rpass-analysis=kernel-resource-usage", f'-DTMPC_GENERATED_STAGE="{header}"', *extra, "-o", out, CSRC]
+           "-Rpass-analysis=kernel-resource-usage", f'-DTMPC_GENERATED_STAGE="{header}"', *extra, "-o", out, CSRC, CSRC_LANES]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError("hipcc failed:\n" + res.stderr[-4000:])
@@ -32,7 +33,7 @@ def _compile(header, out, extra):
             name = m.group(1)
         for key, pat in (("vgprs", r"\bVGPRs: (\d+)"), ("agprs", r"AGPRs: (\d+)"), ("scratch", r"ScratchSize \[bytes/lane\]: (\d+)")):
             m = re.search(pat, line)
-            if m and name and "tmpc_solve" in name:
+            if m and name and ("tmpc_solve" in name or "lanes_solve" in name):
                 usage.setdefault(name, {})[key] = int(m.group(1))
     return usage
 

@@ -31,6 +31,7 @@
 
 #include "../../include/tmpc_hip.h"
 #include "tmpc_stage.hpp"
+#include "tmpc_lanes_api.hpp"
 
 namespace tmpc {
 
@@ -729,6 +730,8 @@ struct tmpc_handle {
     int threads = tmpc::NT;          // threads per trajectory (64, or 128 for the two-wave fast variant)
     tmpc::SolveKernel kernel_lat = nullptr;   // optional latency variant (128 threads), used when latency_mode is on
     bool latency_mode = false;
+    bool throughput_mode = false;             // lane-per-trajectory kernels (tmpc_lanes.hip) instead of one wave per trajectory
+    tmpc::lanes::Context *lanes = nullptr;    // their HBM workspace, created when the mode is first enabled
     bool fast = false;
     std::vector<hipEvent_t> ev;      // per-launch timing events (pairs)
     int ev_used = 0;
@@ -851,6 +854,7 @@ void tmpc_destroy(tmpc_handle *h)
                     h->exit_code, h->qp_status, h->sqp_iter, h->qp_iter, h->d_best, h->d_disabled};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &e : h->ev) (void)hipEventDestroy(e);
+    tmpc::lanes::destroy(h->lanes);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -882,6 +886,15 @@ int tmpc_solve(tmpc_handle *h)
     TMPC_HIP_CHECK(h, hipSetDevice(h->device));
     const bool rec = h->timing && h->ev_used + 2 <= (int)h->ev.size();
     if (rec) TMPC_HIP_CHECK(h, hipEventRecord(h->ev[h->ev_used], h->stream));
+    if (h->throughput_mode) {
+        // lane-per-trajectory variant: transpose the reference-layout inputs into the lane-major workspace (fresh solver state),
+        // then one launch of the scalar-per-lane SQP_RTI program
+        if (tmpc::lanes::stage_in(h->lanes, h->stream, h->B, h->xinit, h->x0, h->params, true, h->err)) return TMPC_ERR_HIP;
+        if (tmpc::lanes::solve(h->lanes, h->stream, h->B, h->d.n_sqp, h->xtraj, h->utraj, h->pobj, h->exit_code, h->qp_status,
+                               h->sqp_iter, h->res_eq, h->qp_iter, h->err)) return TMPC_ERR_HIP;
+        if (rec) { TMPC_HIP_CHECK(h, hipEventRecord(h->ev[h->ev_used + 1], h->stream)); h->ev_used += 2; }
+        return TMPC_OK;
+    }
     const bool lat = h->kernel_lat && h->latency_mode;
     hipLaunchKernelGGL(lat ? h->kernel_lat : h->kernel, dim3(h->B), dim3(lat ? 128 : h->threads), h->lds_bytes, h->stream, h->d, h->B,
                        h->xinit, h->x0, h->params, h->xtraj, h->utraj, h->pobj, h->exit_code, h->qp_status,
@@ -896,6 +909,18 @@ int tmpc_set_latency_mode(tmpc_handle *h, int32_t on)
     if (!h) return TMPC_ERR_INVALID;
     h->latency_mode = on != 0;
     return (h->latency_mode && !h->kernel_lat) ? 1 : TMPC_OK;      // 1: accepted, but this shape has no latency variant
+}
+
+int tmpc_set_throughput_mode(tmpc_handle *h, int32_t on)
+{
+    if (!h) return TMPC_ERR_INVALID;
+    if (on && !h->lanes) {
+        TMPC_HIP_CHECK(h, hipSetDevice(h->device));
+        h->lanes = tmpc::lanes::create(h->d, h->B_max, h->err);
+        if (!h->lanes) return TMPC_ERR_HIP;
+    }
+    h->throughput_mode = on != 0;
+    return TMPC_OK;
 }
 
 int tmpc_synchronize(tmpc_handle *h)

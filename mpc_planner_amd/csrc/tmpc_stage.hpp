@@ -29,6 +29,18 @@
 #include TMPC_GENERATED_STAGE
 #endif
 
+// The stage functions are plain per-lane arithmetic: they are compiled for the device (all kernels) and, with the same
+// source, for the host -- the host instantiation exists only for tests/cpu_twin (a test-side re-run of the lane-per-trajectory
+// kernel's scalar program, used to debug it against the oracle without a GPU); the product never calls it.
+#define TMPC_HD __host__ __device__ __forceinline__
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TMPC_RSQ_SEED(x) __builtin_amdgcn_rsq(x)      // v_rsq_f64 / v_rcp_f64 seeds, refined by Newton steps below
+#define TMPC_RCP_SEED(x) __builtin_amdgcn_rcp(x)
+#else
+#define TMPC_RSQ_SEED(x) (1.0 / sqrt(x))
+#define TMPC_RCP_SEED(x) (1.0 / (x))
+#endif
+
 namespace tmpc {
 
 constexpr int NU = 2, NX = 5, NV = 7, NP28 = 28;
@@ -52,27 +64,27 @@ __host__ inline void derive_dims(Dims &d)
     d.erk_h = d.dt / d.erk_steps; d.erk_eta = 0.5 * d.erk_h; d.erk_w6 = d.erk_h / 6.0;
     d.hdt2 = 0.5 * d.dt * d.dt;
 }
-__host__ __device__ __forceinline__ int ext_nx(const Dims &d) { return NX + d.slack; }   // strides of xinit / xtraj
-__host__ __device__ __forceinline__ int ext_nv(const Dims &d) { return NV + d.slack; }   // stride of x0
+__host__ TMPC_HD int ext_nx(const Dims &d) { return NX + d.slack; }   // strides of xinit / xtraj
+__host__ TMPC_HD int ext_nv(const Dims &d) { return NV + d.slack; }   // stride of x0
 
 // packed lower-triangular index of a symmetric 7x7: (i >= j)
-__host__ __device__ __forceinline__ constexpr int pidx(int i, int j) { return i * (i + 1) / 2 + j; }
-__host__ __device__ __forceinline__ constexpr int sidx(int i, int j) { return i >= j ? pidx(i, j) : pidx(j, i); }
+__host__ TMPC_HD constexpr int pidx(int i, int j) { return i * (i + 1) / 2 + j; }
+__host__ TMPC_HD constexpr int sidx(int i, int j) { return i >= j ? pidx(i, j) : pidx(j, i); }
 
 // ---- parameter index map (reference rule: util/parameters.py:25-55, solver_definition.py:5-16) ----------
 // weights: acceleration, angular_velocity, [slack,] velocity, reference_velocity, contour, lag, terminal_angle,
 // terminal_contouring; then 9 per spline segment; topology rows; [ego_disc_radius, ego_disc_0_offset, 7 per ellipsoid];
 // [ego_disc_0_offset unless the ellipsoid module defined it,] 3 per slack row (scenario rows before decomp rows).
-__host__ __device__ __forceinline__ int ip_spline(const Dims &d, int seg, int which) { return 8 + d.slack + 9 * seg + which; }
-__host__ __device__ __forceinline__ int ip_lin(const Dims &d, int j, int which) { return 8 + d.slack + 9 * d.S + 3 * j + which; }
-__host__ __device__ __forceinline__ int ip_disc_radius(const Dims &d) { return 8 + d.slack + 9 * d.S + 3 * d.n_lin; }
-__host__ __device__ __forceinline__ int ip_disc_offset(const Dims &d) { return ip_disc_radius(d) + (d.M > 0 ? 1 : 0); }
-__host__ __device__ __forceinline__ int ip_ellipsoid(const Dims &d, int j, int which) { return ip_disc_radius(d) + 2 + 7 * j + which; }
-__host__ __device__ __forceinline__ int ip_slk(const Dims &d, int j, int which)
+__host__ TMPC_HD int ip_spline(const Dims &d, int seg, int which) { return 8 + d.slack + 9 * seg + which; }
+__host__ TMPC_HD int ip_lin(const Dims &d, int j, int which) { return 8 + d.slack + 9 * d.S + 3 * j + which; }
+__host__ TMPC_HD int ip_disc_radius(const Dims &d) { return 8 + d.slack + 9 * d.S + 3 * d.n_lin; }
+__host__ TMPC_HD int ip_disc_offset(const Dims &d) { return ip_disc_radius(d) + (d.M > 0 ? 1 : 0); }
+__host__ TMPC_HD int ip_ellipsoid(const Dims &d, int j, int which) { return ip_disc_radius(d) + 2 + 7 * j + which; }
+__host__ TMPC_HD int ip_slk(const Dims &d, int j, int which)
 {
     return (d.M > 0 ? ip_disc_radius(d) + 2 + 7 * d.M : ip_disc_radius(d) + 1) + 3 * j + which;
 }
-__host__ __device__ __forceinline__ int expected_npar(const Dims &d)
+__host__ TMPC_HD int expected_npar(const Dims &d)
 {
 #ifdef TMPC_GENERATED_STAGE
     (void)d;
@@ -95,7 +107,7 @@ struct DynOut {
     double Yaw, Yap, Yww, Ywp, Ywv, Ypp, Ypv;
 };
 
-__device__ __forceinline__ void dyn_eval(const Dims &d, const double *z, DynOut &o, bool second_order)
+TMPC_HD void dyn_eval(const Dims &d, const double *z, DynOut &o, bool second_order)
 {
     const double a = z[ZA], w = z[ZW], psi = z[ZPSI], v = z[ZV];
     const double eta = d.erk_eta, w6 = d.erk_w6;
@@ -128,7 +140,7 @@ __device__ __forceinline__ void dyn_eval(const Dims &d, const double *z, DynOut 
 }
 
 // [B A] (5 x 7, row-major), columns ordered like z
-__device__ __forceinline__ void dyn_jacobian(const Dims &d, const DynOut &o, double *BA)
+TMPC_HD void dyn_jacobian(const Dims &d, const DynOut &o, double *BA)
 {
 #pragma unroll
     for (int i = 0; i < NX * NV; i++) BA[i] = 0.0;
@@ -140,7 +152,7 @@ __device__ __forceinline__ void dyn_jacobian(const Dims &d, const DynOut &o, dou
 }
 
 // W += pix * hess(x+) + piy * hess(y+)   (W full symmetric 7x7)
-__device__ __forceinline__ void dyn_add_hessian(const DynOut &o, double pix, double piy, double (*W)[NV])
+TMPC_HD void dyn_add_hessian(const DynOut &o, double pix, double piy, double (*W)[NV])
 {
     auto add = [&](int i, int j, double val) { W[i][j] += val; W[j][i] += val; };
     add(ZA, ZW, pix * o.Xaw + piy * o.Yaw);
@@ -156,37 +168,37 @@ __device__ __forceinline__ void dyn_add_hessian(const DynOut &o, double pix, dou
 // Cost.  One-variable second-order Taylor triples in s for everything that depends on the spline only.
 // =============================================================================================
 struct J1 { double v, d1, d2; };
-__device__ __forceinline__ J1 j_add(J1 a, J1 b) { return {a.v + b.v, a.d1 + b.d1, a.d2 + b.d2}; }
-__device__ __forceinline__ J1 j_sub(J1 a, J1 b) { return {a.v - b.v, a.d1 - b.d1, a.d2 - b.d2}; }
-__device__ __forceinline__ J1 j_mul(J1 a, J1 b)
+TMPC_HD J1 j_add(J1 a, J1 b) { return {a.v + b.v, a.d1 + b.d1, a.d2 + b.d2}; }
+TMPC_HD J1 j_sub(J1 a, J1 b) { return {a.v - b.v, a.d1 - b.d1, a.d2 - b.d2}; }
+TMPC_HD J1 j_mul(J1 a, J1 b)
 {
     return {a.v * b.v, a.v * b.d1 + a.d1 * b.v, a.v * b.d2 + 2.0 * a.d1 * b.d1 + a.d2 * b.v};
 }
-__device__ __forceinline__ J1 j_chain(J1 a, double f, double f1, double f2)
+TMPC_HD J1 j_chain(J1 a, double f, double f1, double f2)
 {
     return {f, f1 * a.d1, f1 * a.d2 + f2 * a.d1 * a.d1};
 }
 
 // spline.py:16-22 segment value / derivative as triples in s
-__device__ __forceinline__ J1 seg_at(double a, double b, double c, double dd, double t)
+TMPC_HD J1 seg_at(double a, double b, double c, double dd, double t)
 {
     return {((a * t + b) * t + c) * t + dd, (3.0 * a * t + 2.0 * b) * t + c, 6.0 * a * t + 2.0 * b};
 }
-__device__ __forceinline__ J1 seg_deriv(double a, double b, double c, double t)
+TMPC_HD J1 seg_deriv(double a, double b, double c, double t)
 {
     return {(3.0 * a * t + 2.0 * b) * t + c, 6.0 * a * t + 2.0 * b, 6.0 * a};
 }
 
 #ifdef TMPC_GENERATED_STAGE
 struct CostOut { double val; double g[NV]; double H[NP28]; };      // dense packed Hessian from the generated code
-__device__ __forceinline__ void cost_eval(const Dims &d, const double *z, const double *p, int pstride, CostOut &o,
+TMPC_HD void cost_eval(const Dims &d, const double *z, const double *p, int pstride, CostOut &o,
                                           bool derivs, double slack = 0.0)
 {
     (void)d;
     if (derivs) tmpc_gen::cost_full(z, p, pstride, slack, &o.val, o.g, o.H);
     else tmpc_gen::cost_value(z, p, pstride, slack, &o.val);
 }
-__device__ __forceinline__ void cost_add_hessian(const CostOut &o, double scale, double (*W)[NV])
+TMPC_HD void cost_add_hessian(const CostOut &o, double scale, double (*W)[NV])
 {
 #pragma unroll
     for (int i = 0; i < NV; i++)
@@ -202,7 +214,7 @@ struct CostOut { double val; double g[NV]; double Hxx, Hxy, Hyy, Hxs, Hys, Hss, 
 
 // p: this stage's parameter row, element i at p[i * pstride]
 // slack: the trajectory's (constant) slack value, 0 without the slack model
-__device__ __forceinline__ void cost_eval(const Dims &d, const double *z, const double *p, int pstride, CostOut &o,
+TMPC_HD void cost_eval(const Dims &d, const double *z, const double *p, int pstride, CostOut &o,
                                           bool derivs, double slack = 0.0)
 {
     auto P = [&](int i) { return p[(size_t)i * pstride]; };
@@ -275,7 +287,7 @@ __device__ __forceinline__ void cost_eval(const Dims &d, const double *z, const 
 }
 
 // W += scale * hess(cost)
-__device__ __forceinline__ void cost_add_hessian(const CostOut &o, double scale, double (*W)[NV])
+TMPC_HD void cost_add_hessian(const CostOut &o, double scale, double (*W)[NV])
 {
     W[ZA][ZA] += scale * o.Haa; W[ZW][ZW] += scale * o.Hww; W[ZV][ZV] += scale * o.Hvv;
     W[ZX][ZX] += scale * o.Hxx; W[ZY][ZY] += scale * o.Hyy; W[ZS][ZS] += scale * o.Hss;
@@ -292,7 +304,7 @@ __device__ __forceinline__ void cost_add_hessian(const CostOut &o, double scale,
 // =============================================================================================
 struct RowOut { double h; double gx, gy, gp; double Hxx, Hxy, Hyy, Hxp, Hyp, Hpp; };
 
-__device__ __forceinline__ void lin_row_eval(const Dims &d, const double *z, const double *p, int pstride, int j, RowOut &o)
+TMPC_HD void lin_row_eval(const Dims &d, const double *z, const double *p, int pstride, int j, RowOut &o)
 {
     const double a1 = p[(size_t)ip_lin(d, j, 0) * pstride], a2 = p[(size_t)ip_lin(d, j, 1) * pstride];
     const double b = p[(size_t)ip_lin(d, j, 2) * pstride];
@@ -301,7 +313,7 @@ __device__ __forceinline__ void lin_row_eval(const Dims &d, const double *z, con
     o.Hxx = o.Hxy = o.Hyy = o.Hxp = o.Hyp = o.Hpp = 0.0;
 }
 
-__device__ __forceinline__ void ellipsoid_row_eval(const Dims &d, const double *z, const double *p, int pstride, int j,
+TMPC_HD void ellipsoid_row_eval(const Dims &d, const double *z, const double *p, int pstride, int j,
                                                    double r_disc, double off, double spsi, double cpsi, RowOut &o)
 {
     auto P = [&](int w) { return p[(size_t)ip_ellipsoid(d, j, w) * pstride]; };
@@ -328,7 +340,7 @@ __device__ __forceinline__ void ellipsoid_row_eval(const Dims &d, const double *
 
 // decomp / scenario halfspace (decomp_constraints.py:86-96, scenario_constraints.py:82-92):
 //   a1 (x + off cos psi) + a2 (y + off sin psi) - (b + slack)  <= 0
-__device__ __forceinline__ void slk_row_eval(const Dims &d, const double *z, const double *p, int pstride, int j, double off,
+TMPC_HD void slk_row_eval(const Dims &d, const double *z, const double *p, int pstride, int j, double off,
                                              double spsi, double cpsi, double slack, RowOut &o)
 {
     const double a1 = p[(size_t)ip_slk(d, j, 0) * pstride], a2 = p[(size_t)ip_slk(d, j, 1) * pstride];
@@ -339,7 +351,7 @@ __device__ __forceinline__ void slk_row_eval(const Dims &d, const double *z, con
     o.Hpp = -off * (a1 * cpsi + a2 * spsi);
 }
 
-__device__ __forceinline__ void row_add_hessian(const RowOut &o, double scale, double (*W)[NV])
+TMPC_HD void row_add_hessian(const RowOut &o, double scale, double (*W)[NV])
 {
     W[ZX][ZX] += scale * o.Hxx; W[ZY][ZY] += scale * o.Hyy; W[ZPSI][ZPSI] += scale * o.Hpp;
     W[ZX][ZY] += scale * o.Hxy; W[ZY][ZX] += scale * o.Hxy;
@@ -353,17 +365,17 @@ __device__ __forceinline__ void row_add_hessian(const RowOut &o, double scale, d
 // =============================================================================================
 // 1/sqrt(x), 1/x for x > 0: hardware seed + two Newton steps (full double precision, ~8 / ~6 VALU ops instead of the
 // ~35-instruction IEEE sqrt / divide sequences)
-__device__ __forceinline__ double st_rsqrt(double x)
+TMPC_HD double st_rsqrt(double x)
 {
-    double y = __builtin_amdgcn_rsq(x);
+    double y = TMPC_RSQ_SEED(x);
     const double hx = 0.5 * x;
     y = y * (1.5 - hx * y * y);
     y = y * (1.5 - hx * y * y);
     return y;
 }
-__device__ __forceinline__ double st_rcp(double x)
+TMPC_HD double st_rcp(double x)
 {
-    double y = __builtin_amdgcn_rcp(x);
+    double y = TMPC_RCP_SEED(x);
     y = y * (2.0 - x * y);
     y = y * (2.0 - x * y);
     return y;
@@ -371,7 +383,7 @@ __device__ __forceinline__ double st_rcp(double x)
 
 // MIRROR of an n x n symmetric matrix held in registers (fully unrolled cyclic Jacobi): A <- V max(|e|, eps) V^T.
 template <int NN>
-__device__ __forceinline__ void mirror_n(double (&A)[NN][NN], double eps)
+TMPC_HD void mirror_n(double (&A)[NN][NN], double eps)
 {
     double V[NN][NN];
 #pragma unroll
@@ -441,7 +453,7 @@ __device__ __forceinline__ void mirror_n(double (&A)[NN][NN], double eps)
 // the Lagrangian Hessian is block diagonal under the permutation {a, w, psi, v} | {x, y, spline} (dynamics curvature
 // couples the first set, contouring cost + ellipsoids the second): the two blocks are then regularised separately
 // (same result, ~half the rotations' work); any coupling entry != 0 falls back to the full 7x7 iteration.
-__device__ __forceinline__ void mirror7(double (*A)[NV], double eps)
+TMPC_HD void mirror7(double (*A)[NV], double eps)
 {
     constexpr int IA[4] = {ZA, ZW, ZPSI, ZV}, IB[3] = {ZX, ZY, ZS};
     bool coupled = false;
@@ -487,7 +499,7 @@ __device__ __forceinline__ void mirror7(double (*A)[NV], double eps)
 // plus the linearisation data of the stage.  lamh(r) is supplied by a functor (zero for inactive rows).
 // Rows are numbered in the kernels' internal order [topology | slack rows | ellipsoids] (upper-bounded rows first).
 template <typename LamH, typename RowSink>
-__device__ __forceinline__ void stage_linearise(const Dims &d, const double *z, const double *p, int pstride,
+TMPC_HD void stage_linearise(const Dims &d, const double *z, const double *p, int pstride,
                                                 double pix, double piy, LamH lamh, RowSink sink,
                                                 double (*W)[NV], double *g, double *BA, double *xn, double slack = 0.0,
                                                 double *stash = nullptr)

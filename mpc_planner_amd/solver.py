@@ -40,7 +40,7 @@ EXPORTS = ["tmpc_default_dims", "tmpc_default_dims_ex", "tmpc_create", "tmpc_des
            "tmpc_result_device_ptrs", "tmpc_time_solve", "tmpc_debug_eval_stage", "tmpc_pack_records",
            "tmpc_select_best_records", "tmpc_enable_timing", "tmpc_get_timings", "tmpc_debug_profile",
            "tmpc_linearize_topology", "tmpc_scenario_halfspaces", "tmpc_warmstart", "tmpc_init_with_guidance",
-           "tmpc_debug_get_x0", "tmpc_debug_get_params"]
+           "tmpc_debug_get_x0", "tmpc_debug_get_params", "tmpc_set_throughput_mode"]
 
 class TmpcError(RuntimeError):
     pass
@@ -70,6 +70,7 @@ def load_library(path=None):
     lib.tmpc_set_batch_device.argtypes = [vp, C.c_int32, vp, vp, vp]
     lib.tmpc_solve.argtypes = [vp]
     lib.tmpc_set_latency_mode.argtypes = [vp, C.c_int32]
+    lib.tmpc_set_throughput_mode.argtypes = [vp, C.c_int32]
     lib.tmpc_synchronize.argtypes = [vp]
     lib.tmpc_get.argtypes = [vp] + [vp] * 8
     lib.tmpc_select_best.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, C.POINTER(C.c_int32)]
@@ -166,6 +167,10 @@ class BatchedSolver:
         if rc < 0:
             self._check(rc, "tmpc_set_latency_mode")
         return rc == 0
+
+    def set_throughput_mode(self, on=True):
+        """Lane-per-trajectory kernels for large batches (allocates the HBM workspace for B_max trajectories on first use)."""
+        self._check(self.lib.tmpc_set_throughput_mode(self._h, int(bool(on))), "tmpc_set_throughput_mode")
 
     def synchronize(self):
         self._check(self.lib.tmpc_synchronize(self._h), "tmpc_synchronize")

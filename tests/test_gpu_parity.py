@@ -182,6 +182,39 @@ def test_failure_paths_and_edge_batches():
     s.close()
 
 
+@pytest.mark.parametrize("cfg", ["cfg1", "cfg2", "cfg3", "cfg4", "cfg5"])
+def test_throughput_mode_matches_oracle(cfg):
+    """tmpc_set_throughput_mode: the lane-per-trajectory kernels (one lane per trajectory, state streamed from HBM) against the
+    oracle and against the default wave-per-trajectory kernels on the same batch; batches that are not a multiple of 64."""
+    import oracle_lib as O
+    from mpc_planner_amd import scenes
+    if cfg == "cfg1":
+        sc = scenes.make_batch(range(50, 59), N=20, M=4, B=1, guidance=False); pkw = dict(N=20, S=5, n_lin=0, M=4)
+    else:
+        mk, pkw = BASELINE_CASES[cfg]
+        sc = mk(scenes)
+    B = sc["xinit"].shape[0] - (3 if cfg == "cfg2" else 0)                 # ragged last block
+    xi, x0, pa = sc["xinit"][:B], sc["x0"][:B], sc["params"][:B]
+    s = _solver(B_max=B, **pkw)
+    s.set_batch(xi, x0, pa); s.solve(); wave = s.get()
+    s.set_throughput_mode(True)
+    s.set_batch(xi, x0, pa); s.solve(); got = s.get()
+    pb = O.problem(**pkw)
+    xt, ut, info = O.solve_batch(pb, xi, x0.reshape(B, -1), pa.reshape(B, -1))
+    _compare(got, xt, ut, info)
+    assert (got["exit_code"] == wave["exit_code"]).all() and (got["qp_iter_total"] == wave["qp_iter_total"]).all()
+    ok = info["exit_code"] == 1
+    np.testing.assert_allclose(got["xtraj"][ok], wave["xtraj"][ok], rtol=0, atol=1e-7)
+    # a trajectory's result does not depend on the rest of the batch: the first 5 alone, bitwise
+    s.set_batch(xi[:5], x0[:5], pa[:5]); s.solve(); alone = s.get()
+    np.testing.assert_array_equal(alone["xtraj"], got["xtraj"][:5])
+    _check_selection(s.select_best(), alone, {k: v[:5] for k, v in info.items()})
+    s.set_throughput_mode(False)
+    s.set_batch(xi, x0, pa); s.solve(); again = s.get()
+    np.testing.assert_array_equal(again["xtraj"], wave["xtraj"])             # switching back restores the default kernels
+    s.close()
+
+
 # ---- BASELINE.json sizes: every configuration at the batch size its config line names, HIP path vs oracle ----------------
 BASELINE_CASES = {
     # cfg 2: 64 guidance trajectories per tick; four ticks of the bench workload (scenes 0..3 of bench.py's launch)
