@@ -30,6 +30,6 @@ typedef struct {
     int status;                          /* 0 ok, 2 max iter, 3 min step, 4 NaN */
 } orc_qp_sol;
 
-void orc_qp_solve(const orc_qp *qp, orc_qp_sol *sol, int iter_max, double tol, double mu0, double thr0);
+void orc_qp_solve(const orc_qp *qp, orc_qp_sol *sol, int iter_max, double tol, double mu0, double thr0, double tau);
 
 #endif

@@ -181,7 +181,7 @@ static double max_step(const orc_qp *qp, const orc_qp_sol *s, const ipm_ws *w)
     return alpha;
 }
 
-void orc_qp_solve(const orc_qp *qp, orc_qp_sol *s, int iter_max, double tol, double mu0, double thr0)
+void orc_qp_solve(const orc_qp *qp, orc_qp_sol *s, int iter_max, double tol, double mu0, double thr0, double tau)
 {
     const int N = qp->N;
     /* per-thread workspace, reused across solves (a calloc/free pair per QP makes hundreds of OpenMP threads fight over
@@ -271,7 +271,7 @@ void orc_qp_solve(const orc_qp *qp, orc_qp_sol *s, int iter_max, double tol, dou
             for (int i = 0; i < qp->nrow[k]; i++)
                 w->q[k][i] = s->lam[k][i] * s->t[k][i] - sigma * mu + w->dt[k][i] * w->dlam[k][i];
         newton_direction(qp, s, w);
-        double alpha = 0.999 * max_step(qp, s, w); if (alpha > 1.0) alpha = 1.0;
+        double alpha = tau * max_step(qp, s, w); if (alpha > 1.0) alpha = 1.0;
         if (getenv("ORC_IPM_TRACE")) fprintf(stderr, "   a_aff %.3e sigma %.3e alpha %.3e\n", a_aff, sigma, alpha);
         if (!isfinite(alpha)) { s->status = 4; break; }
         if (alpha < 1e-12) { s->status = 3; break; }

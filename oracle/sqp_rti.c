@@ -171,7 +171,7 @@ void orc_solve_debug(const orc_problem *pb, const double *xinit, const double *x
     info->qp_status = 0; info->sqp_iter = 0; info->qp_iter_total = 0;
     for (int it = 0; it < pb->n_sqp; it++) {                        /* :99-117 */
         build_qp(pb, st, xinit, params, qp, row_lo, row_hi, (dbg && it == capture_sqp_iter) ? dbg : 0, dslack);
-        orc_qp_solve(qp, sol, pb->qp_iter_max, pb->qp_tol, pb->ipm_mu0, pb->ipm_thr0);
+        orc_qp_solve(qp, sol, pb->qp_iter_max, pb->qp_tol, pb->ipm_mu0, pb->ipm_thr0, pb->ipm_tau);
         info->qp_status = sol->status; info->sqp_iter = it + 1; info->qp_iter_total += sol->iters;
         if (tls_qp_iter_trace) tls_qp_iter_trace[it] = sol->iters;
         if (dbg && it == capture_sqp_iter) {

@@ -67,6 +67,7 @@ void orc_problem_init_ex(orc_problem *pb, int N, int S, int n_lin, int M, int n_
     pb->reg_eps = 1e-4;           /* [UPSTREAM] acados reg_epsilon default */
     pb->ipm_mu0 = 1e-2;           /* own IPM (any converged QP solver reproduces the unique QP solution); tuned: fewest iterations */
     pb->ipm_thr0 = 1e-2;
+    pb->ipm_tau = 0.999;
     pb->erk_steps = 3;            /* generate_acados_solver.py:150 */
     /* solver_model.py:204-205 ContouringSecondOrderUnicycleModel bounds, order [a,w,x,y,psi,v,spline] */
     const double lb[ORC_NV] = {-2.0, -0.8, -2000.0, -2000.0, -M_PI * 4, -0.01, -1.0};

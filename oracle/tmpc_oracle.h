@@ -76,6 +76,10 @@ typedef struct {
      * guidance submodule instead of the ellipsoids, generate_jackal_solver.py:53-73): rows >= 0, after the topology rows.
      * Only with M == 0 and n_slk == 0. */
     int n_gauss;
+    /* fraction-to-the-boundary factor of the interior-point step.  An ORACLE option on purpose: tests re-run the oracle with
+     * textbook interior-point constants (0.995, mu0 = thr0 = 1) to show that its RTI iterate -- which tests/independent_rti.py
+     * pins with an active-set QP solver -- does not depend on the constants the kernels were tuned with (0.999, 0.01, 0.01). */
+    double ipm_tau;
 } orc_problem;
 
 /* Fill sizes, default options and bounds for the Jackal contouring unicycle. */
