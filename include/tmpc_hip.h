@@ -95,6 +95,29 @@ int tmpc_set_batch_device(tmpc_handle *h, int32_t B, const void *d_xinit, const 
  * (:86-204) for all B trajectories: one kernel launch, asynchronous on the handle's stream. */
 int tmpc_solve(tmpc_handle *h);
 int tmpc_synchronize(tmpc_handle *h);
+
+/* ---- persistent solver state: the "one iteration at a time" protocol and multipliers carried across ticks ---------------
+ * The reference's capsules keep the NLP iterate and its multipliers between calls: Solver::solveOneIteration() = ONE
+ * Solver_acados_solve continuing from them (acados_solver_interface.cpp:149-160; driven by SH-MPC's scenario module,
+ * scenario_constraints.cpp:85), Solver::operator= copies parameters only (:67-77), loadWarmstart() overwrites the primal iterate
+ * only (:274-284), and a solve that does not succeed resets the capsule (:187-191).  tmpc_solve_iterations does n_iter RTI
+ * iterations for every trajectory slot of the current batch and then completeOneIteration (so tmpc_get is valid after every
+ * call), starting
+ *   from the batch's warm start x0 and zero multipliers                      flags = 0            (a fresh capsule)
+ *   from the iterate the handle holds for the slot (no loadWarmstart)         TMPC_ITER_KEEP_ITERATE
+ *   with the multipliers the handle holds for the slot                        TMPC_ITER_KEEP_MULTIPLIERS
+ *   and, as the last call of a solve (completeOneIteration, :162-204)          TMPC_ITER_COMPLETE: slots whose exit code is
+ *                                                                             not 1 get zero multipliers (the capsule reset, :187-191)
+ * and stores iterate + multipliers of every slot afterwards.  A slot whose QP stopped with qp_status != 0 has left the reference's iteration loop (:105-106): further
+ * KEEP_ITERATE calls leave it untouched until a call without KEEP_ITERATE loads a new warm start.  n_iter calls with one
+ * iteration each give bitwise the same result as one call with n_iter.  The first call on a handle has nothing to keep and
+ * behaves like flags = 0.  tmpc_solve() itself never reads or writes this state. */
+#define TMPC_ITER_KEEP_ITERATE 1
+#define TMPC_ITER_KEEP_MULTIPLIERS 2
+#define TMPC_ITER_COMPLETE 4
+int tmpc_solve_iterations(tmpc_handle *h, int32_t n_iter, int32_t flags);
+/* Zero the multipliers of every slot (a new capsule / Solver_acados_reset). */
+int tmpc_reset_multipliers(tmpc_handle *h);
 /* Kernel variant for the following tmpc_solve calls: 0 (default) = throughput variant, 1 = latency variant (two waves per
  * trajectory; for control ticks of a few planners, like the 8 OpenMP threads of guidance_constraints.cpp:279).  Returns
  * 0, or 1 if the handle's shape has no separate latency variant (the default kernel is used).  A trajectory's result

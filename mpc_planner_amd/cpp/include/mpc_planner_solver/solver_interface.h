@@ -88,10 +88,14 @@ namespace MPCPlanner
         };
 
     private:
-        tmpc_handle *_handle{nullptr};          // replaces the acados capsule; created lazily on the first solve
+        tmpc_handle *_handle{nullptr};          // replaces the acados capsule; created lazily on the first solve.  Like the capsule
+                                                // it keeps the NLP iterate and its multipliers between calls (tmpc_solve_iterations)
         int _exit_code_one_iter{-1};
         int _device{0};
+        bool _warmstart_pending{true};          // loadWarmstart() since the last iteration: the next one starts from _params.x0
+        int _iterations_done{0};                // RTI iterations since initializeOneIteration
         void ensureHandle();
+        int runIterations(int n, bool complete);
 
     public:
         int _solver_id;
@@ -113,9 +117,11 @@ namespace MPCPlanner
         void reset();
 
         int solve();                            // :86-119
-        void initializeOneIteration();          // :121-143 (parameters are handed over at solve time)
-        int solveOneIteration();                // :145-160 (runs the whole fixed-budget solve)
-        int completeOneIteration();             // :162-204
+        void initializeOneIteration();          // :121-143 xinit + parameters to the device
+        int solveOneIteration();                // :145-160 exactly ONE RTI iteration, continuing from the iterate / multipliers the
+                                                //          handle holds (or from _params.x0 after loadWarmstart()); returns the acados-style
+                                                //          status (0, or 4 after a QP failure) and sets _info.qp_status
+        int completeOneIteration();             // :162-204 cost, trajectories, res_eq test, capsule reset on failure, exit-code mapping
 
         /* GuidanceConstraints::optimize batch path: solvers[i]->_params in, _output/_info out, exit codes returned */
         static std::vector<int> solveBatch(const std::vector<Solver *> &solvers);

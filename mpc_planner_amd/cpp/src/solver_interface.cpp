@@ -125,34 +125,56 @@ namespace MPCPlanner
     Solver &Solver::operator=(const Solver &rhs) { _params = rhs._params; return *this; }      // (:67-77)
     void Solver::reset() { _params = AcadosParameters(); _info = AcadosInfo(); _output = AcadosOutput(); }  // (:79-84)
 
-    // ---- solve (:86-204).  The RTI loop runs on the device with a fixed iteration budget (_num_iterations);
-    // the reference's wall-clock early exit (:111-116) is intentionally not reproduced (non-deterministic). ----
+    // ---- solve (:86-204).  The reference's wall-clock early exit (:111-116) is intentionally not reproduced (non-deterministic):
+    // the RTI loop has the fixed budget _num_iterations and runs in ONE launch; it is bitwise the same as the one-iteration
+    // protocol below (tests/test_gpu_iterations.py, tests/cpp/test_solver.cpp). ----
     int Solver::solve()
     {
         initializeOneIteration();
-        solveOneIteration();
+        runIterations(_num_iterations, true);
+        _iterations_done = 0;                                   // (sqp_iter of the call is the whole loop's count)
         return completeOneIteration();
     }
     void Solver::initializeOneIteration()
     {
         ensureHandle();
         _info = AcadosInfo();
+        _iterations_done = 0;
         if (tmpc_set_batch(_handle, 1, _params.xinit, _params.x0, _params.all_parameters)) {
             std::fprintf(stderr, "tmpc_set_batch: %s\n", tmpc_last_error(_handle)); std::exit(1);
         }
     }
+    // n RTI iterations from the capsule's state: multipliers always kept (the reference never clears them except after a failed
+    // solve), primal iterate kept unless loadWarmstart() asked for _params.x0 (:274-284)
+    int Solver::runIterations(int n, bool complete)
+    {
+        const int flags = TMPC_ITER_KEEP_MULTIPLIERS | (_warmstart_pending ? 0 : TMPC_ITER_KEEP_ITERATE) | (complete ? TMPC_ITER_COMPLETE : 0);
+        if (tmpc_solve_iterations(_handle, n, flags)) { std::fprintf(stderr, "tmpc_solve_iterations: %s\n", tmpc_last_error(_handle)); std::exit(1); }
+        if (n > 0) _warmstart_pending = false;
+        return 0;
+    }
     int Solver::solveOneIteration()
     {
-        if (tmpc_solve(_handle)) { std::fprintf(stderr, "tmpc_solve: %s\n", tmpc_last_error(_handle)); std::exit(1); }
-        return 0;
+        if (_iterations_done > 0 && _info.qp_status != 0) return _exit_code_one_iter == 1 ? 0 : 4;   // the loop has ended (:105-106)
+        runIterations(1, false);
+        int32_t exit_code = 0, qp_status = 0;
+        if (tmpc_get(_handle, nullptr, nullptr, nullptr, &exit_code, &qp_status, nullptr, nullptr, nullptr)) {
+            std::fprintf(stderr, "tmpc_get: %s\n", tmpc_last_error(_handle)); std::exit(1);
+        }
+        _iterations_done++;
+        _info.qp_status = qp_status;
+        _exit_code_one_iter = exit_code;
+        return (qp_status == 0 || qp_status == 2) ? 0 : 4;      // ACADOS_SUCCESS / ACADOS_QP_FAILURE (DESIGN U5)
     }
     int Solver::completeOneIteration()
     {
+        const int done = _iterations_done, last_qp = _info.qp_status;
+        if (done > 0) runIterations(0, true);                   // completeOneIteration of the one-iteration protocol: evaluation + reset on failure
         int32_t exit_code = 0, qp_status = 0, sqp_iter = 0, qp_it = 0; double res_eq = 0.;
         if (tmpc_get(_handle, _output.xtraj, _output.utraj, &_info.pobj, &exit_code, &qp_status, &sqp_iter, &res_eq, &qp_it)) {
             std::fprintf(stderr, "tmpc_get: %s\n", tmpc_last_error(_handle)); std::exit(1);
         }
-        _info.qp_status = qp_status; _info.sqp_iter = sqp_iter; _info.nlp_res = res_eq;
+        _info.qp_status = done > 0 ? last_qp : qp_status; _info.sqp_iter = done > 0 ? done : sqp_iter; _info.nlp_res = res_eq;
         _exit_code_one_iter = exit_code;
         return _exit_code_one_iter;
     }
@@ -188,7 +210,10 @@ namespace MPCPlanner
         const size_t nxt = (size_t)SOLVER_NX * (SOLVER_N + 1), nut = (size_t)SOLVER_NU * SOLVER_N;
         std::vector<double> xt(B * nxt), ut(B * nut), pobj(B), res(B);
         std::vector<int32_t> ec(B), qs(B), si(B), qi(B);
-        if (tmpc_set_batch(batch_handle, B, xinit.data(), x0.data(), par.data()) || tmpc_solve(batch_handle) ||
+        // slot b = solvers[b]: like the planners' own capsules, every slot keeps its multipliers from tick to tick (and loses them
+        // after a failed solve); GuidanceConstraints::optimize loads every planner's warm start (:337), so the iterate comes from x0
+        if (tmpc_set_batch(batch_handle, B, xinit.data(), x0.data(), par.data()) ||
+            tmpc_solve_iterations(batch_handle, s0->_num_iterations, TMPC_ITER_KEEP_MULTIPLIERS | TMPC_ITER_COMPLETE) ||
             tmpc_get(batch_handle, xt.data(), ut.data(), pobj.data(), ec.data(), qs.data(), si.data(), res.data(), qi.data())) {
             std::fprintf(stderr, "solveBatch: %s\n", tmpc_last_error(batch_handle)); std::exit(1);
         }
@@ -217,7 +242,8 @@ namespace MPCPlanner
     double Solver::getEgoPrediction(unsigned int k, std::string &&var_name) { return _params.x0[k * nvar + _model_map.at(var_name).index]; }
     void Solver::setEgoPredictionPosition(unsigned int k, const Vector2d &value) { setEgoPrediction(k, "x", value(0)); setEgoPrediction(k, "y", value(1)); }
     Vector2d Solver::getEgoPredictionPosition(unsigned int k) { return Vector2d(getEgoPrediction(k, "x"), getEgoPrediction(k, "y")); }
-    void Solver::loadWarmstart() { /* x0 travels with _params at solve time (tmpc_set_batch replaces ocp_nlp_out_set, :274-284) */ }
+    // (:274-284) ocp_nlp_out_set(x, u) from _params.x0: the next iteration starts from the warm start; the multipliers stay
+    void Solver::loadWarmstart() { _warmstart_pending = true; }
 
     void Solver::initializeWithState(const State &initial_state)          // (:286-301)
     {

@@ -265,6 +265,18 @@ __global__ void tmpc_init_with_guidance_kernel(Dims d, int B, const double *gpos
     z[ZV] = sqrt(vx * vx + vy * vy);
 }
 
+// ---- persistent state: a solve that did not succeed resets the reference's capsule (Solver_acados_reset + reset_qp_memory,
+// acados_solver_interface.cpp:187-191): the slot's multipliers go back to zero (the primal iterate is overwritten by the next
+// loadWarmstart anyway) ----
+__global__ void tmpc_state_finalize_kernel(int n_pi, int n_lam, const int *__restrict__ exit_code, double *__restrict__ pi,
+                                           double *__restrict__ lamh)
+{
+    const int b = blockIdx.x;
+    if (exit_code[b] == 1) return;
+    for (int e = threadIdx.x; e < n_pi; e += blockDim.x) pi[(size_t)b * n_pi + e] = 0.0;
+    for (int e = threadIdx.x; e < n_lam; e += blockDim.x) lamh[(size_t)b * n_lam + e] = 0.0;
+}
+
 // ---- debug: stage functions on device -----------------------------------------------------------
 __global__ void tmpc_debug_eval_kernel(Dims d, int n, const double *z, const double *p, const double *pi, const double *lamh,
                                        double *cost, double *cgrad, double *chess, double *hval, double *hjac,

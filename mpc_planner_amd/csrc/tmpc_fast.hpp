@@ -359,7 +359,7 @@ void tmpc_solve_fast_kernel(Dims d, int B, const double *__restrict__ xinit,
                                                              double *__restrict__ pobj, int *__restrict__ exit_code,
                                                              int *__restrict__ qp_status_out, int *__restrict__ sqp_iter_out,
                                                              double *__restrict__ res_eq_out, int *__restrict__ qp_iter_out,
-                                                             long long *__restrict__ prof_out)
+                                                             long long *__restrict__ prof_out, StateIO io)
 {
     using C = FastCfg<NLIN, MM, LPS>;
     constexpr int NT = NTH;
@@ -368,6 +368,7 @@ void tmpc_solve_fast_kernel(Dims d, int B, const double *__restrict__ xinit,
     const int tid = threadIdx.x;
     if ((int)blockIdx.x >= B) return;
     const int b = trajectory_of_block(blockIdx.x, B);
+    if ((io.flags & ST_KEEP_ITERATE) && io.stopped[b]) return;      // this solver's loop has ended: outputs of its last call stand
     const Lds L = carve_fast(smem, d);
     const int N = d.N;
     const double *xi = xinit + (size_t)b * ext_nx(d);
@@ -376,12 +377,13 @@ void tmpc_solve_fast_kernel(Dims d, int B, const double *__restrict__ xinit,
     // in registers across the whole solve.
     auto slack_of = [&]() { return d.slack ? __builtin_nontemporal_load(xi + NX) : 0.0; };
 
+    // loadWarmstart, or the iterate the handle holds; fresh or kept multipliers (StateIO, tmpc_solve.hip)
     for (int e = tid; e < (N + 1) * NV; e += NT) {
         const int k = e / NV, i = e - k * NV;
-        L.z[e] = x0[((size_t)b * (N + 1) + k) * ext_nv(d) + i];
+        L.z[e] = (io.flags & ST_KEEP_ITERATE) ? io.z[(size_t)b * (N + 1) * NV + e] : x0[((size_t)b * (N + 1) + k) * ext_nv(d) + i];
     }
-    for (int e = tid; e < (N + 1) * NX; e += NT) L.pi[e] = 0.0;
-    for (int e = tid; e < N * NHk; e += NT) L.lamh[e] = 0.0;
+    for (int e = tid; e < (N + 1) * NX; e += NT) L.pi[e] = (io.flags & ST_KEEP_MULTIPLIERS) ? io.pi[(size_t)b * (N + 1) * NX + e] : 0.0;
+    for (int e = tid; e < N * NHk; e += NT) L.lamh[e] = (io.flags & ST_KEEP_MULTIPLIERS) ? io.lamh[(size_t)b * N * NHk + e] : 0.0;
     if (tid < 3) L.D[N * NHk * 3 + tid] = 0.0;      // zero triple read by box rows
     __syncthreads();
     if (tid < NU) L.z[N * NV + tid] = 0.0;
@@ -424,6 +426,14 @@ void tmpc_solve_fast_kernel(Dims d, int B, const double *__restrict__ xinit,
         }
         __syncthreads();
         if (qp_status != 0) break;
+    }
+    if (io.flags & ST_STORE) {
+        // (after a QP failure the staging area is stale; the host-side finalisation zeroes the multipliers of failed slots anyway,
+        // as the reference resets a failed capsule, :187-191)
+        for (int e = tid; e < (N + 1) * NV; e += NT) io.z[(size_t)b * (N + 1) * NV + e] = L.z[e];
+        for (int e = tid; e < (N + 1) * NX; e += NT) io.pi[(size_t)b * (N + 1) * NX + e] = L.pi[e];
+        for (int e = tid; e < N * NHk; e += NT) io.lamh[(size_t)b * N * NHk + e] = L.lamh[e];
+        if (tid == 0 && sqp_iter > 0) io.stopped[b] = qp_status != 0;
     }
     solve_epilogue(L, d, tid, b, xi, pb, slack_of(), status, qp_status, sqp_iter, qp_iter_total, xtraj, utraj, pobj, exit_code,
                    qp_status_out, sqp_iter_out, res_eq_out, qp_iter_out, prof_out, pf, t_begin, NTH);

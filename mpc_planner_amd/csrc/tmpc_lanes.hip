@@ -42,25 +42,29 @@ __global__ __launch_bounds__(256) void lanes_transpose_in_kernel(Layout L, int B
     }
 }
 
-// fresh solver state: zero multipliers (pi of every node, lam of every general row)
-__global__ __launch_bounds__(LW) void lanes_reset_multipliers_kernel(Layout L, double *__restrict__ ws)
+// start of a call: fresh multipliers (pi of every node, lam of every general row) and / or a newly loaded iterate
+__global__ __launch_bounds__(LW) void lanes_prepare_kernel(Layout L, int load_iterate, int fresh_multipliers, double *__restrict__ ws)
 {
     double *w = ws + (size_t)blockIdx.x * block_doubles(L) + threadIdx.x;
-    for (int k = 0; k <= L.N; k++) {
-        for (int i = 0; i < NX; i++) w[((size_t)k * L.sd + L.o_pi + i) * LW] = 0.0;
-        if (k < L.N)
-            for (int r = 0; r < L.nh; r++) w[((size_t)k * L.sd + L.o_rows + 6 * r + 5) * LW] = 0.0;
+    if (fresh_multipliers) {
+        for (int k = 0; k <= L.N; k++) {
+            for (int i = 0; i < NX; i++) w[((size_t)k * L.sd + L.o_pi + i) * LW] = 0.0;
+            if (k < L.N)
+                for (int r = 0; r < L.nh; r++) w[((size_t)k * L.sd + L.o_rows + 6 * r + 5) * LW] = 0.0;
+        }
     }
-    // inputs of the terminal node are not variables
-    w[((size_t)L.N * L.sd + L.o_z + 0) * LW] = 0.0;
-    w[((size_t)L.N * L.sd + L.o_z + 1) * LW] = 0.0;
+    if (load_iterate) {
+        w[((size_t)L.N * L.sd + L.o_z + 0) * LW] = 0.0;            // inputs of the terminal node are not variables
+        w[((size_t)L.N * L.sd + L.o_z + 1) * LW] = 0.0;
+        w[((size_t)L.o_xinit + 7) * LW] = 0.0;                      // the slot's RTI loop is open again
+    }
 }
 
 #if defined(TMPC_LANES_PROF)
 __device__ long long g_lanes_prof[65536 * PF_COUNT];      // profiling build only: per-trajectory phase cycles (first 65536 trajectories)
 #endif
 
-__global__ __launch_bounds__(LW) void lanes_solve_kernel(Dims d, Layout L, int B, int n_iter, double *__restrict__ ws,
+__global__ __launch_bounds__(LW) void lanes_solve_kernel(Dims d, Layout L, int B, int n_iter, int persistent, int complete, double *__restrict__ ws,
                                                          double *__restrict__ xtraj, double *__restrict__ utraj,
                                                          double *__restrict__ pobj, int *__restrict__ exit_code,
                                                          int *__restrict__ qp_status, int *__restrict__ sqp_iter,
@@ -76,7 +80,9 @@ __global__ __launch_bounds__(LW) void lanes_solve_kernel(Dims d, Layout L, int B
     long long *prof = nullptr;
 #endif
     const Lane ln{d, L, ws + (size_t)blockIdx.x * block_doubles(L), (unsigned)lane, prof};
+    if (persistent && ln.stopped()) return;                        // this solver's loop has ended: outputs of its last call stand
     const Result R = ln.solve(n_iter);
+    if (persistent) ln.close_call(R, complete != 0);
     const int N = d.N, nxe = ext_nx(d);
     const double sl = ln.slack();
     for (int k = 0; k <= N; k++) {
@@ -126,28 +132,37 @@ size_t workspace_bytes(const Context *c) { return c ? c->bytes : 0; }
         if (e_ != hipSuccess) { err = std::string(#expr) + ": " + hipGetErrorString(e_); return -2; } \
     } while (0)
 
-int stage_in(Context *c, hipStream_t stream, int B, const double *xinit, const double *x0, const double *params, bool fresh,
-             std::string &err)
+int stage_in(Context *c, hipStream_t stream, int B, const double *xinit, const double *x0, const double *params, bool load_iterate,
+             bool fresh_multipliers, std::string &err)
 {
     if (!c || B <= 0 || B > c->B_max) { err = "lanes::stage_in: bad batch size"; return -1; }
     const Layout &L = c->L;
     const int nb = (B + LW - 1) / LW, N = c->d.N, nve = ext_nv(c->d), nxe = ext_nx(c->d);
     const int n_par = N * c->d.npar, n_x0 = (N + 1) * nve;
     hipLaunchKernelGGL(lanes_transpose_in_kernel<IN_PARAMS>, dim3((n_par + LW - 1) / LW, nb), dim3(256), 0, stream, L, B, n_par, nve, params, c->ws);
-    hipLaunchKernelGGL(lanes_transpose_in_kernel<IN_X0>, dim3((n_x0 + LW - 1) / LW, nb), dim3(256), 0, stream, L, B, n_x0, nve, x0, c->ws);
+    if (load_iterate)
+        hipLaunchKernelGGL(lanes_transpose_in_kernel<IN_X0>, dim3((n_x0 + LW - 1) / LW, nb), dim3(256), 0, stream, L, B, n_x0, nve, x0, c->ws);
     hipLaunchKernelGGL(lanes_transpose_in_kernel<IN_XINIT>, dim3(1, nb), dim3(256), 0, stream, L, B, nxe, nve, xinit, c->ws);
-    if (fresh) hipLaunchKernelGGL(lanes_reset_multipliers_kernel, dim3(nb), dim3(LW), 0, stream, L, c->ws);
+    hipLaunchKernelGGL(lanes_prepare_kernel, dim3(nb), dim3(LW), 0, stream, L, (int)load_iterate, (int)fresh_multipliers, c->ws);
     LANES_CHECK(hipGetLastError());
     return 0;
 }
 
-int solve(Context *c, hipStream_t stream, int B, int n_iter, double *xtraj, double *utraj, double *pobj, int *exit_code,
+int solve(Context *c, hipStream_t stream, int B, int n_iter, bool persistent, bool complete, double *xtraj, double *utraj, double *pobj, int *exit_code,
           int *qp_status, int *sqp_iter, double *res_eq, int *qp_iter, std::string &err)
 {
     if (!c || B <= 0 || B > c->B_max || n_iter < 0) { err = "lanes::solve: bad argument"; return -1; }
     const int nb = (B + LW - 1) / LW;
-    hipLaunchKernelGGL(lanes_solve_kernel, dim3(nb), dim3(LW), 0, stream, c->d, c->L, B, n_iter, c->ws, xtraj, utraj, pobj, exit_code,
-                       qp_status, sqp_iter, res_eq, qp_iter);
+    hipLaunchKernelGGL(lanes_solve_kernel, dim3(nb), dim3(LW), 0, stream, c->d, c->L, B, n_iter, (int)persistent, (int)complete, c->ws, xtraj, utraj, pobj,
+                       exit_code, qp_status, sqp_iter, res_eq, qp_iter);
+    LANES_CHECK(hipGetLastError());
+    return 0;
+}
+
+int reset_multipliers(Context *c, hipStream_t stream, int B, std::string &err)
+{
+    if (!c || B <= 0 || B > c->B_max) { err = "lanes::reset_multipliers: bad batch size"; return -1; }
+    hipLaunchKernelGGL(lanes_prepare_kernel, dim3((B + LW - 1) / LW), dim3(LW), 0, stream, c->L, 0, 1, c->ws);
     LANES_CHECK(hipGetLastError());
     return 0;
 }

@@ -719,6 +719,22 @@ struct Lane {
         for (int j = 0; j < NX; j++) dvec[NU + j] = dx[j];
     }
 
+    // ---- tmpc_solve_iterations protocol: a slot whose QP stopped with qp_status != 0 has left the reference's loop (:105-106);
+    // a solve that did not succeed resets the capsule's multipliers (:187-191) ----
+    TMPC_HD bool stopped() const { return at(row(L.o_xinit + 7)) != 0.0; }
+    TMPC_HD void close_call(const Result &R, bool complete) const
+    {
+        if (R.sqp_iter > 0) at(row(L.o_xinit + 7)) = R.qp_status != 0 ? 1.0 : 0.0;
+        if (complete && R.exit_code != 1) {
+            for (int k = 0; k <= d.N; k++) {
+#pragma unroll
+                for (int i = 0; i < NX; i++) F(k, L.o_pi + i) = 0.0;
+                if (k < d.N)
+                    for (int r = 0; r < L.nh; r++) F(k, L.o_rows + 6 * r + 5) = 0.0;
+            }
+        }
+    }
+
     // ---- n_iter RTI iterations from the lane's current (z, pi, lam) + completeOneIteration (:162-204) ----
     TMPC_HD Result solve(int n_iter) const
     {

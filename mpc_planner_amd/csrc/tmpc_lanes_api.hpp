@@ -16,13 +16,16 @@ void destroy(Context *c);
 size_t workspace_bytes(const Context *c);
 
 // Reference-layout inputs (device pointers: xinit [B][nx], x0 [B][(N+1) nvar], params [B][N npar]) -> lane-major workspace,
-// transposed through LDS (coalesced reads and writes).  fresh: zero the multipliers (a new solver instance); otherwise the
-// multipliers of the previous solve stay (the reference's capsules keep them across ticks).
-int stage_in(Context *c, hipStream_t stream, int B, const double *xinit, const double *x0, const double *params, bool fresh,
-             std::string &err);
+// transposed through LDS (coalesced reads and writes).  load_iterate: take the primal iterate from x0 (loadWarmstart); otherwise
+// the iterate the workspace holds continues.  fresh_multipliers: zero them (a new solver instance); otherwise the multipliers
+// of the previous call stay (the reference's capsules keep them across ticks).
+int stage_in(Context *c, hipStream_t stream, int B, const double *xinit, const double *x0, const double *params, bool load_iterate,
+             bool fresh_multipliers, std::string &err);
 // n_iter RTI iterations for every trajectory + completeOneIteration; outputs in the reference layouts (device pointers).
-int solve(Context *c, hipStream_t stream, int B, int n_iter, double *xtraj, double *utraj, double *pobj, int *exit_code,
+// persistent: the tmpc_solve_iterations protocol (slots whose loop ended are skipped); complete: failed slots get zero multipliers.
+int solve(Context *c, hipStream_t stream, int B, int n_iter, bool persistent, bool complete, double *xtraj, double *utraj, double *pobj, int *exit_code,
           int *qp_status, int *sqp_iter, double *res_eq, int *qp_iter, std::string &err);
+int reset_multipliers(Context *c, hipStream_t stream, int B, std::string &err);
 
 }  // namespace lanes
 }  // namespace tmpc

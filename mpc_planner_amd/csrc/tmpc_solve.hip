@@ -40,6 +40,19 @@ constexpr int NT = 64;   // threads per trajectory (one wavefront)
 __constant__ int c_pi[NP28] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 4, 5, 5, 5, 5, 5, 5, 6, 6, 6, 6, 6, 6, 6};
 __constant__ int c_pj[NP28] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 3, 0, 1, 2, 3, 4, 0, 1, 2, 3, 4, 5, 0, 1, 2, 3, 4, 5, 6};
 
+// ---- persistent solver state (tmpc_solve_iterations) ---------------------------------------------------------------
+// The reference's acados capsules keep the NLP iterate and its multipliers between calls: solveOneIteration continues from
+// them and loadWarmstart overwrites the primal part only (acados_solver_interface.cpp:67-77,121-160,274-284; SURVEY Appendix
+// D-4).  Here that state lives in HBM per trajectory slot; a solve launch optionally starts from it and writes it back.
+enum { ST_KEEP_ITERATE = 1, ST_KEEP_MULTIPLIERS = 2, ST_STORE = 4, ST_COMPLETE = 8 };
+struct StateIO {
+    double *z;          // [B][(N+1) NV]  iterate
+    double *pi;         // [B][(N+1) NX]  dynamics multipliers
+    double *lamh;       // [B][N nh]      (lam_upper - lam_lower) of the general rows, kernel row order [topology | slack | ellipsoids]
+    int *stopped;       // [B]            1: this slot's RTI loop has ended (a QP stopped with qp_status != 0, :105-106)
+    int flags;
+};
+
 // ---- per-trajectory LDS layout (doubles) ----------------------------------------------------
 struct Lds {
     double *z, *pi, *W, *g, *BA, *b, *D, *beta;          // NLP iterate + stage blocks of the current QP
@@ -580,25 +593,33 @@ __global__ __launch_bounds__(NT) void tmpc_solve_kernel(Dims d, int B, const dou
                                                         double *__restrict__ pobj, int *__restrict__ exit_code,
                                                         int *__restrict__ qp_status_out, int *__restrict__ sqp_iter_out,
                                                         double *__restrict__ res_eq_out, int *__restrict__ qp_iter_out,
-                                                        long long *__restrict__ prof_out)
+                                                        long long *__restrict__ prof_out, StateIO io)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x;
     if ((int)blockIdx.x >= B) return;
     const int b = trajectory_of_block(blockIdx.x, B);
+    if ((io.flags & ST_KEEP_ITERATE) && io.stopped[b]) return;      // this solver's loop has ended: outputs of its last call stand
     const Lds L = carve(smem, d);
     const int N = d.N;
     const double *xi = xinit + (size_t)b * ext_nx(d);
     const double *pb = params + (size_t)b * N * d.npar;
     const double slack = d.slack ? xi[NX] : 0.0;              // pinned by x_0 = xinit and slack' = 0 (tmpc_stage.hpp)
 
-    // loadWarmstart (acados_solver_interface.cpp:274-284); fresh multipliers
+    // loadWarmstart (acados_solver_interface.cpp:274-284), or the iterate the handle holds; fresh or kept multipliers
     for (int e = tid; e < (N + 1) * NV; e += NT) {
         const int k = e / NV, i = e - k * NV;
-        L.z[e] = x0[((size_t)b * (N + 1) + k) * ext_nv(d) + i];
+        L.z[e] = (io.flags & ST_KEEP_ITERATE) ? io.z[(size_t)b * (N + 1) * NV + e] : x0[((size_t)b * (N + 1) + k) * ext_nv(d) + i];
     }
-    for (int e = tid; e < (N + 1) * NX; e += NT) L.pi[e] = 0.0;
-    for (int r = tid; r < L.nrows; r += NT) L.lam[r] = 0.0;
+    for (int e = tid; e < (N + 1) * NX; e += NT) L.pi[e] = (io.flags & ST_KEEP_MULTIPLIERS) ? io.pi[(size_t)b * (N + 1) * NX + e] : 0.0;
+    for (int r = tid; r < L.nrows; r += NT) {
+        double l0 = 0.0;
+        if ((io.flags & ST_KEEP_MULTIPLIERS) && r < L.NG) {
+            const int j = r % L.nh;
+            l0 = ((j < d.n_up) ? 1.0 : -1.0) * io.lamh[(size_t)b * L.NG + r];         // lam = -sgn (lam_upper - lam_lower)
+        }
+        L.lam[r] = l0;
+    }
     __syncthreads();
     if (tid < NU) L.z[N * NV + tid] = 0.0;
     __syncthreads();
@@ -631,6 +652,12 @@ __global__ __launch_bounds__(NT) void tmpc_solve_kernel(Dims d, int B, const dou
         if (qp_status != 0) break;
     }
 
+    if (io.flags & ST_STORE) {
+        for (int e = tid; e < (N + 1) * NV; e += NT) io.z[(size_t)b * (N + 1) * NV + e] = L.z[e];
+        for (int e = tid; e < (N + 1) * NX; e += NT) io.pi[(size_t)b * (N + 1) * NX + e] = L.pi[e];
+        for (int r = tid; r < L.NG; r += NT) io.lamh[(size_t)b * L.NG + r] = (((r % L.nh) < d.n_up) ? 1.0 : -1.0) * L.lam[r];
+        if (tid == 0 && sqp_iter > 0) io.stopped[b] = qp_status != 0;
+    }
     solve_epilogue(L, d, tid, b, xi, pb, slack, status, qp_status, sqp_iter, qp_iter_total, xtraj, utraj, pobj, exit_code,
                    qp_status_out, sqp_iter_out, res_eq_out, qp_iter_out, prof_out, pf, t_begin);
 }
@@ -644,7 +671,7 @@ __global__ __launch_bounds__(NT) void tmpc_solve_kernel(Dims d, int B, const dou
 // =================================================================================================
 namespace tmpc {
 typedef void (*SolveKernel)(Dims, int, const double *, const double *, const double *, double *, double *, double *, int *,
-                            int *, int *, double *, int *, long long *);
+                            int *, int *, double *, int *, long long *, StateIO);
 // Registered fast shapes (upper-bounded rows n_lin + n_slk, ellipsoids M) x lanes-per-stage; anything else runs the generic kernel.
 // Only instantiations that compile WITHOUT scratch (zero VGPR spills) are registered: __graft_entry__.build() checks
 // the compiler's resource remarks and fails otherwise.  Reason: with > ~100 spilled VGPRs this kernel was observed to
@@ -733,6 +760,10 @@ struct tmpc_handle {
     bool throughput_mode = false;             // lane-per-trajectory kernels (tmpc_lanes.hip) instead of one wave per trajectory
     tmpc::lanes::Context *lanes = nullptr;    // their HBM workspace, created when the mode is first enabled
     bool fast = false;
+    // persistent per-slot solver state (tmpc_solve_iterations), allocated on first use
+    double *st_z = nullptr, *st_pi = nullptr, *st_lamh = nullptr;
+    int *st_stopped = nullptr;
+    bool st_valid = false;           // the state arrays hold the result of a previous tmpc_solve_iterations on this handle
     std::vector<hipEvent_t> ev;      // per-launch timing events (pairs)
     int ev_used = 0;
     bool timing = false;
@@ -790,7 +821,9 @@ int tmpc_create(tmpc_handle **out, const tmpc_dims *dims, int32_t B_max, int32_t
     {
         tmpc::Dims t; t.S = dims->S; t.n_lin = dims->n_lin; t.M = dims->M; t.n_slk = dims->n_slk; t.slack = dims->slack;
         if (dims->N < 2 || dims->N > 62 || dims->S < 1 || dims->M < 0 || dims->n_lin < 0 || dims->n_slk < 0 ||
-            (dims->slack != 0 && dims->slack != 1) || dims->npar != tmpc::expected_npar(t) || dims->erk_steps < 1)
+            (dims->slack != 0 && dims->slack != 1) || dims->npar != tmpc::expected_npar(t) || dims->erk_steps < 1 ||
+            dims->n_sqp < 1 || dims->qp_iter_max < 1 || !(dims->dt > 0.0) || !(dims->qp_tol > 0.0) || !(dims->reg_eps > 0.0) ||
+            !(dims->ipm_mu0 > 0.0) || !(dims->ipm_thr0 > 0.0))
             return TMPC_ERR_INVALID;
 #ifdef TMPC_GENERATED_STAGE
         if (dims->n_lin != tmpc_gen::NH || dims->M != 0 || dims->n_slk != 0 || dims->slack != tmpc_gen::SLACK) return TMPC_ERR_INVALID;
@@ -851,7 +884,8 @@ void tmpc_destroy(tmpc_handle *h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void *ptrs[] = {h->o_xinit, h->o_x0, h->o_params, h->xtraj, h->utraj, h->pobj, h->res_eq, h->d_weight,
-                    h->exit_code, h->qp_status, h->sqp_iter, h->qp_iter, h->d_best, h->d_disabled};
+                    h->exit_code, h->qp_status, h->sqp_iter, h->qp_iter, h->d_best, h->d_disabled,
+                    h->st_z, h->st_pi, h->st_lamh, h->st_stopped};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &e : h->ev) (void)hipEventDestroy(e);
     tmpc::lanes::destroy(h->lanes);
@@ -880,27 +914,83 @@ int tmpc_set_batch_device(tmpc_handle *h, int32_t B, const void *d_xinit, const 
     return TMPC_OK;
 }
 
+// One launch over the current batch: n_iter RTI iterations per trajectory + completeOneIteration.  st_flags: ST_* (0 = fresh
+// solver instances from the batch's warm start, nothing kept or stored: Solver::solve() of a new capsule).
+static int launch_solve(tmpc_handle *h, int n_iter, int st_flags)
+{
+    const bool rec = h->timing && h->ev_used + 2 <= (int)h->ev.size();
+    if (rec) TMPC_HIP_CHECK(h, hipEventRecord(h->ev[h->ev_used], h->stream));
+    if (h->throughput_mode) {
+        // lane-per-trajectory variant: transpose the reference-layout inputs into the lane-major workspace, then one launch of
+        // the scalar-per-lane SQP_RTI program; the workspace itself is the persistent state
+        if (tmpc::lanes::stage_in(h->lanes, h->stream, h->B, h->xinit, h->x0, h->params, !(st_flags & tmpc::ST_KEEP_ITERATE),
+                                  !(st_flags & tmpc::ST_KEEP_MULTIPLIERS), h->err)) return TMPC_ERR_HIP;
+        if (tmpc::lanes::solve(h->lanes, h->stream, h->B, n_iter, (st_flags & tmpc::ST_STORE) != 0, (st_flags & tmpc::ST_COMPLETE) != 0,
+                               h->xtraj, h->utraj, h->pobj,
+                               h->exit_code, h->qp_status, h->sqp_iter, h->res_eq, h->qp_iter, h->err)) return TMPC_ERR_HIP;
+    } else {
+        tmpc::Dims dd = h->d;
+        dd.n_sqp = n_iter;
+        tmpc::StateIO io{h->st_z, h->st_pi, h->st_lamh, h->st_stopped, st_flags};
+        const bool lat = h->kernel_lat && h->latency_mode;
+        hipLaunchKernelGGL(lat ? h->kernel_lat : h->kernel, dim3(h->B), dim3(lat ? 128 : h->threads), h->lds_bytes, h->stream, dd, h->B,
+                           h->xinit, h->x0, h->params, h->xtraj, h->utraj, h->pobj, h->exit_code, h->qp_status,
+                           h->sqp_iter, h->res_eq, h->qp_iter, (long long *)nullptr, io);
+        TMPC_HIP_CHECK(h, hipGetLastError());
+        if (st_flags & tmpc::ST_COMPLETE) {
+            // a failed solve resets the reference's capsule (Solver_acados_reset, acados_solver_interface.cpp:187-191): zero multipliers
+            const int n_pi = (h->d.N + 1) * tmpc::NX, n_lam = h->d.N * (h->d.n_up + h->d.M);
+            hipLaunchKernelGGL(tmpc::tmpc_state_finalize_kernel, dim3(h->B), dim3(64), 0, h->stream, n_pi, n_lam, h->exit_code, h->st_pi, h->st_lamh);
+            TMPC_HIP_CHECK(h, hipGetLastError());
+        }
+    }
+    if (rec) { TMPC_HIP_CHECK(h, hipEventRecord(h->ev[h->ev_used + 1], h->stream)); h->ev_used += 2; }
+    return TMPC_OK;
+}
+
 int tmpc_solve(tmpc_handle *h)
 {
     if (!h || h->B <= 0 || !h->xinit) { if (h) h->err = "tmpc_solve: no batch set"; return TMPC_ERR_INVALID; }
     TMPC_HIP_CHECK(h, hipSetDevice(h->device));
-    const bool rec = h->timing && h->ev_used + 2 <= (int)h->ev.size();
-    if (rec) TMPC_HIP_CHECK(h, hipEventRecord(h->ev[h->ev_used], h->stream));
-    if (h->throughput_mode) {
-        // lane-per-trajectory variant: transpose the reference-layout inputs into the lane-major workspace (fresh solver state),
-        // then one launch of the scalar-per-lane SQP_RTI program
-        if (tmpc::lanes::stage_in(h->lanes, h->stream, h->B, h->xinit, h->x0, h->params, true, h->err)) return TMPC_ERR_HIP;
-        if (tmpc::lanes::solve(h->lanes, h->stream, h->B, h->d.n_sqp, h->xtraj, h->utraj, h->pobj, h->exit_code, h->qp_status,
-                               h->sqp_iter, h->res_eq, h->qp_iter, h->err)) return TMPC_ERR_HIP;
-        if (rec) { TMPC_HIP_CHECK(h, hipEventRecord(h->ev[h->ev_used + 1], h->stream)); h->ev_used += 2; }
-        return TMPC_OK;
+    h->st_valid = false;
+    return launch_solve(h, h->d.n_sqp, 0);
+}
+
+int tmpc_solve_iterations(tmpc_handle *h, int32_t n_iter, int32_t flags)
+{
+    if (!h || h->B <= 0 || !h->xinit || n_iter < 0 || (flags & ~7)) { if (h) h->err = "tmpc_solve_iterations: no batch set / bad argument"; return TMPC_ERR_INVALID; }
+    TMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    if (!h->throughput_mode && !h->st_z) {
+        const size_t B = h->B_max, N = h->d.N, nh = h->d.n_up + h->d.M;
+        bool ok = hipMalloc(&h->st_z, B * (N + 1) * tmpc::NV * 8) == hipSuccess;
+        ok &= hipMalloc(&h->st_pi, B * (N + 1) * tmpc::NX * 8) == hipSuccess;
+        ok &= hipMalloc(&h->st_lamh, (B * N * nh + 1) * 8) == hipSuccess;
+        ok &= hipMalloc(&h->st_stopped, B * 4) == hipSuccess;
+        if (!ok) { h->err = "tmpc_solve_iterations: state allocation failed"; return TMPC_ERR_HIP; }
+        h->st_valid = false;
     }
-    const bool lat = h->kernel_lat && h->latency_mode;
-    hipLaunchKernelGGL(lat ? h->kernel_lat : h->kernel, dim3(h->B), dim3(lat ? 128 : h->threads), h->lds_bytes, h->stream, h->d, h->B,
-                       h->xinit, h->x0, h->params, h->xtraj, h->utraj, h->pobj, h->exit_code, h->qp_status,
-                       h->sqp_iter, h->res_eq, h->qp_iter, (long long *)nullptr);
-    TMPC_HIP_CHECK(h, hipGetLastError());
-    if (rec) { TMPC_HIP_CHECK(h, hipEventRecord(h->ev[h->ev_used + 1], h->stream)); h->ev_used += 2; }
+    int st = tmpc::ST_STORE;
+    if (h->st_valid) {                      // nothing to keep on the first call: behaves like a fresh capsule
+        if (flags & TMPC_ITER_KEEP_ITERATE) st |= tmpc::ST_KEEP_ITERATE;
+        if (flags & TMPC_ITER_KEEP_MULTIPLIERS) st |= tmpc::ST_KEEP_MULTIPLIERS;
+    }
+    if (flags & TMPC_ITER_COMPLETE) st |= tmpc::ST_COMPLETE;
+    const int rc = launch_solve(h, n_iter, st);
+    if (rc == TMPC_OK) h->st_valid = true;
+    return rc;
+}
+
+int tmpc_reset_multipliers(tmpc_handle *h)
+{
+    if (!h) return TMPC_ERR_INVALID;
+    TMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    if (h->throughput_mode) {
+        if (h->lanes && tmpc::lanes::reset_multipliers(h->lanes, h->stream, h->B_max, h->err)) return TMPC_ERR_HIP;
+    } else if (h->st_pi) {
+        const size_t B = h->B_max, N = h->d.N, nh = h->d.n_up + h->d.M;
+        TMPC_HIP_CHECK(h, hipMemsetAsync(h->st_pi, 0, B * (N + 1) * tmpc::NX * 8, h->stream));
+        TMPC_HIP_CHECK(h, hipMemsetAsync(h->st_lamh, 0, B * N * nh * 8, h->stream));
+    }
     return TMPC_OK;
 }
 
@@ -1130,7 +1220,7 @@ int tmpc_debug_profile(tmpc_handle *h, int64_t *cycles, int32_t n_phases)
     }
     hipLaunchKernelGGL(pk, dim3(h->B), dim3(h->threads), h->lds_bytes, h->stream, h->d, h->B,
                        h->xinit, h->x0, h->params, h->xtraj, h->utraj, h->pobj, h->exit_code, h->qp_status,
-                       h->sqp_iter, h->res_eq, h->qp_iter, dp);
+                       h->sqp_iter, h->res_eq, h->qp_iter, dp, tmpc::StateIO{nullptr, nullptr, nullptr, nullptr, 0});
     TMPC_HIP_CHECK(h, hipGetLastError());
     TMPC_HIP_CHECK(h, hipStreamSynchronize(h->stream));
     std::vector<long long> host(n);

@@ -40,7 +40,8 @@ EXPORTS = ["tmpc_default_dims", "tmpc_default_dims_ex", "tmpc_create", "tmpc_des
            "tmpc_result_device_ptrs", "tmpc_time_solve", "tmpc_debug_eval_stage", "tmpc_pack_records",
            "tmpc_select_best_records", "tmpc_enable_timing", "tmpc_get_timings", "tmpc_debug_profile",
            "tmpc_linearize_topology", "tmpc_scenario_halfspaces", "tmpc_warmstart", "tmpc_init_with_guidance",
-           "tmpc_debug_get_x0", "tmpc_debug_get_params", "tmpc_set_throughput_mode"]
+           "tmpc_debug_get_x0", "tmpc_debug_get_params", "tmpc_set_throughput_mode", "tmpc_solve_iterations",
+           "tmpc_reset_multipliers"]
 
 class TmpcError(RuntimeError):
     pass
@@ -71,6 +72,8 @@ def load_library(path=None):
     lib.tmpc_solve.argtypes = [vp]
     lib.tmpc_set_latency_mode.argtypes = [vp, C.c_int32]
     lib.tmpc_set_throughput_mode.argtypes = [vp, C.c_int32]
+    lib.tmpc_solve_iterations.argtypes = [vp, C.c_int32, C.c_int32]
+    lib.tmpc_reset_multipliers.argtypes = [vp]
     lib.tmpc_synchronize.argtypes = [vp]
     lib.tmpc_get.argtypes = [vp] + [vp] * 8
     lib.tmpc_select_best.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, C.POINTER(C.c_int32)]
@@ -167,6 +170,19 @@ class BatchedSolver:
         if rc < 0:
             self._check(rc, "tmpc_set_latency_mode")
         return rc == 0
+
+    KEEP_ITERATE, KEEP_MULTIPLIERS, COMPLETE = 1, 2, 4
+
+    def solve_iterations(self, n_iter, keep_iterate=False, keep_multipliers=False, complete=True, sync=True):
+        """n_iter RTI iterations per trajectory slot from the state the handle keeps (tmpc_solve_iterations): the reference's
+        initializeOneIteration / solveOneIteration / completeOneIteration protocol and multipliers carried across ticks."""
+        flags = (self.KEEP_ITERATE if keep_iterate else 0) | (self.KEEP_MULTIPLIERS if keep_multipliers else 0) | (self.COMPLETE if complete else 0)
+        self._check(self.lib.tmpc_solve_iterations(self._h, int(n_iter), flags), "tmpc_solve_iterations")
+        if sync:
+            self.synchronize()
+
+    def reset_multipliers(self):
+        self._check(self.lib.tmpc_reset_multipliers(self._h), "tmpc_reset_multipliers")
 
     def set_throughput_mode(self, on=True):
         """Lane-per-trajectory kernels for large batches (allocates the HBM workspace for B_max trajectories on first use)."""

@@ -144,8 +144,29 @@ static void build_qp(const orc_problem *pb, const nlp_state *st, const double *x
 static __thread int *tls_qp_iter_trace = NULL;
 void orc_set_qp_iter_trace(int *per_sqp_iteration) { tls_qp_iter_trace = per_sqp_iteration; }
 
+static void solve_impl(const orc_problem *pb, const double *xinit, const double *x0, const double *params,
+                       double *xtraj, double *utraj, orc_info *info, orc_debug *dbg, int capture_sqp_iter,
+                       int n_iter, double *pi_io, double *lamh_io);
+
 void orc_solve_debug(const orc_problem *pb, const double *xinit, const double *x0, const double *params,
                      double *xtraj, double *utraj, orc_info *info, orc_debug *dbg, int capture_sqp_iter)
+{
+    solve_impl(pb, xinit, x0, params, xtraj, utraj, info, dbg, capture_sqp_iter, pb->n_sqp, 0, 0);
+}
+
+/* The reference's capsules keep their multipliers between solves (acados_solver_interface.cpp:67-77 copies parameters only,
+ * :274-284 overwrites the primal iterate only) and reset them when a solve does not succeed (:187-191).
+ * pi_io [(N+1) NX] and lamh_io [N ORC_MAX_NH] (lam_upper - lam_lower per general row) are read as the starting multipliers
+ * and overwritten with the final ones (zeros if exit_code != 1); n_iter RTI iterations. */
+void orc_solve_carry(const orc_problem *pb, const double *xinit, const double *x0, const double *params, int n_iter,
+                     double *pi_io, double *lamh_io, double *xtraj, double *utraj, orc_info *info)
+{
+    solve_impl(pb, xinit, x0, params, xtraj, utraj, info, 0, -1, n_iter, pi_io, lamh_io);
+}
+
+static void solve_impl(const orc_problem *pb, const double *xinit, const double *x0, const double *params,
+                       double *xtraj, double *utraj, orc_info *info, orc_debug *dbg, int capture_sqp_iter,
+                       int n_iter, double *pi_io, double *lamh_io)
 {
     const int N = pb->N, nh = pb->n_lin + pb->M + pb->n_gauss + pb->n_slk;
     double dslack[ORC_MAX_N + 1];
@@ -166,10 +187,14 @@ void orc_solve_debug(const orc_problem *pb, const double *xinit, const double *x
     for (int k = 0; k <= N; k++)
         for (int j = 0; j < ORC_NVE; j++) st->z[k][j] = x0[k * ORC_NVE + j];
     st->z[N][0] = st->z[N][1] = 0.0;
+    if (pi_io) {
+        for (int k = 0; k <= N; k++) for (int j = 0; j < ORC_NX; j++) st->pi[k][j] = pi_io[k * ORC_NX + j];
+        for (int k = 0; k < N; k++) for (int r = 0; r < nh; r++) st->lam_h[k][r] = lamh_io[k * ORC_MAX_NH + r];
+    }
 
     int status = 0;           /* acados status of the last Solver_acados_solve */
     info->qp_status = 0; info->sqp_iter = 0; info->qp_iter_total = 0;
-    for (int it = 0; it < pb->n_sqp; it++) {                        /* :99-117 */
+    for (int it = 0; it < n_iter; it++) {                           /* :99-117 */
         build_qp(pb, st, xinit, params, qp, row_lo, row_hi, (dbg && it == capture_sqp_iter) ? dbg : 0, dslack);
         orc_qp_solve(qp, sol, pb->qp_iter_max, pb->qp_tol, pb->ipm_mu0, pb->ipm_thr0, pb->ipm_tau);
         info->qp_status = sol->status; info->sqp_iter = it + 1; info->qp_iter_total += sol->iters;
@@ -217,6 +242,11 @@ void orc_solve_debug(const orc_problem *pb, const double *xinit, const double *x
     /* map to Forces codes (:197-201): 0 -> 1, 1 -> 0 */
     int exit_code = status == 0 ? 1 : (status == 1 ? 0 : status);
     info->pobj = pobj; info->res_eq = res_eq; info->exit_code = exit_code;
+    if (pi_io) {
+        const int keep = exit_code == 1;                                   /* Solver_acados_reset on failure (:187-191) */
+        for (int k = 0; k <= N; k++) for (int j = 0; j < ORC_NX; j++) pi_io[k * ORC_NX + j] = keep ? st->pi[k][j] : 0.0;
+        for (int k = 0; k < N; k++) for (int r = 0; r < nh; r++) lamh_io[k * ORC_MAX_NH + r] = keep ? st->lam_h[k][r] : 0.0;
+    }
 }
 
 void orc_solve(const orc_problem *pb, const double *xinit, const double *x0, const double *params,

@@ -132,6 +132,11 @@ typedef struct {
 void orc_solve(const orc_problem *pb, const double *xinit, const double *x0, const double *params,
                double *xtraj, double *utraj, orc_info *info);
 
+/* Same with multipliers carried in / out (the reference's capsules keep them between solves and reset them after a failed one:
+ * acados_solver_interface.cpp:67-77,187-191,274-284): pi_io [(N+1) NX], lamh_io [N ORC_MAX_NH]; n_iter RTI iterations. */
+void orc_solve_carry(const orc_problem *pb, const double *xinit, const double *x0, const double *params, int n_iter,
+                     double *pi_io, double *lamh_io, double *xtraj, double *utraj, orc_info *info);
+
 /* Optional debug capture of the first linearisation / QP of a solve (for per-phase GPU diffing). */
 typedef struct {
     double W[(ORC_MAX_N + 1) * ORC_NV * ORC_NV];

@@ -105,6 +105,35 @@ int main(int argc, char **argv)
         for (int k = 0; k <= single.N; k++) ASSERT_TRUE(single.getOutput(k, "x") == batch[b]->getOutput(k, "x"));
         ASSERT_TRUE(single.getOutput(5, "v") > 1.0 && single.getOutput(single.N, "x") > 3.0);
     }
+    // ---- the one-iteration protocol (initializeOneIteration / solveOneIteration x n / completeOneIteration, :121-204; what
+    // SH-MPC's scenario module drives, scenario_constraints.cpp:85) gives bitwise what solve() gives ----
+    {
+        Solver a(20), b(21);
+        a = *batch[1]; b = *batch[1];
+        a.loadWarmstart(); b.loadWarmstart();
+        const int ea = a.solve();
+        b.initializeOneIteration();
+        int n_done = 0;
+        for (int it = 0; it < b._num_iterations; it++) {
+            const int st = b.solveOneIteration();
+            n_done++;
+            ASSERT_TRUE(st == 0);
+            if (b._info.qp_status != 0) break;
+        }
+        const int eb = b.completeOneIteration();
+        ASSERT_TRUE(ea == 1 && eb == 1 && n_done == b._num_iterations && b._info.sqp_iter == a._info.sqp_iter);
+        ASSERT_TRUE(a._info.pobj == b._info.pobj);
+        for (int k = 0; k <= a.N; k++) { ASSERT_TRUE(a.getOutput(k, "x") == b.getOutput(k, "x")); ASSERT_TRUE(a.getOutput(k, "v") == b.getOutput(k, "v")); }
+        // a second solve() of the same solver without loadWarmstart() continues from its own iterate and multipliers (the capsule's
+        // state persists): more RTI iterations on the same problem move the objective towards the converged optimum, not away
+        const double first = a._info.pobj;
+        ASSERT_TRUE(a.solve() == 1);
+        ASSERT_TRUE(a._info.pobj <= first + 1e-9 && std::fabs(a._info.pobj - first) < 1e-2);
+        // with loadWarmstart() the primal iterate comes from _params.x0 again, the multipliers stay: not the fresh result bitwise
+        a.loadWarmstart();
+        ASSERT_TRUE(a.solve() == 1);
+        ASSERT_TRUE(std::fabs(a._info.pobj - first) < 1e-3);
+    }
     std::printf("solve ok: pobj %.6f %.6f %.6f\n", batch[0]->_info.pobj, batch[1]->_info.pobj, batch[2]->_info.pobj);
     return 0;
 }

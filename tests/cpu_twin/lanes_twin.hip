@@ -28,13 +28,13 @@ extern "C" int lanes_twin_solve(const tmpc_dims *dims, int32_t B, const double *
     const int nb = (B + LW - 1) / LW, N = d.N, nve = ext_nv(d), nxe = ext_nx(d);
     double *ws = (double *)calloc((size_t)nb * block_doubles(L), sizeof(double));
     if (!ws) return -1;
-    for (int b = 0; b < B; b++) {                       // what lanes_transpose_in_kernel + lanes_reset_multipliers_kernel do
+    for (int b = 0; b < B; b++) {                       // what lanes_transpose_in_kernel + lanes_prepare_kernel do
         double *w = ws + (size_t)(b / LW) * block_doubles(L) + (b % LW);
         for (int e = 0; e < N * d.npar; e++) w[((size_t)L.o_par + e) * LW] = params[(size_t)b * N * d.npar + e];
         for (int i = 0; i < nxe; i++) w[((size_t)L.o_xinit + i) * LW] = xinit[(size_t)b * nxe + i];
         for (int k = 0; k <= N; k++)
             for (int i = 0; i < NV; i++) w[((size_t)k * L.sd + L.o_z + i) * LW] = x0[((size_t)b * (N + 1) + k) * nve + i];
-        w[((size_t)N * L.sd + L.o_z + 0) * LW] = 0.0; w[((size_t)N * L.sd + L.o_z + 1) * LW] = 0.0;
+        w[((size_t)N * L.sd + L.o_z + 0) * LW] = 0.0; w[((size_t)N * L.sd + L.o_z + 1) * LW] = 0.0;      // (lanes_prepare_kernel)
     }
 #pragma omp parallel for schedule(dynamic, 1)
     for (int b = 0; b < B; b++) {

@@ -134,6 +134,16 @@ def solve(pb, xinit, x0, params, debug_iter=None):
     return xt, ut, info, dbg
 
 
+def solve_carry(pb, xinit, x0, params, n_iter, pi, lamh):
+    """One solve with multipliers carried in and out (pi [(N+1)*NX], lamh [N*MAX_NH] are updated in place)."""
+    xinit = np.ascontiguousarray(xinit, float); x0 = np.ascontiguousarray(x0, float); params = np.ascontiguousarray(params, float)
+    assert pi.size == (pb.N + 1) * NX and lamh.size == pb.N * MAX_NH and pi.flags.c_contiguous and lamh.flags.c_contiguous
+    xt = np.zeros((pb.N + 1, pb.nxe)); ut = np.zeros((pb.N, NU)); info = Info()
+    lib(pb.slack).orc_solve_carry(C.byref(pb), dptr(xinit), dptr(x0), dptr(params), int(n_iter), dptr(pi), dptr(lamh),
+                                  dptr(xt), dptr(ut), C.byref(info))
+    return xt, ut, info
+
+
 def solve_batch(pb, xinit, x0, params, num_threads=0):
     B = xinit.shape[0]
     xinit = np.ascontiguousarray(xinit, float); x0 = np.ascontiguousarray(x0, float)

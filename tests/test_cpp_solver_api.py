@@ -41,6 +41,42 @@ def test_cpp_solver_plumbing():
     assert out.returncode == 0 and "plumbing ok" in out.stdout, out.stdout + out.stderr
 
 
+GEN_SLACK = os.path.join(ROOT, "build", "generated_cfg5")
+BIN_SLACK = os.path.join(ROOT, "build", "test_solver_slack")
+
+
+def _build_slack():
+    """configuration_safe_horizon (cfg 5): slack model, 24 scenario halfspaces, no ellipsoid / topology rows."""
+    import __graft_entry__ as g
+    g.build()
+    from mpc_planner_amd.generate_solver import generate_solver
+    pm = generate_solver(GEN_SLACK, N=20, max_obstacles=8, num_segments=5, guidance=False, slack=True, ellipsoids=False, n_scenario=24)
+    assert pm.length() == 127
+    cpp = os.path.join(ROOT, "mpc_planner_amd", "cpp")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(cpp, "include"), "-I", os.path.join(GEN_SLACK, "include"),
+                           "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "test_solver_slack.cpp"),
+                           os.path.join(cpp, "src", "solver_interface.cpp"), os.path.join(GEN_SLACK, "src", "mpc_planner_parameters.cpp"),
+                           "-L", os.path.join(ROOT, "mpc_planner_amd"), "-ltmpc_hip", "-Wl,-rpath," + os.path.join(ROOT, "mpc_planner_amd"),
+                           "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-lamdhip64", "-o", BIN_SLACK])
+
+
+def test_cpp_solver_plumbing_slack_model():
+    _build_slack()
+    mm = open(os.path.join(GEN_SLACK, "config", "model_map.yaml")).read()
+    assert "slack: [x, 7, 0.0, 5000.0]" in mm
+    out = subprocess.run([BIN_SLACK, os.path.join(GEN_SLACK, "config")], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "plumbing ok" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.gpu
+def test_cpp_solver_solves_slack_model():
+    """Round-1 advisor finding (high): the slack model's ninth model_map entry overflowed tmpc_dims::lb/ub and tmpc_create failed."""
+    if not os.path.exists(BIN_SLACK) or os.path.getmtime(BIN_SLACK) < os.path.getmtime(os.path.join(ROOT, "mpc_planner_amd", "libtmpc_hip.so")):
+        _build_slack()
+    out = subprocess.run([BIN_SLACK, os.path.join(GEN_SLACK, "config"), "--solve"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "solve ok" in out.stdout, out.stdout + out.stderr
+
+
 def _stale():
     if not os.path.exists(BIN):
         return True
