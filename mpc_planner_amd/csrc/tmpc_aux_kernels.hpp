@@ -84,15 +84,29 @@ __global__ void tmpc_linearize_topology_kernel(Dims d, int B, const double *x0, 
     double px = x0[((size_t)b * (N + 1) + k) * ext_nv(d) + ZX], py = x0[((size_t)b * (N + 1) + k) * ext_nv(d) + ZY];
     const double *ob = obst + (size_t)sc * d.n_lin * N * 2;
     if (!dummy) {
-        for (int sweep = 0; sweep < 3; sweep++)                         // projectToSafety: at most 3 iterations (:137)
+        // projectToSafety (:130-148): at most 3 sweeps over the obstacles of ros_tools' Douglas-Rachford step with obstacle 0 as the
+        // anchor.  ros_tools is not in the reference tree; restated from the published operator p <- (p + R_delta R_anchor p) / 2,
+        // R = 2 P - I, P = nearest point outside the disc of radius r, applied when p is inside the obstacle's disc (same arithmetic
+        // as modules.py::project_to_safety and the C++ DouglasRachford).  No FMA contraction: bit-equal to the host mirrors.
+        const double ax0 = ob[(size_t)(k - 1) * 2], ay0 = ob[(size_t)(k - 1) * 2 + 1];          // anchor = obstacle 0 at step k-1
+        auto outside = [&](double qx, double qy, double cx, double cy, double &ox_, double &oy_) {
+            const double dx = qx - cx, dy = qy - cy;
+            const double dist = sqrt(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)));
+            if (dist >= r) { ox_ = qx; oy_ = qy; }
+            else if (dist > 1e-12) { const double s = r / dist; ox_ = __dadd_rn(cx, __dmul_rn(dx, s)); oy_ = __dadd_rn(cy, __dmul_rn(dy, s)); }
+            else { ox_ = cx; oy_ = cy + r; }
+        };
+        for (int sweep = 0; sweep < 3; sweep++)
             for (int j = 0; j < d.n_lin; j++) {
                 const double ox = ob[((size_t)j * N + (k - 1)) * 2], oy = ob[((size_t)j * N + (k - 1)) * 2 + 1];
                 const double dx = px - ox, dy = py - oy;
-                const double dist = sqrt(dx * dx + dy * dy);
-                if (dist < r) {
-                    const double s = dist > 1e-12 ? r * 1.001 / dist : 0.0;
-                    px = dist > 1e-12 ? ox + dx * s : ox;
-                    py = dist > 1e-12 ? oy + dy * s : oy + r * 1.001;
+                if (sqrt(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy))) < r) {
+                    double qx, qy, bx, by;
+                    outside(px, py, ax0, ay0, qx, qy);
+                    const double rx = __dmul_rn(2.0, qx) - px, ry = __dmul_rn(2.0, qy) - py;
+                    outside(rx, ry, ox, oy, bx, by);
+                    const double sx = __dmul_rn(2.0, bx) - rx, sy = __dmul_rn(2.0, by) - ry;
+                    px = (px + sx) / 2.0; py = (py + sy) / 2.0;
                 }
             }
     }

@@ -69,23 +69,38 @@ def gaussian_set_parameters(pm, params, state_xy, obstacles, robot_radius, risk,
         params[1:, ix[5]] = obstacles["radius"][j]
 
 
+def _outside_disc(qx, qy, cx, cy, r):
+    """Nearest point of the closed outside of the disc (c, r)."""
+    dx, dy = qx - cx, qy - cy
+    dist = np.sqrt(dx * dx + dy * dy)
+    if dist >= r:
+        return qx, qy
+    if dist > 1e-12:
+        s = r / dist
+        return cx + dx * s, cy + dy * s
+    return cx, cy + r
+
+
 def project_to_safety(pos, obstacles_k, r):
-    """Stand-in for LinearizedConstraints::projectToSafety (linearized_constraints.cpp:130-148: at most 3 sweeps of
-    ros_tools' Douglas-Rachford projection over the obstacles; the ros_tools source is absent -- DESIGN.md [UPSTREAM]):
-    a guess closer than r to an obstacle is moved radially to 1.001 r from it.  The identity whenever the guess is
-    already clear of every obstacle, which is the only case the parity claims rest on.  Same arithmetic as
-    tmpc_linearize_topology_kernel (csrc/tmpc_aux_kernels.hpp)."""
+    """LinearizedConstraints::projectToSafety (linearized_constraints.cpp:130-148): at most 3 sweeps over the obstacles of
+    ros_tools' Douglas-Rachford projection, with obstacle 0 as the anchor.  The ros_tools source is not in the reference tree
+    (DESIGN.md U10); restated from the published Douglas-Rachford operator p <- (p + R_delta R_anchor p) / 2 with reflections
+    R = 2 P - I, P = nearest point outside the disc of radius r, applied when p is inside the obstacle's disc -- the call order of
+    the reference (anchor first, then the obstacle).  The identity for a guess clear of every obstacle.  Same arithmetic as
+    tmpc_linearize_topology_kernel (csrc/tmpc_aux_kernels.hpp) and the C++ DouglasRachford (modules_hip.h)."""
     px, py = float(pos[0]), float(pos[1])
+    if len(obstacles_k) == 0:
+        return np.array([px, py])
+    ax, ay = float(obstacles_k[0][0]), float(obstacles_k[0][1])
     for _ in range(3):
         for o in obstacles_k:
             dx, dy = px - o[0], py - o[1]
-            dist = np.sqrt(dx * dx + dy * dy)
-            if dist < r:
-                if dist > 1e-12:
-                    s = r * 1.001 / dist
-                    px, py = o[0] + dx * s, o[1] + dy * s
-                else:
-                    px, py = o[0], o[1] + r * 1.001
+            if np.sqrt(dx * dx + dy * dy) < r:
+                qx, qy = _outside_disc(px, py, ax, ay, r)
+                rx, ry = 2.0 * qx - px, 2.0 * qy - py
+                bx, by = _outside_disc(rx, ry, float(o[0]), float(o[1]), r)
+                sx, sy = 2.0 * bx - rx, 2.0 * by - ry
+                px, py = (px + sx) / 2.0, (py + sy) / 2.0
     return np.array([px, py])
 
 

@@ -197,6 +197,7 @@ def make_scene(scene_idx, N=20, M=8, B=64, S=5, tmpc_pp=False, gaussian=False, g
     xinit = np.tile(state, (Bt, 1))
     x0 = np.zeros((Bt, N + 1, nv)); params = np.zeros((Bt, N, npar))
     guidance_id = np.zeros(Bt, np.int32)
+    guidance_pos = np.zeros((B, N + 1, 2)); guidance_vel = np.zeros((B, N + 1, 2))        # what the guidance planner hands over
     T = N * DT; t = np.arange(N + 1) * DT
     v_ref = WEIGHTS["reference_velocity"]
     amps = np.linspace(-A_MAX, A_MAX, B) + rng.normal(0.0, 0.05, B) if B > 1 else np.array([rng.normal(0.0, 0.5)])
@@ -271,6 +272,7 @@ def make_scene(scene_idx, N=20, M=8, B=64, S=5, tmpc_pp=False, gaussian=False, g
                     if dist[j] >= r_s:
                         break
                     gpos[k] = cloud[j] + (dvec[j] / dist[j] if dist[j] > 1e-12 else np.array([0.0, 1.0])) * (r_s * 1.001)
+        guidance_pos[b] = gpos; guidance_vel[b] = gvel
         x0[b] = md.initialize_solver_with_guidance(main_x0.copy(), gpos, gvel)
         params[b] = base
         if guidance:
@@ -287,7 +289,7 @@ def make_scene(scene_idx, N=20, M=8, B=64, S=5, tmpc_pp=False, gaussian=False, g
         guidance_id[B] = 2 * B                                              # guidance_constraints.cpp:349
     return dict(xinit=xinit, x0=x0, params=params, pm=pm, guidance_id=guidance_id, obstacles=obs,
                 segments=segs, N=N, M=(M if ellipsoids else 0), S=S, n_lin=(M if guidance else 0), n_gauss=(M if chance else 0),
-                n_slk=n_scenario + n_decomp, slack=int(slack), samples=samples)
+                n_slk=n_scenario + n_decomp, slack=int(slack), samples=samples, guidance_pos=guidance_pos, guidance_vel=guidance_vel)
 
 
 def make_batch(scene_indices, **kw):

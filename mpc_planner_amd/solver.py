@@ -56,6 +56,13 @@ def load_library(path=None):
     path = os.path.abspath(path) if path else LIB_PATH
     if path in _libs:
         return _libs[path]
+    try:
+        # If torch is going to be used in this process (device buffers, torch.distributed) its bundled HIP runtime must be the
+        # one that gets loaded: libtmpc_hip.so resolves the same libamdhip64 SONAME, and whichever is loaded first serves both.
+        # Loading the system runtime first has been seen to leave torch without devices ("No HIP GPUs are available").
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(path):
         raise TmpcError(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                         "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
@@ -313,3 +320,24 @@ def optimize_batch(solver, scene_batch, tmpc_consistency_weight=None):
         idx = np.nonzero(scene_of == s)[0]
         best[s] = solver.select_best(first=int(idx[0]), count=len(idx))
     return res, best
+
+
+def optimize_scenarios(solver, xinit, x0, params, n_iter=None):
+    """Batched counterpart of ScenarioConstraints::optimize (scenario_constraints.cpp:58-108): the P parallel scenario solvers
+    (each a copy of the main solver with its own scenario halfspaces in `params` [P][N][npar]; copying the main solver and
+    scenario_module.setParameters happen on the caller's side, e.g. modules.halfspace_rows_set_parameters) are solved together,
+    driven ONE RTI iteration at a time like the scenario module drives its solver (initializeOneIteration, solveOneIteration x n
+    with the loop exit on qp_status != 0, completeOneIteration; :85), then the selection of :93-107: lowest objective among exit
+    code 1 (init 1e9, strict '<': lowest index wins ties).  Returns (results dict, best index or -1, exit code the reference
+    returns: the best solver's, or the first solver's when none succeeded)."""
+    n_iter = solver.dims.n_sqp if n_iter is None else int(n_iter)
+    solver.set_batch(xinit, x0, params)                               # *solver = *_solver; setParameters; loadWarmstart
+    for it in range(n_iter):                                          # every slot stops by itself once its QP reports a status
+        solver.solve_iterations(1, keep_iterate=it > 0, keep_multipliers=True, complete=False)
+    solver.solve_iterations(0, keep_iterate=True, keep_multipliers=True, complete=True)
+    res = solver.get()
+    best, lowest = -1, 1e9
+    for i in range(len(res["pobj"])):
+        if res["exit_code"][i] == 1 and res["pobj"][i] < lowest:
+            lowest, best = res["pobj"][i], i
+    return res, best, int(res["exit_code"][best if best >= 0 else 0])

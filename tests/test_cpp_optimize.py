@@ -1,0 +1,153 @@
+"""C++ end-to-end of the boundary: the batched GuidanceConstraints::optimize restated in
+mpc_planner_amd/cpp/include/mpc_planner_modules/modules_hip.h (INTEGRATION.md section 4 as compiled code: C++ DynamicObstacle /
+RealTimeData / ModuleData, C++ MPCBase / Contouring / EllipsoidConstraints / LinearizedConstraints setParameters,
+initializeSolverWithGuidance, ONE Solver::solveBatch launch, FindBestPlanner) against the Python path (scenes.py + modules.py +
+BatchedSolver) on a cfg-2 tick."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GEN = os.path.join(ROOT, "build", "generated_cfg2")
+BIN = os.path.join(ROOT, "build", "test_optimize")
+N, M, B, S = 20, 8, 12, 5
+
+
+def _build():
+    import __graft_entry__ as g
+    g.build()
+    from mpc_planner_amd.generate_solver import generate_solver
+    generate_solver(GEN, N=N, max_obstacles=M, num_segments=S, guidance=True)
+    cpp = os.path.join(ROOT, "mpc_planner_amd", "cpp")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(cpp, "include"), "-I", os.path.join(GEN, "include"),
+                           "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "test_optimize.cpp"),
+                           os.path.join(cpp, "src", "solver_interface.cpp"), os.path.join(GEN, "src", "mpc_planner_parameters.cpp"),
+                           "-L", os.path.join(ROOT, "mpc_planner_amd"), "-ltmpc_hip", "-Wl,-rpath," + os.path.join(ROOT, "mpc_planner_amd"),
+                           "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-lamdhip64", "-o", BIN])
+
+
+def test_cpp_modules_compile():
+    """The C++ types + modules + batched optimize() compile against the generated setSolverParameter* functions (CPU)."""
+    _build()
+    assert os.path.exists(BIN)
+
+
+def _scene_file(sc, path, selected=-1):
+    from mpc_planner_amd import scenes
+    W = scenes.WEIGHTS
+    vals = [N, M, B, S, 1]
+    vals += [W[k] for k in ("acceleration", "angular_velocity", "velocity", "reference_velocity", "contour", "lag", "terminal_angle", "terminal_contouring")]
+    vals += [scenes.ROBOT_RADIUS, scenes.OBSTACLE_RADIUS]
+    vals += list(sc["xinit"][0])
+    vals += list(sc["obstacles"]["pos"].ravel())                       # [M][N][2]
+    vals += list(sc["segments"].ravel())                               # [S][9] = ax bx cx dx ay by cy dy start
+    for b in range(B):
+        vals += list(sc["guidance_pos"][b].ravel()) + list(sc["guidance_vel"][b].ravel())
+    vals += [selected]
+    np.array(vals, float).tofile(path)
+
+
+@pytest.mark.gpu
+def test_cpp_optimize_matches_python_path(tmp_path):
+    from mpc_planner_amd import scenes, solver
+    if not os.path.exists(BIN) or os.path.getmtime(BIN) < os.path.getmtime(os.path.join(ROOT, "mpc_planner_amd", "libtmpc_hip.so")):
+        _build()
+    sc = scenes.make_scene(21, N=N, M=M, B=B, tmpc_pp=True)
+    selected = 3
+    f = str(tmp_path / "scene.bin")
+    _scene_file(sc, f, selected)
+    out = subprocess.run([BIN, os.path.join(GEN, "config"), f], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = out.stdout.splitlines()
+    head = lines[0].split()
+    exit_code, best = int(head[1]), int(head[3])
+    planners = [l.split() for l in lines if l.startswith("planner")]
+    xs = np.array([[float(v) for v in l.split()[2:]] for l in lines if l.startswith("x ")])
+    ps = np.array([[float(v) for v in l.split()[2:]] for l in lines if l.startswith("p ")])
+    # ---- the Python path on the same tick ----
+    s = solver.BatchedSolver(solver.default_dims(N=N, S=S, n_lin=M, M=M), B_max=B + 1)
+    s.set_latency_mode(True)                                           # the C++ Solver mirror serves ticks with the latency variant
+    s.set_batch(sc["xinit"], sc["x0"], sc["params"]); s.solve(); g = s.get()
+    w = np.ones(B + 1); w[selected] = 0.75                             # selection_weight_consistency_ (guidance_constraints.cpp:358-359)
+    py_best = s.select_best(weight=w)
+    s.close()
+    assert len(planners) == B + 1
+    for b, pl in enumerate(planners):
+        assert int(pl[3]) == 0 and int(pl[5]) == g["exit_code"][b], (b, pl)
+        if g["exit_code"][b] == 1:
+            assert abs(float(pl[7]) - g["pobj"][b] * w[b]) <= 1e-7 * max(1.0, abs(g["pobj"][b]))     # (inputs built twice: equal to rounding)
+        assert int(pl[9]) == (2 * B if b == B else b)                  # guidance_ID: topology class, or 2 n_paths for the non-guided planner (:349)
+    assert best == py_best and exit_code == g["exit_code"][py_best]
+    np.testing.assert_allclose(ps, sc["params"][py_best], rtol=0, atol=1e-12)        # a3-a5 built in C++ == numpy mirrors
+    np.testing.assert_allclose(xs, g["xtraj"][py_best], rtol=0, atol=1e-7)
+
+
+# ---- SH-MPC: ScenarioConstraints::optimize (scenario_constraints.cpp:58-108), C++ batched restatement vs the Python driver ----
+GEN5 = os.path.join(ROOT, "build", "generated_cfg5")
+BIN5 = os.path.join(ROOT, "build", "test_scenario_optimize")
+P_SOLVERS, R_ROWS = 6, 24
+
+
+def _build_scenario():
+    import __graft_entry__ as g
+    g.build()
+    from mpc_planner_amd.generate_solver import generate_solver
+    generate_solver(GEN5, N=N, max_obstacles=M, num_segments=S, guidance=False, slack=True, ellipsoids=False, n_scenario=R_ROWS)
+    cpp = os.path.join(ROOT, "mpc_planner_amd", "cpp")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(cpp, "include"), "-I", os.path.join(GEN5, "include"),
+                           "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "test_scenario_optimize.cpp"),
+                           os.path.join(cpp, "src", "solver_interface.cpp"), os.path.join(GEN5, "src", "mpc_planner_parameters.cpp"),
+                           "-L", os.path.join(ROOT, "mpc_planner_amd"), "-ltmpc_hip", "-Wl,-rpath," + os.path.join(ROOT, "mpc_planner_amd"),
+                           "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-lamdhip64", "-o", BIN5])
+
+
+def test_cpp_scenario_modules_compile():
+    _build_scenario()
+    assert os.path.exists(BIN5)
+
+
+@pytest.mark.gpu
+def test_scenario_optimize_cpp_matches_python_driver(tmp_path):
+    """a11: the P parallel scenario solvers of SH-MPC in one launch -- C++ ScenarioConstraints::optimize and the Python driver
+    (solver.optimize_scenarios: one RTI iteration at a time, like the scenario module drives its solver) agree with each other and
+    with a plain batched solve; selection = lowest objective among exit code 1."""
+    from mpc_planner_amd import scenes, solver
+    if not os.path.exists(BIN5) or os.path.getmtime(BIN5) < os.path.getmtime(os.path.join(ROOT, "mpc_planner_amd", "libtmpc_hip.so")):
+        _build_scenario()
+    sc = scenes.make_scene(31, N=N, M=M, B=P_SOLVERS, slack=True, n_scenario=R_ROWS)
+    pm = sc["pm"]
+    # every parallel solver starts from the MAIN solver's warm start (scenario_constraints.cpp:73: *solver->solver = *_solver); the
+    # scene's trajectories only supply six different scenario-halfspace sets
+    x0 = np.repeat(sc["x0"][:1], P_SOLVERS, 0)
+    vals = [N, P_SOLVERS, R_ROWS, S]
+    W = scenes.WEIGHTS
+    vals += [W[k] for k in ("acceleration", "angular_velocity", "slack", "velocity", "reference_velocity", "contour", "lag", "terminal_angle", "terminal_contouring")]
+    vals += list(sc["xinit"][0]) + list(sc["segments"].ravel()) + list(x0[0].ravel())
+    for p in range(P_SOLVERS):
+        for k in range(1, N):
+            for r in range(R_ROWS):
+                vals += [sc["params"][p, k, pm.index(f"disc_0_scenario_constraint_{r}_{f}")] for f in ("a1", "a2", "b")]
+    f = str(tmp_path / "scenario.bin")
+    np.array(vals, float).tofile(f)
+    out = subprocess.run([BIN5, os.path.join(GEN5, "config"), f], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = out.stdout.splitlines()
+    c_exit, c_best = int(lines[0].split()[1]), int(lines[0].split()[3])
+    c_solvers = [l.split() for l in lines if l.startswith("solver")]
+    c_x = np.array([[float(v) for v in l.split()[2:]] for l in lines if l.startswith("x ")])
+    dims = solver.default_dims(N=N, S=S, n_lin=0, M=0, n_slk=R_ROWS, slack=1)
+    s = solver.BatchedSolver(dims, B_max=P_SOLVERS)
+    s.set_latency_mode(True)
+    res, best, code = solver.optimize_scenarios(s, sc["xinit"], x0, sc["params"])
+    s.set_batch(sc["xinit"], x0, sc["params"]); s.solve(); plain = s.get()
+    s.close()
+    np.testing.assert_array_equal(res["xtraj"], plain["xtraj"])                  # 10 x one iteration == solve(), bitwise
+    assert (res["exit_code"] == 1).sum() >= 2 and best >= 0
+    assert c_best == best and c_exit == code
+    for p_, row in enumerate(c_solvers):
+        assert int(row[3]) == res["exit_code"][p_]
+        if res["exit_code"][p_] == 1:
+            assert abs(float(row[5]) - res["pobj"][p_]) <= 1e-7 * max(1.0, abs(res["pobj"][p_]))
+    np.testing.assert_allclose(c_x, res["xtraj"][best][:, :4], rtol=0, atol=1e-7)

@@ -290,12 +290,20 @@ def test_device_linearize_topology_matches_host_mirror():
     is_orig = np.concatenate([(np.arange(len(s["xinit"])) == len(s["xinit"]) - 1).astype(np.uint8) for s in scs])
     obst = np.stack([s["obstacles"]["pos"] for s in scs])                       # [3][8][20][2]
     state_x = np.array([s["xinit"][0, 0] for s in scs])
-    # put one guess inside an obstacle's projection disc
+    # guesses that need projectToSafety: inside one obstacle's disc; inside two overlapping discs; inside the anchor's
+    # (obstacle 0) disc; exactly on an obstacle's centre
+    obst[0, 4, 8] = obst[0, 3, 8] + np.array([0.30, 0.05])                     # obstacles 3 and 4 overlap at step 8 (stage 9)
     x0[5, 7, 2:4] = obst[0, 3, 6] + np.array([0.05, 0.02])
+    x0[6, 9, 2:4] = obst[0, 3, 8] + np.array([0.16, 0.04])
+    x0[7, 4, 2:4] = obst[0, 0, 3] + np.array([-0.1, 0.12])
+    x0[8, 11, 2:4] = obst[0, 5, 10]
     pm = scs[0]["pm"]
     ref = want.copy()
-    lin = md.linearized_update(x0[5], obst[0], 0.325)              # applies the same radial projection (project_to_safety)
-    md.linearized_set_parameters(pm, ref[5], state_x[0], lin, n_rows=8)
+    for b in range(len(scs[0]["xinit"]) - 1):                        # every guided trajectory of scene 0 sees the moved obstacle 4
+        lin = md.linearized_update(x0[b], obst[0], 0.325)          # applies the Douglas-Rachford projection (project_to_safety)
+        md.linearized_set_parameters(pm, ref[b], state_x[0], lin, n_rows=8)
+        if b in (5, 6, 7, 8):
+            assert np.abs(ref[b] - want[b]).max() > 1e-3           # the projection moved something
     start = want.copy()
     for j in range(8):                                                          # wipe the lin rows: the device must rebuild them
         for f in ("a1", "a2", "b"):

@@ -69,3 +69,21 @@ def test_project_to_safety_is_identity_when_clear_and_pushes_out_otherwise():
     a1, a2, b = md.linearized_update(x0, pos, 0.325)
     assert np.isfinite(a1).all() and np.isfinite(a2).all() and np.isfinite(b).all()
     np.testing.assert_allclose(a1[1:] ** 2 + a2[1:] ** 2, 1.0, atol=1e-12)
+
+
+def test_project_to_safety_douglas_rachford_properties():
+    """LinearizedConstraints::projectToSafety restated with the Douglas-Rachford operator (modules.project_to_safety): identity
+    on a collision-free guess; a guess inside one disc lands on that disc's boundary (the DR step with a non-colliding anchor is
+    the nearest-point projection); three sweeps clear two overlapping discs."""
+    from mpc_planner_amd import modules as md
+    r = 0.326
+    obs = np.array([[5.0, 5.0], [1.0, 0.0], [1.4, 0.1]])
+    p = md.project_to_safety(np.array([3.0, 3.0]), obs, r)
+    assert (p == [3.0, 3.0]).all()
+    p = md.project_to_safety(np.array([1.1, 0.05]), obs[:2], r)
+    assert abs(np.linalg.norm(p - obs[1]) - r) < 1e-12
+    np.testing.assert_allclose((p - obs[1]) / r, np.array([0.1, 0.05]) / np.hypot(0.1, 0.05), atol=1e-12)      # radially outwards
+    p = md.project_to_safety(np.array([1.2, 0.06]), obs, r)
+    assert min(np.linalg.norm(p - o) for o in obs) >= r - 1e-9
+    p = md.project_to_safety(np.array([1.0, 0.0]), obs[:2], r)                    # on the centre: a fixed direction, still outside
+    assert np.linalg.norm(p - obs[1]) >= r - 1e-12
