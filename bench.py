@@ -28,6 +28,25 @@ HBM_PEAK_GBS = 8000.0                           # MI355X_MICROARCH.md: HBM3E 8.0
 FP64_VALU_PEAK_TFLOPS = 78.6                    # MI355X FP64 vector peak (AMD spec; f64 MFMA has the same rate)
 
 
+# BASELINE.json configs as bench workloads.  configs[1] (cfg2) is what the metric is quoted on and the default; cfg4 / cfg5 are the
+# multi-GPU configurations (one guidance / scenario set split over the ranks): `--workload cfg4` under torch.distributed.run.
+WORKLOADS = {
+    "cfg2": dict(dims=dict(N=20, S=5, n_lin=8, M=8), scene=dict(N=20, M=8), traj=64, nh=16, npar=135,
+                 what="configs[1]: Jackal MPCC N=20, 8 obstacles, 64 T-MPC guidance trajectories per scene"),
+    "cfg4": dict(dims=dict(N=20, S=5, n_lin=12, M=12), scene=dict(N=20, M=12), traj=4096, nh=24, npar=175, one_set=True,
+                 what="configs[3]: T-MPC++ 4096 guidance trajectories, N=20, 12 obstacles, ONE guidance set split over the ranks"),
+    "cfg5": dict(dims=dict(N=20, S=5, n_lin=0, M=0, n_slk=24, slack=1), scene=dict(N=20, M=8, slack=True, n_scenario=24), traj=32, nh=24,
+                 npar=127, one_set=True, what="configs[4]: SH-MPC, 8 obstacles x 256 scenarios -> 24 halfspaces, 32 scenario solvers split over the ranks"),
+}
+
+
+def library_sha256():
+    import hashlib
+    path = os.path.join(ROOT, "mpc_planner_amd", "libtmpc_hip.so")
+    with open(path, "rb") as fh:
+        return hashlib.sha256(fh.read()).hexdigest()
+
+
 def flops_per_solve(n_sqp_mean, n_ipm_per_qp, N=N_H, nv=NV, nx=NX, nh=2 * M_OBS):
     """SURVEY.md 8(d) algorithmic FP64 flop model, with MEASURED iteration counts."""
     f_dyn = 12 * (2 * nx * nx * nv + 2 * nx * nv * nv + 20)
@@ -102,9 +121,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--scenes", type=int, default=256,
-                    help="scenes (control ticks) per launch per GPU; 256 x 64 = 16384 trajectories keep the tail of uneven solve "
-                         "times small (64 scenes: 391k solves/s, 256: 479k, 1024: 489k on one MI355X)")
+    ap.add_argument("--scenes", type=int, default=512,
+                    help="scenes (control ticks) per launch per GPU; 512 x 64 = 32768 trajectories keep the tail of uneven solve "
+                         "times small (256 scenes: 497k solves/s, 1024: 514k, 2048: 516k on one MI355X)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cfg2")
+    ap.add_argument("--no-lanes", action="store_true", help="skip the lane-per-trajectory variant's measurement")
     ap.add_argument("--cpu-scenes", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--latency-reps", type=int, default=100)
@@ -112,13 +133,34 @@ def main():
                     help="trajectories of the timed launch re-solved by the CPU oracle after timing (0 = skip)")
     a = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
-    from mpc_planner_amd import scenes, solver, distributed as D
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    wl = WORKLOADS[a.workload]
+    TRAJ_SET = wl["traj"]                                 # trajectories of one guidance / scenario set (one FindBestPlanner domain)
+
+    # ---- synthetic inputs, generated before the GPU runtime is touched (forked workers) -------------------------
+    from mpc_planner_amd import scenes
+    if wl.get("one_set"):
+        # one set split over the ranks: every rank builds the same scene and keeps its contiguous share
+        per_rank = TRAJ_SET // world
+        full = scenes.make_scene(7, B=TRAJ_SET, **wl["scene"])
+        sl = slice(rank * per_rank, (rank + 1) * per_rank)
+        batch = {k: full[k][sl] for k in ("xinit", "x0", "params", "guidance_id")}
+        n_sets, traj_local = 1, per_rank
+    else:
+        # weak scaling: rank r owns trajectories [64 r, 64 (r+1)) of every scene's guidance set -> different seeds per rank
+        first_scene = 100000 * rank
+        batch = scenes.make_batch(range(first_scene, first_scene + a.scenes), workers=usable_cpus(), B=TRAJ_SET, **wl["scene"])
+        n_sets, traj_local = a.scenes, TRAJ_SET
+    B = batch["xinit"].shape[0]
+
+    import torch
+    import torch.distributed as dist
+    from mpc_planner_amd import solver, distributed as D
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -128,38 +170,32 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    if a.gpus != world:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
 
-    # ---- synthetic inputs, resident in HBM before timing ------------------------------------
-    # rank r owns trajectories [64 r, 64 (r+1)) of every scene's guidance set -> different seeds per rank
-    first_scene = 100000 * rank
-    batch = scenes.make_batch(range(first_scene, first_scene + a.scenes), N=N_H, M=M_OBS, B=TRAJ)
-    B = batch["xinit"].shape[0]
     t_xinit = torch.from_numpy(batch["xinit"]).to(dev)
     t_x0 = torch.from_numpy(batch["x0"].reshape(B, -1)).to(dev)
     t_params = torch.from_numpy(batch["params"].reshape(B, -1)).to(dev)
-    t_gid = torch.from_numpy(batch["guidance_id"].astype(np.int32) + TRAJ * rank).to(dev)
+    t_gid = torch.from_numpy(batch["guidance_id"].astype(np.int32) + traj_local * rank).to(dev)
     t_rec = torch.zeros((B, 2), dtype=torch.int64, device=dev)              # 16-byte tmpc_record each
-    t_best = torch.full((a.scenes,), -2, dtype=torch.int32, device=dev)
+    t_best = torch.full((n_sets,), -2, dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
 
-    dims = solver.default_dims(N=N_H, S=S_SEG, n_lin=M_OBS, M=M_OBS)
+    dims = solver.default_dims(**wl["dims"])
     sv = solver.BatchedSolver(dims, B_max=B, device=local_rank)
     sv.set_batch_device(B, t_xinit.data_ptr(), t_x0.data_ptr(), t_params.data_ptr())
     sv.enable_timing(a.steps + a.warmup + 4)
+    gather_stream = torch.cuda.Stream(device=dev) if use_dist else None
 
     def step():
         sv.solve(sync=False)                                                # the dominant kernel
         sv.pack_records(t_rec.data_ptr(), t_gid.data_ptr())
         if use_dist:
-            sv.synchronize()                                                # records visible to torch's stream
+            sv.synchronize()                                                # the records are complete: hand them to the collective
             gathered = D.all_gather_records(t_rec, world)                   # ONE RCCL all-gather, 16 B x B per rank
-            torch.cuda.current_stream().synchronize()
-            sv.select_best_records(gathered.data_ptr(), world, a.scenes, TRAJ, t_best.data_ptr())
+            torch.cuda.current_stream().synchronize()                       # the gathered records are complete: hand them back
+            sv.select_best_records(gathered.data_ptr(), world, n_sets, traj_local, t_best.data_ptr())
             step.keep = gathered
         else:
-            sv.select_best_records(t_rec.data_ptr(), 1, a.scenes, TRAJ, t_best.data_ptr())
+            sv.select_best_records(t_rec.data_ptr(), 1, n_sets, traj_local, t_best.data_ptr())
 
     for _ in range(a.warmup):
         step()
@@ -193,7 +229,7 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib as O
         n = min(a.parity_check, B)
-        pbo = O.problem(N=N_H, S=S_SEG, n_lin=M_OBS, M=M_OBS)
+        pbo = O.problem(**wl["dims"])
         xt, ut, info = O.solve_batch(pbo, batch["xinit"][:n], batch["x0"][:n].reshape(n, -1), batch["params"][:n].reshape(n, -1),
                                      num_threads=usable_cpus())
         both = (info["exit_code"] == 1) & (res["exit_code"][:n] == 1)
@@ -211,7 +247,21 @@ def main():
 
     # ---- p50 latency of one control tick (64 trajectories, host call -> best index on host) --------------
     lat = None
-    if rank == 0 and a.latency_reps > 0:
+    lanes = None
+    if rank == 0 and not a.no_lanes and not use_dist:
+        # the lane-per-trajectory variant (tmpc_set_throughput_mode) on the same resident batch: the measured alternative design
+        sv.set_throughput_mode(True)
+        sv.solve(); sv.solve(sync=False)
+        ms_l = sv.time_solve(3)
+        rl = sv.get()
+        sv.set_throughput_mode(False)
+        okl = (rl["exit_code"] == 1) & ok
+        lanes = {"kernel": "lanes_solve_kernel (one lane per trajectory, state streamed from a lane-major HBM workspace)",
+                 "kernel_ms": float(np.median(ms_l)), "solves_per_s": float(B / (np.median(ms_l) * 1e-3)),
+                 "exit_code_mismatch_vs_default": int((rl["exit_code"] != res["exit_code"]).sum()),
+                 "ipm_iter_mismatch_vs_default": int((rl["qp_iter_total"][okl] != res["qp_iter_total"][okl]).sum()),
+                 "max_abs_traj_diff_vs_default": float(np.abs(rl["xtraj"][okl] - res["xtraj"][okl]).max()) if okl.any() else None}
+    if rank == 0 and a.latency_reps > 0 and a.workload == "cfg2":
         one = solver.BatchedSolver(dims, B_max=TRAJ, device=local_rank)
         lat_variant = one.set_latency_mode(True)          # two-waves-per-trajectory kernel variant for small ticks
         sl = slice(0, TRAJ)
@@ -237,30 +287,37 @@ def main():
         attempted = solves / elapsed
         value = attempted * float(ok.mean())               # successful solves only (rank 0's success fraction; same workload on every rank)
         k_avg = float(np.mean(kernel_ms)) * 1e-3
-        fl = flops_per_solve(n_sqp_mean, ipm_per_qp)
-        by = bytes_per_solve()
+        fl = flops_per_solve(n_sqp_mean, ipm_per_qp, N=dims.N, nh=wl["nh"])
+        by = bytes_per_solve(N=dims.N, npar=wl["npar"], nv=dims.nvar, nx=dims.nx)
         tflops = B * fl / k_avg / 1e12
         gbs = B * by / k_avg / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "round1_pmc.json")
-        if os.path.exists(pmc):
+        # HBM traffic comes from rocprofv3 PMC passes (tools/collect_profiles.py), which cannot run inside this process: it is
+        # reported only if the committed counters were collected on THIS build of the library and this launch size
+        traffic, traffic_note, lib_hash = None, None, library_sha256()
+        pmc = os.path.join(ROOT, "profiles", "round2_pmc.json")
+        if os.path.exists(pmc) and a.workload == "cfg2":
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                pj = json.load(open(pmc))
+                if pj.get("library_sha256") == lib_hash and pj.get("trajectories_per_launch") == B:
+                    traffic = pj.get("hbm_bytes_per_launch")
+                    traffic_note = f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this build ({lib_hash[:12]}), {pmc.split(os.sep)[-1]}"
+                else:
+                    traffic_note = f"profiles/round2_pmc.json is for build {str(pj.get('library_sha256'))[:12]} / {pj.get('trajectories_per_launch')} trajectories per launch; this run: {lib_hash[:12]} / {B}"
             except Exception:
                 traffic = None
         out = {
-            "metric": "MPC solves/s (Jackal N=20, 8 obs)", "value": value, "unit": "solves/s",
+            "metric": "MPC solves/s (Jackal N=20, 8 obs)" if a.workload == "cfg2" else f"MPC solves/s ({a.workload})", "value": value, "unit": "solves/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"configs[1]: Jackal MPCC N=20, 8 obstacles, 64 T-MPC guidance trajectories per scene; "
-                                   f"{a.scenes} scenes x 64 = {B} trajectories per launch per GPU, n_sqp=10, qp_tol=1e-5",
-                       "trajectories_per_launch_per_gpu": B, "scenes_per_launch": a.scenes,
+            "higher_is_better": True, "scaling": "strong" if wl.get("one_set") else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{wl['what']}; {n_sets} set(s) x {traj_local} = {B} trajectories per launch per GPU, n_sqp=10, qp_tol=1e-5",
+                       "trajectories_per_launch_per_gpu": B, "scenes_per_launch": n_sets,
                        "success_fraction": float(ok.mean()), "mean_sqp_iter": n_sqp_mean, "mean_ipm_iter_per_qp": ipm_per_qp,
                        "value_counts": "successful solves (exit_code == 1) only",
                        "parallelism": f"trajectory-sharded x{world}, one 16 B/trajectory all-gather" if world > 1 else "single GPU"},
             "roofline": {"bound": "valu_fp64", "achieved": tflops, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": tflops / FP64_VALU_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel": "tmpc_solve_fast_kernel<8,8,3>", "kernel_ms_avg": k_avg * 1e3, "flops_per_solve": fl,
+                         "frac": tflops / FP64_VALU_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_note,
+                         "library_sha256": lib_hash,
+                         "kernel": "tmpc_solve_fast_kernel (one wavefront per trajectory)", "kernel_ms_avg": k_avg * 1e3, "flops_per_solve": fl,
                          "note": "compute roofline for dtype f64: on MI355X the dense f64 MFMA peak equals the f64 vector (VALU) "
                                  "peak, 78.6 TFLOP/s (AMD spec); the kernel issues FP64 VALU (7x7 stage blocks, SURVEY 8d), so "
                                  "this is the binding roofline; achieved = algorithmic flops (SURVEY 8d model x measured "
@@ -270,6 +327,7 @@ def main():
             "success_solves_per_s": value, "attempted_solves_per_s": attempted,
             "value_all_10_iter": attempted * float(full.mean()),
             "parity": parity,
+            "lanes_variant": lanes,
             "latency_b64": lat,
             "best_index_sample": best[:4].tolist(),
         }

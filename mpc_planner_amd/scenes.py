@@ -292,9 +292,21 @@ def make_scene(scene_idx, N=20, M=8, B=64, S=5, tmpc_pp=False, gaussian=False, g
                 n_slk=n_scenario + n_decomp, slack=int(slack), samples=samples, guidance_pos=guidance_pos, guidance_vel=guidance_vel)
 
 
-def make_batch(scene_indices, **kw):
-    """Concatenate scenes into one launch batch (throughput mode: S scenes x B trajectories)."""
-    scenes = [make_scene(i, **kw) for i in scene_indices]
+def _make_scene_kw(args):
+    idx, kw = args
+    return make_scene(idx, **kw)
+
+
+def make_batch(scene_indices, workers=1, **kw):
+    """Concatenate scenes into one launch batch (throughput mode: S scenes x B trajectories).  workers > 1 generates the
+    scenes in that many forked processes (call it before anything initialises the GPU runtime in this process)."""
+    scene_indices = list(scene_indices)
+    if workers > 1 and len(scene_indices) > 1:
+        import multiprocessing as mp
+        with mp.get_context("fork").Pool(min(workers, len(scene_indices))) as pool:
+            scenes = pool.map(_make_scene_kw, [(i, kw) for i in scene_indices], chunksize=max(1, len(scene_indices) // (4 * workers)))
+    else:
+        scenes = [make_scene(i, **kw) for i in scene_indices]
     out = dict(scenes[0])
     for key in ("xinit", "x0", "params", "guidance_id"):
         out[key] = np.concatenate([s[key] for s in scenes], 0)

@@ -14,7 +14,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out")
 tag = sys.argv[1] if len(sys.argv) > 1 else "profile"
-BENCH = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "1", "--no-cpu-baseline", "--latency-reps", "0"]
+BENCH = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "1", "--no-cpu-baseline", "--latency-reps", "0", "--no-lanes", "--parity-check", "0"]
 env = dict(os.environ, TMPDIR="/tmp")
 
 
@@ -36,8 +36,12 @@ def rows(d, suffix):
     return out
 
 
-summary = {"command": "rocprofv3 --kernel-trace --stats -- " + " ".join(BENCH[1:]) + "   (cfg2, 256 scenes x 64 = 16384 trajectories per launch); "
-           "PMC in separate --pmc passes", "tag": tag}
+import hashlib
+with open(os.path.join(ROOT, "mpc_planner_amd", "libtmpc_hip.so"), "rb") as fh:
+    LIB_HASH = hashlib.sha256(fh.read()).hexdigest()
+summary = {"command": "rocprofv3 --kernel-trace --stats -- " + " ".join(BENCH[1:]) + "   (cfg2, bench.py's default launch: 512 scenes x 64 = 32768 trajectories); "
+           "PMC in separate --pmc passes; kernel trace and every counter pass ran on the same build of the library", "tag": tag,
+           "library_sha256": LIB_HASH, "trajectories_per_launch": 512 * 64}
 d = rocprof("kt", ["--kernel-trace", "--stats"], BENCH)
 ks = rows(d, "kernel_stats")
 summary["kernel_stats"] = ks
@@ -79,6 +83,11 @@ if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
                                            note="counter x calibrated bytes-per-count (known 1 GiB read / write streams, 8 B per lane)")
 with open(os.path.join(OUT, f"{tag}_rocprof_summary.json"), "w") as fh:
     json.dump(summary, fh, indent=1)
+if "hbm_bytes_per_launch" in summary:                        # what bench.py's roofline.traffic reads (matched by library hash + launch size)
+    with open(os.path.join(OUT, f"{tag}_pmc.json"), "w") as fh:
+        json.dump({"library_sha256": LIB_HASH, "trajectories_per_launch": 512 * 64, "hbm_bytes_per_launch": summary["hbm_bytes_per_launch"]["total"],
+                   "fetch": summary["hbm_bytes_per_launch"]["fetch"], "write": summary["hbm_bytes_per_launch"]["write"],
+                   "source": f"tools/collect_profiles.py {tag}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on the solve kernel, calibrated bytes per count"}, fh, indent=1)
 print(json.dumps({k: summary[k] for k in ("calibration", "pmc_mean_per_launch") if k in summary}, indent=1))
 for r in ks[:4]:
     print(r.get("Name", "")[:80], r.get("Calls"), r.get("AverageNs"))
