@@ -126,6 +126,8 @@ def main():
                          "times small (256 scenes: 497k solves/s, 1024: 514k, 2048: 516k on one MI355X)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cfg2")
     ap.add_argument("--no-lanes", action="store_true", help="skip the lane-per-trajectory variant's measurement")
+    ap.add_argument("--gen-workers", type=int, default=0, help="processes that generate the scenes (0 = all usable CPUs; 1 = no fork, e.g. under a profiler)")
+    ap.add_argument("--scene-cache", default="", help="npz file to keep the generated batch in (repeated profiler passes)")
     ap.add_argument("--cpu-scenes", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--latency-reps", type=int, default=100)
@@ -153,7 +155,13 @@ def main():
     else:
         # weak scaling: rank r owns trajectories [64 r, 64 (r+1)) of every scene's guidance set -> different seeds per rank
         first_scene = 100000 * rank
-        batch = scenes.make_batch(range(first_scene, first_scene + a.scenes), workers=usable_cpus(), B=TRAJ_SET, **wl["scene"])
+        cache = f"{a.scene_cache}.{a.workload}.{a.scenes}.{rank}.npz" if a.scene_cache else ""
+        if cache and os.path.exists(cache):
+            batch = dict(np.load(cache))
+        else:
+            batch = scenes.make_batch(range(first_scene, first_scene + a.scenes), workers=a.gen_workers or usable_cpus(), B=TRAJ_SET, **wl["scene"])
+            if cache:
+                np.savez(cache, **{k: batch[k] for k in ("xinit", "x0", "params", "guidance_id")})
         n_sets, traj_local = a.scenes, TRAJ_SET
     B = batch["xinit"].shape[0]
 

@@ -14,17 +14,20 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out")
 tag = sys.argv[1] if len(sys.argv) > 1 else "profile"
-BENCH = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "1", "--no-cpu-baseline", "--latency-reps", "0", "--no-lanes", "--parity-check", "0"]
+BENCH = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "1", "--no-cpu-baseline", "--latency-reps", "0", "--no-lanes", "--parity-check", "0", "--gen-workers", "1", "--scene-cache", "/tmp/tmpc_bench_scenes"]
 env = dict(os.environ, TMPDIR="/tmp")
 
 
 def rocprof(name, args, cmd):
     d = os.path.join(OUT, f"{tag}_{name}")
     shutil.rmtree(d, ignore_errors=True)
-    r = subprocess.run(["rocprofv3", *args, "-d", d, "--output-format", "csv", "--"] + cmd, cwd="/tmp", env=env,
-                       capture_output=True, text=True)
-    if r.returncode != 0:
-        print(name, "failed:", r.stderr[-2000:])
+    try:
+        r = subprocess.run(["rocprofv3", *args, "-d", d, "--output-format", "csv", "--"] + cmd, cwd="/tmp", env=env,
+                           capture_output=True, text=True, timeout=240)
+        if r.returncode != 0:
+            print(name, "failed:", r.stderr[-2000:], flush=True)
+    except subprocess.TimeoutExpired:
+        print(name, "timed out after 240 s", flush=True)
     return d
 
 
@@ -39,6 +42,7 @@ def rows(d, suffix):
 import hashlib
 with open(os.path.join(ROOT, "mpc_planner_amd", "libtmpc_hip.so"), "rb") as fh:
     LIB_HASH = hashlib.sha256(fh.read()).hexdigest()
+subprocess.run(BENCH + ["--steps", "1", "--warmup", "0"], cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)   # fills the scene cache
 summary = {"command": "rocprofv3 --kernel-trace --stats -- " + " ".join(BENCH[1:]) + "   (cfg2, bench.py's default launch: 512 scenes x 64 = 32768 trajectories); "
            "PMC in separate --pmc passes; kernel trace and every counter pass ran on the same build of the library", "tag": tag,
            "library_sha256": LIB_HASH, "trajectories_per_launch": 512 * 64}
@@ -52,6 +56,12 @@ if ks:
 SETS = [["FETCH_SIZE"], ["WRITE_SIZE"],
         ["SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU"],
         ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_SMEM", "SQ_ACTIVE_INST_LDS", "SQ_INST_CYCLES_VMEM"]]
+def flush():
+    with open(os.path.join(OUT, f"{tag}_rocprof_summary.json"), "w") as fh:
+        json.dump(summary, fh, indent=1)
+
+
+flush()
 pmc = {}
 for i, cs in enumerate(SETS):
     d = rocprof(f"pmc{i}", ["--pmc", *cs], BENCH)
@@ -62,7 +72,8 @@ for i, cs in enumerate(SETS):
         acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
     for k, v in acc.items():
         pmc[k] = sum(v) / len(v)
-summary["pmc_mean_per_launch"] = pmc
+    summary["pmc_mean_per_launch"] = pmc
+    flush()
 
 # calibration of FETCH_SIZE / WRITE_SIZE on a known stream with the solve kernel's access width
 exe = "/tmp/pmc_calibrate"
