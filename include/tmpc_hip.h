@@ -137,9 +137,11 @@ int tmpc_set_throughput_mode(tmpc_handle *h, int32_t on);
 int tmpc_get(tmpc_handle *h, double *xtraj, double *utraj, double *pobj, int32_t *exit_code,
              int32_t *qp_status, int32_t *sqp_iter, double *res_eq, int32_t *qp_iter_total);
 
-/* Replaces FindBestPlanner (guidance_constraints.cpp:416-434) on device: argmin over trajectories
- * [first, first+count) of pobj*weight among exit_code == 1 && !disabled; init 1e10, strict '<'
- * (lowest index wins ties); *best = -1 if none.  weight/disabled are host pointers or NULL. */
+/* Replaces FindBestPlanner (guidance_constraints.cpp:416-434) on device for ONE planner set = the contiguous trajectories
+ * [first, first+count) of the batch (one scene's local planners): argmin of pobj*weight among exit_code == 1 && !disabled; init 1e10,
+ * strict '<' (lowest index wins ties).  Index convention: everything is RELATIVE TO `first`, like an index into the reference's
+ * planners_ vector -- weight[i] / disabled[i] (host pointers, `count` entries, or NULL) belong to trajectory first + i, and *best
+ * is in [0, count) (the batch index is first + *best), or -1 if none. */
 int tmpc_select_best(tmpc_handle *h, int32_t first, int32_t count, const double *weight,
                      const uint8_t *disabled, int32_t *best);
 
@@ -183,6 +185,9 @@ int tmpc_time_solve(tmpc_handle *h, int32_t reps, float *ms_each);
  * a = (o - p)/|o - p|, b = a.o - (1e-3 + robot_radius) (:84-105, guidance mode) and write lin_constraint_j_{a1,a2,b}
  * into params[b][k]; stage 0 and the rows of non-guided planners get the dummies (1, 0, state_x + 100) (:155-166,
  * guidance_constraints.cpp:301-305).  The batch's params buffer is modified IN PLACE (device memory).
+ * ALL n_lin topology rows are treated as dynamic obstacles (d_obstacle_pos has n_lin entries per scene): a configuration with
+ * linearized_constraints/add_halfspaces > 0 (static halfspace rows behind the obstacle rows, :107-123) must pass dummy
+ * obstacles far away for those slots and write the static rows itself afterwards (they are per-scene constants).
  *   d_obstacle_pos : f64 [n_scenes][n_lin][N][2]   prediction step i of obstacle j (stage k uses step k-1)
  *   d_scene_of     : i32 [B]                       scene of trajectory b
  *   d_state_x      : f64 [n_scenes]                current state x (for the dummy b)

@@ -50,13 +50,28 @@ def generate_solver_from_modules(out_dir, name, modules, model, settings, n_sqp=
     # in a generated library every row is one of the nh normalised rows; SOLVER_S only informs host code (segment loops)
     _write_host_side(out_dir, pm, settings["N"], bool(meta["slack"]), n_sqp, settings.get("integrator_step", 0.2), n_lin=meta["nh"], M=0,
                      n_slk=0, num_segments=settings.get("contouring", {}).get("num_segments", 1),
-                     max_obstacles=settings.get("max_obstacles", 0))
+                     max_obstacles=settings.get("max_obstacles", 0), model=model)
     from .codegen import cpp_glue
     cpp_glue.write_module_glue(out_dir, modules)        # modules.h / definitions.h / modules.cmake for mpc_planner_modules
     return lib, meta
 
 
-def _write_host_side(out_dir, pm, N, slack, n_sqp, dt, n_lin, M, n_slk, num_segments, max_obstacles):
+def _model_map(slack, model=None):
+    """model_map.yaml rows `name: [x|u, index, lb, ub]` (solver_model.py:118-128).  A plugin model's own bounds (model.set_bounds,
+    solver_model.py:107-116) are written out, as the reference wires them into lbx/ubx/lbu/ubu (generate_acados_solver.py:100-107);
+    the C++ Solver mirror hands them to tmpc_create through tmpc_dims::lb/ub."""
+    base = MODEL_MAP_UNICYCLE_SLACK if slack else MODEL_MAP_UNICYCLE
+    if model is None or not hasattr(model, "lower_bound"):
+        return base
+    out = type(base)()
+    for name, (kind, idx, lb, ub) in base.items():
+        if idx < len(model.lower_bound):
+            lb, ub = float(model.lower_bound[idx]), float(model.upper_bound[idx])
+        out[name] = [kind, idx, lb, ub]
+    return out
+
+
+def _write_host_side(out_dir, pm, N, slack, n_sqp, dt, n_lin, M, n_slk, num_segments, max_obstacles, model=None):
     npar = pm.length()
     nu, nx = 2, 5 + int(bool(slack))
     cfg = os.path.join(out_dir, "config"); inc = os.path.join(out_dir, "include", "mpc_planner_solver")
@@ -64,7 +79,7 @@ def _write_host_side(out_dir, pm, N, slack, n_sqp, dt, n_lin, M, n_slk, num_segm
     for p in (cfg, inc, src):
         os.makedirs(p, exist_ok=True)
     open(os.path.join(cfg, "parameter_map.yaml"), "w").write(_yaml_dump_flat(pm.as_dict()))
-    open(os.path.join(cfg, "model_map.yaml"), "w").write(_yaml_dump_flat(MODEL_MAP_UNICYCLE_SLACK if slack else MODEL_MAP_UNICYCLE))
+    open(os.path.join(cfg, "model_map.yaml"), "w").write(_yaml_dump_flat(_model_map(slack, model)))
     open(os.path.join(cfg, "solver_settings.yaml"), "w").write(_yaml_dump_flat(
         dict(N=N, nx=nx, nu=nu, nvar=nx + nu, npar=npar, integrator_step=dt, iterations=n_sqp,
              n_lin=n_lin, max_obstacles=max_obstacles, num_segments=num_segments)))

@@ -250,3 +250,16 @@ def test_plugin_base_classes_like_the_reference_tests():
     # unicycle at psi = pi/2, v = 2: moves along +y
     dx = P.UnicycleContouringModel().continuous_model([0., 0., np.pi / 2, 2.0, 0.], [0.5, -0.1])
     np.testing.assert_allclose(dx, [0.0, 2.0, -0.1, 0.5, 2.0], atol=1e-15)
+
+
+def test_generated_model_map_carries_the_models_bounds(tmp_path):
+    """Round-1 advisor finding: a plugin model's set_bounds(...) never reached the generated solver's model_map.yaml."""
+    from mpc_planner_amd.generate_solver import _model_map
+    from mpc_planner_amd.codegen import plugin
+    model = plugin.UnicycleContouringModel()
+    lb = list(model.lower_bound); ub = list(model.upper_bound)
+    lb[0], ub[0], ub[5] = -1.2, 1.2, 2.5                           # a, v
+    model.set_bounds(lb, ub)
+    mm = _model_map(False, model)
+    assert mm["a"] == ["u", 0, -1.2, 1.2] and mm["v"][3] == 2.5 and mm["w"] == ["u", 1, -0.8, 0.8]
+    assert _model_map(True)["slack"] == ["x", 7, 0.0, 5000.0]

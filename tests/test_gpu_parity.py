@@ -215,6 +215,23 @@ def test_throughput_mode_matches_oracle(cfg):
     s.close()
 
 
+def test_select_best_index_convention_with_offset():
+    """tmpc_select_best over a planner set that does not start at trajectory 0: weight / disabled / the returned index are all
+    relative to `first` (round-1 advisor finding: undocumented and untested)."""
+    import oracle_lib as O
+    from mpc_planner_amd import scenes
+    sc = scenes.make_batch(range(3, 6), N=20, M=8, B=16)
+    s = _solver(B_max=48)
+    s.set_batch(sc["xinit"], sc["x0"], sc["params"]); s.solve(); g = s.get()
+    for first in (0, 16, 32):
+        sl = slice(first, first + 16)
+        w = np.ones(16); w[5] = 0.75
+        dis = np.zeros(16, np.uint8); dis[int(np.argmin(np.where(g["exit_code"][sl] == 1, g["pobj"][sl], np.inf)))] = 1
+        assert s.select_best(first=first, count=16) == O.find_best(g["pobj"][sl], g["exit_code"][sl])
+        assert s.select_best(first=first, count=16, weight=w, disabled=dis) == O.find_best(g["pobj"][sl] * w, g["exit_code"][sl], dis)
+    s.close()
+
+
 # ---- BASELINE.json sizes: every configuration at the batch size its config line names, HIP path vs oracle ----------------
 BASELINE_CASES = {
     # cfg 2: 64 guidance trajectories per tick; four ticks of the bench workload (scenes 0..3 of bench.py's launch)
