@@ -117,3 +117,35 @@ def test_cpp_solver_over_a_generated_library():
                            lib, "-Wl,-rpath," + os.path.dirname(lib), "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-lamdhip64", "-o", exe])
     res = subprocess.run([exe, os.path.join(out, "config"), "--solve"], capture_output=True, text=True, timeout=300)
     assert res.returncode == 0 and "solve ok" in res.stdout, res.stdout + res.stderr
+
+
+BIN_SHARDED = os.path.join(ROOT, "build", "test_sharded")
+
+
+def _build_sharded():
+    import __graft_entry__ as g
+    g.build()
+    cpp = os.path.join(ROOT, "mpc_planner_amd", "cpp")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(cpp, "include"), "-I", os.path.join(ROOT, "include"),
+                           "-I/opt/rocm/include", os.path.join(ROOT, "tests", "cpp", "test_sharded.cpp"), os.path.join(cpp, "src", "sharded_batch.cpp"),
+                           "-L", os.path.join(ROOT, "mpc_planner_amd"), "-ltmpc_hip", "-Wl,-rpath," + os.path.join(ROOT, "mpc_planner_amd"),
+                           "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-lamdhip64", "-lrccl", "-o", BIN_SHARDED])
+
+
+def test_cpp_sharded_selection_compiles():
+    """Native multi-GPU path (RCCL all-gather of the records + gathered FindBestPlanner) builds against librccl."""
+    _build_sharded()
+
+
+@pytest.mark.gpu
+def test_cpp_sharded_selection_one_rank(tmp_path):
+    import numpy as np
+    from mpc_planner_amd import scenes
+    if not os.path.exists(BIN_SHARDED) or os.path.getmtime(BIN_SHARDED) < os.path.getmtime(os.path.join(ROOT, "mpc_planner_amd", "libtmpc_hip.so")):
+        _build_sharded()
+    sc = scenes.make_batch(range(3, 6), N=20, M=8, B=16)
+    B = sc["xinit"].shape[0]
+    f = str(tmp_path / "batch.bin")
+    np.concatenate([[B, 20, 3], sc["xinit"].ravel(), sc["x0"].ravel(), sc["params"].ravel()]).astype(float).tofile(f)
+    out = subprocess.run([BIN_SHARDED, f], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "sharded ok" in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
