@@ -66,6 +66,7 @@ namespace MPCPlanner
         double solver_timeout{0.};
         double *getU0() { return x0; }
         AcadosParameters();
+        void printParameters(const ParameterMap &parameter_map) const;      /* :76-88 (YAML::Node -> the flat map read from parameter_map.yaml) */
     };
 
     class Solver
@@ -79,12 +80,14 @@ namespace MPCPlanner
             int qp_status;
             double pobj{0.};
             AcadosInfo() : min_time(1e12), kkt_norm_inf(0.), elapsed_time(0.), sqp_iter(0), nlp_res(0.), solvetime(0.), qp_status(0) {}
+            void print() const;              /* :115-124 without the capsule argument (no acados statistics to print) */
         };
         struct AcadosOutput            /* :127-148 */
         {
             double xtraj[NX * (SOLVER_N + 1)];
             double utraj[NU * SOLVER_N];
             AcadosOutput();
+            void print() const;              /* :141-147 */
         };
 
     private:
@@ -94,6 +97,7 @@ namespace MPCPlanner
         int _device{0};
         bool _warmstart_pending{true};          // loadWarmstart() since the last iteration: the next one starts from _params.x0
         int _iterations_done{0};                // RTI iterations since initializeOneIteration
+        double _iteration_time_estimate{0.};
         void ensureHandle();
         int runIterations(int n, bool complete);
 
@@ -115,6 +119,13 @@ namespace MPCPlanner
         Solver(const Solver &) = delete;
         Solver &operator=(const Solver &rhs);   // copies _params only (acados_solver_interface.cpp:67-77)
         void reset();
+
+        /* The reference leaves its RTI loop when the planning time runs out (:111-116: elapsed + average iteration time >=
+         * _params.solver_timeout), which makes the iteration count wall-clock dependent.  Deterministic counterpart: with an
+         * iteration-time estimate set (seconds per RTI iteration, > 0) and _params.solver_timeout > 0, solve() runs
+         * min(_num_iterations, max(1, floor(solver_timeout / estimate))) iterations; 0 (default) keeps the fixed budget. */
+        void setIterationTimeEstimate(double seconds_per_iteration) { _iteration_time_estimate = seconds_per_iteration; }
+        int iterationBudget() const;
 
         int solve();                            // :86-119
         void initializeOneIteration();          // :121-143 xinit + parameters to the device

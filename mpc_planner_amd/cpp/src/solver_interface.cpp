@@ -2,6 +2,7 @@
 // Each method cites the reference method it mirrors (mpc_planner_solver/src/acados_solver_interface.cpp).
 #include <mpc_planner_solver/solver_interface.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -77,6 +78,27 @@ namespace MPCPlanner
         std::memset(xinit, 0, sizeof xinit); std::memset(x0, 0, sizeof x0); std::memset(all_parameters, 0, sizeof all_parameters);
     }
     Solver::AcadosOutput::AcadosOutput() { std::memset(xtraj, 0, sizeof xtraj); std::memset(utraj, 0, sizeof utraj); }
+    void AcadosParameters::printParameters(const ParameterMap &parameter_map) const
+    {
+        std::printf("--- Parameters ---\n");
+        for (int k = 0; k < SOLVER_N; k++) {
+            std::printf("[%d]\n", k);
+            for (auto &e : parameter_map)
+                if (e.first != "num parameters") std::printf("  %s: %g\n", e.first.c_str(), all_parameters[k * SOLVER_NP + e.second]);
+        }
+    }
+    void Solver::AcadosInfo::print() const
+    {
+        std::printf("--- Solver Info ---\nSQP iterations: %d\nMinimum time for solve [ms]: %g\nKKT: %g\nSolve Time [ms]: %g\nNLP Residuals: %g\n",
+                    sqp_iter, min_time * 1000., kkt_norm_inf, solvetime * 1000., nlp_res);
+    }
+    void Solver::AcadosOutput::print() const
+    {
+        std::printf("\n--- xtraj ---\n");
+        for (int k = 0; k <= SOLVER_N; k++) { for (int i = 0; i < NX; i++) std::printf("%14.6e", xtraj[k * NX + i]); std::printf("\n"); }
+        std::printf("\n--- utraj ---\n");
+        for (int k = 0; k < SOLVER_N; k++) { for (int i = 0; i < NU; i++) std::printf("%14.6e", utraj[k * NU + i]); std::printf("\n"); }
+    }
 
     // ---- construction (acados_solver_interface.cpp:9-65) ----
     Solver::Solver(int solver_id)
@@ -128,10 +150,18 @@ namespace MPCPlanner
     // ---- solve (:86-204).  The reference's wall-clock early exit (:111-116) is intentionally not reproduced (non-deterministic):
     // the RTI loop has the fixed budget _num_iterations and runs in ONE launch; it is bitwise the same as the one-iteration
     // protocol below (tests/test_gpu_iterations.py, tests/cpp/test_solver.cpp). ----
+    int Solver::iterationBudget() const
+    {
+        if (_iteration_time_estimate > 0. && _params.solver_timeout > 0.) {
+            const int n = (int)std::floor(_params.solver_timeout / _iteration_time_estimate);
+            return std::min(_num_iterations, std::max(1, n));
+        }
+        return _num_iterations;
+    }
     int Solver::solve()
     {
         initializeOneIteration();
-        runIterations(_num_iterations, true);
+        runIterations(iterationBudget(), true);
         _iterations_done = 0;                                   // (sqp_iter of the call is the whole loop's count)
         return completeOneIteration();
     }

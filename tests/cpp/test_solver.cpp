@@ -6,6 +6,7 @@
 #include <mpc_planner_solver/solver_interface.h>
 #include <mpc_planner_solver/mpc_planner_parameters.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -71,6 +72,13 @@ int main(int argc, char **argv)
     solver2 = solver;
     ASSERT_TRUE(solver2.getParameter(0, "reference_velocity") == 1.);
     ASSERT_TRUE(solver.explainExitFlag(1) == "Success");
+    // deterministic stand-in for the wall-clock exit of Solver::solve (:111-116)
+    ASSERT_TRUE(solver.iterationBudget() == solver._num_iterations);
+    solver.setIterationTimeEstimate(0.004); solver._params.solver_timeout = 0.02;
+    ASSERT_TRUE(solver.iterationBudget() == std::min(5, solver._num_iterations));
+    solver._params.solver_timeout = 0.001;
+    ASSERT_TRUE(solver.iterationBudget() == 1);
+    solver.setIterationTimeEstimate(0.);
     std::printf("plumbing ok\n");
     if (!do_solve) return 0;
 
