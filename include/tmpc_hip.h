@@ -129,7 +129,8 @@ int tmpc_set_latency_mode(tmpc_handle *h, int32_t on);
  * each), and the reference-layout inputs are transposed into it at the start of every tmpc_solve.  Same algorithm and stopping
  * rules as the default kernels: exit codes and iteration counts agree, trajectories agree to rounding (1e-10), and a
  * trajectory's result does not depend on the rest of the batch.  The default (0) stays the choice for control ticks of a few
- * planners; the mode is chosen by the caller, never by the batch size.  Returns 0, or <0 if the workspace cannot be allocated. */
+ * planners; the mode is chosen by the caller, never by the batch size.  Returns 0, or <0 if the workspace cannot be allocated or if
+ * this build of the lane kernel spills registers to scratch (possible in generated solvers: refused, tmpc_last_error says so). */
 int tmpc_set_throughput_mode(tmpc_handle *h, int32_t on);
 
 /* Replaces ocp_nlp_out_get / ocp_nlp_get / ocp_nlp_eval_cost of completeOneIteration (:162-204).

@@ -105,6 +105,17 @@ struct Context {
 
 Context *create(const Dims &d, int B_max, std::string &err)
 {
+    // Same rule as for the wave kernels (tmpc_solve.hip, pick_fast_kernel): a solve kernel that spills registers to scratch is not
+    // dispatched.  The hand-written library is built with zero scratch (__graft_entry__.build() refuses anything else); a generated
+    // solver's long emitted stage functions can push the lane kernel into scratch, and such a build was observed to return
+    // non-finite linearisations on the device (its host twin is fine): refuse instead of returning wrong iterates.
+    hipFuncAttributes attr;
+    if (hipFuncGetAttributes(&attr, (const void *)lanes_solve_kernel) != hipSuccess) { err = "lanes::create: hipFuncGetAttributes failed"; return nullptr; }
+    if (attr.localSizeBytes > 0) {
+        err = "throughput mode is not available in this library: its lane-per-trajectory kernel uses " + std::to_string(attr.localSizeBytes) +
+              " B/lane of scratch (register spills of the generated stage functions); use the default kernels";
+        return nullptr;
+    }
     Context *c = new Context();
     c->d = d; c->L = make_layout(d); c->B_max = B_max; c->nblocks = (B_max + LW - 1) / LW;
     c->bytes = (size_t)c->nblocks * block_doubles(c->L) * sizeof(double);

@@ -621,6 +621,20 @@ def test_generated_tmpc_solver_equals_hand_written_kernels():
     assert ok.sum() > 100 and np.array_equal(a["qp_iter_total"][ok], b["qp_iter_total"][ok])
     np.testing.assert_allclose(a["xtraj"][ok], b["xtraj"][ok], rtol=0, atol=1e-9)
     np.testing.assert_allclose(a["pobj"][ok], b["pobj"][ok], rtol=1e-10)
+    # the generated library carries the lane-per-trajectory kernels too; they are offered only if they compiled without scratch
+    # (the emitted stage functions are long: this build spills, and a spilling lane kernel is refused rather than trusted)
+    lanes_scratch = [v["scratch"] for k, v in meta["kernel_resources"].items() if "lanes_solve" in k]
+    if lanes_scratch and lanes_scratch[0] == 0:
+        sg.set_throughput_mode(True)
+        sg.set_batch(sc["xinit"], sc["x0"], sc["params"]); sg.solve(); c = sg.get()
+        sg.set_throughput_mode(False)
+        assert np.array_equal(c["exit_code"], b["exit_code"]) and np.array_equal(c["qp_iter_total"][ok], b["qp_iter_total"][ok])
+        np.testing.assert_allclose(c["xtraj"][ok], b["xtraj"][ok], rtol=0, atol=1e-8)
+    else:
+        with pytest.raises(solver.TmpcError):
+            sg.set_throughput_mode(True)
+        sg.set_batch(sc["xinit"], sc["x0"], sc["params"]); sg.solve()          # the default kernels are unaffected
+        np.testing.assert_array_equal(sg.get()["xtraj"], a["xtraj"])
     # stage functions on device against the golden vectors of the reference's scripts (row k = sign * (h_src - bound))
     with open(os.path.join(HERE, "golden", "stage_functions.json")) as fh:
         case = [c for c in json.load(fh)["cases"] if c["config"] == "cfg2_tmpc_M8"][1]
