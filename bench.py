@@ -41,10 +41,17 @@ WORKLOADS = {
 
 
 def library_sha256():
+    """Identity of the kernels a profile was taken on: sha256 over the library's sources (csrc/*.hip, *.hpp, include/tmpc_hip.h) --
+    stable across rebuilds of the same sources on different machines, unlike a hash of the binary."""
     import hashlib
-    path = os.path.join(ROOT, "mpc_planner_amd", "libtmpc_hip.so")
-    with open(path, "rb") as fh:
-        return hashlib.sha256(fh.read()).hexdigest()
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "mpc_planner_amd", "csrc")
+    for f in sorted(os.listdir(csrc)) + [os.path.join(ROOT, "include", "tmpc_hip.h")]:
+        path = f if os.path.isabs(f) else os.path.join(csrc, f)
+        if path.endswith((".hip", ".hpp", ".h")):
+            with open(path, "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()
 
 
 def flops_per_solve(n_sqp_mean, n_ipm_per_qp, N=N_H, nv=NV, nx=NX, nh=2 * M_OBS):
@@ -191,7 +198,6 @@ def main():
     sv = solver.BatchedSolver(dims, B_max=B, device=local_rank)
     sv.set_batch_device(B, t_xinit.data_ptr(), t_x0.data_ptr(), t_params.data_ptr())
     sv.enable_timing(a.steps + a.warmup + 4)
-    gather_stream = torch.cuda.Stream(device=dev) if use_dist else None
 
     def step():
         sv.solve(sync=False)                                                # the dominant kernel

@@ -39,9 +39,9 @@ def rows(d, suffix):
     return out
 
 
-import hashlib
-with open(os.path.join(ROOT, "mpc_planner_amd", "libtmpc_hip.so"), "rb") as fh:
-    LIB_HASH = hashlib.sha256(fh.read()).hexdigest()
+sys.path.insert(0, ROOT)
+import bench as _bench                                   # library_sha256(): hash of the kernel sources, what bench.py matches on
+LIB_HASH = _bench.library_sha256()
 subprocess.run(BENCH + ["--steps", "1", "--warmup", "0"], cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)   # fills the scene cache
 summary = {"command": "rocprofv3 --kernel-trace --stats -- " + " ".join(BENCH[1:]) + "   (cfg2, bench.py's default launch: 512 scenes x 64 = 32768 trajectories); "
            "PMC in separate --pmc passes; kernel trace and every counter pass ran on the same build of the library", "tag": tag,
