@@ -111,7 +111,8 @@ int tmpc_synchronize(tmpc_handle *h);
  * and stores iterate + multipliers of every slot afterwards.  A slot whose QP stopped with qp_status != 0 has left the reference's iteration loop (:105-106): further
  * KEEP_ITERATE calls leave it untouched until a call without KEEP_ITERATE loads a new warm start.  n_iter calls with one
  * iteration each give bitwise the same result as one call with n_iter.  The first call on a handle has nothing to keep and
- * behaves like flags = 0.  tmpc_solve() itself never reads or writes this state. */
+ * behaves like flags = 0, and so does the first call after tmpc_set_throughput_mode changed the kernel family (the wave kernels keep
+ * the state in per-slot arrays, the lane kernels in their workspace).  tmpc_solve() itself never reads or writes this state. */
 #define TMPC_ITER_KEEP_ITERATE 1
 #define TMPC_ITER_KEEP_MULTIPLIERS 2
 #define TMPC_ITER_COMPLETE 4

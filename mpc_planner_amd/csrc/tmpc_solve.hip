@@ -1009,6 +1009,7 @@ int tmpc_set_throughput_mode(tmpc_handle *h, int32_t on)
         h->lanes = tmpc::lanes::create(h->d, h->B_max, h->err);
         if (!h->lanes) return TMPC_ERR_HIP;
     }
+    if (h->throughput_mode != (on != 0)) h->st_valid = false;      // the two kernel families keep their persistent state separately
     h->throughput_mode = on != 0;
     return TMPC_OK;
 }
