@@ -199,13 +199,17 @@ def main():
     sv.set_batch_device(B, t_xinit.data_ptr(), t_x0.data_ptr(), t_params.data_ptr())
     sv.enable_timing(a.steps + a.warmup + 4)
 
+    # The whole step is stream-ordered on the handle's stream: solve -> pack -> (N > 1: the all-gather, issued with that stream as
+    # torch's current stream, so RCCL waits for the records and the selection waits for RCCL) -> FindBestPlanner.  No host
+    # synchronisation inside a step.
+    ext_stream = torch.cuda.ExternalStream(sv.stream_ptr(), device=dev) if use_dist else None
+
     def step():
         sv.solve(sync=False)                                                # the dominant kernel
         sv.pack_records(t_rec.data_ptr(), t_gid.data_ptr())
         if use_dist:
-            sv.synchronize()                                                # the records are complete: hand them to the collective
-            gathered = D.all_gather_records(t_rec, world)                   # ONE RCCL all-gather, 16 B x B per rank
-            torch.cuda.current_stream().synchronize()                       # the gathered records are complete: hand them back
+            with torch.cuda.stream(ext_stream):
+                gathered = D.all_gather_records(t_rec, world)               # ONE RCCL all-gather, 16 B x B per rank
             sv.select_best_records(gathered.data_ptr(), world, n_sets, traj_local, t_best.data_ptr())
             step.keep = gathered
         else:

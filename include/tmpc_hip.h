@@ -150,6 +150,10 @@ int tmpc_select_best(tmpc_handle *h, int32_t first, int32_t count, const double 
 /* Device-resident result records for the multi-GPU all-gather: pointers to the handle's
  * pobj[B] (f64) and exit_code[B] (i32) device arrays. */
 int tmpc_result_device_ptrs(tmpc_handle *h, void **d_pobj, void **d_exit_code);
+/* The HIP stream (hipStream_t) every launch of this handle is enqueued on, for callers that order their own work against it
+ * without host synchronisation -- e.g. the multi-GPU step runs the record all-gather stream-ordered between tmpc_pack_records and
+ * tmpc_select_best_records by making that stream the collective's current stream. */
+int tmpc_get_stream(tmpc_handle *h, void **stream);
 
 /* ---- multi-GPU sharding: a scene's trajectories are split over ranks; after the solve every rank
  * packs one 16-byte record per local trajectory, the host all-gathers the record arrays (RCCL over xGMI via

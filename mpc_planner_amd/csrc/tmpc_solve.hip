@@ -1054,6 +1054,13 @@ int tmpc_select_best(tmpc_handle *h, int32_t first, int32_t count, const double 
     return TMPC_OK;
 }
 
+int tmpc_get_stream(tmpc_handle *h, void **stream)
+{
+    if (!h || !stream) return TMPC_ERR_INVALID;
+    *stream = (void *)h->stream;
+    return TMPC_OK;
+}
+
 int tmpc_result_device_ptrs(tmpc_handle *h, void **d_pobj, void **d_exit_code)
 {
     if (!h) return TMPC_ERR_INVALID;

@@ -41,7 +41,7 @@ EXPORTS = ["tmpc_default_dims", "tmpc_default_dims_ex", "tmpc_create", "tmpc_des
            "tmpc_select_best_records", "tmpc_enable_timing", "tmpc_get_timings", "tmpc_debug_profile",
            "tmpc_linearize_topology", "tmpc_scenario_halfspaces", "tmpc_warmstart", "tmpc_init_with_guidance",
            "tmpc_debug_get_x0", "tmpc_debug_get_params", "tmpc_set_throughput_mode", "tmpc_solve_iterations",
-           "tmpc_reset_multipliers"]
+           "tmpc_reset_multipliers", "tmpc_get_stream"]
 
 class TmpcError(RuntimeError):
     pass
@@ -81,6 +81,7 @@ def load_library(path=None):
     lib.tmpc_set_throughput_mode.argtypes = [vp, C.c_int32]
     lib.tmpc_solve_iterations.argtypes = [vp, C.c_int32, C.c_int32]
     lib.tmpc_reset_multipliers.argtypes = [vp]
+    lib.tmpc_get_stream.argtypes = [vp, C.POINTER(vp)]
     lib.tmpc_synchronize.argtypes = [vp]
     lib.tmpc_get.argtypes = [vp] + [vp] * 8
     lib.tmpc_select_best.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, C.POINTER(C.c_int32)]
@@ -187,6 +188,12 @@ class BatchedSolver:
         self._check(self.lib.tmpc_solve_iterations(self._h, int(n_iter), flags), "tmpc_solve_iterations")
         if sync:
             self.synchronize()
+
+    def stream_ptr(self):
+        """hipStream_t of the handle (as an integer), e.g. for torch.cuda.ExternalStream."""
+        st = C.c_void_p()
+        self._check(self.lib.tmpc_get_stream(self._h, C.byref(st)), "tmpc_get_stream")
+        return st.value or 0
 
     def reset_multipliers(self):
         self._check(self.lib.tmpc_reset_multipliers(self._h), "tmpc_reset_multipliers")
