@@ -232,6 +232,24 @@ def test_select_best_index_convention_with_offset():
     s.close()
 
 
+@pytest.mark.parametrize("shape", ["N2", "N32", "ellipsoids_only", "many_rows", "three_segments"])
+def test_throughput_mode_edge_shapes(shape):
+    """Lane kernels on edge shapes (minimal / long horizon, one row class, 36 rows per stage with the slack model, 3 segments):
+    one program, no per-shape instantiation; against the oracle."""
+    import oracle_lib as O
+    import test_lanes_twin as TW
+    from mpc_planner_amd import scenes
+    skw, pkw = TW.CASES[shape]
+    sc = scenes.make_scene(44, **skw)
+    B = sc["xinit"].shape[0]
+    s = _solver(B_max=B, **pkw)
+    s.set_throughput_mode(True)
+    s.set_batch(sc["xinit"], sc["x0"], sc["params"]); s.solve(); got = s.get()
+    xt, ut, info = O.solve_batch(O.problem(**pkw), sc["xinit"], sc["x0"].reshape(B, -1), sc["params"].reshape(B, -1))
+    _compare(got, xt, ut, info)
+    s.close()
+
+
 # ---- BASELINE.json sizes: every configuration at the batch size its config line names, HIP path vs oracle ----------------
 BASELINE_CASES = {
     # cfg 2: 64 guidance trajectories per tick; four ticks of the bench workload (scenes 0..3 of bench.py's launch)

@@ -45,6 +45,12 @@ CASES = {
     "cfg4": (dict(N=20, M=12, B=32, tmpc_pp=True), dict(N=20, S=5, n_lin=12, M=12)),
     "cfg5": (dict(N=20, M=8, B=32, slack=True, n_scenario=24), dict(N=20, S=5, n_lin=0, M=0, n_slk=24, slack=1)),
     "short_horizon": (dict(N=5, M=4, B=8), dict(N=5, S=5, n_lin=4, M=4)),
+    # edge shapes: minimal horizon, the oracle's maximal horizon, one row class only, many rows, other segment count
+    "N2": (dict(N=2, M=4, B=8), dict(N=2, S=5, n_lin=4, M=4)),
+    "N32": (dict(N=32, M=6, B=8), dict(N=32, S=5, n_lin=6, M=6)),
+    "ellipsoids_only": (dict(N=20, M=12, B=6, guidance=False), dict(N=20, S=5, n_lin=0, M=12)),
+    "many_rows": (dict(N=20, M=12, S=8, B=8, slack=True, n_decomp=12), dict(N=20, S=8, n_lin=12, M=12, n_slk=12, slack=1)),
+    "three_segments": (dict(N=30, M=5, S=3, B=8), dict(N=30, S=3, n_lin=5, M=5)),
 }
 
 
