@@ -201,17 +201,29 @@ int tmpc_time_solve(tmpc_handle *h, int32_t reps, float *ms_each);
 int tmpc_linearize_topology(tmpc_handle *h, const void *d_obstacle_pos, const void *d_scene_of, const void *d_state_x,
                             double robot_radius, const void *d_is_original);
 
-/* ---- scenario -> halfspace reduction of SH-MPC on device.  Replaces what the reference gets from the
+/* ---- scenario -> polygon construction of SH-MPC on device.  Replaces what the reference gets from the
  * external scenario_module (scenario_constraints.cpp:47 update, :76-79 setParameters; source absent -> restated, see
- * mpc_planner_amd/modules.py::scenario_halfspaces): for every trajectory b and stage k >= 1, the n_pts sampled obstacle
- * positions of prediction step k-1 are reduced to n_rows halfspaces a.x <= b around the guess x0[b][k] (closest sample
- * per angular sector of a; empty sectors / stage 0 = dummy rows), written into the first n_rows decomp/scenario rows of
- * the batch's parameter tensor together with ego_disc_0_offset.  Device pointers:
+ * mpc_planner_amd/modules.py::scenario_halfspaces): for every trajectory b and stage k >= 1, each of the n_pts sampled
+ * obstacle positions of prediction step k-1 gives a halfspace a.x <= b linearised around the guess x0[b][k]; the
+ * halfspaces that form the boundary of their intersection polygon (all others are redundant) are written, closest first
+ * and at most n_rows of them (<= 64), into the first n_rows decomp/scenario rows of the batch's parameter tensor together
+ * with ego_disc_0_offset; unused rows and stage 0 = dummy rows.  n_pts <= 5485 (a stage's halfspaces live in LDS).
+ * Device pointers:
  *   d_samples  : f64 [n_scenes][N][n_pts][2]   sampled positions, n_pts = obstacles x scenarios (index i = step k-1)
  *   d_scene_of : i32 [B];  d_state_x : f64 [n_scenes]  (dummy b = x + 100)
  * Operates in place on the parameter tensor of the last tmpc_set_batch / tmpc_set_batch_device call. */
 int tmpc_scenario_halfspaces(tmpc_handle *h, const void *d_samples, int32_t n_pts, int32_t n_rows, const void *d_scene_of,
                              const void *d_state_x, double radius, double disc_offset);
+
+/* Support of each trajectory's solution after a solve on rows written by tmpc_scenario_halfspaces: the number of distinct
+ * scenarios with an active constraint, a.p_disc - (b + slack) >= -tol at the solution (ScenarioSolver::support,
+ * scenario_constraints.h:38-40; filled by the absent scenario_module, restated from the method's definition: the plan's
+ * collision-probability certificate holds while the support stays within the bound the sample size was chosen for -- see
+ * mpc_planner_amd/modules.py::scenario_risk / scenario_sample_size).  Scenario of sample i = i % n_scenarios (samples are
+ * [obstacle][scenario]); n_scenarios <= 8192.
+ *   d_support     : i32 [B] out    distinct active scenarios
+ *   d_active_rows : i32 [B] out or NULL    active rows */
+int tmpc_scenario_support(tmpc_handle *h, int32_t n_scenarios, double tol, void *d_support, void *d_active_rows);
 
 /* ---- cross-tick state on device, so a closed loop runs without host round trips --------------------
  * tmpc_warmstart builds the next tick's warm start x0 and xinit of every trajectory of the current batch from the

@@ -19,6 +19,7 @@
 #ifndef MPC_PLANNER_MODULES_HIP_H
 #define MPC_PLANNER_MODULES_HIP_H
 
+#include <algorithm>
 #include <cmath>
 #include <map>
 #include <memory>
@@ -412,8 +413,27 @@ namespace MPCPlanner
             std::shared_ptr<Solver> solver;
             int exit_code{-1};
             std::vector<StaticObstacle> halfspaces;                                            /* [k] -> rows a.x <= b (+ slack) for this solver's scenario set */
+            std::vector<std::vector<int>> scenario_of_row;                                     /* [k][row] -> scenario the row's sample belongs to (optional) */
+            /* scenario_constraints.h:38-40: the scenarios of support of this solver's solution (those with an active row) */
+            struct SupportSubsample { std::vector<int> scenarios; int active_rows{0}; int size() const { return (int)scenarios.size(); } } support;
             ScenarioSolver(int id) : solver(std::make_shared<Solver>(id)) {}
         };
+        /* support of a solver's solution: rows with a.p_disc - (b + slack) >= -tol, distinct scenarios (host counterpart of tmpc_scenario_support) */
+        void computeSupport(ScenarioSolver &s, double tol = 1e-6) const
+        {
+            s.support = {};
+            for (int k = 1; k < _solver->N && k < (int)s.halfspaces.size() && k < (int)s.scenario_of_row.size(); k++) {
+                const double psi = s.solver->getOutput(k, "psi"), slack = s.solver->getOutput(k, "slack");
+                const double px = s.solver->getOutput(k, "x") + _disc_offset * std::cos(psi), py = s.solver->getOutput(k, "y") + _disc_offset * std::sin(psi);
+                for (size_t j = 0; j < s.halfspaces[k].size() && j < s.scenario_of_row[k].size(); j++) {
+                    const int scenario = s.scenario_of_row[k][j];
+                    const auto &row = s.halfspaces[k][j];
+                    if (scenario < 0 || row.A(0) * px + row.A(1) * py - (row.b + slack) < -tol) continue;
+                    s.support.active_rows++;
+                    if (std::find(s.support.scenarios.begin(), s.support.scenarios.end(), scenario) == s.support.scenarios.end()) s.support.scenarios.push_back(scenario);
+                }
+            }
+        }
         ScenarioConstraints(std::shared_ptr<Solver> solver, int parallel_solvers, double disc_offset = 0.) : _solver(solver), _disc_offset(disc_offset)
         {
             for (int i = 0; i < parallel_solvers; i++) _scenario_solvers.emplace_back(new ScenarioSolver(i));   /* :18-26 */
@@ -442,7 +462,7 @@ namespace MPCPlanner
                 batch.push_back(solver->solver.get());
             }
             const std::vector<int> codes = Solver::solveBatch(batch);                          /* scenario_module.optimize(data) of every solver: one launch */
-            for (size_t i = 0; i < codes.size(); i++) _scenario_solvers[i]->exit_code = codes[i];
+            for (size_t i = 0; i < codes.size(); i++) { _scenario_solvers[i]->exit_code = codes[i]; computeSupport(*_scenario_solvers[i], _support_tolerance); }
             double lowest_cost = 1e9;                                                           /* :93-107 */
             _best_solver = nullptr;
             for (auto &solver : _scenario_solvers)
@@ -456,6 +476,7 @@ namespace MPCPlanner
         std::vector<std::unique_ptr<ScenarioSolver>> _scenario_solvers;
         ScenarioSolver *_best_solver{nullptr};
         std::shared_ptr<Solver> _solver;
+        double _support_tolerance{1e-6};
     private:
         double _disc_offset;
     };

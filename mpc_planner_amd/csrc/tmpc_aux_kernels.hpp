@@ -124,87 +124,320 @@ __global__ void tmpc_linearize_topology_kernel(Dims d, int B, const double *x0, 
 }
 
 
-// ---- f-3: scenario -> halfspace reduction on device (SH-MPC, BASELINE config 5) -----------------------------------
+// ---- f-3: scenario -> polygon on device (SH-MPC, BASELINE config 5) ------------------------------------------------
 // The reference delegates this to the external scenario_module (scenario_constraints.cpp:47,76-79; source absent), so
 // this restates the host mirror mpc_planner_amd/modules.py::scenario_halfspaces: for stage k >= 1 of trajectory b every
 // sampled obstacle position o (n_pts = obstacles x scenarios of the trajectory's scene, prediction step k-1) gives the
-// halfspace a = (o - p)/|o - p|, b = a.o - radius around the guess p = x0[b][k](x, y); the n_rows angular sectors of a
-// each keep their closest sample (lowest sample index on ties); empty sectors and stage 0 get the dummy row
-// (1, 0, x + 100) (decomp_constraints.cpp:153-169 pattern).  One workgroup per (trajectory, stage); the samples of a
-// stage are contiguous ([scene][N][n_pts][2]) so the scan is a coalesced HBM/L2 stream shared by the scene's
-// trajectories.  Arithmetic is written without FMA contraction so the rows equal the host mirror's bit for bit.
+// halfspace a = (o - p)/|o - p|, b = a.o - radius around the guess p = x0[b][k](x, y); the constraints of the stage are
+// the halfspaces that form the boundary of the intersection polygon (all others are redundant), closest first, at most
+// n_rows of them; unused rows and stage 0 get the dummy row (1, 0, x + 100) (decomp_constraints.cpp:153-169 pattern).
+// One workgroup per (trajectory, stage), in two parts:
+//   FILTER (free to be anything conservative: a halfspace whose boundary line misses the polygon of SOME of the
+//      halfspaces -- the "seeds" -- cannot touch the smaller polygon of all of them, and dropping such halfspaces
+//      changes neither the polygon nor which halfspaces are its edges).  Round 1, on registers: the closest halfspace
+//      of each of 256 direction sectors is a seed (LDS table, atomicMin on an order-preserving key of the margin, then on
+//      the index); a halfspace is clipped by the seed of its own sector and the two nearest seeds on either side only --
+//      those decide, 5 clips instead of one per seed; the survivors (~100 of 2048 on the SH-MPC scenes) are appended to
+//      a compact LDS list.  Round 2, on the list: 2048 sectors, seeds by pairwise comparison, every seed clips -> ~11.
+//      The filter's clips keep the interval as two fractions compared by cross-multiplication: no division.
+//   EDGE TEST (the definition, same per-pair arithmetic as the mirror): candidate i is an edge iff the piece of its line
+//      inside all other candidates' halfspaces has positive length; its row index is its rank by (margin, sample index).
+// The samples of a stage are contiguous ([scene][N][n_pts][2]): a coalesced stream shared through L2 by the scene's
+// trajectories.  The edge test is written without FMA contraction, so the rows equal the mirror's bit for bit.
+#ifndef POLY_STOP
+#define POLY_STOP 99
+#endif
+constexpr double POLY_EPS_PARALLEL = 1e-12, POLY_TOL_EDGE = 1e-9, POLY_SEED_MARGIN = 1e-6;
+constexpr int POLY_IDX_MASK = 0x1fff, POLY_DROP_FLAG = 1 << 29;     // a candidate's index word, see the kernel
+constexpr int POLY_SEC1 = 256;                        // direction sectors of round 1 (32 per octant, in angular order)
+constexpr int POLY_NONE = 0x7fffffff;
+constexpr int POLY_SEED_CAP = 2 * POLY_SEC1;        // seeds of round 2 that fit the (then free) round-1 table
+
+__device__ __forceinline__ int poly_sector(double ax, double ay, int bins)        // octant x bins of min(|ax|,|ay|)/max: a partition of the directions
+{
+    const double u = fabs(ax), v = fabs(ay);
+    const int oct = (ax < 0.0 ? 1 : 0) | (ay < 0.0 ? 2 : 0) | (v > u ? 4 : 0);
+    const double t = (v > u ? u : v) / (v > u ? v : u);
+    int sub = (int)(t * (double)bins);
+    sub = sub > bins - 1 ? bins - 1 : sub;
+    return oct * bins + sub;
+}
+
+__device__ __forceinline__ int poly_sector_angular(double ax, double ay)          // the same partition with 32 bins, numbered counter-clockwise
+{
+    const double u = fabs(ax), v = fabs(ay);
+    const bool steep = v > u;
+    const double t = (steep ? u : v) / (steep ? v : u);
+    int bin = (int)(t * 32.0);
+    bin = bin > 31 ? 31 : bin;
+    const int quad = ax >= 0.0 ? (ay >= 0.0 ? 0 : 3) : (ay >= 0.0 ? 1 : 2);
+    const bool second = ((quad & 1) == 0) == steep;           // second half (45..90 deg) of the quadrant
+    const bool rising = ((quad & 1) == 0) != steep;           // t grows with the angle in this half
+    return quad * 64 + (second ? 32 : 0) + (rising ? bin : 31 - bin);
+}
+
+__device__ __forceinline__ unsigned long long poly_key(double x)          // order-preserving map of a double to an unsigned integer
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+
+// halfspace j = (aj1, aj2, dmj) clips the boundary line of halfspace i, q_i + t perp_i, to  c t <= rhs
+struct PolyClip { double lo, hi; bool kill; };
+__device__ __forceinline__ void poly_clip(PolyClip &w, double ai1, double ai2, double dmi, int i, double aj1, double aj2, double dmj, int j)
+{
+#pragma clang fp contract(off)
+    const double c = aj1 * (-ai2) + aj2 * ai1;
+    const double dot = aj1 * ai1 + aj2 * ai2;
+    const double rhs = dmj - dmi * dot;
+    // hi = min(hi, rhs / c), lo = max(lo, rhs / c); the division only when the bound may move: a quotient that is clearly (1e-9
+    // relative) on the far side of the current bound leaves it as it is, so the result equals the plain min / max
+    if (c > POLY_EPS_PARALLEL) {
+        const double t = w.hi * c;
+        if (!(rhs > t + 1e-9 * fabs(t))) { const double r = rhs / c; w.hi = r < w.hi ? r : w.hi; }
+    } else if (c < -POLY_EPS_PARALLEL) {
+        const double t = w.lo * c;                                // c < 0:  rhs / c > lo  <=>  rhs < lo c
+        if (!(rhs > t + 1e-9 * fabs(t))) { const double r = rhs / c; w.lo = r > w.lo ? r : w.lo; }
+    } else if (dot > 0.0 ? (dmj < dmi || (dmj == dmi && j < i)) : rhs < 0.0) w.kill = true;   // parallel: same direction -> the closer one (lowest index) wins
+}
+
+// The filter's clip: the same interval kept as two fractions, hi = nh / dh and lo = nl / dl (dh, dl >= 0; 1/0 and -1/0 are the
+// infinities), compared by cross-multiplication -- no division.  Nearly parallel seeds (|c| < 1e-6) are skipped, which keeps every
+// quotient below ~1e8 m and the rounding of the products (1e-16 relative) far inside the filter's margin; skipping only loosens it.
+struct PolyFrac { double nh, dh, nl, dl; };
+__device__ __forceinline__ void poly_clip_fast(PolyFrac &w, double ai1, double ai2, double dmi, double aj1, double aj2, double dmj)
+{
+    const double c = aj1 * (-ai2) + aj2 * ai1;
+    const double rhs = dmj - dmi * (aj1 * ai1 + aj2 * ai2);
+    if (c > 1e-6) { if (rhs * w.dh < w.nh * c) { w.nh = rhs; w.dh = c; } }
+    else if (c < -1e-6) { if (-rhs * w.dl > w.nl * -c) { w.nl = -rhs; w.dl = -c; } }
+}
+__device__ __forceinline__ bool poly_frac_alive(const PolyFrac &w) { return w.nh * w.dl - w.nl * w.dh >= -POLY_SEED_MARGIN * (w.dh * w.dl); }   // (>=: both sides are 0 while a bound is infinite)
+
 __global__ __launch_bounds__(256) void tmpc_scenario_halfspaces_kernel(Dims d, int B, const double *x0, double *params,
                                                                        const double *samples, int n_pts, int n_rows,
                                                                        const int *scene_of, const double *state_x,
-                                                                       double radius, double disc_offset)
+                                                                       double radius, double disc_offset, int *row_sample)
 {
 #pragma clang fp contract(off)
-    __shared__ unsigned long long s_best[64];
-    __shared__ int s_idx[64];
+    extern __shared__ double s_dyn[];                                    // the candidates, compact: normal, margin, index word
+    __shared__ unsigned long long s_best[POLY_SEC1];
+    __shared__ double sd_ax[POLY_SEC1], sd_ay[POLY_SEC1], sd_dm[POLY_SEC1];
+    __shared__ int s_seed[POLY_SEC1];
+    __shared__ short s_next[POLY_SEC1], s_prev[POLY_SEC1];              // nearest sector with a seed, counter-clockwise / clockwise (-1: none)
+    __shared__ int s_nk, s_nw, s_ne;
+    int *s_list = reinterpret_cast<int *>(s_best);                        // round 2's seeds (list positions); the table is free by then
+    double *c_ax = s_dyn, *c_ay = s_dyn + n_pts, *c_dm = s_dyn + 2 * (size_t)n_pts;
+    int *c_idx = reinterpret_cast<int *>(s_dyn + 3 * (size_t)n_pts);
     const int N = d.N;
     const int b = blockIdx.x / N, k = blockIdx.x - b * N;
     if (b >= B) return;
     const int sc = scene_of[b];
     double *p = params + ((size_t)b * N + k) * d.npar;
     const int tid = threadIdx.x;
+    int *which = row_sample + (size_t)blockIdx.x * n_rows;            // the sample behind each row (-1: dummy), for tmpc_scenario_support
     if (tid == 0) p[ip_disc_offset(d)] = disc_offset;
     if (k == 0) {
-        if (tid < n_rows) { p[ip_slk(d, tid, 0)] = 1.0; p[ip_slk(d, tid, 1)] = 0.0; p[ip_slk(d, tid, 2)] = state_x[sc] + 100.0; }
+        if (tid < n_rows) { p[ip_slk(d, tid, 0)] = 1.0; p[ip_slk(d, tid, 1)] = 0.0; p[ip_slk(d, tid, 2)] = state_x[sc] + 100.0; which[tid] = -1; }
         return;
     }
-    if (tid < n_rows) { s_best[tid] = ~0ull; s_idx[tid] = 0x7fffffff; }
+    s_best[tid] = ~0ull; s_seed[tid] = POLY_NONE;
+    if (tid == 0) { s_nk = 0; s_ne = 0; }
     __syncthreads();
     const double px = x0[((size_t)b * (N + 1) + k) * ext_nv(d) + ZX], py = x0[((size_t)b * (N + 1) + k) * ext_nv(d) + ZY];
     const double2 *o = reinterpret_cast<const double2 *>(samples) + ((size_t)sc * N + (k - 1)) * n_pts;
-    const double scale = (double)n_rows / (2.0 * M_PI);
-    auto classify = [&](int i, double &dist, double &ax, double &ay) {
+    auto halfspace = [&](int i, double &ax, double &ay, double &dm) {
         const double2 q = o[i];
         const double dx = q.x - px, dy = q.y - py;
-        dist = sqrt(dx * dx + dy * dy);
-        ax = dx / dist; ay = dy / dist;
-        int sec = (int)((atan2(ay, ax) + M_PI) * scale);
-        return sec < n_rows - 1 ? sec : n_rows - 1;
+        const double dist = sqrt(dx * dx + dy * dy);
+        ax = dx / dist; ay = dy / dist; dm = dist - radius;
     };
-    // pass 1: per-sector minimum distance; the first CACHE classifications of a thread stay in registers for pass 2
+    // ---- round 1 on registers: the first CACHE halfspaces of a thread are kept, the rest (n_pts > 2048) recomputed per pass
     constexpr int CACHE = 8;
-    double c_dist[CACHE]; int c_sec[CACHE];
-#pragma unroll
-    for (int c = 0; c < CACHE; c++) {
-        const int i = tid + c * 256;
-        c_sec[c] = -1; c_dist[c] = 0.0;
-        if (i < n_pts) {
-            double ax, ay;
-            c_sec[c] = classify(i, c_dist[c], ax, ay);
-            atomicMin(&s_best[c_sec[c]], (unsigned long long)__double_as_longlong(c_dist[c]));   // dist > 0: bit pattern is monotone
-        }
-    }
-    for (int i = tid + CACHE * 256; i < n_pts; i += 256) {
-        double dist, ax, ay;
-        const int sec = classify(i, dist, ax, ay);
-        atomicMin(&s_best[sec], (unsigned long long)__double_as_longlong(dist));
-    }
-    __syncthreads();
-    // pass 2: lowest sample index among the samples at the minimum
+    double r_ax[CACHE], r_ay[CACHE], r_dm[CACHE]; int r_sec[CACHE];
 #pragma unroll
     for (int c = 0; c < CACHE; c++)
-        if (c_sec[c] >= 0 && (unsigned long long)__double_as_longlong(c_dist[c]) == s_best[c_sec[c]]) atomicMin(&s_idx[c_sec[c]], tid + c * 256);
-    for (int i = tid + CACHE * 256; i < n_pts; i += 256) {
-        double dist, ax, ay;
-        const int sec = classify(i, dist, ax, ay);
-        if ((unsigned long long)__double_as_longlong(dist) == s_best[sec]) atomicMin(&s_idx[sec], i);
+        if (tid + c * 256 < n_pts) { halfspace(tid + c * 256, r_ax[c], r_ay[c], r_dm[c]); r_sec[c] = poly_sector_angular(r_ax[c], r_ay[c]); }
+    auto every_sample = [&](auto &&f) {
+#pragma unroll
+        for (int c = 0; c < CACHE; c++) if (tid + c * 256 < n_pts) f(tid + c * 256, r_ax[c], r_ay[c], r_dm[c], r_sec[c]);
+        for (int i = tid + CACHE * 256; i < n_pts; i += 256) { double ax, ay, dm; halfspace(i, ax, ay, dm); f(i, ax, ay, dm, poly_sector_angular(ax, ay)); }
+    };
+    every_sample([&](int, double, double, double dm, int sec) { atomicMin(&s_best[sec], poly_key(dm)); });
+    __syncthreads();
+    every_sample([&](int i, double, double, double dm, int sec) { if (poly_key(dm) == s_best[sec]) atomicMin(&s_seed[sec], i); });
+    __syncthreads();
+    every_sample([&](int i, double ax, double ay, double dm, int sec) { if (s_seed[sec] == i) { sd_ax[sec] = ax; sd_ay[sec] = ay; sd_dm[sec] = dm; } });
+    {                                                             // nearest sectors with a seed on either side of sector tid
+        int nx = -1, pv = -1;
+        for (int q = 1; q < POLY_SEC1 && nx < 0; q++) if (s_seed[(tid + q) & (POLY_SEC1 - 1)] != POLY_NONE) nx = (tid + q) & (POLY_SEC1 - 1);
+        for (int q = 1; q < POLY_SEC1 && pv < 0; q++) if (s_seed[(tid - q) & (POLY_SEC1 - 1)] != POLY_NONE) pv = (tid - q) & (POLY_SEC1 - 1);
+        s_next[tid] = (short)nx; s_prev[tid] = (short)pv;
     }
     __syncthreads();
-    if (tid < n_rows) {
-        double a1 = 1.0, a2 = 0.0, bb = state_x[sc] + 100.0;
-        const int i = s_idx[tid];
-        if (i != 0x7fffffff) {
-            double dist;
-            classify(i, dist, a1, a2);
-            const double2 q = o[i];
-            bb = a1 * q.x + a2 * q.y - radius;
+    if (POLY_STOP <= 2) { if (s_seed[tid] == 12345) p[0] = 1.0; return; }
+    // a halfspace is clipped by the seed of its own sector and the two nearest seeds on either side; the interval only shrinks,
+    // so once it is empty the halfspace is out, whatever other seeds would do.  The thread's eight halfspaces advance in lockstep
+    // (slot by slot), so that their LDS gathers overlap.
+    {
+        int slot[CACHE][5];
+        PolyFrac w[CACHE];
+#pragma unroll
+        for (int c = 0; c < CACHE; c++) {
+            w[c] = {1.0, 0.0, -1.0, 0.0};
+            const int sec = tid + c * 256 < n_pts ? r_sec[c] : 0;
+            const int n1 = s_next[sec], p1 = s_prev[sec];
+            slot[c][0] = sec; slot[c][1] = n1; slot[c][2] = p1;
+            slot[c][3] = n1 >= 0 ? s_next[n1] : -1; slot[c][4] = p1 >= 0 ? s_prev[p1] : -1;
         }
-        p[ip_slk(d, tid, 0)] = a1; p[ip_slk(d, tid, 1)] = a2; p[ip_slk(d, tid, 2)] = bb;
+#pragma unroll
+        for (int q = 0; q < 5; q++) {
+#pragma unroll
+            for (int c = 0; c < CACHE; c++) {
+                const int i = tid + c * 256, s = slot[c][q];
+                if (i >= n_pts || s < 0 || !poly_frac_alive(w[c])) continue;
+                if (s_seed[s] != i) poly_clip_fast(w[c], r_ax[c], r_ay[c], r_dm[c], sd_ax[s], sd_ay[s], sd_dm[s]);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CACHE; c++) {
+            const int i = tid + c * 256;
+            if (i < n_pts && poly_frac_alive(w[c])) { const int e = atomicAdd(&s_nk, 1); c_ax[e] = r_ax[c]; c_ay[e] = r_ay[c]; c_dm[e] = r_dm[c]; c_idx[e] = i; }
+        }
+        for (int i = tid + CACHE * 256; i < n_pts; i += 256) {       // n_pts > 2048
+            double ax, ay, dm; halfspace(i, ax, ay, dm);
+            const int sec = poly_sector_angular(ax, ay), n1 = s_next[sec], p1 = s_prev[sec];
+            const int at[5] = {sec, n1, p1, n1 >= 0 ? s_next[n1] : -1, p1 >= 0 ? s_prev[p1] : -1};
+            PolyFrac v = {1.0, 0.0, -1.0, 0.0};
+            for (int q = 0; q < 5 && poly_frac_alive(v); q++)
+                if (at[q] >= 0 && s_seed[at[q]] != i) poly_clip_fast(v, ax, ay, dm, sd_ax[at[q]], sd_ay[at[q]], sd_dm[at[q]]);
+            if (poly_frac_alive(v)) { const int e = atomicAdd(&s_nk, 1); c_ax[e] = ax; c_ay[e] = ay; c_dm[e] = dm; c_idx[e] = i; }
+        }
     }
+    __syncthreads();
+    if (POLY_STOP <= 3) { if (tid == 0) which[0] = s_nk; return; }
+    // ---- round 2 on the compact list.  An entry's index word: bits 0-12 the sample index, 13-23 its sector of this round,
+    //      29 dropped by this round's filter; an entry is only ever rewritten by the thread that owns it.
+    {
+        const int nk = s_nk;
+        for (int ci = tid; ci < nk; ci += 256) c_idx[ci] = (c_idx[ci] & POLY_IDX_MASK) | (poly_sector(c_ax[ci], c_ay[ci], 256) << 13);
+        if (tid == 0) s_nw = 0;
+        __syncthreads();
+        for (int ci = tid; ci < nk; ci += 256) {                  // seed = the closest of its sector (lowest sample index on ties)
+            const double dmi = c_dm[ci];
+            const int me = c_idx[ci], i = me & POLY_IDX_MASK, sec = (me >> 13) & 0x7ff;
+            bool seed = true;
+#pragma unroll 8
+            for (int cj = 0; cj < nk; cj++) {                     // (no early exit: the reads pipeline)
+                const int other = c_idx[cj];
+                const double dmj = c_dm[cj];
+                if (((other >> 13) & 0x7ff) == sec && (dmj < dmi || (dmj == dmi && (other & POLY_IDX_MASK) < i))) seed = false;
+            }
+            if (seed) { const int e = atomicAdd(&s_nw, 1); if (e < POLY_SEED_CAP) s_list[e] = ci; }     // (seeds beyond the list's capacity are not used: a looser filter)
+        }
+        __syncthreads();
+        const int ns = s_nw < POLY_SEED_CAP ? s_nw : POLY_SEED_CAP;
+        __syncthreads();
+        if (tid == 0) s_nw = 0;
+        for (int ci = tid; ci < nk; ci += 256) {                  // filter: does the boundary line reach the seeds' polygon?
+            const double ax = c_ax[ci], ay = c_ay[ci], dm = c_dm[ci];
+            PolyFrac w = {1.0, 0.0, -1.0, 0.0};
+            for (int s0 = 0; s0 < ns && poly_frac_alive(w); s0 += 4) {                  // 4 seeds per trip: the reads pipeline
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int cj = s_list[s0 + u < ns ? s0 + u : s0];
+                    if (cj != ci) poly_clip_fast(w, ax, ay, dm, c_ax[cj], c_ay[cj], c_dm[cj]);
+                }
+            }
+            if (!poly_frac_alive(w)) c_idx[ci] |= POLY_DROP_FLAG;
+        }
+        __syncthreads();
+        for (int c0 = 0; c0 < nk; c0 += 256) {                    // in-place compaction, chunk-wise: read, then append below the chunk
+            const int ci = c0 + tid;
+            double ax = 0.0, ay = 0.0, dm = 0.0; int me = POLY_DROP_FLAG;
+            if (ci < nk) { ax = c_ax[ci]; ay = c_ay[ci]; dm = c_dm[ci]; me = c_idx[ci]; }
+            __syncthreads();
+            if (!(me & POLY_DROP_FLAG)) { const int e = atomicAdd(&s_nw, 1); c_ax[e] = ax; c_ay[e] = ay; c_dm[e] = dm; c_idx[e] = me & POLY_IDX_MASK; }
+            __syncthreads();
+        }
+        if (tid == 0) s_nk = s_nw;
+        __syncthreads();
+    }
+    if (POLY_STOP <= 4) { if (tid == 0) which[0] = s_nk; return; }
+    // ---- edge test among the candidates (a candidate found redundant stays in the list as ~index: it still clips the others,
+    //      like in the mirror, where every candidate clips every other)
+    const int nk = s_nk;
+    for (int ci = tid; ci < nk; ci += 256) {
+        const int i = c_idx[ci];                                  // (only this thread ever rewrites entry ci)
+        const double ai1 = c_ax[ci], ai2 = c_ay[ci], dmi = c_dm[ci];
+        PolyClip w = {-HUGE_VAL, HUGE_VAL, false};
+        for (int cj = 0; cj < nk && !w.kill && w.hi - w.lo > POLY_TOL_EDGE; cj++) {
+            int j = c_idx[cj];
+            j = j < 0 ? ~j : j;
+            if (j != i) poly_clip(w, ai1, ai2, dmi, i, c_ax[cj], c_ay[cj], c_dm[cj], j);
+        }
+        if (!w.kill && w.hi - w.lo > POLY_TOL_EDGE) atomicAdd(&s_ne, 1);
+        else c_idx[ci] = ~i;
+    }
+    __syncthreads();
+    // ---- rows: an edge's row is its rank by (margin, sample index)
+    for (int ci = tid; ci < nk; ci += 256) {
+        const int i = c_idx[ci];
+        if (i < 0) continue;
+        const double dmi = c_dm[ci];
+        int rank = 0;
+        for (int cj = 0; cj < nk; cj++) {
+            const int j = c_idx[cj];
+            if (j >= 0 && (c_dm[cj] < dmi || (c_dm[cj] == dmi && j < i))) rank++;
+        }
+        if (rank < n_rows) {
+            const double2 q = o[i];
+            const double a1 = c_ax[ci], a2 = c_ay[ci];
+            p[ip_slk(d, rank, 0)] = a1; p[ip_slk(d, rank, 1)] = a2; p[ip_slk(d, rank, 2)] = a1 * q.x + a2 * q.y - radius;
+            which[rank] = i;
+        }
+    }
+    if (tid < n_rows && tid >= s_ne) { p[ip_slk(d, tid, 0)] = 1.0; p[ip_slk(d, tid, 1)] = 0.0; p[ip_slk(d, tid, 2)] = state_x[sc] + 100.0; which[tid] = -1; }
+}
+
+
+// Support of a scenario program's solution (the scenarios whose constraints are active at it; SH-MPC bounds the collision
+// probability of the plan through the size of this set -- ScenarioSolver::support / ::status, scenario_constraints.h:38-40; the
+// scenario_module that fills them is absent, so this restates the definition of the method the reference cites, README.md:22):
+// scenario s = sample index % n_scenarios (samples are [obstacle][scenario]: one scenario is one joint draw of all obstacles over
+// the horizon); a row is active when  a.p_disc - (b + slack) >= -tol  at the solution.  One wave per trajectory; the set is a
+// bitmask in LDS.  support[b] = number of distinct active scenarios, active_rows[b] = number of active rows.
+__global__ __launch_bounds__(64) void tmpc_scenario_support_kernel(Dims d, int B, const double *params, const double *xtraj, const int *row_sample,
+                                                                  int n_rows, int n_scenarios, double tol, int *support, int *active_rows)
+{
+#pragma clang fp contract(off)
+    __shared__ unsigned int s_mask[256];                                // up to 8192 scenarios
+    __shared__ int s_rows;
+    const int b = blockIdx.x, tid = threadIdx.x, N = d.N, nxe = ext_nx(d);
+    if (b >= B) return;
+    for (int w = tid; w < 256; w += 64) s_mask[w] = 0u;
+    if (tid == 0) s_rows = 0;
+    __syncthreads();
+    for (int e = tid; e < (N - 1) * n_rows; e += 64) {
+        const int k = 1 + e / n_rows, r = e - (k - 1) * n_rows;
+        const int smp = row_sample[((size_t)b * N + k) * n_rows + r];
+        if (smp < 0) continue;
+        const double *p = params + ((size_t)b * N + k) * d.npar;
+        const double *x = xtraj + ((size_t)b * (N + 1) + k) * nxe;
+        const double off = p[ip_disc_offset(d)], slack = d.slack ? x[NX] : 0.0;
+        const double px = x[0] + off * cos(x[2]), py = x[1] + off * sin(x[2]);
+        const double h = p[ip_slk(d, r, 0)] * px + p[ip_slk(d, r, 1)] * py - (p[ip_slk(d, r, 2)] + slack);
+        if (h >= -tol) {
+            const int s = smp % n_scenarios;
+            atomicOr(&s_mask[s >> 5], 1u << (s & 31));
+            atomicAdd(&s_rows, 1);
+        }
+    }
+    __syncthreads();
+    int cnt = 0;
+    for (int w = tid; w < 256; w += 64) cnt += __popc(s_mask[w]);
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o, 64);
+    if (tid == 0) { support[b] = cnt; if (active_rows) active_rows[b] = s_rows; }
 }
 
 

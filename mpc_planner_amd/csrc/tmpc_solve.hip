@@ -764,6 +764,10 @@ struct tmpc_handle {
     double *st_z = nullptr, *st_pi = nullptr, *st_lamh = nullptr;
     int *st_stopped = nullptr;
     bool st_valid = false;           // the state arrays hold the result of a previous tmpc_solve_iterations on this handle
+    // SH-MPC bookkeeping: the sample behind each scenario row of the last tmpc_scenario_halfspaces (i32 [B][N][scn_rows])
+    int *scn_sample = nullptr;
+    size_t scn_cap = 0;
+    int scn_rows = 0, scn_B = 0;
     std::vector<hipEvent_t> ev;      // per-launch timing events (pairs)
     int ev_used = 0;
     bool timing = false;
@@ -885,7 +889,7 @@ void tmpc_destroy(tmpc_handle *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void *ptrs[] = {h->o_xinit, h->o_x0, h->o_params, h->xtraj, h->utraj, h->pobj, h->res_eq, h->d_weight,
                     h->exit_code, h->qp_status, h->sqp_iter, h->qp_iter, h->d_best, h->d_disabled,
-                    h->st_z, h->st_pi, h->st_lamh, h->st_stopped};
+                    h->st_z, h->st_pi, h->st_lamh, h->st_stopped, h->scn_sample};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &e : h->ev) (void)hipEventDestroy(e);
     tmpc::lanes::destroy(h->lanes);
@@ -1122,9 +1126,38 @@ int tmpc_scenario_halfspaces(tmpc_handle *h, const void *d_samples, int32_t n_pt
         return TMPC_ERR_INVALID;
     }
     TMPC_HIP_CHECK(h, hipSetDevice(h->device));
-    hipLaunchKernelGGL(tmpc::tmpc_scenario_halfspaces_kernel, dim3(h->B * h->d.N), dim3(256), 0, h->stream, h->d, h->B, h->x0,
+    const size_t lds = (size_t)n_pts * (3 * sizeof(double) + sizeof(int));          // normals, margins, candidate list
+    if (lds > 150 * 1024) { h->err = "tmpc_scenario_halfspaces: more than 5485 samples per stage do not fit the workgroup's LDS"; return TMPC_ERR_INVALID; }
+    const size_t need = (size_t)h->B * h->d.N * n_rows;
+    if (need > h->scn_cap) {
+        if (h->scn_sample) { TMPC_HIP_CHECK(h, hipStreamSynchronize(h->stream)); (void)hipFree(h->scn_sample); h->scn_sample = nullptr; h->scn_cap = 0; }
+        TMPC_HIP_CHECK(h, hipMalloc(&h->scn_sample, need * sizeof(int)));
+        h->scn_cap = need;
+    }
+    h->scn_rows = n_rows; h->scn_B = h->B;
+    if (lds > 48 * 1024)
+        TMPC_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(tmpc::tmpc_scenario_halfspaces_kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(tmpc::tmpc_scenario_halfspaces_kernel, dim3(h->B * h->d.N), dim3(256), lds, h->stream, h->d, h->B, h->x0,
                        const_cast<double *>(h->params), (const double *)d_samples, n_pts, n_rows, (const int *)d_scene_of,
-                       (const double *)d_state_x, radius, disc_offset);
+                       (const double *)d_state_x, radius, disc_offset, h->scn_sample);
+    TMPC_HIP_CHECK(h, hipGetLastError());
+    return TMPC_OK;
+}
+
+int tmpc_scenario_support(tmpc_handle *h, int32_t n_scenarios, double tol, void *d_support, void *d_active_rows)
+{
+    if (!h || !d_support || n_scenarios <= 0 || n_scenarios > 8192 || !(tol >= 0.0)) {
+        if (h) h->err = "tmpc_scenario_support: bad argument (1 <= n_scenarios <= 8192, tol >= 0)";
+        return TMPC_ERR_INVALID;
+    }
+    if (!h->scn_sample || h->scn_B != h->B || h->B <= 0 || !h->params) {
+        h->err = "tmpc_scenario_support: no tmpc_scenario_halfspaces on the current batch";
+        return TMPC_ERR_INVALID;
+    }
+    TMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    hipLaunchKernelGGL(tmpc::tmpc_scenario_support_kernel, dim3(h->B), dim3(64), 0, h->stream, h->d, h->B, h->params, h->xtraj,
+                       h->scn_sample, h->scn_rows, n_scenarios, tol, (int *)d_support, (int *)d_active_rows);
     TMPC_HIP_CHECK(h, hipGetLastError());
     return TMPC_OK;
 }

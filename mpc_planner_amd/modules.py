@@ -154,30 +154,149 @@ def halfspace_rows_set_parameters(pm, params, state_x, rows, prefix, n_rows, dis
                 params[1:, ia[w]] = col
 
 
-def scenario_halfspaces(x0, samples, radius, n_rows=24):
-    """Stand-in for scenario_module's per-stage polygon construction (source absent: README.md:24,76):
-    every sampled obstacle position o of stage k gives the halfspace a = (o - p)/|o - p|, b = a.o - radius around the
-    guess p (the same linearisation LinearizedConstraints uses, linearized_constraints.cpp:84-105); of the
-    M * S_cen halfspaces the tightest one of each of the n_rows equal angular sectors of a is kept (the edges of the
-    free polygon around p), empty sectors stay dummies.
-    x0 [N+1][nv]; samples [M][S_cen][N][2] (index k-1 for stage k).  Returns a1, a2, b [N][n_rows] with NaN = dummy."""
+POLY_EPS_PARALLEL = 1e-12       # |sin| below which two halfspace boundaries count as parallel
+POLY_TOL_EDGE = 1e-9            # minimal length [m] of the piece of a boundary line that lies on the polygon
+POLY_SEED_MARGIN = 1e-6         # slack of the candidate filter
+POLY_BINS = (4, 32, 256)        # sector resolution (bins per octant) of the three filter rounds
+
+
+def _poly_sector(ax, ay, bins):
+    """Direction sector 0..8*bins-1 of unit vectors (octant x bins of min(|ax|,|ay|)/max(|ax|,|ay|)): only comparisons, one divide
+    and one multiply by a power of two, so host and device classify identically."""
+    u, v = np.abs(ax), np.abs(ay)
+    steep = v > u
+    octant = (ax < 0).astype(int) | ((ay < 0).astype(int) << 1) | (steep.astype(int) << 2)
+    t = np.where(steep, u, v) / np.where(steep, v, u)
+    return octant * bins + np.minimum((t * float(bins)).astype(int), bins - 1)
+
+
+def _poly_clip(ax, ay, dm, rows, cols, kill_below, dedup):
+    """Clip the boundary line of every halfspace in `rows` (q_i + t perp_i, q_i = p + dm_i a_i) with the halfspaces in `cols`:
+    (a_j . perp_i) t <= dm_j - dm_i (a_j . a_i).  Returns lo, hi (the interval of t left) and kill (a parallel halfspace
+    excludes the whole line -- kill_below <= 0 is the slack of that decision; with dedup, of identical halfspaces only the
+    lowest index survives)."""
+    a1i, a2i, di = ax[rows][:, None], ay[rows][:, None], dm[rows][:, None]
+    a1j, a2j, dj = ax[cols][None, :], ay[cols][None, :], dm[cols][None, :]
+    c = a1j * (-a2i) + a2j * a1i
+    dot = a1j * a1i + a2j * a2i
+    rhs = dj - di * dot
+    other = np.asarray(rows)[:, None] != np.asarray(cols)[None, :]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ratio = rhs / c
+    hi = np.where(other & (c > POLY_EPS_PARALLEL), ratio, np.inf).min(axis=1, initial=np.inf)
+    lo = np.where(other & (c < -POLY_EPS_PARALLEL), ratio, -np.inf).max(axis=1, initial=-np.inf)
+    par = other & (np.abs(c) <= POLY_EPS_PARALLEL)
+    same = dot > 0.0                                   # same direction: the closer one wins; opposite: an empty strip kills both
+    k = par & np.where(same, dj < di + kill_below, rhs < kill_below)
+    if dedup:
+        k |= par & same & (dj == di) & (np.asarray(cols)[None, :] < np.asarray(rows)[:, None])
+    return lo, hi, k.any(axis=1)
+
+
+def polygon_edges(ax, ay, dm):
+    """Which of the halfspaces  a_i . (q - p) <= dm_i  (unit normals a_i = (ax, ay), margins dm_i measured from the point p they
+    were linearised around) form the boundary of their intersection polygon: halfspace i is an edge iff the piece of its boundary
+    line inside all other halfspaces has positive length (every other halfspace is redundant -- removing it changes nothing).
+    The steps tmpc_scenario_halfspaces_kernel runs with the same per-pair arithmetic:
+      filter rounds (sector resolution POLY_BINS): the closest halfspace of each direction sector is a seed (lowest index on
+         ties); a halfspace whose boundary line misses the seeds' polygon cannot touch the (smaller) polygon of all -- the rest
+         stay candidates,
+      the edge test above among the candidates of the last round.
+    Returns a bool array."""
+    n = len(dm)
+    cand = np.arange(n)
+    for bins in POLY_BINS:
+        sec = _poly_sector(ax[cand], ay[cand], bins)
+        order = np.lexsort((cand, dm[cand]))                    # by margin, then index
+        seeds = np.sort(cand[order[np.unique(sec[order], return_index=True)[1]]])
+        lo, hi, kill = _poly_clip(ax, ay, dm, cand, seeds, -POLY_SEED_MARGIN, False)
+        cand = cand[~kill & (hi - lo > -POLY_SEED_MARGIN)]
+    lo, hi, kill = _poly_clip(ax, ay, dm, cand, cand, 0.0, True)
+    edge = np.zeros(n, bool)
+    edge[cand] = ~kill & (hi - lo > POLY_TOL_EDGE)
+    return edge
+
+
+def scenario_halfspaces(x0, samples, radius, n_rows=24, return_index=False):
+    """Per-stage polygon construction of SH-MPC (scenario_constraints.cpp:47,76-79 hand this to the external scenario_module, whose
+    source is not in the reference tree; restated from the method the reference cites, README.md:22: every sampled obstacle
+    position o of stage k gives the halfspace a = (o - p)/|o - p|, b = a.o - radius linearised around the previous plan's position
+    p -- the linearisation LinearizedConstraints uses too, linearized_constraints.cpp:84-105 --, the free region of the stage is
+    their intersection polygon, and only the halfspaces that form its boundary are constraints of the optimisation).  Exact here:
+    `polygon_edges` keeps precisely the non-redundant halfspaces; if the polygon has more than n_rows edges (the solver's capacity)
+    the n_rows closest to p are kept (lowest sample index on ties), unused slots stay dummies.
+    x0 [N+1][nv]; samples [M][S_cen][N][2] (index k-1 for stage k).  Returns a1, a2, b [N][n_rows] with NaN = dummy; rows in order of
+    increasing distance.  return_index: also the flat sample index m * S_cen + s behind each row ([N][n_rows], -1 = dummy)."""
     N = x0.shape[0] - 1
     a1 = np.full((N, n_rows), np.nan); a2 = np.full((N, n_rows), np.nan); b = np.full((N, n_rows), np.nan)
+    which = np.full((N, n_rows), -1, np.int32)
     for k in range(1, N):
         p = x0[k, [IDX["x"], IDX["y"]]]
         o = samples[:, :, k - 1, :].reshape(-1, 2)
         diff = o - p
         dist = np.sqrt(diff[:, 0] * diff[:, 0] + diff[:, 1] * diff[:, 1])
         ax = diff[:, 0] / dist; ay = diff[:, 1] / dist
-        sector = np.minimum(((np.arctan2(ay, ax) + np.pi) * (n_rows / (2.0 * np.pi))).astype(np.int64), n_rows - 1)
-        for s in range(n_rows):
-            idx = np.nonzero(sector == s)[0]
-            if idx.size == 0:
+        dm = dist - radius
+        idx = np.nonzero(polygon_edges(ax, ay, dm))[0]
+        idx = idx[np.argsort(dm[idx], kind="stable")][:n_rows]             # closest first; stable: lowest sample index on ties
+        m = len(idx)
+        a1[k, :m] = ax[idx]; a2[k, :m] = ay[idx]
+        b[k, :m] = ax[idx] * o[idx, 0] + ay[idx] * o[idx, 1] - radius
+        which[k, :m] = idx
+    return (a1, a2, b, which) if return_index else (a1, a2, b)
+
+
+def scenario_support(xtraj, params, pm, row_sample, n_scenarios, tol=1e-6, prefix="disc_0_scenario_constraint"):
+    """Support of one trajectory's solution (host mirror of tmpc_scenario_support_kernel; ScenarioSolver::support,
+    scenario_constraints.h:38-40, filled by the absent scenario_module -- restated from the definition of the method the reference
+    cites, README.md:22): the scenarios with an active constraint  a.p_disc - (b + slack) >= -tol  at the solution, scenario of
+    flat sample index i = i % n_scenarios (one scenario = one joint draw of all obstacles over the horizon).
+    xtraj [N+1][nx(+1)], params [N][npar], row_sample [N][n_rows].  Returns (support, active_rows)."""
+    N, n_rows = row_sample.shape
+    off = params[:, pm.index("ego_disc_0_offset")]
+    slack = xtraj[:N, 5] if xtraj.shape[1] > 5 else np.zeros(N)
+    px = xtraj[:N, 0] + off * np.cos(xtraj[:N, 2]); py = xtraj[:N, 1] + off * np.sin(xtraj[:N, 2])
+    active = set(); rows = 0
+    for k in range(1, N):
+        for r in range(n_rows):
+            if row_sample[k, r] < 0:
                 continue
-            i = idx[np.argmin(dist[idx])]                   # first minimum: lowest sample index on ties
-            a1[k, s] = ax[i]; a2[k, s] = ay[i]
-            b[k, s] = ax[i] * o[i, 0] + ay[i] * o[i, 1] - radius
-    return a1, a2, b
+            a1, a2, b = (params[k, pm.index(f"{prefix}_{r}_{f}")] for f in ("a1", "a2", "b"))
+            if a1 * px[k] + a2 * py[k] - (b + slack[k]) >= -tol:
+                active.add(int(row_sample[k, r]) % n_scenarios); rows += 1
+    return len(active), rows
+
+
+def scenario_risk(n_samples, support, confidence=1e-6, removed=0):
+    """Bound on the collision probability of a plan certified by a scenario program with `n_samples` scenarios whose solution has
+    `support` scenarios of support after `removed` scenarios were discarded (non-convex scenario optimisation, Campi-Garatti-Ramponi
+    2018, Theorem 1, the bound SH-MPC builds on -- README.md:22; the discarded scenarios count into the compression set):
+        eps(k) = 1 - (beta / (S * C(S, k)))^(1 / (S - k)),  k = support + removed,   eps(S) = 1,
+    holds with probability >= 1 - beta (confidence = beta).  The reference's `probabilistic.risk` (settings.yaml) is the value this
+    has to stay below."""
+    from math import lgamma, log, exp
+    S, k = int(n_samples), int(support) + int(removed)
+    if k >= S:
+        return 1.0
+    log_binom = lgamma(S + 1) - lgamma(k + 1) - lgamma(S - k + 1)
+    return 1.0 - exp((log(confidence) - log(S) - log_binom) / (S - k))
+
+
+def scenario_sample_size(risk, confidence=1e-6, max_support=8, removed=0):
+    """Smallest number of scenarios S for which a solution with at most `max_support` scenarios of support (after `removed`
+    discarded ones) certifies  P(collision) <= risk  with confidence 1 - beta: the smallest S with scenario_risk(S, max_support)
+    <= risk (eps decreases in S for fixed k)."""
+    lo = max_support + removed + 1
+    hi = lo
+    while scenario_risk(hi, max_support, confidence, removed) > risk:
+        hi *= 2
+    while lo < hi:
+        mid = (lo + hi) // 2
+        if scenario_risk(mid, max_support, confidence, removed) <= risk:
+            hi = mid
+        else:
+            lo = mid + 1
+    return lo
 
 
 def initialize_with_forward_propagation(state, N, dt, nv=NV):

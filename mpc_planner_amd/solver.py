@@ -39,7 +39,7 @@ EXPORTS = ["tmpc_default_dims", "tmpc_default_dims_ex", "tmpc_create", "tmpc_des
            "tmpc_set_batch_device", "tmpc_solve", "tmpc_set_latency_mode", "tmpc_synchronize", "tmpc_get", "tmpc_select_best",
            "tmpc_result_device_ptrs", "tmpc_time_solve", "tmpc_debug_eval_stage", "tmpc_pack_records",
            "tmpc_select_best_records", "tmpc_enable_timing", "tmpc_get_timings", "tmpc_debug_profile",
-           "tmpc_linearize_topology", "tmpc_scenario_halfspaces", "tmpc_warmstart", "tmpc_init_with_guidance",
+           "tmpc_linearize_topology", "tmpc_scenario_halfspaces", "tmpc_scenario_support", "tmpc_warmstart", "tmpc_init_with_guidance",
            "tmpc_debug_get_x0", "tmpc_debug_get_params", "tmpc_set_throughput_mode", "tmpc_solve_iterations",
            "tmpc_reset_multipliers", "tmpc_get_stream"]
 
@@ -98,6 +98,7 @@ def load_library(path=None):
     lib.tmpc_init_with_guidance.argtypes = [vp, vp, vp, vp]
     lib.tmpc_debug_get_x0.argtypes = [vp, vp, vp]
     lib.tmpc_scenario_halfspaces.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, vp, C.c_double, C.c_double]
+    lib.tmpc_scenario_support.argtypes = [vp, C.c_int32, C.c_double, vp, vp]
     lib.tmpc_debug_get_params.argtypes = [vp, vp]
     _libs[path] = lib
     return lib
@@ -124,6 +125,7 @@ class BatchedSolver:
         self.dims = dims
         self.B_max = int(B_max)
         self.B = 0
+        self.device = int(device)
         self._h = C.c_void_p()
         rc = self.lib.tmpc_create(C.byref(self._h), C.byref(dims), self.B_max, int(device))
         if rc != 0:
@@ -262,6 +264,17 @@ class BatchedSolver:
                                                       C.c_void_p(d_scene_of), C.c_void_p(d_state_x), float(radius),
                                                       float(disc_offset)), "tmpc_scenario_halfspaces")
 
+    def scenario_support(self, n_scenarios, tol=1e-6):
+        """Support of every trajectory's solution (distinct scenarios with an active row; tmpc_scenario_support) after a solve on
+        rows built by scenario_halfspaces.  Returns (support [B], active_rows [B]) as numpy int32."""
+        import torch
+        out = torch.empty((2, self.B), dtype=torch.int32, device=f"cuda:{self.device}")
+        self._check(self.lib.tmpc_scenario_support(self._h, int(n_scenarios), float(tol), C.c_void_p(out[0].data_ptr()),
+                                                   C.c_void_p(out[1].data_ptr())), "tmpc_scenario_support")
+        self.synchronize()
+        o = out.cpu().numpy()
+        return o[0], o[1]
+
     def warmstart(self, d_state, d_mode=None, d_src=None, deceleration=3.0):
         """Device warm start of the next tick from the solution held by the handle (raw device pointers)."""
         self._check(self.lib.tmpc_warmstart(self._h, C.c_void_p(d_state), C.c_void_p(d_mode) if d_mode else None,
@@ -329,22 +342,37 @@ def optimize_batch(solver, scene_batch, tmpc_consistency_weight=None):
     return res, best
 
 
-def optimize_scenarios(solver, xinit, x0, params, n_iter=None):
+def optimize_scenarios(solver, xinit, x0, params, n_iter=None, scenario=None):
     """Batched counterpart of ScenarioConstraints::optimize (scenario_constraints.cpp:58-108): the P parallel scenario solvers
     (each a copy of the main solver with its own scenario halfspaces in `params` [P][N][npar]; copying the main solver and
     scenario_module.setParameters happen on the caller's side, e.g. modules.halfspace_rows_set_parameters) are solved together,
     driven ONE RTI iteration at a time like the scenario module drives its solver (initializeOneIteration, solveOneIteration x n
     with the loop exit on qp_status != 0, completeOneIteration; :85), then the selection of :93-107: lowest objective among exit
     code 1 (init 1e9, strict '<': lowest index wins ties).  Returns (results dict, best index or -1, exit code the reference
-    returns: the best solver's, or the first solver's when none succeeded)."""
+    returns: the best solver's, or the first solver's when none succeeded).
+
+    scenario = dict(d_samples, n_pts, n_rows, d_scene_of, d_state_x, radius, n_scenarios[, disc_offset, tol, max_support]) builds
+    the rows on device from the sampled scenarios (tmpc_scenario_halfspaces, scenario_module.update + setParameters) and adds the
+    support bookkeeping of ScenarioSolver (scenario_constraints.h:38-40): res["support"], res["active_rows"], and with max_support
+    res["scenario_status"] (0 = within the bound the sample size was chosen for, 1 = support exceeded: no certificate) -- a solver
+    with status 1 is then not eligible as the best one."""
     n_iter = solver.dims.n_sqp if n_iter is None else int(n_iter)
     solver.set_batch(xinit, x0, params)                               # *solver = *_solver; setParameters; loadWarmstart
+    if scenario is not None:
+        solver.scenario_halfspaces(scenario["d_samples"], scenario["n_pts"], scenario["n_rows"], scenario["d_scene_of"],
+                                   scenario["d_state_x"], scenario["radius"], scenario.get("disc_offset", 0.0))
     for it in range(n_iter):                                          # every slot stops by itself once its QP reports a status
         solver.solve_iterations(1, keep_iterate=it > 0, keep_multipliers=True, complete=False)
     solver.solve_iterations(0, keep_iterate=True, keep_multipliers=True, complete=True)
     res = solver.get()
+    eligible = res["exit_code"] == 1
+    if scenario is not None:
+        res["support"], res["active_rows"] = solver.scenario_support(scenario["n_scenarios"], scenario.get("tol", 1e-6))
+        if scenario.get("max_support") is not None:
+            res["scenario_status"] = (res["support"] > scenario["max_support"]).astype(np.int32)
+            eligible = eligible & (res["scenario_status"] == 0)
     best, lowest = -1, 1e9
     for i in range(len(res["pobj"])):
-        if res["exit_code"][i] == 1 and res["pobj"][i] < lowest:
+        if eligible[i] and res["pobj"][i] < lowest:
             lowest, best = res["pobj"][i], i
     return res, best, int(res["exit_code"][best if best >= 0 else 0])

@@ -49,12 +49,19 @@ int main(int argc, char **argv)
         hs.resize(N);
         for (int k = 1; k < N; k++)
             for (int r = 0; r < R; r++) { const double a1 = next(), a2 = next(), b = next(); hs[k].emplace_back(Vector2d(a1, a2), b); }
+        auto &sr = sc._scenario_solvers[p]->scenario_of_row;          // the scenario behind each row (-1: dummy row)
+        sr.resize(N);
+        for (int k = 1; k < N; k++)
+            for (int r = 0; r < R; r++) sr[k].push_back((int)next());
     }
+    sc._support_tolerance = next();
     const int exit_code = sc.optimize(state, data, module_data);
     int best = -1;
     for (int p = 0; p < P; p++) if (sc._best_solver == sc._scenario_solvers[p].get()) best = p;
     std::printf("exit_code %d best %d\n", exit_code, best);
-    for (int p = 0; p < P; p++) std::printf("solver %d exit %d objective %.17g\n", p, sc._scenario_solvers[p]->exit_code, sc._scenario_solvers[p]->solver->_info.pobj);
+    for (int p = 0; p < P; p++)
+        std::printf("solver %d exit %d objective %.17g support %d rows %d\n", p, sc._scenario_solvers[p]->exit_code, sc._scenario_solvers[p]->solver->_info.pobj,
+                    sc._scenario_solvers[p]->support.size(), sc._scenario_solvers[p]->support.active_rows);
     for (int k = 0; k <= N; k++) std::printf("x %d %.17g %.17g %.17g %.17g\n", k, solver->getOutput(k, "x"), solver->getOutput(k, "y"), solver->getOutput(k, "psi"), solver->getOutput(k, "v"));
     return 0;
 }

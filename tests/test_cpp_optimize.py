@@ -125,10 +125,20 @@ def test_scenario_optimize_cpp_matches_python_driver(tmp_path):
     W = scenes.WEIGHTS
     vals += [W[k] for k in ("acceleration", "angular_velocity", "slack", "velocity", "reference_velocity", "contour", "lag", "terminal_angle", "terminal_contouring")]
     vals += list(sc["xinit"][0]) + list(sc["segments"].ravel()) + list(x0[0].ravel())
+    from mpc_planner_amd import modules as md
+    S_CEN = sc["samples"].shape[1]
+    whichs = []
     for p in range(P_SOLVERS):
         for k in range(1, N):
             for r in range(R_ROWS):
                 vals += [sc["params"][p, k, pm.index(f"disc_0_scenario_constraint_{r}_{f}")] for f in ("a1", "a2", "b")]
+        # the scenario behind each row (ScenarioSolver::support bookkeeping): flat sample index m * S_cen + s -> s
+        which = md.scenario_halfspaces(sc["x0"][p], sc["samples"], scenes.OBSTACLE_RADIUS + scenes.ROBOT_RADIUS, R_ROWS, return_index=True)[3]
+        whichs.append(which)
+        for k in range(1, N):
+            vals += [float(w % S_CEN) if w >= 0 else -1.0 for w in which[k]]
+    TOL = 1e-3
+    vals.append(TOL)
     f = str(tmp_path / "scenario.bin")
     np.array(vals, float).tofile(f)
     out = subprocess.run([BIN5, os.path.join(GEN5, "config"), f], capture_output=True, text=True, timeout=300)
@@ -150,4 +160,8 @@ def test_scenario_optimize_cpp_matches_python_driver(tmp_path):
         assert int(row[3]) == res["exit_code"][p_]
         if res["exit_code"][p_] == 1:
             assert abs(float(row[5]) - res["pobj"][p_]) <= 1e-7 * max(1.0, abs(res["pobj"][p_]))
+            # support of the solution: C++ bookkeeping == host mirror on the Python driver's solution (rows are the scene's own:
+            # the polygon around sc["x0"][p_], while every solver starts from the main solver's warm start)
+            want = md.scenario_support(res["xtraj"][p_], sc["params"][p_], pm, whichs[p_], S_CEN, TOL)
+            assert (int(row[7]), int(row[9])) == want
     np.testing.assert_allclose(c_x, res["xtraj"][best][:, :4], rtol=0, atol=1e-7)

@@ -463,9 +463,10 @@ def test_slack_value_comes_from_xinit():
 
 
 def test_device_scenario_halfspaces_match_host_mirror():
-    """the SH-MPC scenario -> 24-halfspace reduction on device (8 obstacles x 256 scenarios per stage)
-    vs the host mirror mpc_planner_amd/modules.py::scenario_halfspaces: identical rows (bit for bit), and the solve on
-    device-built rows equals the solve on host-built rows."""
+    """the SH-MPC scenario -> polygon construction on device (8 obstacles x 256 scenarios per stage, the polygon's
+    edges as <= 24 halfspaces) vs the host mirror mpc_planner_amd/modules.py::scenario_halfspaces (itself pinned on Qhull's
+    halfspace intersection, tests/test_polygon.py): identical rows (bit for bit), and the solve on device-built rows equals
+    the solve on host-built rows."""
     import torch
     from mpc_planner_amd import scenes
     skw, pkw = SLACK_CFG["cfg5"]
@@ -491,8 +492,111 @@ def test_device_scenario_halfspaces_match_host_mirror():
     got = s.debug_get_params()
     assert np.array_equal(got, want)
     s.solve(); a = s.get()
+    # support bookkeeping (tmpc_scenario_support) against its host mirror: distinct active scenarios / active rows per trajectory
+    from mpc_planner_amd import modules as md
+    S_cen = scs[0]["samples"].shape[1]
+    for tol in (1e-6, 1e-3):
+        sup, rows = s.scenario_support(S_cen, tol)
+        ref = [md.scenario_support(a["xtraj"][i], want[i], pm,
+                                   md.scenario_halfspaces(x0[i], scs[i // 16]["samples"], 0.4 + 0.325, 24, return_index=True)[3], S_cen, tol)
+               for i in range(B)]
+        assert sup.tolist() == [r[0] for r in ref] and rows.tolist() == [r[1] for r in ref]
+    assert sup.max() >= 1 and (rows >= sup).all()
     s.set_batch(xinit, x0, want); s.solve(); b = s.get()
     assert (a["exit_code"] == b["exit_code"]).all() and np.array_equal(a["xtraj"], b["xtraj"])
+    with pytest.raises(Exception):                     # a batch of another size: the previous batch's bookkeeping does not apply
+        s.set_batch(xinit[:8], x0[:8], want[:8]); s.scenario_support(S_cen)
+    s.close()
+
+
+def test_optimize_scenarios_with_device_rows_and_support_bound():
+    """solver.optimize_scenarios with the rows built on device from the samples equals the host-row path; with a support bound the
+    solvers whose support exceeds it get status 1 and are not eligible (ScenarioSolver::status / ::support)."""
+    import torch
+    from mpc_planner_amd import scenes, solver
+    skw, pkw = SLACK_CFG["cfg5"]
+    sc = scenes.make_scene(3, B=16, **skw)
+    B, N = 16, 20
+    smp = np.ascontiguousarray(sc["samples"].transpose(2, 0, 1, 3)).reshape(1, N, -1, 2)
+    dev = torch.device("cuda")
+    t_s = torch.from_numpy(smp).to(dev); t_sc = torch.zeros(B, dtype=torch.int32, device=dev)
+    t_sx = torch.from_numpy(sc["xinit"][:1, 0].copy()).to(dev)
+    s = _solver(S=5, B_max=B, **pkw)
+    ref, best_ref, code_ref = solver.optimize_scenarios(s, sc["xinit"], sc["x0"], sc["params"])
+    s.reset_multipliers()                                  # (the solvers keep their multipliers from call to call, like the capsules)
+    scn = dict(d_samples=t_s.data_ptr(), n_pts=smp.shape[2], n_rows=24, d_scene_of=t_sc.data_ptr(), d_state_x=t_sx.data_ptr(),
+               radius=0.4 + 0.325, n_scenarios=sc["samples"].shape[1], tol=1e-3)
+    blank = sc["params"].copy()
+    pm = sc["pm"]
+    for j in range(24):
+        blank[:, :, pm.index(f"disc_0_scenario_constraint_{j}_a1")] = 1.0
+        blank[:, :, pm.index(f"disc_0_scenario_constraint_{j}_a2")] = 0.0
+        blank[:, :, pm.index(f"disc_0_scenario_constraint_{j}_b")] = 1e3
+    res, best, code = solver.optimize_scenarios(s, sc["xinit"], sc["x0"], blank, scenario=scn)
+    assert best == best_ref and code == code_ref and np.array_equal(res["xtraj"], ref["xtraj"])
+    assert "scenario_status" not in res and res["support"].shape == (B,)
+    ok = res["exit_code"] == 1
+    bound = int(np.sort(res["support"][ok])[ok.sum() // 2])            # a bound that splits the successful solvers
+    if (res["support"][ok] > bound).any():
+        s.reset_multipliers()
+        res2, best2, _ = solver.optimize_scenarios(s, sc["xinit"], sc["x0"], blank, scenario=dict(scn, max_support=bound))
+        assert np.array_equal(res2["support"], res["support"])
+        assert (res2["scenario_status"] == (res2["support"] > bound)).all()
+        elig = ok & (res2["support"] <= bound)
+        assert best2 == int(np.flatnonzero(elig)[np.argmin(res2["pobj"][elig])])
+    s.close()
+
+
+@pytest.mark.parametrize("shape", ["ragged", "ring", "one_sided", "duplicates", "large", "tiny"])
+def test_device_polygon_edge_cases(shape):
+    """The polygon kernel on sample sets the scenes do not produce: a sample count that is no multiple of the workgroup, more edges
+    than rows (truncation by distance), an unbounded polygon, exact duplicates (lowest index kept), 3000 samples per stage (the
+    dynamic-LDS path above 48 KB), and fewer samples than rows (dummies).  Rows equal the host mirror's bit for bit."""
+    import torch
+    from mpc_planner_amd import scenes, modules as md
+    skw, pkw = SLACK_CFG["cfg5"]
+    sc = scenes.make_scene(6, B=8, **skw)
+    B, N = 8, 20
+    pm = sc["pm"]
+    rng = np.random.default_rng(17)
+    x0 = sc["x0"].copy()
+    p_mid = x0[:, :, 2:4].mean(axis=(0, 1))
+    n = dict(ragged=777, ring=96, one_sided=1024, duplicates=300, large=3000, tiny=5)[shape]
+    if shape == "ring":
+        th = rng.uniform(0, 2 * np.pi, (N, n))
+        o = np.stack([np.cos(th), np.sin(th)], axis=-1) * 9.0 + p_mid                  # far: nearly every sample is an edge
+    elif shape == "one_sided":
+        o = p_mid + np.array([12.0, 0.0]) + rng.normal(0, 1.5, (N, n, 2))
+    else:
+        o = p_mid + rng.normal(0, 8.0, (N, n, 2))
+        if shape == "duplicates":
+            o[:, 150:] = o[:, :150]
+    # keep the samples off the guess positions (|o - p| -> 0 has no direction)
+    for k in range(1, N):
+        d = np.linalg.norm(o[k - 1][None] - x0[:, k, None, 2:4], axis=2).min(axis=0)
+        o[k - 1][d < 0.8] += 40.0
+    radius = 0.725
+    want = sc["params"].copy()
+    for b in range(B):
+        rows = md.scenario_halfspaces(x0[b], o.transpose(1, 0, 2)[None], radius, 24)
+        md.halfspace_rows_set_parameters(pm, want[b], sc["xinit"][0, 0], rows, "disc_0_scenario_constraint", 24)
+    n_real = [(~np.isnan(md.scenario_halfspaces(x0[0], o.transpose(1, 0, 2)[None], radius, 24)[0][k])).sum() for k in range(1, N)]
+    if shape == "ring":
+        assert max(n_real) == 24                           # truncated
+    if shape == "tiny":
+        assert max(n_real) <= 5
+    start = want.copy()
+    for j in range(24):
+        for f in ("a1", "a2", "b"):
+            start[:, :, pm.index(f"disc_0_scenario_constraint_{j}_{f}")] = -7.0
+    s = _solver(S=5, B_max=B, **pkw)
+    s.set_batch(sc["xinit"], x0, start)
+    dev = torch.device("cuda")
+    t_s = torch.from_numpy(np.ascontiguousarray(o[None])).to(dev)
+    t_sc = torch.zeros(B, dtype=torch.int32, device=dev); t_sx = torch.from_numpy(sc["xinit"][:1, 0].copy()).to(dev)
+    s.scenario_halfspaces(t_s.data_ptr(), n, 24, t_sc.data_ptr(), t_sx.data_ptr(), radius)
+    got = s.debug_get_params()
+    assert np.array_equal(got, want)
     s.close()
 
 
