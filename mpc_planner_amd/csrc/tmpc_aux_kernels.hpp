@@ -134,24 +134,21 @@ __global__ void tmpc_linearize_topology_kernel(Dims d, int B, const double *x0, 
 // One workgroup per (trajectory, stage), in two parts:
 //   FILTER (free to be anything conservative: a halfspace whose boundary line misses the polygon of SOME of the
 //      halfspaces -- the "seeds" -- cannot touch the smaller polygon of all of them, and dropping such halfspaces
-//      changes neither the polygon nor which halfspaces are its edges).  Round 1, on registers: the closest halfspace
-//      of each of 256 direction sectors is a seed (LDS table, atomicMin on an order-preserving key of the margin, then on
-//      the index); a halfspace is clipped by the seed of its own sector and the two nearest seeds on either side only --
-//      those decide, 5 clips instead of one per seed; the survivors (~100 of 2048 on the SH-MPC scenes) are appended to
-//      a compact LDS list.  Round 2, on the list: 2048 sectors, seeds by pairwise comparison, every seed clips -> ~11.
-//      The filter's clips keep the interval as two fractions compared by cross-multiplication: no division.
+//      changes neither the polygon nor which halfspaces are its edges).  On registers: the closest halfspace of each of
+//      256 direction sectors is a seed (LDS table, atomicMin on an order-preserving key of the margin, then on the
+//      index); a halfspace is clipped by the seed of its own sector and the two nearest seeds on either side only --
+//      those decide, 5 clips instead of one per seed, the interval kept as two fractions compared by cross-multiplication
+//      (no division); the survivors (~100 of 2048 on the SH-MPC scenes) are appended to a compact LDS list, on which a
+//      second round with 2048 sectors and every seed clipping leaves ~11.
 //   EDGE TEST (the definition, same per-pair arithmetic as the mirror): candidate i is an edge iff the piece of its line
 //      inside all other candidates' halfspaces has positive length; its row index is its rank by (margin, sample index).
 // The samples of a stage are contiguous ([scene][N][n_pts][2]): a coalesced stream shared through L2 by the scene's
 // trajectories.  The edge test is written without FMA contraction, so the rows equal the mirror's bit for bit.
-#ifndef POLY_STOP
-#define POLY_STOP 99
-#endif
 constexpr double POLY_EPS_PARALLEL = 1e-12, POLY_TOL_EDGE = 1e-9, POLY_SEED_MARGIN = 1e-6;
-constexpr int POLY_IDX_MASK = 0x1fff, POLY_DROP_FLAG = 1 << 29;     // a candidate's index word, see the kernel
+constexpr int POLY_IDX_MASK = 0x1fff, POLY_DROP_FLAG = 1 << 29;     // a candidate's index word during the second filter round
 constexpr int POLY_SEC1 = 256;                        // direction sectors of round 1 (32 per octant, in angular order)
 constexpr int POLY_NONE = 0x7fffffff;
-constexpr int POLY_SEED_CAP = 2 * POLY_SEC1;        // seeds of round 2 that fit the (then free) round-1 table
+constexpr int POLY_LIST_CAP = 512;                  // candidate list of the first pass
 
 __device__ __forceinline__ int poly_sector(double ax, double ay, int bins)        // octant x bins of min(|ax|,|ay|)/max: a partition of the directions
 {
@@ -214,28 +211,27 @@ __device__ __forceinline__ void poly_clip_fast(PolyFrac &w, double ai1, double a
 }
 __device__ __forceinline__ bool poly_frac_alive(const PolyFrac &w) { return w.nh * w.dl - w.nl * w.dh >= -POLY_SEED_MARGIN * (w.dh * w.dl); }   // (>=: both sides are 0 while a bound is infinite)
 
-__global__ __launch_bounds__(256) void tmpc_scenario_halfspaces_kernel(Dims d, int B, const double *x0, double *params,
-                                                                       const double *samples, int n_pts, int n_rows,
-                                                                       const int *scene_of, const double *state_x,
-                                                                       double radius, double disc_offset, int *row_sample)
+// one (trajectory, stage) = `unit` by one workgroup of 256 threads
+__device__ __forceinline__ void poly_stage(int unit, const Dims &d, int B, const double *x0, double *params, const double *samples, int n_pts,
+                                           int n_rows, const int *scene_of, const double *state_x, double radius, double disc_offset,
+                                           int *row_sample, int cap, int *overflow)
 {
 #pragma clang fp contract(off)
-    extern __shared__ double s_dyn[];                                    // the candidates, compact: normal, margin, index word
+    extern __shared__ double s_dyn[];                                    // the candidates, compact: normal, margin, sample index (~index: not an edge)
     __shared__ unsigned long long s_best[POLY_SEC1];
     __shared__ double sd_ax[POLY_SEC1], sd_ay[POLY_SEC1], sd_dm[POLY_SEC1];
     __shared__ int s_seed[POLY_SEC1];
     __shared__ short s_next[POLY_SEC1], s_prev[POLY_SEC1];              // nearest sector with a seed, counter-clockwise / clockwise (-1: none)
-    __shared__ int s_nk, s_nw, s_ne;
-    int *s_list = reinterpret_cast<int *>(s_best);                        // round 2's seeds (list positions); the table is free by then
-    double *c_ax = s_dyn, *c_ay = s_dyn + n_pts, *c_dm = s_dyn + 2 * (size_t)n_pts;
-    int *c_idx = reinterpret_cast<int *>(s_dyn + 3 * (size_t)n_pts);
+    __shared__ int s_nk, s_ns, s_nw, s_ne;
+    __shared__ unsigned long long s_mask[4];
+    double *c_ax = s_dyn, *c_ay = s_dyn + cap, *c_dm = s_dyn + 2 * (size_t)cap;
+    int *c_idx = reinterpret_cast<int *>(s_dyn + 3 * (size_t)cap);
     const int N = d.N;
-    const int b = blockIdx.x / N, k = blockIdx.x - b * N;
-    if (b >= B) return;
+    const int b = unit / N, k = unit - b * N;
     const int sc = scene_of[b];
     double *p = params + ((size_t)b * N + k) * d.npar;
     const int tid = threadIdx.x;
-    int *which = row_sample + (size_t)blockIdx.x * n_rows;            // the sample behind each row (-1: dummy), for tmpc_scenario_support
+    int *which = row_sample + (size_t)unit * n_rows;                  // the sample behind each row (-1: dummy), for tmpc_scenario_support
     if (tid == 0) p[ip_disc_offset(d)] = disc_offset;
     if (k == 0) {
         if (tid < n_rows) { p[ip_slk(d, tid, 0)] = 1.0; p[ip_slk(d, tid, 1)] = 0.0; p[ip_slk(d, tid, 2)] = state_x[sc] + 100.0; which[tid] = -1; }
@@ -268,94 +264,86 @@ __global__ __launch_bounds__(256) void tmpc_scenario_halfspaces_kernel(Dims d, i
     every_sample([&](int i, double, double, double dm, int sec) { if (poly_key(dm) == s_best[sec]) atomicMin(&s_seed[sec], i); });
     __syncthreads();
     every_sample([&](int i, double ax, double ay, double dm, int sec) { if (s_seed[sec] == i) { sd_ax[sec] = ax; sd_ay[sec] = ay; sd_dm[sec] = dm; } });
-    {                                                             // nearest sectors with a seed on either side of sector tid
+    {   // nearest sectors with a seed on either side of sector tid: from the four ballot words of the table (wave w holds sectors 64w..64w+63)
+        const unsigned long long mine = __ballot(s_seed[tid] != POLY_NONE);
+        if ((tid & 63) == 0) s_mask[tid >> 6] = mine;
+        __syncthreads();
+        const int w0 = tid >> 6, bit = tid & 63;
         int nx = -1, pv = -1;
-        for (int q = 1; q < POLY_SEC1 && nx < 0; q++) if (s_seed[(tid + q) & (POLY_SEC1 - 1)] != POLY_NONE) nx = (tid + q) & (POLY_SEC1 - 1);
-        for (int q = 1; q < POLY_SEC1 && pv < 0; q++) if (s_seed[(tid - q) & (POLY_SEC1 - 1)] != POLY_NONE) pv = (tid - q) & (POLY_SEC1 - 1);
+#pragma unroll
+        for (int step = 0; step <= 4; step++) {                   // own word above the bit, the three other words, own word below the bit
+            const int wn = (w0 + step) & 3, wp = (w0 - step) & 3;
+            unsigned long long xn = s_mask[wn], xp = s_mask[wp];
+            if (step == 0) { xn &= bit == 63 ? 0ull : ~0ull << (bit + 1); xp &= (1ull << bit) - 1ull; }
+            if (step == 4) { xn &= (1ull << bit) - 1ull; xp &= bit == 63 ? 0ull : ~0ull << (bit + 1); }
+            if (nx < 0 && xn) nx = wn * 64 + __ffsll((long long)xn) - 1;
+            if (pv < 0 && xp) pv = wp * 64 + 63 - __clzll((long long)xp);
+        }
         s_next[tid] = (short)nx; s_prev[tid] = (short)pv;
     }
     __syncthreads();
-    if (POLY_STOP <= 2) { if (s_seed[tid] == 12345) p[0] = 1.0; return; }
     // a halfspace is clipped by the seed of its own sector and the two nearest seeds on either side; the interval only shrinks,
-    // so once it is empty the halfspace is out, whatever other seeds would do.  The thread's eight halfspaces advance in lockstep
-    // (slot by slot), so that their LDS gathers overlap.
-    {
-        int slot[CACHE][5];
-        PolyFrac w[CACHE];
+    // so once it is empty the halfspace is out, whatever other seeds would do
+    every_sample([&](int i, double ax, double ay, double dm, int sec) {
+        const int n1 = s_next[sec], p1 = s_prev[sec];
+        const int at[5] = {sec, n1, p1, n1 >= 0 ? s_next[n1] : -1, p1 >= 0 ? s_prev[p1] : -1};
+        PolyFrac w = {1.0, 0.0, -1.0, 0.0};
 #pragma unroll
-        for (int c = 0; c < CACHE; c++) {
-            w[c] = {1.0, 0.0, -1.0, 0.0};
-            const int sec = tid + c * 256 < n_pts ? r_sec[c] : 0;
-            const int n1 = s_next[sec], p1 = s_prev[sec];
-            slot[c][0] = sec; slot[c][1] = n1; slot[c][2] = p1;
-            slot[c][3] = n1 >= 0 ? s_next[n1] : -1; slot[c][4] = p1 >= 0 ? s_prev[p1] : -1;
-        }
-#pragma unroll
-        for (int q = 0; q < 5; q++) {
-#pragma unroll
-            for (int c = 0; c < CACHE; c++) {
-                const int i = tid + c * 256, s = slot[c][q];
-                if (i >= n_pts || s < 0 || !poly_frac_alive(w[c])) continue;
-                if (s_seed[s] != i) poly_clip_fast(w[c], r_ax[c], r_ay[c], r_dm[c], sd_ax[s], sd_ay[s], sd_dm[s]);
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < CACHE; c++) {
-            const int i = tid + c * 256;
-            if (i < n_pts && poly_frac_alive(w[c])) { const int e = atomicAdd(&s_nk, 1); c_ax[e] = r_ax[c]; c_ay[e] = r_ay[c]; c_dm[e] = r_dm[c]; c_idx[e] = i; }
-        }
-        for (int i = tid + CACHE * 256; i < n_pts; i += 256) {       // n_pts > 2048
-            double ax, ay, dm; halfspace(i, ax, ay, dm);
-            const int sec = poly_sector_angular(ax, ay), n1 = s_next[sec], p1 = s_prev[sec];
-            const int at[5] = {sec, n1, p1, n1 >= 0 ? s_next[n1] : -1, p1 >= 0 ? s_prev[p1] : -1};
-            PolyFrac v = {1.0, 0.0, -1.0, 0.0};
-            for (int q = 0; q < 5 && poly_frac_alive(v); q++)
-                if (at[q] >= 0 && s_seed[at[q]] != i) poly_clip_fast(v, ax, ay, dm, sd_ax[at[q]], sd_ay[at[q]], sd_dm[at[q]]);
-            if (poly_frac_alive(v)) { const int e = atomicAdd(&s_nk, 1); c_ax[e] = ax; c_ay[e] = ay; c_dm[e] = dm; c_idx[e] = i; }
-        }
-    }
+        for (int q = 0; q < 5; q++)
+            if (at[q] >= 0 && poly_frac_alive(w) && s_seed[at[q]] != i) poly_clip_fast(w, ax, ay, dm, sd_ax[at[q]], sd_ay[at[q]], sd_dm[at[q]]);
+        if (poly_frac_alive(w)) { const int e = atomicAdd(&s_nk, 1); if (e < cap) { c_ax[e] = ax; c_ay[e] = ay; c_dm[e] = dm; c_idx[e] = i; } }
+    });
     __syncthreads();
-    if (POLY_STOP <= 3) { if (tid == 0) which[0] = s_nk; return; }
-    // ---- round 2 on the compact list.  An entry's index word: bits 0-12 the sample index, 13-23 its sector of this round,
-    //      29 dropped by this round's filter; an entry is only ever rewritten by the thread that owns it.
+    if (s_nk > cap) { if (tid == 0) overflow[1 + atomicAdd(&overflow[0], 1)] = unit; return; }          // (uniform: s_nk is final after the barrier; only in the first pass)
+    // ---- filter, second round, on the list (~100 -> ~11): seeds = the closest candidate of each of 2048 sectors (pairwise comparison:
+    //      the list is short; the sector rides in bits 13-23 of the index word), every seed clips every candidate -- G threads per
+    //      candidate, each taking every G-th seed, the fractions combined over the G lanes --, then the list is compacted in place
     {
-        const int nk = s_nk;
-        for (int ci = tid; ci < nk; ci += 256) c_idx[ci] = (c_idx[ci] & POLY_IDX_MASK) | (poly_sector(c_ax[ci], c_ay[ci], 256) << 13);
-        if (tid == 0) s_nw = 0;
+        const int nk1 = s_nk;
+        for (int ci = tid; ci < nk1; ci += 256) c_idx[ci] |= poly_sector(c_ax[ci], c_ay[ci], 256) << 13;
+        if (tid == 0) { s_ns = 0; s_nw = 0; }
         __syncthreads();
-        for (int ci = tid; ci < nk; ci += 256) {                  // seed = the closest of its sector (lowest sample index on ties)
+        for (int ci = tid; ci < nk1; ci += 256) {
             const double dmi = c_dm[ci];
-            const int me = c_idx[ci], i = me & POLY_IDX_MASK, sec = (me >> 13) & 0x7ff;
+            const int me = c_idx[ci], i = me & POLY_IDX_MASK, sec = me >> 13;
             bool seed = true;
 #pragma unroll 8
-            for (int cj = 0; cj < nk; cj++) {                     // (no early exit: the reads pipeline)
+            for (int cj = 0; cj < nk1; cj++) {                    // (no early exit: the reads pipeline)
                 const int other = c_idx[cj];
                 const double dmj = c_dm[cj];
-                if (((other >> 13) & 0x7ff) == sec && (dmj < dmi || (dmj == dmi && (other & POLY_IDX_MASK) < i))) seed = false;
+                if ((other >> 13) == sec && (dmj < dmi || (dmj == dmi && (other & POLY_IDX_MASK) < i))) seed = false;
             }
-            if (seed) { const int e = atomicAdd(&s_nw, 1); if (e < POLY_SEED_CAP) s_list[e] = ci; }     // (seeds beyond the list's capacity are not used: a looser filter)
+            if (seed) {                                           // (the round-1 seed table is free; seeds beyond its size are not used: a looser filter)
+                const int e = atomicAdd(&s_ns, 1);
+                if (e < POLY_SEC1) { sd_ax[e] = c_ax[ci]; sd_ay[e] = c_ay[ci]; sd_dm[e] = dmi; s_seed[e] = i; }
+            }
         }
         __syncthreads();
-        const int ns = s_nw < POLY_SEED_CAP ? s_nw : POLY_SEED_CAP;
-        __syncthreads();
-        if (tid == 0) s_nw = 0;
-        for (int ci = tid; ci < nk; ci += 256) {                  // filter: does the boundary line reach the seeds' polygon?
-            const double ax = c_ax[ci], ay = c_ay[ci], dm = c_dm[ci];
+        const int ns = s_ns < POLY_SEC1 ? s_ns : POLY_SEC1;
+        int G = 1;
+        while (G < 64 && 2 * G * nk1 <= 256) G *= 2;
+        const int g = tid & (G - 1);
+        for (int base = 0; base < nk1; base += 256 / G) {
+            const int ci = base + tid / G;
+            const bool valid = ci < nk1;
+            const double ax = valid ? c_ax[ci] : 1.0, ay = valid ? c_ay[ci] : 0.0, dm = valid ? c_dm[ci] : 0.0;
+            const int i = valid ? c_idx[ci] & POLY_IDX_MASK : -1;
             PolyFrac w = {1.0, 0.0, -1.0, 0.0};
-            for (int s0 = 0; s0 < ns && poly_frac_alive(w); s0 += 4) {                  // 4 seeds per trip: the reads pipeline
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int cj = s_list[s0 + u < ns ? s0 + u : s0];
-                    if (cj != ci) poly_clip_fast(w, ax, ay, dm, c_ax[cj], c_ay[cj], c_dm[cj]);
-                }
+            if (valid)
+                for (int q = g; q < ns; q += G)
+                    if (s_seed[q] != i) poly_clip_fast(w, ax, ay, dm, sd_ax[q], sd_ay[q], sd_dm[q]);
+            for (int m = 1; m < G; m <<= 1) {                     // the lower upper bound, the higher lower bound
+                const double onh = __shfl_xor(w.nh, m, 64), odh = __shfl_xor(w.dh, m, 64), onl = __shfl_xor(w.nl, m, 64), odl = __shfl_xor(w.dl, m, 64);
+                if (onh * w.dh < w.nh * odh) { w.nh = onh; w.dh = odh; }
+                if (onl * w.dl > w.nl * odl) { w.nl = onl; w.dl = odl; }
             }
-            if (!poly_frac_alive(w)) c_idx[ci] |= POLY_DROP_FLAG;
+            if (valid && g == 0 && !poly_frac_alive(w)) c_idx[ci] |= POLY_DROP_FLAG;
         }
         __syncthreads();
-        for (int c0 = 0; c0 < nk; c0 += 256) {                    // in-place compaction, chunk-wise: read, then append below the chunk
+        for (int c0 = 0; c0 < nk1; c0 += 256) {                   // in-place compaction, chunk-wise: read, then append below the chunk
             const int ci = c0 + tid;
             double ax = 0.0, ay = 0.0, dm = 0.0; int me = POLY_DROP_FLAG;
-            if (ci < nk) { ax = c_ax[ci]; ay = c_ay[ci]; dm = c_dm[ci]; me = c_idx[ci]; }
+            if (ci < nk1) { ax = c_ax[ci]; ay = c_ay[ci]; dm = c_dm[ci]; me = c_idx[ci]; }
             __syncthreads();
             if (!(me & POLY_DROP_FLAG)) { const int e = atomicAdd(&s_nw, 1); c_ax[e] = ax; c_ay[e] = ay; c_dm[e] = dm; c_idx[e] = me & POLY_IDX_MASK; }
             __syncthreads();
@@ -363,21 +351,35 @@ __global__ __launch_bounds__(256) void tmpc_scenario_halfspaces_kernel(Dims d, i
         if (tid == 0) s_nk = s_nw;
         __syncthreads();
     }
-    if (POLY_STOP <= 4) { if (tid == 0) which[0] = s_nk; return; }
-    // ---- edge test among the candidates (a candidate found redundant stays in the list as ~index: it still clips the others,
-    //      like in the mirror, where every candidate clips every other)
+    // ---- edge test among the candidates, G threads per candidate (G = 256 / candidates, rounded down to a power of two): each takes
+    //      every G-th of the other candidates, then min / max / or across the G lanes.  Every candidate clips every other, like in
+    //      the mirror, and a quotient is the same whichever thread computes it, so the split does not change the result.  A
+    //      candidate found redundant stays in the list as ~index (readers decode it): it still clips the others.
     const int nk = s_nk;
-    for (int ci = tid; ci < nk; ci += 256) {
-        const int i = c_idx[ci];                                  // (only this thread ever rewrites entry ci)
-        const double ai1 = c_ax[ci], ai2 = c_ay[ci], dmi = c_dm[ci];
+    int G = 1;
+    while (G < 64 && 2 * G * nk <= 256) G *= 2;
+    const int g = tid & (G - 1);
+    for (int base = 0; base < nk; base += 256 / G) {                 // (more than one trip only if nk > 256)
+        const int ci = base + tid / G;
+        const bool valid = ci < nk;
+        const int i = valid ? c_idx[ci] : -1;                         // (entry ci is rewritten only below, by this group)
+        const double ai1 = valid ? c_ax[ci] : 1.0, ai2 = valid ? c_ay[ci] : 0.0, dmi = valid ? c_dm[ci] : 0.0;
         PolyClip w = {-HUGE_VAL, HUGE_VAL, false};
-        for (int cj = 0; cj < nk && !w.kill && w.hi - w.lo > POLY_TOL_EDGE; cj++) {
-            int j = c_idx[cj];
-            j = j < 0 ? ~j : j;
-            if (j != i) poly_clip(w, ai1, ai2, dmi, i, c_ax[cj], c_ay[cj], c_dm[cj], j);
+        if (valid)
+            for (int cj = g; cj < nk; cj += G) {
+                int j = c_idx[cj];
+                j = j < 0 ? ~j : j;
+                if (cj != ci) poly_clip(w, ai1, ai2, dmi, i, c_ax[cj], c_ay[cj], c_dm[cj], j);
+            }
+        int kill = w.kill ? 1 : 0;
+        for (int m = 1; m < G; m <<= 1) {
+            const double hi = __shfl_xor(w.hi, m, 64), lo = __shfl_xor(w.lo, m, 64);
+            w.hi = hi < w.hi ? hi : w.hi; w.lo = lo > w.lo ? lo : w.lo; kill |= __shfl_xor(kill, m, 64);
         }
-        if (!w.kill && w.hi - w.lo > POLY_TOL_EDGE) atomicAdd(&s_ne, 1);
-        else c_idx[ci] = ~i;
+        if (valid && g == 0) {
+            if (!kill && w.hi - w.lo > POLY_TOL_EDGE) atomicAdd(&s_ne, 1);
+            else c_idx[ci] = ~i;
+        }
     }
     __syncthreads();
     // ---- rows: an edge's row is its rank by (margin, sample index)
@@ -398,6 +400,23 @@ __global__ __launch_bounds__(256) void tmpc_scenario_halfspaces_kernel(Dims d, i
         }
     }
     if (tid < n_rows && tid >= s_ne) { p[ip_slk(d, tid, 0)] = 1.0; p[ip_slk(d, tid, 1)] = 0.0; p[ip_slk(d, tid, 2)] = state_x[sc] + 100.0; which[tid] = -1; }
+}
+
+
+// The candidate list (`cap` entries of dynamic LDS) is what bounds the workgroups per CU, and the filter leaves ~100 candidates of 2048
+// samples: the first pass (one workgroup per unit) runs with a short list (POLY_LIST_CAP) and records the rare unit whose candidates do
+// not fit (overflow[0] = their number, overflow[1..] = the units); the second pass, a few workgroups with room for every sample, redoes
+// only those.
+__global__ __launch_bounds__(256, 4) void tmpc_scenario_halfspaces_kernel(Dims d, int B, const double *x0, double *params,
+                                                                       const double *samples, int n_pts, int n_rows,
+                                                                       const int *scene_of, const double *state_x,
+                                                                       double radius, double disc_offset, int *row_sample, int cap, int *overflow, int second_pass)
+{
+    const int n_units = second_pass ? overflow[0] : B * d.N;
+    for (int q = blockIdx.x; q < n_units; q += gridDim.x) {      // (first pass: one unit per workgroup)
+        poly_stage(second_pass ? overflow[1 + q] : q, d, B, x0, params, samples, n_pts, n_rows, scene_of, state_x, radius, disc_offset, row_sample, cap, overflow);
+        __syncthreads();                                          // (the LDS tables are reused by the next unit)
+    }
 }
 
 

@@ -1126,21 +1126,31 @@ int tmpc_scenario_halfspaces(tmpc_handle *h, const void *d_samples, int32_t n_pt
         return TMPC_ERR_INVALID;
     }
     TMPC_HIP_CHECK(h, hipSetDevice(h->device));
-    const size_t lds = (size_t)n_pts * (3 * sizeof(double) + sizeof(int));          // normals, margins, candidate list
-    if (lds > 150 * 1024) { h->err = "tmpc_scenario_halfspaces: more than 5485 samples per stage do not fit the workgroup's LDS"; return TMPC_ERR_INVALID; }
-    const size_t need = (size_t)h->B * h->d.N * n_rows;
+    const size_t per_entry = 3 * sizeof(double) + sizeof(int);                        // a candidate: normal, margin, index word
+    if ((size_t)n_pts * per_entry > 150 * 1024) { h->err = "tmpc_scenario_halfspaces: more than 5485 samples per stage do not fit a workgroup's LDS"; return TMPC_ERR_INVALID; }
+    const size_t units = (size_t)h->B * h->d.N;
+    const size_t need = units * n_rows + 1 + units;                 // rows' samples, then the first pass's overflow list (count, units)
     if (need > h->scn_cap) {
         if (h->scn_sample) { TMPC_HIP_CHECK(h, hipStreamSynchronize(h->stream)); (void)hipFree(h->scn_sample); h->scn_sample = nullptr; h->scn_cap = 0; }
         TMPC_HIP_CHECK(h, hipMalloc(&h->scn_sample, need * sizeof(int)));
         h->scn_cap = need;
     }
     h->scn_rows = n_rows; h->scn_B = h->B;
-    if (lds > 48 * 1024)
-        TMPC_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(tmpc::tmpc_scenario_halfspaces_kernel),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(tmpc::tmpc_scenario_halfspaces_kernel, dim3(h->B * h->d.N), dim3(256), lds, h->stream, h->d, h->B, h->x0,
-                       const_cast<double *>(h->params), (const double *)d_samples, n_pts, n_rows, (const int *)d_scene_of,
-                       (const double *)d_state_x, radius, disc_offset, h->scn_sample);
+    // first pass with a short candidate list (more workgroups per CU); second pass, with room for every sample, only for the
+    // units the first pass recorded as not fitting
+    int *overflow = h->scn_sample + units * n_rows;
+    TMPC_HIP_CHECK(h, hipMemsetAsync(overflow, 0, sizeof(int), h->stream));
+    const int cap1 = n_pts < tmpc::POLY_LIST_CAP ? n_pts : tmpc::POLY_LIST_CAP;
+    for (int pass = 0; pass < (cap1 < n_pts ? 2 : 1); pass++) {
+        const int cap = pass == 0 ? cap1 : n_pts;
+        const size_t lds = (size_t)cap * per_entry;
+        if (lds > 48 * 1024)
+            TMPC_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(tmpc::tmpc_scenario_halfspaces_kernel),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(tmpc::tmpc_scenario_halfspaces_kernel, dim3(pass == 0 ? units : (units < 512 ? units : 512)), dim3(256), lds, h->stream, h->d, h->B, h->x0,
+                           const_cast<double *>(h->params), (const double *)d_samples, n_pts, n_rows, (const int *)d_scene_of,
+                           (const double *)d_state_x, radius, disc_offset, h->scn_sample, cap, overflow, pass);
+    }
     TMPC_HIP_CHECK(h, hipGetLastError());
     return TMPC_OK;
 }

@@ -547,11 +547,12 @@ def test_optimize_scenarios_with_device_rows_and_support_bound():
     s.close()
 
 
-@pytest.mark.parametrize("shape", ["ragged", "ring", "one_sided", "duplicates", "large", "tiny"])
+@pytest.mark.parametrize("shape", ["ragged", "ring", "big_ring", "one_sided", "duplicates", "large", "tiny"])
 def test_device_polygon_edge_cases(shape):
     """The polygon kernel on sample sets the scenes do not produce: a sample count that is no multiple of the workgroup, more edges
-    than rows (truncation by distance), an unbounded polygon, exact duplicates (lowest index kept), 3000 samples per stage (the
-    dynamic-LDS path above 48 KB), and fewer samples than rows (dummies).  Rows equal the host mirror's bit for bit."""
+    than rows (truncation by distance; with 1500 samples on the ring the candidates overflow the first pass's short list and the
+    second pass redoes the stage), an unbounded polygon, exact duplicates (lowest index kept), 3000 samples per stage, and fewer
+    samples than rows (dummies).  Rows equal the host mirror's bit for bit."""
     import torch
     from mpc_planner_amd import scenes, modules as md
     skw, pkw = SLACK_CFG["cfg5"]
@@ -561,8 +562,8 @@ def test_device_polygon_edge_cases(shape):
     rng = np.random.default_rng(17)
     x0 = sc["x0"].copy()
     p_mid = x0[:, :, 2:4].mean(axis=(0, 1))
-    n = dict(ragged=777, ring=96, one_sided=1024, duplicates=300, large=3000, tiny=5)[shape]
-    if shape == "ring":
+    n = dict(ragged=777, ring=96, big_ring=1500, one_sided=1024, duplicates=300, large=3000, tiny=5)[shape]
+    if shape in ("ring", "big_ring"):
         th = rng.uniform(0, 2 * np.pi, (N, n))
         o = np.stack([np.cos(th), np.sin(th)], axis=-1) * 9.0 + p_mid                  # far: nearly every sample is an edge
     elif shape == "one_sided":
@@ -581,7 +582,7 @@ def test_device_polygon_edge_cases(shape):
         rows = md.scenario_halfspaces(x0[b], o.transpose(1, 0, 2)[None], radius, 24)
         md.halfspace_rows_set_parameters(pm, want[b], sc["xinit"][0, 0], rows, "disc_0_scenario_constraint", 24)
     n_real = [(~np.isnan(md.scenario_halfspaces(x0[0], o.transpose(1, 0, 2)[None], radius, 24)[0][k])).sum() for k in range(1, N)]
-    if shape == "ring":
+    if shape in ("ring", "big_ring"):
         assert max(n_real) == 24                           # truncated
     if shape == "tiny":
         assert max(n_real) <= 5

@@ -31,7 +31,7 @@ for name, kw, dims_kw, per_scene in (
                         success=float((res["exit_code"] == 1).mean()), ipm_per_qp=float(res["qp_iter_total"].sum() / res["sqp_iter"].sum())))
         print(json.dumps(out[-1]), flush=True)
 
-# f-3: scenario -> halfspace reduction kernel (8 obstacles x 256 scenarios per stage), 128 scenes x 32 trajectories
+# f-3: scenario -> polygon kernel (8 obstacles x 256 scenarios per stage), 128 scenes x 32 trajectories
 if len(sys.argv) == 1 or any("f3" in a for a in sys.argv[1:]):
     kw = dict(N=20, M=8, B=32, slack=True, n_scenario=24)
     scs = [scenes.make_scene(500 + i, **kw) for i in range(16)]
@@ -53,7 +53,7 @@ if len(sys.argv) == 1 or any("f3" in a for a in sys.argv[1:]):
     for it in range(20):
         s.scenario_halfspaces(t_s.data_ptr(), smp.shape[2], 24, t_sc.data_ptr(), t_sx.data_ptr(), 0.725)
     s.synchronize(); ms = (time.perf_counter() - t0) / 20 * 1e3
-    pts = B * 19 * smp.shape[2]                                   # samples classified per launch (two passes each)
-    print(json.dumps(dict(shape="f-3 scenario->halfspace reduction", B=B, kernel_ms=ms, samples_per_launch=pts,
+    pts = B * 19 * smp.shape[2]                                   # sampled positions turned into halfspaces per launch
+    print(json.dumps(dict(shape="f-3 scenario->polygon", B=B, kernel_ms=ms, samples_per_launch=pts,
                           algorithmic_GBps=pts * 16 / (ms * 1e-3) / 1e9, unique_sample_bytes=int(smp.nbytes))), flush=True)
     s.close()
