@@ -197,11 +197,11 @@ def polygon_edges(ax, ay, dm):
     """Which of the halfspaces  a_i . (q - p) <= dm_i  (unit normals a_i = (ax, ay), margins dm_i measured from the point p they
     were linearised around) form the boundary of their intersection polygon: halfspace i is an edge iff the piece of its boundary
     line inside all other halfspaces has positive length (every other halfspace is redundant -- removing it changes nothing).
-    The steps tmpc_scenario_halfspaces_kernel runs with the same per-pair arithmetic:
-      filter rounds (sector resolution POLY_BINS): the closest halfspace of each direction sector is a seed (lowest index on
-         ties); a halfspace whose boundary line misses the seeds' polygon cannot touch the (smaller) polygon of all -- the rest
-         stay candidates,
-      the edge test above among the candidates of the last round.
+    A filter comes first -- free to be anything conservative, since a halfspace whose boundary line misses the polygon of SOME of
+    the halfspaces (the seeds) cannot touch the smaller polygon of all, and dropping it changes neither the polygon nor its edges:
+    here three rounds at sector resolution POLY_BINS, the closest halfspace of each direction sector a seed (lowest index on ties),
+    every seed clipping; tmpc_scenario_halfspaces_kernel filters differently (neighbouring seeds only, no division).  Then the edge
+    test above among the candidates, which the kernel runs with the same per-pair arithmetic -- the rows are equal bit for bit.
     Returns a bool array."""
     n = len(dm)
     cand = np.arange(n)
