@@ -101,7 +101,7 @@ __device__ bool riccati_factor(const Lds &L, const Dims &d, int tid, int sw = 0)
         if (rowl && lane >= NU) {
             double *Ln = L.Hh + (k + 1) * NP28 + FB_P;
 #pragma unroll
-            for (int l = 0; l < NX; l++) if (l <= i5) Ln[i5 * (i5 + 1) / 2 + l] = f[NU + l];
+            for (int l = 0; l < NX; l++) *(l <= i5 ? Ln + i5 * (i5 + 1) / 2 + l : L.scr + 56 + l) = f[NU + l];   // (entries above the diagonal go to a dummy slot: a select on the address instead of five masked stores)
         }
         // G = Lp^T [B A] (5 x 7).  Own column densely from ba[]; all columns (wave-uniform) from the sparse [B A]:
         //   x: e0   y: e1   s: e4   psi: (Xp,Yp,1,0,0)   v: (Xv,Yv,0,1,dt)   a: (Xa,Ya,0,dt,dt^2/2)   w: (Xw,Yw,dt,0,0)
@@ -149,7 +149,7 @@ __device__ bool riccati_factor(const Lds &L, const Dims &d, int tid, int sw = 0)
             }
             f[ZA] = a0; f[ZW] = a1; f[ZX] = a2; f[ZY] = a3; f[ZPSI] = a4; f[ZV] = a5; f[ZS] = a6;
         }
-        if (k > 0) load_stage(k - 1);                 // operands of the next stage, hidden under the Cholesky
+        load_stage(k > 0 ? k - 1 : 0);                // operands of the next stage, hidden under the Cholesky (unconditional, clamped: a branch here costs a second register set)
         double r0 = 0.0, r1 = 0.0;
         bad |= chol_rows<0>(f, lane, &r0, &r1);
         if (rowl) {
