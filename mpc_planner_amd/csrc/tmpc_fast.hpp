@@ -147,7 +147,7 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
             ROW_C(s)
             const double r0 = c0s * vx + c1s * vy + c2s * vp + CU(s) * L.v[kk * NV + VAR(s)] - sb[s];
             t[s] = r0 > d.thr0 ? r0 : d.thr0;
-            if constexpr (!LEAN) invt_[s] = 1.0 / t[s];
+            if constexpr (!LEAN) invt_[s] = rcp_nr(t[s]);
             lam[s] = (act >> s & 1) ? d.mu0 / t[s] : 0.0;
             qt[s] = 0.0;
         }
@@ -262,7 +262,10 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
             return a ? ddot + rds : 0.0;
         };
         double dt_[DIET ? 1 : RPL];                      // row steps (stored unless DIET)
-        double amax = 1e300;
+        // Step lengths: alpha_max = min over rows of -t/dt (dt < 0) and -lam/dl (dl < 0) is taken as 1 / max of the reciprocal
+        // ratios -dt (1/t) and -dl/lam: 1/t is at hand, and in the predictor dl = -lam (1 + dt/t), so -dl/lam = 1 + dt/t --
+        // no division per row (there were four IEEE divisions per row and iteration), one per lane after the reduction.
+        double gmax = 0.0;
         double mu_aff = 0.0;
         double a_aff;
         {
@@ -273,11 +276,11 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
                 const bool a = act >> s & 1;
                 const double dt = row_dt(s, dx, dy, dp, vx, vy, vp);
                 if constexpr (!DIET) dt_[DIET ? 0 : s] = dt;
-                const double dl = a ? -lam[s] - lam[s] * INVT(s) * dt : 0.0;
-                if (dt < 0.0) amax = fmin(amax, -t[s] / dt);
-                if (dl < 0.0) amax = fmin(amax, -lam[s] / dl);
+                const double q = dt * INVT(s);
+                gmax = fmax(gmax, a ? fmax(-q, 1.0 + q) : 0.0);
             }
-            a_aff = fmin(1.0, blk_min<NTH>(amax, L.scr, tl, 5));
+            gmax = blk_max<NTH>(gmax, L.scr, tl, 5);
+            a_aff = gmax > 1.0 ? 1.0 / gmax : 1.0;          // min(1, alpha_max)
 #pragma unroll
             for (int s = 0; s < RPL; s++)
                 if (act >> s & 1) {
@@ -314,7 +317,7 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
         pf.stop(PH_RHS);
         riccati_solve<NTH>(L, d, tl, 1 - sw);
         pf.stop(PH_SOLVE);
-        amax = 1e300;
+        gmax = 0.0;
         const double dxc = L.dv[kk * NV + ZX], dyc = L.dv[kk * NV + ZY], dpc = L.dv[kk * NV + ZPSI];
         const double vxc = L.v[kk * NV + ZX], vyc = L.v[kk * NV + ZY], vpc = L.v[kk * NV + ZPSI];
 #pragma unroll
@@ -322,11 +325,12 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
             const bool a = act >> s & 1;
             const double dt = row_dt(s, dxc, dyc, dpc, vxc, vyc, vpc);
             if constexpr (!DIET) dt_[DIET ? 0 : s] = dt;
-            const double dl = a ? -qt[s] - lam[s] * INVT(s) * dt : 0.0;
-            if (dt < 0.0) amax = fmin(amax, -t[s] / dt);
-            if (dl < 0.0) amax = fmin(amax, -lam[s] / dl);
+            const double it_ = INVT(s);
+            const double dl = -qt[s] - lam[s] * it_ * dt;
+            gmax = fmax(gmax, a ? fmax(-dt * it_, -dl * rcp_nr(lam[s])) : 0.0);
         }
-        const double alpha = fmin(1.0, 0.999 * blk_min<NTH>(amax, L.scr, tl, 7));
+        gmax = blk_max<NTH>(gmax, L.scr, tl, 7);
+        const double alpha = 0.999 > gmax ? 1.0 : 0.999 / gmax;        // min(1, 0.999 alpha_max)
         pf.stop(PH_ROWS);
         if (!isfinite(alpha)) { status = 4; break; }
         if (alpha < 1e-12) { status = 3; break; }
@@ -336,7 +340,7 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
                 const double dt = DIET ? row_dt(s, dxc, dyc, dpc, vxc, vyc, vpc) : dt_[DIET ? 0 : s];
                 const double dl = -qt[s] - lam[s] * INVT(s) * dt;
                 t[s] += alpha * dt; lam[s] += alpha * dl;
-                if constexpr (!LEAN) invt_[s] = 1.0 / t[s];
+                if constexpr (!LEAN) invt_[s] = rcp_nr(t[s]);
             }
         }
         __syncthreads();                                 // the rows read v / dv above; v changes below
