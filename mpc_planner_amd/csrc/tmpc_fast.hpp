@@ -50,13 +50,12 @@ __device__ __forceinline__ Lds carve_fast(double *s, const Dims &d)
     return L;
 }
 
-// 1/x: v_rcp_f64 seed + two Newton steps
+// 1/x: v_rcp_f64 seed + one third-order step (e = 1 - x y; y (1 + e + e^2): error of order e^3, three dependent operations)
 __device__ __forceinline__ double rcp_nr(double x)
 {
-    double y = __builtin_amdgcn_rcp(x);
-    y = y * (2.0 - x * y);
-    y = y * (2.0 - x * y);
-    return y;
+    const double y = __builtin_amdgcn_rcp(x);
+    const double e = fma(-x, y, 1.0);
+    return fma(y, fma(e, e, e), y);
 }
 
 __device__ __forceinline__ void lds_add(double *p, double v) { atomicAdd(p, v); }   // ds_add_f64
