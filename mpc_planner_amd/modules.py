@@ -224,7 +224,9 @@ def scenario_halfspaces(x0, samples, radius, n_rows=24, return_index=False):
     p -- the linearisation LinearizedConstraints uses too, linearized_constraints.cpp:84-105 --, the free region of the stage is
     their intersection polygon, and only the halfspaces that form its boundary are constraints of the optimisation).  Exact here:
     `polygon_edges` keeps precisely the non-redundant halfspaces; if the polygon has more than n_rows edges (the solver's capacity)
-    the n_rows closest to p are kept (lowest sample index on ties), unused slots stay dummies.
+    the n_rows closest to p are kept (lowest sample index on ties), unused slots stay dummies.  If the halfspaces contradict each
+    other (the guess sits in the overlap of inflated discs on opposite sides: an empty polygon) there is no edge and every slot is a
+    dummy -- the stage is then unconstrained by the scenarios, which is what the definition gives, not a repair.
     x0 [N+1][nv]; samples [M][S_cen][N][2] (index k-1 for stage k).  Returns a1, a2, b [N][n_rows] with NaN = dummy; rows in order of
     increasing distance.  return_index: also the flat sample index m * S_cen + s behind each row ([N][n_rows], -1 = dummy)."""
     N = x0.shape[0] - 1

@@ -150,3 +150,31 @@ def test_scenario_support_counts_distinct_active_scenarios():
     xtraj[:, 5] = 0.05                                            # a positive slack relaxes every row by 5 cm
     assert md.scenario_support(xtraj, params, pm, which, S_cen) == (0, 0)
     assert md.scenario_support(xtraj, params, pm, which, S_cen, tol=0.06) == (2, 2 * (N - 2) + 1)
+
+
+def test_random_geometries_against_the_definition():
+    """200 seeded sample sets of mixed shape (3 ... 400 samples; clouds, lines of samples, samples on both sides, guesses close to a
+    cloud): the filtered edge set equals the unpruned definition, and the kept rows are sorted by margin."""
+    rng = np.random.default_rng(2024)
+    n_nonempty = 0
+    for case in range(200):
+        n = int(rng.integers(3, 400))
+        kind = case % 4
+        if kind == 0:
+            o = P + rng.normal(0, rng.uniform(1.0, 6.0), (n, 2))
+        elif kind == 1:                                             # samples along a line (a wall of predictions)
+            t = rng.uniform(-6, 6, n)
+            th = rng.uniform(0, np.pi)
+            o = P + np.array([3.0 * np.cos(th + 1.3), 3.0 * np.sin(th + 1.3)]) + np.outer(t, [np.cos(th), np.sin(th)]) + rng.normal(0, 0.02, (n, 2))
+        elif kind == 2:                                             # two clouds on opposite sides
+            o = P + np.where(rng.random((n, 1)) < 0.5, 1.0, -1.0) * np.array([4.0, 0.5]) + rng.normal(0, 0.8, (n, 2))
+        else:                                                       # a cloud the guess almost touches
+            o = P + np.array([1.2, 0.0]) + rng.normal(0, 0.3, (n, 2))
+        o = o[np.linalg.norm(o - P, axis=1) > 0.05]
+        if len(o) < 2:
+            continue
+        ax, ay, dm, _ = _halfspaces(o)
+        e = md.polygon_edges(ax, ay, dm)
+        assert np.array_equal(e, _brute(ax, ay, dm)), case
+        n_nonempty += bool(e.any())
+    assert n_nonempty >= 150          # (a guess inside overlapping discs on opposite sides has an EMPTY polygon: no edge, all rows dummies)
