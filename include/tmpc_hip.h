@@ -221,6 +221,8 @@ int tmpc_scenario_halfspaces(tmpc_handle *h, const void *d_samples, int32_t n_pt
  * collision-probability certificate holds while the support stays within the bound the sample size was chosen for -- see
  * mpc_planner_amd/modules.py::scenario_risk / scenario_sample_size).  Scenario of sample i = i % n_scenarios (samples are
  * [obstacle][scenario]); n_scenarios <= 8192.
+ * Valid only while the batch's scenario rows are the ones tmpc_scenario_halfspaces wrote (a later tmpc_set_batch* invalidates
+ * the bookkeeping: TMPC_ERR_INVALID).
  *   d_support     : i32 [B] out    distinct active scenarios
  *   d_active_rows : i32 [B] out or NULL    active rows */
 int tmpc_scenario_support(tmpc_handle *h, int32_t n_scenarios, double tol, void *d_support, void *d_active_rows);

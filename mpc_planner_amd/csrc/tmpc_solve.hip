@@ -908,6 +908,7 @@ int tmpc_set_batch(tmpc_handle *h, int32_t B, const double *xinit, const double 
     TMPC_HIP_CHECK(h, hipMemcpyAsync(h->o_x0, x0, (size_t)B * (N + 1) * tmpc::ext_nv(h->d) * 8, hipMemcpyHostToDevice, h->stream));
     TMPC_HIP_CHECK(h, hipMemcpyAsync(h->o_params, params, (size_t)B * N * h->d.npar * 8, hipMemcpyHostToDevice, h->stream));
     h->xinit = h->o_xinit; h->x0 = h->o_x0; h->params = h->o_params; h->B = B;
+    h->scn_B = 0;                      // new parameter rows: the scenario-row bookkeeping of the previous batch no longer describes them
     return TMPC_OK;
 }
 
@@ -915,6 +916,7 @@ int tmpc_set_batch_device(tmpc_handle *h, int32_t B, const void *d_xinit, const 
 {
     if (!h || B <= 0 || B > h->B_max || !d_xinit || !d_x0 || !d_params) { if (h) h->err = "tmpc_set_batch_device: bad argument"; return TMPC_ERR_INVALID; }
     h->xinit = (const double *)d_xinit; h->x0 = (const double *)d_x0; h->params = (const double *)d_params; h->B = B;
+    h->scn_B = 0;
     return TMPC_OK;
 }
 
@@ -1162,7 +1164,7 @@ int tmpc_scenario_support(tmpc_handle *h, int32_t n_scenarios, double tol, void 
         return TMPC_ERR_INVALID;
     }
     if (!h->scn_sample || h->scn_B != h->B || h->B <= 0 || !h->params) {
-        h->err = "tmpc_scenario_support: no tmpc_scenario_halfspaces on the current batch";
+        h->err = "tmpc_scenario_support: the scenario rows of the current batch were not built by tmpc_scenario_halfspaces (call it after tmpc_set_batch)";
         return TMPC_ERR_INVALID;
     }
     TMPC_HIP_CHECK(h, hipSetDevice(h->device));

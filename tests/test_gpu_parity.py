@@ -504,8 +504,8 @@ def test_device_scenario_halfspaces_match_host_mirror():
     assert sup.max() >= 1 and (rows >= sup).all()
     s.set_batch(xinit, x0, want); s.solve(); b = s.get()
     assert (a["exit_code"] == b["exit_code"]).all() and np.array_equal(a["xtraj"], b["xtraj"])
-    with pytest.raises(Exception):                     # a batch of another size: the previous batch's bookkeeping does not apply
-        s.set_batch(xinit[:8], x0[:8], want[:8]); s.scenario_support(S_cen)
+    with pytest.raises(Exception):                     # rows set from the host: the bookkeeping of the device-built rows does not apply
+        s.scenario_support(S_cen)
     s.close()
 
 
