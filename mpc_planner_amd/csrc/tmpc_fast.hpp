@@ -50,6 +50,44 @@ __device__ __forceinline__ Lds carve_fast(double *s, const Dims &d)
     return L;
 }
 
+// Compact layout (two trajectories' waves per SIMD, eight trajectories per CU: <= 20 KB of LDS and <= 256 registers each).
+// LDS keeps only what an interior-point iteration touches at LDS rates: the sparse [B A] table, the packed row Jacobians, the
+// QP iterate and the Riccati work arrays.  The NLP-level data -- iterate z, multipliers pi and the stage blocks W, g, b, written
+// once per RTI iteration and read once per interior-point iteration -- live in a per-workgroup workspace in global memory
+// (one slot per RESIDENT workgroup: ~9 KB x 8 per CU, L2-resident).  L.pr aliases L.dpi (tmpc_riccati.hpp).
+__host__ __device__ inline int lds_doubles_compact(int N, int n_pair, int nh)
+{
+    const int dstride = 2 * n_pair + 3 * (nh - n_pair);
+    const int persistent = N * 8 + BA_NCONST + N * dstride + 3;
+    const int work = (N + 1) * NV + (N + 1) * NX + (N + 1) * NP28 + 2 * (N + 1) * NV + N * NX + (N + 1) * NV + (N + 1) * NX + N * NU + 8;
+    const int staging = 2 * N * nh;
+    return persistent + (work > staging ? work : staging);
+}
+
+__device__ __forceinline__ Lds carve_compact(double *s, double *ws, const Dims &d)
+{
+    Lds L;
+    const int N = d.N;
+    L.nh = d.n_up + d.M;
+    L.NG = N * L.nh; L.GB = L.NG; L.XB = L.NG + 4 * N; L.nrows = L.XB + 10 * (N - 1);
+    L.n_pair = d.n_lin; L.dstride = 2 * d.n_lin + 3 * (L.nh - d.n_lin);
+    auto take = [&](int n) { double *p = s; s += n; return p; };
+    auto takeg = [&](int n) { double *p = ws; ws += n; return p; };
+    L.z = takeg((N + 1) * NV); L.pi = takeg((N + 1) * NX); L.W = takeg((N + 1) * NP28); L.g = takeg((N + 1) * NV);
+    L.b = takeg((N + 1) * NX);
+    L.BA = nullptr; L.dyn8 = nullptr;
+    L.tab = take(N * 8 + BA_NCONST);
+    L.D = take(N * L.dstride + 3);                      // (+ one zero triple for box rows / the third entry of topology rows)
+    double *w = s;
+    L.v = take((N + 1) * NV); L.pq = take((N + 1) * NX); L.Hh = take((N + 1) * NP28);
+    L.rg = take((N + 1) * NV); L.gh = take((N + 1) * NV); L.rb = take(N * NX); L.dv = take((N + 1) * NV);
+    L.dpi = take((N + 1) * NX); L.pr = L.dpi; L.y = take(N * NU); L.scr = take(8);
+    s = w;
+    L.beta = take(N * L.nh); L.lamh = take(N * L.nh);
+    L.t = L.lam = L.invt = L.qt = L.rdiag = nullptr;
+    return L;
+}
+
 // 1/x: v_rcp_f64 seed + one third-order step (e = 1 - x y; y (1 + e + e^2): error of order e^3, three dependent operations)
 __device__ __forceinline__ double rcp_nr(double x)
 {
@@ -60,16 +98,21 @@ __device__ __forceinline__ double rcp_nr(double x)
 
 __device__ __forceinline__ void lds_add(double *p, double v) { atomicAdd(p, v); }   // ds_add_f64
 
-template <int NLIN, int MM, int LPS, int NTH, typename PF>
-__device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, int *iters_out, PF &pf,
+template <int NLIN, int MM, int LPS, int NTH, bool CP, typename PF>
+__device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, int *iters_out, PF &pf,
                         double (&lam)[FastCfg<NLIN, MM, LPS>::RPL])
 {
     constexpr int NT = NTH;                         // threads per trajectory: 64 (one wave) or 128 (two waves; N > 21)
     using C = FastCfg<NLIN, MM, LPS>;
     constexpr int RPL = C::RPL;
+#ifdef TMPC_EXP_FASTDIET                            // experiment: the register diet in the fast-layout kernels too (A/B of the diet alone)
+    constexpr bool OCC2 = true;
+#else
+    constexpr bool OCC2 = CP;                       // compact instantiations are built for two waves per SIMD (<= 256 registers)
+#endif
     // compile-time constants for the tuned shapes, kernel arguments for runtime-shape instantiations
     const int NH = C::RT ? L.nh : C::NH, NR = NH + 14, NLIN_ = C::RT ? d.n_up : NLIN;
-    constexpr bool DIET = LPS == 6 && NLIN == 8;                 // 256-register budget (two waves per SIMD): recompute per-row values instead of storing them
+    constexpr bool DIET = (LPS == 6 && NLIN == 8) || OCC2;                // 256-register budget (two waves per SIMD): recompute per-row values instead of storing them
     const int N = d.N;
     // Opaque copy of the lane id: keeps the compiler from hoisting this QP's per-row setup (masks, LDS addresses) out of
     // the RTI loop of the caller, where it would stay live across the register-hungry linearisation and be spilled.
@@ -79,9 +122,14 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
     // come from one wave in lane order -- results do not depend on how the two waves happen to interleave
     constexpr int SPW = 64 / LPS;                   // stages per wave
     const int wl = tid_q & 63;
-    const int k = (tid_q >> 6) * SPW + wl / LPS, c = wl % LPS;
-    const bool stage_lane = wl < SPW * LPS && k < N;
-    const int kk = stage_lane ? k : 0;
+    int k = (tid_q >> 6) * SPW + wl / LPS, c = wl % LPS;
+    int sl_ = (wl < SPW * LPS && k < N) ? 1 : 0;
+    int kk = sl_ ? k : 0;
+    // Two-waves-per-SIMD instantiations (256 registers): the lane's indices are made opaque again before every row pass, so that
+    // the passes' per-row invariants (LDS addresses, sign constants) are recomputed there instead of being hoisted out of the
+    // interior-point loop and kept live -- ~7 registers per row otherwise.
+#define ROW_PASS_BEGIN() do { if constexpr (OCC2) asm volatile("" : "+v"(k), "+v"(c), "+v"(kk), "+v"(sl_), "+v"(act), "+v"(box), "+v"(upper), "+v"(neg), "+v"(varpack)); } while (0)
+#define stage_lane (sl_ != 0)
     const double m_rows = (double)(N * NH + 4 * N + 10 * (N - 1));
 
     // ---- load this lane's rows (signed coefficients) from the staging area into registers ----
@@ -121,10 +169,19 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
     // row's Jacobian triple in L.D (box rows and idle lanes: the zero triple behind the last row); recomputed, not stored
     auto DIDX = [&](int s) {
         if constexpr (!DIET) return didx_[DIET ? 0 : s];
-        const int r = c + LPS * s; return (stage_lane && r < NH) ? (k * NH + r) * 3 : N * NH * 3;
+        const int r = c + LPS * s;
+        if constexpr (CP) return (stage_lane && r < NH) ? k * L.dstride + (r < L.n_pair ? 2 * r : 3 * r - L.n_pair) : N * L.dstride;
+        return (stage_lane && r < NH) ? (k * NH + r) * 3 : N * NH * 3;
+    };
+    // third entry of the row's Jacobian: packed rows (topology) have none -- they read the 0.0 of the zero triple, so that the
+    // row's arithmetic (sg * 0.0 included) is that of the unpacked layout
+    auto DIDX2 = [&](int s) {
+        const int r = c + LPS * s;
+        if constexpr (CP) return (stage_lane && r < NH && r >= L.n_pair) ? DIDX(s) + 2 : N * L.dstride + 2;
+        return DIDX(s) + 2;
     };
 #define ROW_C(s) const double sg_ = (neg >> (s) & 1) ? -1.0 : 1.0; const double *Dr_ = L.D + DIDX(s); \
-    const double c0s = sg_ * Dr_[0], c1s = sg_ * Dr_[1], c2s = sg_ * Dr_[2];
+    const double c0s = sg_ * Dr_[0], c1s = sg_ * Dr_[1], c2s = sg_ * L.D[DIDX2(s)];
 #define INVT(s) (LEAN ? rcp_nr(t[s]) : invt_[(LEAN ? 0 : (s))])
     auto CU = [&](int s) { return (box >> s & 1) ? ((upper >> s & 1) ? -1.0 : 1.0) : 0.0; };   // signed unit coefficient
     __syncthreads();                                             // staging is dead from here on
@@ -135,8 +192,9 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
     if (tid_q < NX) L.v[NU + tid_q] = xi[tid_q] - L.z[NU + tid_q];
     __syncthreads();
 
+    ROW_PASS_BEGIN();
     double t[RPL], qt[RPL];
-    constexpr bool LEAN = RPL > 10 || (LPS == 6 && NLIN == 8);     // recompute 1/t instead of keeping it: many rows per lane, or the 256-register
+    constexpr bool LEAN = RPL > 10 || (LPS == 6 && NLIN == 8) || OCC2;    // recompute 1/t instead of keeping it: many rows per lane, or the 256-register
                                                     // budget of the two-waves-per-SIMD instantiations
     double invt_[LEAN ? 1 : RPL];               // the row residual r_d = c.v - sb - t is recomputed where needed
     {
@@ -157,19 +215,39 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
         int tl = tid;                                    // per-iteration opaque lane id: per-lane addresses of the item loops and
         asm volatile("" : "+v"(tl));                   // sweeps are recomputed, not kept live (and spilled) across the whole solve
         // ---- stage parts of the residuals: rg0 = g + W v + [B A]^T pi_{k+1} - [0; pi_k];  rb;  Hh <- W ----
+        if constexpr (CP) {
+            // Hh <- W from the global workspace, all loads in flight before the first store;
+            // the residual below then reads W from Hh
+            constexpr int WR = (21 * NP28 + NT - 1) / NT;            // N <= 20 (21 nodes) for these instantiations
+            const int tot = (N + 1) * NP28;
+            double wv[WR];
+#pragma unroll
+            for (int j = 0; j < WR; j++) { const int e = tl + NT * j; wv[j] = L.W[e < tot ? e : tot - 1]; }
+#pragma unroll
+            for (int j = 0; j < WR; j++) {
+                const int e = tl + NT * j;
+                if (e < tot) L.Hh[e] = wv[j];
+            }
+            __syncthreads();
+        }
         for (int e = tl; e < (N + 1) * NV; e += NT) {
             const int ks = e / NV, i = e - ks * NV;
             double acc = 0.0;
             const bool skip = (ks == N && i < NU) || (ks == 0 && i >= NU);
             if (!skip) {
                 acc = L.g[e];
-                const double *Wk = L.W + ks * NP28; const double *vk = L.v + ks * NV;
+                const double *Wk = (CP ? L.Hh : L.W) + ks * NP28; const double *vk = L.v + ks * NV;
 #pragma unroll
                 for (int j = 0; j < NV; j++) acc += Wk[sidx(i, j)] * vk[j];
                 if (ks < N) {
-                    const double *BA = L.BA + ks * NX * NV;
+                    if constexpr (CP) {
 #pragma unroll
-                    for (int l = 0; l < NX; l++) acc += BA[l * NV + i] * L.pq[(ks + 1) * NX + l];
+                        for (int l = 0; l < NX; l++) acc += L.tab[ba_off(N, ks, l, i)] * L.pq[(ks + 1) * NX + l];
+                    } else {
+                        const double *BA = L.BA + ks * NX * NV;
+#pragma unroll
+                        for (int l = 0; l < NX; l++) acc += BA[l * NV + i] * L.pq[(ks + 1) * NX + l];
+                    }
                 }
                 if (i >= NU && ks >= 1) acc -= L.pq[ks * NX + i - NU];
             }
@@ -179,17 +257,24 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
         for (int e = tl; e < N * NX; e += NT) {
             const int ks = e / NX, i = e - ks * NX;
             double acc = L.b[e] - L.v[(ks + 1) * NV + NU + i];
-            const double *BA = L.BA + ks * NX * NV + i * NV; const double *vk = L.v + ks * NV;
+            const double *vk = L.v + ks * NV;
+            if constexpr (CP) {
 #pragma unroll
-            for (int j = 0; j < NV; j++) acc += BA[j] * vk[j];
+                for (int j = 0; j < NV; j++) acc += L.tab[ba_off(N, ks, i, j)] * vk[j];
+            } else {
+                const double *BA = L.BA + ks * NX * NV + i * NV;
+#pragma unroll
+                for (int j = 0; j < NV; j++) acc += BA[j] * vk[j];
+            }
             L.rb[e] = acc;
             res_b = fmax(res_b, fabs(acc));
         }
-        for (int e = tl; e < (N + 1) * NP28; e += NT) L.Hh[e] = L.W[e];
+        if constexpr (!CP) for (int e = tl; e < (N + 1) * NP28; e += NT) L.Hh[e] = L.W[e];
         __syncthreads();
         pf.stop(PH_HH);                                   // (profile: stage-vector part of the residuals)
         // ---- row pass R (registers): residuals, rg -= lam c, Hh += d c c^T, gh += d rd c ----
         double res_d = 0.0, res_m = 0.0, mu = 0.0;
+        ROW_PASS_BEGIN();
         {
             const double vx = L.v[kk * NV + ZX], vy = L.v[kk * NV + ZY], vp = L.v[kk * NV + ZPSI];
             double gs0 = 0, gs1 = 0, gs2 = 0, rs0 = 0, rs1 = 0, rs2 = 0;
@@ -243,11 +328,11 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
         // two-wave variant: the sweeping wave alternates with the iteration (and differs between neighbouring trajectories),
         // so that co-resident trajectories seldom run the same sweep on the same SIMD
         const int sw = NTH == 128 ? ((it + (int)(blockIdx.x >> 8)) & 1) : 0;
-        const bool fbad = riccati_factor<NTH>(L, d, tl, sw);
+        const bool fbad = riccati_factor<NTH, CP>(L, d, tl, sw);
         pf.stop(PH_FACTOR);
         if (fbad) { status = 4; break; }
         // ---- predictor: rhs = rg + sum c (lam + d rd)  (q/t = lam) ----
-        riccati_solve<NTH>(L, d, tl, 1 - sw);
+        riccati_solve<NTH, CP>(L, d, tl, 1 - sw);
         pf.stop(PH_SOLVE);
         // Row step dt = c.dv + r_d is recomputed from the direction in LDS wherever it is needed (no per-row storage:
         // the register budget decides how many waves a SIMD holds)
@@ -267,6 +352,7 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
         double gmax = 0.0;
         double mu_aff = 0.0;
         double a_aff;
+        ROW_PASS_BEGIN();
         {
             const double dx = L.dv[kk * NV + ZX], dy = L.dv[kk * NV + ZY], dp = L.dv[kk * NV + ZPSI];
             const double vx = L.v[kk * NV + ZX], vy = L.v[kk * NV + ZY], vp = L.v[kk * NV + ZPSI];
@@ -280,6 +366,7 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
             }
             gmax = blk_max<NTH>(gmax, L.scr, tl, 5);
             a_aff = gmax > 1.0 ? 1.0 / gmax : 1.0;          // min(1, alpha_max)
+            ROW_PASS_BEGIN();
 #pragma unroll
             for (int s = 0; s < RPL; s++)
                 if (act >> s & 1) {
@@ -294,6 +381,7 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
         // ---- corrector rhs: gh = rg + sum c (qt + d rd) ----
         for (int e = tl; e < (N + 1) * NV; e += NT) L.gh[e] = L.rg[e];
         __syncthreads();
+        ROW_PASS_BEGIN();
         {
             double cs0 = 0, cs1 = 0, cs2 = 0;
             const double dx = L.dv[kk * NV + ZX], dy = L.dv[kk * NV + ZY], dp = L.dv[kk * NV + ZPSI];   // predictor direction
@@ -314,9 +402,10 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
         }
         __syncthreads();
         pf.stop(PH_RHS);
-        riccati_solve<NTH>(L, d, tl, 1 - sw);
+        riccati_solve<NTH, CP>(L, d, tl, 1 - sw);
         pf.stop(PH_SOLVE);
         gmax = 0.0;
+        ROW_PASS_BEGIN();
         const double dxc = L.dv[kk * NV + ZX], dyc = L.dv[kk * NV + ZY], dpc = L.dv[kk * NV + ZPSI];
         const double vxc = L.v[kk * NV + ZX], vyc = L.v[kk * NV + ZY], vpc = L.v[kk * NV + ZPSI];
 #pragma unroll
@@ -333,6 +422,7 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
         pf.stop(PH_ROWS);
         if (!isfinite(alpha)) { status = 4; break; }
         if (alpha < 1e-12) { status = 3; break; }
+        ROW_PASS_BEGIN();
 #pragma unroll
         for (int s = 0; s < RPL; s++) {
             if (act >> s & 1) {
@@ -350,6 +440,8 @@ __device__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, 
     }
     *iters_out = iters;
     return status;
+#undef stage_lane
+#undef ROW_PASS_BEGIN
 }
 
 // Two-wave instantiations with 6 lanes per stage are built for two waves per SIMD (<= 256 registers): four trajectories
@@ -403,7 +495,7 @@ void tmpc_solve_fast_kernel(Dims d, int B, const double *__restrict__ xinit,
         __syncthreads();
         pf.stop(PH_LIN);
         int iters = 0;
-        qp_status = ipm_fast<NLIN, MM, LPS, NTH>(L, d, tid, xi, &iters, pf, lam);
+        qp_status = ipm_fast<NLIN, MM, LPS, NTH, false>(L, d, tid, xi, &iters, pf, lam);
         sqp_iter = it + 1; qp_iter_total += iters;
         if (qp_status != 0 && qp_status != 2) { status = 4; break; }
         status = 0;
@@ -440,6 +532,104 @@ void tmpc_solve_fast_kernel(Dims d, int B, const double *__restrict__ xinit,
     }
     solve_epilogue(L, d, tid, b, xi, pb, slack_of(), status, qp_status, sqp_iter, qp_iter_total, xtraj, utraj, pobj, exit_code,
                    qp_status_out, sqp_iter_out, res_eq_out, qp_iter_out, prof_out, pf, t_begin, NTH);
+}
+
+// ---- compact kernel: eight trajectories per CU ---------------------------------------------------------------------------
+// Same algorithm and arithmetic as tmpc_solve_fast_kernel (results are bitwise identical), laid out for two waves per SIMD:
+// <= 256 registers (per-row values recomputed, lane indices re-made opaque per row pass) and <= 20 KB of LDS per trajectory
+// (carve_compact).  Persistent workgroups: the launch has at most as many workgroups as the GPU holds resident, each takes
+// trajectories from a ticket counter; the global NLP workspace is indexed by WORKGROUP, so it stays as small as the resident
+// set (L2-resident) whatever the batch size.
+template <int NLIN, int MM, int LPS, bool PROF = false>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void tmpc_solve_compact_kernel(Dims d, int B, const double *__restrict__ xinit,
+                               const double *__restrict__ x0, const double *__restrict__ params,
+                               double *__restrict__ xtraj, double *__restrict__ utraj,
+                               double *__restrict__ pobj, int *__restrict__ exit_code,
+                               int *__restrict__ qp_status_out, int *__restrict__ sqp_iter_out,
+                               double *__restrict__ res_eq_out, int *__restrict__ qp_iter_out,
+                               long long *__restrict__ prof_out, StateIO io)
+{
+    using C = FastCfg<NLIN, MM, LPS>;
+    constexpr int NT = 64;
+    const int NHk = C::RT ? d.n_up + d.M : C::NH, NLINk = C::RT ? d.n_up : NLIN;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int tid0 = threadIdx.x;
+    const int N = d.N;
+    int tid = tid0;
+    const Lds L = carve_compact(smem, io.ws + (size_t)blockIdx.x * ws_doubles(N), d);
+    ba_tab_init(L.tab, d, tid);
+    if (tid < 3) L.D[N * L.dstride + tid] = 0.0;        // zero triple read by box rows (and as the third entry of packed rows)
+    __syncthreads();
+    for (;;) {
+        int b = 0;
+        if (tid == 0) b = atomicAdd(io.ticket, 1);
+        b = __builtin_amdgcn_readfirstlane(b);
+        if (b >= B) break;
+        asm volatile("" : "+v"(tid));                   // opaque per trajectory: per-lane addresses are recomputed, not kept live (and spilled) across solves
+        if ((io.flags & ST_KEEP_ITERATE) && io.stopped[b]) continue;      // this solver's loop has ended: outputs of its last call stand
+        const double *xi = xinit + (size_t)b * ext_nx(d);
+        const double *pb = params + (size_t)b * N * d.npar;
+        auto slack_of = [&]() { return d.slack ? __builtin_nontemporal_load(xi + NX) : 0.0; };
+
+        for (int e = tid; e < (N + 1) * NV; e += NT) {
+            const int k = e / NV, i = e - k * NV;
+            L.z[e] = (io.flags & ST_KEEP_ITERATE) ? io.z[(size_t)b * (N + 1) * NV + e] : x0[((size_t)b * (N + 1) + k) * ext_nv(d) + i];
+        }
+        for (int e = tid; e < (N + 1) * NX; e += NT) L.pi[e] = (io.flags & ST_KEEP_MULTIPLIERS) ? io.pi[(size_t)b * (N + 1) * NX + e] : 0.0;
+        for (int e = tid; e < N * NHk; e += NT) L.lamh[e] = (io.flags & ST_KEEP_MULTIPLIERS) ? io.lamh[(size_t)b * N * NHk + e] : 0.0;
+        __syncthreads();
+        if (tid < NU) L.z[N * NV + tid] = 0.0;
+        __syncthreads();
+
+        typename std::conditional<PROF, Prof, NoProf>::type pf;
+        pf.init(prof_out);
+        const long long t_begin = (PROF && prof_out) ? clock64() : 0;
+        int status = 0, qp_status = 0, sqp_iter = 0, qp_iter_total = 0;
+        double lam[C::RPL];
+        for (int it = 0; it < d.n_sqp; it++) {
+            pf.start();
+            linearise<true, true>(L, d, tid, pb, slack_of());
+            __syncthreads();
+            pf.stop(PH_LIN);
+            int iters = 0;
+            qp_status = ipm_fast<NLIN, MM, LPS, 64, true>(L, d, tid, xi, &iters, pf, lam);
+            sqp_iter = it + 1; qp_iter_total += iters;
+            if (qp_status != 0 && qp_status != 2) { status = 4; break; }
+            status = 0;
+            __syncthreads();
+            int tid_w = tid;
+            asm volatile("" : "+v"(tid_w));
+            for (int e = tid_w; e < (N + 1) * NV; e += NT) {
+                const int ks = e / NV, i = e - ks * NV;
+                if (!(ks == N && i < NU)) L.z[e] += L.v[e];
+            }
+            for (int e = tid_w; e < N * NX; e += NT) L.pi[NX + e] = L.pq[NX + e];
+            __syncthreads();
+            constexpr int SPW = 64 / LPS;
+            const int wl = tid_w & 63;
+            const int k = wl / LPS, c = wl % LPS;
+            if (wl < SPW * LPS && k < N) {
+#pragma unroll
+                for (int s = 0; s < C::RPL; s++) {
+                    const int r = c + LPS * s;
+                    if (r < NHk) L.lamh[k * NHk + r] = (r < NLINk) ? lam[s] : -lam[s];
+                }
+            }
+            __syncthreads();
+            if (qp_status != 0) break;
+        }
+        asm volatile("" : "+v"(tid));
+        if (io.flags & ST_STORE) {
+            for (int e = tid; e < (N + 1) * NV; e += NT) io.z[(size_t)b * (N + 1) * NV + e] = L.z[e];
+            for (int e = tid; e < (N + 1) * NX; e += NT) io.pi[(size_t)b * (N + 1) * NX + e] = L.pi[e];
+            for (int e = tid; e < N * NHk; e += NT) io.lamh[(size_t)b * N * NHk + e] = L.lamh[e];
+            if (tid == 0 && sqp_iter > 0) io.stopped[b] = qp_status != 0;
+        }
+        solve_epilogue(L, d, tid, b, xi, pb, slack_of(), status, qp_status, sqp_iter, qp_iter_total, xtraj, utraj, pobj, exit_code,
+                       qp_status_out, sqp_iter_out, res_eq_out, qp_iter_out, prof_out, pf, t_begin, 64);
+        __syncthreads();                                // the next trajectory reuses LDS and the workspace
+    }
 }
 
 }  // namespace tmpc

@@ -53,16 +53,36 @@ __device__ __forceinline__ bool chol_rows(double (&f)[NV], int lane, double *r0,
 // (tmpc_stage.hpp dyn_jacobian); the rest is identity / dt / dt^2/2.
 enum { D8_XA = 0, D8_XW, D8_XP, D8_XV, D8_YA, D8_YW, D8_YP, D8_YV };
 
+// Compact layout (no dense [B A] in LDS): a lane's column / row of [B A] through the table `tab` (ba_off, tmpc_solve.hip).
+// Column j: entries 0, 1 are stage-dependent for j in {a, w, psi, v} (offset o + 8 k) and constants otherwise (stride 0); entries
+// 2..4 are constants for every column.  Row i (state index) in dyn8 column order (a, w, psi, v): stage-dependent for x, y.
+struct BaLane { int o0, o1, st; };
+__device__ __forceinline__ BaLane ba_column(int N, int j)
+{
+    BaLane c;
+    c.o0 = ba_off(N, 0, 0, j); c.o1 = ba_off(N, 0, 1, j);
+    c.st = c.o0 < 8 ? 8 : 0;
+    return c;
+}
+__device__ __forceinline__ BaLane ba_row4(int N, int i5)          // o0: base of (b_a, b_w, a_psi, a_v) of row i5
+{
+    BaLane c;
+    c.o0 = i5 < 2 ? 4 * i5 : N * 8 + 4 + 4 * (i5 - 2); c.o1 = 0;
+    c.st = i5 < 2 ? 8 : 0;
+    return c;
+}
+
 // The sweeps below are strictly sequential over stages; to keep LDS latency off the critical path every
 // operand of stage k-1 is (re)loaded into the same registers right after its last use in stage k, so the loads
 // complete underneath the dependent Cholesky / readlane chain of stage k.
 // NTH = threads per trajectory: 64, or 128 for the two-wave variant, in which the sweeps run on wave 0 alone (wave 1
 // waits at the closing barrier) and only the stage-parallel loops use all threads.
 // `sw`: which of the two waves sweeps (two-wave variant); the other one waits at the closing barrier.
-template <int NTH>
-__device__ bool riccati_factor(const Lds &L, const Dims &d, int tid, int sw = 0)
+template <int NTH, bool CP = false>
+__device__ __forceinline__ bool riccati_factor(const Lds &L, const Dims &d, int tid, int sw = 0)
 {
     const int N = d.N;
+    asm volatile("" : "+v"(tid));                    // opaque per call: lane-derived addresses are not shared with (kept live until) other phases
     bool anybad = false;
     SWEEP_T0(); SWEEP_COUNT(SP_CALLS_FACTOR);
     if (NTH == 64 || (tid >> 6) == sw) {
@@ -73,16 +93,27 @@ __device__ bool riccati_factor(const Lds &L, const Dims &d, int tid, int sw = 0)
     const double dt = d.dt, hdt2 = d.hdt2;
     bool bad = false;
     double f[NV], hk[NV], ba[NX], dn[8];
+    const BaLane bc = ba_column(N, ls);
+    if constexpr (CP) {                                  // constant entries of the own column of [B A]
+#pragma unroll
+        for (int m = 2; m < NX; m++) ba[m] = L.tab[ba_off(N, 0, m, ls)];
+    }
     auto load_stage = [&](int k) {
         const double *Hk = L.Hh + k * NP28;
-        const double *BA = L.BA + k * NX * NV;
         // unconditional loads (clamped indices): entries above the diagonal / of idle lanes are never used
 #pragma unroll
         for (int j = 0; j < NV; j++) hk[j] = Hk[pidx(ls, j <= ls ? j : ls)];
+        if constexpr (CP) {
+            ba[0] = L.tab[bc.o0 + k * bc.st]; ba[1] = L.tab[bc.o1 + k * bc.st];
 #pragma unroll
-        for (int m = 0; m < NX; m++) ba[m] = BA[m * NV + ls];
+            for (int q = 0; q < 8; q++) dn[q] = L.tab[k * 8 + q];
+        } else {
+            const double *BA = L.BA + k * NX * NV;
 #pragma unroll
-        for (int q = 0; q < 8; q++) dn[q] = L.dyn8[k * 8 + q];
+            for (int m = 0; m < NX; m++) ba[m] = BA[m * NV + ls];
+#pragma unroll
+            for (int q = 0; q < 8; q++) dn[q] = L.dyn8[k * 8 + q];
+        }
     };
     // terminal node: Cholesky of the xx-block (rows/cols 2..6)
 #pragma unroll
@@ -101,7 +132,7 @@ __device__ bool riccati_factor(const Lds &L, const Dims &d, int tid, int sw = 0)
         if (rowl && lane >= NU) {
             double *Ln = L.Hh + (k + 1) * NP28 + FB_P;
 #pragma unroll
-            for (int l = 0; l < NX; l++) *(l <= i5 ? Ln + i5 * (i5 + 1) / 2 + l : L.scr + 56 + l) = f[NU + l];   // (entries above the diagonal go to a dummy slot: a select on the address instead of five masked stores)
+            for (int l = 0; l < NX; l++) *(l <= i5 ? Ln + i5 * (i5 + 1) / 2 + l : L.scr + (CP ? 0 : 56) + l) = f[NU + l];   // (entries above the diagonal go to a dummy slot: a select on the address instead of five masked stores)
         }
         // G = Lp^T [B A] (5 x 7).  Own column densely from ba[]; all columns (wave-uniform) from the sparse [B A]:
         //   x: e0   y: e1   s: e4   psi: (Xp,Yp,1,0,0)   v: (Xv,Yv,0,1,dt)   a: (Xa,Ya,0,dt,dt^2/2)   w: (Xw,Yw,dt,0,0)
@@ -169,10 +200,11 @@ __device__ bool riccati_factor(const Lds &L, const Dims &d, int tid, int sw = 0)
 
 // ---- square-root Riccati: vector solve (backward + forward), rhs gh / rb -> dv, dpi ------------------
 // Lane j (< 7) = component j of the stage vector [u; x]; the cost-to-go gradient p lives in lanes 2..6.
-template <int NTH>
-__device__ void riccati_solve(const Lds &L, const Dims &d, int tid, int sw = 1)
+template <int NTH, bool CP = false>
+__device__ __forceinline__ void riccati_solve(const Lds &L, const Dims &d, int tid, int sw = 1)
 {
     const int N = d.N;
+    asm volatile("" : "+v"(tid));                    // opaque per call (see riccati_factor): the two solves of an iteration do not share address registers
     // two-wave variant: the vector sweeps run on the wave that did not factorise, so that with two trajectories' waves
     // sharing a SIMD pair the sequential work is spread over both SIMDs
     const bool sweeper = NTH == 64 || (tid >> 6) == sw;
@@ -210,18 +242,32 @@ __device__ void riccati_solve(const Lds &L, const Dims &d, int tid, int sw = 1)
     SWEEP_T(SP_SOLVE_PRE);
     if (sweeper) {
     double p = L.gh[N * NV + ls];                       // p_N (lanes 2..6 meaningful)
-    if (xl) L.pr[N * NX + i5] = p;
     {
         // Two operand sets, filled alternately two stages ahead: a set is (re)loaded right after the stage that used it, so
         // its LDS latency passes underneath the other set's stage (with a single set the loads were issued at the end of
         // stage k and awaited at the top of stage k-1: ~120 exposed cycles per stage).
+        // Compact layout: L.pr aliases L.dpi -- p_k takes the slot of q_{k-1} = (P rb)_{k-1}, which stage k - 1's operand load
+        // (always issued before stage k runs: the sets are filled at least one stage ahead, and LDS operations of a wave
+        // execute in order) has fetched by then; the closing loop adds P dx in place.
         struct Ops { double ghj, ba[NX], r0, l10, r1, lx0, lx1, q; };
+        const BaLane bc = ba_column(N, ls);
+        double bac[NX];
+        if constexpr (CP) {
+#pragma unroll
+            for (int m = 2; m < NX; m++) bac[m] = L.tab[ba_off(N, 0, m, ls)];
+        }
         auto load_stage = [&](Ops &o, int k) {
             const double *Fb = L.Hh + k * NP28;
-            const double *BA = L.BA + k * NX * NV;
             o.ghj = L.gh[k * NV + ls];
+            if constexpr (CP) {
+                o.ba[0] = L.tab[bc.o0 + k * bc.st]; o.ba[1] = L.tab[bc.o1 + k * bc.st];
 #pragma unroll
-            for (int l = 0; l < NX; l++) o.ba[l] = BA[l * NV + ls];
+                for (int l = 2; l < NX; l++) o.ba[l] = bac[l];
+            } else {
+                const double *BA = L.BA + k * NX * NV;
+#pragma unroll
+                for (int l = 0; l < NX; l++) o.ba[l] = BA[l * NV + ls];
+            }
             o.r0 = Fb[FB_R0]; o.l10 = Fb[FB_L10]; o.r1 = Fb[FB_R1];
             o.lx0 = Fb[FB_LXU + 2 * i5]; o.lx1 = Fb[FB_LXU + 2 * i5 + 1];
             o.q = L.dpi[(k + 1) * NX + i5];
@@ -239,6 +285,7 @@ __device__ void riccati_solve(const Lds &L, const Dims &d, int tid, int sw = 1)
         };
         Ops oa, ob;
         load_stage(oa, N - 1);
+        if (xl) L.pr[N * NX + i5] = p;                                    // (after the load of q_{N-1}: same slot when aliased)
         int k = N - 1;
         for (; k >= 1; k -= 2) {
             load_stage(ob, k - 1);
@@ -258,14 +305,21 @@ __device__ void riccati_solve(const Lds &L, const Dims &d, int tid, int sw = 1)
         struct Ops { double lx0, lx1, y0, y1, r0, l10, r1, a_psi, a_v, b_a, b_w, rbi; };
         const double i_psi = lane == ZPSI ? 1.0 : 0.0, i_v = lane == ZV ? 1.0 : 0.0;
         double *dv_own = L.dv + (rowl ? lane : 0);
+        const BaLane br = ba_row4(N, i5);
         auto load_stage = [&](Ops &o, int k) {
             const double *Fb = L.Hh + k * NP28;
-            const double *BAr = L.BA + k * NX * NV + i5 * NV;              // own row of [B A]
             o.lx0 = Fb[FB_LXU + 2 * i5]; o.lx1 = Fb[FB_LXU + 2 * i5 + 1];
             o.y0 = L.y[k * NU]; o.y1 = L.y[k * NU + 1];
             o.r0 = Fb[FB_R0]; o.l10 = Fb[FB_L10]; o.r1 = Fb[FB_R1];
-            o.a_psi = BAr[ZPSI]; o.a_v = BAr[ZV];                          // loads only: arithmetic here would wait for them
-            o.b_a = BAr[ZA]; o.b_w = BAr[ZW];
+            if constexpr (CP) {
+                const double *Tr = L.tab + br.o0 + k * br.st;              // own row of [B A] as (b_a, b_w, a_psi, a_v)
+                o.a_psi = Tr[2]; o.a_v = Tr[3];
+                o.b_a = Tr[0]; o.b_w = Tr[1];
+            } else {
+                const double *BAr = L.BA + k * NX * NV + i5 * NV;          // own row of [B A]
+                o.a_psi = BAr[ZPSI]; o.a_v = BAr[ZV];                      // loads only: arithmetic here would wait for them
+                o.b_a = BAr[ZA]; o.b_w = BAr[ZW];
+            }
             o.rbi = L.rb[k * NX + i5];
         };
         auto stage = [&](const Ops &o, int k) {

@@ -51,6 +51,10 @@ struct StateIO {
     double *lamh;       // [B][N nh]      (lam_upper - lam_lower) of the general rows, kernel row order [topology | slack | ellipsoids]
     int *stopped;       // [B]            1: this slot's RTI loop has ended (a QP stopped with qp_status != 0, :105-106)
     int flags;
+    // compact kernels only (tmpc_fast.hpp): per-workgroup NLP workspace in global memory (L2-resident: one slot per RESIDENT
+    // workgroup, not per trajectory) and the work ticket of the persistent launch
+    double *ws;         // [grid][ws_doubles(N)]
+    int *ticket;        // next trajectory to solve (zeroed before the launch)
 };
 
 // ---- per-trajectory LDS layout (doubles) ----------------------------------------------------
@@ -61,7 +65,54 @@ struct Lds {
     double *dyn8;                                        // 8 non-constant entries of [B A] per stage
     double *lamh;                                        // fast kernel: staged (lam_upper - lam_lower) of the general rows
     int nh, NG, GB, XB, nrows;
+    // compact layout (tmpc_fast.hpp, carve_compact): z, pi, W, g, b point into the GLOBAL workspace; [B A] is not stored -- `tab` holds the 8 non-constant entries per stage
+    // followed by 16 constants (ba_tab below); the rows' Jacobians are packed (pairs for topology rows, triples otherwise)
+    double *tab;
+    int n_pair, dstride;                                 // rows r < n_pair store (gx, gy) only; doubles per stage in D
 };
+
+// ---- sparse [B A] (compact kernels) ------------------------------------------------------------------------------
+// For the unicycle [B A] (5 x 7) has 8 stage-dependent entries (dyn8, tmpc_riccati.hpp) and constants 0, 1, dt, dt^2/2.  `tab` =
+// dyn8[N][8] followed by 16 constants; an entry is addressed by a 4-bit code: 0..7 = dyn8 entry of the stage, 8..11 = 0, 1, dt,
+// dt^2/2.  The remaining 12 constants are rows psi, v, s of [B A] in dyn8 column order (a, w, psi, v) for the forward sweep.
+// Reading [B A] through the table returns exactly the values the dense copy held (zeros and ones included), so every sum that
+// runs over a row or column of [B A] keeps its operation order: results are bitwise those of the dense layout.
+constexpr int BAC_0 = 8, BAC_1 = 9, BAC_DT = 10, BAC_H = 11, BA_NCONST = 16;
+constexpr unsigned ba_pack(int a, int w, int x, int y, int p, int v, int s_)
+{
+    return (unsigned)a | (unsigned)w << 4 | (unsigned)x << 8 | (unsigned)y << 12 | (unsigned)p << 16 | (unsigned)v << 20 | (unsigned)s_ << 24;
+}
+// row m of [B A]: codes of its 7 columns (a, w, x, y, psi, v, s)
+__device__ __forceinline__ constexpr unsigned ba_rowcode(int m)
+{
+    return m == 0 ? ba_pack(0, 1, BAC_1, BAC_0, 2, 3, BAC_0)
+         : m == 1 ? ba_pack(4, 5, BAC_0, BAC_1, 6, 7, BAC_0)
+         : m == 2 ? ba_pack(BAC_0, BAC_DT, BAC_0, BAC_0, BAC_1, BAC_0, BAC_0)
+         : m == 3 ? ba_pack(BAC_DT, BAC_0, BAC_0, BAC_0, BAC_0, BAC_1, BAC_0)
+                  : ba_pack(BAC_H, BAC_0, BAC_0, BAC_0, BAC_0, BAC_DT, BAC_1);
+}
+// offset (doubles) of entry (m, j) of stage k in `tab`
+__device__ __forceinline__ int ba_off(int N, int k, int m, int j)
+{
+    const unsigned rc = m == 0 ? ba_rowcode(0) : m == 1 ? ba_rowcode(1) : m == 2 ? ba_rowcode(2) : m == 3 ? ba_rowcode(3) : ba_rowcode(4);
+    const int code = (int)((rc >> (4 * j)) & 15u);
+    return code < 8 ? k * 8 + code : N * 8 + code - 8;
+}
+__device__ __forceinline__ void ba_tab_init(double *tab, const Dims &d, int tid)
+{
+    if (tid < BA_NCONST) {
+        const double dt = d.dt, h = d.hdt2;
+        //                          0    1    dt  h  | psi: a  w   psi  v  | v: a   w    psi  v  | s: a  w    psi  v
+        const double c[BA_NCONST] = {0.0, 1.0, dt, h,   0.0, dt, 1.0, 0.0,   dt, 0.0, 0.0, 1.0,   h, 0.0, 0.0, dt};
+        double val = 0.0;
+#pragma unroll
+        for (int i = 0; i < BA_NCONST; i++) if (i == tid) val = c[i];
+        tab[d.N * 8 + tid] = val;
+    }
+}
+// doubles of one workgroup's global workspace
+__host__ __device__ inline int ws_doubles(int N) { return (N + 1) * NV + (N + 1) * NX + (N + 1) * NP28 + (N + 1) * NV + (N + 1) * NX; }
+
 
 __host__ __device__ inline int lds_doubles(int N, int nh)
 {
@@ -476,8 +527,8 @@ __device__ int ipm_solve(const Lds &L, const Dims &d, int tid, int *iters_out, P
 }
 
 // ---- stage linearisation by lane k --------------------------------------------------------------
-template <bool FAST>
-__device__ void linearise(const Lds &L, const Dims &d, int tid, const double *params, double slack)
+template <bool FAST, bool CP = false>
+__device__ __forceinline__ void linearise(const Lds &L, const Dims &d, int tid, const double *params, double slack)
 {
     const int N = d.N;
     // Every lane runs the (register-hungry) stage evaluation with the full EXEC mask -- lanes >= N redo stage N-1 and
@@ -500,8 +551,15 @@ __device__ void linearise(const Lds &L, const Dims &d, int tid, const double *pa
         };
         auto sink = [&](int r, const RowOut &ro) {
             if (owner) {
-                double *Dr = L.D + (k * nh + r) * 3;
-                Dr[0] = ro.gx; Dr[1] = ro.gy; Dr[2] = ro.gp;
+                if constexpr (CP) {
+                    // packed Jacobians: (gx, gy) for topology rows (gp == 0 exactly, lin_row_eval), triples for the others
+                    double *Dr = L.D + k * L.dstride + (r < L.n_pair ? 2 * r : 3 * r - L.n_pair);
+                    Dr[0] = ro.gx; Dr[1] = ro.gy;
+                    if (r >= L.n_pair) Dr[2] = ro.gp;
+                } else {
+                    double *Dr = L.D + (k * nh + r) * 3;
+                    Dr[0] = ro.gx; Dr[1] = ro.gy; Dr[2] = ro.gp;
+                }
                 const double bound = (r < d.n_up) ? 0.0 : 1.0;
                 L.beta[k * nh + r] = bound - ro.h;
             }
@@ -509,36 +567,44 @@ __device__ void linearise(const Lds &L, const Dims &d, int tid, const double *pa
         stage_linearise(d, z, p, 1, L.pi[(k + 1) * NX + 0], L.pi[(k + 1) * NX + 1], lamh, sink, W, g, BA, xn, slack,
                         L.W + k * NP28);                    // (generated solvers park the cost Hessian in the stage's W slot)
         // everything but W leaves the registers BEFORE the register-hungry MIRROR
+        // compact layout: g, b, W live in the global workspace (same [stage][entry] layout: a lane's stores of one array share
+        // one address register and differ in the immediate offset); [B A] is kept as its 8 non-constant entries only
+        constexpr int es = 1;
+        const int gk = k * NV, bk = k * NX, wk = k * NP28;
         if (owner) {
 #pragma unroll
-            for (int i = 0; i < NV; i++) L.g[k * NV + i] = g[i];
+            for (int i = 0; i < NV; i++) L.g[gk + i * es] = g[i];
+            if constexpr (!CP) {
 #pragma unroll
-            for (int i = 0; i < NX * NV; i++) L.BA[k * NX * NV + i] = BA[i];
-            double *d8 = L.dyn8 + k * 8;
+                for (int i = 0; i < NX * NV; i++) L.BA[k * NX * NV + i] = BA[i];
+            }
+            double *d8 = (CP ? L.tab : L.dyn8) + k * 8;
             d8[D8_XA] = BA[0 * NV + ZA]; d8[D8_XW] = BA[0 * NV + ZW]; d8[D8_XP] = BA[0 * NV + ZPSI]; d8[D8_XV] = BA[0 * NV + ZV];
             d8[D8_YA] = BA[1 * NV + ZA]; d8[D8_YW] = BA[1 * NV + ZW]; d8[D8_YP] = BA[1 * NV + ZPSI]; d8[D8_YV] = BA[1 * NV + ZV];
 #pragma unroll
-            for (int i = 0; i < NX; i++) L.b[k * NX + i] = xn[i] - L.z[(k + 1) * NV + NU + i];
+            for (int i = 0; i < NX; i++) L.b[bk + i * es] = xn[i] - L.z[(k + 1) * NV + NU + i];
         }
         mirror7(W, d.reg_eps);
         if (owner) {
 #pragma unroll
             for (int i = 0; i < NV; i++)
 #pragma unroll
-                for (int j = 0; j <= i; j++) L.W[k * NP28 + pidx(i, j)] = W[i][j];
+                for (int j = 0; j <= i; j++) L.W[wk + pidx(i, j) * es] = W[i][j];
         }
     }
     if (tid == N) {
         // terminal node: zero cost, no rows: MIRROR(0) = eps I on the state block
-        for (int e = 0; e < NP28; e++) L.W[N * NP28 + e] = 0.0;
-        for (int i = NU; i < NV; i++) L.W[N * NP28 + pidx(i, i)] = d.reg_eps;
-        for (int i = 0; i < NV; i++) L.g[N * NV + i] = 0.0;
+        constexpr int es = 1;
+        const int wN = N * NP28, gN = N * NV;
+        for (int e = 0; e < NP28; e++) L.W[wN + e * es] = 0.0;
+        for (int i = NU; i < NV; i++) L.W[wN + pidx(i, i) * es] = d.reg_eps;
+        for (int i = 0; i < NV; i++) L.g[gN + i * es] = 0.0;
     }
 }
 
 // ---- completeOneIteration (acados_solver_interface.cpp:162-204): cost, trajectories, res_eq, exit-code mapping ----
 template <typename PF>
-__device__ void solve_epilogue(const Lds &L, const Dims &d, int tid, int b, const double *xi, const double *pb, double slack, int status,
+__device__ __forceinline__ void solve_epilogue(const Lds &L, const Dims &d, int tid, int b, const double *xi, const double *pb, double slack, int status,
                                int qp_status, int sqp_iter, int qp_iter_total, double *xtraj, double *utraj, double *pobj,
                                int *exit_code, int *qp_status_out, int *sqp_iter_out, double *res_eq_out, int *qp_iter_out,
                                long long *prof_out, PF &pf, long long t_begin, int nth = NT)
@@ -664,6 +730,17 @@ __global__ __launch_bounds__(NT) void tmpc_solve_kernel(Dims d, int B, const dou
 
 }  // namespace tmpc
 #include "tmpc_fast.hpp"
+#ifdef TMPC_SINGLE_COMPACT
+template __global__ void tmpc::tmpc_solve_compact_kernel<TMPC_SINGLE_COMPACT>(tmpc::Dims, int, const double *, const double *, const double *,
+                                                                             double *, double *, double *, int *, int *, int *, double *, int *,
+                                                                             long long *, tmpc::StateIO);
+#elif defined(TMPC_SINGLE_KERNEL)
+// Experiment builds (tools/kernel_probe.sh): one instantiation only, no C-ABI -- seconds instead of minutes per compile when
+// looking at one kernel's registers / ISA.  TMPC_SINGLE_KERNEL = the template argument list, e.g. -DTMPC_SINGLE_KERNEL=8,8,3,64,false
+template __global__ void tmpc::tmpc_solve_fast_kernel<TMPC_SINGLE_KERNEL>(tmpc::Dims, int, const double *, const double *, const double *,
+                                                                          double *, double *, double *, int *, int *, int *, double *, int *,
+                                                                          long long *, tmpc::StateIO);
+#else
 #include "tmpc_aux_kernels.hpp"
 
 // =================================================================================================
@@ -726,6 +803,17 @@ static SolveKernel pick_fast_kernel(const Dims &d, int *threads, bool prof)
     return nullptr;
 #endif
 }
+// Compact variant (tmpc_fast.hpp: tmpc_solve_compact_kernel): two waves per SIMD, eight trajectories per CU, persistent
+// workgroups.  Bitwise the same results as the fast kernel of the shape (tools/ab_compare.py against TMPC_NO_COMPACT=1).
+static SolveKernel pick_compact_kernel(const Dims &d, bool prof)
+{
+#ifndef TMPC_GENERATED_STAGE
+    if (getenv("TMPC_FORCE_GENERIC") || getenv("TMPC_NO_COMPACT") || prof || d.N > 20) return nullptr;
+    if (d.n_up == 8 && d.M == 8) return (SolveKernel)tmpc_solve_compact_kernel<8, 8, 3, false>;
+#endif
+    (void)d; (void)prof;
+    return nullptr;
+}
 // Latency variant (tmpc_set_latency_mode): two waves per trajectory at 6 lanes per stage, built for two waves per SIMD
 // (<= 256 registers, so four trajectories per CU stay resident).  The stage-parallel phases run on twice the lanes:
 // -8 % kernel time on a 64-trajectory control tick; on a saturated GPU the one-wave kernel is as fast or faster, which is
@@ -756,6 +844,11 @@ struct tmpc_handle {
     tmpc::SolveKernel kernel = nullptr;
     int threads = tmpc::NT;          // threads per trajectory (64, or 128 for the two-wave fast variant)
     tmpc::SolveKernel kernel_lat = nullptr;   // optional latency variant (128 threads), used when latency_mode is on
+    size_t lds_bytes_fast = 0;                // LDS of the fast-layout kernels (kernel_lat, the profiled twin) when `kernel` is compact
+    bool compact = false;                     // `kernel` is a compact persistent kernel: grid = resident workgroups, needs ws + ticket
+    int grid_max = 0;                         // resident workgroups of the compact kernel on this device
+    double *ws = nullptr;                     // [grid_max][ws_doubles(N)] per-workgroup NLP workspace
+    int *ticket = nullptr;
     bool latency_mode = false;
     bool throughput_mode = false;             // lane-per-trajectory kernels (tmpc_lanes.hip) instead of one wave per trajectory
     tmpc::lanes::Context *lanes = nullptr;    // their HBM workspace, created when the mode is first enabled
@@ -849,15 +942,28 @@ int tmpc_create(tmpc_handle **out, const tmpc_dims *dims, int32_t B_max, int32_t
     h->fast = h->kernel != nullptr;
     if (h->fast) h->lds_bytes = sizeof(double) * (size_t)tmpc::lds_doubles_fast(d.N, d.n_up + d.M);
     else { h->kernel = tmpc::tmpc_solve_kernel; h->lds_bytes = sizeof(double) * (size_t)tmpc::lds_doubles(d.N, d.n_up + d.M); }
+    h->lds_bytes_fast = h->lds_bytes;
     auto fail = [&](int code) { delete h; return code; };
     if (hipSetDevice(device) != hipSuccess) return fail(TMPC_ERR_HIP);
     if (h->lds_bytes > 160 * 1024) return fail(TMPC_ERR_INVALID);
+    if (h->fast && h->threads == tmpc::NT && (h->kernel_lat = tmpc::pick_latency_kernel(d, false)) != nullptr) {
+        if (hipFuncSetAttribute((const void *)h->kernel_lat, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes_fast) != hipSuccess)
+            h->kernel_lat = nullptr;
+    }
+    if (tmpc::SolveKernel kc = (h->fast && h->threads == tmpc::NT) ? tmpc::pick_compact_kernel(d, false) : nullptr) {
+        h->kernel = kc; h->compact = true;
+        h->lds_bytes = sizeof(double) * (size_t)tmpc::lds_doubles_compact(d.N, d.n_lin, d.n_up + d.M);
+    }
     if (hipFuncSetAttribute((const void *)h->kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)h->lds_bytes) != hipSuccess)
         return fail(TMPC_ERR_NO_DEVICE);
-    if (h->fast && h->threads == tmpc::NT && (h->kernel_lat = tmpc::pick_latency_kernel(d, false)) != nullptr) {
-        if (hipFuncSetAttribute((const void *)h->kernel_lat, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes) != hipSuccess)
-            h->kernel_lat = nullptr;
+    if (h->compact) {
+        int per_cu = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)h->kernel, 64, h->lds_bytes) != hipSuccess || per_cu <= 0 ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0)
+            return fail(TMPC_ERR_HIP);
+        if (const char *e = getenv("TMPC_COMPACT_PER_CU")) { const int v = atoi(e); if (v > 0 && v < per_cu) per_cu = v; }   // experiments
+        h->grid_max = per_cu * cus;
     }
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return fail(TMPC_ERR_HIP);
     const size_t N = d.N, B = B_max;
@@ -877,6 +983,10 @@ int tmpc_create(tmpc_handle **out, const tmpc_dims *dims, int32_t B_max, int32_t
     ok &= hipMalloc(&h->qp_iter, B * 4) == hipSuccess;
     ok &= hipMalloc(&h->d_best, 4) == hipSuccess;
     ok &= hipMalloc(&h->d_disabled, B) == hipSuccess;
+    if (h->compact) {
+        ok &= hipMalloc(&h->ws, (size_t)h->grid_max * tmpc::ws_doubles(d.N) * 8) == hipSuccess;
+        ok &= hipMalloc(&h->ticket, 4) == hipSuccess;
+    }
     if (!ok) { tmpc_destroy(h); return TMPC_ERR_HIP; }
     *out = h;
     return TMPC_OK;
@@ -889,7 +999,7 @@ void tmpc_destroy(tmpc_handle *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void *ptrs[] = {h->o_xinit, h->o_x0, h->o_params, h->xtraj, h->utraj, h->pobj, h->res_eq, h->d_weight,
                     h->exit_code, h->qp_status, h->sqp_iter, h->qp_iter, h->d_best, h->d_disabled,
-                    h->st_z, h->st_pi, h->st_lamh, h->st_stopped, h->scn_sample};
+                    h->st_z, h->st_pi, h->st_lamh, h->st_stopped, h->scn_sample, h->ws, h->ticket};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &e : h->ev) (void)hipEventDestroy(e);
     tmpc::lanes::destroy(h->lanes);
@@ -937,9 +1047,12 @@ static int launch_solve(tmpc_handle *h, int n_iter, int st_flags)
     } else {
         tmpc::Dims dd = h->d;
         dd.n_sqp = n_iter;
-        tmpc::StateIO io{h->st_z, h->st_pi, h->st_lamh, h->st_stopped, st_flags};
+        tmpc::StateIO io{h->st_z, h->st_pi, h->st_lamh, h->st_stopped, st_flags, h->ws, h->ticket};
         const bool lat = h->kernel_lat && h->latency_mode;
-        hipLaunchKernelGGL(lat ? h->kernel_lat : h->kernel, dim3(h->B), dim3(lat ? 128 : h->threads), h->lds_bytes, h->stream, dd, h->B,
+        const bool cp = h->compact && !lat;
+        if (cp) TMPC_HIP_CHECK(h, hipMemsetAsync(h->ticket, 0, 4, h->stream));        // the persistent launch's work counter
+        hipLaunchKernelGGL(lat ? h->kernel_lat : h->kernel, dim3(cp ? (h->B < h->grid_max ? h->B : h->grid_max) : h->B),
+                           dim3(lat ? 128 : h->threads), lat ? h->lds_bytes_fast : h->lds_bytes, h->stream, dd, h->B,
                            h->xinit, h->x0, h->params, h->xtraj, h->utraj, h->pobj, h->exit_code, h->qp_status,
                            h->sqp_iter, h->res_eq, h->qp_iter, (long long *)nullptr, io);
         TMPC_HIP_CHECK(h, hipGetLastError());
@@ -1269,11 +1382,12 @@ int tmpc_debug_profile(tmpc_handle *h, int64_t *cycles, int32_t n_phases)
     if (h->fast) {
         int thr = 0;
         pk = tmpc::pick_fast_kernel(h->d, &thr, true);
-        TMPC_HIP_CHECK(h, hipFuncSetAttribute((const void *)pk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
+        TMPC_HIP_CHECK(h, hipFuncSetAttribute((const void *)pk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes_fast));
     }
-    hipLaunchKernelGGL(pk, dim3(h->B), dim3(h->threads), h->lds_bytes, h->stream, h->d, h->B,
+    // (a compact handle is profiled through the fast kernel of its shape: same phases and arithmetic, one wave per SIMD)
+    hipLaunchKernelGGL(pk, dim3(h->B), dim3(h->threads), h->fast ? h->lds_bytes_fast : h->lds_bytes, h->stream, h->d, h->B,
                        h->xinit, h->x0, h->params, h->xtraj, h->utraj, h->pobj, h->exit_code, h->qp_status,
-                       h->sqp_iter, h->res_eq, h->qp_iter, dp, tmpc::StateIO{nullptr, nullptr, nullptr, nullptr, 0});
+                       h->sqp_iter, h->res_eq, h->qp_iter, dp, tmpc::StateIO{nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr});
     TMPC_HIP_CHECK(h, hipGetLastError());
     TMPC_HIP_CHECK(h, hipStreamSynchronize(h->stream));
     std::vector<long long> host(n);
@@ -1332,3 +1446,4 @@ int tmpc_debug_sweep_profile(tmpc_handle *h, uint64_t *out, int32_t n)
 #endif
 
 }  // extern "C"
+#endif  // TMPC_SINGLE_KERNEL

@@ -12,6 +12,7 @@ def parse(text):
         if not m:
             continue
         body = m.group(1).strip()
+        body = re.sub(r"^\S+:\d+:\d+:\s*", "", body)      # "file:line:col: " prefix (present when the source path is relative)
         if body.startswith("Function Name:"):
             cur = {"name": body.split(":", 1)[1].strip()}
             out.append(cur)
