@@ -31,20 +31,20 @@ template <int C0>
 __device__ __forceinline__ bool chol_rows(double (&f)[NV], int lane, double *r0, double *r1)
 {
     bool bad = false;
-#pragma unroll
-    for (int c = C0; c < NV; c++) {
-        const double dpiv = readlane_d(f[c], c);
+    static_for<C0, NV>([&](auto c_) {
+        constexpr int c = decltype(c_)::value;
+        const double dpiv = bcast16<c>(f[c]);
         if (!(dpiv > 0.0)) bad = true;
         const double y = rsqrt_nr(dpiv);
         f[c] *= y;                                  // lane i >= c: L_ic (i == c: sqrt(d))
         if (c == 0 && r0) *r0 = y;
         if (c == 1 && r1) *r1 = y;
-#pragma unroll
-        for (int j = c + 1; j < NV; j++) {
-            const double ljc = readlane_d(f[c], j);
+        static_for<c + 1, NV>([&](auto j_) {
+            constexpr int j = decltype(j_)::value;
+            const double ljc = bcast16<j>(f[c]);
             f[j] -= f[c] * ljc;                     // lane i >= j: F_ij -= L_ic L_jc
-        }
-    }
+        });
+    });
     (void)lane;                                       // entries above the diagonal are never read
     return bad;
 }
@@ -124,10 +124,11 @@ __device__ __forceinline__ bool riccati_factor(const Lds &L, const Dims &d, int 
     for (int k = N - 1; k >= 0; k--) {
         // broadcast Lp (lower 5x5 of the factor of stage k+1) to every lane
         double Lp[NX][NX];
+        static_for<0, NX>([&](auto m_) {
+            constexpr int m = decltype(m_)::value;
 #pragma unroll
-        for (int m = 0; m < NX; m++)
-#pragma unroll
-            for (int l = 0; l <= m; l++) Lp[m][l] = readlane_d(f[NU + l], NU + m);
+            for (int l = 0; l <= m; l++) Lp[m][l] = bcast16<NU + m>(f[NU + l]);
+        });
         // Lxx of stage k+1 (own row of lanes 2..6) is kept for the vector solves: P_{k+1} = Lxx Lxx^T is never formed
         if (rowl && lane >= NU) {
             double *Ln = L.Hh + (k + 1) * NP28 + FB_P;
@@ -189,7 +190,7 @@ __device__ __forceinline__ bool riccati_factor(const Lds &L, const Dims &d, int 
             if (lane == 1) { Fb[FB_L10] = f[0]; Fb[FB_R0] = r0; Fb[FB_R1] = r1; }
         }
     }
-    anybad = __any(bad);
+    anybad = __any(bad && lane < 16);             // (rows 1..3 of the wave compute on copies: their pivots mean nothing)
     if (NTH > 64 && lane == 0) L.scr[63] = anybad ? 1.0 : 0.0;
     }
     __syncthreads();
@@ -275,10 +276,9 @@ __device__ __forceinline__ void riccati_solve(const Lds &L, const Dims &d, int t
         auto stage = [&](const Ops &o, int k) {
             const double Pb = p + o.q;                                     // (P_{k+1} rb_k + p_{k+1}), lane 2+i
             double fj = o.ghj;
-#pragma unroll
-            for (int l = 0; l < NX; l++) fj += o.ba[l] * readlane_d(Pb, NU + l);
-            const double y0 = readlane_d(fj, 0) * o.r0;
-            const double y1 = (readlane_d(fj, 1) - o.l10 * y0) * o.r1;
+            static_for<0, NX>([&](auto l_) { constexpr int l = decltype(l_)::value; fj += o.ba[l] * bcast16<NU + l>(Pb); });
+            const double y0 = bcast16<0>(fj) * o.r0;
+            const double y1 = (bcast16<1>(fj) - o.l10 * y0) * o.r1;
             p = fj - o.lx0 * y0 - o.lx1 * y1;
             if (lane == 0) { L.y[k * NU] = y0; L.y[k * NU + 1] = y1; }
             if (xl) L.pr[k * NX + i5] = p;
@@ -329,12 +329,12 @@ __device__ __forceinline__ void riccati_solve(const Lds &L, const Dims &d, int t
             q0 += dpp_shift_zero<0x111>(q0); q1 += dpp_shift_zero<0x111>(q1);
             q0 += dpp_shift_zero<0x112>(q0); q1 += dpp_shift_zero<0x112>(q1);
             q0 += dpp_shift_zero<0x114>(q0); q1 += dpp_shift_zero<0x114>(q1);
-            const double s0 = o.y0 + readlane_d(q0, NV - 1), s1 = o.y1 + readlane_d(q1, NV - 1);
+            const double s0 = o.y0 + bcast16<NV - 1>(q0), s1 = o.y1 + bcast16<NV - 1>(q1);
             const double u1 = -s1 * o.r1;
             const double u0 = (-s0 - o.l10 * u1) * o.r0;
             if (lane == 0) { L.dv[k * NV] = u0; L.dv[k * NV + 1] = u1; }
             if (xl) dv_own[k * NV] = dx;
-            const double dpsi = readlane_d(dx, ZPSI), dvv = readlane_d(dx, ZV);
+            const double dpsi = bcast16<ZPSI>(dx), dvv = bcast16<ZV>(dx);
             const double e_psi = o.a_psi - i_psi, e_v = o.a_v - i_v;
             dx = dx + e_psi * dpsi + e_v * dvv + o.b_a * u0 + o.b_w * u1 + o.rbi;   // lanes 2..6 meaningful
         };

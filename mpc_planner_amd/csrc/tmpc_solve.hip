@@ -275,6 +275,27 @@ __device__ __forceinline__ double readlane_d(double x, int src)
     u.i[1] = __builtin_amdgcn_readlane(u.i[1], src);
     return u.d;
 }
+// Broadcast lane LANE of every 16-lane row to the whole row: ONE v_mov_b64_dpp row_newbcast (the only DPP control the f64 ALU
+// supports).  Unlike v_readlane the value stays in a VGPR: no SGPR-pair operand limit on its consumers, no VALU -> SGPR -> VALU
+// hazard waits, and the four rows of a wave stay independent.  The Riccati sweeps use rows of 16 lanes: lanes 0..6 of row 0
+// hold the trajectory, the other rows compute on copies and are ignored.
+#ifdef TMPC_RICCATI_READLANE            // A/B builds only: the round-2 cross-lane path (v_readlane, wave-uniform values)
+template <int LANE> __device__ __forceinline__ double bcast16(double x) { return readlane_d(x, LANE); }
+#else
+template <int LANE>
+__device__ __forceinline__ double bcast16(double x)
+{
+    static_assert(LANE >= 0 && LANE < 16, "row_newbcast lane");
+    const long long r = __builtin_amdgcn_mov_dpp(__builtin_bit_cast(long long, x), 0x150 + LANE, 0xf, 0xf, false);   // (no `old` value to materialise)
+    return __builtin_bit_cast(double, r);
+}
+#endif
+// compile-time loop: f(std::integral_constant<int, I>) for I = A .. B-1 (lane numbers of DPP controls must be immediates)
+template <int A, int B, typename F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (A < B) { f(std::integral_constant<int, A>{}); static_for<A + 1, B>(f); }
+}
 // 1/sqrt(d) for d > 0: v_rsq_f64 seed (5e-8 relative, measured) + one third-order (Halley) step: with e = 1 - d y^2,
 // y (1 + e/2 + 3 e^2/8) leaves an error of order e^3 -- full double precision in five dependent operations, where two Newton steps
 // take eight (this sits on the critical chain of the Cholesky: seven pivots per stage)
