@@ -33,6 +33,8 @@ FP64_VALU_PEAK_TFLOPS = 78.6                    # MI355X FP64 vector peak (AMD s
 WORKLOADS = {
     "cfg2": dict(dims=dict(N=20, S=5, n_lin=8, M=8), scene=dict(N=20, M=8), traj=64, nh=16, npar=135,
                  what="configs[1]: Jackal MPCC N=20, 8 obstacles, 64 T-MPC guidance trajectories per scene"),
+    "cfg3": dict(dims=dict(N=30, S=5, n_lin=8, M=8, n_slk=12, slack=1), scene=dict(N=30, M=8, slack=True, n_decomp=12), traj=512, nh=28, npar=172,
+                 one_set=True, what="configs[2]: slack model + guidance + 8 ellipsoids + 12 decomp rows (rosnavigation T-MPC stack; see DESIGN 3 on 'CA-MPC'), N=30, ONE set of 512 trajectories"),
     "cfg4": dict(dims=dict(N=20, S=5, n_lin=12, M=12), scene=dict(N=20, M=12), traj=4096, nh=24, npar=175, one_set=True,
                  what="configs[3]: T-MPC++ 4096 guidance trajectories, N=20, 12 obstacles, ONE guidance set split over the ranks"),
     "cfg5": dict(dims=dict(N=20, S=5, n_lin=0, M=0, n_slk=24, slack=1), scene=dict(N=20, M=8, slack=True, n_scenario=24), traj=32, nh=24,
@@ -123,6 +125,26 @@ def cpu_baseline(n_scenes):
                       f"process (affinity / cgroup quota; {os.cpu_count()} logical CPUs visible)"}
 
 
+def parity_block(O, wl, batch, res, n_check, opts):
+    """Compare `n_check` trajectories of a launch, spread evenly over the whole batch (first and last scene included), with the CPU oracle."""
+    B = batch["xinit"].shape[0]
+    idx = np.unique(np.linspace(0, B - 1, min(n_check, B)).round().astype(int))
+    n = len(idx)
+    pbo = O.problem(**wl["dims"], **opts)
+    xt, ut, info = O.solve_batch(pbo, batch["xinit"][idx], batch["x0"][idx].reshape(n, -1), batch["params"][idx].reshape(n, -1),
+                                 num_threads=usable_cpus())
+    both = (info["exit_code"] == 1) & (res["exit_code"][idx] == 1)
+    sx = np.maximum(np.abs(xt[both]).max(axis=2, keepdims=True), 1.0)
+    su = np.maximum(np.abs(ut[both]).max(axis=2, keepdims=True), 1.0)
+    return {"trajectories": int(n), "sample": f"every {max(1, (B - 1) // max(1, n - 1))}-th trajectory of the {B} in the timed launch (first and last included)",
+            "parity_max_rel": float(max((np.abs(res["xtraj"][idx][both] - xt[both]) / sx).max(),
+                                        (np.abs(res["utraj"][idx][both] - ut[both]) / su).max())) if both.any() else None,
+            "exit_code_mismatch": int((res["exit_code"][idx] != info["exit_code"]).sum()),
+            "sqp_iter_mismatch": int((res["sqp_iter"][idx] != info["sqp_iter"]).sum()),
+            "ipm_iter_mismatch": int((res["qp_iter_total"][idx][both] != info["qp_iter_total"][both]).sum()),
+            "against": "oracle/ (restated acados-equivalent CPU path), same options"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -133,6 +155,7 @@ def main():
                          "times small (256 scenes: 497k solves/s, 1024: 514k, 2048: 516k on one MI355X)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cfg2")
     ap.add_argument("--no-lanes", action="store_true", help="skip the lane-per-trajectory variant's measurement")
+    ap.add_argument("--no-tight", action="store_true", help="skip the qp_tol = 1e-9 leg")
     ap.add_argument("--gen-workers", type=int, default=0, help="processes that generate the scenes (0 = all usable CPUs; 1 = no fork, e.g. under a profiler)")
     ap.add_argument("--scene-cache", default="", help="npz file to keep the generated batch in (repeated profiler passes)")
     ap.add_argument("--cpu-scenes", type=int, default=16)
@@ -198,6 +221,7 @@ def main():
     sv = solver.BatchedSolver(dims, B_max=B, device=local_rank)
     sv.set_batch_device(B, t_xinit.data_ptr(), t_x0.data_ptr(), t_params.data_ptr())
     sv.enable_timing(a.steps + a.warmup + 4)
+    kernel_info = sv.kernel_info()                        # which solve kernel the handle dispatches (fast / compact / ...), from the library
 
     # The whole step is stream-ordered on the handle's stream: solve -> pack -> (N > 1: the all-gather, issued with that stream as
     # torch's current stream, so RCCL waits for the records and the selection waits for RCCL) -> FindBestPlanner.  No host
@@ -246,22 +270,26 @@ def main():
     if rank == 0 and a.parity_check > 0:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib as O
-        n = min(a.parity_check, B)
-        pbo = O.problem(**wl["dims"])
-        xt, ut, info = O.solve_batch(pbo, batch["xinit"][:n], batch["x0"][:n].reshape(n, -1), batch["params"][:n].reshape(n, -1),
-                                     num_threads=usable_cpus())
-        both = (info["exit_code"] == 1) & (res["exit_code"][:n] == 1)
-        sx = np.maximum(np.abs(xt[both]).max(axis=2, keepdims=True), 1.0)
-        su = np.maximum(np.abs(ut[both]).max(axis=2, keepdims=True), 1.0)
-        parity = {"trajectories": int(n),
-                  "parity_max_rel": float(max((np.abs(res["xtraj"][:n][both] - xt[both]) / sx).max(),
-                                              (np.abs(res["utraj"][:n][both] - ut[both]) / su).max())) if both.any() else None,
-                  "exit_code_mismatch": int((res["exit_code"][:n] != info["exit_code"]).sum()),
-                  "sqp_iter_mismatch": int((res["sqp_iter"][:n] != info["sqp_iter"]).sum()),
-                  "ipm_iter_mismatch": int((res["qp_iter_total"][:n][both] != info["qp_iter_total"][both]).sum()),
-                  "against": "oracle/ (restated acados-equivalent CPU path) on the first trajectories of the timed launch"}
+        parity = parity_block(O, wl, batch, res, a.parity_check, {})
     n_sqp_mean = float(res["sqp_iter"].mean())
     ipm_per_qp = float(res["qp_iter_total"].sum() / max(res["sqp_iter"].sum(), 1))
+
+    # ---- the same launch at qp_tol = 1e-9: the tolerance at which the RTI iterate no longer depends on the QP solver ------
+    # (tests/test_independent_rti.py: oracle <-> exact active-set RTI 2e-7 there, up to 1e-3 at the reference's 1e-5)
+    tight = None
+    if rank == 0 and not a.no_tight and not use_dist:
+        dims9 = solver.default_dims(**wl["dims"], qp_tol=1e-9)
+        s9 = solver.BatchedSolver(dims9, B_max=B, device=local_rank)
+        s9.set_batch_device(B, t_xinit.data_ptr(), t_x0.data_ptr(), t_params.data_ptr())
+        s9.solve(); ms9 = s9.time_solve(3); r9 = s9.get(); s9.close()
+        ok9 = r9["exit_code"] == 1
+        tight = {"qp_tol": 1e-9, "kernel_ms": float(np.median(ms9)), "success_fraction": float(ok9.mean()),
+                 "value": float(B * ok9.mean() / (np.median(ms9) * 1e-3)), "unit": "successful solves/s (kernel time, same resident batch)",
+                 "mean_ipm_iter_per_qp": float(r9["qp_iter_total"].sum() / max(r9["sqp_iter"].sum(), 1))}
+        if a.parity_check > 0:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_lib as O
+            tight["parity"] = parity_block(O, wl, batch, r9, min(a.parity_check, 128), {"qp_tol": 1e-9})
 
     # ---- p50 latency of one control tick (64 trajectories, host call -> best index on host) --------------
     lat = None
@@ -312,17 +340,21 @@ def main():
         # HBM traffic comes from rocprofv3 PMC passes (tools/collect_profiles.py), which cannot run inside this process: it is
         # reported only if the committed counters were collected on THIS build of the library and this launch size
         traffic, traffic_note, lib_hash = None, None, library_sha256()
-        pmc = os.path.join(ROOT, "profiles", "round2_pmc.json")
-        if os.path.exists(pmc) and a.workload == "cfg2":
-            try:
-                pj = json.load(open(pmc))
+        import glob
+        if a.workload == "cfg2":
+            seen = []
+            for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_pmc.json")), reverse=True):
+                try:
+                    pj = json.load(open(pmc))
+                except Exception:
+                    continue
                 if pj.get("library_sha256") == lib_hash and pj.get("trajectories_per_launch") == B:
                     traffic = pj.get("hbm_bytes_per_launch")
-                    traffic_note = f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this build ({lib_hash[:12]}), {pmc.split(os.sep)[-1]}"
-                else:
-                    traffic_note = f"profiles/round2_pmc.json is for build {str(pj.get('library_sha256'))[:12]} / {pj.get('trajectories_per_launch')} trajectories per launch; this run: {lib_hash[:12]} / {B}"
-            except Exception:
-                traffic = None
+                    traffic_note = f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this build ({lib_hash[:12]}), profiles/{os.path.basename(pmc)}"
+                    break
+                seen.append(f"{os.path.basename(pmc)}: build {str(pj.get('library_sha256'))[:12]} / {pj.get('trajectories_per_launch')} per launch")
+            if traffic is None:
+                traffic_note = f"no committed PMC passes for this build ({lib_hash[:12]}) at {B} trajectories per launch; found " + "; ".join(seen[:3])
         out = {
             "metric": "MPC solves/s (Jackal N=20, 8 obs)" if a.workload == "cfg2" else f"MPC solves/s ({a.workload})", "value": value, "unit": "solves/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
@@ -335,7 +367,7 @@ def main():
             "roofline": {"bound": "valu_fp64", "achieved": tflops, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": tflops / FP64_VALU_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_note,
                          "library_sha256": lib_hash,
-                         "kernel": "tmpc_solve_fast_kernel (one wavefront per trajectory)", "kernel_ms_avg": k_avg * 1e3, "flops_per_solve": fl,
+                         "kernel": kernel_info, "kernel_ms_avg": k_avg * 1e3, "flops_per_solve": fl,
                          "note": "compute roofline for dtype f64: on MI355X the dense f64 MFMA peak equals the f64 vector (VALU) "
                                  "peak, 78.6 TFLOP/s (AMD spec); the kernel issues FP64 VALU (7x7 stage blocks, SURVEY 8d), so "
                                  "this is the binding roofline; achieved = algorithmic flops (SURVEY 8d model x measured "
@@ -345,6 +377,8 @@ def main():
             "success_solves_per_s": value, "attempted_solves_per_s": attempted,
             "value_all_10_iter": attempted * float(full.mean()),
             "parity": parity,
+            "value_qp_tol_1e_9": tight["value"] if tight else None,
+            "qp_tol_1e_9": tight,
             "lanes_variant": lanes,
             "latency_b64": lat,
             "best_index_sample": best[:4].tolist(),

@@ -109,14 +109,26 @@ int tmpc_synchronize(tmpc_handle *h);
  *   and, as the last call of a solve (completeOneIteration, :162-204)          TMPC_ITER_COMPLETE: slots whose exit code is
  *                                                                             not 1 get zero multipliers (the capsule reset, :187-191)
  * and stores iterate + multipliers of every slot afterwards.  A slot whose QP stopped with qp_status != 0 has left the reference's iteration loop (:105-106): further
- * KEEP_ITERATE calls leave it untouched until a call without KEEP_ITERATE loads a new warm start.  n_iter calls with one
+ * KEEP_ITERATE calls leave it untouched until a call without KEEP_ITERATE loads a new warm start or a call with TMPC_ITER_NEW_SOLVE starts the next solve.  Slots the handle has no state for yet (a batch larger than any before) start fresh whatever the flags say.  n_iter calls with one
  * iteration each give bitwise the same result as one call with n_iter.  The first call on a handle has nothing to keep and
  * behaves like flags = 0, and so does the first call after tmpc_set_throughput_mode changed the kernel family (the wave kernels keep
  * the state in per-slot arrays, the lane kernels in their workspace).  tmpc_solve() itself never reads or writes this state. */
 #define TMPC_ITER_KEEP_ITERATE 1
 #define TMPC_ITER_KEEP_MULTIPLIERS 2
 #define TMPC_ITER_COMPLETE 4
+/* first call of a NEW solve() of the slots' Solvers: a slot's "left the iteration loop" mark (a QP that stopped with qp_status != 0) belongs
+ * to the solve that set it -- the reference's loop exit is local to one solve() (:105-106) and every new solve() iterates again from the
+ * capsule's state, warm start loaded or not. */
+#define TMPC_ITER_NEW_SOLVE 8
 int tmpc_solve_iterations(tmpc_handle *h, int32_t n_iter, int32_t flags);
+/* State slots.  By default batch entry b uses state slot b.  A caller that owns one slot per Solver (the reference: one capsule
+ * per Solver, acados_solver_interface.cpp:17,51-65) but launches a changing subset of them -- GuidanceConstraints::optimize skips
+ * disabled planners (guidance_constraints.cpp:286-293) -- passes the slot of every entry of the CURRENT batch: slots[B], distinct,
+ * in [0, B_max).  The map stays in force for the following tmpc_solve_iterations calls until it is replaced or cleared
+ * (slots = NULL).  A slot nothing was stored in yet starts like a fresh capsule whatever the keep-flags say.  Wave kernels only. */
+int tmpc_set_slots(tmpc_handle *h, const int32_t *slots);
+/* Copy the persistent state of min(B_max) slots from another handle of the same shape and device (a caller that outgrew its handle). */
+int tmpc_copy_state(tmpc_handle *dst, tmpc_handle *src);
 /* Zero the multipliers of every slot (a new capsule / Solver_acados_reset). */
 int tmpc_reset_multipliers(tmpc_handle *h);
 /* Kernel variant for the following tmpc_solve calls: 0 (default) = throughput variant, 1 = latency variant (two waves per
@@ -154,6 +166,9 @@ int tmpc_result_device_ptrs(tmpc_handle *h, void **d_pobj, void **d_exit_code);
  * without host synchronisation -- e.g. the multi-GPU step runs the record all-gather stream-ordered between tmpc_pack_records and
  * tmpc_select_best_records by making that stream the collective's current stream. */
 int tmpc_get_stream(tmpc_handle *h, void **stream);
+/* Which solve kernel this handle dispatches and how it is launched, as a short text for logs and benchmark records (kernel family,
+ * trajectories per workgroup, LDS bytes per workgroup, resident workgroups of a persistent launch).  Returns the length written. */
+int tmpc_kernel_info(const tmpc_handle *h, char *buf, int32_t capacity);
 
 /* ---- multi-GPU sharding: a scene's trajectories are split over ranks; after the solve every rank
  * packs one 16-byte record per local trajectory, the host all-gathers the record arrays (RCCL over xGMI via
@@ -207,7 +222,7 @@ int tmpc_linearize_topology(tmpc_handle *h, const void *d_obstacle_pos, const vo
  * obstacle positions of prediction step k-1 gives a halfspace a.x <= b linearised around the guess x0[b][k]; the
  * halfspaces that form the boundary of their intersection polygon (all others are redundant) are written, closest first
  * and at most n_rows of them (<= 64), into the first n_rows decomp/scenario rows of the batch's parameter tensor together
- * with ego_disc_0_offset; unused rows and stage 0 = dummy rows.  n_pts <= 5485 (a stage's halfspaces live in LDS).
+ * with ego_disc_0_offset; unused rows and stage 0 = dummy rows.  n_pts <= about 5480 (a stage's halfspaces live in LDS next to the kernel's static tables; the call checks the exact bound).
  * Device pointers:
  *   d_samples  : f64 [n_scenes][N][n_pts][2]   sampled positions, n_pts = obstacles x scenarios (index i = step k-1)
  *   d_scene_of : i32 [B];  d_state_x : f64 [n_scenes]  (dummy b = x + 100)
@@ -226,6 +241,11 @@ int tmpc_scenario_halfspaces(tmpc_handle *h, const void *d_samples, int32_t n_pt
  *   d_support     : i32 [B] out    distinct active scenarios
  *   d_active_rows : i32 [B] out or NULL    active rows */
 int tmpc_scenario_support(tmpc_handle *h, int32_t n_scenarios, double tol, void *d_support, void *d_active_rows);
+/* Stages of every trajectory whose sampled halfspaces CONTRADICT each other (an empty polygon: the guess sits in the overlap of inflated
+ * discs on opposite sides).  Such a stage keeps the n_rows closest halfspaces instead of dummies -- the QP is then infeasible or pays
+ * slack, never silently unconstrained -- and is counted here: d_count int32 [B] (device).  Callers treat a trajectory with a count
+ * > 0 as not eligible (solver.optimize_scenarios: scenario_status 2). */
+int tmpc_scenario_empty_stages(tmpc_handle *h, void *d_count);
 
 /* ---- cross-tick state on device, so a closed loop runs without host round trips --------------------
  * tmpc_warmstart builds the next tick's warm start x0 and xinit of every trajectory of the current batch from the

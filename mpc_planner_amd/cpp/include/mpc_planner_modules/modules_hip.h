@@ -311,7 +311,29 @@ namespace MPCPlanner
             if (_use_tmpcpp) planners_.emplace_back(cfg.n_paths, cfg, true);                 /* the non-guided planner */
         }
         /* stands in for global_guidance_->Update() + GetGuidanceTrajectory(i): the trajectories found for this tick */
-        void setGuidanceTrajectories(const std::vector<GuidanceTrajectory> &t) { _guidance = t; }
+        void setGuidanceTrajectories(const std::vector<GuidanceTrajectory> &t) { _guidance = t; mapGuidanceTrajectoriesToPlanners(); }   /* :106-108 */
+        /* guidance_constraints.cpp:192-250 -- which planner continues which homotopy class.  Pass 1: a trajectory whose class equals
+         * the guidance_ID of a planner's last result reserves that planner (existing_guidance: its previous MPC solution is a valid
+         * warm start, consumed at :310).  Pass 2: the trajectories left over go to the planners left over -- with the reference's
+         * quirk kept: its inner loop has no `break`, so the FIRST left-over trajectory claims every free planner (its entry ends at
+         * the last one) and later left-over trajectories get none.  Integer bookkeeping: equal to modules.map_guidance_trajectories_to_planners. */
+        void mapGuidanceTrajectoriesToPlanners()
+        {
+            for (auto &pl : planners_) { pl.taken = false; pl.existing_guidance = false; }
+            _map_homotopy_class_to_planner.clear();
+            std::vector<int> left_over;
+            for (int i = 0; i < NumberOfGuidanceTrajectories(); i++) {
+                size_t p = 0;
+                while (p < planners_.size() && !(planners_[p].result.guidance_ID == _guidance[i].topology_class && !planners_[p].taken)) p++;
+                if (p == planners_.size()) { left_over.push_back(i); continue; }
+                _map_homotopy_class_to_planner[i] = (int)p;
+                planners_[p].taken = planners_[p].existing_guidance = true;
+            }
+            for (int i : left_over)
+                for (size_t p = 0; p < planners_.size(); p++)
+                    if (!planners_[p].taken) { _map_homotopy_class_to_planner[i] = (int)p; planners_[p].taken = true; planners_[p].existing_guidance = false; }
+        }
+        const std::map<int, int> &guidanceToPlannerMap() const { return _map_homotopy_class_to_planner; }
         int NumberOfGuidanceTrajectories() const { return (int)_guidance.size(); }
 
         int optimize(State &state, const RealTimeData &data, ModuleData &module_data)
@@ -343,7 +365,7 @@ namespace MPCPlanner
                 planner.local_solver->loadWarmstart();
                 active.push_back(solver.get()); active_planners.push_back(&planner);
             }
-            const std::vector<int> codes = Solver::solveBatch(active);                         /* ONE launch instead of solver->solve() per thread (:339) */
+            const std::vector<int> codes = Solver::solveBatch(_batch, active);                 /* ONE launch instead of solver->solve() per thread (:339); every planner on its own slot */
             for (size_t i = 0; i < active.size(); i++) {                                       /* ANALYSIS AND PROCESSING (:343-360) */
                 LocalPlanner &planner = *active_planners[i];
                 planner.result.exit_code = codes[i];
@@ -393,7 +415,9 @@ namespace MPCPlanner
         std::vector<LocalPlanner> planners_;
         int best_planner_index_{-1};
         std::shared_ptr<Solver> _solver;
+        BatchContext _batch;                                                     /* this module instance's batch: one state slot per local planner */
     private:
+        std::map<int, int> _map_homotopy_class_to_planner;
         ModuleConfig _cfg;
         std::vector<GuidanceTrajectory> _guidance;
         RealTimeData empty_data_;
@@ -461,7 +485,7 @@ namespace MPCPlanner
                 solver->solver->loadWarmstart();                                               /* load the previous solution */
                 batch.push_back(solver->solver.get());
             }
-            const std::vector<int> codes = Solver::solveBatch(batch);                          /* scenario_module.optimize(data) of every solver: one launch */
+            const std::vector<int> codes = Solver::solveBatch(_batch, batch);                  /* scenario_module.optimize(data) of every solver: one launch */
             for (size_t i = 0; i < codes.size(); i++) { _scenario_solvers[i]->exit_code = codes[i]; computeSupport(*_scenario_solvers[i], _support_tolerance); }
             double lowest_cost = 1e9;                                                           /* :93-107 */
             _best_solver = nullptr;
@@ -477,6 +501,7 @@ namespace MPCPlanner
         ScenarioSolver *_best_solver{nullptr};
         std::shared_ptr<Solver> _solver;
         double _support_tolerance{1e-6};
+        BatchContext _batch;                                                     /* this module instance's batch: one state slot per scenario solver */
     private:
         double _disc_offset;
     };

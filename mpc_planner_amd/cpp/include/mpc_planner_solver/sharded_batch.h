@@ -25,7 +25,8 @@ namespace MPCPlanner
         ShardedSelection(ncclComm_t comm, int rank, int world, int B_max);
         ~ShardedSelection();
         ShardedSelection(const ShardedSelection &) = delete;
-        /* After tmpc_solve / tmpc_solve_iterations on `h` (B = n_sets * per_rank local trajectories, set s = trajectories
+        /* Stream-ordered on the handle's own stream (pack -> ncclAllGather -> selection -> copy of the winners), one host wait at the end.
+         * After tmpc_solve / tmpc_solve_iterations on `h` (B = n_sets * per_rank local trajectories, set s = trajectories
          * [s per_rank, (s+1) per_rank)): returns per set the winner's GLOBAL index rank * per_rank + t (or -1).
          * d_guidance_id / d_weight: device arrays [B] or nullptr (tmpc_pack_records). */
         std::vector<int> findBestPlanner(tmpc_handle *h, int n_sets, int per_rank, const void *d_guidance_id = nullptr, const void *d_weight = nullptr);
@@ -34,8 +35,9 @@ namespace MPCPlanner
     private:
         ncclComm_t _comm;
         int _rank, _world, _B_max;
-        hipStream_t _stream{nullptr};
         void *_d_rec{nullptr}, *_d_all{nullptr}, *_d_best{nullptr};
+        std::vector<int32_t> _host_best;
+        int32_t *_h_best_scratch(int n);
     };
 }
 #endif

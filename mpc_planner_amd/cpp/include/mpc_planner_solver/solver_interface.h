@@ -69,6 +69,7 @@ namespace MPCPlanner
         void printParameters(const ParameterMap &parameter_map) const;      /* :76-88 (YAML::Node -> the flat map read from parameter_map.yaml) */
     };
 
+    class BatchContext;
     class Solver
     {
     public:
@@ -91,11 +92,13 @@ namespace MPCPlanner
         };
 
     private:
+        void recordTiming(double launch_seconds, int iterations);     // _info.elapsed_time / solvetime / min_time (:151-153)
         tmpc_handle *_handle{nullptr};          // replaces the acados capsule; created lazily on the first solve.  Like the capsule
                                                 // it keeps the NLP iterate and its multipliers between calls (tmpc_solve_iterations)
         int _exit_code_one_iter{-1};
         int _device{0};
         bool _warmstart_pending{true};          // loadWarmstart() since the last iteration: the next one starts from _params.x0
+        bool _new_solve{true};                  // initializeOneIteration() since the last iteration: the next one opens a new solve (TMPC_ITER_NEW_SOLVE)
         int _iterations_done{0};                // RTI iterations since initializeOneIteration
         double _iteration_time_estimate{0.};
         void ensureHandle();
@@ -134,8 +137,11 @@ namespace MPCPlanner
                                                 //          status (0, or 4 after a QP failure) and sets _info.qp_status
         int completeOneIteration();             // :162-204 cost, trajectories, res_eq test, capsule reset on failure, exit-code mapping
 
-        /* GuidanceConstraints::optimize batch path: solvers[i]->_params in, _output/_info out, exit codes returned */
-        static std::vector<int> solveBatch(const std::vector<Solver *> &solvers);
+        /* GuidanceConstraints::optimize / ScenarioConstraints::optimize batch path: solvers[i]->_params in, _output/_info out, exit codes
+         * returned.  The batch belongs to the CALLER (one BatchContext per module instance, below): every Solver that goes through a
+         * context owns one state slot of it for the context's lifetime, like the reference's one capsule per Solver (:17,51-65). */
+        static std::vector<int> solveBatch(BatchContext &ctx, const std::vector<Solver *> &solvers);
+        friend class BatchContext;
 
         bool hasParameter(std::string &&parameter);
         void setParameter(int k, std::string &&parameter, double value);
@@ -154,6 +160,32 @@ namespace MPCPlanner
         double getOutput(int k, std::string &&state_name) const;
         std::string explainExitFlag(int exitflag) const;
         void printIfBoundLimited() const;
+    };
+
+    /* One batched launch for several Solvers, owned by the caller.  Holds the HIP handle of the batch and one persistent state slot
+     * (NLP iterate + multipliers, the capsule's state) per Solver that ever went through it: a planner keeps its slot whatever
+     * subset of the planners a tick launches (disabled planners are skipped, guidance_constraints.cpp:286-293) and whatever other
+     * module instances do with their own contexts.  The handle grows (state copied) when more Solvers appear than it has slots.
+     * Not thread safe: like a Solver, a context belongs to one caller. */
+    class BatchContext
+    {
+    public:
+        BatchContext() = default;
+        ~BatchContext();
+        BatchContext(const BatchContext &) = delete;
+        BatchContext &operator=(const BatchContext &) = delete;
+        std::vector<int> solve(const std::vector<Solver *> &solvers);
+        int slotOf(const Solver *s) const { auto it = _slot.find(s); return it == _slot.end() ? -1 : it->second; }
+        int capacity() const { return _capacity; }
+        void forget(const Solver *s) { _slot.erase(s); }              // a Solver that is destroyed while the context lives
+        double lastLaunchSeconds() const { return _last_launch_s; }
+
+    private:
+        void ensure(const Solver *s0, int needed_slots);
+        tmpc_handle *_handle{nullptr};
+        int _capacity{0}, _device{-1}, _iterations{-1}, _next_slot{0};
+        double _dt{0.}, _last_launch_s{0.};
+        std::map<const Solver *, int> _slot;
     };
 }
 #endif

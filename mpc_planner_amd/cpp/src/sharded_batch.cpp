@@ -11,7 +11,6 @@ namespace MPCPlanner
 
     ShardedSelection::ShardedSelection(ncclComm_t comm, int rank, int world, int B_max) : _comm(comm), _rank(rank), _world(world), _B_max(B_max)
     {
-        SB_HIP(hipStreamCreateWithFlags(&_stream, hipStreamNonBlocking));
         SB_HIP(hipMalloc(&_d_rec, (size_t)B_max * sizeof(tmpc_record)));
         SB_HIP(hipMalloc(&_d_all, (size_t)world * B_max * sizeof(tmpc_record)));
         SB_HIP(hipMalloc(&_d_best, (size_t)B_max * sizeof(int32_t)));
@@ -21,20 +20,22 @@ namespace MPCPlanner
         if (_d_rec) (void)hipFree(_d_rec);
         if (_d_all) (void)hipFree(_d_all);
         if (_d_best) (void)hipFree(_d_best);
-        if (_stream) (void)hipStreamDestroy(_stream);
     }
 
     std::vector<int> ShardedSelection::findBestPlanner(tmpc_handle *h, int n_sets, int per_rank, const void *d_guidance_id, const void *d_weight)
     {
         const int B = n_sets * per_rank;
         if (B > _B_max || B <= 0) { std::fprintf(stderr, "ShardedSelection: batch of %d exceeds %d\n", B, _B_max); std::exit(1); }
-        if (tmpc_pack_records(h, _d_rec, d_guidance_id, d_weight) || tmpc_synchronize(h)) { std::fprintf(stderr, "%s\n", tmpc_last_error(h)); std::exit(1); }
+        // pack -> all-gather -> select, all enqueued on the HANDLE's stream (tmpc_get_stream): RCCL waits for the packed records and
+        // the selection kernel for RCCL by stream order -- no host synchronisation between them (round 2 had two)
+        void *st = nullptr;
+        if (tmpc_pack_records(h, _d_rec, d_guidance_id, d_weight) || tmpc_get_stream(h, &st)) { std::fprintf(stderr, "%s\n", tmpc_last_error(h)); std::exit(1); }
         // records of rank r land at [r][n_sets][per_rank]: the layout tmpc_select_best_records expects
-        SB_NCCL(ncclAllGather(_d_rec, _d_all, (size_t)B * sizeof(tmpc_record), ncclUint8, _comm, _stream));
-        SB_HIP(hipStreamSynchronize(_stream));
-        if (tmpc_select_best_records(h, _d_all, _world, n_sets, per_rank, _d_best) || tmpc_synchronize(h)) { std::fprintf(stderr, "%s\n", tmpc_last_error(h)); std::exit(1); }
-        std::vector<int32_t> best(n_sets);
-        SB_HIP(hipMemcpy(best.data(), _d_best, (size_t)n_sets * sizeof(int32_t), hipMemcpyDeviceToHost));
-        return std::vector<int>(best.begin(), best.end());
+        SB_NCCL(ncclAllGather(_d_rec, _d_all, (size_t)B * sizeof(tmpc_record), ncclUint8, _comm, (hipStream_t)st));
+        if (tmpc_select_best_records(h, _d_all, _world, n_sets, per_rank, _d_best)) { std::fprintf(stderr, "%s\n", tmpc_last_error(h)); std::exit(1); }
+        SB_HIP(hipMemcpyAsync(_h_best_scratch(n_sets), _d_best, (size_t)n_sets * sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)st));
+        if (tmpc_synchronize(h)) { std::fprintf(stderr, "%s\n", tmpc_last_error(h)); std::exit(1); }      // the one wait: the winners are needed on the host
+        return std::vector<int>(_host_best.begin(), _host_best.begin() + n_sets);
     }
+    int32_t *ShardedSelection::_h_best_scratch(int n) { if ((int)_host_best.size() < n) _host_best.resize(n); return _host_best.data(); }
 }

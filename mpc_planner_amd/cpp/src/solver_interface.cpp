@@ -142,6 +142,7 @@ namespace MPCPlanner
             std::exit(1);
         }
         tmpc_set_latency_mode(_handle, 1);              // a Solver serves control ticks of a few planners: latency variant
+        tmpc_enable_timing(_handle, 4);                 // HIP events around every launch -> _info.elapsed_time / solvetime / min_time
     }
 
     Solver &Solver::operator=(const Solver &rhs) { _params = rhs._params; return *this; }      // (:67-77)
@@ -170,6 +171,7 @@ namespace MPCPlanner
         ensureHandle();
         _info = AcadosInfo();
         _iterations_done = 0;
+        _new_solve = true;
         if (tmpc_set_batch(_handle, 1, _params.xinit, _params.x0, _params.all_parameters)) {
             std::fprintf(stderr, "tmpc_set_batch: %s\n", tmpc_last_error(_handle)); std::exit(1);
         }
@@ -178,8 +180,13 @@ namespace MPCPlanner
     // solve), primal iterate kept unless loadWarmstart() asked for _params.x0 (:274-284)
     int Solver::runIterations(int n, bool complete)
     {
-        const int flags = TMPC_ITER_KEEP_MULTIPLIERS | (_warmstart_pending ? 0 : TMPC_ITER_KEEP_ITERATE) | (complete ? TMPC_ITER_COMPLETE : 0);
+        // the first iteration call after initializeOneIteration() opens a new solve: a loop exit of the previous solve (:105-106) does not carry over
+        const int flags = TMPC_ITER_KEEP_MULTIPLIERS | (_warmstart_pending ? 0 : TMPC_ITER_KEEP_ITERATE) | (complete ? TMPC_ITER_COMPLETE : 0) |
+                          (_new_solve ? TMPC_ITER_NEW_SOLVE : 0);
         if (tmpc_solve_iterations(_handle, n, flags)) { std::fprintf(stderr, "tmpc_solve_iterations: %s\n", tmpc_last_error(_handle)); std::exit(1); }
+        _new_solve = false;
+        float ms[4] = {0.f, 0.f, 0.f, 0.f}; int32_t n_ms = 0;   // (:151-153) the launch's time, HIP events on the handle's stream (drained every call)
+        if (tmpc_get_timings(_handle, ms, 4, &n_ms) == 0 && n_ms > 0 && n > 0) recordTiming(ms[n_ms - 1] * 1e-3, n);
         if (n > 0) _warmstart_pending = false;
         return 0;
     }
@@ -209,49 +216,80 @@ namespace MPCPlanner
         return _exit_code_one_iter;
     }
 
-    std::vector<int> Solver::solveBatch(const std::vector<Solver *> &solvers)
+    std::vector<int> Solver::solveBatch(BatchContext &ctx, const std::vector<Solver *> &solvers) { return ctx.solve(solvers); }
+
+    // (:151-153) time_tot of the last Solver_acados_solve -> elapsed_time, accumulated in solvetime, minimum in min_time.  Here the
+    // time is that of the HIP launch that did `iterations` RTI iterations (HIP events on the handle's stream, tmpc_get_timings).
+    void Solver::recordTiming(double launch_seconds, int iterations)
+    {
+        const double per_iteration = launch_seconds / (iterations > 0 ? iterations : 1);
+        _info.elapsed_time = per_iteration;
+        _info.solvetime += launch_seconds;
+        _info.min_time = std::min(per_iteration, _info.min_time);
+    }
+
+    BatchContext::~BatchContext() { if (_handle) tmpc_destroy(_handle); }
+
+    // (re)create the handle when the solver settings change, grow it (keeping every slot's state) when more Solvers appear than it holds
+    void BatchContext::ensure(const Solver *s0, int needed_slots)
+    {
+        const bool settings_changed = _handle && (_device != s0->_device || _iterations != s0->_num_iterations || _dt != s0->dt);
+        if (_handle && !settings_changed && needed_slots <= _capacity) return;
+        const int cap = settings_changed ? std::max(_capacity, needed_slots) : std::max(8, 2 * needed_slots);
+        tmpc_dims d; tmpc_default_dims_ex(&d, SOLVER_N, SOLVER_S, SOLVER_NLIN, SOLVER_M, SOLVER_NSLK, SOLVER_SLACK);
+        d.n_sqp = s0->_num_iterations; d.dt = s0->dt;
+        applyModelBounds(d, s0->_model_map);
+        tmpc_handle *h = nullptr;
+        if (tmpc_create(&h, &d, cap, s0->_device)) { std::printf("tmpc_create() failed. Exiting.\n"); std::exit(1); }
+        tmpc_set_latency_mode(h, 1);                    // same variant as solve(): solve() and solveBatch() stay bitwise equal
+        tmpc_enable_timing(h, 4);
+        if (_handle) {
+            if (!settings_changed && tmpc_copy_state(h, _handle)) { std::fprintf(stderr, "tmpc_copy_state: %s\n", tmpc_last_error(h)); std::exit(1); }
+            if (settings_changed) { _slot.clear(); _next_slot = 0; }      // other iteration budget / dt / device: a different solver, nothing to carry over
+            tmpc_destroy(_handle);
+        }
+        _handle = h; _capacity = cap; _device = s0->_device; _iterations = s0->_num_iterations; _dt = s0->dt;
+    }
+
+    std::vector<int> BatchContext::solve(const std::vector<Solver *> &solvers)
     {
         const int B = (int)solvers.size();
         std::vector<int> codes(B, 0);
         if (B == 0) return codes;
-        // one shared batch handle, (re)created when the batch outgrows it or the solver settings change; calls are serialised
-        static std::mutex batch_mutex;
-        static tmpc_handle *batch_handle = nullptr;
-        static int batch_cap = 0, batch_device = -1, batch_iterations = -1; static double batch_dt = 0.0;
-        std::lock_guard<std::mutex> lock(batch_mutex);
         Solver *s0 = solvers[0];
-        if (!batch_handle || batch_cap < B || batch_device != s0->_device || batch_iterations != s0->_num_iterations || batch_dt != s0->dt) {
-            if (batch_handle) tmpc_destroy(batch_handle);
-            batch_handle = nullptr;
-            tmpc_dims d; tmpc_default_dims_ex(&d, SOLVER_N, SOLVER_S, SOLVER_NLIN, SOLVER_M, SOLVER_NSLK, SOLVER_SLACK);
-            d.n_sqp = s0->_num_iterations; d.dt = s0->dt;
-            applyModelBounds(d, s0->_model_map);
-            if (tmpc_create(&batch_handle, &d, B, s0->_device)) { std::printf("tmpc_create() failed. Exiting.\n"); std::exit(1); }
-            tmpc_set_latency_mode(batch_handle, 1);     // same variant as solve(): solve() and solveBatch() stay bitwise equal
-            batch_cap = B; batch_device = s0->_device; batch_iterations = s0->_num_iterations; batch_dt = s0->dt;
-        }
+        int known = _next_slot;
+        for (Solver *s : solvers) if (!_slot.count(s)) known++;
+        ensure(s0, known);
+        for (Solver *s : solvers) if (!_slot.count(s)) _slot[s] = _next_slot++;      // (slots are never reused: a forgotten Solver's state is not inherited)
         const size_t n0 = (SOLVER_NU + SOLVER_NX) * (SOLVER_N + 1), np = (size_t)SOLVER_NP * SOLVER_N;
         std::vector<double> xinit((size_t)B * SOLVER_NX), x0(B * n0), par(B * np);
+        std::vector<int32_t> slots(B);
         for (int b = 0; b < B; b++) {
             std::memcpy(&xinit[(size_t)b * SOLVER_NX], solvers[b]->_params.xinit, sizeof(double) * SOLVER_NX);
             std::memcpy(&x0[b * n0], solvers[b]->_params.x0, sizeof(double) * n0);
             std::memcpy(&par[b * np], solvers[b]->_params.all_parameters, sizeof(double) * np);
+            slots[b] = _slot.at(solvers[b]);
         }
         const size_t nxt = (size_t)SOLVER_NX * (SOLVER_N + 1), nut = (size_t)SOLVER_NU * SOLVER_N;
         std::vector<double> xt(B * nxt), ut(B * nut), pobj(B), res(B);
         std::vector<int32_t> ec(B), qs(B), si(B), qi(B);
-        // slot b = solvers[b]: like the planners' own capsules, every slot keeps its multipliers from tick to tick (and loses them
-        // after a failed solve); GuidanceConstraints::optimize loads every planner's warm start (:337), so the iterate comes from x0
-        if (tmpc_set_batch(batch_handle, B, xinit.data(), x0.data(), par.data()) ||
-            tmpc_solve_iterations(batch_handle, s0->_num_iterations, TMPC_ITER_KEEP_MULTIPLIERS | TMPC_ITER_COMPLETE) ||
-            tmpc_get(batch_handle, xt.data(), ut.data(), pobj.data(), ec.data(), qs.data(), si.data(), res.data(), qi.data())) {
-            std::fprintf(stderr, "solveBatch: %s\n", tmpc_last_error(batch_handle)); std::exit(1);
+        // entry b = solvers[b] on ITS slot: like the planners' own capsules, every Solver keeps its multipliers from tick to tick (and
+        // loses them after a failed solve); GuidanceConstraints::optimize loads every planner's warm start (:337), so the iterate comes
+        // from x0.  A new solve() of every Solver: loop exits of the previous tick do not carry over.
+        float ms[4] = {0.f, 0.f, 0.f, 0.f}; int32_t n_ms = 0;
+        if (tmpc_set_batch(_handle, B, xinit.data(), x0.data(), par.data()) || tmpc_set_slots(_handle, slots.data()) ||
+            tmpc_solve_iterations(_handle, s0->_num_iterations, TMPC_ITER_KEEP_MULTIPLIERS | TMPC_ITER_COMPLETE | TMPC_ITER_NEW_SOLVE) ||
+            tmpc_get(_handle, xt.data(), ut.data(), pobj.data(), ec.data(), qs.data(), si.data(), res.data(), qi.data()) ||
+            tmpc_get_timings(_handle, ms, 4, &n_ms)) {
+            std::fprintf(stderr, "solveBatch: %s\n", tmpc_last_error(_handle)); std::exit(1);
         }
+        _last_launch_s = n_ms > 0 ? ms[n_ms - 1] * 1e-3 : 0.;
         for (int b = 0; b < B; b++) {
             Solver *s = solvers[b];
             std::memcpy(s->_output.xtraj, &xt[b * nxt], sizeof(double) * nxt);
             std::memcpy(s->_output.utraj, &ut[b * nut], sizeof(double) * nut);
-            s->_info = AcadosInfo(); s->_info.pobj = pobj[b]; s->_info.qp_status = qs[b]; s->_info.sqp_iter = si[b]; s->_info.nlp_res = res[b];
+            s->_info = Solver::AcadosInfo(); s->_info.pobj = pobj[b]; s->_info.qp_status = qs[b]; s->_info.sqp_iter = si[b]; s->_info.nlp_res = res[b];
+            s->recordTiming(_last_launch_s, s0->_num_iterations);      // (the batch is one launch: every Solver of it sees that launch's time)
             s->_exit_code_one_iter = ec[b]; codes[b] = ec[b];
         }
         return codes;

@@ -214,7 +214,7 @@ __device__ __forceinline__ bool poly_frac_alive(const PolyFrac &w) { return w.nh
 // one (trajectory, stage) = `unit` by one workgroup of 256 threads
 __device__ __forceinline__ void poly_stage(int unit, const Dims &d, int B, const double *x0, double *params, const double *samples, int n_pts,
                                            int n_rows, const int *scene_of, const double *state_x, double radius, double disc_offset,
-                                           int *row_sample, int cap, int *overflow)
+                                           int *row_sample, int cap, int *overflow, int *empty_stages)
 {
 #pragma clang fp contract(off)
     extern __shared__ double s_dyn[];                                    // the candidates, compact: normal, margin, sample index (~index: not an edge)
@@ -399,7 +399,42 @@ __device__ __forceinline__ void poly_stage(int unit, const Dims &d, int B, const
             which[rank] = i;
         }
     }
-    if (tid < n_rows && tid >= s_ne) { p[ip_slk(d, tid, 0)] = 1.0; p[ip_slk(d, tid, 1)] = 0.0; p[ip_slk(d, tid, 2)] = state_x[sc] + 100.0; which[tid] = -1; }
+    int n_real = s_ne;
+    if (s_ne == 0 && n_pts > 0) {
+        // EMPTY polygon: the halfspaces contradict each other (the guess sits in the overlap of inflated discs on opposite sides).
+        // Leaving the stage unconstrained would certify the most dangerous geometry as safe, so the stage keeps the n_rows CLOSEST
+        // halfspaces of all samples (lowest index on ties) -- contradictory rows: the QP is infeasible, or pays slack, and the solve
+        // reports it -- and the unit is counted in empty_stages[b] (tmpc_scenario_empty_stages), which the callers turn into "not
+        // eligible".  n_rows rounds of a block-wide argmin over (margin, index) above the previous pick; a rare path.
+        unsigned long long prev_key = 0ull; int prev_idx = -1;
+        const int rounds = n_rows < n_pts ? n_rows : n_pts;
+        for (int r = 0; r < rounds; r++) {
+            if (tid == 0) { s_best[0] = ~0ull; s_seed[0] = POLY_NONE; }
+            __syncthreads();
+            every_sample([&](int i, double, double, double dm, int) {
+                const unsigned long long key = poly_key(dm);
+                if (prev_idx < 0 || key > prev_key || (key == prev_key && i > prev_idx)) atomicMin(&s_best[0], key);
+            });
+            __syncthreads();
+            every_sample([&](int i, double, double, double dm, int) {
+                const unsigned long long key = poly_key(dm);
+                if (key == s_best[0] && (prev_idx < 0 || key > prev_key || i > prev_idx)) atomicMin(&s_seed[0], i);
+            });
+            __syncthreads();
+            every_sample([&](int i, double ax, double ay, double, int) {
+                if (i == s_seed[0]) {
+                    const double2 q = o[i];
+                    p[ip_slk(d, r, 0)] = ax; p[ip_slk(d, r, 1)] = ay; p[ip_slk(d, r, 2)] = ax * q.x + ay * q.y - radius;
+                    which[r] = i;
+                }
+            });
+            prev_key = s_best[0]; prev_idx = s_seed[0];
+            __syncthreads();
+        }
+        n_real = rounds;
+        if (tid == 0 && empty_stages) atomicAdd(&empty_stages[b], 1);
+    }
+    if (tid < n_rows && tid >= n_real) { p[ip_slk(d, tid, 0)] = 1.0; p[ip_slk(d, tid, 1)] = 0.0; p[ip_slk(d, tid, 2)] = state_x[sc] + 100.0; which[tid] = -1; }
 }
 
 
@@ -410,11 +445,12 @@ __device__ __forceinline__ void poly_stage(int unit, const Dims &d, int B, const
 __global__ __launch_bounds__(256, 4) void tmpc_scenario_halfspaces_kernel(Dims d, int B, const double *x0, double *params,
                                                                        const double *samples, int n_pts, int n_rows,
                                                                        const int *scene_of, const double *state_x,
-                                                                       double radius, double disc_offset, int *row_sample, int cap, int *overflow, int second_pass)
+                                                                       double radius, double disc_offset, int *row_sample, int cap, int *overflow, int second_pass,
+                                                                       int *empty_stages)
 {
     const int n_units = second_pass ? overflow[0] : B * d.N;
     for (int q = blockIdx.x; q < n_units; q += gridDim.x) {      // (first pass: one unit per workgroup)
-        poly_stage(second_pass ? overflow[1 + q] : q, d, B, x0, params, samples, n_pts, n_rows, scene_of, state_x, radius, disc_offset, row_sample, cap, overflow);
+        poly_stage(second_pass ? overflow[1 + q] : q, d, B, x0, params, samples, n_pts, n_rows, scene_of, state_x, radius, disc_offset, row_sample, cap, overflow, empty_stages);
         __syncthreads();                                          // (the LDS tables are reused by the next unit)
     }
 }
@@ -535,12 +571,13 @@ __global__ void tmpc_init_with_guidance_kernel(Dims d, int B, const double *gpos
 // acados_solver_interface.cpp:187-191): the slot's multipliers go back to zero (the primal iterate is overwritten by the next
 // loadWarmstart anyway) ----
 __global__ void tmpc_state_finalize_kernel(int n_pi, int n_lam, const int *__restrict__ exit_code, double *__restrict__ pi,
-                                           double *__restrict__ lamh)
+                                           double *__restrict__ lamh, const int *__restrict__ slot)
 {
     const int b = blockIdx.x;
     if (exit_code[b] == 1) return;
-    for (int e = threadIdx.x; e < n_pi; e += blockDim.x) pi[(size_t)b * n_pi + e] = 0.0;
-    for (int e = threadIdx.x; e < n_lam; e += blockDim.x) lamh[(size_t)b * n_lam + e] = 0.0;
+    const int sb = slot ? slot[b] : b;                      // the batch entry's state slot (tmpc_set_slots)
+    for (int e = threadIdx.x; e < n_pi; e += blockDim.x) pi[(size_t)sb * n_pi + e] = 0.0;
+    for (int e = threadIdx.x; e < n_lam; e += blockDim.x) lamh[(size_t)sb * n_lam + e] = 0.0;
 }
 
 // ---- debug: stage functions on device -----------------------------------------------------------

@@ -98,9 +98,24 @@ __device__ __forceinline__ double rcp_nr(double x)
 
 __device__ __forceinline__ void lds_add(double *p, double v) { atomicAdd(p, v); }   // ds_add_f64
 
-template <int NLIN, int MM, int LPS, int NTH, bool CP, typename PF>
+// ---- teams --------------------------------------------------------------------------------------------------------------
+// How one interior-point solve relates to the other trajectories of its workgroup.  Solo: there are none (fast and compact
+// kernels: a workgroup is one trajectory).  Team<NQ> (further down): NQ trajectories, one per wave, whose Riccati sweeps run
+// together in one wave, one 16-lane row each.
+struct Solo {
+    static constexpr int NQ = 1;
+    __device__ __forceinline__ bool alive() const { return true; }
+    __device__ __forceinline__ void sync() const { __syncthreads(); }
+    __device__ __forceinline__ bool any(bool active) const { return active; }
+    template <int NTH, bool CP>
+    __device__ __forceinline__ bool factor(const Lds &L, const Dims &d, int tl, int sw, int) const { return riccati_factor<NTH, CP>(L, d, tl, sw); }
+    template <int NTH, bool CP>
+    __device__ __forceinline__ void solve(const Lds &L, const Dims &d, int tl, int sw, int, int, bool) const { riccati_solve<NTH, CP>(L, d, tl, sw); }
+};
+
+template <int NLIN, int MM, int LPS, int NTH, bool CP, typename PF, typename TEAM = Solo>
 __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, int *iters_out, PF &pf,
-                        double (&lam)[FastCfg<NLIN, MM, LPS>::RPL])
+                        double (&lam)[FastCfg<NLIN, MM, LPS>::RPL], const TEAM &team = TEAM())
 {
     constexpr int NT = NTH;                         // threads per trajectory: 64 (one wave) or 128 (two waves; N > 21)
     using C = FastCfg<NLIN, MM, LPS>;
@@ -184,13 +199,13 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
     const double c0s = sg_ * Dr_[0], c1s = sg_ * Dr_[1], c2s = sg_ * L.D[DIDX2(s)];
 #define INVT(s) (LEAN ? rcp_nr(t[s]) : invt_[(LEAN ? 0 : (s))])
     auto CU = [&](int s) { return (box >> s & 1) ? ((upper >> s & 1) ? -1.0 : 1.0) : 0.0; };   // signed unit coefficient
-    __syncthreads();                                             // staging is dead from here on
+    team.sync();                                             // staging is dead from here on
     // QP start: dz = 0 except dx_0 = xinit - x_0; duals 0
     for (int e = tid_q; e < (N + 1) * NV; e += NT) L.v[e] = 0.0;
     for (int e = tid_q; e < (N + 1) * NX; e += NT) L.pq[e] = 0.0;
-    __syncthreads();
+    team.sync();
     if (tid_q < NX) L.v[NU + tid_q] = xi[tid_q] - L.z[NU + tid_q];
-    __syncthreads();
+    team.sync();
 
     ROW_PASS_BEGIN();
     double t[RPL], qt[RPL];
@@ -209,11 +224,17 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
             qt[s] = 0.0;
         }
     }
+    // `active`: this trajectory's QP is still iterating.  One trajectory per workgroup (Solo): the loop ends with it.  Teams: the
+    // trajectories of a workgroup iterate in lock step (the Riccati sweeps of all of them run in one wave), so a finished one
+    // keeps attending the team's barriers until every member is done.
     int status = 2, iters = 0;
+    bool active = team.alive();
     for (int it = 0;; it++) {
         pf.start();
         int tl = tid;                                    // per-iteration opaque lane id: per-lane addresses of the item loops and
         asm volatile("" : "+v"(tl));                   // sweeps are recomputed, not kept live (and spilled) across the whole solve
+        double res_d = 0.0, res_m = 0.0, mu = 0.0;
+        if (active) {
         // ---- stage parts of the residuals: rg0 = g + W v + [B A]^T pi_{k+1} - [0; pi_k];  rb;  Hh <- W ----
         if constexpr (CP) {
             // Hh <- W from the global workspace, all loads in flight before the first store;
@@ -228,7 +249,7 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
                 const int e = tl + NT * j;
                 if (e < tot) L.Hh[e] = wv[j];
             }
-            __syncthreads();
+            team.sync();
         }
         for (int e = tl; e < (N + 1) * NV; e += NT) {
             const int ks = e / NV, i = e - ks * NV;
@@ -270,10 +291,9 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
             res_b = fmax(res_b, fabs(acc));
         }
         if constexpr (!CP) for (int e = tl; e < (N + 1) * NP28; e += NT) L.Hh[e] = L.W[e];
-        __syncthreads();
+        team.sync();
         pf.stop(PH_HH);                                   // (profile: stage-vector part of the residuals)
         // ---- row pass R (registers): residuals, rg -= lam c, Hh += d c c^T, gh += d rd c ----
-        double res_d = 0.0, res_m = 0.0, mu = 0.0;
         ROW_PASS_BEGIN();
         {
             const double vx = L.v[kk * NV + ZX], vy = L.v[kk * NV + ZY], vp = L.v[kk * NV + ZPSI];
@@ -311,7 +331,7 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
                 lds_add(&Hk[pidx(ZPSI, ZX)], h20); lds_add(&Hk[pidx(ZPSI, ZY)], h21); lds_add(&Hk[pidx(ZPSI, ZPSI)], h22);
             }
         }
-        __syncthreads();
+        team.sync();
         // now rg = rg0 - sum lam c (residual) and gh = rg0 + sum d rd c (predictor rhs, q/t = lam)
         double res_g = 0.0;
         for (int e = tl; e < (N + 1) * NV; e += NT)
@@ -320,19 +340,22 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
         res_d = blk_max<NTH>(res_d, L.scr, tl, 2); res_m = blk_max<NTH>(res_m, L.scr, tl, 3);
         mu = blk_sum<NTH>(mu, L.scr, tl, 4) / m_rows;
         pf.stop(PH_RES);
-        if (!(isfinite(res_g) && isfinite(res_b) && isfinite(res_d) && isfinite(res_m))) { status = 4; break; }
-        if (res_g <= d.qp_tol && res_b <= d.qp_tol && res_d <= d.qp_tol && res_m <= d.qp_tol) { status = 0; break; }
-        if (it >= d.qp_iter_max) { status = 2; break; }
-        iters = it + 1;
+        if (!(isfinite(res_g) && isfinite(res_b) && isfinite(res_d) && isfinite(res_m))) { status = 4; active = false; }
+        else if (res_g <= d.qp_tol && res_b <= d.qp_tol && res_d <= d.qp_tol && res_m <= d.qp_tol) { status = 0; active = false; }
+        else if (it >= d.qp_iter_max) { status = 2; active = false; }
+        else iters = it + 1;
+        }
+        if (!team.any(active)) break;                    // (teams: one barrier; the votes also tell the sweeping wave which rows are live)
 
         // two-wave variant: the sweeping wave alternates with the iteration (and differs between neighbouring trajectories),
         // so that co-resident trajectories seldom run the same sweep on the same SIMD
         const int sw = NTH == 128 ? ((it + (int)(blockIdx.x >> 8)) & 1) : 0;
-        const bool fbad = riccati_factor<NTH, CP>(L, d, tl, sw);
+        const bool fbad = team.template factor<NTH, CP>(L, d, tl, sw, it);
         pf.stop(PH_FACTOR);
-        if (fbad) { status = 4; break; }
+        if (active && fbad) { status = 4; active = false; }
+        if (TEAM::NQ == 1 && !active) break;
         // ---- predictor: rhs = rg + sum c (lam + d rd)  (q/t = lam) ----
-        riccati_solve<NTH, CP>(L, d, tl, 1 - sw);
+        team.template solve<NTH, CP>(L, d, tl, 1 - sw, it, 1, active);
         pf.stop(PH_SOLVE);
         // Row step dt = c.dv + r_d is recomputed from the direction in LDS wherever it is needed (no per-row storage:
         // the register budget decides how many waves a SIMD holds)
@@ -352,6 +375,7 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
         double gmax = 0.0;
         double mu_aff = 0.0;
         double a_aff;
+        if (active) {
         ROW_PASS_BEGIN();
         {
             const double dx = L.dv[kk * NV + ZX], dy = L.dv[kk * NV + ZY], dp = L.dv[kk * NV + ZPSI];
@@ -380,7 +404,7 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
         sigma = sigma * sigma * sigma;
         // ---- corrector rhs: gh = rg + sum c (qt + d rd) ----
         for (int e = tl; e < (N + 1) * NV; e += NT) L.gh[e] = L.rg[e];
-        __syncthreads();
+        team.sync();
         ROW_PASS_BEGIN();
         {
             double cs0 = 0, cs1 = 0, cs2 = 0;
@@ -400,10 +424,12 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
             }
             if (stage_lane) { lds_add(&L.gh[k * NV + ZX], cs0); lds_add(&L.gh[k * NV + ZY], cs1); lds_add(&L.gh[k * NV + ZPSI], cs2); }
         }
-        __syncthreads();
+        team.sync();
+        }
         pf.stop(PH_RHS);
-        riccati_solve<NTH, CP>(L, d, tl, 1 - sw);
+        team.template solve<NTH, CP>(L, d, tl, 1 - sw, it, 2, active);
         pf.stop(PH_SOLVE);
+        if (active) {
         gmax = 0.0;
         ROW_PASS_BEGIN();
         const double dxc = L.dv[kk * NV + ZX], dyc = L.dv[kk * NV + ZY], dpc = L.dv[kk * NV + ZPSI];
@@ -420,8 +446,10 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
         gmax = blk_max<NTH>(gmax, L.scr, tl, 7);
         const double alpha = 0.999 > gmax ? 1.0 : 0.999 / gmax;        // min(1, 0.999 alpha_max)
         pf.stop(PH_ROWS);
-        if (!isfinite(alpha)) { status = 4; break; }
-        if (alpha < 1e-12) { status = 3; break; }
+        if (!isfinite(alpha)) { status = 4; active = false; }
+        else if (alpha < 1e-12) { status = 3; active = false; }
+        if (TEAM::NQ == 1 && !active) break;
+        if (active) {
         ROW_PASS_BEGIN();
 #pragma unroll
         for (int s = 0; s < RPL; s++) {
@@ -432,10 +460,12 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
                 if constexpr (!LEAN) invt_[s] = rcp_nr(t[s]);
             }
         }
-        __syncthreads();                                 // the rows read v / dv above; v changes below
+        team.sync();                                 // the rows read v / dv above; v changes below
         for (int e = tl; e < (N + 1) * NV; e += NT) L.v[e] += alpha * L.dv[e];
         for (int e = tl; e < N * NX; e += NT) L.pq[NX + e] += alpha * L.dpi[NX + e];
-        __syncthreads();
+        team.sync();
+        }
+        }
         pf.stop(PH_UPDATE);
     }
     *iters_out = iters;
@@ -463,7 +493,7 @@ void tmpc_solve_fast_kernel(Dims d, int B, const double *__restrict__ xinit,
     const int tid = threadIdx.x;
     if ((int)blockIdx.x >= B) return;
     const int b = trajectory_of_block(blockIdx.x, B);
-    if ((io.flags & ST_KEEP_ITERATE) && io.stopped[b]) return;      // this solver's loop has ended: outputs of its last call stand
+    if ((slot_flags(io, b) & ST_KEEP_ITERATE) && io.stopped[slot_of(io, b)]) return;      // this solver's loop has ended: outputs of its last call stand
     const Lds L = carve_fast(smem, d);
     const int N = d.N;
     const double *xi = xinit + (size_t)b * ext_nx(d);
@@ -475,10 +505,10 @@ void tmpc_solve_fast_kernel(Dims d, int B, const double *__restrict__ xinit,
     // loadWarmstart, or the iterate the handle holds; fresh or kept multipliers (StateIO, tmpc_solve.hip)
     for (int e = tid; e < (N + 1) * NV; e += NT) {
         const int k = e / NV, i = e - k * NV;
-        L.z[e] = (io.flags & ST_KEEP_ITERATE) ? io.z[(size_t)b * (N + 1) * NV + e] : x0[((size_t)b * (N + 1) + k) * ext_nv(d) + i];
+        L.z[e] = (slot_flags(io, b) & ST_KEEP_ITERATE) ? io.z[(size_t)slot_of(io, b) * (N + 1) * NV + e] : x0[((size_t)b * (N + 1) + k) * ext_nv(d) + i];
     }
-    for (int e = tid; e < (N + 1) * NX; e += NT) L.pi[e] = (io.flags & ST_KEEP_MULTIPLIERS) ? io.pi[(size_t)b * (N + 1) * NX + e] : 0.0;
-    for (int e = tid; e < N * NHk; e += NT) L.lamh[e] = (io.flags & ST_KEEP_MULTIPLIERS) ? io.lamh[(size_t)b * N * NHk + e] : 0.0;
+    for (int e = tid; e < (N + 1) * NX; e += NT) L.pi[e] = (slot_flags(io, b) & ST_KEEP_MULTIPLIERS) ? io.pi[(size_t)slot_of(io, b) * (N + 1) * NX + e] : 0.0;
+    for (int e = tid; e < N * NHk; e += NT) L.lamh[e] = (slot_flags(io, b) & ST_KEEP_MULTIPLIERS) ? io.lamh[(size_t)slot_of(io, b) * N * NHk + e] : 0.0;
     if (tid < 3) L.D[N * NHk * 3 + tid] = 0.0;      // zero triple read by box rows
     __syncthreads();
     if (tid < NU) L.z[N * NV + tid] = 0.0;
@@ -525,10 +555,10 @@ void tmpc_solve_fast_kernel(Dims d, int B, const double *__restrict__ xinit,
     if (io.flags & ST_STORE) {
         // (after a QP failure the staging area is stale; the host-side finalisation zeroes the multipliers of failed slots anyway,
         // as the reference resets a failed capsule, :187-191)
-        for (int e = tid; e < (N + 1) * NV; e += NT) io.z[(size_t)b * (N + 1) * NV + e] = L.z[e];
-        for (int e = tid; e < (N + 1) * NX; e += NT) io.pi[(size_t)b * (N + 1) * NX + e] = L.pi[e];
-        for (int e = tid; e < N * NHk; e += NT) io.lamh[(size_t)b * N * NHk + e] = L.lamh[e];
-        if (tid == 0 && sqp_iter > 0) io.stopped[b] = qp_status != 0;
+        for (int e = tid; e < (N + 1) * NV; e += NT) io.z[(size_t)slot_of(io, b) * (N + 1) * NV + e] = L.z[e];
+        for (int e = tid; e < (N + 1) * NX; e += NT) io.pi[(size_t)slot_of(io, b) * (N + 1) * NX + e] = L.pi[e];
+        for (int e = tid; e < N * NHk; e += NT) io.lamh[(size_t)slot_of(io, b) * N * NHk + e] = L.lamh[e];
+        if (tid == 0) { if (sqp_iter > 0) io.stopped[slot_of(io, b)] = qp_status != 0; io.valid[slot_of(io, b)] = 1; }
     }
     solve_epilogue(L, d, tid, b, xi, pb, slack_of(), status, qp_status, sqp_iter, qp_iter_total, xtraj, utraj, pobj, exit_code,
                    qp_status_out, sqp_iter_out, res_eq_out, qp_iter_out, prof_out, pf, t_begin, NTH);
@@ -567,17 +597,17 @@ void tmpc_solve_compact_kernel(Dims d, int B, const double *__restrict__ xinit,
         b = __builtin_amdgcn_readfirstlane(b);
         if (b >= B) break;
         asm volatile("" : "+v"(tid));                   // opaque per trajectory: per-lane addresses are recomputed, not kept live (and spilled) across solves
-        if ((io.flags & ST_KEEP_ITERATE) && io.stopped[b]) continue;      // this solver's loop has ended: outputs of its last call stand
+        if ((slot_flags(io, b) & ST_KEEP_ITERATE) && io.stopped[slot_of(io, b)]) continue;      // this solver's loop has ended: outputs of its last call stand
         const double *xi = xinit + (size_t)b * ext_nx(d);
         const double *pb = params + (size_t)b * N * d.npar;
         auto slack_of = [&]() { return d.slack ? __builtin_nontemporal_load(xi + NX) : 0.0; };
 
         for (int e = tid; e < (N + 1) * NV; e += NT) {
             const int k = e / NV, i = e - k * NV;
-            L.z[e] = (io.flags & ST_KEEP_ITERATE) ? io.z[(size_t)b * (N + 1) * NV + e] : x0[((size_t)b * (N + 1) + k) * ext_nv(d) + i];
+            L.z[e] = (slot_flags(io, b) & ST_KEEP_ITERATE) ? io.z[(size_t)slot_of(io, b) * (N + 1) * NV + e] : x0[((size_t)b * (N + 1) + k) * ext_nv(d) + i];
         }
-        for (int e = tid; e < (N + 1) * NX; e += NT) L.pi[e] = (io.flags & ST_KEEP_MULTIPLIERS) ? io.pi[(size_t)b * (N + 1) * NX + e] : 0.0;
-        for (int e = tid; e < N * NHk; e += NT) L.lamh[e] = (io.flags & ST_KEEP_MULTIPLIERS) ? io.lamh[(size_t)b * N * NHk + e] : 0.0;
+        for (int e = tid; e < (N + 1) * NX; e += NT) L.pi[e] = (slot_flags(io, b) & ST_KEEP_MULTIPLIERS) ? io.pi[(size_t)slot_of(io, b) * (N + 1) * NX + e] : 0.0;
+        for (int e = tid; e < N * NHk; e += NT) L.lamh[e] = (slot_flags(io, b) & ST_KEEP_MULTIPLIERS) ? io.lamh[(size_t)slot_of(io, b) * N * NHk + e] : 0.0;
         __syncthreads();
         if (tid < NU) L.z[N * NV + tid] = 0.0;
         __syncthreads();
@@ -621,15 +651,203 @@ void tmpc_solve_compact_kernel(Dims d, int B, const double *__restrict__ xinit,
         }
         asm volatile("" : "+v"(tid));
         if (io.flags & ST_STORE) {
-            for (int e = tid; e < (N + 1) * NV; e += NT) io.z[(size_t)b * (N + 1) * NV + e] = L.z[e];
-            for (int e = tid; e < (N + 1) * NX; e += NT) io.pi[(size_t)b * (N + 1) * NX + e] = L.pi[e];
-            for (int e = tid; e < N * NHk; e += NT) io.lamh[(size_t)b * N * NHk + e] = L.lamh[e];
-            if (tid == 0 && sqp_iter > 0) io.stopped[b] = qp_status != 0;
+            for (int e = tid; e < (N + 1) * NV; e += NT) io.z[(size_t)slot_of(io, b) * (N + 1) * NV + e] = L.z[e];
+            for (int e = tid; e < (N + 1) * NX; e += NT) io.pi[(size_t)slot_of(io, b) * (N + 1) * NX + e] = L.pi[e];
+            for (int e = tid; e < N * NHk; e += NT) io.lamh[(size_t)slot_of(io, b) * N * NHk + e] = L.lamh[e];
+            if (tid == 0) { if (sqp_iter > 0) io.stopped[slot_of(io, b)] = qp_status != 0; io.valid[slot_of(io, b)] = 1; }
         }
         solve_epilogue(L, d, tid, b, xi, pb, slack_of(), status, qp_status, sqp_iter, qp_iter_total, xtraj, utraj, pobj, exit_code,
                        qp_status_out, sqp_iter_out, res_eq_out, qp_iter_out, prof_out, pf, t_begin, 64);
         __syncthreads();                                // the next trajectory reuses LDS and the workspace
     }
 }
+
+#ifdef TMPC_TEAM_KERNELS
+// ---- team kernel: NQ trajectories per workgroup, their Riccati sweeps packed into one wave ------------------------------------
+// MEASURED AND REJECTED (round 3, profiles/round3_b_team_kernels_rejected.json): correct (bitwise the compact kernel's results) but
+// 4 % (teams of two) / 8 % (teams of four) SLOWER than the compact kernel -- at eight trajectories per CU the solve is bound by the
+// latency of each trajectory's own Riccati chain, which a team does not shorten, while lock step and the barriers add to it.  Kept as
+// an experiment build (-DTMPC_TEAM_KERNELS, TMPC_TEAM=2|4); the row-based sweeps it needed are what all kernels use now.
+// The sequential sweeps use 7 lanes of a wave; all their cross-lane traffic is row-local (tmpc_riccati.hpp), so one wave can sweep
+// for up to four trajectories at once, one 16-lane row each -- the same instruction stream, a quarter of the issue slots per
+// trajectory.  A workgroup is NQ waves = NQ trajectories in the compact layout (NQ LDS regions); every wave runs the stage-parallel
+// phases of its own trajectory exactly as the compact kernel does, and at the three sequential phases of an interior-point
+// iteration (factorisation, predictor and corrector sweeps) the team meets at a barrier and ONE wave (rotating, so that the
+// sequential work spreads over the SIMDs) sweeps all rows.  The price is lock step: the team iterates until its slowest member's QP
+// has converged (+11 % interior-point iterations on the bench scenes for adjacent trajectories, teams of four).  Arithmetic per
+// trajectory is that of the compact kernel: results are bitwise identical to it.
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");        // (no barrier: one wave; LDS / memory operations of a wave are in order,
+    __builtin_amdgcn_wave_barrier();                              //  the fences drain them and pin the compiler's ordering)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+template <int NQ_>
+struct Team {
+    static constexpr int NQ = NQ_;
+    int w;                      // wave in the workgroup (= trajectory slot); wave-uniform
+    int *flags;                 // LDS: [0, NQ) "still iterating" votes, [NQ, 2 NQ) factorisation failed
+    double *smem0;              // LDS base; trajectory q's region starts at smem0 + q * region
+    int region;
+    double *ws;                 // (any workspace pointer: the sweeps do not touch the global part of a view)
+    bool live;                  // this wave's trajectory takes part in the current QP
+    __device__ __forceinline__ bool alive() const { return live; }
+    __device__ __forceinline__ void sync() const { wave_sync(); }
+    // lane in the wave, re-derived (opaquely) wherever it is needed instead of being kept in a register across the client phases
+    __device__ __forceinline__ static int lane_now() { int l = threadIdx.x & 63; asm volatile("" : "+v"(l)); return l; }
+    __device__ __forceinline__ bool any(bool active) const
+    {
+        if (lane_now() == 0) flags[w] = active ? 1 : 0;
+        __syncthreads();
+        int r = 0;
+#pragma unroll
+        for (int q = 0; q < NQ; q++) r |= flags[q];
+        return r != 0;
+    }
+    // the sweeping wave's view of the trajectory in this lane's row (lane >> 4): LDS view, lane index in the row, stores enabled
+    __device__ __forceinline__ Lds row_view(const Dims &d, int *li, bool *wr) const
+    {
+        const int lane = lane_now(), row = lane >> 4;
+        *wr = row < NQ && flags[row < NQ ? row : 0] != 0;         // the row's trajectory voted "iterating" this iteration
+        *li = row < NQ ? (lane & 15) : 16;
+        return carve_compact(smem0 + (row < NQ ? row : 0) * region, ws, d);
+    }
+    template <int NTH, bool CP>
+    __device__ __forceinline__ bool factor(const Lds &, const Dims &d, int, int, int it) const
+    {
+        if (w == (3 * it) % NQ) {
+            int li; bool wr;
+            const Lds Lrow = row_view(d, &li, &wr);
+            const bool bad = riccati_factor_rows<CP>(Lrow, d, li, wr);
+            const unsigned long long m = __ballot(bad && wr);
+            const int lane = lane_now();
+            if (lane < NQ) flags[NQ + lane] = ((m >> (16 * lane)) & 0xffffull) ? 1 : 0;
+        }
+        __syncthreads();
+        return flags[NQ + w] != 0;
+    }
+    template <int NTH, bool CP>
+    __device__ __forceinline__ void solve(const Lds &L, const Dims &d, int tl, int, int it, int phase, bool active) const
+    {
+        if (active) riccati_solve_pre(L, d, tl, 64);
+        __syncthreads();
+        if (w == (3 * it + phase) % NQ) {
+            int li; bool wr;
+            const Lds Lrow = row_view(d, &li, &wr);
+            riccati_sweeps_rows<CP>(Lrow, d, li, wr, true, [] { wave_sync(); });
+        }
+        __syncthreads();
+        if (active) riccati_solve_post(L, d, tl, 64);
+        wave_sync();
+    }
+};
+
+template <int NLIN, int MM, int LPS, int NQ>
+__global__ __launch_bounds__(64 * NQ) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void tmpc_solve_team_kernel(Dims d, int B, const double *__restrict__ xinit,
+                            const double *__restrict__ x0, const double *__restrict__ params,
+                            double *__restrict__ xtraj, double *__restrict__ utraj,
+                            double *__restrict__ pobj, int *__restrict__ exit_code,
+                            int *__restrict__ qp_status_out, int *__restrict__ sqp_iter_out,
+                            double *__restrict__ res_eq_out, int *__restrict__ qp_iter_out,
+                            long long *__restrict__ prof_out, StateIO io)
+{
+    using C = FastCfg<NLIN, MM, LPS>;
+    constexpr int NT = 64;
+    const int NHk = C::RT ? d.n_up + d.M : C::NH, NLINk = C::RT ? d.n_up : NLIN;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;      // (wave-uniform: the own trajectory's view stays in SGPRs)
+    const int N = d.N;
+    int tid = lane;
+    const int region = lds_doubles_compact(N, d.n_lin, d.n_up + d.M);
+    int *flags = (int *)(smem + NQ * region);                    // 2 NQ flags + the team's first ticket
+    double *wsb = io.ws + ((size_t)blockIdx.x * NQ + w) * ws_doubles(N);
+    const Lds L = carve_compact(smem + w * region, wsb, d);
+    ba_tab_init(L.tab, d, tid);
+    if (tid < 3) L.D[N * L.dstride + tid] = 0.0;
+    __syncthreads();
+    Team<NQ> team{w, flags, smem, region, wsb, false};
+    NoProf pf;
+    (void)prof_out;
+    for (;;) {
+        if (threadIdx.x == 0) flags[2 * NQ] = atomicAdd(io.ticket, NQ);
+        __syncthreads();
+        const int b0 = flags[2 * NQ];
+        if (b0 >= B) break;
+        asm volatile("" : "+v"(tid));
+        const bool exists = b0 + w < B;
+        const int b = exists ? b0 + w : B - 1;                     // (a team's spare waves read a valid trajectory and write nothing)
+        const bool did = exists && !((slot_flags(io, b) & ST_KEEP_ITERATE) && io.stopped[slot_of(io, b)]);
+        bool run = did;
+        const double *xi = xinit + (size_t)b * ext_nx(d);
+        const double *pb = params + (size_t)b * N * d.npar;
+        auto slack_of = [&]() { return d.slack ? __builtin_nontemporal_load(xi + NX) : 0.0; };
+
+        for (int e = tid; e < (N + 1) * NV; e += NT) {
+            const int k = e / NV, i = e - k * NV;
+            L.z[e] = (slot_flags(io, b) & ST_KEEP_ITERATE) ? io.z[(size_t)slot_of(io, b) * (N + 1) * NV + e] : x0[((size_t)b * (N + 1) + k) * ext_nv(d) + i];
+        }
+        for (int e = tid; e < (N + 1) * NX; e += NT) L.pi[e] = (slot_flags(io, b) & ST_KEEP_MULTIPLIERS) ? io.pi[(size_t)slot_of(io, b) * (N + 1) * NX + e] : 0.0;
+        for (int e = tid; e < N * NHk; e += NT) L.lamh[e] = (slot_flags(io, b) & ST_KEEP_MULTIPLIERS) ? io.lamh[(size_t)slot_of(io, b) * N * NHk + e] : 0.0;
+        wave_sync();
+        if (tid < NU) L.z[N * NV + tid] = 0.0;
+        wave_sync();
+
+        int status = 0, qp_status = 0, sqp_iter = 0, qp_iter_total = 0;
+        double lam[C::RPL];
+        for (int it = 0; it < d.n_sqp; it++) {
+            if (run) {
+                linearise<true, true>(L, d, tid, pb, slack_of());
+                wave_sync();
+            }
+            int iters = 0;
+            team.live = run;
+            const int qs = ipm_fast<NLIN, MM, LPS, 64, true>(L, d, tid, xi, &iters, pf, lam, team);
+            if (run) {
+                qp_status = qs;
+                sqp_iter = it + 1; qp_iter_total += iters;
+                if (qp_status != 0 && qp_status != 2) { status = 4; run = false; }
+                else {
+                    status = 0;
+                    wave_sync();
+                    int tid_w = tid;
+                    asm volatile("" : "+v"(tid_w));
+                    for (int e = tid_w; e < (N + 1) * NV; e += NT) {
+                        const int ks = e / NV, i = e - ks * NV;
+                        if (!(ks == N && i < NU)) L.z[e] += L.v[e];
+                    }
+                    for (int e = tid_w; e < N * NX; e += NT) L.pi[NX + e] = L.pq[NX + e];
+                    wave_sync();
+                    constexpr int SPW = 64 / LPS;
+                    const int wl = tid_w & 63;
+                    const int k = wl / LPS, c = wl % LPS;
+                    if (wl < SPW * LPS && k < N) {
+#pragma unroll
+                        for (int s = 0; s < C::RPL; s++) {
+                            const int r = c + LPS * s;
+                            if (r < NHk) L.lamh[k * NHk + r] = (r < NLINk) ? lam[s] : -lam[s];
+                        }
+                    }
+                    wave_sync();
+                    if (qp_status != 0) run = false;
+                }
+            }
+        }
+        asm volatile("" : "+v"(tid));
+        if (did) {
+            if (io.flags & ST_STORE) {
+                for (int e = tid; e < (N + 1) * NV; e += NT) io.z[(size_t)slot_of(io, b) * (N + 1) * NV + e] = L.z[e];
+                for (int e = tid; e < (N + 1) * NX; e += NT) io.pi[(size_t)slot_of(io, b) * (N + 1) * NX + e] = L.pi[e];
+                for (int e = tid; e < N * NHk; e += NT) io.lamh[(size_t)slot_of(io, b) * N * NHk + e] = L.lamh[e];
+                if (tid == 0) { if (sqp_iter > 0) io.stopped[slot_of(io, b)] = qp_status != 0; io.valid[slot_of(io, b)] = 1; }
+            }
+            solve_epilogue(L, d, tid, b, xi, pb, slack_of(), status, qp_status, sqp_iter, qp_iter_total, xtraj, utraj, pobj, exit_code,
+                           qp_status_out, sqp_iter_out, res_eq_out, qp_iter_out, prof_out, pf, 0ll, 64);
+        }
+        __syncthreads();                                // the next team reuses LDS, the workspace and the ticket slot
+    }
+}
+
+#endif  // TMPC_TEAM_KERNELS
 
 }  // namespace tmpc

@@ -46,6 +46,7 @@ __global__ __launch_bounds__(256) void lanes_transpose_in_kernel(Layout L, int B
 __global__ __launch_bounds__(LW) void lanes_prepare_kernel(Layout L, int load_iterate, int fresh_multipliers, double *__restrict__ ws)
 {
     double *w = ws + (size_t)blockIdx.x * block_doubles(L) + threadIdx.x;
+    if (load_iterate < 0) { w[((size_t)L.o_xinit + 7) * LW] = 0.0; return; }      // clear_stopped: a new solve() of the slots' Solvers
     if (fresh_multipliers) {
         for (int k = 0; k <= L.N; k++) {
             for (int i = 0; i < NX; i++) w[((size_t)k * L.sd + L.o_pi + i) * LW] = 0.0;
@@ -174,6 +175,14 @@ int reset_multipliers(Context *c, hipStream_t stream, int B, std::string &err)
 {
     if (!c || B <= 0 || B > c->B_max) { err = "lanes::reset_multipliers: bad batch size"; return -1; }
     hipLaunchKernelGGL(lanes_prepare_kernel, dim3((B + LW - 1) / LW), dim3(LW), 0, stream, c->L, 0, 1, c->ws);
+    LANES_CHECK(hipGetLastError());
+    return 0;
+}
+
+int clear_stopped(Context *c, hipStream_t stream, int B, std::string &err)
+{
+    if (!c || B <= 0 || B > c->B_max) { err = "lanes::clear_stopped: bad batch size"; return -1; }
+    hipLaunchKernelGGL(lanes_prepare_kernel, dim3((B + LW - 1) / LW), dim3(LW), 0, stream, c->L, -1, 0, c->ws);
     LANES_CHECK(hipGetLastError());
     return 0;
 }

@@ -26,6 +26,8 @@ int stage_in(Context *c, hipStream_t stream, int B, const double *xinit, const d
 int solve(Context *c, hipStream_t stream, int B, int n_iter, bool persistent, bool complete, double *xtraj, double *utraj, double *pobj, int *exit_code,
           int *qp_status, int *sqp_iter, double *res_eq, int *qp_iter, std::string &err);
 int reset_multipliers(Context *c, hipStream_t stream, int B, std::string &err);
+// A new solve() of the slots' Solvers: the "iteration loop has ended" marks of the previous solve are cleared (TMPC_ITER_NEW_SOLVE).
+int clear_stopped(Context *c, hipStream_t stream, int B, std::string &err);
 
 }  // namespace lanes
 }  // namespace tmpc

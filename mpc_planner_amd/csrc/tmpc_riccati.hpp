@@ -78,18 +78,18 @@ __device__ __forceinline__ BaLane ba_row4(int N, int i5)          // o0: base of
 // NTH = threads per trajectory: 64, or 128 for the two-wave variant, in which the sweeps run on wave 0 alone (wave 1
 // waits at the closing barrier) and only the stage-parallel loops use all threads.
 // `sw`: which of the two waves sweeps (two-wave variant); the other one waits at the closing barrier.
-template <int NTH, bool CP = false>
-__device__ __forceinline__ bool riccati_factor(const Lds &L, const Dims &d, int tid, int sw = 0)
+// ---- the sequential parts work on 16-lane ROWS ---------------------------------------------------------------------------
+// All cross-lane traffic of the sweeps is row-local (bcast16, row shifts), so a wave can run up to four trajectories' sweeps at
+// once, one per row: `li` is the lane's index inside its row (li >= 16: idle lane), `L` the LDS view of the row's trajectory
+// (per-lane pointers when rows differ) and `wr` enables the row's stores.  One trajectory per wave (the fast / compact kernels):
+// li = lane, rows 1..3 idle.  Four per wave: the team kernels (tmpc_fast.hpp).
+template <bool CP>
+__device__ __forceinline__ bool riccati_factor_rows(const Lds &L, const Dims &d, int li, bool wr)
 {
     const int N = d.N;
-    asm volatile("" : "+v"(tid));                    // opaque per call: lane-derived addresses are not shared with (kept live until) other phases
-    bool anybad = false;
-    SWEEP_T0(); SWEEP_COUNT(SP_CALLS_FACTOR);
-    if (NTH == 64 || (tid >> 6) == sw) {
-    const int lane = tid & 63;
-    const bool rowl = lane < NV;
-    const int ls = rowl ? lane : 0;
-    const int i5 = lane - NU;                        // state index of lanes 2..6
+    const bool rowl = li < NV && wr;
+    const int ls = li < NV ? li : 0;
+    const int i5 = li - NU;                          // state index of lanes 2..6
     const double dt = d.dt, hdt2 = d.hdt2;
     bool bad = false;
     double f[NV], hk[NV], ba[NX], dn[8];
@@ -119,10 +119,9 @@ __device__ __forceinline__ bool riccati_factor(const Lds &L, const Dims &d, int 
 #pragma unroll
     for (int j = 0; j < NV; j++) f[j] = (j >= NU) ? L.Hh[N * NP28 + pidx(ls, j <= ls ? j : ls)] : 0.0;
     load_stage(N - 1);
-    bad |= chol_rows<NU>(f, lane, nullptr, nullptr);
-    SWEEP_T(SP_FACTOR_TERM);
+    bad |= chol_rows<NU>(f, li, nullptr, nullptr);
     for (int k = N - 1; k >= 0; k--) {
-        // broadcast Lp (lower 5x5 of the factor of stage k+1) to every lane
+        // broadcast Lp (lower 5x5 of the factor of stage k+1) to every lane of the row
         double Lp[NX][NX];
         static_for<0, NX>([&](auto m_) {
             constexpr int m = decltype(m_)::value;
@@ -130,12 +129,12 @@ __device__ __forceinline__ bool riccati_factor(const Lds &L, const Dims &d, int 
             for (int l = 0; l <= m; l++) Lp[m][l] = bcast16<NU + m>(f[NU + l]);
         });
         // Lxx of stage k+1 (own row of lanes 2..6) is kept for the vector solves: P_{k+1} = Lxx Lxx^T is never formed
-        if (rowl && lane >= NU) {
+        if (rowl && li >= NU) {
             double *Ln = L.Hh + (k + 1) * NP28 + FB_P;
 #pragma unroll
             for (int l = 0; l < NX; l++) *(l <= i5 ? Ln + i5 * (i5 + 1) / 2 + l : L.scr + (CP ? 0 : 56) + l) = f[NU + l];   // (entries above the diagonal go to a dummy slot: a select on the address instead of five masked stores)
         }
-        // G = Lp^T [B A] (5 x 7).  Own column densely from ba[]; all columns (wave-uniform) from the sparse [B A]:
+        // G = Lp^T [B A] (5 x 7).  Own column densely from ba[]; all columns (row-uniform) from the sparse [B A]:
         //   x: e0   y: e1   s: e4   psi: (Xp,Yp,1,0,0)   v: (Xv,Yv,0,1,dt)   a: (Xa,Ya,0,dt,dt^2/2)   w: (Xw,Yw,dt,0,0)
         // Same operation order as the dense product (zeros skipped, ones exact), i.e. F = Hh + G^T G keeps the
         // square-root structure (a factor-level perturbation only) -- do not replace by Hh + [B A]^T (P [B A]).
@@ -166,7 +165,7 @@ __device__ __forceinline__ bool riccati_factor(const Lds &L, const Dims &d, int 
         Gv[2] = Lp[3][2] + Lp[4][2] * dt;
         Gv[3] = Lp[3][3] + Lp[4][3] * dt;
         Gv[4] = Lp[4][4] * dt;
-        // F row `lane`: F_ij = Hh_ij + sum_l G_l,lane G_l,j
+        // F row `li`: F_ij = Hh_ij + sum_l G_l,li G_l,j
         {
             double a0 = hk[ZA], a1 = hk[ZW], a2 = hk[ZX], a3 = hk[ZY], a4 = hk[ZPSI], a5 = hk[ZV], a6 = hk[ZS];
 #pragma unroll
@@ -183,15 +182,29 @@ __device__ __forceinline__ bool riccati_factor(const Lds &L, const Dims &d, int 
         }
         load_stage(k > 0 ? k - 1 : 0);                // operands of the next stage, hidden under the Cholesky (unconditional, clamped: a branch here costs a second register set)
         double r0 = 0.0, r1 = 0.0;
-        bad |= chol_rows<0>(f, lane, &r0, &r1);
+        bad |= chol_rows<0>(f, li, &r0, &r1);
         if (rowl) {
             double *Fb = L.Hh + k * NP28;
-            if (lane >= NU) { Fb[FB_LXU + 2 * i5] = f[0]; Fb[FB_LXU + 2 * i5 + 1] = f[1]; }
-            if (lane == 1) { Fb[FB_L10] = f[0]; Fb[FB_R0] = r0; Fb[FB_R1] = r1; }
+            if (li >= NU) { Fb[FB_LXU + 2 * i5] = f[0]; Fb[FB_LXU + 2 * i5 + 1] = f[1]; }
+            if (li == 1) { Fb[FB_L10] = f[0]; Fb[FB_R0] = r0; Fb[FB_R1] = r1; }
         }
     }
-    anybad = __any(bad && lane < 16);             // (rows 1..3 of the wave compute on copies: their pivots mean nothing)
-    if (NTH > 64 && lane == 0) L.scr[63] = anybad ? 1.0 : 0.0;
+    return bad;
+}
+
+// NTH = threads per trajectory: 64, or 128 for the two-wave variant, in which the sweeps run on one wave (the other waits at the
+// closing barrier) and only the stage-parallel loops use all threads.  `sw`: which of the two waves sweeps.
+template <int NTH, bool CP = false>
+__device__ __forceinline__ bool riccati_factor(const Lds &L, const Dims &d, int tid, int sw = 0)
+{
+    asm volatile("" : "+v"(tid));                    // opaque per call: lane-derived addresses are not shared with (kept live until) other phases
+    bool anybad = false;
+    SWEEP_T0(); SWEEP_COUNT(SP_CALLS_FACTOR);
+    if (NTH == 64 || (tid >> 6) == sw) {
+        const int lane = tid & 63;
+        const bool bad = riccati_factor_rows<CP>(L, d, lane, true);
+        anybad = __any(bad && lane < 16);             // (rows 1..3 of the wave compute on copies: their pivots mean nothing)
+        if (NTH > 64 && lane == 0) L.scr[63] = anybad ? 1.0 : 0.0;
     }
     __syncthreads();
     SWEEP_T(SP_FACTOR_LOOP);
@@ -200,23 +213,13 @@ __device__ __forceinline__ bool riccati_factor(const Lds &L, const Dims &d, int 
 }
 
 // ---- square-root Riccati: vector solve (backward + forward), rhs gh / rb -> dv, dpi ------------------
-// Lane j (< 7) = component j of the stage vector [u; x]; the cost-to-go gradient p lives in lanes 2..6.
-template <int NTH, bool CP = false>
-__device__ __forceinline__ void riccati_solve(const Lds &L, const Dims &d, int tid, int sw = 1)
+// Stage-parallel parts (one lane per stage, `nth` lanes of the trajectory's own wave(s)):
+//   pre   q_k = P_{k+1} rb_k = Lxx (Lxx^T rb_k) for all stages at once (off the sequential chain); parked in dpi[k+1]
+//   post  dpi_k = P_k dx_k + p_k = Lxx (Lxx^T dx_k) + p_k, k = 1..N
+__device__ __forceinline__ void riccati_solve_pre(const Lds &L, const Dims &d, int tid, int nth)
 {
     const int N = d.N;
-    asm volatile("" : "+v"(tid));                    // opaque per call (see riccati_factor): the two solves of an iteration do not share address registers
-    // two-wave variant: the vector sweeps run on the wave that did not factorise, so that with two trajectories' waves
-    // sharing a SIMD pair the sequential work is spread over both SIMDs
-    const bool sweeper = NTH == 64 || (tid >> 6) == sw;
-    const int lane = NTH == 64 ? tid : (sweeper ? (tid & 63) : 64);
-    const bool rowl = lane < NV, xl = rowl && lane >= NU;
-    const int ls = rowl ? lane : 0;
-    const int i5 = xl ? lane - NU : 0;
-    SWEEP_T0(); SWEEP_COUNT(SP_CALLS_SOLVE);
-    // q_k = P_{k+1} rb_k = Lxx (Lxx^T rb_k) for all stages at once (off the sequential chain); parked in dpi[k+1].
-    // One lane per stage, fully unrolled (30 FMAs for the 5 components).
-    for (int k = tid; k < N; k += NTH) {
+    for (int k = tid; k < N; k += nth) {
         const double *Ln = L.Hh + (k + 1) * NP28 + FB_P;
         const double *r = L.rb + k * NX;
         double ll[15], rr[NX], tl[NX];
@@ -239,8 +242,47 @@ __device__ __forceinline__ void riccati_solve(const Lds &L, const Dims &d, int t
             L.dpi[(k + 1) * NX + i] = acc;
         }
     }
-    __syncthreads();
-    SWEEP_T(SP_SOLVE_PRE);
+}
+__device__ __forceinline__ void riccati_solve_post(const Lds &L, const Dims &d, int tid, int nth)
+{
+    const int N = d.N;
+    for (int kk = tid; kk < N; kk += nth) {
+        const int k = kk + 1;
+        const double *Lk = L.Hh + k * NP28 + FB_P;
+        const double *dxk = L.dv + k * NV + NU;
+        double ll[15], rr[NX], tl[NX];
+#pragma unroll
+        for (int e = 0; e < 15; e++) ll[e] = Lk[e];
+#pragma unroll
+        for (int m = 0; m < NX; m++) rr[m] = dxk[m];
+#pragma unroll
+        for (int l = 0; l < NX; l++) {
+            double acc = 0.0;
+#pragma unroll
+            for (int m = l; m < NX; m++) acc += ll[m * (m + 1) / 2 + l] * rr[m];
+            tl[l] = acc;
+        }
+#pragma unroll
+        for (int i = 0; i < NX; i++) {
+            double acc = 0.0;
+#pragma unroll
+            for (int l = 0; l <= i; l++) acc += ll[i * (i + 1) / 2 + l] * tl[l];
+            L.dpi[k * NX + i] = acc + L.pr[k * NX + i];
+        }
+    }
+}
+
+// The two sequential sweeps on rows (see riccati_factor_rows for li / L / wr).  Lane j (< 7) of a row = component j of the stage
+// vector [u; x]; the cost-to-go gradient p lives in lanes 2..6.  MID: what separates the sweeps (the forward sweep reads the y the
+// backward sweep stored): a workgroup barrier in the one-trajectory kernels, a wave-level fence when one wave sweeps for a team.
+template <bool CP, typename MID>
+__device__ __forceinline__ void riccati_sweeps_rows(const Lds &L, const Dims &d, int li, bool wr, bool sweeper, MID mid)
+{
+    const int N = d.N;
+    const bool rowl = li < NV && wr, xl = rowl && li >= NU;
+    const int ls = li < NV ? li : 0;
+    const int i5 = (li >= NU && li < NV) ? li - NU : 0;
+    SWEEP_T0();
     if (sweeper) {
     double p = L.gh[N * NV + ls];                       // p_N (lanes 2..6 meaningful)
     {
@@ -280,7 +322,7 @@ __device__ __forceinline__ void riccati_solve(const Lds &L, const Dims &d, int t
             const double y0 = bcast16<0>(fj) * o.r0;
             const double y1 = (bcast16<1>(fj) - o.l10 * y0) * o.r1;
             p = fj - o.lx0 * y0 - o.lx1 * y1;
-            if (lane == 0) { L.y[k * NU] = y0; L.y[k * NU + 1] = y1; }
+            if (rowl && li == 0) { L.y[k * NU] = y0; L.y[k * NU + 1] = y1; }
             if (xl) L.pr[k * NX + i5] = p;
         };
         Ops oa, ob;
@@ -297,14 +339,14 @@ __device__ __forceinline__ void riccati_solve(const Lds &L, const Dims &d, int t
         if (k == 0) stage(oa, 0);
     }
     }
-    __syncthreads();
+    mid();
     SWEEP_T(SP_SOLVE_BWD);
     // forward sweep; dx_0 = 0 (dx lives in lanes 2..6).  dx+ = A dx + B du + rb with A = I + E (E: columns psi, v).
     if (sweeper) {
         double dx = 0.0;
         struct Ops { double lx0, lx1, y0, y1, r0, l10, r1, a_psi, a_v, b_a, b_w, rbi; };
-        const double i_psi = lane == ZPSI ? 1.0 : 0.0, i_v = lane == ZV ? 1.0 : 0.0;
-        double *dv_own = L.dv + (rowl ? lane : 0);
+        const double i_psi = li == ZPSI ? 1.0 : 0.0, i_v = li == ZV ? 1.0 : 0.0;
+        double *dv_own = L.dv + ls;
         const BaLane br = ba_row4(N, i5);
         auto load_stage = [&](Ops &o, int k) {
             const double *Fb = L.Hh + k * NP28;
@@ -325,14 +367,15 @@ __device__ __forceinline__ void riccati_solve(const Lds &L, const Dims &d, int t
         auto stage = [&](const Ops &o, int k) {
             // du = -Luu^-T (Lxu^T dx + y).  (Lxu^T dx)_{0,1}: sums over lanes 2..6, folded with DPP row shifts (lanes 0, 1
             // contribute zeros, vacated lanes read zeros; lane 6 ends up with the total)
-            double q0 = xl ? o.lx0 * dx : 0.0, q1 = xl ? o.lx1 * dx : 0.0;
+            const bool xv = li >= NU && li < NV;                           // (independent of `wr`: an idle row still shifts zeros only into itself)
+            double q0 = xv ? o.lx0 * dx : 0.0, q1 = xv ? o.lx1 * dx : 0.0;
             q0 += dpp_shift_zero<0x111>(q0); q1 += dpp_shift_zero<0x111>(q1);
             q0 += dpp_shift_zero<0x112>(q0); q1 += dpp_shift_zero<0x112>(q1);
             q0 += dpp_shift_zero<0x114>(q0); q1 += dpp_shift_zero<0x114>(q1);
             const double s0 = o.y0 + bcast16<NV - 1>(q0), s1 = o.y1 + bcast16<NV - 1>(q1);
             const double u1 = -s1 * o.r1;
             const double u0 = (-s0 - o.l10 * u1) * o.r0;
-            if (lane == 0) { L.dv[k * NV] = u0; L.dv[k * NV + 1] = u1; }
+            if (rowl && li == 0) { L.dv[k * NV] = u0; L.dv[k * NV + 1] = u1; }
             if (xl) dv_own[k * NV] = dx;
             const double dpsi = bcast16<ZPSI>(dx), dvv = bcast16<ZV>(dx);
             const double e_psi = o.a_psi - i_psi, e_v = o.a_v - i_v;
@@ -348,37 +391,26 @@ __device__ __forceinline__ void riccati_solve(const Lds &L, const Dims &d, int t
             stage(ob, k + 1);
         }
         if (k < N) stage(oa, k);
-        if (rowl) L.dv[N * NV + lane] = xl ? dx : 0.0;
+        if (rowl) L.dv[N * NV + li] = xl ? dx : 0.0;
     }
-    __syncthreads();
     SWEEP_T(SP_SOLVE_FWD);
-    // dpi_k = P_k dx_k + p_k = Lxx (Lxx^T dx_k) + p_k, k = 1..N  (one lane per stage, unrolled)
-    for (int kk = tid; kk < N; kk += NTH) {
-        const int k = kk + 1;
-        const double *Lk = L.Hh + k * NP28 + FB_P;
-        const double *dxk = L.dv + k * NV + NU;
-        double ll[15], rr[NX], tl[NX];
-#pragma unroll
-        for (int e = 0; e < 15; e++) ll[e] = Lk[e];
-#pragma unroll
-        for (int m = 0; m < NX; m++) rr[m] = dxk[m];
-#pragma unroll
-        for (int l = 0; l < NX; l++) {
-            double acc = 0.0;
-#pragma unroll
-            for (int m = l; m < NX; m++) acc += ll[m * (m + 1) / 2 + l] * rr[m];
-            tl[l] = acc;
-        }
-#pragma unroll
-        for (int i = 0; i < NX; i++) {
-            double acc = 0.0;
-#pragma unroll
-            for (int l = 0; l <= i; l++) acc += ll[i * (i + 1) / 2 + l] * tl[l];
-            L.dpi[k * NX + i] = acc + L.pr[k * NX + i];
-        }
-    }
+}
+
+template <int NTH, bool CP = false>
+__device__ __forceinline__ void riccati_solve(const Lds &L, const Dims &d, int tid, int sw = 1)
+{
+    asm volatile("" : "+v"(tid));                    // opaque per call (see riccati_factor): the two solves of an iteration do not share address registers
+    // two-wave variant: the vector sweeps run on the wave that did not factorise, so that with two trajectories' waves
+    // sharing a SIMD pair the sequential work is spread over both SIMDs
+    const bool sweeper = NTH == 64 || (tid >> 6) == sw;
+    const int lane = NTH == 64 ? tid : (sweeper ? (tid & 63) : 64);
+    SWEEP_COUNT(SP_CALLS_SOLVE);
+    riccati_solve_pre(L, d, tid, NTH);
     __syncthreads();
-    SWEEP_T(SP_SOLVE_POST);
+    riccati_sweeps_rows<CP>(L, d, lane, true, sweeper, [] { __syncthreads(); });
+    __syncthreads();
+    riccati_solve_post(L, d, tid, NTH);
+    __syncthreads();
 }
 
 }  // namespace tmpc

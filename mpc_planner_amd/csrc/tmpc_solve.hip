@@ -55,7 +55,18 @@ struct StateIO {
     // workgroup, not per trajectory) and the work ticket of the persistent launch
     double *ws;         // [grid][ws_doubles(N)]
     int *ticket;        // next trajectory to solve (zeroed before the launch)
+    const int *slot;    // [B] state slot of every batch entry (tmpc_set_slots); nullptr: entry b uses slot b
+    int *valid;         // [B_max] the slot holds state of an earlier call; the others start fresh whatever the flags say
 };
+// State slot of batch entry b: by default b itself; callers that keep one slot per Solver and launch a changing subset of them
+// (GuidanceConstraints with a varying number of guidance trajectories) give the map with tmpc_set_slots.
+__device__ __forceinline__ int slot_of(const StateIO &io, int b) { return io.slot ? io.slot[b] : b; }
+// The keep-flags apply to slots that have state: a slot that was never stored starts like a fresh capsule.
+__device__ __forceinline__ int slot_flags(const StateIO &io, int b)
+{
+    if (!(io.flags & (ST_KEEP_ITERATE | ST_KEEP_MULTIPLIERS))) return io.flags;
+    return io.valid[slot_of(io, b)] ? io.flags : (io.flags & ~(ST_KEEP_ITERATE | ST_KEEP_MULTIPLIERS));
+}
 
 // ---- per-trajectory LDS layout (doubles) ----------------------------------------------------
 struct Lds {
@@ -667,7 +678,7 @@ __device__ __forceinline__ void solve_epilogue(const Lds &L, const Dims &d, int 
         if (!isfinite(cost)) status = 4;
         pobj[b] = cost; res_eq_out[b] = res;
         exit_code[b] = status == 0 ? 1 : (status == 1 ? 0 : status);      // Forces-style mapping (:197-201)
-        qp_status_out[b] = qp_status; sqp_iter_out[b] = sqp_iter; qp_iter_out[b] = qp_iter_total;
+        if (d.n_sqp > 0) { qp_status_out[b] = qp_status; sqp_iter_out[b] = sqp_iter; qp_iter_out[b] = qp_iter_total; }   // (an evaluation-only call keeps the statistics of the iterations before it)
     }
     (void)prof_out;
     pf.finish(tid, b, t_begin);
@@ -686,7 +697,7 @@ __global__ __launch_bounds__(NT) void tmpc_solve_kernel(Dims d, int B, const dou
     const int tid = threadIdx.x;
     if ((int)blockIdx.x >= B) return;
     const int b = trajectory_of_block(blockIdx.x, B);
-    if ((io.flags & ST_KEEP_ITERATE) && io.stopped[b]) return;      // this solver's loop has ended: outputs of its last call stand
+    if ((slot_flags(io, b) & ST_KEEP_ITERATE) && io.stopped[slot_of(io, b)]) return;      // this solver's loop has ended: outputs of its last call stand
     const Lds L = carve(smem, d);
     const int N = d.N;
     const double *xi = xinit + (size_t)b * ext_nx(d);
@@ -696,14 +707,14 @@ __global__ __launch_bounds__(NT) void tmpc_solve_kernel(Dims d, int B, const dou
     // loadWarmstart (acados_solver_interface.cpp:274-284), or the iterate the handle holds; fresh or kept multipliers
     for (int e = tid; e < (N + 1) * NV; e += NT) {
         const int k = e / NV, i = e - k * NV;
-        L.z[e] = (io.flags & ST_KEEP_ITERATE) ? io.z[(size_t)b * (N + 1) * NV + e] : x0[((size_t)b * (N + 1) + k) * ext_nv(d) + i];
+        L.z[e] = (slot_flags(io, b) & ST_KEEP_ITERATE) ? io.z[(size_t)slot_of(io, b) * (N + 1) * NV + e] : x0[((size_t)b * (N + 1) + k) * ext_nv(d) + i];
     }
-    for (int e = tid; e < (N + 1) * NX; e += NT) L.pi[e] = (io.flags & ST_KEEP_MULTIPLIERS) ? io.pi[(size_t)b * (N + 1) * NX + e] : 0.0;
+    for (int e = tid; e < (N + 1) * NX; e += NT) L.pi[e] = (slot_flags(io, b) & ST_KEEP_MULTIPLIERS) ? io.pi[(size_t)slot_of(io, b) * (N + 1) * NX + e] : 0.0;
     for (int r = tid; r < L.nrows; r += NT) {
         double l0 = 0.0;
-        if ((io.flags & ST_KEEP_MULTIPLIERS) && r < L.NG) {
+        if ((slot_flags(io, b) & ST_KEEP_MULTIPLIERS) && r < L.NG) {
             const int j = r % L.nh;
-            l0 = ((j < d.n_up) ? 1.0 : -1.0) * io.lamh[(size_t)b * L.NG + r];         // lam = -sgn (lam_upper - lam_lower)
+            l0 = ((j < d.n_up) ? 1.0 : -1.0) * io.lamh[(size_t)slot_of(io, b) * L.NG + r];         // lam = -sgn (lam_upper - lam_lower)
         }
         L.lam[r] = l0;
     }
@@ -740,10 +751,10 @@ __global__ __launch_bounds__(NT) void tmpc_solve_kernel(Dims d, int B, const dou
     }
 
     if (io.flags & ST_STORE) {
-        for (int e = tid; e < (N + 1) * NV; e += NT) io.z[(size_t)b * (N + 1) * NV + e] = L.z[e];
-        for (int e = tid; e < (N + 1) * NX; e += NT) io.pi[(size_t)b * (N + 1) * NX + e] = L.pi[e];
-        for (int r = tid; r < L.NG; r += NT) io.lamh[(size_t)b * L.NG + r] = (((r % L.nh) < d.n_up) ? 1.0 : -1.0) * L.lam[r];
-        if (tid == 0 && sqp_iter > 0) io.stopped[b] = qp_status != 0;
+        for (int e = tid; e < (N + 1) * NV; e += NT) io.z[(size_t)slot_of(io, b) * (N + 1) * NV + e] = L.z[e];
+        for (int e = tid; e < (N + 1) * NX; e += NT) io.pi[(size_t)slot_of(io, b) * (N + 1) * NX + e] = L.pi[e];
+        for (int r = tid; r < L.NG; r += NT) io.lamh[(size_t)slot_of(io, b) * L.NG + r] = (((r % L.nh) < d.n_up) ? 1.0 : -1.0) * L.lam[r];
+        if (tid == 0) { if (sqp_iter > 0) io.stopped[slot_of(io, b)] = qp_status != 0; io.valid[slot_of(io, b)] = 1; }
     }
     solve_epilogue(L, d, tid, b, xi, pb, slack, status, qp_status, sqp_iter, qp_iter_total, xtraj, utraj, pobj, exit_code,
                    qp_status_out, sqp_iter_out, res_eq_out, qp_iter_out, prof_out, pf, t_begin);
@@ -751,7 +762,11 @@ __global__ __launch_bounds__(NT) void tmpc_solve_kernel(Dims d, int B, const dou
 
 }  // namespace tmpc
 #include "tmpc_fast.hpp"
-#ifdef TMPC_SINGLE_COMPACT
+#ifdef TMPC_SINGLE_TEAM
+template __global__ void tmpc::tmpc_solve_team_kernel<TMPC_SINGLE_TEAM>(tmpc::Dims, int, const double *, const double *, const double *,
+                                                                       double *, double *, double *, int *, int *, int *, double *, int *,
+                                                                       long long *, tmpc::StateIO);
+#elif defined(TMPC_SINGLE_COMPACT)
 template __global__ void tmpc::tmpc_solve_compact_kernel<TMPC_SINGLE_COMPACT>(tmpc::Dims, int, const double *, const double *, const double *,
                                                                              double *, double *, double *, int *, int *, int *, double *, int *,
                                                                              long long *, tmpc::StateIO);
@@ -826,11 +841,28 @@ static SolveKernel pick_fast_kernel(const Dims &d, int *threads, bool prof)
 }
 // Compact variant (tmpc_fast.hpp: tmpc_solve_compact_kernel): two waves per SIMD, eight trajectories per CU, persistent
 // workgroups.  Bitwise the same results as the fast kernel of the shape (tools/ab_compare.py against TMPC_NO_COMPACT=1).
-static SolveKernel pick_compact_kernel(const Dims &d, bool prof)
+// *team: trajectories per workgroup -- 1: compact kernel; 2 / 4: team kernel (the trajectories' Riccati sweeps packed into one wave;
+// measured slower than the compact kernel, profiles/round3_b_team_kernels_rejected.json -- compiled only with -DTMPC_TEAM_KERNELS).
+// Shapes with 13 rows per lane ((12,12) and (24,0) at three lanes per stage: cfg 4, cfg 5) do not fit 256 registers without scratch
+// and stay on the fast kernels.
+static SolveKernel pick_compact_kernel(const Dims &d, bool prof, int *team)
 {
+    *team = 1;
 #ifndef TMPC_GENERATED_STAGE
     if (getenv("TMPC_FORCE_GENERIC") || getenv("TMPC_NO_COMPACT") || prof || d.N > 20) return nullptr;
+    const int nr = d.n_up + d.M + 14;                    // interior-point rows per stage
+#ifdef TMPC_TEAM_KERNELS
+    const char *e = getenv("TMPC_TEAM");                 // experiments / A-B: 1 = compact kernel, 2 / 4 = team kernels
+    const int nq = e ? atoi(e) : 1;
+    if (d.n_up == 8 && d.M == 8 && nq == 4) { *team = 4; return (SolveKernel)tmpc_solve_team_kernel<8, 8, 3, 4>; }
+    if (d.n_up == 8 && d.M == 8 && nq == 2) { *team = 2; return (SolveKernel)tmpc_solve_team_kernel<8, 8, 3, 2>; }
+#endif
     if (d.n_up == 8 && d.M == 8) return (SolveKernel)tmpc_solve_compact_kernel<8, 8, 3, false>;
+    if (d.n_up == 0 && d.M == 4) return (SolveKernel)tmpc_solve_compact_kernel<0, 4, 3, false>;
+    if (d.n_up == 12 && d.M == 12) return nullptr;
+    if (d.n_up == 24 && d.M == 0) return nullptr;
+    if (nr <= 3 * 7) return (SolveKernel)tmpc_solve_compact_kernel<-1, 7, 3, false>;       // runtime-shape instantiations
+    if (nr <= 3 * 10) return (SolveKernel)tmpc_solve_compact_kernel<-1, 10, 3, false>;
 #endif
     (void)d; (void)prof;
     return nullptr;
@@ -867,6 +899,7 @@ struct tmpc_handle {
     tmpc::SolveKernel kernel_lat = nullptr;   // optional latency variant (128 threads), used when latency_mode is on
     size_t lds_bytes_fast = 0;                // LDS of the fast-layout kernels (kernel_lat, the profiled twin) when `kernel` is compact
     bool compact = false;                     // `kernel` is a compact persistent kernel: grid = resident workgroups, needs ws + ticket
+    int team = 1;                             // trajectories per workgroup of the compact / team kernel (1, 2 or 4 waves)
     int grid_max = 0;                         // resident workgroups of the compact kernel on this device
     double *ws = nullptr;                     // [grid_max][ws_doubles(N)] per-workgroup NLP workspace
     int *ticket = nullptr;
@@ -877,7 +910,11 @@ struct tmpc_handle {
     // persistent per-slot solver state (tmpc_solve_iterations), allocated on first use
     double *st_z = nullptr, *st_pi = nullptr, *st_lamh = nullptr;
     int *st_stopped = nullptr;
-    bool st_valid = false;           // the state arrays hold the result of a previous tmpc_solve_iterations on this handle
+    int *st_has = nullptr;           // [B_max] the slot holds state of an earlier tmpc_solve_iterations (set by the kernels' store)
+    int *d_slot = nullptr;           // [B_max] state slot of every batch entry (tmpc_set_slots)
+    bool slots_set = false;
+    bool st_valid = false;           // lane kernels (state = their workspace, per launch): it holds the result of a previous call ...
+    int st_B = 0;                    // ... for slots [0, st_B)
     // SH-MPC bookkeeping: the sample behind each scenario row of the last tmpc_scenario_halfspaces (i32 [B][N][scn_rows])
     int *scn_sample = nullptr;
     size_t scn_cap = 0;
@@ -971,16 +1008,16 @@ int tmpc_create(tmpc_handle **out, const tmpc_dims *dims, int32_t B_max, int32_t
         if (hipFuncSetAttribute((const void *)h->kernel_lat, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes_fast) != hipSuccess)
             h->kernel_lat = nullptr;
     }
-    if (tmpc::SolveKernel kc = (h->fast && h->threads == tmpc::NT) ? tmpc::pick_compact_kernel(d, false) : nullptr) {
+    if (tmpc::SolveKernel kc = (h->fast && h->threads == tmpc::NT) ? tmpc::pick_compact_kernel(d, false, &h->team) : nullptr) {
         h->kernel = kc; h->compact = true;
-        h->lds_bytes = sizeof(double) * (size_t)tmpc::lds_doubles_compact(d.N, d.n_lin, d.n_up + d.M);
+        h->lds_bytes = sizeof(double) * (size_t)tmpc::lds_doubles_compact(d.N, d.n_lin, d.n_up + d.M) * h->team + (h->team > 1 ? 64 : 0);
     }
     if (hipFuncSetAttribute((const void *)h->kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)h->lds_bytes) != hipSuccess)
         return fail(TMPC_ERR_NO_DEVICE);
     if (h->compact) {
         int per_cu = 0, cus = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)h->kernel, 64, h->lds_bytes) != hipSuccess || per_cu <= 0 ||
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)h->kernel, 64 * h->team, h->lds_bytes) != hipSuccess || per_cu <= 0 ||
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0)
             return fail(TMPC_ERR_HIP);
         if (const char *e = getenv("TMPC_COMPACT_PER_CU")) { const int v = atoi(e); if (v > 0 && v < per_cu) per_cu = v; }   // experiments
@@ -1005,7 +1042,7 @@ int tmpc_create(tmpc_handle **out, const tmpc_dims *dims, int32_t B_max, int32_t
     ok &= hipMalloc(&h->d_best, 4) == hipSuccess;
     ok &= hipMalloc(&h->d_disabled, B) == hipSuccess;
     if (h->compact) {
-        ok &= hipMalloc(&h->ws, (size_t)h->grid_max * tmpc::ws_doubles(d.N) * 8) == hipSuccess;
+        ok &= hipMalloc(&h->ws, (size_t)h->grid_max * h->team * tmpc::ws_doubles(d.N) * 8) == hipSuccess;
         ok &= hipMalloc(&h->ticket, 4) == hipSuccess;
     }
     if (!ok) { tmpc_destroy(h); return TMPC_ERR_HIP; }
@@ -1020,7 +1057,7 @@ void tmpc_destroy(tmpc_handle *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void *ptrs[] = {h->o_xinit, h->o_x0, h->o_params, h->xtraj, h->utraj, h->pobj, h->res_eq, h->d_weight,
                     h->exit_code, h->qp_status, h->sqp_iter, h->qp_iter, h->d_best, h->d_disabled,
-                    h->st_z, h->st_pi, h->st_lamh, h->st_stopped, h->scn_sample, h->ws, h->ticket};
+                    h->st_z, h->st_pi, h->st_lamh, h->st_stopped, h->st_has, h->d_slot, h->scn_sample, h->ws, h->ticket};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &e : h->ev) (void)hipEventDestroy(e);
     tmpc::lanes::destroy(h->lanes);
@@ -1068,19 +1105,21 @@ static int launch_solve(tmpc_handle *h, int n_iter, int st_flags)
     } else {
         tmpc::Dims dd = h->d;
         dd.n_sqp = n_iter;
-        tmpc::StateIO io{h->st_z, h->st_pi, h->st_lamh, h->st_stopped, st_flags, h->ws, h->ticket};
+        tmpc::StateIO io{h->st_z, h->st_pi, h->st_lamh, h->st_stopped, st_flags, h->ws, h->ticket, h->slots_set ? h->d_slot : nullptr, h->st_has};
         const bool lat = h->kernel_lat && h->latency_mode;
         const bool cp = h->compact && !lat;
         if (cp) TMPC_HIP_CHECK(h, hipMemsetAsync(h->ticket, 0, 4, h->stream));        // the persistent launch's work counter
-        hipLaunchKernelGGL(lat ? h->kernel_lat : h->kernel, dim3(cp ? (h->B < h->grid_max ? h->B : h->grid_max) : h->B),
-                           dim3(lat ? 128 : h->threads), lat ? h->lds_bytes_fast : h->lds_bytes, h->stream, dd, h->B,
+        const int teams = (h->B + h->team - 1) / h->team;                              // workgroups' worth of work of a persistent launch
+        hipLaunchKernelGGL(lat ? h->kernel_lat : h->kernel, dim3(cp ? (teams < h->grid_max ? teams : h->grid_max) : h->B),
+                           dim3(lat ? 128 : (cp ? 64 * h->team : h->threads)), lat ? h->lds_bytes_fast : h->lds_bytes, h->stream, dd, h->B,
                            h->xinit, h->x0, h->params, h->xtraj, h->utraj, h->pobj, h->exit_code, h->qp_status,
                            h->sqp_iter, h->res_eq, h->qp_iter, (long long *)nullptr, io);
         TMPC_HIP_CHECK(h, hipGetLastError());
         if (st_flags & tmpc::ST_COMPLETE) {
             // a failed solve resets the reference's capsule (Solver_acados_reset, acados_solver_interface.cpp:187-191): zero multipliers
             const int n_pi = (h->d.N + 1) * tmpc::NX, n_lam = h->d.N * (h->d.n_up + h->d.M);
-            hipLaunchKernelGGL(tmpc::tmpc_state_finalize_kernel, dim3(h->B), dim3(64), 0, h->stream, n_pi, n_lam, h->exit_code, h->st_pi, h->st_lamh);
+            hipLaunchKernelGGL(tmpc::tmpc_state_finalize_kernel, dim3(h->B), dim3(64), 0, h->stream, n_pi, n_lam, h->exit_code, h->st_pi, h->st_lamh,
+                               h->slots_set ? h->d_slot : nullptr);
             TMPC_HIP_CHECK(h, hipGetLastError());
         }
     }
@@ -1088,35 +1127,60 @@ static int launch_solve(tmpc_handle *h, int n_iter, int st_flags)
     return TMPC_OK;
 }
 
+// the slots' persistent state no longer describes what the handle last solved
+static int invalidate_state(tmpc_handle *h)
+{
+    h->st_valid = false; h->st_B = 0;
+    if (h->st_has) TMPC_HIP_CHECK(h, hipMemsetAsync(h->st_has, 0, (size_t)h->B_max * 4, h->stream));
+    return TMPC_OK;
+}
+
 int tmpc_solve(tmpc_handle *h)
 {
     if (!h || h->B <= 0 || !h->xinit) { if (h) h->err = "tmpc_solve: no batch set"; return TMPC_ERR_INVALID; }
     TMPC_HIP_CHECK(h, hipSetDevice(h->device));
-    h->st_valid = false;
+    if (int rc = invalidate_state(h)) return rc;
     return launch_solve(h, h->d.n_sqp, 0);
 }
 
 int tmpc_solve_iterations(tmpc_handle *h, int32_t n_iter, int32_t flags)
 {
-    if (!h || h->B <= 0 || !h->xinit || n_iter < 0 || (flags & ~7)) { if (h) h->err = "tmpc_solve_iterations: no batch set / bad argument"; return TMPC_ERR_INVALID; }
+    if (!h || h->B <= 0 || !h->xinit || n_iter < 0 || (flags & ~15)) { if (h) h->err = "tmpc_solve_iterations: no batch set / bad argument"; return TMPC_ERR_INVALID; }
     TMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    if (h->throughput_mode && h->slots_set) { h->err = "tmpc_solve_iterations: slot maps (tmpc_set_slots) are not available with the lane kernels"; return TMPC_ERR_INVALID; }
     if (!h->throughput_mode && !h->st_z) {
         const size_t B = h->B_max, N = h->d.N, nh = h->d.n_up + h->d.M;
-        bool ok = hipMalloc(&h->st_z, B * (N + 1) * tmpc::NV * 8) == hipSuccess;
-        ok &= hipMalloc(&h->st_pi, B * (N + 1) * tmpc::NX * 8) == hipSuccess;
-        ok &= hipMalloc(&h->st_lamh, (B * N * nh + 1) * 8) == hipSuccess;
-        ok &= hipMalloc(&h->st_stopped, B * 4) == hipSuccess;
-        if (!ok) { h->err = "tmpc_solve_iterations: state allocation failed"; return TMPC_ERR_HIP; }
-        h->st_valid = false;
+        const size_t sz[5] = {B * (N + 1) * tmpc::NV * 8, B * (N + 1) * tmpc::NX * 8, (B * N * nh + 1) * 8, B * 4, B * 4};
+        void **dst[5] = {(void **)&h->st_z, (void **)&h->st_pi, (void **)&h->st_lamh, (void **)&h->st_stopped, (void **)&h->st_has};
+        bool ok = true;
+        for (int i = 0; i < 5 && ok; i++) ok = hipMalloc(dst[i], sz[i]) == hipSuccess && hipMemsetAsync(*dst[i], 0, sz[i], h->stream) == hipSuccess;
+        if (!ok) {                          // all or nothing: a later call must not find half of the arrays
+            for (int i = 0; i < 5; i++) { if (*dst[i]) (void)hipFree(*dst[i]); *dst[i] = nullptr; }
+            h->err = "tmpc_solve_iterations: state allocation failed"; return TMPC_ERR_HIP;
+        }
+        h->st_valid = false; h->st_B = 0;
     }
     int st = tmpc::ST_STORE;
-    if (h->st_valid) {                      // nothing to keep on the first call: behaves like a fresh capsule
+    if (h->throughput_mode) {
+        // lane kernels keep their state per launch, not per slot: nothing to keep on the first call, and a grown batch starts fresh
+        if (!h->st_valid) h->st_B = 0;
+        if (h->B > h->st_B) h->st_valid = false;
+        if (h->st_valid) {
+            if (flags & TMPC_ITER_KEEP_ITERATE) st |= tmpc::ST_KEEP_ITERATE;
+            if (flags & TMPC_ITER_KEEP_MULTIPLIERS) st |= tmpc::ST_KEEP_MULTIPLIERS;
+        }
+    } else {
+        // wave kernels: the keep-flags apply per slot -- a slot without stored state (first call, grown batch, new slot of a map)
+        // starts like a fresh capsule (slot_flags in the kernels)
         if (flags & TMPC_ITER_KEEP_ITERATE) st |= tmpc::ST_KEEP_ITERATE;
         if (flags & TMPC_ITER_KEEP_MULTIPLIERS) st |= tmpc::ST_KEEP_MULTIPLIERS;
     }
     if (flags & TMPC_ITER_COMPLETE) st |= tmpc::ST_COMPLETE;
+    // a new solve() of the slots' Solvers: the "iteration loop has ended" marks belong to the previous solve (:105-106 is local to one solve())
+    if ((flags & TMPC_ITER_NEW_SOLVE) && !h->throughput_mode && h->st_stopped) TMPC_HIP_CHECK(h, hipMemsetAsync(h->st_stopped, 0, (size_t)h->B_max * 4, h->stream));
+    if ((flags & TMPC_ITER_NEW_SOLVE) && h->throughput_mode && h->lanes && tmpc::lanes::clear_stopped(h->lanes, h->stream, h->B_max, h->err)) return TMPC_ERR_HIP;
     const int rc = launch_solve(h, n_iter, st);
-    if (rc == TMPC_OK) h->st_valid = true;
+    if (rc == TMPC_OK && h->throughput_mode) { h->st_valid = true; if (h->B > h->st_B) h->st_B = h->B; }
     return rc;
 }
 
@@ -1141,6 +1205,52 @@ int tmpc_set_latency_mode(tmpc_handle *h, int32_t on)
     return (h->latency_mode && !h->kernel_lat) ? 1 : TMPC_OK;      // 1: accepted, but this shape has no latency variant
 }
 
+int tmpc_set_slots(tmpc_handle *h, const int32_t *slots)
+{
+    if (!h) return TMPC_ERR_INVALID;
+    if (!slots) { h->slots_set = false; return TMPC_OK; }
+    if (h->B <= 0) { h->err = "tmpc_set_slots: set the batch first (the map has one entry per batch entry)"; return TMPC_ERR_INVALID; }
+    std::vector<char> seen((size_t)h->B_max, 0);
+    for (int b = 0; b < h->B; b++) {
+        if (slots[b] < 0 || slots[b] >= h->B_max || seen[slots[b]]) { h->err = "tmpc_set_slots: slots must be distinct and in [0, B_max)"; return TMPC_ERR_INVALID; }
+        seen[slots[b]] = 1;
+    }
+    TMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    if (!h->d_slot) TMPC_HIP_CHECK(h, hipMalloc(&h->d_slot, (size_t)h->B_max * 4));
+    TMPC_HIP_CHECK(h, hipMemcpyAsync(h->d_slot, slots, (size_t)h->B * 4, hipMemcpyHostToDevice, h->stream));
+    TMPC_HIP_CHECK(h, hipStreamSynchronize(h->stream));            // (the caller's array may go away)
+    h->slots_set = true;
+    return TMPC_OK;
+}
+
+int tmpc_copy_state(tmpc_handle *dst, tmpc_handle *src)
+{
+    if (!dst || !src || dst == src) return TMPC_ERR_INVALID;
+    const tmpc::Dims &a = dst->d, &b = src->d;
+    if (a.N != b.N || a.n_up != b.n_up || a.M != b.M || dst->device != src->device || dst->throughput_mode || src->throughput_mode) {
+        dst->err = "tmpc_copy_state: handles of different shape / device / kernel family"; return TMPC_ERR_INVALID;
+    }
+    if (!src->st_z) return TMPC_OK;                                 // nothing stored yet
+    TMPC_HIP_CHECK(dst, hipSetDevice(dst->device));
+    TMPC_HIP_CHECK(dst, hipStreamSynchronize(src->stream));
+    if (!dst->st_z) {                                               // allocate through the regular path: an evaluation-only call on the (unset) batch is not possible, so inline it
+        const size_t B = dst->B_max, N = a.N, nh = a.n_up + a.M;
+        const size_t sz[5] = {B * (N + 1) * tmpc::NV * 8, B * (N + 1) * tmpc::NX * 8, (B * N * nh + 1) * 8, B * 4, B * 4};
+        void **p[5] = {(void **)&dst->st_z, (void **)&dst->st_pi, (void **)&dst->st_lamh, (void **)&dst->st_stopped, (void **)&dst->st_has};
+        bool ok = true;
+        for (int i = 0; i < 5 && ok; i++) ok = hipMalloc(p[i], sz[i]) == hipSuccess && hipMemsetAsync(*p[i], 0, sz[i], dst->stream) == hipSuccess;
+        if (!ok) { for (int i = 0; i < 5; i++) { if (*p[i]) (void)hipFree(*p[i]); *p[i] = nullptr; } dst->err = "tmpc_copy_state: allocation failed"; return TMPC_ERR_HIP; }
+    }
+    const size_t n = (size_t)(dst->B_max < src->B_max ? dst->B_max : src->B_max), N = a.N, nh = a.n_up + a.M;
+    TMPC_HIP_CHECK(dst, hipMemcpyAsync(dst->st_z, src->st_z, n * (N + 1) * tmpc::NV * 8, hipMemcpyDeviceToDevice, dst->stream));
+    TMPC_HIP_CHECK(dst, hipMemcpyAsync(dst->st_pi, src->st_pi, n * (N + 1) * tmpc::NX * 8, hipMemcpyDeviceToDevice, dst->stream));
+    TMPC_HIP_CHECK(dst, hipMemcpyAsync(dst->st_lamh, src->st_lamh, n * N * nh * 8, hipMemcpyDeviceToDevice, dst->stream));
+    TMPC_HIP_CHECK(dst, hipMemcpyAsync(dst->st_stopped, src->st_stopped, n * 4, hipMemcpyDeviceToDevice, dst->stream));
+    TMPC_HIP_CHECK(dst, hipMemcpyAsync(dst->st_has, src->st_has, n * 4, hipMemcpyDeviceToDevice, dst->stream));
+    TMPC_HIP_CHECK(dst, hipStreamSynchronize(dst->stream));
+    return TMPC_OK;
+}
+
 int tmpc_set_throughput_mode(tmpc_handle *h, int32_t on)
 {
     if (!h) return TMPC_ERR_INVALID;
@@ -1149,7 +1259,7 @@ int tmpc_set_throughput_mode(tmpc_handle *h, int32_t on)
         h->lanes = tmpc::lanes::create(h->d, h->B_max, h->err);
         if (!h->lanes) return TMPC_ERR_HIP;
     }
-    if (h->throughput_mode != (on != 0)) h->st_valid = false;      // the two kernel families keep their persistent state separately
+    if (h->throughput_mode != (on != 0)) { if (int rc = invalidate_state(h)) return rc; }      // the two kernel families keep their persistent state separately
     h->throughput_mode = on != 0;
     return TMPC_OK;
 }
@@ -1199,6 +1309,20 @@ int tmpc_get_stream(tmpc_handle *h, void **stream)
     if (!h || !stream) return TMPC_ERR_INVALID;
     *stream = (void *)h->stream;
     return TMPC_OK;
+}
+
+int tmpc_kernel_info(const tmpc_handle *h, char *buf, int32_t capacity)
+{
+    if (!h || !buf || capacity <= 0) return TMPC_ERR_INVALID;
+    const char *family = h->throughput_mode ? "lanes (one lane per trajectory)"
+                         : !h->fast        ? "generic (one wave per trajectory, rows in LDS)"
+                         : !h->compact     ? (h->threads == 128 ? "fast, two waves per trajectory" : "fast (one wave per trajectory)")
+                         : h->team > 1     ? "team (compact layout, Riccati sweeps of the workgroup's trajectories packed into one wave)"
+                                           : "compact (one wave per trajectory, two waves per SIMD)";
+    const int n = snprintf(buf, (size_t)capacity, "%s; trajectories per workgroup %d; LDS %zu B per workgroup; %s", family, h->compact ? h->team : 1,
+                           h->lds_bytes, h->compact ? (std::string("persistent launch, resident workgroups ") + std::to_string(h->grid_max)).c_str()
+                                                    : "one workgroup per trajectory");
+    return n < capacity ? n : capacity - 1;
 }
 
 int tmpc_result_device_ptrs(tmpc_handle *h, void **d_pobj, void **d_exit_code)
@@ -1263,9 +1387,14 @@ int tmpc_scenario_halfspaces(tmpc_handle *h, const void *d_samples, int32_t n_pt
     }
     TMPC_HIP_CHECK(h, hipSetDevice(h->device));
     const size_t per_entry = 3 * sizeof(double) + sizeof(int);                        // a candidate: normal, margin, index word
-    if ((size_t)n_pts * per_entry > 150 * 1024) { h->err = "tmpc_scenario_halfspaces: more than 5485 samples per stage do not fit a workgroup's LDS"; return TMPC_ERR_INVALID; }
+    hipFuncAttributes fa;
+    TMPC_HIP_CHECK(h, hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(tmpc::tmpc_scenario_halfspaces_kernel)));
+    if ((size_t)n_pts * per_entry + fa.sharedSizeBytes > 160 * 1024) {      // the second pass's list (room for every sample) + the kernel's static tables
+        h->err = "tmpc_scenario_halfspaces: that many samples per stage do not fit a workgroup's LDS (160 KiB minus the kernel's static tables: about 5480)";
+        return TMPC_ERR_INVALID;
+    }
     const size_t units = (size_t)h->B * h->d.N;
-    const size_t need = units * n_rows + 1 + units;                 // rows' samples, then the first pass's overflow list (count, units)
+    const size_t need = units * n_rows + 1 + units + (size_t)h->B;  // rows' samples, the first pass's overflow list (count, units), empty-polygon stages per trajectory
     if (need > h->scn_cap) {
         if (h->scn_sample) { TMPC_HIP_CHECK(h, hipStreamSynchronize(h->stream)); (void)hipFree(h->scn_sample); h->scn_sample = nullptr; h->scn_cap = 0; }
         TMPC_HIP_CHECK(h, hipMalloc(&h->scn_sample, need * sizeof(int)));
@@ -1275,7 +1404,9 @@ int tmpc_scenario_halfspaces(tmpc_handle *h, const void *d_samples, int32_t n_pt
     // first pass with a short candidate list (more workgroups per CU); second pass, with room for every sample, only for the
     // units the first pass recorded as not fitting
     int *overflow = h->scn_sample + units * n_rows;
+    int *empty_stages = overflow + 1 + units;
     TMPC_HIP_CHECK(h, hipMemsetAsync(overflow, 0, sizeof(int), h->stream));
+    TMPC_HIP_CHECK(h, hipMemsetAsync(empty_stages, 0, sizeof(int) * (size_t)h->B, h->stream));
     const int cap1 = n_pts < tmpc::POLY_LIST_CAP ? n_pts : tmpc::POLY_LIST_CAP;
     for (int pass = 0; pass < (cap1 < n_pts ? 2 : 1); pass++) {
         const int cap = pass == 0 ? cap1 : n_pts;
@@ -1285,9 +1416,19 @@ int tmpc_scenario_halfspaces(tmpc_handle *h, const void *d_samples, int32_t n_pt
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(tmpc::tmpc_scenario_halfspaces_kernel, dim3(pass == 0 ? units : (units < 512 ? units : 512)), dim3(256), lds, h->stream, h->d, h->B, h->x0,
                            const_cast<double *>(h->params), (const double *)d_samples, n_pts, n_rows, (const int *)d_scene_of,
-                           (const double *)d_state_x, radius, disc_offset, h->scn_sample, cap, overflow, pass);
+                           (const double *)d_state_x, radius, disc_offset, h->scn_sample, cap, overflow, pass, empty_stages);
     }
     TMPC_HIP_CHECK(h, hipGetLastError());
+    return TMPC_OK;
+}
+
+int tmpc_scenario_empty_stages(tmpc_handle *h, void *d_count)
+{
+    if (!h || !d_count) return TMPC_ERR_INVALID;
+    if (!h->scn_sample || h->scn_B != h->B || h->B <= 0) { h->err = "tmpc_scenario_empty_stages: the scenario rows of the current batch were not built by tmpc_scenario_halfspaces"; return TMPC_ERR_INVALID; }
+    TMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    const size_t units = (size_t)h->B * h->d.N;
+    TMPC_HIP_CHECK(h, hipMemcpyAsync(d_count, h->scn_sample + units * h->scn_rows + 1 + units, sizeof(int) * (size_t)h->B, hipMemcpyDeviceToDevice, h->stream));
     return TMPC_OK;
 }
 
@@ -1408,7 +1549,7 @@ int tmpc_debug_profile(tmpc_handle *h, int64_t *cycles, int32_t n_phases)
     // (a compact handle is profiled through the fast kernel of its shape: same phases and arithmetic, one wave per SIMD)
     hipLaunchKernelGGL(pk, dim3(h->B), dim3(h->threads), h->fast ? h->lds_bytes_fast : h->lds_bytes, h->stream, h->d, h->B,
                        h->xinit, h->x0, h->params, h->xtraj, h->utraj, h->pobj, h->exit_code, h->qp_status,
-                       h->sqp_iter, h->res_eq, h->qp_iter, dp, tmpc::StateIO{nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr});
+                       h->sqp_iter, h->res_eq, h->qp_iter, dp, tmpc::StateIO{nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr});
     TMPC_HIP_CHECK(h, hipGetLastError());
     TMPC_HIP_CHECK(h, hipStreamSynchronize(h->stream));
     std::vector<long long> host(n);

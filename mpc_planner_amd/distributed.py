@@ -19,6 +19,37 @@ def shard_bounds(total, world_size, rank):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def max_shard(total, world_size):
+    """Size of the largest shard of shard_bounds(total, world_size, .): what uneven shards are padded to for the collective."""
+    return -(-total // world_size)
+
+
+EMPTY_EXIT_CODE = -999          # EXIT_CODE_NOT_OPTIMIZED_YET (controller_module.h:13): a padding record is never eligible
+
+
+def pad_records(local_records_tensor, n_sets, n_local, n_max):
+    """Uneven shards: all-gather needs equal contributions, so a rank whose shard has n_local < n_max trajectories per set appends
+    (n_max - n_local) records per set that can never win (exit code -999, objective +inf).  local_records_tensor: int64
+    [n_sets * n_local][2]; returns [n_sets * n_max][2]."""
+    import torch
+    if n_local == n_max:
+        return local_records_tensor
+    pad = np.zeros((n_sets, n_max - n_local), RECORD_DTYPE)
+    pad["objective"] = np.inf; pad["exit_code"] = EMPTY_EXIT_CODE; pad["guidance_id"] = -1
+    pad_t = torch.from_numpy(pad.view(np.int64).reshape(n_sets, n_max - n_local, 2).copy()).to(local_records_tensor.device)
+    return torch.cat([local_records_tensor.view(n_sets, n_local, 2), pad_t], dim=1).reshape(n_sets * n_max, 2).contiguous()
+
+
+def padded_to_global(best, total, world_size):
+    """Index in the padded numbering (rank * max_shard + t, what the selection over padded records returns) -> index in the
+    scene's own numbering (shard_bounds(rank).lo + t); -1 stays -1.  The map is monotone, so 'lowest index wins ties' is kept."""
+    best = np.asarray(best)
+    n_max = max_shard(total, world_size)
+    rk, t = np.divmod(np.maximum(best, 0), n_max)
+    lo = np.array([shard_bounds(total, world_size, int(r))[0] for r in rk.ravel()]).reshape(rk.shape)
+    return np.where(best < 0, -1, lo + t).astype(np.int32)
+
+
 def pack_records_host(pobj, exit_code, guidance_id=None, weight=None):
     """Host mirror of tmpc_pack_records (SolverResult bookkeeping, guidance_constraints.cpp:344-360)."""
     rec = np.zeros(len(pobj), RECORD_DTYPE)

@@ -225,13 +225,16 @@ def scenario_halfspaces(x0, samples, radius, n_rows=24, return_index=False):
     their intersection polygon, and only the halfspaces that form its boundary are constraints of the optimisation).  Exact here:
     `polygon_edges` keeps precisely the non-redundant halfspaces; if the polygon has more than n_rows edges (the solver's capacity)
     the n_rows closest to p are kept (lowest sample index on ties), unused slots stay dummies.  If the halfspaces contradict each
-    other (the guess sits in the overlap of inflated discs on opposite sides: an empty polygon) there is no edge and every slot is a
-    dummy -- the stage is then unconstrained by the scenarios, which is what the definition gives, not a repair.
+    other (the guess sits in the overlap of inflated discs on opposite sides: an EMPTY polygon) there is no edge; leaving the stage
+    unconstrained would certify the most dangerous geometry as safe, so such a stage keeps the n_rows closest halfspaces of all samples
+    (contradictory rows: the QP is infeasible or pays slack) and is reported in `empty` (advisor finding, round 2).
     x0 [N+1][nv]; samples [M][S_cen][N][2] (index k-1 for stage k).  Returns a1, a2, b [N][n_rows] with NaN = dummy; rows in order of
-    increasing distance.  return_index: also the flat sample index m * S_cen + s behind each row ([N][n_rows], -1 = dummy)."""
+    increasing distance.  return_index: also the flat sample index m * S_cen + s behind each row ([N][n_rows], -1 = dummy) and
+    empty [N] (bool: the stage's polygon was empty)."""
     N = x0.shape[0] - 1
     a1 = np.full((N, n_rows), np.nan); a2 = np.full((N, n_rows), np.nan); b = np.full((N, n_rows), np.nan)
     which = np.full((N, n_rows), -1, np.int32)
+    empty = np.zeros(N, bool)
     for k in range(1, N):
         p = x0[k, [IDX["x"], IDX["y"]]]
         o = samples[:, :, k - 1, :].reshape(-1, 2)
@@ -240,12 +243,14 @@ def scenario_halfspaces(x0, samples, radius, n_rows=24, return_index=False):
         ax = diff[:, 0] / dist; ay = diff[:, 1] / dist
         dm = dist - radius
         idx = np.nonzero(polygon_edges(ax, ay, dm))[0]
+        if len(idx) == 0 and len(dm) > 0:                                  # empty polygon: the closest halfspaces of all samples
+            idx = np.arange(len(dm)); empty[k] = True
         idx = idx[np.argsort(dm[idx], kind="stable")][:n_rows]             # closest first; stable: lowest sample index on ties
         m = len(idx)
         a1[k, :m] = ax[idx]; a2[k, :m] = ay[idx]
         b[k, :m] = ax[idx] * o[idx, 0] + ay[idx] * o[idx, 1] - radius
         which[k, :m] = idx
-    return (a1, a2, b, which) if return_index else (a1, a2, b)
+    return (a1, a2, b, which, empty) if return_index else (a1, a2, b)
 
 
 def scenario_support(xtraj, params, pm, row_sample, n_scenarios, tol=1e-6, prefix="disc_0_scenario_constraint"):

@@ -41,7 +41,7 @@ EXPORTS = ["tmpc_default_dims", "tmpc_default_dims_ex", "tmpc_create", "tmpc_des
            "tmpc_select_best_records", "tmpc_enable_timing", "tmpc_get_timings", "tmpc_debug_profile",
            "tmpc_linearize_topology", "tmpc_scenario_halfspaces", "tmpc_scenario_support", "tmpc_warmstart", "tmpc_init_with_guidance",
            "tmpc_debug_get_x0", "tmpc_debug_get_params", "tmpc_set_throughput_mode", "tmpc_solve_iterations",
-           "tmpc_reset_multipliers", "tmpc_get_stream"]
+           "tmpc_reset_multipliers", "tmpc_get_stream", "tmpc_kernel_info", "tmpc_set_slots", "tmpc_copy_state", "tmpc_scenario_empty_stages"]
 
 class TmpcError(RuntimeError):
     pass
@@ -82,6 +82,10 @@ def load_library(path=None):
     lib.tmpc_solve_iterations.argtypes = [vp, C.c_int32, C.c_int32]
     lib.tmpc_reset_multipliers.argtypes = [vp]
     lib.tmpc_get_stream.argtypes = [vp, C.POINTER(vp)]
+    lib.tmpc_kernel_info.argtypes = [vp, C.c_char_p, C.c_int32]
+    lib.tmpc_set_slots.argtypes = [vp, vp]
+    lib.tmpc_scenario_empty_stages.argtypes = [vp, vp]
+    lib.tmpc_copy_state.argtypes = [vp, vp]
     lib.tmpc_synchronize.argtypes = [vp]
     lib.tmpc_get.argtypes = [vp] + [vp] * 8
     lib.tmpc_select_best.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, C.POINTER(C.c_int32)]
@@ -181,15 +185,34 @@ class BatchedSolver:
             self._check(rc, "tmpc_set_latency_mode")
         return rc == 0
 
-    KEEP_ITERATE, KEEP_MULTIPLIERS, COMPLETE = 1, 2, 4
+    KEEP_ITERATE, KEEP_MULTIPLIERS, COMPLETE, NEW_SOLVE = 1, 2, 4, 8
 
-    def solve_iterations(self, n_iter, keep_iterate=False, keep_multipliers=False, complete=True, sync=True):
+    def solve_iterations(self, n_iter, keep_iterate=False, keep_multipliers=False, complete=True, sync=True, new_solve=False):
         """n_iter RTI iterations per trajectory slot from the state the handle keeps (tmpc_solve_iterations): the reference's
         initializeOneIteration / solveOneIteration / completeOneIteration protocol and multipliers carried across ticks."""
-        flags = (self.KEEP_ITERATE if keep_iterate else 0) | (self.KEEP_MULTIPLIERS if keep_multipliers else 0) | (self.COMPLETE if complete else 0)
+        flags = (self.KEEP_ITERATE if keep_iterate else 0) | (self.KEEP_MULTIPLIERS if keep_multipliers else 0) | (self.COMPLETE if complete else 0) \
+            | (self.NEW_SOLVE if new_solve else 0)      # new_solve: first call of a new Solver::solve(): loop exits of the previous solve do not carry over
         self._check(self.lib.tmpc_solve_iterations(self._h, int(n_iter), flags), "tmpc_solve_iterations")
         if sync:
             self.synchronize()
+
+    def set_slots(self, slots):
+        """State slot of every entry of the current batch (tmpc_set_slots); None: entry b uses slot b."""
+        if slots is None:
+            self._check(self.lib.tmpc_set_slots(self._h, None), "tmpc_set_slots")
+            return
+        a = np.ascontiguousarray(slots, np.int32)
+        assert a.size == self.B
+        self._check(self.lib.tmpc_set_slots(self._h, a.ctypes.data_as(C.c_void_p)), "tmpc_set_slots")
+
+    def copy_state_from(self, other):
+        self._check(self.lib.tmpc_copy_state(self._h, other._h), "tmpc_copy_state")
+
+    def kernel_info(self):
+        """Which solve kernel the handle dispatches and how it is launched (text)."""
+        buf = C.create_string_buffer(512)
+        n = self.lib.tmpc_kernel_info(self._h, buf, 512)
+        return buf.value.decode() if n >= 0 else ""
 
     def stream_ptr(self):
         """hipStream_t of the handle (as an integer), e.g. for torch.cuda.ExternalStream."""
@@ -275,6 +298,15 @@ class BatchedSolver:
         o = out.cpu().numpy()
         return o[0], o[1]
 
+    def scenario_empty_stages(self):
+        """Per trajectory: the stages whose sampled halfspaces contradicted each other in the last scenario_halfspaces (empty polygon;
+        such a stage keeps the closest halfspaces and the trajectory is not eligible)."""
+        import torch
+        out = torch.zeros(self.B, dtype=torch.int32, device=f"cuda:{self.device}")
+        self._check(self.lib.tmpc_scenario_empty_stages(self._h, C.c_void_p(out.data_ptr())), "tmpc_scenario_empty_stages")
+        self.synchronize()
+        return out.cpu().numpy()
+
     def warmstart(self, d_state, d_mode=None, d_src=None, deceleration=3.0):
         """Device warm start of the next tick from the solution held by the handle (raw device pointers)."""
         self._check(self.lib.tmpc_warmstart(self._h, C.c_void_p(d_state), C.c_void_p(d_mode) if d_mode else None,
@@ -354,7 +386,8 @@ def optimize_scenarios(solver, xinit, x0, params, n_iter=None, scenario=None):
     scenario = dict(d_samples, n_pts, n_rows, d_scene_of, d_state_x, radius, n_scenarios[, disc_offset, tol, max_support]) builds
     the rows on device from the sampled scenarios (tmpc_scenario_halfspaces, scenario_module.update + setParameters) and adds the
     support bookkeeping of ScenarioSolver (scenario_constraints.h:38-40): res["support"], res["active_rows"], and with max_support
-    res["scenario_status"] (0 = within the bound the sample size was chosen for, 1 = support exceeded: no certificate) -- a solver
+    res["scenario_status"] (0 = within the bound the sample size was chosen for, 1 = support exceeded: no certificate, 2 = a stage's
+    scenario halfspaces contradicted each other -- an empty polygon; res["empty_polygon_stages"] counts them) -- a solver
     with status 1 is then not eligible as the best one."""
     n_iter = solver.dims.n_sqp if n_iter is None else int(n_iter)
     solver.set_batch(xinit, x0, params)                               # *solver = *_solver; setParameters; loadWarmstart
@@ -368,9 +401,14 @@ def optimize_scenarios(solver, xinit, x0, params, n_iter=None, scenario=None):
     eligible = res["exit_code"] == 1
     if scenario is not None:
         res["support"], res["active_rows"] = solver.scenario_support(scenario["n_scenarios"], scenario.get("tol", 1e-6))
+        res["empty_polygon_stages"] = solver.scenario_empty_stages()
+        status = np.zeros(len(res["pobj"]), np.int32)
         if scenario.get("max_support") is not None:
-            res["scenario_status"] = (res["support"] > scenario["max_support"]).astype(np.int32)
-            eligible = eligible & (res["scenario_status"] == 0)
+            status[res["support"] > scenario["max_support"]] = 1
+        status[res["empty_polygon_stages"] > 0] = 2                  # contradictory scenario halfspaces somewhere on the horizon: never eligible
+        if scenario.get("max_support") is not None or (status == 2).any():
+            res["scenario_status"] = status
+        eligible = eligible & (status == 0)
     best, lowest = -1, 1e9
     for i in range(len(res["pobj"])):
         if eligible[i] and res["pobj"][i] < lowest:

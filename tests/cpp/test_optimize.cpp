@@ -82,6 +82,15 @@ int main(int argc, char **argv)
     for (int k = 0; k <= N; k++)
         std::printf("x %d %.17g %.17g %.17g %.17g %.17g\n", k, solver->getOutput(k, "x"), solver->getOutput(k, "y"), solver->getOutput(k, "psi"),
                     solver->getOutput(k, "v"), solver->getOutput(k, "spline"));
+    // next tick's bookkeeping (:106-108, 192-250): the same trajectories arrive in reverse order plus one new class -- every known class finds
+    // the planner that solved it last tick (existing_guidance: the `warmstart_with_mpc_solution` branch, :310, is reachable)
+    {
+        std::vector<GuidanceTrajectory> next_tick(guidance.rbegin(), guidance.rend());
+        next_tick.front().topology_class = 1000;                             // a class nobody solved
+        guidance_constraints.setGuidanceTrajectories(next_tick);
+        for (auto &kv : guidance_constraints.guidanceToPlannerMap()) std::printf("map %d %d\n", kv.first, kv.second);
+        for (auto &pl : guidance_constraints.planners_) std::printf("taken %d %d %d\n", pl.id, (int)pl.taken, (int)pl.existing_guidance);
+    }
     // the parameter rows the best planner was solved with (a3-a5 on the C++ side)
     for (int k = 0; k < N; k++) {
         std::printf("p %d", k);

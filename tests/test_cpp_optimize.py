@@ -82,6 +82,16 @@ def test_cpp_optimize_matches_python_path(tmp_path):
     assert best == py_best and exit_code == g["exit_code"][py_best]
     np.testing.assert_allclose(ps, sc["params"][py_best], rtol=0, atol=1e-12)        # a3-a5 built in C++ == numpy mirrors
     np.testing.assert_allclose(xs, g["xtraj"][py_best], rtol=0, atol=1e-7)
+    # mapGuidanceTrajectoriesToPlanners (guidance_constraints.cpp:192-250) in C++ == the numpy restatement, on the next tick's trajectories
+    from mpc_planner_amd import modules as md
+    ids = [int(pl[9]) for pl in planners]                               # result.guidance_ID of every planner after this tick
+    classes = list(range(B))[::-1]; classes[0] = 1000                   # the same classes in reverse order, the first one unknown
+    want_map, want_taken, want_existing = md.map_guidance_trajectories_to_planners(ids, classes)
+    got_map = {int(l.split()[1]): int(l.split()[2]) for l in lines if l.startswith("map ")}
+    got_flags = {int(l.split()[1]): (bool(int(l.split()[2])), bool(int(l.split()[3]))) for l in lines if l.startswith("taken ")}
+    assert got_map == want_map
+    assert [got_flags[p] for p in range(B + 1)] == list(zip(want_taken, want_existing))
+    assert sum(want_existing) == B - 1                                  # every known class found its planner
 
 
 # ---- SH-MPC: ScenarioConstraints::optimize (scenario_constraints.cpp:58-108), C++ batched restatement vs the Python driver ----

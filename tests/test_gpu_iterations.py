@@ -106,3 +106,87 @@ def test_reset_multipliers_and_other_iteration_budget():
     s.solve_iterations(4, keep_multipliers=True); c = s.get()          # after the reset: the fresh result again, bitwise
     np.testing.assert_array_equal(c["xtraj"], a["xtraj"])
     s.close()
+
+
+@pytest.mark.parametrize("mode", ["wave", "lanes"])
+def test_new_solve_reopens_loops_that_ended(mode):
+    """Advisor (round 2): a slot whose last QP stopped with qp_status != 0 must iterate again in the NEXT solve() even without a
+    loadWarmstart -- the reference's loop exit (:105-106) is local to one solve().  Without TMPC_ITER_NEW_SOLVE the slot would be
+    skipped and the previous trajectory returned as a fresh result."""
+    from mpc_planner_amd import scenes
+    sc = scenes.make_scene(7, N=20, M=8, B=64)
+    s = _solver(mode, 64, N=20, S=5, n_lin=8, M=8, qp_iter_max=6)          # a low QP iteration limit: some loops end early (qp_status 2)
+    s.set_batch(sc["xinit"], sc["x0"], sc["params"]); s.solve_iterations(10); a = s.get()
+    early = a["qp_status"] != 0
+    assert early.any() and (~early).any()
+    # second solve() of the same Solvers, iterate kept (no loadWarmstart): every slot must run again
+    s.solve_iterations(10, keep_iterate=True, keep_multipliers=True, new_solve=True); b = s.get()
+    assert (b["sqp_iter"] >= 1).all()
+    moved = np.abs(b["xtraj"] - a["xtraj"]).max(axis=(1, 2))
+    assert (moved[early & (a["exit_code"] == 1)] > 0).all()                # they iterated: the trajectory changed
+    # without the flag the early slots are left as they are (the documented keep-call behaviour)
+    s.set_batch(sc["xinit"], sc["x0"], sc["params"]); s.solve_iterations(10); a2 = s.get()
+    s.solve_iterations(10, keep_iterate=True, keep_multipliers=True); c = s.get()
+    np.testing.assert_array_equal(c["xtraj"][early], a2["xtraj"][early])
+    s.close()
+
+
+def test_grown_batch_starts_new_slots_fresh_and_evaluation_call_keeps_statistics():
+    """Advisor (round 2): (i) state arrays are zeroed and a batch larger than any before starts its new slots like fresh capsules
+    whatever the keep-flags say; (ii) an n_iter = 0 'complete' call keeps the iteration statistics of the iterations before it."""
+    from mpc_planner_amd import scenes
+    sc = scenes.make_scene(11, N=20, M=8, B=32)
+    s = _solver("wave", 32, N=20, S=5, n_lin=8, M=8)
+    s.set_batch(sc["xinit"][:8], sc["x0"][:8], sc["params"][:8]); s.solve_iterations(3)
+    s.set_batch(sc["xinit"], sc["x0"], sc["params"])
+    s.solve_iterations(3, keep_iterate=True, keep_multipliers=True); grown = s.get()       # slots 8.. have no state: fresh
+    f = _solver("wave", 32, N=20, S=5, n_lin=8, M=8)
+    f.set_batch(sc["xinit"], sc["x0"], sc["params"]); f.solve_iterations(3); fresh = f.get()
+    for k in ("xtraj", "utraj", "pobj", "exit_code", "qp_status"):
+        np.testing.assert_array_equal(grown[k][8:], fresh[k][8:], err_msg=k)
+    assert np.isfinite(grown["xtraj"]).all()
+    # (ii)
+    f.solve_iterations(0, keep_iterate=True, keep_multipliers=True, complete=True); ev = f.get()
+    np.testing.assert_array_equal(ev["sqp_iter"], fresh["sqp_iter"]); np.testing.assert_array_equal(ev["qp_iter_total"], fresh["qp_iter_total"])
+    np.testing.assert_array_equal(ev["xtraj"], fresh["xtraj"])
+    s.close(); f.close()
+
+
+def test_slot_map_keys_the_state_by_slot_not_by_batch_position():
+    """tmpc_set_slots (round-2 verdict: per-caller batches with one state slot per Solver): a Solver keeps ITS multipliers whatever
+    position it has in a tick's batch and whatever subset of the Solvers the tick launches."""
+    from mpc_planner_amd import scenes
+    sc = scenes.make_scene(5, N=20, M=8, B=16)
+    # reference: every trajectory alone on the identity map, two ticks with carried multipliers
+    r = _solver("wave", 16, N=20, S=5, n_lin=8, M=8)
+    r.set_batch(sc["xinit"], sc["x0"], sc["params"]); r.solve_iterations(10, keep_multipliers=True, new_solve=True); t1 = r.get()
+    r.solve_iterations(10, keep_multipliers=True, new_solve=True); t2 = r.get()
+    assert np.abs(t2["xtraj"] - t1["xtraj"]).max() > 1e-9                     # carried multipliers matter on these scenes
+    # same Solvers through a slot map: tick 1 launches all 16 in a permuted order, tick 2 only a subset, again permuted
+    s = _solver("wave", 16, N=20, S=5, n_lin=8, M=8)
+    perm = np.random.default_rng(3).permutation(16)
+    s.set_batch(sc["xinit"][perm], sc["x0"][perm], sc["params"][perm]); s.set_slots(perm)     # batch entry b is Solver perm[b]
+    s.solve_iterations(10, keep_multipliers=True, new_solve=True); a = s.get()
+    np.testing.assert_array_equal(a["xtraj"], t1["xtraj"][perm])
+    sub = np.array([11, 2, 7, 14, 0])
+    s.set_batch(sc["xinit"][sub], sc["x0"][sub], sc["params"][sub]); s.set_slots(sub)
+    s.solve_iterations(10, keep_multipliers=True, new_solve=True); b = s.get()
+    np.testing.assert_array_equal(b["xtraj"], t2["xtraj"][sub])                # each got its OWN first-tick multipliers
+    np.testing.assert_array_equal(b["pobj"], t2["pobj"][sub])
+    # a slot nothing was stored in starts fresh whatever the keep-flags say; clearing the map restores entry b <-> slot b
+    f = _solver("wave", 16, N=20, S=5, n_lin=8, M=8)
+    f.set_batch(sc["xinit"][:4], sc["x0"][:4], sc["params"][:4]); f.set_slots([12, 13, 14, 15])
+    f.solve_iterations(10, keep_iterate=True, keep_multipliers=True); c = f.get()
+    np.testing.assert_array_equal(c["xtraj"], t1["xtraj"][:4])
+    f.set_slots(None)
+    f.solve_iterations(10, keep_multipliers=True); d = f.get()                   # slots 0..3: never stored -> fresh again
+    np.testing.assert_array_equal(d["xtraj"], t1["xtraj"][:4])
+    # copying the state to a larger handle keeps every slot (a caller that outgrew its handle)
+    g = _solver("wave", 32, N=20, S=5, n_lin=8, M=8)
+    g.copy_state_from(r)
+    g.set_batch(sc["xinit"], sc["x0"], sc["params"])
+    g.solve_iterations(10, keep_multipliers=True, new_solve=True); e = g.get()
+    r.solve_iterations(10, keep_multipliers=True, new_solve=True); t3 = r.get()
+    np.testing.assert_array_equal(e["xtraj"], t3["xtraj"])
+    for x in (r, s, f, g):
+        x.close()

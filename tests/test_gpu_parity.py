@@ -547,7 +547,7 @@ def test_optimize_scenarios_with_device_rows_and_support_bound():
     s.close()
 
 
-@pytest.mark.parametrize("shape", ["ragged", "ring", "big_ring", "one_sided", "duplicates", "large", "tiny"])
+@pytest.mark.parametrize("shape", ["ragged", "ring", "big_ring", "one_sided", "duplicates", "large", "tiny", "contradictory"])
 def test_device_polygon_edge_cases(shape):
     """The polygon kernel on sample sets the scenes do not produce: a sample count that is no multiple of the workgroup, more edges
     than rows (truncation by distance; with 1500 samples on the ring the candidates overflow the first pass's short list and the
@@ -562,7 +562,7 @@ def test_device_polygon_edge_cases(shape):
     rng = np.random.default_rng(17)
     x0 = sc["x0"].copy()
     p_mid = x0[:, :, 2:4].mean(axis=(0, 1))
-    n = dict(ragged=777, ring=96, big_ring=1500, one_sided=1024, duplicates=300, large=3000, tiny=5)[shape]
+    n = dict(ragged=777, ring=96, big_ring=1500, one_sided=1024, duplicates=300, large=3000, tiny=5, contradictory=400)[shape]
     if shape in ("ring", "big_ring"):
         th = rng.uniform(0, 2 * np.pi, (N, n))
         o = np.stack([np.cos(th), np.sin(th)], axis=-1) * 9.0 + p_mid                  # far: nearly every sample is an edge
@@ -576,6 +576,10 @@ def test_device_polygon_edge_cases(shape):
     for k in range(1, N):
         d = np.linalg.norm(o[k - 1][None] - x0[:, k, None, 2:4], axis=2).min(axis=0)
         o[k - 1][d < 0.8] += 40.0
+    if shape == "contradictory":
+        # trajectory 3's guess at stages 5..7 sits inside inflated discs on opposite sides: an EMPTY polygon there (advisor, round 2)
+        for k in (5, 6, 7):
+            o[k - 1, :6] = x0[3, k, 2:4] + np.array([[0.3, 0.0], [-0.3, 0.0], [0.31, 0.02], [-0.31, 0.02], [0.0, 0.35], [0.0, -0.35]])
     radius = 0.725
     want = sc["params"].copy()
     for b in range(B):
@@ -598,6 +602,16 @@ def test_device_polygon_edge_cases(shape):
     s.scenario_halfspaces(t_s.data_ptr(), n, 24, t_sc.data_ptr(), t_sx.data_ptr(), radius)
     got = s.debug_get_params()
     assert np.array_equal(got, want)
+    empty_dev = s.scenario_empty_stages()
+    empty_host = np.array([md.scenario_halfspaces(x0[b], o.transpose(1, 0, 2)[None], radius, 24, return_index=True)[4].sum() for b in range(B)])
+    assert np.array_equal(empty_dev, empty_host)
+    if shape == "contradictory":
+        assert empty_dev[3] >= 3                               # flagged, and its rows are real halfspaces, not dummies
+        jb = pm.index("disc_0_scenario_constraint_0_b")
+        assert (got[3, 5:8, jb] < 50.0).all()                   # (a dummy row has b = x + 100)
+        s.solve_iterations(10)
+        g = s.get()                                            # contradictory rows: the QP cannot converge -- the solve says so (failure, or a
+        assert g["exit_code"][3] != 1 or g["qp_status"][3] != 0   # QP at its iteration limit) instead of returning a "safe" plan silently
     s.close()
 
 

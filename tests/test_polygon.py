@@ -137,7 +137,8 @@ def test_scenario_support_counts_distinct_active_scenarios():
     smp[1, :, :, 1] = 3.0 + 0.1 * np.arange(S_cen)[:, None]; smp[1, 3, :, 1] = 2.0
     smp[1, 5, :, :] = [-2.5, 0.0]                              # scenario 5: an obstacle 1 sample behind the robot
     x0 = np.zeros((N + 1, 8))
-    a1, a2, b, which = md.scenario_halfspaces(x0, smp, RADIUS, 24, return_index=True)
+    a1, a2, b, which, empty = md.scenario_halfspaces(x0, smp, RADIUS, 24, return_index=True)
+    assert not empty.any()
     assert sorted(which[1][which[1] >= 0].tolist()) == [3, S_cen + 3, S_cen + 5]
     params = np.zeros((N, pm.length()))
     md.halfspace_rows_set_parameters(pm, params, 0.0, (a1, a2, b), "disc_0_scenario_constraint", 24)
@@ -178,3 +179,23 @@ def test_random_geometries_against_the_definition():
         assert np.array_equal(e, _brute(ax, ay, dm)), case
         n_nonempty += bool(e.any())
     assert n_nonempty >= 150          # (a guess inside overlapping discs on opposite sides has an EMPTY polygon: no edge, all rows dummies)
+
+
+def test_empty_polygon_keeps_the_closest_halfspaces_and_is_reported():
+    """Advisor (round 2): a guess inside the overlap of inflated discs on opposite sides has contradictory halfspaces -- an empty
+    polygon.  The stage must not be left unconstrained (that would certify the most dangerous geometry as safe): it keeps the n_rows
+    closest halfspaces (infeasible rows: the QP fails or pays slack) and the stage is flagged."""
+    N, S_cen = 3, 6
+    smp = np.zeros((2, S_cen, N, 2))
+    smp[0, :, :, 0] = 0.3 + 0.01 * np.arange(S_cen)[:, None]          # obstacle 0: 0.3 m ahead -> margins -0.4 (inside the inflated disc)
+    smp[1, :, :, 0] = -0.3 - 0.01 * np.arange(S_cen)[:, None]         # obstacle 1: 0.3 m behind: contradicts obstacle 0
+    x0 = np.zeros((N + 1, 8))
+    a1, a2, b, which, empty = md.scenario_halfspaces(x0, smp, RADIUS, 4, return_index=True)
+    assert empty[1:].all() and not empty[0]
+    assert which[1].tolist() == [0, S_cen, 1, S_cen + 1]                 # closest first, lowest sample index on ties
+    assert np.isfinite(a1[1]).all() and (b[1] < 0).all()                 # rows that exclude the guess itself
+    # a feasible neighbour geometry is unaffected
+    smp[1, :, :, 0] = -3.0
+    smp[0, :, :, 0] = 3.0
+    _, _, _, which2, empty2 = md.scenario_halfspaces(x0, smp, RADIUS, 4, return_index=True)
+    assert not empty2.any() and (which2[1] >= 0).sum() == 2
