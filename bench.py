@@ -156,6 +156,9 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cfg2")
     ap.add_argument("--no-lanes", action="store_true", help="skip the lane-per-trajectory variant's measurement")
     ap.add_argument("--no-tight", action="store_true", help="skip the qp_tol = 1e-9 leg")
+    ap.add_argument("--share-of", type=int, default=0,
+                    help="one-set workloads on ONE GPU: solve rank 0's share of a split over this many ranks (what one GPU of such a node "
+                         "does, without the collective) instead of the whole set")
     ap.add_argument("--gen-workers", type=int, default=0, help="processes that generate the scenes (0 = all usable CPUs; 1 = no fork, e.g. under a profiler)")
     ap.add_argument("--scene-cache", default="", help="npz file to keep the generated batch in (repeated profiler passes)")
     ap.add_argument("--cpu-scenes", type=int, default=16)
@@ -177,7 +180,7 @@ def main():
     from mpc_planner_amd import scenes
     if wl.get("one_set"):
         # one set split over the ranks: every rank builds the same scene and keeps its contiguous share
-        per_rank = TRAJ_SET // world
+        per_rank = TRAJ_SET // (a.share_of if (a.share_of > 0 and world == 1) else world)
         full = scenes.make_scene(7, B=TRAJ_SET, **wl["scene"])
         sl = slice(rank * per_rank, (rank + 1) * per_rank)
         batch = {k: full[k][sl] for k in ("xinit", "x0", "params", "guidance_id")}
@@ -359,7 +362,8 @@ def main():
             "metric": "MPC solves/s (Jackal N=20, 8 obs)" if a.workload == "cfg2" else f"MPC solves/s ({a.workload})", "value": value, "unit": "solves/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if wl.get("one_set") else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{wl['what']}; {n_sets} set(s) x {traj_local} = {B} trajectories per launch per GPU, n_sqp=10, qp_tol=1e-5",
+            "config": {"workload": f"{wl['what']}; {n_sets} set(s) x {traj_local} = {B} trajectories per launch per GPU, n_sqp=10, qp_tol=1e-5"
+                                   + (f" (rank 0's share of a {a.share_of}-rank split, solved on one GPU without the collective)" if a.share_of > 0 and world == 1 else ""),
                        "trajectories_per_launch_per_gpu": B, "scenes_per_launch": n_sets,
                        "success_fraction": float(ok.mean()), "mean_sqp_iter": n_sqp_mean, "mean_ipm_iter_per_qp": ipm_per_qp,
                        "value_counts": "successful solves (exit_code == 1) only",
