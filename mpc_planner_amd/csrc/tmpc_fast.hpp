@@ -108,9 +108,12 @@ struct Solo {
     __device__ __forceinline__ void sync() const { __syncthreads(); }
     __device__ __forceinline__ bool any(bool active) const { return active; }
     template <int NTH, bool CP>
-    __device__ __forceinline__ bool factor(const Lds &L, const Dims &d, int tl, int sw, int) const { return riccati_factor<NTH, CP>(L, d, tl, sw); }
+    __device__ __forceinline__ bool factor(const Lds &L, const Dims &d, int tl, int sw, int) const { return riccati_factor<NTH, CP, true>(L, d, tl, sw); }   // (the predictor's backward sweep rides along)
     template <int NTH, bool CP>
-    __device__ __forceinline__ void solve(const Lds &L, const Dims &d, int tl, int sw, int, int, bool) const { riccati_solve<NTH, CP>(L, d, tl, sw); }
+    __device__ __forceinline__ void solve(const Lds &L, const Dims &d, int tl, int sw, int, int phase, bool) const
+    {
+        if (phase == 1) riccati_forward<NTH, CP>(L, d, tl, sw); else riccati_solve<NTH, CP>(L, d, tl, sw);
+    }
 };
 
 template <int NLIN, int MM, int LPS, int NTH, bool CP, typename PF, typename TEAM = Solo>
@@ -718,7 +721,7 @@ struct Team {
         if (w == (3 * it) % NQ) {
             int li; bool wr;
             const Lds Lrow = row_view(d, &li, &wr);
-            const bool bad = riccati_factor_rows<CP>(Lrow, d, li, wr);
+            const bool bad = riccati_factor_rows<CP, true>(Lrow, d, li, wr);
             const unsigned long long m = __ballot(bad && wr);
             const int lane = lane_now();
             if (lane < NQ) flags[NQ + lane] = ((m >> (16 * lane)) & 0xffffull) ? 1 : 0;
@@ -729,15 +732,16 @@ struct Team {
     template <int NTH, bool CP>
     __device__ __forceinline__ void solve(const Lds &L, const Dims &d, int tl, int, int it, int phase, bool active) const
     {
-        if (active) riccati_solve_pre(L, d, tl, 64);
+        if (active && phase != 1) riccati_solve_pre(L, d, tl, 64);
         __syncthreads();
         if (w == (3 * it + phase) % NQ) {
             int li; bool wr;
             const Lds Lrow = row_view(d, &li, &wr);
-            riccati_sweeps_rows<CP>(Lrow, d, li, wr, true, [] { wave_sync(); });
+            if (phase == 1) riccati_sweeps_rows<CP, false>(Lrow, d, li, wr, true, [] {});
+            else riccati_sweeps_rows<CP, true>(Lrow, d, li, wr, true, [] { wave_sync(); });
         }
         __syncthreads();
-        if (active) riccati_solve_post(L, d, tl, 64);
+        if (active) { if (phase == 1) riccati_solve_post<true>(L, d, tl, 64); else riccati_solve_post<false>(L, d, tl, 64); }
         wave_sync();
     }
 };

@@ -83,43 +83,78 @@ __device__ __forceinline__ BaLane ba_row4(int N, int i5)          // o0: base of
 // once, one per row: `li` is the lane's index inside its row (li >= 16: idle lane), `L` the LDS view of the row's trajectory
 // (per-lane pointers when rows differ) and `wr` enables the row's stores.  One trajectory per wave (the fast / compact kernels):
 // li = lane, rows 1..3 idle.  Four per wave: the team kernels (tmpc_fast.hpp).
-template <bool CP>
+// VEC (the register-row kernels): the PREDICTOR's right-hand side rides through the factorisation as an extra row.  Lane 7 of the row
+// holds the row [g_u g_x] of the bordered matrix [[F, g], [g^T, .]] (g = gh, the predictor right-hand side, complete before the
+// factorisation starts): it takes part in every column update like the rows below the pivot and never becomes a pivot, so after the
+// stage's Cholesky it is  l = [y0 y1 | lx] = [g_u g_x] L^-T  -- y is what the forward sweep needs, and lx carries the cost-to-go
+// gradient to the next stage (p_k = Lxx lx): there the row's "own column" is the dynamics residual rb and lx joins its G entries,
+// G_l,7 = (Lp^T rb)_l + lx_l, i.e. Lp G_.,7 = P rb + p.  The separate backward vector sweep of the predictor (and its stage-parallel
+// prologue P rb) disappear: one of the five sequential passes over the stages of an interior-point iteration.  Same algebra as the
+// separate sweep; the operations associate differently (rounding-level differences).
+template <bool CP, bool VEC = false>
 __device__ __forceinline__ bool riccati_factor_rows(const Lds &L, const Dims &d, int li, bool wr)
 {
     const int N = d.N;
     const bool rowl = li < NV && wr;
+    const bool vec = VEC && li == NV;                // the right-hand-side row
     const int ls = li < NV ? li : 0;
     const int i5 = li - NU;                          // state index of lanes 2..6
     const double dt = d.dt, hdt2 = d.hdt2;
     bool bad = false;
     double f[NV], hk[NV], ba[NX], dn[8];
     const BaLane bc = ba_column(N, ls);
-    if constexpr (CP) {                                  // constant entries of the own column of [B A]
+    if constexpr (CP && !VEC) {                          // constant entries of the own column of [B A]
 #pragma unroll
         for (int m = 2; m < NX; m++) ba[m] = L.tab[ba_off(N, 0, m, ls)];
     }
+    // VEC: every lane loads hk[] / ba[] through per-lane (base, stride) pairs, so that the extra row reads gh / rb with the same loads
+    const double *hbase = vec ? L.gh : L.Hh;
+    const int hstride = vec ? NV : NP28;
+    const double *bbase = CP ? L.tab : L.BA;
+    int bo[NX], bst[NX];
+    if constexpr (VEC) {
+#pragma unroll
+        for (int m = 0; m < NX; m++) {
+            if constexpr (CP) { bo[m] = vec ? (int)(L.rb - L.tab) + m : ba_off(N, 0, m, ls); bst[m] = vec ? NX : (bo[m] < 8 ? 8 : 0); }
+            else { bo[m] = vec ? (int)(L.rb - L.BA) + m : m * NV + ls; bst[m] = vec ? NX : NX * NV; }
+        }
+    }
     auto load_stage = [&](int k) {
-        const double *Hk = L.Hh + k * NP28;
         // unconditional loads (clamped indices): entries above the diagonal / of idle lanes are never used
+        if constexpr (VEC) {
+            const double *Hk = hbase + k * hstride;
 #pragma unroll
-        for (int j = 0; j < NV; j++) hk[j] = Hk[pidx(ls, j <= ls ? j : ls)];
-        if constexpr (CP) {
-            ba[0] = L.tab[bc.o0 + k * bc.st]; ba[1] = L.tab[bc.o1 + k * bc.st];
+            for (int j = 0; j < NV; j++) hk[j] = Hk[vec ? j : pidx(ls, j <= ls ? j : ls)];
 #pragma unroll
-            for (int q = 0; q < 8; q++) dn[q] = L.tab[k * 8 + q];
+            for (int m = 0; m < NX; m++) ba[m] = bbase[bo[m] + k * bst[m]];
+#pragma unroll
+            for (int q = 0; q < 8; q++) dn[q] = (CP ? L.tab : L.dyn8)[k * 8 + q];
         } else {
-            const double *BA = L.BA + k * NX * NV;
+            const double *Hk = L.Hh + k * NP28;
 #pragma unroll
-            for (int m = 0; m < NX; m++) ba[m] = BA[m * NV + ls];
+            for (int j = 0; j < NV; j++) hk[j] = Hk[pidx(ls, j <= ls ? j : ls)];
+            if constexpr (CP) {
+                ba[0] = L.tab[bc.o0 + k * bc.st]; ba[1] = L.tab[bc.o1 + k * bc.st];
 #pragma unroll
-            for (int q = 0; q < 8; q++) dn[q] = L.dyn8[k * 8 + q];
+                for (int q = 0; q < 8; q++) dn[q] = L.tab[k * 8 + q];
+            } else {
+                const double *BA = L.BA + k * NX * NV;
+#pragma unroll
+                for (int m = 0; m < NX; m++) ba[m] = BA[m * NV + ls];
+#pragma unroll
+                for (int q = 0; q < 8; q++) dn[q] = L.dyn8[k * 8 + q];
+            }
         }
     };
-    // terminal node: Cholesky of the xx-block (rows/cols 2..6)
+    // terminal node: Cholesky of the xx-block (rows/cols 2..6); the extra row starts as g_x of node N
 #pragma unroll
-    for (int j = 0; j < NV; j++) f[j] = (j >= NU) ? L.Hh[N * NP28 + pidx(ls, j <= ls ? j : ls)] : 0.0;
+    for (int j = 0; j < NV; j++) f[j] = (j >= NU) ? (vec ? L.gh[N * NV + j] : L.Hh[N * NP28 + pidx(ls, j <= ls ? j : ls)]) : 0.0;
     load_stage(N - 1);
     bad |= chol_rows<NU>(f, li, nullptr, nullptr);
+    if (vec && wr) {
+#pragma unroll
+        for (int l = 0; l < NX; l++) L.pr[N * NX + l] = f[NU + l];          // lx of node N
+    }
     for (int k = N - 1; k >= 0; k--) {
         // broadcast Lp (lower 5x5 of the factor of stage k+1) to every lane of the row
         double Lp[NX][NX];
@@ -144,7 +179,7 @@ __device__ __forceinline__ bool riccati_factor_rows(const Lds &L, const Dims &d,
             double acc = 0.0;
 #pragma unroll
             for (int m = l; m < NX; m++) acc += Lp[m][l] * ba[m];
-            Go[l] = acc;
+            Go[l] = (VEC && vec) ? acc + f[NU + l] : acc;        // the extra row: (Lp^T rb)_l + lx_l of stage k + 1
         }
         const double Xa = dn[D8_XA], Xw = dn[D8_XW], Xp = dn[D8_XP], Xv = dn[D8_XV];
         const double Ya = dn[D8_YA], Yw = dn[D8_YW], Yp = dn[D8_YP], Yv = dn[D8_YV];
@@ -188,13 +223,18 @@ __device__ __forceinline__ bool riccati_factor_rows(const Lds &L, const Dims &d,
             if (li >= NU) { Fb[FB_LXU + 2 * i5] = f[0]; Fb[FB_LXU + 2 * i5 + 1] = f[1]; }
             if (li == 1) { Fb[FB_L10] = f[0]; Fb[FB_R0] = r0; Fb[FB_R1] = r1; }
         }
+        if (vec && wr) {                                           // [y0 y1 | lx] of stage k
+            L.y[k * NU] = f[0]; L.y[k * NU + 1] = f[1];
+#pragma unroll
+            for (int l = 0; l < NX; l++) L.pr[k * NX + l] = f[NU + l];
+        }
     }
     return bad;
 }
 
 // NTH = threads per trajectory: 64, or 128 for the two-wave variant, in which the sweeps run on one wave (the other waits at the
 // closing barrier) and only the stage-parallel loops use all threads.  `sw`: which of the two waves sweeps.
-template <int NTH, bool CP = false>
+template <int NTH, bool CP = false, bool VEC = false>
 __device__ __forceinline__ bool riccati_factor(const Lds &L, const Dims &d, int tid, int sw = 0)
 {
     asm volatile("" : "+v"(tid));                    // opaque per call: lane-derived addresses are not shared with (kept live until) other phases
@@ -202,7 +242,7 @@ __device__ __forceinline__ bool riccati_factor(const Lds &L, const Dims &d, int 
     SWEEP_T0(); SWEEP_COUNT(SP_CALLS_FACTOR);
     if (NTH == 64 || (tid >> 6) == sw) {
         const int lane = tid & 63;
-        const bool bad = riccati_factor_rows<CP>(L, d, lane, true);
+        const bool bad = riccati_factor_rows<CP, VEC>(L, d, lane, true);
         anybad = __any(bad && lane < 16);             // (rows 1..3 of the wave compute on copies: their pivots mean nothing)
         if (NTH > 64 && lane == 0) L.scr[63] = anybad ? 1.0 : 0.0;
     }
@@ -243,6 +283,8 @@ __device__ __forceinline__ void riccati_solve_pre(const Lds &L, const Dims &d, i
         }
     }
 }
+// LX: L.pr holds lx (the fused predictor: p_k = Lxx lx, so dpi_k = Lxx (Lxx^T dx_k + lx_k)) instead of p_k
+template <bool LX = false>
 __device__ __forceinline__ void riccati_solve_post(const Lds &L, const Dims &d, int tid, int nth)
 {
     const int N = d.N;
@@ -250,24 +292,24 @@ __device__ __forceinline__ void riccati_solve_post(const Lds &L, const Dims &d, 
         const int k = kk + 1;
         const double *Lk = L.Hh + k * NP28 + FB_P;
         const double *dxk = L.dv + k * NV + NU;
-        double ll[15], rr[NX], tl[NX];
+        double ll[15], rr[NX], tl[NX], pk[NX];
 #pragma unroll
         for (int e = 0; e < 15; e++) ll[e] = Lk[e];
 #pragma unroll
-        for (int m = 0; m < NX; m++) rr[m] = dxk[m];
+        for (int m = 0; m < NX; m++) { rr[m] = dxk[m]; pk[m] = L.pr[k * NX + m]; }
 #pragma unroll
         for (int l = 0; l < NX; l++) {
             double acc = 0.0;
 #pragma unroll
             for (int m = l; m < NX; m++) acc += ll[m * (m + 1) / 2 + l] * rr[m];
-            tl[l] = acc;
+            tl[l] = LX ? acc + pk[l] : acc;
         }
 #pragma unroll
         for (int i = 0; i < NX; i++) {
             double acc = 0.0;
 #pragma unroll
             for (int l = 0; l <= i; l++) acc += ll[i * (i + 1) / 2 + l] * tl[l];
-            L.dpi[k * NX + i] = acc + L.pr[k * NX + i];
+            L.dpi[k * NX + i] = LX ? acc : acc + pk[i];
         }
     }
 }
@@ -275,7 +317,7 @@ __device__ __forceinline__ void riccati_solve_post(const Lds &L, const Dims &d, 
 // The two sequential sweeps on rows (see riccati_factor_rows for li / L / wr).  Lane j (< 7) of a row = component j of the stage
 // vector [u; x]; the cost-to-go gradient p lives in lanes 2..6.  MID: what separates the sweeps (the forward sweep reads the y the
 // backward sweep stored): a workgroup barrier in the one-trajectory kernels, a wave-level fence when one wave sweeps for a team.
-template <bool CP, typename MID>
+template <bool CP, bool BWD = true, typename MID>
 __device__ __forceinline__ void riccati_sweeps_rows(const Lds &L, const Dims &d, int li, bool wr, bool sweeper, MID mid)
 {
     const int N = d.N;
@@ -283,6 +325,7 @@ __device__ __forceinline__ void riccati_sweeps_rows(const Lds &L, const Dims &d,
     const int ls = li < NV ? li : 0;
     const int i5 = (li >= NU && li < NV) ? li - NU : 0;
     SWEEP_T0();
+    if constexpr (BWD) {                                // (the fused predictor has done this part inside the factorisation)
     if (sweeper) {
     double p = L.gh[N * NV + ls];                       // p_N (lanes 2..6 meaningful)
     {
@@ -340,6 +383,7 @@ __device__ __forceinline__ void riccati_sweeps_rows(const Lds &L, const Dims &d,
     }
     }
     mid();
+    }
     SWEEP_T(SP_SOLVE_BWD);
     // forward sweep; dx_0 = 0 (dx lives in lanes 2..6).  dx+ = A dx + B du + rb with A = I + E (E: columns psi, v).
     if (sweeper) {
@@ -407,9 +451,23 @@ __device__ __forceinline__ void riccati_solve(const Lds &L, const Dims &d, int t
     SWEEP_COUNT(SP_CALLS_SOLVE);
     riccati_solve_pre(L, d, tid, NTH);
     __syncthreads();
-    riccati_sweeps_rows<CP>(L, d, lane, true, sweeper, [] { __syncthreads(); });
+    riccati_sweeps_rows<CP, true>(L, d, lane, true, sweeper, [] { __syncthreads(); });
     __syncthreads();
-    riccati_solve_post(L, d, tid, NTH);
+    riccati_solve_post<false>(L, d, tid, NTH);
+    __syncthreads();
+}
+
+// The rest of the predictor solve after a VEC factorisation: forward sweep + stage-parallel closing loop.
+template <int NTH, bool CP = false>
+__device__ __forceinline__ void riccati_forward(const Lds &L, const Dims &d, int tid, int sw = 1)
+{
+    asm volatile("" : "+v"(tid));
+    const bool sweeper = NTH == 64 || (tid >> 6) == sw;
+    const int lane = NTH == 64 ? tid : (sweeper ? (tid & 63) : 64);
+    SWEEP_COUNT(SP_CALLS_SOLVE);
+    riccati_sweeps_rows<CP, false>(L, d, lane, true, sweeper, [] {});
+    __syncthreads();
+    riccati_solve_post<true>(L, d, tid, NTH);
     __syncthreads();
 }
 
