@@ -241,6 +241,23 @@ int tmpc_scenario_halfspaces(tmpc_handle *h, const void *d_samples, int32_t n_pt
  *   d_support     : i32 [B] out    distinct active scenarios
  *   d_active_rows : i32 [B] out or NULL    active rows */
 int tmpc_scenario_support(tmpc_handle *h, int32_t n_scenarios, double tol, void *d_support, void *d_active_rows);
+/* SH-MPC scenario sampler on device (f-3; scenario_constraints.cpp:121-131: scenario_module.GetSampler().IntegrateAndTranslateToMeanAndVariance
+ * per solver -- the scenario_module is absent, the sampler is restated from the call's inputs): for each of n_solvers solvers (scenes), each of
+ * n_obstacles obstacles and each of n_scenarios scenarios, a mode of the obstacle's Gaussian mixture is drawn from d_prob
+ * [n_solvers][n_obstacles][n_modes] and ONE standard-normal pair places the obstacle on every prediction step of that mode:
+ * o_k = mean_k + R(angle_k) (major_k xi1, minor_k xi2), d_pred [n_solvers][n_obstacles][n_modes][N][6] = (x, y, cos angle, sin angle, major,
+ * minor).  d_samples [n_solvers][N][n_obstacles * n_scenarios][2] is what tmpc_scenario_halfspaces / tmpc_scenario_discard read.
+ * Counter-based (splitmix64 of seed, solver, obstacle, scenario) and free of library transcendentals: mpc_planner_amd.modules.sample_scenarios
+ * reproduces every sample bit for bit. */
+int tmpc_sample_scenarios(tmpc_handle *h, const void *d_pred, const void *d_prob, int32_t n_solvers, int32_t n_obstacles, int32_t n_modes,
+                          int32_t n_scenarios, uint64_t seed, void *d_samples);
+/* Scenario removal: for every trajectory of the current batch the n_discard scenarios that constrain its guess most (smallest clearance
+ * min over obstacles and stages of |o - p_k| - radius; lowest scenario index on ties) are marked; the next tmpc_scenario_halfspaces on this
+ * batch leaves their samples out.  The discarded scenarios count into the bound (modules.scenario_risk(removed = n_discard)).  The policy of
+ * the absent scenario_module is not in the reference tree: this is the greedy rule of the method the reference cites (README.md:22).
+ * tmpc_scenario_discarded copies the marks (uint8 [B][n_scenarios], device). */
+int tmpc_scenario_discard(tmpc_handle *h, const void *d_samples, int32_t n_pts, int32_t n_scenarios, int32_t n_discard, const void *d_scene_of, double radius);
+int tmpc_scenario_discarded(tmpc_handle *h, void *d_mask);
 /* Stages of every trajectory whose sampled halfspaces CONTRADICT each other (an empty polygon: the guess sits in the overlap of inflated
  * discs on opposite sides).  Such a stage keeps the n_rows closest halfspaces instead of dummies -- the QP is then infeasible or pays
  * slack, never silently unconstrained -- and is counted here: d_count int32 [B] (device).  Callers treat a trajectory with a count

@@ -179,6 +179,134 @@ __device__ __forceinline__ unsigned long long poly_key(double x)          // ord
     return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
 }
 
+// ---- SH-MPC scenario sampler (f-3; scenario_constraints.cpp:121-131: every solver draws its own scenarios,
+// scenario_module.GetSampler().IntegrateAndTranslateToMeanAndVariance -- the scenario_module is absent from the reference tree, so this
+// restates what the call's name and its inputs say: unit samples translated to the mean and the integrated variance of every prediction
+// step).  One scenario = one joint draw for all obstacles over the horizon.  For obstacle m of solver (scene) q and scenario s:
+// a mode of the obstacle's Gaussian mixture is drawn from its probabilities, then ONE standard-normal pair (xi1, xi2) places the obstacle
+// on every step k of that mode:  o_k = mean_k + R(angle_k) (major_k xi1, minor_k xi2)  (PredictionStep: position, angle, major / minor
+// radius = the integrated standard deviations, data_types.h:42-54).
+// Counter-based and bit-reproducible: the random bits are a splitmix64 hash of (seed, solver, obstacle, scenario, draw), the normal
+// deviates come from the inverse normal CDF (Acklam's rational approximation, |error| < 1.2e-9) evaluated with +, x, /, sqrt and a
+// logarithm built from the same operations (det_log), no FMA contraction -- so modules.sample_scenarios reproduces every sample
+// bit for bit and the polygon rows of a device-sampled tick can be checked exactly.  The rotation enters as (cos, sin) computed by
+// the caller: trigonometric functions are not reproducible across libraries.
+__host__ __device__ inline unsigned long long smp_mix(unsigned long long z)
+{
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__host__ __device__ inline double smp_uniform(unsigned long long key, unsigned long long ctr)      // in (0, 1), 53 bits
+{
+    const unsigned long long r = smp_mix(key + (ctr + 1ull) * 0x9E3779B97F4A7C15ull);
+    return ((double)(r >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+}
+__device__ inline double det_log(double x)                   // natural logarithm from +, x, / only (x > 0, normal): ~1e-14 relative
+{
+#pragma clang fp contract(off)
+    int e;
+    double m = frexp(x, &e);                                  // x = m 2^e, m in [0.5, 1)
+    if (m < 0.70710678118654752) { m = m * 2.0; e = e - 1; }  // m in [sqrt(1/2), sqrt(2))
+    const double f = (m - 1.0) / (m + 1.0), w = f * f;
+    double p = 1.0 / 19.0;
+    p = p * w + 1.0 / 17.0; p = p * w + 1.0 / 15.0; p = p * w + 1.0 / 13.0; p = p * w + 1.0 / 11.0; p = p * w + 1.0 / 9.0;
+    p = p * w + 1.0 / 7.0; p = p * w + 1.0 / 5.0; p = p * w + 1.0 / 3.0; p = p * w + 1.0;
+    return (double)e * 0.69314718055994531 + 2.0 * f * p;
+}
+__device__ inline double smp_normal(double u)                // inverse normal CDF (Acklam), u in (0, 1)
+{
+#pragma clang fp contract(off)
+    const double a0 = -3.969683028665376e+01, a1 = 2.209460984245205e+02, a2 = -2.759285104469687e+02, a3 = 1.383577518672690e+02,
+                 a4 = -3.066479806614716e+01, a5 = 2.506628277459239e+00;
+    const double b0 = -5.447609879822406e+01, b1 = 1.615858368580409e+02, b2 = -1.556989798598866e+02, b3 = 6.680131188771972e+01,
+                 b4 = -1.328068155288572e+01;
+    const double c0 = -7.784894002430293e-03, c1 = -3.223964580411365e-01, c2 = -2.400758277161838e+00, c3 = -2.549732539343734e+00,
+                 c4 = 4.374664141464968e+00, c5 = 2.938163982698783e+00;
+    const double d0 = 7.784695709041462e-03, d1 = 3.224671290700398e-01, d2 = 2.445134137142996e+00, d3 = 3.754408661907416e+00;
+    const double lo = 0.02425;
+    if (u < lo) {
+        const double q = sqrt(-2.0 * det_log(u));
+        return (((((c0 * q + c1) * q + c2) * q + c3) * q + c4) * q + c5) / ((((d0 * q + d1) * q + d2) * q + d3) * q + 1.0);
+    }
+    if (u > 1.0 - lo) {
+        const double q = sqrt(-2.0 * det_log(1.0 - u));
+        return -(((((c0 * q + c1) * q + c2) * q + c3) * q + c4) * q + c5) / ((((d0 * q + d1) * q + d2) * q + d3) * q + 1.0);
+    }
+    const double q = u - 0.5, r = q * q;
+    return (((((a0 * r + a1) * r + a2) * r + a3) * r + a4) * r + a5) * q / (((((b0 * r + b1) * r + b2) * r + b3) * r + b4) * r + 1.0);
+}
+// pred [n_solvers][M][n_modes][N][6] = (x, y, cos angle, sin angle, major, minor) per prediction step; prob [n_solvers][M][n_modes];
+// out [n_solvers][N][M * S][2] (the layout tmpc_scenario_halfspaces reads: step k - 1 for stage k, sample m * S + s)
+__global__ void tmpc_sample_scenarios_kernel(int N, int n_solvers, int M, int n_modes, int S, unsigned long long seed, const double *pred,
+                                             const double *prob, double *out)
+{
+#pragma clang fp contract(off)
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_solvers * M * S) return;
+    const int s = idx % S, m = (idx / S) % M, q = idx / (S * M);
+    const unsigned long long key = smp_mix(seed ^ smp_mix((unsigned long long)q + 0x51ED270B1ull));
+    const unsigned long long ctr = ((unsigned long long)m * (unsigned long long)S + (unsigned long long)s) * 4ull;
+    const double um = smp_uniform(key, ctr);
+    const double *pr = prob + ((size_t)q * M + m) * n_modes;
+    int mode = n_modes - 1;
+    double cum = 0.0;
+    for (int j = 0; j < n_modes; j++) { cum = cum + pr[j]; if (um < cum) { mode = j; break; } }
+    const double xi1 = smp_normal(smp_uniform(key, ctr + 1ull)), xi2 = smp_normal(smp_uniform(key, ctr + 2ull));
+    const double *ps = pred + (((size_t)q * M + m) * n_modes + mode) * N * 6;
+    for (int k = 0; k < N; k++) {
+        const double *e = ps + (size_t)k * 6;
+        const double a = e[4] * xi1, b = e[5] * xi2;
+        double *o = out + (((size_t)q * N + k) * ((size_t)M * S) + (size_t)m * S + s) * 2;
+        o[0] = (e[0] + e[2] * a) - e[3] * b;
+        o[1] = (e[1] + e[3] * a) + e[2] * b;
+    }
+}
+
+// ---- scenario removal (SH-MPC discards a fixed number of scenarios before building the constraints and pays for it in the bound:
+// the discarded scenarios count into the compression set, modules.scenario_risk(removed=...)).  The scenario_module's own policy is
+// not in the reference tree; restated as the greedy rule of the method's paper: the scenarios that constrain the previous plan most --
+// smallest clearance  min over obstacles m, stages k >= 1 of |o_{m,s,k-1} - p_k| - radius  -- go first (lowest scenario index on ties).
+// One workgroup per trajectory: clearance per scenario in LDS, then n_discard rounds of a block-wide argmin.  discard [B][S] (1 = out).
+__global__ __launch_bounds__(256) void tmpc_scenario_discard_kernel(Dims d, int B, const double *x0, const double *samples, int n_pts, int S,
+                                                                 const int *scene_of, double radius, int n_discard, unsigned char *discard)
+{
+#pragma clang fp contract(off)
+    extern __shared__ double s_clear[];                               // [S]
+    __shared__ unsigned long long s_min;
+    __shared__ int s_arg;
+    const int b = blockIdx.x, tid = threadIdx.x, N = d.N;
+    if (b >= B) return;
+    const int sc = scene_of[b], M = n_pts / S;
+    for (int s = tid; s < S; s += 256) {
+        double best = 1e300;
+        for (int k = 1; k < N; k++) {
+            const double px = x0[((size_t)b * (N + 1) + k) * ext_nv(d) + ZX], py = x0[((size_t)b * (N + 1) + k) * ext_nv(d) + ZY];
+            const double2 *o = reinterpret_cast<const double2 *>(samples) + ((size_t)sc * N + (k - 1)) * n_pts;
+            for (int m = 0; m < M; m++) {
+                const double2 q = o[m * S + s];
+                const double dx = q.x - px, dy = q.y - py;
+                const double c = sqrt(dx * dx + dy * dy) - radius;
+                best = c < best ? c : best;
+            }
+        }
+        s_clear[s] = best;
+        discard[(size_t)b * S + s] = 0;
+    }
+    __syncthreads();
+    for (int r = 0; r < n_discard && r < S; r++) {
+        if (tid == 0) { s_min = ~0ull; s_arg = 0x7fffffff; }
+        __syncthreads();
+        for (int s = tid; s < S; s += 256) if (!discard[(size_t)b * S + s]) atomicMin(&s_min, poly_key(s_clear[s]));
+        __syncthreads();
+        for (int s = tid; s < S; s += 256) if (!discard[(size_t)b * S + s] && poly_key(s_clear[s]) == s_min) atomicMin(&s_arg, s);
+        __syncthreads();
+        if (tid == 0) discard[(size_t)b * S + s_arg] = 1;
+        __syncthreads();
+    }
+}
+
+
 // halfspace j = (aj1, aj2, dmj) clips the boundary line of halfspace i, q_i + t perp_i, to  c t <= rhs
 struct PolyClip { double lo, hi; bool kill; };
 __device__ __forceinline__ void poly_clip(PolyClip &w, double ai1, double ai2, double dmi, int i, double aj1, double aj2, double dmj, int j)
@@ -214,7 +342,7 @@ __device__ __forceinline__ bool poly_frac_alive(const PolyFrac &w) { return w.nh
 // one (trajectory, stage) = `unit` by one workgroup of 256 threads
 __device__ __forceinline__ void poly_stage(int unit, const Dims &d, int B, const double *x0, double *params, const double *samples, int n_pts,
                                            int n_rows, const int *scene_of, const double *state_x, double radius, double disc_offset,
-                                           int *row_sample, int cap, int *overflow, int *empty_stages)
+                                           int *row_sample, int cap, int *overflow, int *empty_stages, const unsigned char *discard, int n_scen)
 {
 #pragma clang fp contract(off)
     extern __shared__ double s_dyn[];                                    // the candidates, compact: normal, margin, sample index (~index: not an edge)
@@ -251,13 +379,16 @@ __device__ __forceinline__ void poly_stage(int unit, const Dims &d, int B, const
     // ---- round 1 on registers: the first CACHE halfspaces of a thread are kept, the rest (n_pts > 2048) recomputed per pass
     constexpr int CACHE = 8;
     double r_ax[CACHE], r_ay[CACHE], r_dm[CACHE]; int r_sec[CACHE];
+    // discarded scenarios (tmpc_scenario_discard; scenario of sample i = i % n_scen) do not exist for this trajectory's polygons
+    auto alive = [&](int i) { return discard == nullptr || discard[(size_t)b * n_scen + i % n_scen] == 0; };
+    unsigned r_alive = 0;
 #pragma unroll
     for (int c = 0; c < CACHE; c++)
-        if (tid + c * 256 < n_pts) { halfspace(tid + c * 256, r_ax[c], r_ay[c], r_dm[c]); r_sec[c] = poly_sector_angular(r_ax[c], r_ay[c]); }
+        if (tid + c * 256 < n_pts && alive(tid + c * 256)) { r_alive |= 1u << c; halfspace(tid + c * 256, r_ax[c], r_ay[c], r_dm[c]); r_sec[c] = poly_sector_angular(r_ax[c], r_ay[c]); }
     auto every_sample = [&](auto &&f) {
 #pragma unroll
-        for (int c = 0; c < CACHE; c++) if (tid + c * 256 < n_pts) f(tid + c * 256, r_ax[c], r_ay[c], r_dm[c], r_sec[c]);
-        for (int i = tid + CACHE * 256; i < n_pts; i += 256) { double ax, ay, dm; halfspace(i, ax, ay, dm); f(i, ax, ay, dm, poly_sector_angular(ax, ay)); }
+        for (int c = 0; c < CACHE; c++) if (r_alive >> c & 1) f(tid + c * 256, r_ax[c], r_ay[c], r_dm[c], r_sec[c]);
+        for (int i = tid + CACHE * 256; i < n_pts; i += 256) if (alive(i)) { double ax, ay, dm; halfspace(i, ax, ay, dm); f(i, ax, ay, dm, poly_sector_angular(ax, ay)); }
     };
     every_sample([&](int, double, double, double dm, int sec) { atomicMin(&s_best[sec], poly_key(dm)); });
     __syncthreads();
@@ -446,11 +577,11 @@ __global__ __launch_bounds__(256, 4) void tmpc_scenario_halfspaces_kernel(Dims d
                                                                        const double *samples, int n_pts, int n_rows,
                                                                        const int *scene_of, const double *state_x,
                                                                        double radius, double disc_offset, int *row_sample, int cap, int *overflow, int second_pass,
-                                                                       int *empty_stages)
+                                                                       int *empty_stages, const unsigned char *discard, int n_scen)
 {
     const int n_units = second_pass ? overflow[0] : B * d.N;
     for (int q = blockIdx.x; q < n_units; q += gridDim.x) {      // (first pass: one unit per workgroup)
-        poly_stage(second_pass ? overflow[1 + q] : q, d, B, x0, params, samples, n_pts, n_rows, scene_of, state_x, radius, disc_offset, row_sample, cap, overflow, empty_stages);
+        poly_stage(second_pass ? overflow[1 + q] : q, d, B, x0, params, samples, n_pts, n_rows, scene_of, state_x, radius, disc_offset, row_sample, cap, overflow, empty_stages, discard, n_scen);
         __syncthreads();                                          // (the LDS tables are reused by the next unit)
     }
 }

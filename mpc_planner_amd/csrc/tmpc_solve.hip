@@ -916,6 +916,9 @@ struct tmpc_handle {
     bool st_valid = false;           // lane kernels (state = their workspace, per launch): it holds the result of a previous call ...
     int st_B = 0;                    // ... for slots [0, st_B)
     // SH-MPC bookkeeping: the sample behind each scenario row of the last tmpc_scenario_halfspaces (i32 [B][N][scn_rows])
+    unsigned char *scn_discard = nullptr;     // [B_max][scn_discard_S] scenarios discarded for each trajectory (tmpc_scenario_discard); applies to the next tmpc_scenario_halfspaces
+    int scn_discard_S = 0, scn_discard_B = 0, scn_discard_n = 0;
+    size_t scn_discard_cap = 0;
     int *scn_sample = nullptr;
     size_t scn_cap = 0;
     int scn_rows = 0, scn_B = 0;
@@ -1057,7 +1060,7 @@ void tmpc_destroy(tmpc_handle *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void *ptrs[] = {h->o_xinit, h->o_x0, h->o_params, h->xtraj, h->utraj, h->pobj, h->res_eq, h->d_weight,
                     h->exit_code, h->qp_status, h->sqp_iter, h->qp_iter, h->d_best, h->d_disabled,
-                    h->st_z, h->st_pi, h->st_lamh, h->st_stopped, h->st_has, h->d_slot, h->scn_sample, h->ws, h->ticket};
+                    h->st_z, h->st_pi, h->st_lamh, h->st_stopped, h->st_has, h->d_slot, h->scn_sample, h->scn_discard, h->ws, h->ticket};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &e : h->ev) (void)hipEventDestroy(e);
     tmpc::lanes::destroy(h->lanes);
@@ -1077,6 +1080,7 @@ int tmpc_set_batch(tmpc_handle *h, int32_t B, const double *xinit, const double 
     TMPC_HIP_CHECK(h, hipMemcpyAsync(h->o_params, params, (size_t)B * N * h->d.npar * 8, hipMemcpyHostToDevice, h->stream));
     h->xinit = h->o_xinit; h->x0 = h->o_x0; h->params = h->o_params; h->B = B;
     h->scn_B = 0;                      // new parameter rows: the scenario-row bookkeeping of the previous batch no longer describes them
+    h->scn_discard_B = 0;
     return TMPC_OK;
 }
 
@@ -1084,7 +1088,7 @@ int tmpc_set_batch_device(tmpc_handle *h, int32_t B, const void *d_xinit, const 
 {
     if (!h || B <= 0 || B > h->B_max || !d_xinit || !d_x0 || !d_params) { if (h) h->err = "tmpc_set_batch_device: bad argument"; return TMPC_ERR_INVALID; }
     h->xinit = (const double *)d_xinit; h->x0 = (const double *)d_x0; h->params = (const double *)d_params; h->B = B;
-    h->scn_B = 0;
+    h->scn_B = 0; h->scn_discard_B = 0;
     return TMPC_OK;
 }
 
@@ -1401,6 +1405,8 @@ int tmpc_scenario_halfspaces(tmpc_handle *h, const void *d_samples, int32_t n_pt
         h->scn_cap = need;
     }
     h->scn_rows = n_rows; h->scn_B = h->B;
+    // scenarios discarded for this batch (tmpc_scenario_discard after the batch was set) are left out of the polygons
+    const bool use_discard = h->scn_discard && h->scn_discard_B == h->B && h->scn_discard_S > 0 && n_pts % h->scn_discard_S == 0;
     // first pass with a short candidate list (more workgroups per CU); second pass, with room for every sample, only for the
     // units the first pass recorded as not fitting
     int *overflow = h->scn_sample + units * n_rows;
@@ -1416,9 +1422,57 @@ int tmpc_scenario_halfspaces(tmpc_handle *h, const void *d_samples, int32_t n_pt
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(tmpc::tmpc_scenario_halfspaces_kernel, dim3(pass == 0 ? units : (units < 512 ? units : 512)), dim3(256), lds, h->stream, h->d, h->B, h->x0,
                            const_cast<double *>(h->params), (const double *)d_samples, n_pts, n_rows, (const int *)d_scene_of,
-                           (const double *)d_state_x, radius, disc_offset, h->scn_sample, cap, overflow, pass, empty_stages);
+                           (const double *)d_state_x, radius, disc_offset, h->scn_sample, cap, overflow, pass, empty_stages,
+                           use_discard ? h->scn_discard : nullptr, use_discard ? h->scn_discard_S : 1);
     }
     TMPC_HIP_CHECK(h, hipGetLastError());
+    return TMPC_OK;
+}
+
+int tmpc_sample_scenarios(tmpc_handle *h, const void *d_pred, const void *d_prob, int32_t n_solvers, int32_t n_obstacles, int32_t n_modes,
+                          int32_t n_scenarios, uint64_t seed, void *d_samples)
+{
+    if (!h || !d_pred || !d_prob || !d_samples || n_solvers <= 0 || n_obstacles <= 0 || n_modes <= 0 || n_scenarios <= 0) {
+        if (h) h->err = "tmpc_sample_scenarios: bad argument";
+        return TMPC_ERR_INVALID;
+    }
+    TMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    const int n = n_solvers * n_obstacles * n_scenarios;
+    hipLaunchKernelGGL(tmpc::tmpc_sample_scenarios_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->d.N, n_solvers, n_obstacles, n_modes,
+                       n_scenarios, (unsigned long long)seed, (const double *)d_pred, (const double *)d_prob, (double *)d_samples);
+    TMPC_HIP_CHECK(h, hipGetLastError());
+    return TMPC_OK;
+}
+
+int tmpc_scenario_discard(tmpc_handle *h, const void *d_samples, int32_t n_pts, int32_t n_scenarios, int32_t n_discard, const void *d_scene_of, double radius)
+{
+    if (!h || h->B <= 0 || !h->x0 || !d_samples || !d_scene_of || n_pts <= 0 || n_scenarios <= 0 || n_pts % n_scenarios != 0 || n_discard < 0 ||
+        n_discard >= n_scenarios || n_scenarios > 16384) {
+        if (h) h->err = "tmpc_scenario_discard: bad argument / no batch (n_pts = obstacles x n_scenarios, 0 <= n_discard < n_scenarios <= 16384)";
+        return TMPC_ERR_INVALID;
+    }
+    TMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    const size_t need = (size_t)h->B_max * n_scenarios;
+    if (need > h->scn_discard_cap) {
+        if (h->scn_discard) { TMPC_HIP_CHECK(h, hipStreamSynchronize(h->stream)); (void)hipFree(h->scn_discard); h->scn_discard = nullptr; h->scn_discard_cap = 0; }
+        TMPC_HIP_CHECK(h, hipMalloc(&h->scn_discard, need));
+        h->scn_discard_cap = need;
+    }
+    const size_t lds = (size_t)n_scenarios * sizeof(double);
+    if (lds > 48 * 1024)
+        TMPC_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(tmpc::tmpc_scenario_discard_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(tmpc::tmpc_scenario_discard_kernel, dim3(h->B), dim3(256), lds, h->stream, h->d, h->B, h->x0, (const double *)d_samples, n_pts,
+                       n_scenarios, (const int *)d_scene_of, radius, n_discard, h->scn_discard);
+    TMPC_HIP_CHECK(h, hipGetLastError());
+    h->scn_discard_S = n_scenarios; h->scn_discard_B = h->B; h->scn_discard_n = n_discard;
+    return TMPC_OK;
+}
+
+int tmpc_scenario_discarded(tmpc_handle *h, void *d_mask)
+{
+    if (!h || !d_mask || !h->scn_discard || h->scn_discard_B != h->B) { if (h) h->err = "tmpc_scenario_discarded: no discard set for the current batch"; return TMPC_ERR_INVALID; }
+    TMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    TMPC_HIP_CHECK(h, hipMemcpyAsync(d_mask, h->scn_discard, (size_t)h->B * h->scn_discard_S, hipMemcpyDeviceToDevice, h->stream));
     return TMPC_OK;
 }
 

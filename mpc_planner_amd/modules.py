@@ -217,7 +217,105 @@ def polygon_edges(ax, ay, dm):
     return edge
 
 
-def scenario_halfspaces(x0, samples, radius, n_rows=24, return_index=False):
+# ---- SH-MPC scenario sampler: host mirror of tmpc_sample_scenarios_kernel, bit for bit -------------------------------------------
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _smp_mix(z):
+    z = np.asarray(z, np.uint64)
+    with np.errstate(over="ignore"):
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return z ^ (z >> np.uint64(31))
+
+
+def _smp_uniform(key, ctr):
+    with np.errstate(over="ignore"):
+        r = _smp_mix(np.uint64(key) + (np.asarray(ctr, np.uint64) + np.uint64(1)) * np.uint64(0x9E3779B97F4A7C15))
+    return ((r >> np.uint64(11)).astype(np.float64) + 0.5) * (1.0 / 9007199254740992.0)
+
+
+def _det_log(x):
+    """Natural logarithm from +, x, / only, in the operation order of the device's det_log (no library call: reproducible)."""
+    m, e = np.frexp(x)
+    small = m < 0.70710678118654752
+    m = np.where(small, m * 2.0, m); e = np.where(small, e - 1, e)
+    f = (m - 1.0) / (m + 1.0); w = f * f
+    p = np.full_like(f, 1.0 / 19.0)
+    for c in (17.0, 15.0, 13.0, 11.0, 9.0, 7.0, 5.0, 3.0):
+        p = p * w + 1.0 / c
+    p = p * w + 1.0
+    return e.astype(np.float64) * 0.69314718055994531 + 2.0 * f * p
+
+
+def _smp_normal(u):
+    """Inverse normal CDF (Acklam's rational approximation), same polynomials and operation order as the device."""
+    a = (-3.969683028665376e+01, 2.209460984245205e+02, -2.759285104469687e+02, 1.383577518672690e+02, -3.066479806614716e+01, 2.506628277459239e+00)
+    b = (-5.447609879822406e+01, 1.615858368580409e+02, -1.556989798598866e+02, 6.680131188771972e+01, -1.328068155288572e+01)
+    c = (-7.784894002430293e-03, -3.223964580411365e-01, -2.400758277161838e+00, -2.549732539343734e+00, 4.374664141464968e+00, 2.938163982698783e+00)
+    dd = (7.784695709041462e-03, 3.224671290700398e-01, 2.445134137142996e+00, 3.754408661907416e+00)
+    u = np.asarray(u, np.float64)
+    lo = 0.02425
+
+    def tail(p):
+        q = np.sqrt(-2.0 * _det_log(p))
+        return (((((c[0] * q + c[1]) * q + c[2]) * q + c[3]) * q + c[4]) * q + c[5]) / ((((dd[0] * q + dd[1]) * q + dd[2]) * q + dd[3]) * q + 1.0)
+
+    q = u - 0.5; r = q * q
+    mid = (((((a[0] * r + a[1]) * r + a[2]) * r + a[3]) * r + a[4]) * r + a[5]) * q / (((((b[0] * r + b[1]) * r + b[2]) * r + b[3]) * r + b[4]) * r + 1.0)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        low = tail(np.where(u < lo, u, 0.5)); high = -tail(np.where(u > 1.0 - lo, 1.0 - u, 0.5))
+    return np.where(u < lo, low, np.where(u > 1.0 - lo, high, mid))
+
+
+def sample_scenarios(pred, prob, n_scenarios, seed):
+    """Scenario sampler of SH-MPC (scenario_constraints.cpp:121-131; the scenario_module that implements it is absent -- restated from
+    the call: IntegrateAndTranslateToMeanAndVariance): per solver q, obstacle m and scenario s a mode of the obstacle's Gaussian
+    mixture is drawn from prob [Q][M][n_modes] and ONE standard-normal pair places the obstacle on every prediction step of that
+    mode, o_k = mean_k + R(angle_k) (major_k xi1, minor_k xi2); pred [Q][M][n_modes][N][6] = (x, y, cos angle, sin angle, major, minor).
+    Returns samples [Q][N][M * n_scenarios][2] -- equal bit for bit to tmpc_sample_scenarios (counter-based splitmix64 bits, inverse
+    normal CDF from +, x, /, sqrt only)."""
+    pred = np.asarray(pred, np.float64); prob = np.asarray(prob, np.float64)
+    Q, M, n_modes, N, _ = pred.shape
+    S = int(n_scenarios)
+    out = np.zeros((Q, N, M * S, 2))
+    mm, ss = np.meshgrid(np.arange(M), np.arange(S), indexing="ij")
+    ctr = ((mm.astype(np.uint64) * np.uint64(S) + ss.astype(np.uint64)) * np.uint64(4))
+    for q in range(Q):
+        with np.errstate(over="ignore"):
+            key = _smp_mix(np.uint64(seed) ^ _smp_mix(np.uint64(q) + np.uint64(0x51ED270B1)))
+        um = _smp_uniform(key, ctr)
+        mode = np.full((M, S), n_modes - 1)
+        cum = np.zeros((M, 1)); done = np.zeros((M, S), bool)
+        for j in range(n_modes):
+            cum = cum + prob[q, :, j:j + 1]
+            hit = (um < cum) & ~done
+            mode[hit] = j; done |= hit
+        xi1 = _smp_normal(_smp_uniform(key, ctr + np.uint64(1))); xi2 = _smp_normal(_smp_uniform(key, ctr + np.uint64(2)))
+        e = pred[q][np.arange(M)[:, None], mode]                       # [M][S][N][6]
+        a = e[..., 4] * xi1[..., None]; b = e[..., 5] * xi2[..., None]
+        ox = (e[..., 0] + e[..., 2] * a) - e[..., 3] * b
+        oy = (e[..., 1] + e[..., 3] * a) + e[..., 2] * b
+        out[q, :, :, 0] = ox.transpose(2, 0, 1).reshape(N, M * S)
+        out[q, :, :, 1] = oy.transpose(2, 0, 1).reshape(N, M * S)
+    return out
+
+
+def scenario_discard(x0, samples, radius, n_discard):
+    """Scenario removal (host mirror of tmpc_scenario_discard_kernel): the n_discard scenarios with the smallest clearance
+    min over obstacles m, stages k >= 1 of |o_{m,s,k-1} - p_k| - radius  from the guess (lowest scenario index on ties).
+    x0 [N+1][nv]; samples [M][S][N][2].  Returns a bool mask [S] (True = discarded); they count into the bound:
+    scenario_risk(S, support, removed=n_discard)."""
+    M, S, N, _ = samples.shape
+    p = x0[1:N, [IDX["x"], IDX["y"]]]                                  # stages 1..N-1 use prediction steps 0..N-2
+    d = samples[:, :, :N - 1, :] - p[None, None]
+    clear = (np.sqrt(d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) - radius).min(axis=(0, 2))
+    out = np.zeros(S, bool)
+    out[np.argsort(clear, kind="stable")[:n_discard]] = True
+    return out
+
+
+def scenario_halfspaces(x0, samples, radius, n_rows=24, return_index=False, discard=None):
     """Per-stage polygon construction of SH-MPC (scenario_constraints.cpp:47,76-79 hand this to the external scenario_module, whose
     source is not in the reference tree; restated from the method the reference cites, README.md:22: every sampled obstacle
     position o of stage k gives the halfspace a = (o - p)/|o - p|, b = a.o - radius linearised around the previous plan's position
@@ -230,14 +328,19 @@ def scenario_halfspaces(x0, samples, radius, n_rows=24, return_index=False):
     (contradictory rows: the QP is infeasible or pays slack) and is reported in `empty` (advisor finding, round 2).
     x0 [N+1][nv]; samples [M][S_cen][N][2] (index k-1 for stage k).  Returns a1, a2, b [N][n_rows] with NaN = dummy; rows in order of
     increasing distance.  return_index: also the flat sample index m * S_cen + s behind each row ([N][n_rows], -1 = dummy) and
-    empty [N] (bool: the stage's polygon was empty)."""
+    empty [N] (bool: the stage's polygon was empty).  discard: bool [S_cen], scenarios left out (scenario_discard)."""
     N = x0.shape[0] - 1
     a1 = np.full((N, n_rows), np.nan); a2 = np.full((N, n_rows), np.nan); b = np.full((N, n_rows), np.nan)
     which = np.full((N, n_rows), -1, np.int32)
     empty = np.zeros(N, bool)
+    keep = None
+    if discard is not None:                                            # discarded scenarios (scenario_discard) do not exist for this trajectory
+        keep = np.flatnonzero(~np.tile(np.asarray(discard, bool), samples.shape[0]))
     for k in range(1, N):
         p = x0[k, [IDX["x"], IDX["y"]]]
         o = samples[:, :, k - 1, :].reshape(-1, 2)
+        if keep is not None:
+            o = o[keep]
         diff = o - p
         dist = np.sqrt(diff[:, 0] * diff[:, 0] + diff[:, 1] * diff[:, 1])
         ax = diff[:, 0] / dist; ay = diff[:, 1] / dist
@@ -249,7 +352,7 @@ def scenario_halfspaces(x0, samples, radius, n_rows=24, return_index=False):
         m = len(idx)
         a1[k, :m] = ax[idx]; a2[k, :m] = ay[idx]
         b[k, :m] = ax[idx] * o[idx, 0] + ay[idx] * o[idx, 1] - radius
-        which[k, :m] = idx
+        which[k, :m] = idx if keep is None else keep[idx]
     return (a1, a2, b, which, empty) if return_index else (a1, a2, b)
 
 

@@ -41,7 +41,8 @@ EXPORTS = ["tmpc_default_dims", "tmpc_default_dims_ex", "tmpc_create", "tmpc_des
            "tmpc_select_best_records", "tmpc_enable_timing", "tmpc_get_timings", "tmpc_debug_profile",
            "tmpc_linearize_topology", "tmpc_scenario_halfspaces", "tmpc_scenario_support", "tmpc_warmstart", "tmpc_init_with_guidance",
            "tmpc_debug_get_x0", "tmpc_debug_get_params", "tmpc_set_throughput_mode", "tmpc_solve_iterations",
-           "tmpc_reset_multipliers", "tmpc_get_stream", "tmpc_kernel_info", "tmpc_set_slots", "tmpc_copy_state", "tmpc_scenario_empty_stages"]
+           "tmpc_reset_multipliers", "tmpc_get_stream", "tmpc_kernel_info", "tmpc_set_slots", "tmpc_copy_state", "tmpc_scenario_empty_stages", "tmpc_sample_scenarios",
+           "tmpc_scenario_discard", "tmpc_scenario_discarded"]
 
 class TmpcError(RuntimeError):
     pass
@@ -85,6 +86,9 @@ def load_library(path=None):
     lib.tmpc_kernel_info.argtypes = [vp, C.c_char_p, C.c_int32]
     lib.tmpc_set_slots.argtypes = [vp, vp]
     lib.tmpc_scenario_empty_stages.argtypes = [vp, vp]
+    lib.tmpc_sample_scenarios.argtypes = [vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, vp]
+    lib.tmpc_scenario_discard.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int32, vp, C.c_double]
+    lib.tmpc_scenario_discarded.argtypes = [vp, vp]
     lib.tmpc_copy_state.argtypes = [vp, vp]
     lib.tmpc_synchronize.argtypes = [vp]
     lib.tmpc_get.argtypes = [vp] + [vp] * 8
@@ -298,6 +302,23 @@ class BatchedSolver:
         o = out.cpu().numpy()
         return o[0], o[1]
 
+    def sample_scenarios(self, d_pred, d_prob, n_solvers, n_obstacles, n_modes, n_scenarios, seed, d_samples):
+        """Device scenario sampler (tmpc_sample_scenarios): raw device pointers; d_samples [n_solvers][N][n_obstacles * n_scenarios][2]."""
+        self._check(self.lib.tmpc_sample_scenarios(self._h, C.c_void_p(d_pred), C.c_void_p(d_prob), int(n_solvers), int(n_obstacles), int(n_modes),
+                                                   int(n_scenarios), C.c_uint64(int(seed)), C.c_void_p(d_samples)), "tmpc_sample_scenarios")
+
+    def scenario_discard(self, d_samples, n_pts, n_scenarios, n_discard, d_scene_of, radius):
+        """Scenario removal for the current batch (tmpc_scenario_discard); the next scenario_halfspaces leaves the discarded scenarios out."""
+        self._check(self.lib.tmpc_scenario_discard(self._h, C.c_void_p(d_samples), int(n_pts), int(n_scenarios), int(n_discard),
+                                                   C.c_void_p(d_scene_of), float(radius)), "tmpc_scenario_discard")
+
+    def scenario_discarded(self, n_scenarios):
+        import torch
+        out = torch.zeros((self.B, n_scenarios), dtype=torch.uint8, device=f"cuda:{self.device}")
+        self._check(self.lib.tmpc_scenario_discarded(self._h, C.c_void_p(out.data_ptr())), "tmpc_scenario_discarded")
+        self.synchronize()
+        return out.cpu().numpy().astype(bool)
+
     def scenario_empty_stages(self):
         """Per trajectory: the stages whose sampled halfspaces contradicted each other in the last scenario_halfspaces (empty polygon;
         such a stage keeps the closest halfspaces and the trajectory is not eligible)."""
@@ -383,7 +404,7 @@ def optimize_scenarios(solver, xinit, x0, params, n_iter=None, scenario=None):
     code 1 (init 1e9, strict '<': lowest index wins ties).  Returns (results dict, best index or -1, exit code the reference
     returns: the best solver's, or the first solver's when none succeeded).
 
-    scenario = dict(d_samples, n_pts, n_rows, d_scene_of, d_state_x, radius, n_scenarios[, disc_offset, tol, max_support]) builds
+    scenario = dict(d_samples, n_pts, n_rows, d_scene_of, d_state_x, radius, n_scenarios[, disc_offset, tol, max_support, n_discard]) builds
     the rows on device from the sampled scenarios (tmpc_scenario_halfspaces, scenario_module.update + setParameters) and adds the
     support bookkeeping of ScenarioSolver (scenario_constraints.h:38-40): res["support"], res["active_rows"], and with max_support
     res["scenario_status"] (0 = within the bound the sample size was chosen for, 1 = support exceeded: no certificate, 2 = a stage's
@@ -392,6 +413,9 @@ def optimize_scenarios(solver, xinit, x0, params, n_iter=None, scenario=None):
     n_iter = solver.dims.n_sqp if n_iter is None else int(n_iter)
     solver.set_batch(xinit, x0, params)                               # *solver = *_solver; setParameters; loadWarmstart
     if scenario is not None:
+        if scenario.get("n_discard"):                                  # scenario removal before the polygons; counts into the bound (scenario_risk(removed=...))
+            solver.scenario_discard(scenario["d_samples"], scenario["n_pts"], scenario["n_scenarios"], scenario["n_discard"],
+                                    scenario["d_scene_of"], scenario["radius"])
         solver.scenario_halfspaces(scenario["d_samples"], scenario["n_pts"], scenario["n_rows"], scenario["d_scene_of"],
                                    scenario["d_state_x"], scenario["radius"], scenario.get("disc_offset", 0.0))
     for it in range(n_iter):                                          # every slot stops by itself once its QP reports a status
