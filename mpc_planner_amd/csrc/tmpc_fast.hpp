@@ -573,6 +573,12 @@ void tmpc_solve_fast_kernel(Dims d, int B, const double *__restrict__ xinit,
 // (carve_compact).  Persistent workgroups: the launch has at most as many workgroups as the GPU holds resident, each takes
 // trajectories from a ticket counter; the global NLP workspace is indexed by WORKGROUP, so it stays as small as the resident
 // set (L2-resident) whatever the batch size.
+// Work distribution of the persistent launch: ONE ticket counter, trajectories in batch order (adjacent trajectories -- a scene's
+// guidance set -- run on different CUs and XCDs at the same time).  An XCD-aware variant was built and measured in round 3 (chunks of
+// 64 consecutive trajectories dealt to the XCDs, one counter per XCD read through HW_REG_XCC_ID, exhausted XCDs stealing from the
+// next): the L2 <-> fabric traffic did not move (FETCH 8.6 vs 9.0 GB, WRITE 2.87 GB per 32768-trajectory launch -- it is the
+// per-workgroup workspace, not the parameter rows), a saturated launch ran as fast (833 vs 836 k solves/s) and a
+// 4096-trajectory launch 4.5 % slower: rejected, profiles/round3_c_xcd_tickets_rejected.json.
 template <int NLIN, int MM, int LPS, bool PROF = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void tmpc_solve_compact_kernel(Dims d, int B, const double *__restrict__ xinit,

@@ -37,8 +37,8 @@ namespace tmpc {
 
 constexpr int NT = 64;   // threads per trajectory (one wavefront)
 
-__constant__ int c_pi[NP28] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 4, 5, 5, 5, 5, 5, 5, 6, 6, 6, 6, 6, 6, 6};
-__constant__ int c_pj[NP28] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 3, 0, 1, 2, 3, 4, 0, 1, 2, 3, 4, 5, 0, 1, 2, 3, 4, 5, 6};
+static __constant__ int c_pi[NP28] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 4, 5, 5, 5, 5, 5, 5, 6, 6, 6, 6, 6, 6, 6};
+static __constant__ int c_pj[NP28] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 3, 0, 1, 2, 3, 4, 0, 1, 2, 3, 4, 5, 0, 1, 2, 3, 4, 5, 6};
 
 // ---- persistent solver state (tmpc_solve_iterations) ---------------------------------------------------------------
 // The reference's acados capsules keep the NLP iterate and its multipliers between calls: solveOneIteration continues from
@@ -685,6 +685,7 @@ __device__ __forceinline__ void solve_epilogue(const Lds &L, const Dims &d, int 
 }
 
 // ---- the solve kernel ---------------------------------------------------------------------------
+#ifndef TMPC_PROF_TU
 __global__ __launch_bounds__(NT) void tmpc_solve_kernel(Dims d, int B, const double *__restrict__ xinit,
                                                         const double *__restrict__ x0, const double *__restrict__ params,
                                                         double *__restrict__ xtraj, double *__restrict__ utraj,
@@ -760,9 +761,28 @@ __global__ __launch_bounds__(NT) void tmpc_solve_kernel(Dims d, int B, const dou
                    qp_status_out, sqp_iter_out, res_eq_out, qp_iter_out, prof_out, pf, t_begin);
 }
 
+#endif  // TMPC_PROF_TU
+
 }  // namespace tmpc
 #include "tmpc_fast.hpp"
-#ifdef TMPC_SINGLE_TEAM
+// Hand-written fast shapes (NLIN, MM, LPS, NTH): the list pick_fast_kernel / pick_latency_kernel dispatch over.  The library build
+// splits them over translation units to shorten the build: the profiled twins (PROF = true, tmpc_debug_profile) are compiled in a
+// second unit (-DTMPC_PROF_TU: this file up to here + their explicit instantiations), the main unit (-DTMPC_PROF_EXTERN) only declares
+// them.  Without either macro (generated solvers, probes) everything is instantiated implicitly in one unit.
+#define TMPC_FAST_SHAPES(X) X(8, 8, 4, 128) X(12, 12, 4, 128) X(20, 8, 4, 128) X(-1, 6, 4, 128) X(-1, 9, 4, 128) X(-1, 12, 4, 128) X(0, 4, 3, 64) \
+    X(8, 8, 3, 64) X(12, 12, 3, 64) X(24, 0, 3, 64) X(-1, 7, 3, 64) X(-1, 10, 3, 64) X(-1, 13, 3, 64) X(-1, 9, 6, 128) X(0, 4, 2, 64) X(8, 8, 6, 128)
+#define TMPC_KARGS tmpc::Dims, int, const double *, const double *, const double *, double *, double *, double *, int *, int *, int *, double *, int *, long long *, tmpc::StateIO
+#if defined(TMPC_PROF_TU)
+#define TMPC_X(a, b, c, e) template __global__ void tmpc::tmpc_solve_fast_kernel<a, b, c, e, true>(TMPC_KARGS);
+TMPC_FAST_SHAPES(TMPC_X)
+#undef TMPC_X
+#elif defined(TMPC_PROF_EXTERN)
+#define TMPC_X(a, b, c, e) extern template __global__ void tmpc::tmpc_solve_fast_kernel<a, b, c, e, true>(TMPC_KARGS);
+TMPC_FAST_SHAPES(TMPC_X)
+#undef TMPC_X
+#endif
+#ifdef TMPC_PROF_TU
+#elif defined(TMPC_SINGLE_TEAM)
 template __global__ void tmpc::tmpc_solve_team_kernel<TMPC_SINGLE_TEAM>(tmpc::Dims, int, const double *, const double *, const double *,
                                                                        double *, double *, double *, int *, int *, int *, double *, int *,
                                                                        long long *, tmpc::StateIO);
@@ -1046,7 +1066,7 @@ int tmpc_create(tmpc_handle **out, const tmpc_dims *dims, int32_t B_max, int32_t
     ok &= hipMalloc(&h->d_disabled, B) == hipSuccess;
     if (h->compact) {
         ok &= hipMalloc(&h->ws, (size_t)h->grid_max * h->team * tmpc::ws_doubles(d.N) * 8) == hipSuccess;
-        ok &= hipMalloc(&h->ticket, 4) == hipSuccess;
+        ok &= hipMalloc(&h->ticket, 8 * 4) == hipSuccess;         // one work counter per XCD (next_trajectory)
     }
     if (!ok) { tmpc_destroy(h); return TMPC_ERR_HIP; }
     *out = h;
@@ -1112,7 +1132,7 @@ static int launch_solve(tmpc_handle *h, int n_iter, int st_flags)
         tmpc::StateIO io{h->st_z, h->st_pi, h->st_lamh, h->st_stopped, st_flags, h->ws, h->ticket, h->slots_set ? h->d_slot : nullptr, h->st_has};
         const bool lat = h->kernel_lat && h->latency_mode;
         const bool cp = h->compact && !lat;
-        if (cp) TMPC_HIP_CHECK(h, hipMemsetAsync(h->ticket, 0, 4, h->stream));        // the persistent launch's work counter
+        if (cp) TMPC_HIP_CHECK(h, hipMemsetAsync(h->ticket, 0, 8 * 4, h->stream));    // the persistent launch's work counters (one per XCD)
         const int teams = (h->B + h->team - 1) / h->team;                              // workgroups' worth of work of a persistent launch
         hipLaunchKernelGGL(lat ? h->kernel_lat : h->kernel, dim3(cp ? (teams < h->grid_max ? teams : h->grid_max) : h->B),
                            dim3(lat ? 128 : (cp ? 64 * h->team : h->threads)), lat ? h->lds_bytes_fast : h->lds_bytes, h->stream, dd, h->B,

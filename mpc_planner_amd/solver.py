@@ -83,13 +83,20 @@ def load_library(path=None):
     lib.tmpc_solve_iterations.argtypes = [vp, C.c_int32, C.c_int32]
     lib.tmpc_reset_multipliers.argtypes = [vp]
     lib.tmpc_get_stream.argtypes = [vp, C.POINTER(vp)]
-    lib.tmpc_kernel_info.argtypes = [vp, C.c_char_p, C.c_int32]
-    lib.tmpc_set_slots.argtypes = [vp, vp]
-    lib.tmpc_scenario_empty_stages.argtypes = [vp, vp]
-    lib.tmpc_sample_scenarios.argtypes = [vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, vp]
-    lib.tmpc_scenario_discard.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int32, vp, C.c_double]
-    lib.tmpc_scenario_discarded.argtypes = [vp, vp]
-    lib.tmpc_copy_state.argtypes = [vp, vp]
+    if hasattr(lib, "tmpc_kernel_info"):        # (absent from reference builds of earlier rounds used in A/B runs)
+        lib.tmpc_kernel_info.argtypes = [vp, C.c_char_p, C.c_int32]
+    if hasattr(lib, "tmpc_set_slots"):        # (absent from reference builds of earlier rounds used in A/B runs)
+        lib.tmpc_set_slots.argtypes = [vp, vp]
+    if hasattr(lib, "tmpc_scenario_empty_stages"):        # (absent from reference builds of earlier rounds used in A/B runs)
+        lib.tmpc_scenario_empty_stages.argtypes = [vp, vp]
+    if hasattr(lib, "tmpc_sample_scenarios"):        # (absent from reference builds of earlier rounds used in A/B runs)
+        lib.tmpc_sample_scenarios.argtypes = [vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, vp]
+    if hasattr(lib, "tmpc_scenario_discard"):        # (absent from reference builds of earlier rounds used in A/B runs)
+        lib.tmpc_scenario_discard.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int32, vp, C.c_double]
+    if hasattr(lib, "tmpc_scenario_discarded"):        # (absent from reference builds of earlier rounds used in A/B runs)
+        lib.tmpc_scenario_discarded.argtypes = [vp, vp]
+    if hasattr(lib, "tmpc_copy_state"):        # (absent from reference builds of earlier rounds used in A/B runs)
+        lib.tmpc_copy_state.argtypes = [vp, vp]
     lib.tmpc_synchronize.argtypes = [vp]
     lib.tmpc_get.argtypes = [vp] + [vp] * 8
     lib.tmpc_select_best.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, C.POINTER(C.c_int32)]
