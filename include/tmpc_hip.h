@@ -202,19 +202,29 @@ int tmpc_time_solve(tmpc_handle *h, int32_t reps, float *ms_each);
  * For every trajectory b of the current batch, stage k = 1..N-1 and obstacle j < n_lin: project the guess position
  * x0[b][k].(x,y) out of the discs of radius (1e-3 + robot_radius) around the obstacle predictions (<= 3 sweeps,
  * LinearizedConstraints::projectToSafety, linearized_constraints.cpp:130-148 -- the Douglas-Rachford operator of
- * ros_tools is not in the reference tree; a radial projection is used, identity for collision-free guesses), then
+ * ros_tools is not in the reference tree; restated from the published operator, DESIGN.md U10 -- the identity for collision-free guesses), then
  * a = (o - p)/|o - p|, b = a.o - (1e-3 + robot_radius) (:84-105, guidance mode) and write lin_constraint_j_{a1,a2,b}
  * into params[b][k]; stage 0 and the rows of non-guided planners get the dummies (1, 0, state_x + 100) (:155-166,
  * guidance_constraints.cpp:301-305).  The batch's params buffer is modified IN PLACE (device memory).
- * ALL n_lin topology rows are treated as dynamic obstacles (d_obstacle_pos has n_lin entries per scene): a configuration with
- * linearized_constraints/add_halfspaces > 0 (static halfspace rows behind the obstacle rows, :107-123) must pass dummy
- * obstacles far away for those slots and write the static rows itself afterwards (they are per-scene constants).
+ * ALL n_lin topology rows are treated as dynamic obstacles (d_obstacle_pos has n_lin entries per scene); tmpc_linearize_topology_ex
+ * below covers fewer obstacles than rows, static halfspace rows and the disc mode.
  *   d_obstacle_pos : f64 [n_scenes][n_lin][N][2]   prediction step i of obstacle j (stage k uses step k-1)
  *   d_scene_of     : i32 [B]                       scene of trajectory b
  *   d_state_x      : f64 [n_scenes]                current state x (for the dummy b)
  *   d_is_original  : u8  [B] or NULL               1 = non-guided T-MPC++ planner (all rows dummy) */
 int tmpc_linearize_topology(tmpc_handle *h, const void *d_obstacle_pos, const void *d_scene_of, const void *d_state_x,
                             double robot_radius, const void *d_is_original);
+/* The whole of LinearizedConstraints::update / setParameters (linearized_constraints.cpp:49-189):
+ *   rows 0 .. n_obstacles-1          dynamic obstacles, d_obstacle_pos f64 [n_scenes][n_obstacles][N][2]
+ *   rows n_obstacles .. +n_static-1  static halfspaces of the stage, copied as given (`linearized_constraints/add_halfspaces`, :107-123):
+ *                                    d_static_halfspaces f64 [n_scenes][N][n_static][3] = (a1, a2, b) for stage k (k = 0 unused)
+ *   remaining rows up to n_lin       dummies (1, 0, state_x + 100) (:181-187); n_obstacles + n_static <= n_lin
+ * d_obstacle_radius == NULL: guidance mode, every obstacle disc has radius 1e-3 + robot_radius (:99, :140).  Otherwise the
+ * `_use_guidance == false` branch (:63-73): f64 [n_scenes][n_obstacles], obstacle j's own radius + robot_radius in the projection and
+ * in b.  One disc at the robot's centre (n_discs = 1, offset 0: the Jackal configurations); rows of further discs are not generated. */
+int tmpc_linearize_topology_ex(tmpc_handle *h, const void *d_obstacle_pos, int32_t n_obstacles, const void *d_obstacle_radius,
+                               const void *d_static_halfspaces, int32_t n_static, const void *d_scene_of, const void *d_state_x,
+                               double robot_radius, const void *d_is_original);
 
 /* ---- scenario -> polygon construction of SH-MPC on device.  Replaces what the reference gets from the
  * external scenario_module (scenario_constraints.cpp:47 update, :76-79 setParameters; source absent -> restated, see

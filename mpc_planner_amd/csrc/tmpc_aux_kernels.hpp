@@ -68,9 +68,12 @@ __global__ void tmpc_select_best_records_kernel(const tmpc_record *rec, int n_ra
 
 // ---- f-1: LinearizedConstraints::update + setParameters on device (linearized_constraints.cpp:49-189) ----------
 // one thread per (trajectory, stage)
+// n_obs dynamic obstacles (rows 0 .. n_obs-1), then n_static static halfspaces per stage copied as they are (linearized_constraints.cpp:
+// 107-123, `add_halfspaces`), then dummies up to n_lin.  obst_radius == nullptr: guidance mode, every disc has radius 1e-3 + robot_radius
+// (:99, :140); otherwise the `_use_guidance == false` branch (:63-73): obstacle j's own radius + robot_radius, in the projection and in b.
 __global__ void tmpc_linearize_topology_kernel(Dims d, int B, const double *x0, double *params, const double *obst,
                                                const int *scene_of, const double *state_x, double robot_radius,
-                                               const uint8_t *is_original)
+                                               const uint8_t *is_original, int n_obs, const double *obst_radius, const double *stat, int n_static)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     const int N = d.N;
@@ -80,16 +83,16 @@ __global__ void tmpc_linearize_topology_kernel(Dims d, int B, const double *x0, 
     double *p = params + ((size_t)b * N + k) * d.npar;
     const double dummy_b = state_x[sc] + 100.0;                         // _dummy_b (:54)
     const bool dummy = (k == 0) || (is_original && is_original[b]);
-    const double r = 1e-3 + robot_radius;                               // guidance mode radius (:99)
+    auto radius_of = [&](int j) { return (obst_radius ? obst_radius[(size_t)sc * n_obs + j] : 1e-3) + robot_radius; };   // (:99, :140)
     double px = x0[((size_t)b * (N + 1) + k) * ext_nv(d) + ZX], py = x0[((size_t)b * (N + 1) + k) * ext_nv(d) + ZY];
-    const double *ob = obst + (size_t)sc * d.n_lin * N * 2;
-    if (!dummy) {
+    const double *ob = obst + (size_t)sc * n_obs * N * 2;
+    if (!dummy && n_obs > 0) {
         // projectToSafety (:130-148): at most 3 sweeps over the obstacles of ros_tools' Douglas-Rachford step with obstacle 0 as the
         // anchor.  ros_tools is not in the reference tree; restated from the published operator p <- (p + R_delta R_anchor p) / 2,
         // R = 2 P - I, P = nearest point outside the disc of radius r, applied when p is inside the obstacle's disc (same arithmetic
         // as modules.py::project_to_safety and the C++ DouglasRachford).  No FMA contraction: bit-equal to the host mirrors.
         const double ax0 = ob[(size_t)(k - 1) * 2], ay0 = ob[(size_t)(k - 1) * 2 + 1];          // anchor = obstacle 0 at step k-1
-        auto outside = [&](double qx, double qy, double cx, double cy, double &ox_, double &oy_) {
+        auto outside = [&](double qx, double qy, double cx, double cy, double r, double &ox_, double &oy_) {
             const double dx = qx - cx, dy = qy - cy;
             const double dist = sqrt(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)));
             if (dist >= r) { ox_ = qx; oy_ = qy; }
@@ -97,14 +100,15 @@ __global__ void tmpc_linearize_topology_kernel(Dims d, int B, const double *x0, 
             else { ox_ = cx; oy_ = cy + r; }
         };
         for (int sweep = 0; sweep < 3; sweep++)
-            for (int j = 0; j < d.n_lin; j++) {
+            for (int j = 0; j < n_obs; j++) {
                 const double ox = ob[((size_t)j * N + (k - 1)) * 2], oy = ob[((size_t)j * N + (k - 1)) * 2 + 1];
                 const double dx = px - ox, dy = py - oy;
+                const double r = radius_of(j);
                 if (sqrt(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy))) < r) {
                     double qx, qy, bx, by;
-                    outside(px, py, ax0, ay0, qx, qy);
+                    outside(px, py, ax0, ay0, r, qx, qy);
                     const double rx = __dmul_rn(2.0, qx) - px, ry = __dmul_rn(2.0, qy) - py;
-                    outside(rx, ry, ox, oy, bx, by);
+                    outside(rx, ry, ox, oy, r, bx, by);
                     const double sx = __dmul_rn(2.0, bx) - rx, sy = __dmul_rn(2.0, by) - ry;
                     px = (px + sx) / 2.0; py = (py + sy) / 2.0;
                 }
@@ -112,12 +116,15 @@ __global__ void tmpc_linearize_topology_kernel(Dims d, int B, const double *x0, 
     }
     for (int j = 0; j < d.n_lin; j++) {
         double a1 = 1.0, a2 = 0.0, bb = dummy_b;                        // _dummy_a1, _dummy_a2
-        if (!dummy) {
+        if (!dummy && j < n_obs) {
             const double ox = ob[((size_t)j * N + (k - 1)) * 2], oy = ob[((size_t)j * N + (k - 1)) * 2 + 1];
             const double dx = ox - px, dy = oy - py;
             const double dist = sqrt(dx * dx + dy * dy);
             a1 = dx / dist; a2 = dy / dist;
-            bb = a1 * ox + a2 * oy - r;
+            bb = a1 * ox + a2 * oy - radius_of(j);
+        } else if (!dummy && stat && j < n_obs + n_static) {            // static halfspaces of the stage, as given (:107-123)
+            const double *hs = stat + (((size_t)sc * N + k) * n_static + (j - n_obs)) * 3;
+            a1 = hs[0]; a2 = hs[1]; bb = hs[2];
         }
         p[ip_lin(d, j, 0)] = a1; p[ip_lin(d, j, 1)] = a2; p[ip_lin(d, j, 2)] = bb;
     }

@@ -1377,24 +1377,34 @@ int tmpc_select_best_records(tmpc_handle *h, const void *d_records, int32_t n_ra
     return TMPC_OK;
 }
 
-int tmpc_linearize_topology(tmpc_handle *h, const void *d_obstacle_pos, const void *d_scene_of, const void *d_state_x,
-                            double robot_radius, const void *d_is_original)
+int tmpc_linearize_topology_ex(tmpc_handle *h, const void *d_obstacle_pos, int32_t n_obstacles, const void *d_obstacle_radius,
+                               const void *d_static_halfspaces, int32_t n_static, const void *d_scene_of, const void *d_state_x,
+                               double robot_radius, const void *d_is_original)
 {
 #ifdef TMPC_GENERATED_STAGE
     if (h) h->err = "tmpc_linearize_topology: not available in a generated solver (its parameter layout is the module stack's)";
     return TMPC_ERR_INVALID;
 #endif
-    if (!h || h->B <= 0 || !h->params || !d_obstacle_pos || !d_scene_of || !d_state_x || h->d.n_lin <= 0) {
-        if (h) h->err = "tmpc_linearize_topology: bad argument / no batch / no topology rows";
+    if (!h || h->B <= 0 || !h->params || !d_scene_of || !d_state_x || h->d.n_lin <= 0 || n_obstacles < 0 || n_static < 0 ||
+        n_obstacles + n_static > h->d.n_lin || (n_obstacles > 0 && !d_obstacle_pos) || (n_static > 0 && !d_static_halfspaces)) {
+        if (h) h->err = "tmpc_linearize_topology: bad argument / no batch / more obstacle + static rows than the problem's topology rows";
         return TMPC_ERR_INVALID;
     }
     TMPC_HIP_CHECK(h, hipSetDevice(h->device));
     const int n = h->B * h->d.N;
     hipLaunchKernelGGL(tmpc::tmpc_linearize_topology_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->d, h->B,
                        h->x0, const_cast<double *>(h->params), (const double *)d_obstacle_pos, (const int *)d_scene_of,
-                       (const double *)d_state_x, robot_radius, (const uint8_t *)d_is_original);
+                       (const double *)d_state_x, robot_radius, (const uint8_t *)d_is_original, n_obstacles, (const double *)d_obstacle_radius,
+                       (const double *)d_static_halfspaces, n_static);
     TMPC_HIP_CHECK(h, hipGetLastError());
     return TMPC_OK;
+}
+
+int tmpc_linearize_topology(tmpc_handle *h, const void *d_obstacle_pos, const void *d_scene_of, const void *d_state_x,
+                            double robot_radius, const void *d_is_original)
+{
+    if (!h || !d_obstacle_pos) { if (h) h->err = "tmpc_linearize_topology: bad argument"; return TMPC_ERR_INVALID; }
+    return tmpc_linearize_topology_ex(h, d_obstacle_pos, h->d.n_lin, nullptr, nullptr, 0, d_scene_of, d_state_x, robot_radius, d_is_original);
 }
 
 int tmpc_scenario_halfspaces(tmpc_handle *h, const void *d_samples, int32_t n_pts, int32_t n_rows, const void *d_scene_of,

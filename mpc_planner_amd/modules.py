@@ -82,6 +82,11 @@ def _outside_disc(qx, qy, cx, cy, r):
 
 
 def project_to_safety(pos, obstacles_k, r):
+    """(r: one radius for every obstacle, or one per obstacle -- the `_use_guidance == false` branch uses each obstacle's own.)"""
+    return _project_to_safety(pos, obstacles_k, np.broadcast_to(np.asarray(r, float), (len(obstacles_k),)))
+
+
+def _project_to_safety(pos, obstacles_k, radii):
     """LinearizedConstraints::projectToSafety (linearized_constraints.cpp:130-148): at most 3 sweeps over the obstacles of
     ros_tools' Douglas-Rachford projection, with obstacle 0 as the anchor.  The ros_tools source is not in the reference tree
     (DESIGN.md U10); restated from the published Douglas-Rachford operator p <- (p + R_delta R_anchor p) / 2 with reflections
@@ -93,7 +98,7 @@ def project_to_safety(pos, obstacles_k, r):
         return np.array([px, py])
     ax, ay = float(obstacles_k[0][0]), float(obstacles_k[0][1])
     for _ in range(3):
-        for o in obstacles_k:
+        for o, r in zip(obstacles_k, radii):
             dx, dy = px - o[0], py - o[1]
             if np.sqrt(dx * dx + dy * dy) < r:
                 qx, qy = _outside_disc(px, py, ax, ay, r)
@@ -104,21 +109,26 @@ def project_to_safety(pos, obstacles_k, r):
     return np.array([px, py])
 
 
-def linearized_update(x0, obstacle_pos, robot_radius):
-    """LinearizedConstraints::update in guidance mode (linearized_constraints.cpp:49-105).
-    x0: warm start [N+1][nvar]; obstacle_pos [M][N][2].  Returns a1,a2,b [N][M] (row k=0 unused)."""
+def linearized_update(x0, obstacle_pos, robot_radius, obstacle_radius=None, static=None):
+    """LinearizedConstraints::update (linearized_constraints.cpp:49-123).  x0: warm start [N+1][nvar]; obstacle_pos [M][N][2].
+    obstacle_radius None: guidance mode, radius 1e-3 (:99); else [M], the `_use_guidance == false` branch with each obstacle's own radius.
+    static: [N][n_static][3] static halfspaces (a1, a2, b) per stage, appended behind the obstacle rows as they are (:107-123).
+    Returns a1, a2, b [N][M + n_static] (row k = 0 unused)."""
     Np1 = x0.shape[0]; N = Np1 - 1; M = obstacle_pos.shape[0]
-    a1 = np.zeros((N, M)); a2 = np.zeros((N, M)); b = np.zeros((N, M))
-    radius = 1e-3                                             # _use_guidance (:99)
+    n_static = 0 if static is None else static.shape[1]
+    a1 = np.zeros((N, M + n_static)); a2 = np.zeros((N, M + n_static)); b = np.zeros((N, M + n_static))
+    radii = (np.full(M, 1e-3) if obstacle_radius is None else np.asarray(obstacle_radius, float)) + robot_radius   # _use_guidance (:99, :140)
     for k in range(1, N):
-        pos = project_to_safety(x0[k, [IDX["x"], IDX["y"]]], obstacle_pos[:, k - 1], radius + robot_radius)
+        pos = project_to_safety(x0[k, [IDX["x"], IDX["y"]]], obstacle_pos[:, k - 1], radii) if M else x0[k, [IDX["x"], IDX["y"]]]
         for j in range(M):
             o = obstacle_pos[j, k - 1]
             diff = o - pos
             dist = np.sqrt(diff[0] * diff[0] + diff[1] * diff[1])
             a1[k, j] = diff[0] / dist
             a2[k, j] = diff[1] / dist
-            b[k, j] = a1[k, j] * o[0] + a2[k, j] * o[1] - (radius + robot_radius)
+            b[k, j] = a1[k, j] * o[0] + a2[k, j] * o[1] - radii[j]
+        if n_static:
+            a1[k, M:] = static[k, :, 0]; a2[k, M:] = static[k, :, 1]; b[k, M:] = static[k, :, 2]
     return a1, a2, b
 
 

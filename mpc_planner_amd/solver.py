@@ -42,7 +42,7 @@ EXPORTS = ["tmpc_default_dims", "tmpc_default_dims_ex", "tmpc_create", "tmpc_des
            "tmpc_linearize_topology", "tmpc_scenario_halfspaces", "tmpc_scenario_support", "tmpc_warmstart", "tmpc_init_with_guidance",
            "tmpc_debug_get_x0", "tmpc_debug_get_params", "tmpc_set_throughput_mode", "tmpc_solve_iterations",
            "tmpc_reset_multipliers", "tmpc_get_stream", "tmpc_kernel_info", "tmpc_set_slots", "tmpc_copy_state", "tmpc_scenario_empty_stages", "tmpc_sample_scenarios",
-           "tmpc_scenario_discard", "tmpc_scenario_discarded"]
+           "tmpc_scenario_discard", "tmpc_scenario_discarded", "tmpc_linearize_topology_ex"]
 
 class TmpcError(RuntimeError):
     pass
@@ -93,6 +93,8 @@ def load_library(path=None):
         lib.tmpc_sample_scenarios.argtypes = [vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, vp]
     if hasattr(lib, "tmpc_scenario_discard"):        # (absent from reference builds of earlier rounds used in A/B runs)
         lib.tmpc_scenario_discard.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int32, vp, C.c_double]
+    if hasattr(lib, "tmpc_linearize_topology_ex"):
+        lib.tmpc_linearize_topology_ex.argtypes = [vp, vp, C.c_int32, vp, vp, C.c_int32, vp, vp, C.c_double, vp]
     if hasattr(lib, "tmpc_scenario_discarded"):        # (absent from reference builds of earlier rounds used in A/B runs)
         lib.tmpc_scenario_discarded.argtypes = [vp, vp]
     if hasattr(lib, "tmpc_copy_state"):        # (absent from reference builds of earlier rounds used in A/B runs)
@@ -290,6 +292,15 @@ class BatchedSolver:
                                                      C.c_void_p(d_state_x), float(robot_radius),
                                                      C.c_void_p(d_is_original) if d_is_original else None),
                     "tmpc_linearize_topology")
+
+    def linearize_topology_ex(self, d_obstacle_pos, n_obstacles, d_scene_of, d_state_x, robot_radius, d_obstacle_radius=None,
+                              d_static_halfspaces=None, n_static=0, d_is_original=None):
+        """The whole of LinearizedConstraints::update / setParameters on device (tmpc_linearize_topology_ex): fewer obstacles than rows,
+        static halfspace rows (`add_halfspaces`), per-obstacle radii (the `_use_guidance == false` branch)."""
+        vp = lambda p_: C.c_void_p(p_) if p_ else None
+        self._check(self.lib.tmpc_linearize_topology_ex(self._h, vp(d_obstacle_pos), int(n_obstacles), vp(d_obstacle_radius),
+                                                        vp(d_static_halfspaces), int(n_static), C.c_void_p(d_scene_of), C.c_void_p(d_state_x),
+                                                        float(robot_radius), vp(d_is_original)), "tmpc_linearize_topology_ex")
 
     def scenario_halfspaces(self, d_samples, n_pts, n_rows, d_scene_of, d_state_x, radius, disc_offset=0.0):
         """Device scenario -> halfspace reduction of SH-MPC (raw device pointers; samples [n_scenes][N][n_pts][2]);

@@ -312,6 +312,52 @@ def test_full_size_properties_multi_scene_batch():
     s.close()
 
 
+def test_device_linearize_topology_static_rows_and_disc_mode():
+    """Round-2 verdict (missing 6): the rest of LinearizedConstraints::update on device -- fewer obstacles than topology rows, static
+    halfspace rows behind them (`add_halfspaces`, linearized_constraints.cpp:107-123), and the `_use_guidance == false` branch with
+    every obstacle's own radius (:63-73, :99, :140) -- against the host mirror."""
+    import torch
+    from mpc_planner_amd import scenes, modules as md
+    scs = [scenes.make_scene(70 + i, N=20, M=8, B=8) for i in range(2)]
+    B = sum(len(s["xinit"]) for s in scs)
+    xinit = np.concatenate([s["xinit"] for s in scs]); x0 = np.concatenate([s["x0"] for s in scs]); base = np.concatenate([s["params"] for s in scs])
+    scene_of = np.concatenate([np.full(len(s["xinit"]), i, np.int32) for i, s in enumerate(scs)])
+    state_x = np.array([s["xinit"][0, 0] for s in scs])
+    pm = scs[0]["pm"]
+    n_obs, n_static, N = 5, 2, 20
+    obst = np.ascontiguousarray(np.stack([s["obstacles"]["pos"][:n_obs] for s in scs]))           # [2][5][20][2]
+    rng = np.random.default_rng(4)
+    radii = rng.uniform(0.3, 0.6, (2, n_obs))
+    stat = np.zeros((2, N, n_static, 3))
+    ang = rng.uniform(0, 2 * np.pi, (2, N, n_static))
+    stat[..., 0] = np.cos(ang); stat[..., 1] = np.sin(ang); stat[..., 2] = rng.uniform(5.0, 9.0, (2, N, n_static))
+    x0[3, 6, 2:4] = obst[0, 2, 5] + np.array([0.2, 0.1])                        # a guess inside obstacle 2's (inflated) disc: projection
+    dev = torch.device("cuda")
+    t_ob = torch.from_numpy(obst).to(dev); t_sc = torch.from_numpy(scene_of).to(dev); t_sx = torch.from_numpy(state_x).to(dev)
+    t_r = torch.from_numpy(radii).to(dev); t_st = torch.from_numpy(stat).to(dev)
+    start = base.copy()
+    for j in range(8):
+        for f in ("a1", "a2", "b"):
+            start[:, :, pm.index(f"lin_constraint_{j}_{f}")] = -7.0
+    s = _solver(B_max=B)
+    for mode in ("guidance", "discs"):
+        ref = base.copy()
+        for b in range(B):
+            sc_ = scene_of[b]
+            lin = md.linearized_update(x0[b], obst[sc_], 0.325, obstacle_radius=None if mode == "guidance" else radii[sc_], static=stat[sc_])
+            md.linearized_set_parameters(pm, ref[b], state_x[sc_], lin, n_rows=8)           # rows 7: dummy
+        s.set_batch(xinit, x0, start)
+        s.linearize_topology_ex(t_ob.data_ptr(), n_obs, t_sc.data_ptr(), t_sx.data_ptr(), 0.325,
+                                d_obstacle_radius=None if mode == "guidance" else t_r.data_ptr(), d_static_halfspaces=t_st.data_ptr(), n_static=n_static)
+        got = s.debug_get_params()
+        np.testing.assert_allclose(got, ref, rtol=1e-14, atol=1e-14)
+        j5 = [pm.index(f"lin_constraint_5_{f}") for f in ("a1", "a2", "b")]
+        np.testing.assert_array_equal(got[0, 4, j5], stat[0, 4, 0])                           # static rows are copied as given
+        assert got[0, 4, pm.index("lin_constraint_7_b")] == state_x[0] + 100.0                # the row left over: dummy
+        assert (got[:, 0, pm.index("lin_constraint_5_a1")] == 1.0).all()                      # stage 0: dummies everywhere
+    s.close()
+
+
 def test_device_linearize_topology_matches_host_mirror():
     """SURVEY 8(f-1): LinearizedConstraints::update + setParameters on device vs the host mirror
     (mpc_planner_amd/modules.py, written after linearized_constraints.cpp:49-189), incl. the T-MPC++ dummy rows,
