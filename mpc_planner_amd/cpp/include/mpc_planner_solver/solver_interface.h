@@ -158,6 +158,10 @@ namespace MPCPlanner
         void initializeWithState(const State &initial_state);
         void initializeWithBraking(const State &initial_state);
         double getOutput(int k, std::string &&state_name) const;
+        /* Forces-style access (forces_solver_interface.cpp:241-244: getForcesOutput(_output, k, index) reads entry `index` of the
+         * stage vector z_k = [u_k; x_k] of stage k = 0 .. N-1 -- the Forces flavour has N stages x01 .. xN, the acados flavour N + 1
+         * nodes): callers written against the Forces interface index the same solution through this accessor. */
+        double getForcesStyleOutput(int k, int index) const { return index < (int)nu ? _output.utraj[k * nu + index] : _output.xtraj[k * nx + index - nu]; }
         std::string explainExitFlag(int exitflag) const;
         void printIfBoundLimited() const;
     };

@@ -41,8 +41,8 @@ __device__ __forceinline__ bool chol_rows(double (&f)[NV], int lane, double *r0,
         if (c == 1 && r1) *r1 = y;
         static_for<c + 1, NV>([&](auto j_) {
             constexpr int j = decltype(j_)::value;
-            const double ljc = bcast16<j>(f[c]);
-            f[j] -= f[c] * ljc;                     // lane i >= j: F_ij -= L_ic L_jc
+            const double ljc = bcast16<j>(f[c]);    // L_jc to the row's lanes (one v_mov_b64_dpp; folding it into the fmac as
+            f[j] -= f[c] * ljc;                     //  v_fmac_f64_dpp by hand measured no gain: profiles/round3_e_fused_fmac_dpp_rejected.json)
         });
     });
     (void)lane;                                       // entries above the diagonal are never read

@@ -114,6 +114,9 @@ int main(int argc, char **argv)
         ASSERT_TRUE(single._info.pobj == batch[b]->_info.pobj);          // bitwise: same kernel, batch-composition invariant
         for (int k = 0; k <= single.N; k++) ASSERT_TRUE(single.getOutput(k, "x") == batch[b]->getOutput(k, "x"));
         ASSERT_TRUE(single.getOutput(5, "v") > 1.0 && single.getOutput(single.N, "x") > 3.0);
+        // Forces-style indexing of the same solution (forces_solver_interface.cpp:241-244): entry i of z_k = [u_k; x_k], k < N
+        ASSERT_TRUE(single.getForcesStyleOutput(3, 0) == single.getOutput(3, "a") && single.getForcesStyleOutput(3, 1) == single.getOutput(3, "w"));
+        ASSERT_TRUE(single.getForcesStyleOutput(7, 2) == single.getOutput(7, "x") && single.getForcesStyleOutput(7, 5) == single.getOutput(7, "v"));
     }
     // ---- the one-iteration protocol (initializeOneIteration / solveOneIteration x n / completeOneIteration, :121-204; what
     // SH-MPC's scenario module drives, scenario_constraints.cpp:85) gives bitwise what solve() gives ----
