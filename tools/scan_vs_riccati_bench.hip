@@ -1,0 +1,230 @@
+// tools/scan_vs_riccati_bench.hip -- measurement for VERDICT r2 next-2 ("measure a parallel-in-time Riccati for the B = 64 tick"):
+// the Newton system of ONE interior-point iteration of the cfg-2 QP (N = 20, nu = 2, nx = 5) solved PARALLEL IN TIME by one
+// wavefront -- Schur complement in the dynamics multipliers + block cyclic reduction over the 20 stages, all 64 lanes busy --
+// in the same harness and units as tools/condensed_mfma_bench.hip: cycles per Newton system (factor + predictor solve + corrector
+// solve) next to what the production kernels spend on the same system with the sequential square-root Riccati recursion
+// (tmpc_debug_profile), and the error of the step against an extended-precision reference next to the sequential recursion's.
+//
+// Input: build/newton_systems.bin (tools/make_newton_systems.py): 64 REAL Newton systems of bench scenes on interior-point iterates
+// with barrier parameter 1e-1 .. 1e-6, each with its reference solution.
+//
+// Algorithm (one wave per system; lane = 3 k + s in the stage phases, like the production kernels' row layout):
+//   stage phase     L_k = chol(H_k) in registers (every lane of the stage), then 10 columns of P_k [F_k^T E^T] (P = H^-1, F = [B A], E = [0 I])
+//                   dealt to the three lanes, two triangular solves each; F_k applied to every column (structural sparsity of [B A]):
+//                       Y_jj = F_j P_j F_j^T + E P_{j+1} E^T,   Y_{j,j-1} = -F_j P_j E^T,   beta_j = rb_j - F_j P_j g_j + E P_{j+1} g_{j+1}
+//                   accumulated into LDS with ds_add_f64 (Y block tridiagonal, 20 blocks of 5 x 5, symmetric positive definite)
+//   cyclic reduction  level l (stride s = 2^l) eliminates the blocks j = s mod 2s: 10, 5, 2, 1, 1 of them.  One lane per COLUMN of
+//                   [Lc Rc] (the couplings to j - s and j + s): in-register chol(D_j) (5 x 5), w = D_j^-1 column, Lc^T w and Rc^T w
+//                   update the neighbours' diagonal blocks and create their new coupling; W = D^-1 [Lc Rc] replaces [Lc Rc]
+//   solve (per right-hand side: predictor, corrector)   beta from P_k g_k, forward elimination beta_{j+-s} -= W^T beta_j (one lane per
+//                   row), all D_j^-1 beta_j at once, back substitution pi_j = beta_j - W_L pi_{j-s} - W_R pi_{j+s}, and the step
+//                   dz_k = -P_k (g_k + F_k^T pi_k - E^T pi_{k-1}) per stage.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o build/scan_vs_riccati_bench tools/scan_vs_riccati_bench.hip
+// Run on the GPU box: build/scan_vs_riccati_bench [reps]  -> one JSON line (profiles/round3_f_scan_vs_riccati.json).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <vector>
+
+#include "../mpc_planner_amd/csrc/tmpc_scan.hpp"
+
+constexpr int N = 20, NU = 2, NX = 5, NV = 7, NS = N + 1;
+enum { PH_STAGE = 0, PH_CR, PH_SOLVE1, PH_SOLVE2, PH_COUNT };
+
+struct System {
+    double H[NS][49];
+    double g[2][NS][7];      // two right-hand sides (predictor, corrector)
+    double BA[N][35];
+    double rb[N][5];
+};
+
+// The device code is the product's (mpc_planner_amd/csrc/tmpc_scan.hpp); operands staged in LDS as the solve kernels hold them.
+constexpr int LDS_DOUBLES = NS * 28 + N * 35 + 2 * NS * 7 + N * 5 + NS * 7 + NS * 5 + tmpc::scan::lds_doubles(N);
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void scan_kernel(const System *__restrict__ sys, int n_sys, double *__restrict__ dz_out, long long *__restrict__ cycles, int reps)
+{
+    __shared__ __attribute__((aligned(16))) double smem[LDS_DOUBLES];
+    double *Hh = smem, *BA = Hh + NS * 28, *gh = BA + N * 35, *rb = gh + 2 * NS * 7, *dv = rb + N * 5, *dpi = dv + NS * 7, *scr = dpi + NS * 5;
+    const int lane = threadIdx.x;
+    const System &P = sys[blockIdx.x % n_sys];
+    for (int e = lane; e < NS * 28; e += 64) {
+        const int k = e / 28, r = e - k * 28;
+        int i = 0; while ((i + 1) * (i + 2) / 2 <= r) i++;
+        Hh[e] = P.H[k][i * 7 + (r - i * (i + 1) / 2)];
+    }
+    for (int e = lane; e < N * 35; e += 64) BA[e] = P.BA[0][e];
+    for (int e = lane; e < 2 * NS * 7; e += 64) gh[e] = P.g[0][0][e];
+    for (int e = lane; e < N * 5; e += 64) rb[e] = P.rb[0][e];
+    __syncthreads();
+    tmpc::scan::View V{Hh, BA, gh, rb, dv, dpi, scr, N};
+    tmpc::scan::View V2 = V; V2.gh = gh + NS * 7;
+    double *out = dz_out + (size_t)blockIdx.x * 2 * NS * NV;
+    long long acc[PH_COUNT] = {0, 0, 0, 0};
+    bool bad = false;
+    for (int rep = 0; rep < reps; rep++) {
+        long long t0 = clock64(), t1;
+        bad |= tmpc::scan::stage_phase(V, lane);
+        t1 = clock64(); acc[PH_STAGE] += t1 - t0; t0 = t1;
+        bad |= tmpc::scan::reduce(V, lane);
+        t1 = clock64(); acc[PH_CR] += t1 - t0; t0 = t1;
+        tmpc::scan::solve(V, lane, true);
+        for (int e = lane; e < NS * NV; e += 64) out[e] = dv[e];
+        t1 = clock64(); acc[PH_SOLVE1] += t1 - t0; t0 = t1;
+        tmpc::scan::solve(V2, lane, false);
+        for (int e = lane; e < NS * NV; e += 64) out[NS * NV + e] = dv[e];
+        t1 = clock64(); acc[PH_SOLVE2] += t1 - t0;
+    }
+    if (bad && lane == 0) out[0] = __builtin_nan("");
+    if (lane == 0 && cycles)
+        for (int i = 0; i < PH_COUNT; i++) cycles[(size_t)blockIdx.x * PH_COUNT + i] = acc[i];
+}
+
+// ---------------- host ----------------
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+// sequential square-root Riccati recursion in double (the production kernels' algorithm restated on the host): F = H + G^T G, G = Lp^T [B A]
+static void chol_host(double *A, int n) { for (int j = 0; j < n; j++) { for (int c = 0; c < j; c++) A[j * n + j] -= A[j * n + c] * A[j * n + c]; A[j * n + j] = sqrt(A[j * n + j]);
+    for (int i = j + 1; i < n; i++) { for (int c = 0; c < j; c++) A[i * n + j] -= A[i * n + c] * A[j * n + c]; A[i * n + j] /= A[j * n + j]; } for (int c = j + 1; c < n; c++) A[j * n + c] = 0.0; } }
+static void riccati_host(const double *H, const double *g, const double *BA, const double *rb, double *dz)
+{
+    double Lp[25], p[5];
+    for (int i = 0; i < 5; i++) { for (int j = 0; j < 5; j++) Lp[i * 5 + j] = H[N * 49 + (NU + i) * 7 + NU + j]; p[i] = g[N * 7 + NU + i]; }
+    chol_host(Lp, 5);
+    static double Lk[N][49], yk[N][2], f0[7];
+    for (int k = N - 1; k >= 0; k--) {
+        const double *F = BA + k * 35;
+        double G[35], Fm[49], f[7], t[5], u[5];
+        for (int i = 0; i < 5; i++) for (int j = 0; j < 7; j++) { double a = 0; for (int m = 0; m < 5; m++) a += Lp[m * 5 + i] * F[m * 7 + j]; G[i * 7 + j] = a; }
+        for (int i = 0; i < 7; i++) for (int j = 0; j < 7; j++) { double a = H[k * 49 + i * 7 + j]; for (int m = 0; m < 5; m++) a += G[m * 7 + i] * G[m * 7 + j]; Fm[i * 7 + j] = a; }
+        for (int i = 0; i < 5; i++) { double a = 0; for (int m = 0; m < 5; m++) a += Lp[m * 5 + i] * rb[k * 5 + m]; t[i] = a; }
+        for (int i = 0; i < 5; i++) { double a = p[i]; for (int m = 0; m < 5; m++) a += Lp[i * 5 + m] * t[m]; u[i] = a; }
+        for (int j = 0; j < 7; j++) { double a = g[k * 7 + j]; for (int m = 0; m < 5; m++) a += F[m * 7 + j] * u[m]; f[j] = a; }
+        if (k == 0) { double Luu[4] = {Fm[0], Fm[1], Fm[7], Fm[8]}; chol_host(Luu, 2); Lk[0][0] = Luu[0]; Lk[0][1] = Luu[2]; Lk[0][2] = Luu[3]; memcpy(f0, f, sizeof f); break; }
+        chol_host(Fm, 7); memcpy(Lk[k], Fm, sizeof Fm);
+        yk[k][0] = f[0] / Fm[0]; yk[k][1] = (f[1] - Fm[7] * yk[k][0]) / Fm[8];
+        for (int i = 0; i < 5; i++) { p[i] = f[NU + i] - Fm[(NU + i) * 7] * yk[k][0] - Fm[(NU + i) * 7 + 1] * yk[k][1]; for (int j = 0; j < 5; j++) Lp[i * 5 + j] = Fm[(NU + i) * 7 + NU + j]; }
+    }
+    double dx[5] = {0, 0, 0, 0, 0};
+    for (int k = 0; k < N; k++) {
+        double du[2];
+        if (k == 0) { const double l00 = Lk[0][0], l10 = Lk[0][1], l11 = Lk[0][2]; double y0 = f0[0] / l00, y1 = (f0[1] - l10 * y0) / l11; du[1] = -y1 / l11; du[0] = (-y0 - l10 * du[1]) / l00; }
+        else { const double *L = Lk[k]; double r0 = yk[k][0], r1 = yk[k][1];
+            for (int m = 0; m < 5; m++) { r0 += L[(NU + m) * 7] * dx[m]; r1 += L[(NU + m) * 7 + 1] * dx[m]; }
+            du[1] = -r1 / L[8]; du[0] = (-r0 - L[7] * du[1]) / L[0]; }
+        dz[k * 7] = du[0]; dz[k * 7 + 1] = du[1]; for (int m = 0; m < 5; m++) dz[k * 7 + 2 + m] = dx[m];
+        double nx[5];
+        for (int i = 0; i < 5; i++) { double a = rb[k * 5 + i]; for (int j = 0; j < 7; j++) a += BA[k * 35 + i * 7 + j] * dz[k * 7 + j]; nx[i] = a; }
+        memcpy(dx, nx, sizeof nx);
+    }
+    dz[N * 7] = dz[N * 7 + 1] = 0.0; for (int m = 0; m < 5; m++) dz[N * 7 + 2 + m] = dx[m];
+}
+
+static double rel_err(const double *a, const double *ref)
+{
+    double worst = 0.0;
+    for (int k = 0; k <= N; k++) {
+        double sc = 1e-6, d = 0.0;
+        for (int i = 0; i < NV; i++) { sc = fmax(sc, fabs(ref[k * 7 + i])); d = fmax(d, fabs(a[k * 7 + i] - ref[k * 7 + i])); }
+        worst = fmax(worst, d / sc);
+    }
+    return worst;
+}
+
+int main(int argc, char **argv)
+{
+    const int reps = argc > 1 ? atoi(argv[1]) : 50;
+    const char *path = argc > 2 ? argv[2] : "build/newton_systems.bin";
+    FILE *fh = fopen(path, "rb");
+    if (!fh) { printf("cannot open %s (python tools/make_newton_systems.py)\n", path); return 1; }
+    int hdr[4];
+    if (fread(hdr, 4, 4, fh) != 4 || hdr[1] != N || hdr[2] != NV || hdr[3] != NX) { printf("bad header\n"); return 1; }
+    const int B = hdr[0];
+    const size_t per = NS * 49 + NS * 7 + N * 35 + N * 5 + NS * 7;
+    std::vector<double> raw(per * B);
+    if (fread(raw.data(), 8, raw.size(), fh) != raw.size()) { printf("short file\n"); return 1; }
+    fclose(fh);
+    std::vector<System> h(B);
+    std::vector<double> ref((size_t)B * NS * 7), ric((size_t)B * 2 * NS * 7), g2((size_t)B * NS * 7);
+    srand(3);
+    static const int nz[12][2] = {{0, 0}, {0, 1}, {0, 4}, {0, 5}, {1, 0}, {1, 1}, {1, 4}, {1, 5}, {2, 1}, {3, 0}, {4, 0}, {4, 5}};
+    static const int ones[5][2] = {{0, 2}, {1, 3}, {2, 4}, {3, 5}, {4, 6}};
+    for (int b = 0; b < B; b++) {
+        const double *H = &raw[per * b], *g = H + NS * 49, *BA = g + NS * 7, *rb = BA + N * 35, *dz = rb + N * 5;
+        System &P = h[b];
+        memcpy(P.H, H, sizeof P.H); memcpy(P.g[0], g, sizeof P.g[0]); memcpy(P.BA, BA, sizeof P.BA); memcpy(P.rb, rb, sizeof P.rb);
+        memcpy(&ref[(size_t)b * NS * 7], dz, NS * 7 * 8);
+        for (int k = 0; k <= N; k++) for (int i = 0; i < 7; i++) {                  // corrector-like second right-hand side
+            const bool fixed = (k == 0 && i >= NU) || (k == N && i < NU);
+            P.g[1][k][i] = fixed ? 0.0 : g[k * 7 + i] * (1.0 + 0.3 * (rand() / (double)RAND_MAX - 0.5)) + 0.01 * (rand() / (double)RAND_MAX - 0.5);
+            g2[((size_t)b * NS + k) * 7 + i] = P.g[1][k][i];
+        }
+        for (int k = 0; k < N; k++) {                                               // the structure the kernel relies on
+            double chk[35]; memcpy(chk, BA + k * 35, sizeof chk);
+            for (auto &e : nz) chk[e[0] * 7 + e[1]] = 0.0;
+            for (auto &e : ones) { if (chk[e[0] * 7 + e[1]] != 1.0) { printf("[B A] structure: expected 1\n"); return 1; } chk[e[0] * 7 + e[1]] = 0.0; }
+            for (double v : chk) if (v != 0.0) { printf("[B A] structure: unexpected non-zero\n"); return 1; }
+        }
+        riccati_host(H, g, BA, rb, &ric[((size_t)b * 2) * NS * 7]);
+        riccati_host(H, &g2[(size_t)b * NS * 7], BA, rb, &ric[((size_t)b * 2 + 1) * NS * 7]);
+    }
+    System *d_sys; double *d_dz; long long *d_cyc;
+    const int B2 = 16384;
+    CK(hipMalloc(&d_sys, sizeof(System) * B));
+    CK(hipMalloc(&d_dz, sizeof(double) * (size_t)B2 * 2 * NS * NV));
+    CK(hipMalloc(&d_cyc, sizeof(long long) * (size_t)B * PH_COUNT));
+    CK(hipMemcpy(d_sys, h.data(), sizeof(System) * B, hipMemcpyHostToDevice));
+    // 1. one tick: B workgroups (one wave each), phases timed with the shader clock
+    scan_kernel<<<B, 64>>>(d_sys, B, d_dz, d_cyc, 2);
+    CK(hipDeviceSynchronize());
+    scan_kernel<<<B, 64>>>(d_sys, B, d_dz, d_cyc, reps);
+    CK(hipDeviceSynchronize());
+    std::vector<long long> cyc((size_t)B * PH_COUNT);
+    std::vector<double> dz((size_t)B * 2 * NS * NV);
+    CK(hipMemcpy(cyc.data(), d_cyc, cyc.size() * 8, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(dz.data(), d_dz, dz.size() * 8, hipMemcpyDeviceToHost));
+    double ph[PH_COUNT] = {0, 0, 0, 0};
+    for (int b = 0; b < B; b++) for (int i = 0; i < PH_COUNT; i++) ph[i] += (double)cyc[(size_t)b * PH_COUNT + i] / reps / B;
+    double e_scan = 0, e_ric = 0, e_scan_ric = 0, e_scan2 = 0; int bad = 0;
+    std::vector<double> es(B);
+    for (int b = 0; b < B; b++) {
+        const double *a = &dz[(size_t)b * 2 * NS * NV], *r = &ref[(size_t)b * NS * 7], *rc = &ric[(size_t)b * 2 * NS * 7];
+        double e1 = rel_err(a, r);
+        if (!(e1 == e1)) { bad++; e1 = 1e300; }
+        es[b] = e1;
+        e_scan = fmax(e_scan, e1); e_ric = fmax(e_ric, rel_err(rc, r)); e_scan_ric = fmax(e_scan_ric, rel_err(a, rc));
+        e_scan2 = fmax(e_scan2, rel_err(a + NS * NV, rc + NS * 7));
+    }
+    std::vector<double> sorted = es; std::sort(sorted.begin(), sorted.end());
+    // 2. throughput: B2 workgroups, one pass each, wall clock
+    hipEvent_t ev0, ev1; CK(hipEventCreate(&ev0)); CK(hipEventCreate(&ev1));
+    scan_kernel<<<B2, 64>>>(d_sys, B, d_dz, nullptr, 1);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(ev0));
+    for (int i = 0; i < 5; i++) scan_kernel<<<B2, 64>>>(d_sys, B, d_dz, nullptr, 1);
+    CK(hipEventRecord(ev1)); CK(hipEventSynchronize(ev1));
+    float ms; CK(hipEventElapsedTime(&ms, ev0, ev1)); ms /= 5;
+#ifdef TMPC_SCAN_PROFILE
+    {
+        unsigned long long z16[16] = {0}, c16[16];
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(g_scan_clk), z16, sizeof z16));
+        scan_kernel<<<B, 64>>>(d_sys, B, d_dz, d_cyc, reps);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpyFromSymbol(c16, HIP_SYMBOL(g_scan_clk), sizeof c16));
+        static const char *nm[10] = {"stage_zero_fill", "stage_chol7", "stage_columns", "stage_stores", "solve_rb", "solve_Pg", "solve_forward_levels", "solve_Dinv_beta", "solve_back_levels", "solve_recover"};
+        printf("{\"scan_profile_cycles\": {");
+        for (int i = 0; i < 10; i++) printf("\"%s\": %.0f%s", nm[i], (double)c16[i] / B / reps / (i >= 4 ? 2 : 1), i < 9 ? ", " : "}}\n");
+    }
+#endif
+    int occ = 0; CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, scan_kernel, 64, 0));
+    hipFuncAttributes fa; CK(hipFuncGetAttributes(&fa, (const void *)scan_kernel));
+    const double total = ph[0] + ph[1] + ph[2] + ph[3];
+    printf("{\"what\": \"parallel-in-time Newton solve (multiplier Schur complement + block cyclic reduction, one wave per system) vs the sequential Riccati recursion\", "
+           "\"systems\": %d, \"reps\": %d, \"cycles_per_system\": {\"factor_stage_phase\": %.0f, \"factor_cyclic_reduction\": %.0f, \"solve_predictor\": %.0f, \"solve_corrector\": %.0f, \"total\": %.0f}, "
+           "\"max_rel_err_vs_reference\": {\"scan\": %.3e, \"scan_median\": %.3e, \"sequential_riccati_f64\": %.3e}, \"scan_vs_sequential_max_rel\": %.3e, \"second_rhs_scan_vs_sequential_max_rel\": %.3e, \"nan_systems\": %d, "
+           "\"throughput\": {\"workgroups\": %d, \"kernel_ms\": %.4f, \"newton_systems_per_s\": %.0f, \"workgroups_per_cu\": %d}, \"vgprs\": %d, \"lds_bytes\": %d, \"scratch_bytes\": %d}\n",
+           B, reps, ph[0], ph[1], ph[2], ph[3], total, e_scan, sorted[B / 2], e_ric, e_scan_ric, e_scan2, bad,
+           B2, ms, B2 / (ms * 1e-3), occ, fa.numRegs, (int)fa.sharedSizeBytes, (int)fa.localSizeBytes);
+    return 0;
+}
