@@ -329,6 +329,31 @@ def main():
                "kernel_ms_b64": float(np.median(k64)), "solves_per_s_b64": float(TRAJ / (np.percentile(ts, 50) * 1e-3)),
                "kernel_variant": "latency (two waves per trajectory)" if lat_variant else "default",
                "includes": "H2D of params/warm start, solve kernel, FindBestPlanner, D2H of the index"}
+        # latency mode 2: the Newton systems solved parallel in time (csrc/tmpc_scan.hpp) -- same tick, its own parity block
+        if one.set_latency_mode(2):
+            ts2 = []
+            for i in range(a.latency_reps + 10):
+                t1 = time.perf_counter()
+                one.set_batch(hx, h0, hp); one.solve(sync=False); b2 = one.select_best()
+                ts2.append(time.perf_counter() - t1)
+            ts2 = np.array(ts2[10:]) * 1e3
+            one.enable_timing(32)
+            for _ in range(20):
+                one.solve(sync=False)
+            k64s = one.get_timings()
+            r2 = one.get()
+            one.set_latency_mode(1); one.solve(); r1 = one.get()
+            both = (r1["exit_code"] == 1) & (r2["exit_code"] == 1)
+            scan = {"p50_ms": float(np.percentile(ts2, 50)), "p90_ms": float(np.percentile(ts2, 90)), "kernel_ms_b64": float(np.median(k64s)),
+                    "kernel_variant": "latency 2 (one wave per trajectory, parallel-in-time Newton solve: Schur complement + block cyclic reduction)",
+                    "best_index_equal_mode_1": bool(b1 == b2),
+                    "vs_mode_1": {"exit_code_mismatch": int((r1["exit_code"] != r2["exit_code"]).sum()),
+                                  "ipm_iter_mismatch": int((r1["qp_iter_total"] != r2["qp_iter_total"]).sum()),
+                                  "ipm_iter_max_abs_diff": int(np.abs(r1["qp_iter_total"] - r2["qp_iter_total"]).max()),
+                                  "max_abs_xtraj_diff": float(np.abs(r1["xtraj"][both] - r2["xtraj"][both]).max()) if both.any() else None}}
+            if a.parity_check > 0:
+                scan["parity"] = parity_block(O, wl, {"xinit": hx, "x0": h0, "params": hp}, r2, min(a.parity_check, TRAJ), {})
+            lat["parallel_in_time"] = scan
         one.close()
 
     if rank == 0:

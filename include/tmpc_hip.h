@@ -132,9 +132,14 @@ int tmpc_copy_state(tmpc_handle *dst, tmpc_handle *src);
 /* Zero the multipliers of every slot (a new capsule / Solver_acados_reset). */
 int tmpc_reset_multipliers(tmpc_handle *h);
 /* Kernel variant for the following tmpc_solve calls: 0 (default) = throughput variant, 1 = latency variant (two waves per
- * trajectory; for control ticks of a few planners, like the 8 OpenMP threads of guidance_constraints.cpp:279).  Returns
- * 0, or 1 if the handle's shape has no separate latency variant (the default kernel is used).  A trajectory's result
- * is bitwise independent of the batch it is solved in; the two variants agree to rounding (1e-11), not bitwise. */
+ * trajectory; for control ticks of a few planners, like the 8 OpenMP threads of guidance_constraints.cpp:279), 2 = latency
+ * variant with the interior-point Newton systems solved parallel in time (multiplier Schur complement + block cyclic reduction
+ * over the stages, csrc/tmpc_scan.hpp) instead of by the stage-by-stage Riccati recursion that acados / HPIPM -- and modes 0, 1 --
+ * use: about half the kernel time of a tick.  Returns 0, or 1 if the handle's shape has no such variant (mode 2 then runs as mode 1,
+ * mode 1 as the default kernel).  A trajectory's result is bitwise independent of the batch it is solved in.  Modes 0 and 1 agree
+ * to rounding (1e-11), not bitwise.  Mode 2 is another factorisation of the same systems: its steps agree with the recursion's to
+ * ~1e-6 on ill-conditioned late iterations (each is that far from an exact solve), trajectories agree within the 1e-4 parity
+ * tolerance, and the interior-point iteration count of a solve can differ by one where a residual sits at the tolerance. */
 int tmpc_set_latency_mode(tmpc_handle *h, int32_t on);
 /* Throughput variant for large batches (many control ticks / scenario solvers per launch): one LANE per trajectory instead of
  * one wavefront -- every lane runs the scalar SQP_RTI program on its own trajectory, the per-trajectory state is streamed from a

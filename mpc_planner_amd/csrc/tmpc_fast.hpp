@@ -44,6 +44,7 @@ __device__ __forceinline__ Lds carve_fast(double *s, const Dims &d)
     L.v = take((N + 1) * NV); L.pq = take((N + 1) * NX); L.Hh = take((N + 1) * NP28);
     L.rg = take((N + 1) * NV); L.gh = take((N + 1) * NV); L.rb = take(N * NX); L.dv = take((N + 1) * NV);
     L.dpi = take((N + 1) * NX); L.pr = take((N + 1) * NX); L.y = take(N * NU); L.scr = take(64);
+    L.scan = s;                                         // (behind the work region: allocated for the parallel-in-time variant only, never touched otherwise)
     s = w;                                              // ... aliased by the staging region (linearisation <-> IPM)
     L.beta = take(N * L.nh); L.lamh = take(N * L.nh);
     L.t = L.lam = L.invt = L.qt = L.rdiag = nullptr;
@@ -113,6 +114,41 @@ struct Solo {
     __device__ __forceinline__ void solve(const Lds &L, const Dims &d, int tl, int sw, int, int phase, bool) const
     {
         if (phase == 1) riccati_forward<NTH, CP>(L, d, tl, sw); else riccati_solve<NTH, CP>(L, d, tl, sw);
+    }
+};
+
+// Latency mode 2: the Newton systems go through the parallel-in-time solve (tmpc_scan.hpp) instead of the Riccati recursion.  Same
+// operands in LDS (Hh, [B A], gh, rb), same results (dv, dpi); Hh is left as it is (ipm_fast rebuilds it every iteration anyway).
+struct ScanSolo {
+    static constexpr int NQ = 1;
+    __device__ __forceinline__ bool alive() const { return true; }
+    __device__ __forceinline__ void sync() const { __syncthreads(); }
+    __device__ __forceinline__ bool any(bool active) const { return active; }
+    // NTH = 128 (two waves per trajectory, the row phases on twice the lanes): the Newton solve runs on the wave `sw`, the other waits
+    template <int NTH, bool CP>
+    __device__ __forceinline__ bool factor(const Lds &L, const Dims &d, int tl, int sw, int) const
+    {
+        static_assert(!CP, "fast layout");
+        asm volatile("" : "+v"(tl));                 // opaque per call (see riccati_factor)
+        bool bad = false;
+        if (NTH == 64 || (tl >> 6) == sw) {
+            const scan::View V{L.Hh, L.BA, L.gh, L.rb, L.dv, L.dpi, L.scan, d.N};
+            bad = scan::factor(V, tl & 63);
+            if (NTH > 64 && (tl & 63) == 0) L.scr[63] = bad ? 1.0 : 0.0;
+        }
+        __syncthreads();
+        if (NTH > 64) bad = L.scr[63] != 0.0;
+        return bad;
+    }
+    template <int NTH, bool CP>
+    __device__ __forceinline__ void solve(const Lds &L, const Dims &d, int tl, int sw, int, int phase, bool) const
+    {
+        asm volatile("" : "+v"(tl));
+        if (NTH == 64 || (tl >> 6) == sw) {
+            const scan::View V{L.Hh, L.BA, L.gh, L.rb, L.dv, L.dpi, L.scan, d.N};
+            scan::solve(V, tl & 63, phase == 1);     // the predictor's right-hand side went through the factorisation
+        }
+        __syncthreads();
     }
 };
 
@@ -479,8 +515,9 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
 
 // Two-wave instantiations with 6 lanes per stage are built for two waves per SIMD (<= 256 registers): four trajectories
 // per CU stay resident with two waves each.  The build refuses any instantiation that needs scratch.
-template <int NLIN, int MM, int LPS, int NTH = 64, bool PROF = false>
-__global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu((NTH == 128 && LPS == 6 && NLIN == 8 && !PROF) ? 2 : 1, (NTH == 128 && LPS == 6 && NLIN == 8 && !PROF) ? 2 : 1)))
+template <int NLIN, int MM, int LPS, int NTH = 64, bool PROF = false, typename TEAM = Solo>
+__global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu((NTH == 128 && LPS == 6 && NLIN == 8 && !PROF && std::is_same<TEAM, Solo>::value) ? 2 : 1,
+                                                                    (NTH == 128 && LPS == 6 && NLIN == 8 && !PROF && std::is_same<TEAM, Solo>::value) ? 2 : 1)))
 void tmpc_solve_fast_kernel(Dims d, int B, const double *__restrict__ xinit,
                                                              const double *__restrict__ x0, const double *__restrict__ params,
                                                              double *__restrict__ xtraj, double *__restrict__ utraj,
@@ -528,7 +565,7 @@ void tmpc_solve_fast_kernel(Dims d, int B, const double *__restrict__ xinit,
         __syncthreads();
         pf.stop(PH_LIN);
         int iters = 0;
-        qp_status = ipm_fast<NLIN, MM, LPS, NTH, false>(L, d, tid, xi, &iters, pf, lam);
+        qp_status = ipm_fast<NLIN, MM, LPS, NTH, false>(L, d, tid, xi, &iters, pf, lam, TEAM());
         sqp_iter = it + 1; qp_iter_total += iters;
         if (qp_status != 0 && qp_status != 2) { status = 4; break; }
         status = 0;

@@ -79,7 +79,8 @@ struct Lds {
     // compact layout (tmpc_fast.hpp, carve_compact): z, pi, W, g, b point into the GLOBAL workspace; [B A] is not stored -- `tab` holds the 8 non-constant entries per stage
     // followed by 16 constants (ba_tab below); the rows' Jacobians are packed (pairs for topology rows, triples otherwise)
     double *tab;
-    int n_pair, dstride;                                 // rows r < n_pair store (gx, gy) only; doubles per stage in D
+    int n_pair, dstride;
+    double *scan;                                        // fast layout, latency mode 2: scratch of the parallel-in-time solve (tmpc_scan.hpp), behind the layout                                 // rows r < n_pair store (gx, gy) only; doubles per stage in D
 };
 
 // ---- sparse [B A] (compact kernels) ------------------------------------------------------------------------------
@@ -764,6 +765,7 @@ __global__ __launch_bounds__(NT) void tmpc_solve_kernel(Dims d, int B, const dou
 #endif  // TMPC_PROF_TU
 
 }  // namespace tmpc
+#include "tmpc_scan.hpp"
 #include "tmpc_fast.hpp"
 // Hand-written fast shapes (NLIN, MM, LPS, NTH): the list pick_fast_kernel / pick_latency_kernel dispatch over.  The library build
 // splits them over translation units to shorten the build: the profiled twins (PROF = true, tmpc_debug_profile) are compiled in a
@@ -901,6 +903,22 @@ static SolveKernel pick_latency_kernel(const Dims &d, bool prof)
     (void)d; (void)prof;
     return nullptr;
 }
+// Latency variant 2 (tmpc_set_latency_mode(h, 2)): one wave per trajectory like the fast kernels, the interior-point Newton systems
+// solved parallel in time (tmpc_scan.hpp) instead of by the sequential Riccati recursion.  One workgroup per CU is what a control
+// tick gives it anyway: built for one wave per SIMD (all 512 registers, 73 KB of LDS).  Another factorisation of the same systems:
+// steps agree with the recursion's to rounding (~1e-6 of a step on ill-conditioned late iterations, like the recursion itself
+// against an exact solve), so iteration counts can differ by one where a residual sits at the tolerance -- the caller opts in.
+static SolveKernel pick_scan_kernel(const Dims &d, int *threads)
+{
+#ifndef TMPC_GENERATED_STAGE
+    if (getenv("TMPC_FORCE_GENERIC") || d.N > 20 || d.N < 2) return nullptr;
+    const char *w = getenv("TMPC_SCAN_WAVES");               // A/B: "1" = one wave per trajectory
+    if (d.n_up == 8 && d.M == 8 && d.N <= 2 * (64 / 6) && !(w && atoi(w) == 1)) { *threads = 128; return (SolveKernel)tmpc_solve_fast_kernel<8, 8, 6, 128, false, ScanSolo>; }
+    if (d.n_up == 8 && d.M == 8) { *threads = 64; return (SolveKernel)tmpc_solve_fast_kernel<8, 8, 3, 64, false, ScanSolo>; }
+#endif
+    (void)d; (void)threads;
+    return nullptr;
+}
 }  // namespace tmpc
 
 struct tmpc_handle {
@@ -916,14 +934,17 @@ struct tmpc_handle {
     size_t lds_bytes = 0;
     tmpc::SolveKernel kernel = nullptr;
     int threads = tmpc::NT;          // threads per trajectory (64, or 128 for the two-wave fast variant)
-    tmpc::SolveKernel kernel_lat = nullptr;   // optional latency variant (128 threads), used when latency_mode is on
+    tmpc::SolveKernel kernel_lat = nullptr;   // optional latency variant (128 threads), used when latency_mode is 1
+    tmpc::SolveKernel kernel_scan = nullptr;  // optional latency variant 2 (parallel-in-time Newton solve, 64 threads)
+    size_t lds_bytes_scan = 0;
+    int scan_threads = 64;
     size_t lds_bytes_fast = 0;                // LDS of the fast-layout kernels (kernel_lat, the profiled twin) when `kernel` is compact
     bool compact = false;                     // `kernel` is a compact persistent kernel: grid = resident workgroups, needs ws + ticket
     int team = 1;                             // trajectories per workgroup of the compact / team kernel (1, 2 or 4 waves)
     int grid_max = 0;                         // resident workgroups of the compact kernel on this device
     double *ws = nullptr;                     // [grid_max][ws_doubles(N)] per-workgroup NLP workspace
     int *ticket = nullptr;
-    bool latency_mode = false;
+    int latency_mode = 0;                     // 0: throughput kernels, 1: two-wave variant, 2: parallel-in-time variant
     bool throughput_mode = false;             // lane-per-trajectory kernels (tmpc_lanes.hip) instead of one wave per trajectory
     tmpc::lanes::Context *lanes = nullptr;    // their HBM workspace, created when the mode is first enabled
     bool fast = false;
@@ -1019,7 +1040,7 @@ int tmpc_create(tmpc_handle **out, const tmpc_dims *dims, int32_t B_max, int32_t
     for (int i = 0; i < TMPC_NV; i++) { d.lb[i] = dims->lb[i]; d.ub[i] = dims->ub[i]; }
     tmpc::derive_dims(d);
     h->kernel = tmpc::pick_fast_kernel(d, &h->threads, false);
-    h->latency_mode = getenv("TMPC_LATENCY_MODE") != nullptr;      // experiments: latency variant regardless of the caller
+    if (const char *lm = getenv("TMPC_LATENCY_MODE")) h->latency_mode = atoi(lm) == 2 ? 2 : 1;      // experiments: latency variant regardless of the caller
     h->fast = h->kernel != nullptr;
     if (h->fast) h->lds_bytes = sizeof(double) * (size_t)tmpc::lds_doubles_fast(d.N, d.n_up + d.M);
     else { h->kernel = tmpc::tmpc_solve_kernel; h->lds_bytes = sizeof(double) * (size_t)tmpc::lds_doubles(d.N, d.n_up + d.M); }
@@ -1030,6 +1051,11 @@ int tmpc_create(tmpc_handle **out, const tmpc_dims *dims, int32_t B_max, int32_t
     if (h->fast && h->threads == tmpc::NT && (h->kernel_lat = tmpc::pick_latency_kernel(d, false)) != nullptr) {
         if (hipFuncSetAttribute((const void *)h->kernel_lat, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes_fast) != hipSuccess)
             h->kernel_lat = nullptr;
+    }
+    if (h->fast && h->threads == tmpc::NT && (h->kernel_scan = tmpc::pick_scan_kernel(d, &h->scan_threads)) != nullptr) {
+        h->lds_bytes_scan = h->lds_bytes_fast + sizeof(double) * (size_t)tmpc::scan::lds_doubles(d.N);
+        if (hipFuncSetAttribute((const void *)h->kernel_scan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes_scan) != hipSuccess)
+            h->kernel_scan = nullptr;
     }
     if (tmpc::SolveKernel kc = (h->fast && h->threads == tmpc::NT) ? tmpc::pick_compact_kernel(d, false, &h->team) : nullptr) {
         h->kernel = kc; h->compact = true;
@@ -1130,12 +1156,13 @@ static int launch_solve(tmpc_handle *h, int n_iter, int st_flags)
         tmpc::Dims dd = h->d;
         dd.n_sqp = n_iter;
         tmpc::StateIO io{h->st_z, h->st_pi, h->st_lamh, h->st_stopped, st_flags, h->ws, h->ticket, h->slots_set ? h->d_slot : nullptr, h->st_has};
-        const bool lat = h->kernel_lat && h->latency_mode;
-        const bool cp = h->compact && !lat;
+        const bool lat2 = h->kernel_scan && h->latency_mode == 2;
+        const bool lat = !lat2 && h->kernel_lat && h->latency_mode != 0;          // (mode 2 without a scan variant falls back to the two-wave variant)
+        const bool cp = h->compact && !lat && !lat2;
         if (cp) TMPC_HIP_CHECK(h, hipMemsetAsync(h->ticket, 0, 8 * 4, h->stream));    // the persistent launch's work counters (one per XCD)
         const int teams = (h->B + h->team - 1) / h->team;                              // workgroups' worth of work of a persistent launch
-        hipLaunchKernelGGL(lat ? h->kernel_lat : h->kernel, dim3(cp ? (teams < h->grid_max ? teams : h->grid_max) : h->B),
-                           dim3(lat ? 128 : (cp ? 64 * h->team : h->threads)), lat ? h->lds_bytes_fast : h->lds_bytes, h->stream, dd, h->B,
+        hipLaunchKernelGGL(lat2 ? h->kernel_scan : lat ? h->kernel_lat : h->kernel, dim3(cp ? (teams < h->grid_max ? teams : h->grid_max) : h->B),
+                           dim3(lat2 ? h->scan_threads : lat ? 128 : (cp ? 64 * h->team : h->threads)), lat2 ? h->lds_bytes_scan : lat ? h->lds_bytes_fast : h->lds_bytes, h->stream, dd, h->B,
                            h->xinit, h->x0, h->params, h->xtraj, h->utraj, h->pobj, h->exit_code, h->qp_status,
                            h->sqp_iter, h->res_eq, h->qp_iter, (long long *)nullptr, io);
         TMPC_HIP_CHECK(h, hipGetLastError());
@@ -1225,8 +1252,10 @@ int tmpc_reset_multipliers(tmpc_handle *h)
 int tmpc_set_latency_mode(tmpc_handle *h, int32_t on)
 {
     if (!h) return TMPC_ERR_INVALID;
-    h->latency_mode = on != 0;
-    return (h->latency_mode && !h->kernel_lat) ? 1 : TMPC_OK;      // 1: accepted, but this shape has no latency variant
+    if (on < 0 || on > 2) return TMPC_ERR_INVALID;
+    h->latency_mode = on;
+    if (on == 2) return h->kernel_scan ? TMPC_OK : 1;              // 1: accepted, but this shape has no such variant (mode 2 then runs as mode 1 if that exists)
+    return (on == 1 && !h->kernel_lat) ? 1 : TMPC_OK;
 }
 
 int tmpc_set_slots(tmpc_handle *h, const int32_t *slots)

@@ -192,8 +192,9 @@ class BatchedSolver:
             self._check(self.lib.tmpc_synchronize(self._h), "tmpc_synchronize")
 
     def set_latency_mode(self, on=True):
-        """Two-waves-per-trajectory kernel variant for small control ticks; returns False if the shape has none."""
-        rc = self.lib.tmpc_set_latency_mode(self._h, int(bool(on)))
+        """Kernel variant for small control ticks: True / 1 = two waves per trajectory, 2 = one wave per trajectory with the Newton systems
+        solved parallel in time (csrc/tmpc_scan.hpp), False / 0 = the throughput kernels; returns False if the shape has no such variant."""
+        rc = self.lib.tmpc_set_latency_mode(self._h, int(on))
         if rc < 0:
             self._check(rc, "tmpc_set_latency_mode")
         return rc == 0
