@@ -164,6 +164,9 @@ def main():
     ap.add_argument("--cpu-scenes", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--latency-reps", type=int, default=100)
+    ap.add_argument("--latency-mode", type=int, default=0, choices=[0, 1, 2],
+                    help="kernel variant of the timed launch (tmpc_set_latency_mode): 0 throughput kernels (default, what `value` of cfg 2 is quoted on), "
+                         "1 two waves per trajectory, 2 parallel-in-time Newton solve -- for the small one-set workloads (cfg 4 share, cfg 5), which are one dependent chain deep")
     ap.add_argument("--parity-check", type=int, default=256,
                     help="trajectories of the timed launch re-solved by the CPU oracle after timing (0 = skip)")
     a = ap.parse_args()
@@ -225,6 +228,7 @@ def main():
     sv.set_batch_device(B, t_xinit.data_ptr(), t_x0.data_ptr(), t_params.data_ptr())
     sv.enable_timing(a.steps + a.warmup + 4)
     kernel_info = sv.kernel_info()                        # which solve kernel the handle dispatches (fast / compact / ...), from the library
+    lat_mode_ok = sv.set_latency_mode(a.latency_mode) if a.latency_mode else None
 
     # The whole step is stream-ordered on the handle's stream: solve -> pack -> (N > 1: the all-gather, issued with that stream as
     # torch's current stream, so RCCL waits for the records and the selection waits for RCCL) -> FindBestPlanner.  No host
@@ -345,7 +349,7 @@ def main():
             one.set_latency_mode(1); one.solve(); r1 = one.get()
             both = (r1["exit_code"] == 1) & (r2["exit_code"] == 1)
             scan = {"p50_ms": float(np.percentile(ts2, 50)), "p90_ms": float(np.percentile(ts2, 90)), "kernel_ms_b64": float(np.median(k64s)),
-                    "kernel_variant": "latency 2 (one wave per trajectory, parallel-in-time Newton solve: Schur complement + block cyclic reduction)",
+                    "kernel_variant": "latency 2 (two waves per trajectory, parallel-in-time Newton solve: Schur complement + block cyclic reduction)",
                     "best_index_equal_mode_1": bool(b1 == b2),
                     "vs_mode_1": {"exit_code_mismatch": int((r1["exit_code"] != r2["exit_code"]).sum()),
                                   "ipm_iter_mismatch": int((r1["qp_iter_total"] != r2["qp_iter_total"]).sum()),
@@ -392,6 +396,8 @@ def main():
                        "trajectories_per_launch_per_gpu": B, "scenes_per_launch": n_sets,
                        "success_fraction": float(ok.mean()), "mean_sqp_iter": n_sqp_mean, "mean_ipm_iter_per_qp": ipm_per_qp,
                        "value_counts": "successful solves (exit_code == 1) only",
+                       "kernel_variant": {"latency_mode": a.latency_mode, "accepted": lat_mode_ok,
+                                          "what": ["throughput kernels", "two waves per trajectory", "parallel-in-time Newton solve (csrc/tmpc_scan.hpp)"][a.latency_mode]},
                        "parallelism": f"trajectory-sharded x{world}, one 16 B/trajectory all-gather" if world > 1 else "single GPU"},
             "roofline": {"bound": "valu_fp64", "achieved": tflops, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": tflops / FP64_VALU_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_note,

@@ -13,6 +13,15 @@
 
 namespace MPCPlanner
 {
+    /* Kernel variant of a control tick (tmpc_set_latency_mode): 1 = two waves per trajectory with the same stage-by-stage Riccati
+     * recursion as acados / HPIPM (default: rounding-equal to the throughput kernels); MPC_PLANNER_HIP_TICK_VARIANT=2 selects the
+     * parallel-in-time Newton solve (about 30 % less kernel time per tick; steps equal to ~1e-6, see include/tmpc_hip.h). */
+    static int tickKernelVariant()
+    {
+        const char *v = std::getenv("MPC_PLANNER_HIP_TICK_VARIANT");
+        return (v && std::atoi(v) == 2) ? 2 : 1;
+    }
+
     static std::string g_config_dir = "config";
     void setSolverConfigPath(const std::string &dir) { g_config_dir = dir; }
 
@@ -141,7 +150,7 @@ namespace MPCPlanner
             std::printf("tmpc_create() returned status %d (no MI355X / library not built). Exiting.\n", status);
             std::exit(1);
         }
-        tmpc_set_latency_mode(_handle, 1);              // a Solver serves control ticks of a few planners: latency variant
+        tmpc_set_latency_mode(_handle, tickKernelVariant());   // a Solver serves control ticks of a few planners: latency variant
         tmpc_enable_timing(_handle, 4);                 // HIP events around every launch -> _info.elapsed_time / solvetime / min_time
     }
 
@@ -241,7 +250,7 @@ namespace MPCPlanner
         applyModelBounds(d, s0->_model_map);
         tmpc_handle *h = nullptr;
         if (tmpc_create(&h, &d, cap, s0->_device)) { std::printf("tmpc_create() failed. Exiting.\n"); std::exit(1); }
-        tmpc_set_latency_mode(h, 1);                    // same variant as solve(): solve() and solveBatch() stay bitwise equal
+        tmpc_set_latency_mode(h, tickKernelVariant());  // same variant as solve(): solve() and solveBatch() stay bitwise equal
         tmpc_enable_timing(h, 4);
         if (_handle) {
             if (!settings_changed && tmpc_copy_state(h, _handle)) { std::fprintf(stderr, "tmpc_copy_state: %s\n", tmpc_last_error(h)); std::exit(1); }

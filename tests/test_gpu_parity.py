@@ -745,13 +745,27 @@ def test_latency_variant_matches_oracle_and_default_kernel():
     s5.close()
 
 
+def _compare_relaxed_iterations(got, xt, ut, info, tol=1e-4):
+    """Another factorisation of the same Newton systems: everything as in _compare, except that the interior-point iteration count of a
+    solve may differ by a step where a residual sits at the tolerance (at most 2 iterations on at most 10 % of the trajectories)."""
+    assert (got["exit_code"] == info["exit_code"]).all() and (got["sqp_iter"] == info["sqp_iter"]).all()
+    ok = info["exit_code"] == 1
+    assert (got["qp_status"][ok] == info["qp_status"][ok]).all()
+    dit = np.abs(got["qp_iter_total"][ok] - info["qp_iter_total"][ok])
+    assert dit.max() <= 2 and (dit > 0).mean() <= 0.10, (dit.max(), (dit > 0).mean())
+    sx = np.maximum(np.abs(xt[ok]).max(axis=2, keepdims=True), 1.0); su = np.maximum(np.abs(ut[ok]).max(axis=2, keepdims=True), 1.0)
+    ex = (np.abs(got["xtraj"][ok] - xt[ok]) / sx).max(); eu = (np.abs(got["utraj"][ok] - ut[ok]) / su).max()
+    assert ex < tol and eu < tol, (ex, eu)
+    return int((dit > 0).sum())
+
+
 @pytest.mark.parametrize("scene", [1, 4])
 def test_parallel_in_time_variant_matches_oracle(scene):
     """tmpc_set_latency_mode(h, 2): the Newton systems solved parallel in time (Schur complement + block cyclic reduction,
-    csrc/tmpc_scan.hpp) instead of by the Riccati recursion the oracle -- like acados / HPIPM -- runs.  Another factorisation of the
-    same systems: exit codes, SQP iteration counts and QP statuses are the oracle's, trajectories within the parity tolerance 1e-4
-    (observed: below 1e-6), the interior-point iteration count of a solve may differ by a step where a residual sits at the tolerance
-    (bounded here: at most 2 iterations on at most 10 % of the trajectories).  A trajectory's result does not depend on the batch."""
+    csrc/tmpc_scan.hpp) instead of by the Riccati recursion the oracle -- like acados / HPIPM -- runs.  Exit codes, SQP iteration
+    counts and QP statuses are the oracle's, trajectories within the parity tolerance 1e-4 (observed: 1e-13), interior-point iteration
+    counts equal on these scenes (the bound of _compare_relaxed_iterations is what the interface promises).  A trajectory's result
+    does not depend on the batch."""
     import oracle_lib as O
     from mpc_planner_amd import scenes
     sc = scenes.make_scene(scene, N=20, M=8, B=64)
@@ -760,20 +774,34 @@ def test_parallel_in_time_variant_matches_oracle(scene):
     s.set_batch(sc["xinit"], sc["x0"], sc["params"]); s.solve(); got = s.get()
     pb = O.problem(N=20, S=5, n_lin=8, M=8)
     xt, ut, info = O.solve_batch(pb, sc["xinit"], sc["x0"].reshape(64, -1), sc["params"].reshape(64, -1))
-    assert (got["exit_code"] == info["exit_code"]).all() and (got["sqp_iter"] == info["sqp_iter"]).all()
-    ok = info["exit_code"] == 1
-    assert ok.sum() >= 32 and (got["qp_status"][ok] == info["qp_status"][ok]).all()
-    dit = np.abs(got["qp_iter_total"][ok] - info["qp_iter_total"][ok])
-    assert dit.max() <= 2 and (dit > 0).mean() <= 0.10, (dit.max(), (dit > 0).mean())
-    sx = np.maximum(np.abs(xt[ok]).max(axis=2, keepdims=True), 1.0); su = np.maximum(np.abs(ut[ok]).max(axis=2, keepdims=True), 1.0)
-    ex = (np.abs(got["xtraj"][ok] - xt[ok]) / sx).max(); eu = (np.abs(got["utraj"][ok] - ut[ok]) / su).max()
-    assert ex < 1e-4 and eu < 1e-4, (ex, eu)
+    assert (info["exit_code"] == 1).sum() >= 32
+    _compare_relaxed_iterations(got, xt, ut, info)
     s.set_batch(sc["xinit"][9:10], sc["x0"][9:10], sc["params"][9:10]); s.solve(); one = s.get()
     assert np.array_equal(one["xtraj"][0], got["xtraj"][9]) and one["pobj"][0] == got["pobj"][9]
     s.close()
-    s5 = _solver(n_lin=0, M=0, n_slk=24, slack=1, B_max=4)        # a shape without such a variant: accepted, default kernel
-    assert s5.set_latency_mode(2) is False
-    s5.close()
+    s3 = _solver(N=30, n_slk=12, slack=1, B_max=4)                # N > 20 (cfg 3): no such variant -- accepted, runs as before
+    assert s3.set_latency_mode(2) is False
+    s3.close()
+
+
+@pytest.mark.parametrize("cfg", ["cfg1", "cfg4", "cfg5"])
+def test_parallel_in_time_variant_other_shapes(cfg):
+    """Latency mode 2 on the other one-wave shapes (runtime row counts, two waves per trajectory): BASELINE cfg 1 / 4 / 5 against the oracle."""
+    import oracle_lib as O
+    from mpc_planner_amd import scenes
+    if cfg == "cfg1":
+        sc = scenes.make_batch(range(50, 59), N=20, M=4, B=1, guidance=False); pkw = dict(N=20, S=5, n_lin=0, M=4)
+    else:
+        mk, pkw = BASELINE_CASES[cfg]
+        sc = mk(scenes)
+    B = min(sc["xinit"].shape[0], 128)
+    s = _solver(B_max=B, **pkw)
+    assert s.set_latency_mode(2)
+    s.set_batch(sc["xinit"][:B], sc["x0"][:B], sc["params"][:B]); s.solve(); got = s.get()
+    pb = O.problem(**pkw)
+    xt, ut, info = O.solve_batch(pb, sc["xinit"][:B], sc["x0"][:B].reshape(B, -1), sc["params"][:B].reshape(B, -1))
+    _compare_relaxed_iterations(got, xt, ut, info)
+    s.close()
 
 
 @pytest.mark.parametrize("N", [2, 5, 21, 22, 32])
