@@ -14,7 +14,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out")
 tag = sys.argv[1] if len(sys.argv) > 1 else "profile"
-BENCH = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "1", "--no-cpu-baseline", "--latency-reps", "0", "--no-lanes", "--parity-check", "0", "--gen-workers", "1", "--scene-cache", "/tmp/tmpc_bench_scenes"]
+BENCH = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "1", "--no-cpu-baseline", "--latency-reps", "0", "--no-lanes", "--no-tight", "--parity-check", "0", "--gen-workers", "1", "--scene-cache", "/tmp/tmpc_bench_scenes"]
 env = dict(os.environ, TMPDIR="/tmp")
 
 
