@@ -163,6 +163,8 @@ def main():
     ap.add_argument("--scene-cache", default="", help="npz file to keep the generated batch in (repeated profiler passes)")
     ap.add_argument("--cpu-scenes", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-param-sharing", action="store_true",
+                    help="do not give the tmpc_set_param_sharing hint (A/B: every trajectory reads its own copy of its set's parameter rows)")
     ap.add_argument("--latency-reps", type=int, default=100)
     ap.add_argument("--latency-mode", type=int, default=0, choices=[0, 1, 2],
                     help="kernel variant of the timed launch (tmpc_set_latency_mode): 0 throughput kernels (default, what `value` of cfg 2 is quoted on), "
@@ -229,6 +231,12 @@ def main():
     sv.enable_timing(a.steps + a.warmup + 4)
     kernel_info = sv.kernel_info()                        # which solve kernel the handle dispatches (fast / compact / ...), from the library
     lat_mode_ok = sv.set_latency_mode(a.latency_mode) if a.latency_mode else None
+    # A guidance set's planners carry copies of the main solver's parameters and differ in their own halfspace rows only
+    # (guidance_constraints.cpp:300-318): tell the library which entries are such copies (checked on the host, entry by entry)
+    share_map = None
+    if not a.no_param_sharing:
+        share_map = solver.param_sharing_map(batch["params"], dims, traj_local)
+        sv.set_param_sharing(share_map)
 
     # The whole step is stream-ordered on the handle's stream: solve -> pack -> (N > 1: the all-gather, issued with that stream as
     # torch's current stream, so RCCL waits for the records and the selection waits for RCCL) -> FindBestPlanner.  No host
@@ -380,7 +388,8 @@ def main():
                     pj = json.load(open(pmc))
                 except Exception:
                     continue
-                if pj.get("library_sha256") == lib_hash and pj.get("trajectories_per_launch") == B:
+                if pj.get("library_sha256") == lib_hash and pj.get("trajectories_per_launch") == B \
+                        and ("--no-param-sharing" in pj.get("extra_bench_args", [])) == a.no_param_sharing:
                     traffic = pj.get("hbm_bytes_per_launch")
                     traffic_note = f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this build ({lib_hash[:12]}), profiles/{os.path.basename(pmc)}"
                     break
@@ -396,6 +405,8 @@ def main():
                        "trajectories_per_launch_per_gpu": B, "scenes_per_launch": n_sets,
                        "success_fraction": float(ok.mean()), "mean_sqp_iter": n_sqp_mean, "mean_ipm_iter_per_qp": ipm_per_qp,
                        "value_counts": "successful solves (exit_code == 1) only",
+                       "param_sharing": {"hint": share_map is not None, "entries_reading_a_shared_row": int((share_map != np.arange(B)).sum()) if share_map is not None else 0,
+                                         "what": "tmpc_set_param_sharing: a set's copies of the obstacle / spline / weight rows are read from the set's first entry (checked equal on the host); results bitwise unchanged"},
                        "kernel_variant": {"latency_mode": a.latency_mode, "accepted": lat_mode_ok,
                                           "what": ["throughput kernels", "two waves per trajectory", "parallel-in-time Newton solve (csrc/tmpc_scan.hpp)"][a.latency_mode]},
                        "parallelism": f"trajectory-sharded x{world}, one 16 B/trajectory all-gather" if world > 1 else "single GPU"},

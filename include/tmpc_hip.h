@@ -127,6 +127,16 @@ int tmpc_solve_iterations(tmpc_handle *h, int32_t n_iter, int32_t flags);
  * in [0, B_max).  The map stays in force for the following tmpc_solve_iterations calls until it is replaced or cleared
  * (slots = NULL).  A slot nothing was stored in yet starts like a fresh capsule whatever the keep-flags say.  Wave kernels only. */
 int tmpc_set_slots(tmpc_handle *h, const int32_t *slots);
+/* Parameter-sharing hint for the current batch (optional; results are bitwise the same with and without it).  base_of[b] (host, one
+ * entry per batch entry, values in [0, B)): entry b's parameter rows equal entry base_of[b]'s except for its own topology and
+ * scenario halfspace rows (LinearizedConstraints / ScenarioConstraints::setParameters) -- which is how a guidance set comes about:
+ * every planner's solver starts as a copy of the main solver (guidance_constraints.cpp:300 `*solver = *_solver`) and the shared
+ * modules write the same values into each (:312-318).  The kernels then read everything but those rows from entry base_of[b]: a set's
+ * 64 copies of the obstacle / spline / weight rows are fetched once instead of 64 times (the parameter rows are 2/3 of the path's
+ * algorithmic bytes, and at eight trajectories per CU they no longer fit the L2 next to the solve's workspace).  The CALLER guarantees
+ * the equality; the map stays in force until it is replaced, cleared (NULL) or the batch size changes.  Ignored by the lane kernels
+ * (tmpc_set_throughput_mode) and by generated solvers. */
+int tmpc_set_param_sharing(tmpc_handle *h, const int32_t *base_of);
 /* Copy the persistent state of min(B_max) slots from another handle of the same shape and device (a caller that outgrew its handle). */
 int tmpc_copy_state(tmpc_handle *dst, tmpc_handle *src);
 /* Zero the multipliers of every slot (a new capsule / Solver_acados_reset). */

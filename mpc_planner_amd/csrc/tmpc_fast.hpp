@@ -537,7 +537,8 @@ void tmpc_solve_fast_kernel(Dims d, int B, const double *__restrict__ xinit,
     const Lds L = carve_fast(smem, d);
     const int N = d.N;
     const double *xi = xinit + (size_t)b * ext_nx(d);
-    const double *pb = params + (size_t)b * N * d.npar;
+    const double *pb_own = params + (size_t)b * N * d.npar;
+    const double *pb = params + (size_t)param_base_of(io, b) * N * d.npar;
     // slack value: pinned by x_0 = xinit and slack' = 0 (tmpc_stage.hpp).  Re-read where it is used instead of being kept
     // in registers across the whole solve.
     auto slack_of = [&]() { return d.slack ? __builtin_nontemporal_load(xi + NX) : 0.0; };
@@ -561,7 +562,7 @@ void tmpc_solve_fast_kernel(Dims d, int B, const double *__restrict__ xinit,
     double lam[C::RPL];
     for (int it = 0; it < d.n_sqp; it++) {
         pf.start();
-        linearise<true>(L, d, tid, pb, slack_of());
+        linearise<true>(L, d, tid, pb, slack_of(), pb_own);
         __syncthreads();
         pf.stop(PH_LIN);
         int iters = 0;
@@ -645,7 +646,8 @@ void tmpc_solve_compact_kernel(Dims d, int B, const double *__restrict__ xinit,
         asm volatile("" : "+v"(tid));                   // opaque per trajectory: per-lane addresses are recomputed, not kept live (and spilled) across solves
         if ((slot_flags(io, b) & ST_KEEP_ITERATE) && io.stopped[slot_of(io, b)]) continue;      // this solver's loop has ended: outputs of its last call stand
         const double *xi = xinit + (size_t)b * ext_nx(d);
-        const double *pb = params + (size_t)b * N * d.npar;
+        const double *pb_own = params + (size_t)b * N * d.npar;
+        const double *pb = params + (size_t)param_base_of(io, b) * N * d.npar;
         auto slack_of = [&]() { return d.slack ? __builtin_nontemporal_load(xi + NX) : 0.0; };
 
         for (int e = tid; e < (N + 1) * NV; e += NT) {
@@ -665,7 +667,7 @@ void tmpc_solve_compact_kernel(Dims d, int B, const double *__restrict__ xinit,
         double lam[C::RPL];
         for (int it = 0; it < d.n_sqp; it++) {
             pf.start();
-            linearise<true, true>(L, d, tid, pb, slack_of());
+            linearise<true, true>(L, d, tid, pb, slack_of(), pb_own);
             __syncthreads();
             pf.stop(PH_LIN);
             int iters = 0;
@@ -827,7 +829,8 @@ void tmpc_solve_team_kernel(Dims d, int B, const double *__restrict__ xinit,
         const bool did = exists && !((slot_flags(io, b) & ST_KEEP_ITERATE) && io.stopped[slot_of(io, b)]);
         bool run = did;
         const double *xi = xinit + (size_t)b * ext_nx(d);
-        const double *pb = params + (size_t)b * N * d.npar;
+        const double *pb_own = params + (size_t)b * N * d.npar;
+        const double *pb = params + (size_t)param_base_of(io, b) * N * d.npar;
         auto slack_of = [&]() { return d.slack ? __builtin_nontemporal_load(xi + NX) : 0.0; };
 
         for (int e = tid; e < (N + 1) * NV; e += NT) {
@@ -844,7 +847,7 @@ void tmpc_solve_team_kernel(Dims d, int B, const double *__restrict__ xinit,
         double lam[C::RPL];
         for (int it = 0; it < d.n_sqp; it++) {
             if (run) {
-                linearise<true, true>(L, d, tid, pb, slack_of());
+                linearise<true, true>(L, d, tid, pb, slack_of(), pb_own);
                 wave_sync();
             }
             int iters = 0;

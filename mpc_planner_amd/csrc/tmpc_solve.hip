@@ -57,7 +57,12 @@ struct StateIO {
     int *ticket;        // next trajectory to solve (zeroed before the launch)
     const int *slot;    // [B] state slot of every batch entry (tmpc_set_slots); nullptr: entry b uses slot b
     int *valid;         // [B_max] the slot holds state of an earlier call; the others start fresh whatever the flags say
+    const int *share;   // [B] tmpc_set_param_sharing: entry b reads every parameter but its own halfspace rows from entry share[b]; nullptr: none
 };
+// Parameter rows of batch entry b: the row block everything but the topology / scenario halfspaces is read from.  A guidance set's
+// planners carry copies of the main solver's parameters (guidance_constraints.cpp:300 `*solver = *_solver`) and differ in their own
+// halfspaces only: reading the copies from ONE of them keeps the set's parameter footprint in L2 at 1/64 (results are bitwise the same).
+__device__ __forceinline__ int param_base_of(const StateIO &io, int b) { return io.share ? io.share[b] : b; }
 // State slot of batch entry b: by default b itself; callers that keep one slot per Solver and launch a changing subset of them
 // (GuidanceConstraints with a varying number of guidance trajectories) give the map with tmpc_set_slots.
 __device__ __forceinline__ int slot_of(const StateIO &io, int b) { return io.slot ? io.slot[b] : b; }
@@ -561,7 +566,7 @@ __device__ int ipm_solve(const Lds &L, const Dims &d, int tid, int *iters_out, P
 
 // ---- stage linearisation by lane k --------------------------------------------------------------
 template <bool FAST, bool CP = false>
-__device__ __forceinline__ void linearise(const Lds &L, const Dims &d, int tid, const double *params, double slack)
+__device__ __forceinline__ void linearise(const Lds &L, const Dims &d, int tid, const double *params, double slack, const double *params_own = nullptr)
 {
     const int N = d.N;
     // Every lane runs the (register-hungry) stage evaluation with the full EXEC mask -- lanes >= N redo stage N-1 and
@@ -575,6 +580,7 @@ __device__ __forceinline__ void linearise(const Lds &L, const Dims &d, int tid, 
 #pragma unroll
         for (int i = 0; i < NV; i++) z[i] = L.z[k * NV + i];
         const double *p = params + (size_t)k * d.npar;     // Solver_acados_update_params(k, all_parameters[k*NP])
+        const long long own_delta = params_own ? (long long)(params_own - params) : 0;   // (shared rows: where the trajectory's own halfspaces are)
         double W[NV][NV], g[NV], BA[NX * NV], xn[NX];
         const int nh = L.nh;
         auto lamh = [&](int r) {                            // (lam_upper - lam_lower) of the previous QP
@@ -598,7 +604,7 @@ __device__ __forceinline__ void linearise(const Lds &L, const Dims &d, int tid, 
             }
         };
         stage_linearise(d, z, p, 1, L.pi[(k + 1) * NX + 0], L.pi[(k + 1) * NX + 1], lamh, sink, W, g, BA, xn, slack,
-                        L.W + k * NP28);                    // (generated solvers park the cost Hessian in the stage's W slot)
+                        L.W + k * NP28, own_delta);         // (generated solvers park the cost Hessian in the stage's W slot)
         // everything but W leaves the registers BEFORE the register-hungry MIRROR
         // compact layout: g, b, W live in the global workspace (same [stage][entry] layout: a lane's stores of one array share
         // one address register and differ in the immediate offset); [B A] is kept as its 8 non-constant entries only
@@ -703,7 +709,8 @@ __global__ __launch_bounds__(NT) void tmpc_solve_kernel(Dims d, int B, const dou
     const Lds L = carve(smem, d);
     const int N = d.N;
     const double *xi = xinit + (size_t)b * ext_nx(d);
-    const double *pb = params + (size_t)b * N * d.npar;
+    const double *pb_own = params + (size_t)b * N * d.npar;
+    const double *pb = params + (size_t)param_base_of(io, b) * N * d.npar;      // cost / ellipsoid / spline entries: the (possibly shared) row block
     const double slack = d.slack ? xi[NX] : 0.0;              // pinned by x_0 = xinit and slack' = 0 (tmpc_stage.hpp)
 
     // loadWarmstart (acados_solver_interface.cpp:274-284), or the iterate the handle holds; fresh or kept multipliers
@@ -729,7 +736,7 @@ __global__ __launch_bounds__(NT) void tmpc_solve_kernel(Dims d, int B, const dou
     int status = 0, qp_status = 0, sqp_iter = 0, qp_iter_total = 0;
     for (int it = 0; it < d.n_sqp; it++) {
         pf.start();
-        linearise<false>(L, d, tid, pb, slack);
+        linearise<false>(L, d, tid, pb, slack, pb_own);
         // QP primal start: dz = 0 except dx_0 = xinit - x_0; duals 0
         for (int e = tid; e < (N + 1) * NV; e += NT) L.v[e] = 0.0;
         for (int e = tid; e < (N + 1) * NX; e += NT) L.pq[e] = 0.0;
@@ -958,6 +965,8 @@ struct tmpc_handle {
     int *st_has = nullptr;           // [B_max] the slot holds state of an earlier tmpc_solve_iterations (set by the kernels' store)
     int *d_slot = nullptr;           // [B_max] state slot of every batch entry (tmpc_set_slots)
     bool slots_set = false;
+    int *d_share = nullptr;          // [B_max] tmpc_set_param_sharing
+    int share_B = 0;                 // batch size the sharing map was given for (0: none)
     bool st_valid = false;           // lane kernels (state = their workspace, per launch): it holds the result of a previous call ...
     int st_B = 0;                    // ... for slots [0, st_B)
     // SH-MPC bookkeeping: the sample behind each scenario row of the last tmpc_scenario_halfspaces (i32 [B][N][scn_rows])
@@ -1110,7 +1119,7 @@ void tmpc_destroy(tmpc_handle *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void *ptrs[] = {h->o_xinit, h->o_x0, h->o_params, h->xtraj, h->utraj, h->pobj, h->res_eq, h->d_weight,
                     h->exit_code, h->qp_status, h->sqp_iter, h->qp_iter, h->d_best, h->d_disabled,
-                    h->st_z, h->st_pi, h->st_lamh, h->st_stopped, h->st_has, h->d_slot, h->scn_sample, h->scn_discard, h->ws, h->ticket};
+                    h->st_z, h->st_pi, h->st_lamh, h->st_stopped, h->st_has, h->d_slot, h->d_share, h->scn_sample, h->scn_discard, h->ws, h->ticket};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &e : h->ev) (void)hipEventDestroy(e);
     tmpc::lanes::destroy(h->lanes);
@@ -1159,7 +1168,8 @@ static int launch_solve(tmpc_handle *h, int n_iter, int st_flags)
     } else {
         tmpc::Dims dd = h->d;
         dd.n_sqp = n_iter;
-        tmpc::StateIO io{h->st_z, h->st_pi, h->st_lamh, h->st_stopped, st_flags, h->ws, h->ticket, h->slots_set ? h->d_slot : nullptr, h->st_has};
+        tmpc::StateIO io{h->st_z, h->st_pi, h->st_lamh, h->st_stopped, st_flags, h->ws, h->ticket, h->slots_set ? h->d_slot : nullptr, h->st_has,
+                         (h->share_B == h->B) ? h->d_share : nullptr};      // (a map given for another batch size is not applied)
         const bool lat2 = h->kernel_scan && h->latency_mode == 2;
         const bool lat = !lat2 && h->kernel_lat && h->latency_mode != 0;          // (mode 2 without a scan variant falls back to the two-wave variant)
         const bool cp = h->compact && !lat && !lat2;
@@ -1277,6 +1287,21 @@ int tmpc_set_slots(tmpc_handle *h, const int32_t *slots)
     TMPC_HIP_CHECK(h, hipMemcpyAsync(h->d_slot, slots, (size_t)h->B * 4, hipMemcpyHostToDevice, h->stream));
     TMPC_HIP_CHECK(h, hipStreamSynchronize(h->stream));            // (the caller's array may go away)
     h->slots_set = true;
+    return TMPC_OK;
+}
+
+int tmpc_set_param_sharing(tmpc_handle *h, const int32_t *base_of)
+{
+    if (!h) return TMPC_ERR_INVALID;
+    if (!base_of) { h->share_B = 0; return TMPC_OK; }
+    if (h->B <= 0) { h->err = "tmpc_set_param_sharing: set the batch first (the map has one entry per batch entry)"; return TMPC_ERR_INVALID; }
+    for (int b = 0; b < h->B; b++)
+        if (base_of[b] < 0 || base_of[b] >= h->B) { h->err = "tmpc_set_param_sharing: entries must be batch indices in [0, B)"; return TMPC_ERR_INVALID; }
+    TMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    if (!h->d_share) TMPC_HIP_CHECK(h, hipMalloc(&h->d_share, (size_t)h->B_max * 4));
+    TMPC_HIP_CHECK(h, hipMemcpyAsync(h->d_share, base_of, (size_t)h->B * 4, hipMemcpyHostToDevice, h->stream));
+    TMPC_HIP_CHECK(h, hipStreamSynchronize(h->stream));            // (the caller's array may go away)
+    h->share_B = h->B;
     return TMPC_OK;
 }
 

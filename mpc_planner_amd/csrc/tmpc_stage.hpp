@@ -499,8 +499,12 @@ template <typename LamH, typename RowSink>
 TMPC_HD void stage_linearise(const Dims &d, const double *z, const double *p, int pstride,
                                                 double pix, double piy, LamH lamh, RowSink sink,
                                                 double (*W)[NV], double *g, double *BA, double *xn, double slack = 0.0,
-                                                double *stash = nullptr)
+                                                double *stash = nullptr, long long own_delta = 0)
 {
+    // own_delta (doubles, wave-uniform): distance from `p` to the trajectory's OWN parameter row when `p` is a row it shares with others
+    // (tmpc_set_param_sharing): the topology and scenario halfspaces (ip_lin / ip_slk) are read from p + own_delta, everything else
+    // from p.  A delta, not a second pointer: the second address then lives only across the halfspace loads (the linearisation is the
+    // register-hungriest phase of the compact kernels: a second per-lane pointer cost them 8 B of scratch).
 #ifdef TMPC_GENERATED_STAGE
     // The emitted cost is long straight-line code: evaluate it first and park dt * Hessian in `stash` (28 doubles of LDS, the
     // stage's own W slot), so that its temporaries are dead before the dynamics / rows / W accumulation start.
@@ -554,7 +558,7 @@ TMPC_HD void stage_linearise(const Dims &d, const double *z, const double *p, in
     cost_add_hessian(co, d.dt, W);
     RowOut ro;
     for (int j = 0; j < d.n_lin; j++) {
-        lin_row_eval(d, z, p, pstride, j, ro);
+        lin_row_eval(d, z, p + own_delta, pstride, j, ro);
         sink(j, ro);
     }
     if (d.M == 0 && d.n_slk == 0) return;
@@ -562,7 +566,7 @@ TMPC_HD void stage_linearise(const Dims &d, const double *z, const double *p, in
     double spsi, cpsi;
     sincos(z[ZPSI], &spsi, &cpsi);
     for (int j = 0; j < d.n_slk; j++) {
-        slk_row_eval(d, z, p, pstride, j, off, spsi, cpsi, slack, ro);
+        slk_row_eval(d, z, p + own_delta, pstride, j, off, spsi, cpsi, slack, ro);
         W[ZPSI][ZPSI] += lamh(d.n_lin + j) * ro.Hpp;              // the row is linear in (x, y); psi enters through the disc offset
         sink(d.n_lin + j, ro);
     }

@@ -41,7 +41,7 @@ EXPORTS = ["tmpc_default_dims", "tmpc_default_dims_ex", "tmpc_create", "tmpc_des
            "tmpc_select_best_records", "tmpc_enable_timing", "tmpc_get_timings", "tmpc_debug_profile",
            "tmpc_linearize_topology", "tmpc_scenario_halfspaces", "tmpc_scenario_support", "tmpc_warmstart", "tmpc_init_with_guidance",
            "tmpc_debug_get_x0", "tmpc_debug_get_params", "tmpc_set_throughput_mode", "tmpc_solve_iterations",
-           "tmpc_reset_multipliers", "tmpc_get_stream", "tmpc_kernel_info", "tmpc_set_slots", "tmpc_copy_state", "tmpc_scenario_empty_stages", "tmpc_sample_scenarios",
+           "tmpc_reset_multipliers", "tmpc_get_stream", "tmpc_kernel_info", "tmpc_set_slots", "tmpc_set_param_sharing", "tmpc_copy_state", "tmpc_scenario_empty_stages", "tmpc_sample_scenarios",
            "tmpc_scenario_discard", "tmpc_scenario_discarded", "tmpc_linearize_topology_ex"]
 
 class TmpcError(RuntimeError):
@@ -87,6 +87,8 @@ def load_library(path=None):
         lib.tmpc_kernel_info.argtypes = [vp, C.c_char_p, C.c_int32]
     if hasattr(lib, "tmpc_set_slots"):        # (absent from reference builds of earlier rounds used in A/B runs)
         lib.tmpc_set_slots.argtypes = [vp, vp]
+    if hasattr(lib, "tmpc_set_param_sharing"):
+        lib.tmpc_set_param_sharing.argtypes = [vp, vp]
     if hasattr(lib, "tmpc_scenario_empty_stages"):        # (absent from reference builds of earlier rounds used in A/B runs)
         lib.tmpc_scenario_empty_stages.argtypes = [vp, vp]
     if hasattr(lib, "tmpc_sample_scenarios"):        # (absent from reference builds of earlier rounds used in A/B runs)
@@ -132,6 +134,27 @@ def default_dims(N=20, S=5, n_lin=8, M=8, n_slk=0, slack=0, lib_path=None, **opt
 
 def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def own_parameter_columns(dims):
+    """Indices (within a stage's parameter row) of the entries a planner of a guidance / scenario set sets for itself: the topology
+    halfspaces (LinearizedConstraints::setParameters) and the scenario / decomp halfspaces (csrc/tmpc_stage.hpp ip_lin, ip_slk)."""
+    base = 8 + dims.slack + 9 * dims.S
+    lin = np.arange(base, base + 3 * dims.n_lin)
+    disc = base + 3 * dims.n_lin
+    slk0 = (disc + 2 + 7 * dims.M) if dims.M > 0 else disc + 1
+    return np.concatenate([lin, np.arange(slk0, slk0 + 3 * dims.n_slk)]).astype(int)
+
+
+def param_sharing_map(params, dims, set_size):
+    """base_of for tmpc_set_param_sharing: consecutive groups of `set_size` batch entries (one guidance set each) share the rows of
+    their first entry -- CHECKED here: an entry whose shared columns differ from its set's first entry keeps its own rows."""
+    B = params.shape[0]
+    p = params.reshape(B, dims.N, -1)
+    shared = np.setdiff1d(np.arange(p.shape[2]), own_parameter_columns(dims))
+    base = (np.arange(B) // set_size) * set_size
+    same = (p[:, :, shared] == p[base][:, :, shared]).all(axis=(1, 2))
+    return np.where(same, base, np.arange(B)).astype(np.int32)
 
 
 class BatchedSolver:
@@ -218,6 +241,16 @@ class BatchedSolver:
         a = np.ascontiguousarray(slots, np.int32)
         assert a.size == self.B
         self._check(self.lib.tmpc_set_slots(self._h, a.ctypes.data_as(C.c_void_p)), "tmpc_set_slots")
+
+    def set_param_sharing(self, base_of):
+        """Hint (tmpc_set_param_sharing): entry b's parameter rows equal entry base_of[b]'s except for its own topology / scenario
+        halfspace rows; the kernels read the rest from base_of[b] (same results, 1/64 of a guidance set's parameter traffic).  None clears."""
+        if base_of is None:
+            self._check(self.lib.tmpc_set_param_sharing(self._h, None), "tmpc_set_param_sharing")
+            return
+        a = np.ascontiguousarray(base_of, np.int32)
+        assert a.size == self.B
+        self._check(self.lib.tmpc_set_param_sharing(self._h, a.ctypes.data_as(C.c_void_p)), "tmpc_set_param_sharing")
 
     def copy_state_from(self, other):
         self._check(self.lib.tmpc_copy_state(self._h, other._h), "tmpc_copy_state")

@@ -60,3 +60,23 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "oracle_lib" not in txt and "liboracle" not in txt and "tmpc_oracle" not in txt, f
+
+
+def test_param_sharing_map_checks_equality():
+    """solver.param_sharing_map (the host side of tmpc_set_param_sharing): sets of consecutive entries share their first entry's rows;
+    the planners' own columns (topology / scenario halfspaces) may differ, anything else makes an entry keep its own rows."""
+    import numpy as np
+    from mpc_planner_amd import solver, scenes
+    dims = solver.default_dims(N=20, S=5, n_lin=8, M=8)
+    own = solver.own_parameter_columns(dims)
+    assert own.tolist() == list(range(8 + 45, 8 + 45 + 24))                   # 8 weights, 9 x 5 spline entries, then 8 x (a1, a2, b)
+    b = scenes.make_batch(range(3, 5), N=20, M=8, B=64)
+    base = solver.param_sharing_map(b["params"], dims, 64)
+    assert base[:64].tolist() == [0] * 64 and base[64:].tolist() == [64] * 64
+    p = b["params"].copy().reshape(128, 20, -1)
+    p[5, 2, own[3]] += 1.0                                                     # own column: still shared
+    p[9, 7, 0] += 1e-9                                                         # a weight: not shared
+    base = solver.param_sharing_map(p, dims, 64)
+    assert base[5] == 0 and base[9] == 9 and base[10] == 0
+    d5 = solver.default_dims(N=20, S=5, n_lin=0, M=0, n_slk=24, slack=1)       # scenario rows after the disc offset
+    assert solver.own_parameter_columns(d5).tolist() == list(range(8 + 1 + 45 + 1, 8 + 1 + 45 + 1 + 72))

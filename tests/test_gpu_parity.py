@@ -745,6 +745,39 @@ def test_latency_variant_matches_oracle_and_default_kernel():
     s5.close()
 
 
+@pytest.mark.parametrize("cfg", ["cfg2", "cfg5"])
+def test_param_sharing_hint_is_bitwise_neutral(cfg):
+    """tmpc_set_param_sharing: a guidance / scenario set's entries read everything but their own halfspace rows from the set's first
+    entry.  Bitwise the same results as without the hint (default, latency and parallel-in-time kernels); an entry whose shared columns
+    differ keeps its own rows (the host-side map builder checks), and the map is dropped when the batch size changes."""
+    from mpc_planner_amd import scenes, solver as S
+    mk, pkw = BASELINE_CASES[cfg]
+    sc = mk(scenes)
+    B = sc["xinit"].shape[0]
+    set_size = 64 if cfg == "cfg2" else B
+    s = _solver(B_max=B, **pkw)
+    params = sc["params"].copy()
+    if cfg == "cfg2":
+        params[70, 3, 0] *= 1.5                                            # one planner with its own weight: must not share
+    base = S.param_sharing_map(params, s.dims, set_size)
+    assert (base != np.arange(B)).sum() == B - B // set_size - (1 if cfg == "cfg2" else 0)
+    if cfg == "cfg2":
+        assert base[70] == 70 and base[71] == 64
+    for mode in (0, 1, 2):
+        s.set_latency_mode(mode)
+        s.set_batch(sc["xinit"], sc["x0"], params); s.set_param_sharing(None); s.solve(); ref = s.get()
+        s.set_param_sharing(base); s.solve(); got = s.get()
+        for key in ("xtraj", "utraj", "pobj", "exit_code", "qp_iter_total", "sqp_iter", "res_eq"):
+            assert np.array_equal(ref[key], got[key]), (mode, key)
+    assert (ref["exit_code"] == 1).mean() > 0.9
+    # a smaller batch: the old map does not apply (entries would point outside the batch's meaning)
+    s.set_batch(sc["xinit"][:5], sc["x0"][:5], params[:5]); s.solve(); small = s.get()
+    assert np.array_equal(small["xtraj"], ref["xtraj"][:5])
+    with pytest.raises(Exception):
+        s.set_param_sharing(np.array([0, 1, 2, 3, 9], np.int32))          # outside [0, B)
+    s.close()
+
+
 def _compare_relaxed_iterations(got, xt, ut, info, tol=1e-4):
     """Another factorisation of the same Newton systems: everything as in _compare, except that the interior-point iteration count of a
     solve may differ by a step where a residual sits at the tolerance (at most 2 iterations on at most 10 % of the trajectories)."""

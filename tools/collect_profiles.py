@@ -2,7 +2,7 @@
   pass 1  rocprofv3 --kernel-trace --stats         (per-kernel durations of the bench command)
   pass 2+ rocprofv3 --pmc <set>                    (one counter set per pass; never combined with tracing)
   calib   tools/pmc_calibrate.hip under --pmc FETCH_SIZE / WRITE_SIZE (known 1 GiB streams, 8 B per lane)
-Usage: python tools/collect_profiles.py <tag>      -> gpurun_out/<tag>_rocprof_summary.json, <tag>_kernel_stats.csv"""
+Usage: python tools/collect_profiles.py <tag> [extra bench.py arguments]      -> gpurun_out/<tag>_rocprof_summary.json, <tag>_kernel_stats.csv"""
 import csv
 import glob
 import json
@@ -14,7 +14,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out")
 tag = sys.argv[1] if len(sys.argv) > 1 else "profile"
-BENCH = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "1", "--no-cpu-baseline", "--latency-reps", "0", "--no-lanes", "--no-tight", "--parity-check", "0", "--gen-workers", "1", "--scene-cache", "/tmp/tmpc_bench_scenes"]
+BENCH = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "1", "--no-cpu-baseline", "--latency-reps", "0", "--no-lanes", "--no-tight", "--parity-check", "0", "--gen-workers", "1", "--scene-cache", "/tmp/tmpc_bench_scenes"] + sys.argv[2:]
 env = dict(os.environ, TMPDIR="/tmp")
 
 
@@ -98,6 +98,7 @@ if "hbm_bytes_per_launch" in summary:                        # what bench.py's r
     with open(os.path.join(OUT, f"{tag}_pmc.json"), "w") as fh:
         json.dump({"library_sha256": LIB_HASH, "trajectories_per_launch": 512 * 64, "hbm_bytes_per_launch": summary["hbm_bytes_per_launch"]["total"],
                    "fetch": summary["hbm_bytes_per_launch"]["fetch"], "write": summary["hbm_bytes_per_launch"]["write"],
+                   "extra_bench_args": sys.argv[2:],                        # e.g. ["--no-param-sharing"]: bench.py matches the configuration too
                    "source": f"tools/collect_profiles.py {tag}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on the solve kernel, calibrated bytes per count"}, fh, indent=1)
 print(json.dumps({k: summary[k] for k in ("calibration", "pmc_mean_per_launch") if k in summary}, indent=1))
 for r in ks[:4]:
