@@ -151,10 +151,13 @@ def param_sharing_map(params, dims, set_size):
     their first entry -- CHECKED here: an entry whose shared columns differ from its set's first entry keeps its own rows."""
     B = params.shape[0]
     p = params.reshape(B, dims.N, -1)
-    shared = np.setdiff1d(np.arange(p.shape[2]), own_parameter_columns(dims))
-    base = (np.arange(B) // set_size) * set_size
-    same = (p[:, :, shared] == p[base][:, :, shared]).all(axis=(1, 2))
-    return np.where(same, base, np.arange(B)).astype(np.int32)
+    mask = np.ones(p.shape[2], bool); mask[own_parameter_columns(dims)] = False
+    out = np.arange(B, dtype=np.int32)
+    for s0 in range(0, B, set_size):                                          # set by set: no batch-sized temporaries
+        blk = p[s0:s0 + set_size]
+        same = (blk[:, :, mask] == blk[0][None, :, mask]).all(axis=(1, 2))
+        out[s0:s0 + set_size][same] = s0
+    return out
 
 
 class BatchedSolver:
