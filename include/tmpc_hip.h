@@ -145,7 +145,8 @@ int tmpc_reset_multipliers(tmpc_handle *h);
  * trajectory; for control ticks of a few planners, like the 8 OpenMP threads of guidance_constraints.cpp:279), 2 = latency
  * variant with the interior-point Newton systems solved parallel in time (multiplier Schur complement + block cyclic reduction
  * over the stages, csrc/tmpc_scan.hpp) instead of by the stage-by-stage Riccati recursion that acados / HPIPM -- and modes 0, 1 --
- * use: about half the kernel time of a tick.  Returns 0, or 1 if the handle's shape has no such variant (mode 2 then runs as mode 1,
+ * use: 30-40 % less kernel time per tick; available for horizons N <= 31 of the hand-written model, at one workgroup per CU (a launch of
+ * more than 256 trajectories per GPU takes several rounds: the default kernels are the better choice there).  Returns 0, or 1 if the handle's shape has no such variant (mode 2 then runs as mode 1,
  * mode 1 as the default kernel).  A trajectory's result is bitwise independent of the batch it is solved in.  Modes 0 and 1 agree
  * to rounding (1e-11), not bitwise.  Mode 2 is another factorisation of the same systems: its steps agree with the recursion's to
  * ~1e-6 on ill-conditioned late iterations (each is that far from an exact solve), trajectories agree within the 1e-4 parity

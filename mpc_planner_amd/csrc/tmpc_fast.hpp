@@ -119,7 +119,8 @@ struct Solo {
 
 // Latency mode 2: the Newton systems go through the parallel-in-time solve (tmpc_scan.hpp) instead of the Riccati recursion.  Same
 // operands in LDS (Hh, [B A], gh, rb), same results (dv, dpi); Hh is left as it is (ipm_fast rebuilds it every iteration anyway).
-struct ScanSolo {
+template <int SL>                                    // lanes per stage of the Newton solve's stage phases: 3 (N <= 20) or 2 (N <= 31)
+struct ScanSoloT {
     static constexpr int NQ = 1;
     __device__ __forceinline__ bool alive() const { return true; }
     __device__ __forceinline__ void sync() const { __syncthreads(); }
@@ -132,7 +133,7 @@ struct ScanSolo {
         asm volatile("" : "+v"(tl));                 // opaque per call (see riccati_factor)
         bool bad = false;
         if (NTH == 64 || (tl >> 6) == sw) {
-            const scan::View V{L.Hh, L.BA, L.gh, L.rb, L.dv, L.dpi, L.scan, d.N};
+            const scan::ViewT<SL> V{L.Hh, L.BA, L.gh, L.rb, L.dv, L.dpi, L.scan, d.N};
             bad = scan::factor(V, tl & 63);
             if (NTH > 64 && (tl & 63) == 0) L.scr[63] = bad ? 1.0 : 0.0;
         }
@@ -145,12 +146,13 @@ struct ScanSolo {
     {
         asm volatile("" : "+v"(tl));
         if (NTH == 64 || (tl >> 6) == sw) {
-            const scan::View V{L.Hh, L.BA, L.gh, L.rb, L.dv, L.dpi, L.scan, d.N};
+            const scan::ViewT<SL> V{L.Hh, L.BA, L.gh, L.rb, L.dv, L.dpi, L.scan, d.N};
             scan::solve(V, tl & 63, phase == 1);     // the predictor's right-hand side went through the factorisation
         }
         __syncthreads();
     }
 };
+using ScanSolo = ScanSoloT<3>;
 
 template <int NLIN, int MM, int LPS, int NTH, bool CP, typename PF, typename TEAM = Solo>
 __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, int *iters_out, PF &pf,

@@ -45,18 +45,27 @@ constexpr int SNU = 2, SNX = 5, SNV = 7;
 // banks (64-bit accesses; an even stride of 28 doubles put 64 lanes on 8 banks -- measured 2-3x on the phases that stream such arrays).
 constexpr int BS = 95, OD = 0, OL = 25, ORR = 50, OB = 75, OLD = 80;
 constexpr int LS = 29;                                                      // chol(H_k), packed lower (28, inverse diagonal), per stage
-constexpr int ZL = 29;                                                      // per LANE of the stage phase: its four columns of P_k [F_k^T E^T g_k]
-__host__ __device__ constexpr int lds_doubles(int N) { return N * BS + (N + 1) * LS + 3 * (N + 1) * ZL + (N + 1) * SNV + 25; }     // (+ 25 zeros: the coupling of a block without right neighbour)
+// SL = lanes per stage in the stage phases: 3 (N <= 20: 63 lanes) or 2 (N <= 31: 64 lanes); each lane carries CL of the 11 columns
+template <int SL> struct Cfg {
+    static_assert(SL == 2 || SL == 3, "lanes per stage");
+    static constexpr int CL = (11 + SL - 1) / SL;                           // 4 / 6
+    static constexpr int ZL = CL * 7 + ((CL * 7) % 2 == 0 ? 1 : 0);         // per LANE: its columns of P_k [F_k^T E^T g_k] (odd stride)
+    static constexpr int NMAX = 64 / SL - 1;                                // 20 / 31
+};
+template <int SL>
+__host__ __device__ constexpr int lds_doubles(int N) { return N * BS + (N + 1) * LS + SL * (N + 1) * Cfg<SL>::ZL + (N + 1) * SNV + 25; }     // (+ 25 zeros: the coupling of a block without right neighbour)
 
 // operands in LDS: Hh packed lower (28 per stage, row-major), BA dense (5 x 7 per stage), gh (7 per stage), rb (5 per stage);
-// results dv (7 per stage), dpi (5 per stage, dpi_{j+1} = pi_j); scratch of lds_doubles(N) at `blk`
-struct View {
+// results dv (7 per stage), dpi (5 per stage, dpi_{j+1} = pi_j); scratch of lds_doubles<SL>(N) at `blk`
+template <int SL>
+struct ViewT {
     const double *Hh, *BA, *gh, *rb; double *dv, *dpi, *blk; int N;
     __device__ __forceinline__ double *Ls() const { return blk + N * BS; }
     __device__ __forceinline__ double *Zs() const { return blk + N * BS + (N + 1) * LS; }
-    __device__ __forceinline__ double *zg() const { return blk + N * BS + (N + 1) * LS + 3 * (N + 1) * ZL; }
+    __device__ __forceinline__ double *zg() const { return blk + N * BS + (N + 1) * LS + SL * (N + 1) * Cfg<SL>::ZL; }
     __device__ __forceinline__ double *zeros() const { return zg() + (N + 1) * SNV; }
 };
+using View = ViewT<3>;
 
 __device__ __forceinline__ constexpr int tri(int i, int j) { return i * (i + 1) / 2 + j; }
 
@@ -163,15 +172,17 @@ __device__ __forceinline__ bool g_live(int k, int N, int i) { return !((k == 0 &
 
 // ---- factor: stage phase ----
 // The right-hand side V.gh of the call (the predictor's: complete before the factorisation) rides along as an eleventh column.
-__device__ __forceinline__ bool stage_phase(const View &V, int lane)
+template <int SL>
+__device__ __forceinline__ bool stage_phase(const ViewT<SL> &V, int lane)
 {
+    constexpr int CL = Cfg<SL>::CL, ZL = Cfg<SL>::ZL;
     const int N = V.N;
     double *blk = V.blk;
     SCAN_T0();
     if (lane < 25) V.zeros()[lane] = 0.0;
-    const int k = lane / 3, s = lane - 3 * k;
+    const int k = lane / SL, s = lane - SL * k;
     bool bad = false;
-    if (lane < 3 * (N + 1)) {
+    if (lane < SL * (N + 1)) {
         double L[28];
         const double *Hk = V.Hh + k * 28;
 #pragma unroll
@@ -190,36 +201,36 @@ __device__ __forceinline__ bool stage_phase(const View &V, int lane)
 #pragma unroll
             for (int e = 0; e < 28; e++) V.Ls()[k * LS + e] = L[e];
         }
-        // the lane's four columns cid = 4 s + t of [F^T E^T g] (0..4: F^T, 5..9: E^T, 10: g, 11: none), solved together
-        double z[4][SNV], o[4][SNX];
+        // the lane's CL columns cid = CL s + t of [F^T E^T g] (0..4: F^T, 5..9: E^T, 10: g, 11: none), solved together
+        double z[CL][SNV], o[CL][SNX];
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
-            const int cid = 4 * s + t;
+        for (int t = 0; t < CL; t++) {
+            const int cid = CL * s + t;
             double fc[SNV];
             ba_column(F, cid < 5 ? cid : 0, fc);
 #pragma unroll
             for (int i = 0; i < SNV; i++) {
                 z[t][i] = cid < 5 ? fc[i] : ((i == cid - 5 + SNU) ? 1.0 : 0.0);
-                if (t == 2) { const double gi = gk[i]; z[t][i] = cid == 10 ? (g_live(k, N, i) ? gi : 0.0) : z[t][i]; }
+                if (t == 10 % CL) z[t][i] = cid == 10 ? (g_live(k, N, i) ? gk[i] : 0.0) : z[t][i];      // (the only slot that can be column 10)
             }
         }
-        chol_solve<SNV, 4>(L, z);
+        chol_solve<SNV, CL>(L, z);
 #pragma unroll
-        for (int t = 0; t < 4; t++) ba_apply(F, z[t], o[t]);
+        for (int t = 0; t < CL; t++) ba_apply(F, z[t], o[t]);
         SCAN_T(2);
         double *Zl = V.Zs() + lane * ZL;
 #pragma unroll
-        for (int t = 0; t < 4; t++)
+        for (int t = 0; t < CL; t++)
 #pragma unroll
             for (int i = 0; i < SNV; i++) Zl[t * SNV + i] = z[t][i];
-        if (s == 2) {
+        if (s == 10 / CL) {
 #pragma unroll
-            for (int i = 0; i < SNV; i++) V.zg()[k * SNV + i] = z[2][i];
+            for (int i = 0; i < SNV; i++) V.zg()[k * SNV + i] = z[10 % CL][i];
         }
         // D_k = F P F^T (stored: every column of every block exactly once) ...
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
-            const int cid = 4 * s + t;
+        for (int t = 0; t < CL; t++) {
+            const int cid = CL * s + t;
             if (cid < 5 && k < N) {
 #pragma unroll
                 for (int i = 0; i < SNX; i++) blk[k * BS + OD + cid * 5 + i] = o[t][i];
@@ -227,8 +238,8 @@ __device__ __forceinline__ bool stage_phase(const View &V, int lane)
         }
         // ... + E P_{k+1} E^T (added: LDS operations of a wave execute in order), and the couplings Y_{k,k-1} = -F_k P_k E^T
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
-            const int cid = 4 * s + t, c = cid - 5;
+        for (int t = 0; t < CL; t++) {
+            const int cid = CL * s + t, c = cid - 5;
             if (cid >= 5 && cid < 10 && k >= 1) {
 #pragma unroll
                 for (int i = 0; i < SNX; i++) add_lds(&blk[(k - 1) * BS + OD + c * 5 + i], z[t][SNU + i]);
@@ -245,10 +256,10 @@ __device__ __forceinline__ bool stage_phase(const View &V, int lane)
 }
 
 // ---- factor: one level of cyclic reduction (stride s); CPL columns of [Lc Rc] per lane ----
-template <int CPL>
-__device__ __forceinline__ bool cr_level(const View &V, int lane, int s)
+template <int CPL, int SL>
+__device__ __forceinline__ bool cr_level(const ViewT<SL> &V, int lane, int s)
 {
-    constexpr int LPB = 10 / CPL;                            // lanes per eliminated block
+    constexpr int LPB = (10 + CPL - 1) / CPL;                // lanes per eliminated block (CPL = 3: 4 lanes, column slots 10 and 11 idle)
     const int N = V.N;
     double *blk = V.blk;
     const int m = lane / LPB, q = lane - m * LPB;
@@ -271,8 +282,8 @@ __device__ __forceinline__ bool cr_level(const View &V, int lane, int s)
             for (int r = 0; r < SNX; r++) { lc[i][r] = bo[OL + i * 5 + r]; rc[i][r] = br[r * 5 + i]; }
 #pragma unroll
         for (int t = 0; t < CPL; t++) {
-            const int cid = q * CPL + t, c = cid < 5 ? cid : cid - 5;
-            const double *wp = cid < 5 ? bo + OL + c * 5 : br + c;       // column c of Lc (contiguous) or of Rc = row c of Lc_er (stride 5)
+            const int cid = q * CPL + t, c = cid < 5 ? cid : (cid < 10 ? cid - 5 : 0);
+            const double *wp = cid < 5 ? bo + OL + c * 5 : (cid < 10 ? br + c : V.zeros());       // column c of Lc (contiguous) or of Rc = row c of Lc_er (stride 5)
             const int ws = cid < 5 ? 1 : 5;
 #pragma unroll
             for (int i = 0; i < SNX; i++) w[t][i] = wp[i * ws];
@@ -300,6 +311,7 @@ __device__ __forceinline__ bool cr_level(const View &V, int lane, int s)
 #pragma unroll
         for (int t = 0; t < CPL; t++) {
             const int cid = q * CPL + t, c = cid < 5 ? cid : cid - 5;
+            if (CPL == 3 && cid >= 10) continue;                                               // (idle column slot)
 #pragma unroll
             for (int i = 0; i < SNX; i++) bo[(cid < 5 ? OL : ORR) + c * 5 + i] = w[t][i];            // W = D^-1 [Lc Rc]
             if (cid < 5) {
@@ -318,12 +330,30 @@ __device__ __forceinline__ bool cr_level(const View &V, int lane, int s)
     return bad;
 }
 
-// cyclic reduction of the blocks the stage phase left in V.blk (per-lane flag: non-positive pivot)
-__device__ __forceinline__ bool reduce(const View &V, int lane)
+// cyclic reduction of the blocks the stage phase left in V.blk (per-lane flag: non-positive pivot).  Columns per lane by the number
+// of blocks a level eliminates: one where ten lanes per block fit the wave, else two, else three.
+template <int SL>
+__device__ __forceinline__ bool reduce(const ViewT<SL> &V, int lane)
 {
-    bool bad = cr_level<2>(V, lane, 1);
+    const int N = V.N;
+    bool bad = false;
+#ifndef TMPC_SCAN_FORCE_CPL3
+    if constexpr (SL == 3) {                                 // N <= 20: ten blocks at level 0 (two columns per lane), at most five afterwards
+        bad = cr_level<2>(V, lane, 1);
 #pragma unroll 1
-    for (int s = 2; s < V.N; s *= 2) bad |= cr_level<1>(V, lane, s);
+        for (int s = 2; s < N; s *= 2) bad |= cr_level<1>(V, lane, s);
+    } else
+#endif
+#pragma unroll 1
+    for (int s = 1; s < N; s *= 2) {
+        const int ne = (N - s + 2 * s - 1) / (2 * s);        // blocks o = s (2 m + 1) < N
+#ifdef TMPC_SCAN_FORCE_CPL3                                  // (tools/scan_vs_riccati_bench.hip: the three-column path on N = 20 systems)
+        if (ne * 4 <= 64 && s == 1) { bad |= cr_level<3>(V, lane, s); continue; }
+#endif
+        if (ne * 10 <= 64) bad |= cr_level<1>(V, lane, s);
+        else if (ne * 5 <= 64) bad |= cr_level<2>(V, lane, s);
+        else bad |= cr_level<3>(V, lane, s);
+    }
     if (lane == 0) {                                         // what is left: block 0
         double L[15];
 #pragma unroll
@@ -338,7 +368,8 @@ __device__ __forceinline__ bool reduce(const View &V, int lane)
     return bad;
 }
 // Factorisation: chol(H_k) -> V.Ls, the reduced blocks -> V.blk.  Returns true (wave-uniform) on a non-positive pivot anywhere.
-__device__ __forceinline__ bool factor(const View &V, int lane)
+template <int SL>
+__device__ __forceinline__ bool factor(const ViewT<SL> &V, int lane)
 {
     bool bad = stage_phase(V, lane);
     bad |= reduce(V, lane);
@@ -347,14 +378,16 @@ __device__ __forceinline__ bool factor(const View &V, int lane)
 
 // Solve with the factor of the last factor(): V.dv, V.dpi.  pred: the right-hand side is the one factor() saw (its P_k g_k is in
 // LDS already); otherwise (V.gh changed since: the corrector) P_k g_k is recomputed, one lane per stage.  V.rb as at factor().
-__device__ __forceinline__ void solve(const View &V, int lane, bool pred)
+template <int SL>
+__device__ __forceinline__ void solve(const ViewT<SL> &V, int lane, bool pred)
 {
+    constexpr int CL = Cfg<SL>::CL, ZL = Cfg<SL>::ZL;
     const int N = V.N;
     double *blk = V.blk;
-    const int k = lane / 3, s3 = lane - 3 * k;
+    const int k = lane / SL, s3 = lane - SL * k;
     SCAN_T0();
     for (int e = lane; e < N * SNX; e += 64) blk[(e / SNX) * BS + OB + e % SNX] = V.rb[e];
-    const bool stage_lane = lane < 3 * (N + 1) && s3 == 0;
+    const bool stage_lane = lane < SL * (N + 1) && s3 == 0;
     if (!pred) {
         if (stage_lane) {
             double L[28], z[1][SNV];
@@ -390,20 +423,24 @@ __device__ __forceinline__ void solve(const View &V, int lane, bool pred)
     }
     fence();
     SCAN_T(5);
-    const int m = lane / 5, i5 = lane - 5 * m;
+    const int m = lane / 5, i5 = lane - 5 * m;              // one lane per row of a block: 12 blocks per pass
 #pragma unroll 1
     for (int s = 1; s < N; s *= 2) {                         // forward elimination: beta_{o -+ s} -= W^T beta_o
-        const int o = s * (2 * m + 1), el = o - s, er = o + s;
-        const double *bo = blk + (o < N ? o : 0) * BS;       // (clamped: loads are unconditional, only the updates are masked)
-        double sa = 0.0, sb = 0.0, be[SNX], wl[SNX], wr[SNX];
+#pragma unroll 1
+        for (int m0 = 0; s * (2 * m0 + 1) < N && (SL == 2 || m0 == 0); m0 += 12) {      // (N <= 20: at most ten blocks per level, one pass)
+            const int o = s * (2 * (m0 + m) + 1), el = o - s, er = o + s;
+            const bool act = o < N && m < 12;
+            const double *bo = blk + (act ? o : 0) * BS;     // (clamped: loads are unconditional, only the updates are masked)
+            double sa = 0.0, sb = 0.0, be[SNX], wl[SNX], wr[SNX];
 #pragma unroll
-        for (int r = 0; r < SNX; r++) { be[r] = bo[OB + r]; wl[r] = bo[OL + i5 * 5 + r]; wr[r] = bo[ORR + i5 * 5 + r]; }
-        loads_done();
+            for (int r = 0; r < SNX; r++) { be[r] = bo[OB + r]; wl[r] = bo[OL + i5 * 5 + r]; wr[r] = bo[ORR + i5 * 5 + r]; }
+            loads_done();
 #pragma unroll
-        for (int r = 0; r < SNX; r++) { sa = fma(wl[r], be[r], sa); sb = fma(wr[r], be[r], sb); }
-        if (o < N) {
-            add_lds(&blk[el * BS + OB + i5], -sa);
-            if (er < N) add_lds(&blk[er * BS + OB + i5], -sb);
+            for (int r = 0; r < SNX; r++) { sa = fma(wl[r], be[r], sa); sb = fma(wr[r], be[r], sb); }
+            if (act) {
+                add_lds(&blk[el * BS + OB + i5], -sa);
+                if (er < N) add_lds(&blk[er * BS + OB + i5], -sb);
+            }
         }
         fence();
     }
@@ -426,39 +463,42 @@ __device__ __forceinline__ void solve(const View &V, int lane, bool pred)
     while (2 * s_top < N) s_top *= 2;
 #pragma unroll 1
     for (int s = s_top; s >= 1; s >>= 1) {                   // back substitution: pi_o = D^-1 beta_o - W_L pi_el - W_R pi_er
-        const int o = s * (2 * m + 1), el = o - s, er = o + s;
-        const bool act = o < N, has_r = er < N;
-        const double *bo = blk + (act ? o : 0) * BS, *pl = blk + (act ? el : 0) * BS + OB, *pr = blk + (has_r ? er : 0) * BS + OB;
-        double x = bo[OB + i5], y = 0.0, wl[SNX], wr[SNX], xl[SNX], xr[SNX];
+#pragma unroll 1
+        for (int m0 = 0; s * (2 * m0 + 1) < N && (SL == 2 || m0 == 0); m0 += 12) {
+            const int o = s * (2 * (m0 + m) + 1), el = o - s, er = o + s;
+            const bool act = o < N && m < 12, has_r = act && er < N;
+            const double *bo = blk + (act ? o : 0) * BS, *pl = blk + (act ? el : 0) * BS + OB, *pr = blk + (has_r ? er : 0) * BS + OB;
+            double x = bo[OB + i5], y = 0.0, wl[SNX], wr[SNX], xl[SNX], xr[SNX];
 #pragma unroll
-        for (int r = 0; r < SNX; r++) { wl[r] = bo[OL + r * 5 + i5]; wr[r] = bo[ORR + r * 5 + i5]; xl[r] = pl[r]; xr[r] = pr[r]; }
-        loads_done();
+            for (int r = 0; r < SNX; r++) { wl[r] = bo[OL + r * 5 + i5]; wr[r] = bo[ORR + r * 5 + i5]; xl[r] = pl[r]; xr[r] = pr[r]; }
+            loads_done();
 #pragma unroll
-        for (int r = 0; r < SNX; r++) { x = fma(-wl[r], xl[r], x); y = fma(-wr[r], xr[r], y); }
-        if (act) blk[o * BS + OB + i5] = has_r ? x + y : x;  // (a lane reads and replaces its own entry of beta_o only)
+            for (int r = 0; r < SNX; r++) { x = fma(-wl[r], xl[r], x); y = fma(-wr[r], xr[r], y); }
+            if (act) blk[o * BS + OB + i5] = has_r ? x + y : x;  // (a lane reads and replaces its own entry of beta_o only)
+        }
         fence();
     }
     SCAN_T(8);
-    // dv_k = -P_k g_k - (P_k F_k^T) pi_k + (P_k E^T) pi_{k-1} from the columns the stage phase left in LDS: every lane of a stage sums its four
+    // dv_k = -P_k g_k - (P_k F_k^T) pi_k + (P_k E^T) pi_{k-1} from the columns the stage phase left in LDS: every lane of a stage sums its own
     {
-        const bool lv = lane < 3 * (N + 1);
+        const bool lv = lane < SL * (N + 1);
         const int kc = lv ? k : 0;
         const double *Zl = V.Zs() + (lv ? lane : 0) * ZL;
         const double *pk = blk + (kc < N ? kc : 0) * BS + OB, *pm = blk + (kc >= 1 ? kc - 1 : 0) * BS + OB;
         double acc[SNV], pik[SNX], pim[SNX];
 #pragma unroll
         for (int i = 0; i < SNX; i++) { pik[i] = pk[i]; pim[i] = pm[i]; }
-        double zz[4 * SNV], zgk[SNV];
+        double zz[CL * SNV], zgk[SNV];
 #pragma unroll
-        for (int e = 0; e < 4 * SNV; e++) zz[e] = Zl[e];
+        for (int e = 0; e < CL * SNV; e++) zz[e] = Zl[e];
 #pragma unroll
         for (int i = 0; i < SNV; i++) zgk[i] = V.zg()[kc * SNV + i];
         loads_done();
 #pragma unroll
         for (int i = 0; i < SNV; i++) acc[i] = s3 == 0 ? -zgk[i] : 0.0;
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
-            const int cid = 4 * s3 + t, c = cid < 5 ? cid : cid - 5;
+        for (int t = 0; t < CL; t++) {
+            const int cid = CL * s3 + t, c = cid < 5 ? cid : cid - 5;
             double a = pik[0], b = pim[0];
 #pragma unroll
             for (int cc = 1; cc < SNX; cc++) { a = c == cc ? pik[cc] : a; b = c == cc ? pim[cc] : b; }

@@ -915,10 +915,16 @@ static SolveKernel pick_latency_kernel(const Dims &d, bool prof)
 // tick gives it anyway: built for one wave per SIMD (all 512 registers, 73 KB of LDS).  Another factorisation of the same systems:
 // steps agree with the recursion's to rounding (~1e-6 of a step on ill-conditioned late iterations, like the recursion itself
 // against an exact solve), so iteration counts can differ by one where a residual sits at the tolerance -- the caller opts in.
-static SolveKernel pick_scan_kernel(const Dims &d, int *threads)
+static SolveKernel pick_scan_kernel(const Dims &d, int *threads, int *sl)
 {
+    *sl = 3;
 #ifndef TMPC_GENERATED_STAGE
-    if (getenv("TMPC_FORCE_GENERIC") || d.N > 20 || d.N < 2) return nullptr;
+    if (getenv("TMPC_FORCE_GENERIC") || d.N > 31 || d.N < 2) return nullptr;
+    if (d.N > 20) {                                              // 21 <= N <= 31 (cfg 3, the reference's N = 30 defaults): two lanes per stage in the
+        if (d.n_up + d.M + 14 > 4 * 12) return nullptr;          // Newton solve, the runtime-shape two-wave kernel (4 lanes per stage, up to 34 rows) around it
+        *threads = 128; *sl = 2;
+        return (SolveKernel)tmpc_solve_fast_kernel<-1, 12, 4, 128, false, ScanSoloT<2>>;
+    }
     const char *w = getenv("TMPC_SCAN_WAVES");               // A/B: "1" = one wave per trajectory
     if (d.n_up == 8 && d.M == 8 && d.N <= 2 * (64 / 6) && !(w && atoi(w) == 1)) { *threads = 128; return (SolveKernel)tmpc_solve_fast_kernel<8, 8, 6, 128, false, ScanSolo>; }
     if (d.n_up == 8 && d.M == 8) { *threads = 64; return (SolveKernel)tmpc_solve_fast_kernel<8, 8, 3, 64, false, ScanSolo>; }
@@ -948,7 +954,7 @@ struct tmpc_handle {
     tmpc::SolveKernel kernel_lat = nullptr;   // optional latency variant (128 threads), used when latency_mode is 1
     tmpc::SolveKernel kernel_scan = nullptr;  // optional latency variant 2 (parallel-in-time Newton solve, 64 threads)
     size_t lds_bytes_scan = 0;
-    int scan_threads = 64;
+    int scan_threads = 64, scan_sl = 3;
     size_t lds_bytes_fast = 0;                // LDS of the fast-layout kernels (kernel_lat, the profiled twin) when `kernel` is compact
     bool compact = false;                     // `kernel` is a compact persistent kernel: grid = resident workgroups, needs ws + ticket
     int team = 1;                             // trajectories per workgroup of the compact / team kernel (1, 2 or 4 waves)
@@ -1065,8 +1071,11 @@ int tmpc_create(tmpc_handle **out, const tmpc_dims *dims, int32_t B_max, int32_t
         if (hipFuncSetAttribute((const void *)h->kernel_lat, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes_fast) != hipSuccess)
             h->kernel_lat = nullptr;
     }
-    if (h->fast && h->threads == tmpc::NT && (h->kernel_scan = tmpc::pick_scan_kernel(d, &h->scan_threads)) != nullptr) {
-        h->lds_bytes_scan = h->lds_bytes_fast + sizeof(double) * (size_t)tmpc::scan::lds_doubles(d.N);
+    if (h->fast && (h->threads == tmpc::NT || d.N > 20) && (h->kernel_scan = tmpc::pick_scan_kernel(d, &h->scan_threads, &h->scan_sl)) != nullptr) {
+        h->lds_bytes_scan = h->lds_bytes_fast + sizeof(double) * (size_t)(h->scan_sl == 3 ? tmpc::scan::lds_doubles<3>(d.N) : tmpc::scan::lds_doubles<2>(d.N));
+        if (h->lds_bytes_scan > 160 * 1024) h->kernel_scan = nullptr;
+    }
+    if (h->kernel_scan) {
         if (hipFuncSetAttribute((const void *)h->kernel_scan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes_scan) != hipSuccess)
             h->kernel_scan = nullptr;
     }

@@ -812,14 +812,15 @@ def test_parallel_in_time_variant_matches_oracle(scene):
     s.set_batch(sc["xinit"][9:10], sc["x0"][9:10], sc["params"][9:10]); s.solve(); one = s.get()
     assert np.array_equal(one["xtraj"][0], got["xtraj"][9]) and one["pobj"][0] == got["pobj"][9]
     s.close()
-    s3 = _solver(N=30, n_slk=12, slack=1, B_max=4)                # N > 20 (cfg 3): no such variant -- accepted, runs as before
+    s3 = _solver(N=32, B_max=4)                                   # N > 31: no such variant -- accepted, runs as before
     assert s3.set_latency_mode(2) is False
     s3.close()
 
 
-@pytest.mark.parametrize("cfg", ["cfg1", "cfg4", "cfg5"])
+@pytest.mark.parametrize("cfg", ["cfg1", "cfg3", "cfg4", "cfg5"])
 def test_parallel_in_time_variant_other_shapes(cfg):
-    """Latency mode 2 on the other one-wave shapes (runtime row counts, two waves per trajectory): BASELINE cfg 1 / 4 / 5 against the oracle."""
+    """Latency mode 2 on the other shapes (runtime row counts, two waves per trajectory): BASELINE cfg 1 / 4 / 5 and cfg 3 (N = 30: two
+    lanes per stage and three columns per lane in the Newton solve's first reduction level) against the oracle."""
     import oracle_lib as O
     from mpc_planner_amd import scenes
     if cfg == "cfg1":

@@ -42,7 +42,10 @@ struct System {
 };
 
 // The device code is the product's (mpc_planner_amd/csrc/tmpc_scan.hpp); operands staged in LDS as the solve kernels hold them.
-constexpr int LDS_DOUBLES = NS * 28 + N * 35 + 2 * NS * 7 + N * 5 + NS * 7 + NS * 5 + tmpc::scan::lds_doubles(N);
+#ifndef SCAN_SL
+#define SCAN_SL 3                                    // lanes per stage of the stage phases (-DSCAN_SL=2: the N <= 31 configuration on the same systems)
+#endif
+constexpr int LDS_DOUBLES = NS * 28 + N * 35 + 2 * NS * 7 + N * 5 + NS * 7 + NS * 5 + tmpc::scan::lds_doubles<SCAN_SL>(N);
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void scan_kernel(const System *__restrict__ sys, int n_sys, double *__restrict__ dz_out, long long *__restrict__ cycles, int reps)
 {
     __shared__ __attribute__((aligned(16))) double smem[LDS_DOUBLES];
@@ -58,8 +61,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     for (int e = lane; e < 2 * NS * 7; e += 64) gh[e] = P.g[0][0][e];
     for (int e = lane; e < N * 5; e += 64) rb[e] = P.rb[0][e];
     __syncthreads();
-    tmpc::scan::View V{Hh, BA, gh, rb, dv, dpi, scr, N};
-    tmpc::scan::View V2 = V; V2.gh = gh + NS * 7;
+    tmpc::scan::ViewT<SCAN_SL> V{Hh, BA, gh, rb, dv, dpi, scr, N};
+    tmpc::scan::ViewT<SCAN_SL> V2 = V; V2.gh = gh + NS * 7;
     double *out = dz_out + (size_t)blockIdx.x * 2 * NS * NV;
     long long acc[PH_COUNT] = {0, 0, 0, 0};
     bool bad = false;
