@@ -154,6 +154,7 @@ __device__ __forceinline__ void ba_column(const BaRow &r, int c, double (&v)[SNV
     v[6] = c == 4 ? 1.0 : 0.0;
 }
 
+// (ds_add_f64: a plain read-modify-write in its place was measured 50 % slower per write phase -- load, wait, add, store)
 __device__ __forceinline__ void add_lds(double *p, double v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 // Loads of a phase are written first and pinned there: left alone, the scheduler sinks every LDS load next to its use, and a lane then
 // pays one full LDS round trip per load (s_waitcnt lgkmcnt(0) after each) instead of one per phase.
@@ -269,6 +270,7 @@ __device__ __forceinline__ bool cr_level(const ViewT<SL> &V, int lane, int s)
     double w[CPL][SNX], a[CPL][SNX], b[CPL][SNX];
     double *bo = blk + (act ? o : 0) * BS;
     const double *br = (act && has_r) ? blk + er * BS + OL : V.zeros();   // Rc_o = Lc_er^T (zeros without a right neighbour: no selects on the data)
+    SCAN_T0();
     if (act) {
         double L[15];
 #pragma unroll
@@ -289,7 +291,9 @@ __device__ __forceinline__ bool cr_level(const ViewT<SL> &V, int lane, int s)
             for (int i = 0; i < SNX; i++) w[t][i] = wp[i * ws];
         }
         loads_done();
+        SCAN_T(10);
         bad = chol_inlane<SNX>(L);
+        SCAN_T(11);
         if (q == 0) {
 #pragma unroll
             for (int e = 0; e < 15; e++) bo[OLD + e] = L[e];
@@ -307,6 +311,7 @@ __device__ __forceinline__ bool cr_level(const ViewT<SL> &V, int lane, int s)
                 for (int i = 0; i < SNX; i++) { a[t][i] = fma(lc[i][r], w[t][r], a[t][i]); b[t][i] = fma(rc[i][r], w[t][r], b[t][i]); }
     }
     fence();                                                 // every read of the old couplings is done
+    SCAN_T(12);
     if (act) {
 #pragma unroll
         for (int t = 0; t < CPL; t++) {
@@ -316,7 +321,7 @@ __device__ __forceinline__ bool cr_level(const ViewT<SL> &V, int lane, int s)
             for (int i = 0; i < SNX; i++) bo[(cid < 5 ? OL : ORR) + c * 5 + i] = w[t][i];            // W = D^-1 [Lc Rc]
             if (cid < 5) {
 #pragma unroll
-                for (int i = 0; i < SNX; i++) add_lds(&blk[el * BS + OD + c * 5 + i], -a[t][i]);       // D_el -= Lc^T D^-1 Lc
+                for (int i = 0; i < SNX; i++) add_lds(&blk[el * BS + OD + c * 5 + i], -a[t][i]);       // D_el -= Lc^T D^-1 Lc (whole columns: masking the unused upper triangle costs more than it saves)
             } else if (has_r) {
 #pragma unroll
                 for (int i = 0; i < SNX; i++) {
@@ -327,6 +332,7 @@ __device__ __forceinline__ bool cr_level(const ViewT<SL> &V, int lane, int s)
         }
     }
     fence();
+    SCAN_T(13);
     return bad;
 }
 

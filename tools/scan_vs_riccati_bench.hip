@@ -215,9 +215,9 @@ int main(int argc, char **argv)
         scan_kernel<<<B, 64>>>(d_sys, B, d_dz, d_cyc, reps);
         CK(hipDeviceSynchronize());
         CK(hipMemcpyFromSymbol(c16, HIP_SYMBOL(g_scan_clk), sizeof c16));
-        static const char *nm[10] = {"stage_zero_fill", "stage_chol7", "stage_columns", "stage_stores", "solve_rb", "solve_Pg", "solve_forward_levels", "solve_Dinv_beta", "solve_back_levels", "solve_recover"};
+        static const char *nm[14] = {"stage_zero_fill", "stage_chol7", "stage_columns", "stage_stores", "solve_rb", "solve_Pg", "solve_forward_levels", "solve_Dinv_beta", "solve_back_levels", "solve_recover", "cr_loads", "cr_chol5", "cr_solve_matvec", "cr_writes"};
         printf("{\"scan_profile_cycles\": {");
-        for (int i = 0; i < 10; i++) printf("\"%s\": %.0f%s", nm[i], (double)c16[i] / B / reps / (i >= 4 ? 2 : 1), i < 9 ? ", " : "}}\n");
+        for (int i = 0; i < 14; i++) printf("\"%s\": %.0f%s", nm[i], (double)c16[i] / B / reps / ((i >= 4 && i < 10) ? 2 : 1), i < 13 ? ", " : "}}\n");
     }
 #endif
     int occ = 0; CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, scan_kernel, 64, 0));
