@@ -292,6 +292,48 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
             }
             team.sync();
         }
+        double res_b = 0.0;
+        if constexpr (!CP) {
+            // Fast layout (one wave per SIMD: nothing else hides an LDS round trip): every operand of an element is loaded unconditionally
+            // (clamped indices) ahead of the arithmetic and pinned there -- a `cond ? lds[i] : 0` is a branch and a wait per load, and
+            // the scheduler sinks unpinned loads next to their uses.  Same sums in the same order as the compact form below.
+            for (int e = tl; e < (N + 1) * NV; e += NT) {
+                const int ks = e / NV, i = e - ks * NV;
+                const bool skip = (ks == N && i < NU) || (ks == 0 && i >= NU);
+                const int kb = ks < N ? ks : N - 1;
+                const double *Wk = L.W + ks * NP28, *vk = L.v + ks * NV, *BA = L.BA + kb * NX * NV, *pn = L.pq + (kb + 1) * NX;
+                double ge = L.g[e], wv[NV], vv[NV], bav[NX], pv[NX];
+#pragma unroll
+                for (int j = 0; j < NV; j++) { wv[j] = Wk[sidx(i, j)]; vv[j] = vk[j]; }
+#pragma unroll
+                for (int l = 0; l < NX; l++) { bav[l] = BA[l * NV + i]; pv[l] = pn[l]; }
+                const double pm = L.pq[(ks >= 1 ? ks : 1) * NX + (i >= NU ? i - NU : 0)];
+                scan::loads_done();
+                double acc = ge;
+#pragma unroll
+                for (int j = 0; j < NV; j++) acc += wv[j] * vv[j];
+                if (ks < N) {
+#pragma unroll
+                    for (int l = 0; l < NX; l++) acc += bav[l] * pv[l];
+                }
+                if (i >= NU && ks >= 1) acc -= pm;
+                acc = skip ? 0.0 : acc;
+                L.rg[e] = acc; L.gh[e] = acc;
+            }
+            for (int e = tl; e < N * NX; e += NT) {
+                const int ks = e / NX, i = e - ks * NX;
+                const double *vk = L.v + ks * NV, *BA = L.BA + ks * NX * NV + i * NV;
+                double be = L.b[e], vn = L.v[(ks + 1) * NV + NU + i], bav[NV], vv[NV];
+#pragma unroll
+                for (int j = 0; j < NV; j++) { bav[j] = BA[j]; vv[j] = vk[j]; }
+                scan::loads_done();
+                double acc = be - vn;
+#pragma unroll
+                for (int j = 0; j < NV; j++) acc += bav[j] * vv[j];
+                L.rb[e] = acc;
+                res_b = fmax(res_b, fabs(acc));
+            }
+        } else {
         for (int e = tl; e < (N + 1) * NV; e += NT) {
             const int ks = e / NV, i = e - ks * NV;
             double acc = 0.0;
@@ -315,7 +357,6 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
             }
             L.rg[e] = acc; L.gh[e] = acc;
         }
-        double res_b = 0.0;
         for (int e = tl; e < N * NX; e += NT) {
             const int ks = e / NX, i = e - ks * NX;
             double acc = L.b[e] - L.v[(ks + 1) * NV + NU + i];
@@ -330,6 +371,7 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
             }
             L.rb[e] = acc;
             res_b = fmax(res_b, fabs(acc));
+        }
         }
         if constexpr (!CP) for (int e = tl; e < (N + 1) * NP28; e += NT) L.Hh[e] = L.W[e];
         team.sync();
@@ -375,11 +417,12 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
         team.sync();
         // now rg = rg0 - sum lam c (residual) and gh = rg0 + sum d rd c (predictor rhs, q/t = lam)
         double res_g = 0.0;
-        for (int e = tl; e < (N + 1) * NV; e += NT)
-            if (!(e >= NU && e < NV)) res_g = fmax(res_g, fabs(L.rg[e]));      // dx_0 is fixed: its stationarity row is not a residual
-        res_g = blk_max<NTH>(res_g, L.scr, tl, 0); res_b = blk_max<NTH>(res_b, L.scr, tl, 1);
-        res_d = blk_max<NTH>(res_d, L.scr, tl, 2); res_m = blk_max<NTH>(res_m, L.scr, tl, 3);
-        mu = blk_sum<NTH>(mu, L.scr, tl, 4) / m_rows;
+        for (int e = tl; e < (N + 1) * NV; e += NT) {
+            const double r = L.rg[e];                                          // (load, then select: see the residual loops above)
+            res_g = fmax(res_g, (e >= NU && e < NV) ? 0.0 : fabs(r));          // dx_0 is fixed: its stationarity row is not a residual
+        }
+        blk_residuals<NTH>(res_g, res_b, res_d, res_m, mu, L.scr, tl);
+        mu = mu / m_rows;
         pf.stop(PH_RES);
         if (!(isfinite(res_g) && isfinite(res_b) && isfinite(res_d) && isfinite(res_m))) { status = 4; active = false; }
         else if (res_g <= d.qp_tol && res_b <= d.qp_tol && res_d <= d.qp_tol && res_m <= d.qp_tol) { status = 0; active = false; }

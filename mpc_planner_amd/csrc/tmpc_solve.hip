@@ -248,6 +248,22 @@ template <int NTH> __device__ __forceinline__ double blk_sum(double x, double *s
     return blk_combine<NTH>(wave_sum(x), scr, tid, slot, [](double a, double b) { return a + b; });
 }
 
+// The five convergence quantities of an interior-point iteration at once: one LDS exchange and one barrier in the two-wave kernels
+// instead of five (same slots, same combination order as five blk_max / blk_sum calls: bitwise the same values).
+template <int NTH>
+__device__ __forceinline__ void blk_residuals(double &g, double &b, double &dd, double &m, double &mu, double *scr, int tid)
+{
+    g = wave_max(g); b = wave_max(b); dd = wave_max(dd); m = wave_max(m); mu = wave_sum(mu);
+    if constexpr (NTH > 64) {
+        if ((tid & 63) == 0) { const int w = tid >> 6; scr[w] = g; scr[2 + w] = b; scr[4 + w] = dd; scr[6 + w] = m; scr[8 + w] = mu; }
+        __syncthreads();
+        double v[10];
+#pragma unroll
+        for (int i = 0; i < 10; i++) v[i] = scr[i];
+        g = fmax(v[0], v[1]); b = fmax(v[2], v[3]); dd = fmax(v[4], v[5]); m = fmax(v[6], v[7]); mu = v[8] + v[9];
+    }
+}
+
 // ---- interior-point row access --------------------------------------------------------------------
 struct Row { int k, var, general; double sgn; };   // general: index into D/beta; box: var = z index
 
@@ -785,10 +801,16 @@ __global__ __launch_bounds__(NT) void tmpc_solve_kernel(Dims d, int B, const dou
 #define TMPC_X(a, b, c, e) template __global__ void tmpc::tmpc_solve_fast_kernel<a, b, c, e, true>(TMPC_KARGS);
 TMPC_FAST_SHAPES(TMPC_X)
 #undef TMPC_X
+#ifndef TMPC_GENERATED_STAGE
+template __global__ void tmpc::tmpc_solve_fast_kernel<8, 8, 6, 128, true, tmpc::ScanSolo>(TMPC_KARGS);      // profiled twin of latency mode 2 (cfg 2)
+#endif
 #elif defined(TMPC_PROF_EXTERN)
 #define TMPC_X(a, b, c, e) extern template __global__ void tmpc::tmpc_solve_fast_kernel<a, b, c, e, true>(TMPC_KARGS);
 TMPC_FAST_SHAPES(TMPC_X)
 #undef TMPC_X
+#ifndef TMPC_GENERATED_STAGE
+extern template __global__ void tmpc::tmpc_solve_fast_kernel<8, 8, 6, 128, true, tmpc::ScanSolo>(TMPC_KARGS);
+#endif
 #endif
 #ifdef TMPC_PROF_TU
 #elif defined(TMPC_SINGLE_TEAM)
@@ -1692,13 +1714,22 @@ int tmpc_debug_profile(tmpc_handle *h, int64_t *cycles, int32_t n_phases)
     long long *dp = (long long *)dp_;
     TMPC_HIP_CHECK(h, hipMemset(dp, 0, n * 8));
     tmpc::SolveKernel pk = h->kernel;                   // the generic kernel profiles itself; fast shapes have an instrumented twin
+    int thr = h->threads;
+    size_t lds = h->fast ? h->lds_bytes_fast : h->lds_bytes;
     if (h->fast) {
-        int thr = 0;
         pk = tmpc::pick_fast_kernel(h->d, &thr, true);
-        TMPC_HIP_CHECK(h, hipFuncSetAttribute((const void *)pk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes_fast));
+#ifndef TMPC_GENERATED_STAGE
+        // the latency variants of cfg 2 are profiled as themselves (tmpc_set_latency_mode before the call)
+        if (h->latency_mode == 2 && h->kernel_scan && h->scan_threads == 128 && h->scan_sl == 3 && h->d.n_up == 8 && h->d.M == 8) {
+            pk = (tmpc::SolveKernel)tmpc::tmpc_solve_fast_kernel<8, 8, 6, 128, true, tmpc::ScanSolo>; thr = 128; lds = h->lds_bytes_scan;
+        } else if (h->latency_mode != 0 && h->kernel_lat) {
+            pk = tmpc::pick_latency_kernel(h->d, true); thr = 128;
+        }
+#endif
+        TMPC_HIP_CHECK(h, hipFuncSetAttribute((const void *)pk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     // (a compact handle is profiled through the fast kernel of its shape: same phases and arithmetic, one wave per SIMD)
-    hipLaunchKernelGGL(pk, dim3(h->B), dim3(h->threads), h->fast ? h->lds_bytes_fast : h->lds_bytes, h->stream, h->d, h->B,
+    hipLaunchKernelGGL(pk, dim3(h->B), dim3(thr), lds, h->stream, h->d, h->B,
                        h->xinit, h->x0, h->params, h->xtraj, h->utraj, h->pobj, h->exit_code, h->qp_status,
                        h->sqp_iter, h->res_eq, h->qp_iter, dp, tmpc::StateIO{nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr});
     TMPC_HIP_CHECK(h, hipGetLastError());
