@@ -133,7 +133,7 @@ struct ScanSoloT {
         asm volatile("" : "+v"(tl));                 // opaque per call (see riccati_factor)
         bool bad = false;
         if (NTH == 64 || (tl >> 6) == sw) {
-            const scan::ViewT<SL> V{L.Hh, L.BA, L.gh, L.rb, L.dv, L.dpi, L.scan, d.N};
+            const scan::ViewT<SL> V{L.Hh, L.BA, L.gh, L.rb, L.dv, L.dpi, L.scan + d.N * NP28, d.N};      // (behind the W shares of the two-wave linearisation)
             bad = scan::factor(V, tl & 63);
             if (NTH > 64 && (tl & 63) == 0) L.scr[63] = bad ? 1.0 : 0.0;
         }
@@ -146,7 +146,7 @@ struct ScanSoloT {
     {
         asm volatile("" : "+v"(tl));
         if (NTH == 64 || (tl >> 6) == sw) {
-            const scan::ViewT<SL> V{L.Hh, L.BA, L.gh, L.rb, L.dv, L.dpi, L.scan, d.N};
+            const scan::ViewT<SL> V{L.Hh, L.BA, L.gh, L.rb, L.dv, L.dpi, L.scan + d.N * NP28, d.N};      // (behind the W shares of the two-wave linearisation)
             scan::solve(V, tl & 63, phase == 1);     // the predictor's right-hand side went through the factorisation
         }
         __syncthreads();
@@ -607,7 +607,7 @@ void tmpc_solve_fast_kernel(Dims d, int B, const double *__restrict__ xinit,
     double lam[C::RPL];
     for (int it = 0; it < d.n_sqp; it++) {
         pf.start();
-        linearise<true>(L, d, tid, pb, slack_of(), pb_own);
+        linearise<true, false, NTH>(L, d, tid, pb, slack_of(), pb_own);
         __syncthreads();
         pf.stop(PH_LIN);
         int iters = 0;

@@ -581,10 +581,135 @@ __device__ int ipm_solve(const Lds &L, const Dims &d, int tid, int *iters_out, P
 }
 
 // ---- stage linearisation by lane k --------------------------------------------------------------
-template <bool FAST, bool CP = false>
+// NTH = 128 (fast layout, two waves per trajectory; hand-written stages): the stage evaluation is split over the waves -- wave 0 the dynamics
+// (rollout with sensitivities, [B A], the multipliers' share of the Hessian) and half of the ellipsoid rows, wave 1 the cost, the halfspace
+// rows and the other ellipsoids -- which run as different code at the same time; the shares of W are exchanged through LDS and the
+// regularisation (MIRROR: more than half of a stage's chain) is shared too.  W = W_0 + W_1 associates differently from the one-wave sum (rounding level).
+template <bool FAST, bool CP = false, int NTH = 64>
 __device__ __forceinline__ void linearise(const Lds &L, const Dims &d, int tid, const double *params, double slack, const double *params_own = nullptr)
 {
     const int N = d.N;
+#ifndef TMPC_GENERATED_STAGE
+    if constexpr (FAST && !CP && NTH == 128) {
+        int tid_l = tid;
+        asm volatile("" : "+v"(tid_l));
+        const int wv = tid_l >> 6, ln = tid_l & 63;
+        const bool owner = ln < N;
+        const int k = owner ? ln : N - 1;                   // (full EXEC mask: lanes >= N redo stage N - 1 and do not store)
+        double z[NV];
+#pragma unroll
+        for (int i = 0; i < NV; i++) z[i] = L.z[k * NV + i];
+        const double *p = params + (size_t)k * d.npar;
+        const long long own_delta = params_own ? (long long)(params_own - params) : 0;
+        const int nh = L.nh;
+        double W[NV][NV], g[NV], BA[NX * NV], xn[NX];
+        auto lamh = [&](int r) { return L.lamh[k * nh + r]; };
+        auto sink = [&](int r, const RowOut &ro) {
+            if (owner) {
+                double *Dr = L.D + (k * nh + r) * 3;
+                Dr[0] = ro.gx; Dr[1] = ro.gy; Dr[2] = ro.gp;
+                const double bound = (r < d.n_up) ? 0.0 : 1.0;
+                L.beta[k * nh + r] = bound - ro.h;
+            }
+        };
+        // both waves park their share of W (wave 1 in the stage's W slot, wave 0 in the -- idle -- residual arrays of the interior-point
+        // work region), so that after the barrier each of them has the complete W and MIRROR can be shared as well: with a zero disc offset
+        // W is block diagonal under {a, w, psi, v} | {x, y, spline} (mirror7), and the two blocks are regularised on different waves --
+        // bitwise what mirror7 computes.  A coupled W (any cross entry != 0) takes the 7 x 7 iteration on wave 0.
+        double *W0s = L.scan + k * NP28;                     // (N * NP28 doubles behind the layout: every two-wave launch allocates them)
+        if (wv == 1) {                                       // cost, halfspace rows, second half of the ellipsoid rows
+            stage_linearise(d, z, p, 1, 0.0, 0.0, lamh, sink, W, g, BA, xn, slack, nullptr, own_delta, 2);
+            if (owner) {
+#pragma unroll
+                for (int i = 0; i < NV; i++) L.g[k * NV + i] = g[i];
+#pragma unroll
+                for (int i = 0; i < NV; i++)
+#pragma unroll
+                    for (int j = 0; j <= i; j++) L.W[k * NP28 + pidx(i, j)] = W[i][j];
+            }
+        } else {                                             // dynamics, first half of the ellipsoid rows
+            stage_linearise(d, z, p, 1, L.pi[(k + 1) * NX + 0], L.pi[(k + 1) * NX + 1], lamh, sink, W, g, BA, xn, slack, nullptr, own_delta, 1);
+            if (owner) {
+#pragma unroll
+                for (int i = 0; i < NX * NV; i++) L.BA[k * NX * NV + i] = BA[i];
+                double *d8 = L.dyn8 + k * 8;
+                d8[D8_XA] = BA[0 * NV + ZA]; d8[D8_XW] = BA[0 * NV + ZW]; d8[D8_XP] = BA[0 * NV + ZPSI]; d8[D8_XV] = BA[0 * NV + ZV];
+                d8[D8_YA] = BA[1 * NV + ZA]; d8[D8_YW] = BA[1 * NV + ZW]; d8[D8_YP] = BA[1 * NV + ZPSI]; d8[D8_YV] = BA[1 * NV + ZV];
+#pragma unroll
+                for (int i = 0; i < NX; i++) L.b[k * NX + i] = xn[i] - L.z[(k + 1) * NV + NU + i];
+#pragma unroll
+                for (int i = 0; i < NV; i++)
+#pragma unroll
+                    for (int j = 0; j <= i; j++) W0s[pidx(i, j)] = W[i][j];
+            }
+        }
+        __syncthreads();                                     // both shares of W are in LDS
+        {
+            double w0[NP28], w1[NP28];
+#pragma unroll
+            for (int e = 0; e < NP28; e++) { w0[e] = W0s[e]; w1[e] = L.W[k * NP28 + e]; }
+#pragma unroll
+            for (int i = 0; i < NV; i++)
+#pragma unroll
+                for (int j = 0; j <= i; j++) { W[i][j] = w0[pidx(i, j)] + w1[pidx(i, j)]; W[j][i] = W[i][j]; }
+        }
+        __syncthreads();                                     // ... and read by both waves: the W slot may be overwritten
+        constexpr int IA[4] = {ZA, ZW, ZPSI, ZV}, IB[3] = {ZX, ZY, ZS};
+        bool coupled = false;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) coupled |= (W[IA[i]][IB[j]] != 0.0) | (W[IB[j]][IA[i]] != 0.0);
+        if (wv == 0) {
+            if (coupled) {
+                mirror_n<NV>(W, d.reg_eps);
+                if (owner) {
+#pragma unroll
+                    for (int i = 0; i < NV; i++)
+#pragma unroll
+                        for (int j = 0; j <= i; j++) L.W[k * NP28 + pidx(i, j)] = W[i][j];
+                }
+            } else {
+                double Ba[4][4];
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) Ba[i][j] = W[IA[i]][IA[j]];
+                mirror_n<4>(Ba, d.reg_eps);
+                if (owner) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+#pragma unroll
+                        for (int j = 0; j < 4; j++) if (IA[i] >= IA[j]) L.W[k * NP28 + pidx(IA[i], IA[j])] = Ba[i][j];
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+#pragma unroll
+                        for (int j = 0; j < 3; j++) L.W[k * NP28 + sidx(IA[i], IB[j])] = 0.0;      // (the cross entries: exactly zero here)
+                }
+            }
+            if (tid_l == N) {                                // terminal node: zero cost, no rows: MIRROR(0) = eps I on the state block
+                const int wN = N * NP28, gN = N * NV;
+                for (int e = 0; e < NP28; e++) L.W[wN + e] = 0.0;
+                for (int i = NU; i < NV; i++) L.W[wN + pidx(i, i)] = d.reg_eps;
+                for (int i = 0; i < NV; i++) L.g[gN + i] = 0.0;
+            }
+        } else if (!coupled) {
+            double Bb[3][3];
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int j = 0; j < 3; j++) Bb[i][j] = W[IB[i]][IB[j]];
+            mirror_n<3>(Bb, d.reg_eps);
+            if (owner) {
+#pragma unroll
+                for (int i = 0; i < 3; i++)
+#pragma unroll
+                    for (int j = 0; j < 3; j++) if (IB[i] >= IB[j]) L.W[k * NP28 + pidx(IB[i], IB[j])] = Bb[i][j];
+            }
+        }
+        return;
+    }
+#endif
     // Every lane runs the (register-hungry) stage evaluation with the full EXEC mask -- lanes >= N redo stage N-1 and
     // simply do not store -- so that no spill/reload of live registers happens under a partial mask.
     int tid_l = tid;
@@ -977,7 +1102,8 @@ struct tmpc_handle {
     tmpc::SolveKernel kernel_scan = nullptr;  // optional latency variant 2 (parallel-in-time Newton solve, 64 threads)
     size_t lds_bytes_scan = 0;
     int scan_threads = 64, scan_sl = 3;
-    size_t lds_bytes_fast = 0;                // LDS of the fast-layout kernels (kernel_lat, the profiled twin) when `kernel` is compact
+    size_t lds_bytes_fast = 0;                // LDS of the fast-layout kernels (the profiled twin) when `kernel` is compact
+    size_t lds_bytes_fast2 = 0;               // ... of their two-wave variants (kernel_lat): + the W shares parked during the linearisation
     bool compact = false;                     // `kernel` is a compact persistent kernel: grid = resident workgroups, needs ws + ticket
     int team = 1;                             // trajectories per workgroup of the compact / team kernel (1, 2 or 4 waves)
     int grid_max = 0;                         // resident workgroups of the compact kernel on this device
@@ -1086,15 +1212,18 @@ int tmpc_create(tmpc_handle **out, const tmpc_dims *dims, int32_t B_max, int32_t
     if (h->fast) h->lds_bytes = sizeof(double) * (size_t)tmpc::lds_doubles_fast(d.N, d.n_up + d.M);
     else { h->kernel = tmpc::tmpc_solve_kernel; h->lds_bytes = sizeof(double) * (size_t)tmpc::lds_doubles(d.N, d.n_up + d.M); }
     h->lds_bytes_fast = h->lds_bytes;
+    // two-wave (128-thread) fast kernels park one share of W per stage behind the layout while they linearise (linearise<.., 128>)
+    h->lds_bytes_fast2 = h->lds_bytes_fast + sizeof(double) * (size_t)d.N * tmpc::NP28;
+    if (h->fast && h->threads == 128) h->lds_bytes = h->lds_bytes_fast2;
     auto fail = [&](int code) { delete h; return code; };
     if (hipSetDevice(device) != hipSuccess) return fail(TMPC_ERR_HIP);
     if (h->lds_bytes > 160 * 1024) return fail(TMPC_ERR_INVALID);
     if (h->fast && h->threads == tmpc::NT && (h->kernel_lat = tmpc::pick_latency_kernel(d, false)) != nullptr) {
-        if (hipFuncSetAttribute((const void *)h->kernel_lat, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes_fast) != hipSuccess)
+        if (hipFuncSetAttribute((const void *)h->kernel_lat, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes_fast2) != hipSuccess)
             h->kernel_lat = nullptr;
     }
     if (h->fast && (h->threads == tmpc::NT || d.N > 20) && (h->kernel_scan = tmpc::pick_scan_kernel(d, &h->scan_threads, &h->scan_sl)) != nullptr) {
-        h->lds_bytes_scan = h->lds_bytes_fast + sizeof(double) * (size_t)(h->scan_sl == 3 ? tmpc::scan::lds_doubles<3>(d.N) : tmpc::scan::lds_doubles<2>(d.N));
+        h->lds_bytes_scan = h->lds_bytes_fast2 + sizeof(double) * (size_t)(h->scan_sl == 3 ? tmpc::scan::lds_doubles<3>(d.N) : tmpc::scan::lds_doubles<2>(d.N));
         if (h->lds_bytes_scan > 160 * 1024) h->kernel_scan = nullptr;
     }
     if (h->kernel_scan) {
@@ -1207,7 +1336,7 @@ static int launch_solve(tmpc_handle *h, int n_iter, int st_flags)
         if (cp) TMPC_HIP_CHECK(h, hipMemsetAsync(h->ticket, 0, 8 * 4, h->stream));    // the persistent launch's work counters (one per XCD)
         const int teams = (h->B + h->team - 1) / h->team;                              // workgroups' worth of work of a persistent launch
         hipLaunchKernelGGL(lat2 ? h->kernel_scan : lat ? h->kernel_lat : h->kernel, dim3(cp ? (teams < h->grid_max ? teams : h->grid_max) : h->B),
-                           dim3(lat2 ? h->scan_threads : lat ? 128 : (cp ? 64 * h->team : h->threads)), lat2 ? h->lds_bytes_scan : lat ? h->lds_bytes_fast : h->lds_bytes, h->stream, dd, h->B,
+                           dim3(lat2 ? h->scan_threads : lat ? 128 : (cp ? 64 * h->team : h->threads)), lat2 ? h->lds_bytes_scan : lat ? h->lds_bytes_fast2 : h->lds_bytes, h->stream, dd, h->B,
                            h->xinit, h->x0, h->params, h->xtraj, h->utraj, h->pobj, h->exit_code, h->qp_status,
                            h->sqp_iter, h->res_eq, h->qp_iter, (long long *)nullptr, io);
         TMPC_HIP_CHECK(h, hipGetLastError());
@@ -1716,6 +1845,7 @@ int tmpc_debug_profile(tmpc_handle *h, int64_t *cycles, int32_t n_phases)
     tmpc::SolveKernel pk = h->kernel;                   // the generic kernel profiles itself; fast shapes have an instrumented twin
     int thr = h->threads;
     size_t lds = h->fast ? h->lds_bytes_fast : h->lds_bytes;
+    if (h->fast && h->threads == 128) lds = h->lds_bytes_fast2;
     if (h->fast) {
         pk = tmpc::pick_fast_kernel(h->d, &thr, true);
 #ifndef TMPC_GENERATED_STAGE
@@ -1723,7 +1853,7 @@ int tmpc_debug_profile(tmpc_handle *h, int64_t *cycles, int32_t n_phases)
         if (h->latency_mode == 2 && h->kernel_scan && h->scan_threads == 128 && h->scan_sl == 3 && h->d.n_up == 8 && h->d.M == 8) {
             pk = (tmpc::SolveKernel)tmpc::tmpc_solve_fast_kernel<8, 8, 6, 128, true, tmpc::ScanSolo>; thr = 128; lds = h->lds_bytes_scan;
         } else if (h->latency_mode != 0 && h->kernel_lat) {
-            pk = tmpc::pick_latency_kernel(h->d, true); thr = 128;
+            pk = tmpc::pick_latency_kernel(h->d, true); thr = 128; lds = h->lds_bytes_fast2;
         }
 #endif
         TMPC_HIP_CHECK(h, hipFuncSetAttribute((const void *)pk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

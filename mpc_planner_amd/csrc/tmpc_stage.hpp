@@ -499,8 +499,13 @@ template <typename LamH, typename RowSink>
 TMPC_HD void stage_linearise(const Dims &d, const double *z, const double *p, int pstride,
                                                 double pix, double piy, LamH lamh, RowSink sink,
                                                 double (*W)[NV], double *g, double *BA, double *xn, double slack = 0.0,
-                                                double *stash = nullptr, long long own_delta = 0)
+                                                double *stash = nullptr, long long own_delta = 0, int part = 0)
 {
+    // part (hand-written stages; compile-time at every call site): 0 = the whole stage; 1 = dynamics and the first half of the ellipsoid rows
+    // (W = their share of the Lagrangian Hessian, BA, xn; g untouched); 2 = cost, topology and scenario / decomp rows, the other ellipsoid
+    // rows (W = their share, g; BA, xn untouched).  The two-wave kernels run 1 and 2 on different waves at the same time and add the two W
+    // (linearise, tmpc_solve.hip).  Measured shares of a stage's 46 k cycles (cfg 2): dynamics 5.5 k, eight ellipsoid rows 10.2 k, cost and
+    // halfspace rows 8.3 k -- and 22.3 k for MIRROR, which needs the complete W and stays on one wave.
     // own_delta (doubles, wave-uniform): distance from `p` to the trajectory's OWN parameter row when `p` is a row it shares with others
     // (tmpc_set_param_sharing): the topology and scenario halfspaces (ip_lin / ip_slk) are read from p + own_delta, everything else
     // from p.  A delta, not a second pointer: the second address then lives only across the halfspace loads (the linearisation is the
@@ -521,12 +526,17 @@ TMPC_HD void stage_linearise(const Dims &d, const double *z, const double *p, in
     for (int i = 0; i < NV; i++)
 #pragma unroll
         for (int j = 0; j < NV; j++) W[i][j] = 0.0;
-    DynOut dy;
-    dyn_eval(d, z, dy, true);
-    dyn_jacobian(d, dy, BA);
+#ifndef TMPC_GENERATED_STAGE
+    if (part != 2)
+#endif
+    {
+        DynOut dy;
+        dyn_eval(d, z, dy, true);
+        dyn_jacobian(d, dy, BA);
 #pragma unroll
-    for (int i = 0; i < NX; i++) xn[i] = dy.xn[i];
-    dyn_add_hessian(dy, pix, piy, W);
+        for (int i = 0; i < NX; i++) xn[i] = dy.xn[i];
+        dyn_add_hessian(dy, pix, piy, W);
+    }
 #ifdef TMPC_GENERATED_STAGE
     if (stash) {
 #pragma unroll
@@ -550,30 +560,38 @@ TMPC_HD void stage_linearise(const Dims &d, const double *z, const double *p, in
         sink(k, ro);
     });
 #else
-    CostOut co;
-    cost_eval(d, z, p, pstride, co, true, slack);
-#pragma unroll
-    for (int i = 0; i < NV; i++) g[i] = (i == ZPSI) ? 0.0 : d.dt * co.g[i];   // stage cost scaled by the shooting interval (the cost
-                                                                        // does not depend on psi: literal 0, not a hoisted dt * 0)
-    cost_add_hessian(co, d.dt, W);
     RowOut ro;
-    for (int j = 0; j < d.n_lin; j++) {
-        lin_row_eval(d, z, p + own_delta, pstride, j, ro);
-        sink(j, ro);
+    if (part != 1) {
+        CostOut co;
+        cost_eval(d, z, p, pstride, co, true, slack);
+#pragma unroll
+        for (int i = 0; i < NV; i++) g[i] = (i == ZPSI) ? 0.0 : d.dt * co.g[i];   // stage cost scaled by the shooting interval (the cost
+                                                                            // does not depend on psi: literal 0, not a hoisted dt * 0)
+        cost_add_hessian(co, d.dt, W);
+        for (int j = 0; j < d.n_lin; j++) {
+            lin_row_eval(d, z, p + own_delta, pstride, j, ro);
+            sink(j, ro);
+        }
     }
     if (d.M == 0 && d.n_slk == 0) return;
     const double r_disc = d.M > 0 ? p[(size_t)ip_disc_radius(d) * pstride] : 0.0, off = p[(size_t)ip_disc_offset(d) * pstride];
     double spsi, cpsi;
     sincos(z[ZPSI], &spsi, &cpsi);
-    for (int j = 0; j < d.n_slk; j++) {
-        slk_row_eval(d, z, p + own_delta, pstride, j, off, spsi, cpsi, slack, ro);
-        W[ZPSI][ZPSI] += lamh(d.n_lin + j) * ro.Hpp;              // the row is linear in (x, y); psi enters through the disc offset
-        sink(d.n_lin + j, ro);
+    if (part != 1) {
+        for (int j = 0; j < d.n_slk; j++) {
+            slk_row_eval(d, z, p + own_delta, pstride, j, off, spsi, cpsi, slack, ro);
+            W[ZPSI][ZPSI] += lamh(d.n_lin + j) * ro.Hpp;          // the row is linear in (x, y); psi enters through the disc offset
+            sink(d.n_lin + j, ro);
+        }
     }
-    for (int j = 0; j < d.M; j++) {
-        ellipsoid_row_eval(d, z, p, pstride, j, r_disc, off, spsi, cpsi, ro);
-        row_add_hessian(ro, lamh(d.n_up + j), W);
-        sink(d.n_up + j, ro);
+    {
+        // the two parts share the ellipsoid rows (part 1 the first half, next to the dynamics)
+        const int j0 = part == 2 ? d.M / 2 : 0, j1 = part == 1 ? d.M / 2 : d.M;
+        for (int j = j0; j < j1; j++) {
+            ellipsoid_row_eval(d, z, p, pstride, j, r_disc, off, spsi, cpsi, ro);
+            row_add_hessian(ro, lamh(d.n_up + j), W);
+            sink(d.n_up + j, ro);
+        }
     }
 #endif
 }
