@@ -134,7 +134,9 @@ int tmpc_set_slots(tmpc_handle *h, const int32_t *slots);
  * modules write the same values into each (:312-318).  The kernels then read everything but those rows from entry base_of[b]: a set's
  * 64 copies of the obstacle / spline / weight rows are fetched once instead of 64 times (the parameter rows are 2/3 of the path's
  * algorithmic bytes, and at eight trajectories per CU they no longer fit the L2 next to the solve's workspace).  The CALLER guarantees
- * the equality; the map stays in force until it is replaced, cleared (NULL) or the batch size changes.  Ignored by the lane kernels
+ * the equality; the map belongs to the batch it was given for: it stays in force until it is replaced, cleared (NULL) or a tmpc_set_batch* call
+ * names new inputs (kernels of this library that rewrite a batch's rows in place -- tmpc_linearize_topology, tmpc_scenario_halfspaces --
+ * touch the entries' own rows only and keep it valid).  Ignored by the lane kernels
  * (tmpc_set_throughput_mode) and by generated solvers. */
 int tmpc_set_param_sharing(tmpc_handle *h, const int32_t *base_of);
 /* Copy the persistent state of min(B_max) slots from another handle of the same shape and device (a caller that outgrew its handle). */

@@ -1300,6 +1300,7 @@ int tmpc_set_batch(tmpc_handle *h, int32_t B, const double *xinit, const double 
     h->xinit = h->o_xinit; h->x0 = h->o_x0; h->params = h->o_params; h->B = B;
     h->scn_B = 0;                      // new parameter rows: the scenario-row bookkeeping of the previous batch no longer describes them
     h->scn_discard_B = 0;
+    h->share_B = 0;                    // ... nor does a parameter-sharing map given for them
     return TMPC_OK;
 }
 
@@ -1307,7 +1308,7 @@ int tmpc_set_batch_device(tmpc_handle *h, int32_t B, const void *d_xinit, const 
 {
     if (!h || B <= 0 || B > h->B_max || !d_xinit || !d_x0 || !d_params) { if (h) h->err = "tmpc_set_batch_device: bad argument"; return TMPC_ERR_INVALID; }
     h->xinit = (const double *)d_xinit; h->x0 = (const double *)d_x0; h->params = (const double *)d_params; h->B = B;
-    h->scn_B = 0; h->scn_discard_B = 0;
+    h->scn_B = 0; h->scn_discard_B = 0; h->share_B = 0;
     return TMPC_OK;
 }
 

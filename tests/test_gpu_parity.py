@@ -770,7 +770,11 @@ def test_param_sharing_hint_is_bitwise_neutral(cfg):
         for key in ("xtraj", "utraj", "pobj", "exit_code", "qp_iter_total", "sqp_iter", "res_eq"):
             assert np.array_equal(ref[key], got[key]), (mode, key)
     assert (ref["exit_code"] == 1).mean() > 0.9
-    # a smaller batch: the old map does not apply (entries would point outside the batch's meaning)
+    # new inputs: the old map is dropped with them (here it would make entry 1 read the rows of entry 0, which now differ)
+    p2 = params[:B].copy(); p2[1, :, 0] *= 2.0                             # (the map `base` of the loop above is still in force here)
+    s.set_batch(sc["xinit"], sc["x0"], p2); s.solve(); fresh = s.get()
+    s.set_param_sharing(None); s.solve(); plain = s.get()
+    assert np.array_equal(fresh["xtraj"], plain["xtraj"])
     s.set_batch(sc["xinit"][:5], sc["x0"][:5], params[:5]); s.solve(); small = s.get()
     assert np.array_equal(small["xtraj"], ref["xtraj"][:5])
     with pytest.raises(Exception):
