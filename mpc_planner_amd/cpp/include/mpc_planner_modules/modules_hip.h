@@ -15,6 +15,11 @@
  * construction -> halfspaces handed in per scenario solver.  The OpenMP loop over local planners becomes: prepare every planner's
  * parameters on the host (same statements, same order), ONE Solver::solveBatch launch, then the reference's bookkeeping.
  * Header-only: everything is small and is compiled against the generated setSolverParameter* functions.
+ *
+ * STATUS: integration scaffolding, not product.  This file exists so that the patch of INTEGRATION.md section 4 compiles and can be tested
+ * end to end without the reference tree; a maintainer applies the patch to the reference's own modules instead of taking this file.
+ * The product is the C-ABI library (include/tmpc_hip.h, csrc/) and the Solver / BatchContext classes of solver_interface.h; the
+ * module bodies below restate reference statements by necessity (same parameter names, same order of writes).
  */
 #ifndef MPC_PLANNER_MODULES_HIP_H
 #define MPC_PLANNER_MODULES_HIP_H
