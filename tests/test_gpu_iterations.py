@@ -11,12 +11,14 @@ def _solver(mode, B_max, **pkw):
     s = solver.BatchedSolver(solver.default_dims(**pkw), B_max=B_max)
     if mode == "latency":
         s.set_latency_mode(True)
+    elif mode == "latency2":                                           # parallel-in-time Newton solve (csrc/tmpc_scan.hpp)
+        assert s.set_latency_mode(2)
     elif mode == "lanes":
         s.set_throughput_mode(True)
     return s
 
 
-@pytest.mark.parametrize("mode", ["wave", "latency", "lanes"])
+@pytest.mark.parametrize("mode", ["wave", "latency", "latency2", "lanes"])
 def test_one_iteration_calls_equal_one_solve(mode):
     """10 x solveOneIteration == solve(): bitwise, including trajectories whose loop ends early (QP at its iteration limit)
     and infeasible ones."""
