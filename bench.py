@@ -33,12 +33,18 @@ FP64_VALU_PEAK_TFLOPS = 78.6                    # MI355X FP64 vector peak (AMD s
 WORKLOADS = {
     "cfg2": dict(dims=dict(N=20, S=5, n_lin=8, M=8), scene=dict(N=20, M=8), traj=64, nh=16, npar=135,
                  what="configs[1]: Jackal MPCC N=20, 8 obstacles, 64 T-MPC guidance trajectories per scene"),
-    "cfg3": dict(dims=dict(N=30, S=5, n_lin=8, M=8, n_slk=12, slack=1), scene=dict(N=30, M=8, slack=True, n_decomp=12), traj=512, nh=28, npar=172,
-                 one_set=True, what="configs[2]: slack model + guidance + 8 ellipsoids + 12 decomp rows (rosnavigation T-MPC stack; see DESIGN 3 on 'CA-MPC'), N=30, ONE set of 512 trajectories"),
+    "cfg3": dict(dims=dict(N=30, S=5, n_lin=8, M=8, n_slk=12, slack=1, cost_model=1), scene=dict(N=30, M=8, slack=True, n_decomp=12), traj=512, nh=28, npar=172,
+                 one_set=True, what="configs[2] as named: Jackal CA-MPC (curvature_aware_contouring.py:48-105, spline ODE s' = v) + guidance + 8 ellipsoids + 12 decomp "
+                                    "(static) rows, slack model, N=30, ONE set of 512 trajectories"),
+    "cfg3_mpcc": dict(dims=dict(N=30, S=5, n_lin=8, M=8, n_slk=12, slack=1), scene=dict(N=30, M=8, slack=True, n_decomp=12), traj=512, nh=28, npar=172,
+                      one_set=True, what="the rosnavigation T-MPC stack (MPCC contouring instead of the curvature-aware cost; rounds 1-3 ran configs[2] as this), "
+                                         "slack model + guidance + 8 ellipsoids + 12 decomp rows, N=30, ONE set of 512 trajectories"),
     "cfg4": dict(dims=dict(N=20, S=5, n_lin=12, M=12), scene=dict(N=20, M=12), traj=4096, nh=24, npar=175, one_set=True,
                  what="configs[3]: T-MPC++ 4096 guidance trajectories, N=20, 12 obstacles, ONE guidance set split over the ranks"),
     "cfg5": dict(dims=dict(N=20, S=5, n_lin=0, M=0, n_slk=24, slack=1), scene=dict(N=20, M=8, slack=True, n_scenario=24), traj=32, nh=24,
-                 npar=127, one_set=True, what="configs[4]: SH-MPC, 8 obstacles x 256 scenarios -> 24 halfspaces, 32 scenario solvers split over the ranks"),
+                 npar=127, one_set=True, scenario=dict(n_obstacles=8, n_scenarios=256, n_rows=24),
+                 what="configs[4]: SH-MPC, per step: every scenario solver samples 8 obstacles x 256 scenarios on device (tmpc_sample_scenarios), reduces them to "
+                      "24 halfspaces per stage (tmpc_scenario_halfspaces), solves, counts its support (tmpc_scenario_support); 32 scenario solvers split over the ranks"),
 }
 
 
@@ -145,6 +151,43 @@ def parity_block(O, wl, batch, res, n_check, opts):
             "against": "oracle/ (restated acados-equivalent CPU path), same options"}
 
 
+def best_index_block(O, wl, batch, res, best, set_size, max_sets):
+    """FindBestPlanner per set of the timed launch: the device's index against (i) the reference's rule (strict '<', lowest index, init
+    1e10: orc_find_best) applied to the DEVICE's objectives -- integer work, must be 0 mismatches -- and (ii) the index the ORACLE picks from
+    its own solves of the same sets.  (ii) can differ without either being wrong: guidance trajectories that reach the same optimum have
+    objectives that tie to rounding, and then the lowest index among the tied ones is decided by the last bits; such cases are counted as
+    ties (|objective difference| <= 1e-9 relative), anything else as a true mismatch."""
+    B = batch["xinit"].shape[0]
+    n_sets = min(B // set_size, max_sets)
+    which = np.unique(np.linspace(0, B // set_size - 1, n_sets).round().astype(int))
+    idx = (which[:, None] * set_size + np.arange(set_size)[None, :]).ravel()
+    n = len(idx)
+    pbo = O.problem(**wl["dims"])
+    _, _, info = O.solve_batch(pbo, batch["xinit"][idx], batch["x0"][idx].reshape(n, -1), batch["params"][idx].reshape(n, -1), num_threads=usable_cpus())
+    mism_rule = mism_oracle = ties = 0
+    worst = 0.0
+    for j, sset in enumerate(which):
+        sl = slice(j * set_size, (j + 1) * set_size)
+        dsl = slice(sset * set_size, (sset + 1) * set_size)
+        dev_best = int(best[sset])                                                     # (index inside the set, -1: no successful trajectory)
+        rule = O.find_best(res["pobj"][dsl], res["exit_code"][dsl])
+        ref = O.find_best(info["pobj"][sl], info["exit_code"][sl])
+        mism_rule += int(dev_best != rule)
+        if dev_best != ref:
+            mism_oracle += 1
+            if dev_best >= 0 and ref >= 0:
+                a, b = float(res["pobj"][dsl][dev_best]), float(info["pobj"][sl][ref])
+                rel = abs(a - b) / max(1.0, abs(b))
+                worst = max(worst, rel)
+                ties += int(rel <= 1e-9)
+    return {"sets_checked": int(len(which)), "set_size": int(set_size), "trajectories_solved_by_the_oracle": int(n),
+            "best_index_mismatch_vs_rule_on_device_objectives": mism_rule,
+            "best_index_mismatch_vs_oracle": mism_oracle, "of_which_objective_ties_at_rounding": ties,
+            "true_mismatches": mism_oracle - ties, "worst_relative_objective_gap_among_mismatches": worst,
+            "what": "device FindBestPlanner index per set vs orc_find_best on the device's objectives (integer work: must be 0) and vs the index the oracle "
+                    "picks from its own solves (ties at rounding counted separately)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -154,7 +197,11 @@ def main():
                     help="scenes (control ticks) per launch per GPU; 512 x 64 = 32768 trajectories keep the tail of uneven solve "
                          "times small (256 scenes: 497k solves/s, 1024: 514k, 2048: 516k on one MI355X)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cfg2")
-    ap.add_argument("--no-lanes", action="store_true", help="skip the lane-per-trajectory variant's measurement")
+    ap.add_argument("--lanes", action="store_true", help="also measure the lane-per-trajectory variant (tmpc_set_throughput_mode; loses on every shape, "
+                                                        "round 2 -- out of the default run since round 4)")
+    ap.add_argument("--no-lanes", action="store_true", help="(accepted for old command lines; the lanes leg is off unless --lanes)")
+    ap.add_argument("--index-check-sets", type=int, default=512,
+                    help="sets of the timed launch whose FindBestPlanner index is compared with the oracle's pick after timing (0 = skip)")
     ap.add_argument("--no-tight", action="store_true", help="skip the qp_tol = 1e-9 leg")
     ap.add_argument("--share-of", type=int, default=0,
                     help="one-set workloads on ONE GPU: solve rank 0's share of a split over this many ranks (what one GPU of such a node "
@@ -238,13 +285,34 @@ def main():
         share_map = solver.param_sharing_map(batch["params"], dims, traj_local)
         sv.set_param_sharing(share_map)
 
+    # SH-MPC (cfg 5): the scenario pipeline runs inside the timed step -- every scenario solver draws its own 8 x 256 scenarios from the
+    # obstacles' Gaussian-mixture predictions (new seed every step), builds its <= 24 halfspaces per stage around its warm start and, after
+    # the solve, counts the support of its solution; all on the handle's stream, no host synchronisation
+    scn = None
+    if wl.get("scenario"):
+        sk = wl["scenario"]
+        Mo, Sc, Rr = sk["n_obstacles"], sk["n_scenarios"], sk["n_rows"]
+        pred = np.repeat(scenes.mixture_prediction(full["obstacles"]["pos"], 0)[None], B, 0)          # [P][M][3][N][6]: every solver sees the same prediction
+        prob = np.tile(scenes.MIXTURE_WEIGHTS, (B, Mo, 1))
+        scn = dict(pred=torch.from_numpy(pred).to(dev), prob=torch.from_numpy(prob).to(dev), Mo=Mo, Sc=Sc, Rr=Rr,
+                   samples=torch.empty((B, dims.N, Mo * Sc, 2), dtype=torch.float64, device=dev),
+                   scene_of=torch.arange(B, dtype=torch.int32, device=dev), state_x=torch.from_numpy(np.ascontiguousarray(batch["xinit"][:, 0])).to(dev),
+                   support=torch.zeros((2, B), dtype=torch.int32, device=dev), radius=scenes.OBSTACLE_RADIUS + scenes.ROBOT_RADIUS, n=0)
+        torch.cuda.synchronize()
+
     # The whole step is stream-ordered on the handle's stream: solve -> pack -> (N > 1: the all-gather, issued with that stream as
     # torch's current stream, so RCCL waits for the records and the selection waits for RCCL) -> FindBestPlanner.  No host
     # synchronisation inside a step.
     ext_stream = torch.cuda.ExternalStream(sv.stream_ptr(), device=dev) if use_dist else None
 
     def step():
+        if scn is not None:
+            scn["n"] += 1
+            sv.sample_scenarios(scn["pred"].data_ptr(), scn["prob"].data_ptr(), B, scn["Mo"], 3, scn["Sc"], 1000 + 131 * rank + scn["n"], scn["samples"].data_ptr())
+            sv.scenario_halfspaces(scn["samples"].data_ptr(), scn["Mo"] * scn["Sc"], scn["Rr"], scn["scene_of"].data_ptr(), scn["state_x"].data_ptr(), scn["radius"])
         sv.solve(sync=False)                                                # the dominant kernel
+        if scn is not None:
+            sv.scenario_support_async(scn["Sc"], 1e-6, scn["support"][0].data_ptr(), scn["support"][1].data_ptr())
         sv.pack_records(t_rec.data_ptr(), t_gid.data_ptr())
         if use_dist:
             with torch.cuda.stream(ext_stream):
@@ -278,7 +346,16 @@ def main():
     res = sv.get()
     best = t_best.cpu().numpy()
     ok = res["exit_code"] == 1
-    full = res["sqp_iter"] == dims.n_sqp
+    full_iter = res["sqp_iter"] == dims.n_sqp
+    scenario_info = None
+    if scn is not None:
+        # the rows the last step built on device are what its solve saw: the parity block below re-solves exactly those
+        batch = dict(batch, params=sv.debug_get_params())
+        sup = scn["support"].cpu().numpy()
+        scenario_info = {"pipeline_in_timed_step": ["tmpc_sample_scenarios", "tmpc_scenario_halfspaces", "tmpc_solve", "tmpc_scenario_support", "tmpc_pack_records", "tmpc_select_best_records"],
+                         "scenarios_per_solver_per_stage": scn["Mo"] * scn["Sc"], "rows_per_stage": scn["Rr"], "support_mean": float(sup[0][ok].mean()) if ok.any() else None,
+                         "support_max": int(sup[0][ok].max()) if ok.any() else None, "empty_polygon_stages": int(sv.scenario_empty_stages().sum()),
+                         "new_scenarios_every_step": True}
 
     # ---- parity spot check of THIS launch against the CPU oracle (outside the timed region; rank 0) ---------------------
     parity = None
@@ -286,6 +363,8 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib as O
         parity = parity_block(O, wl, batch, res, a.parity_check, {})
+        if a.index_check_sets > 0 and not use_dist:
+            parity["best_index"] = best_index_block(O, wl, batch, res, best, traj_local, a.index_check_sets)
     n_sqp_mean = float(res["sqp_iter"].mean())
     ipm_per_qp = float(res["qp_iter_total"].sum() / max(res["sqp_iter"].sum(), 1))
 
@@ -309,7 +388,7 @@ def main():
     # ---- p50 latency of one control tick (64 trajectories, host call -> best index on host) --------------
     lat = None
     lanes = None
-    if rank == 0 and not a.no_lanes and not use_dist:
+    if rank == 0 and a.lanes and not use_dist and not dims.cost_model:
         # the lane-per-trajectory variant (tmpc_set_throughput_mode) on the same resident batch: the measured alternative design
         sv.set_throughput_mode(True)
         sv.solve(); sv.solve(sync=False)
@@ -426,13 +505,14 @@ def main():
                          "hbm": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": gbs / HBM_PEAK_GBS, "bytes_per_solve": by}},
             "success_solves_per_s": value, "attempted_solves_per_s": attempted,
-            "value_all_10_iter": attempted * float(full.mean()),
+            "value_all_10_iter": attempted * float(full_iter.mean()),
             "parity": parity,
             "value_qp_tol_1e_9": tight["value"] if tight else None,
             "qp_tol_1e_9": tight,
             "lanes_variant": lanes,
             "latency_b64": lat,
             "best_index_sample": best[:4].tolist(),
+            "scenario_pipeline": scenario_info,
         }
         if not a.no_cpu_baseline and world == 1:                      # reported baseline: rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(a.cpu_scenes)

@@ -67,6 +67,9 @@ typedef struct tmpc_dims {
     int32_t n_slk;        /* decomp / scenario halfspace rows a1 x + a2 y - (b + slack) <= 0 per stage
                              (decomp_constraints.py:68-98, scenario_constraints.py:64-94); scenario rows first */
     int32_t slack;        /* 1: slack model (nx = 6, nvar = 8; MPCBase weighs the slack state) */
+    int32_t cost_model;   /* 0: ContouringModule (MPCC: contouring.py:48-98); 1: CurvatureAwareContouringModule (CA-MPC:
+                             curvature_aware_contouring.py:48-105; same parameter map, spline ODE s' = v -- BASELINE configs[2]).  Set by
+                             tmpc_default_dims* to 0.  Hand-written kernels only (a generated solver's cost is its module stack's). */
 } tmpc_dims;
 
 typedef struct tmpc_handle tmpc_handle;
@@ -141,6 +144,9 @@ int tmpc_set_slots(tmpc_handle *h, const int32_t *slots);
 int tmpc_set_param_sharing(tmpc_handle *h, const int32_t *base_of);
 /* Copy the persistent state of min(B_max) slots from another handle of the same shape and device (a caller that outgrew its handle). */
 int tmpc_copy_state(tmpc_handle *dst, tmpc_handle *src);
+/* Forget the persistent state of ONE slot: its next tmpc_solve_iterations starts like a fresh capsule whatever the keep-flags say
+ * (a caller that hands the slot of a destroyed Solver to a new one: a new acados capsule, acados_solver_interface.cpp:17-33). */
+int tmpc_clear_slot(tmpc_handle *h, int32_t slot);
 /* Zero the multipliers of every slot (a new capsule / Solver_acados_reset). */
 int tmpc_reset_multipliers(tmpc_handle *h);
 /* Kernel variant for the following tmpc_solve calls: 0 (default) = throughput variant, 1 = latency variant (two waves per

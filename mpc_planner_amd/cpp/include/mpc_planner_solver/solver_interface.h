@@ -100,6 +100,8 @@ namespace MPCPlanner
         bool _warmstart_pending{true};          // loadWarmstart() since the last iteration: the next one starts from _params.x0
         bool _new_solve{true};                  // initializeOneIteration() since the last iteration: the next one opens a new solve (TMPC_ITER_NEW_SOLVE)
         int _iterations_done{0};                // RTI iterations since initializeOneIteration
+        std::vector<BatchContext *> _contexts;  // contexts this Solver owns a slot of: ~Solver releases the slots (a new Solver at the same
+                                                // address must not inherit this one's multipliers)
         double _iteration_time_estimate{0.};
         void ensureHandle();
         int runIterations(int n, bool complete);
@@ -181,7 +183,7 @@ namespace MPCPlanner
         std::vector<int> solve(const std::vector<Solver *> &solvers);
         int slotOf(const Solver *s) const { auto it = _slot.find(s); return it == _slot.end() ? -1 : it->second; }
         int capacity() const { return _capacity; }
-        void forget(const Solver *s) { _slot.erase(s); }              // a Solver that is destroyed while the context lives
+        void forget(const Solver *s);                                 // a Solver that is destroyed while the context lives (~Solver calls it): its slot is cleared and reused
         double lastLaunchSeconds() const { return _last_launch_s; }
 
     private:
@@ -190,6 +192,8 @@ namespace MPCPlanner
         int _capacity{0}, _device{-1}, _iterations{-1}, _next_slot{0};
         double _dt{0.}, _last_launch_s{0.};
         std::map<const Solver *, int> _slot;
+        std::vector<int> _free_slots;           // slots of forgotten Solvers, cleared (tmpc_clear_slot) before they are handed out again
+        int takeSlot();
     };
 }
 #endif

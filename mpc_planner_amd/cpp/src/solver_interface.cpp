@@ -11,15 +11,22 @@
 #include <mutex>
 #include <sstream>
 
+#ifndef SOLVER_COST_MODEL      // (dims headers written before round 4)
+#define SOLVER_COST_MODEL 0
+#endif
+
 namespace MPCPlanner
 {
-    /* Kernel variant of a control tick (tmpc_set_latency_mode): 1 = two waves per trajectory with the same stage-by-stage Riccati
-     * recursion as acados / HPIPM (default: rounding-equal to the throughput kernels); MPC_PLANNER_HIP_TICK_VARIANT=2 selects the
-     * parallel-in-time Newton solve (about 30 % less kernel time per tick; steps equal to ~1e-6, see include/tmpc_hip.h). */
+    /* Kernel variant of a control tick (tmpc_set_latency_mode).  Default (round 4): 2 = the interior-point Newton systems solved parallel in
+     * time (about 30 % less kernel time per tick; exit codes and iteration counts equal to the oracle's on every set tried, steps equal to
+     * ~1e-6, see include/tmpc_hip.h; shapes without that variant run variant 1).  MPC_PLANNER_HIP_TICK_VARIANT=1 opts out: two waves per
+     * trajectory with the same stage-by-stage Riccati recursion as acados / HPIPM (rounding-equal to the throughput kernels); =0 the
+     * throughput kernels themselves. */
     static int tickKernelVariant()
     {
         const char *v = std::getenv("MPC_PLANNER_HIP_TICK_VARIANT");
-        return (v && std::atoi(v) == 2) ? 2 : 1;
+        if (v && (v[0] == '0' || v[0] == '1' || v[0] == '2') && v[1] == '\0') return v[0] - '0';
+        return 2;
     }
 
     static std::string g_config_dir = "config";
@@ -124,7 +131,12 @@ namespace MPCPlanner
         }
         reset();
     }
-    Solver::~Solver() { if (_handle) tmpc_destroy(_handle); }
+    Solver::~Solver()
+    {
+        const std::vector<BatchContext *> ctxs = _contexts;      // (forget() edits _contexts)
+        for (BatchContext *c : ctxs) c->forget(this);
+        if (_handle) tmpc_destroy(_handle);
+    }
 
     // model_map.yaml -> tmpc_dims bounds.  The slack model's map has one more entry (`slack: [x, 7, 0, 5000]`,
     // solver_model.py:281-298) than tmpc_dims::lb/ub hold (TMPC_NV = 7): acados pins that state (DESIGN U9), it needs no bounds.
@@ -143,7 +155,7 @@ namespace MPCPlanner
         if (_handle) return;
         tmpc_dims d;
         tmpc_default_dims_ex(&d, SOLVER_N, SOLVER_S, SOLVER_NLIN, SOLVER_M, SOLVER_NSLK, SOLVER_SLACK);
-        d.n_sqp = _num_iterations; d.dt = dt;
+        d.n_sqp = _num_iterations; d.dt = dt; d.cost_model = SOLVER_COST_MODEL;
         applyModelBounds(d, _model_map);
         int status = tmpc_create(&_handle, &d, 1, _device);
         if (status) {                                   // reference: exit(1) when the capsule cannot be created (:35-39)
@@ -237,7 +249,32 @@ namespace MPCPlanner
         _info.min_time = std::min(per_iteration, _info.min_time);
     }
 
-    BatchContext::~BatchContext() { if (_handle) tmpc_destroy(_handle); }
+    BatchContext::~BatchContext()
+    {
+        for (auto &e : _slot) {                                  // the Solvers outlive the context: they must not call back into it
+            auto &cs = const_cast<Solver *>(e.first)->_contexts;
+            cs.erase(std::remove(cs.begin(), cs.end(), this), cs.end());
+        }
+        if (_handle) tmpc_destroy(_handle);
+    }
+    // A forgotten Solver's slot goes back to the pool; it is cleared (tmpc_clear_slot: the slot's next launch starts like a new capsule)
+    // before it is handed to another Solver, so neither a new Solver at the same address nor the next owner inherits multipliers.
+    void BatchContext::forget(const Solver *s)
+    {
+        auto it = _slot.find(s);
+        if (it == _slot.end()) return;
+        _free_slots.push_back(it->second);
+        _slot.erase(it);
+        auto &cs = const_cast<Solver *>(s)->_contexts;
+        cs.erase(std::remove(cs.begin(), cs.end(), this), cs.end());
+    }
+    int BatchContext::takeSlot()
+    {
+        if (_free_slots.empty()) return _next_slot++;
+        const int slot = _free_slots.back(); _free_slots.pop_back();
+        if (_handle && tmpc_clear_slot(_handle, slot)) { std::fprintf(stderr, "tmpc_clear_slot: %s\n", tmpc_last_error(_handle)); std::exit(1); }
+        return slot;
+    }
 
     // (re)create the handle when the solver settings change, grow it (keeping every slot's state) when more Solvers appear than it holds
     void BatchContext::ensure(const Solver *s0, int needed_slots)
@@ -246,7 +283,7 @@ namespace MPCPlanner
         if (_handle && !settings_changed && needed_slots <= _capacity) return;
         const int cap = settings_changed ? std::max(_capacity, needed_slots) : std::max(8, 2 * needed_slots);
         tmpc_dims d; tmpc_default_dims_ex(&d, SOLVER_N, SOLVER_S, SOLVER_NLIN, SOLVER_M, SOLVER_NSLK, SOLVER_SLACK);
-        d.n_sqp = s0->_num_iterations; d.dt = s0->dt;
+        d.n_sqp = s0->_num_iterations; d.dt = s0->dt; d.cost_model = SOLVER_COST_MODEL;
         applyModelBounds(d, s0->_model_map);
         tmpc_handle *h = nullptr;
         if (tmpc_create(&h, &d, cap, s0->_device)) { std::printf("tmpc_create() failed. Exiting.\n"); std::exit(1); }
@@ -254,22 +291,39 @@ namespace MPCPlanner
         tmpc_enable_timing(h, 4);
         if (_handle) {
             if (!settings_changed && tmpc_copy_state(h, _handle)) { std::fprintf(stderr, "tmpc_copy_state: %s\n", tmpc_last_error(h)); std::exit(1); }
-            if (settings_changed) { _slot.clear(); _next_slot = 0; }      // other iteration budget / dt / device: a different solver, nothing to carry over
+            if (settings_changed) {                                       // other iteration budget / dt / device: a different solver, nothing to carry over
+                for (auto &e : _slot) { auto &cs = const_cast<Solver *>(e.first)->_contexts; cs.erase(std::remove(cs.begin(), cs.end(), this), cs.end()); }
+                _slot.clear(); _free_slots.clear(); _next_slot = 0;
+            }
             tmpc_destroy(_handle);
         }
         _handle = h; _capacity = cap; _device = s0->_device; _iterations = s0->_num_iterations; _dt = s0->dt;
     }
 
-    std::vector<int> BatchContext::solve(const std::vector<Solver *> &solvers)
+    std::vector<int> BatchContext::solve(const std::vector<Solver *> &solvers_in)
     {
+        std::vector<int> codes_in(solvers_in.size(), 0);
+        if (solvers_in.empty()) return codes_in;
+        // a Solver named twice is solved once (one capsule, one slot); every mention gets its exit code
+        std::vector<Solver *> solvers;
+        std::vector<int> first_of(solvers_in.size());
+        {
+            std::map<const Solver *, int> seen;
+            for (size_t i = 0; i < solvers_in.size(); i++) {
+                auto it = seen.find(solvers_in[i]);
+                if (it == seen.end()) { seen[solvers_in[i]] = (int)solvers.size(); first_of[i] = (int)solvers.size(); solvers.push_back(solvers_in[i]); }
+                else first_of[i] = it->second;
+            }
+        }
         const int B = (int)solvers.size();
         std::vector<int> codes(B, 0);
-        if (B == 0) return codes;
         Solver *s0 = solvers[0];
-        int known = _next_slot;
-        for (Solver *s : solvers) if (!_slot.count(s)) known++;
-        ensure(s0, known);
-        for (Solver *s : solvers) if (!_slot.count(s)) _slot[s] = _next_slot++;      // (slots are never reused: a forgotten Solver's state is not inherited)
+        int fresh = 0;
+        for (Solver *s : solvers) if (!_slot.count(s)) fresh++;
+        const int from_pool = std::min(fresh, (int)_free_slots.size());
+        ensure(s0, _next_slot + fresh - from_pool);
+        for (Solver *s : solvers)
+            if (!_slot.count(s)) { _slot[s] = takeSlot(); s->_contexts.push_back(this); }   // (a reused slot was cleared: the previous owner's state is not inherited)
         const size_t n0 = (SOLVER_NU + SOLVER_NX) * (SOLVER_N + 1), np = (size_t)SOLVER_NP * SOLVER_N;
         std::vector<double> xinit((size_t)B * SOLVER_NX), x0(B * n0), par(B * np);
         std::vector<int32_t> slots(B);
@@ -301,7 +355,8 @@ namespace MPCPlanner
             s->recordTiming(_last_launch_s, s0->_num_iterations);      // (the batch is one launch: every Solver of it sees that launch's time)
             s->_exit_code_one_iter = ec[b]; codes[b] = ec[b];
         }
-        return codes;
+        for (size_t i = 0; i < solvers_in.size(); i++) codes_in[i] = codes[first_of[i]];
+        return codes_in;
     }
 
     // ---- parameters / xinit / warm start / output: host-only, identical index arithmetic (:206-389) ----

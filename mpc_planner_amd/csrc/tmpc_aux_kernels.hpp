@@ -732,14 +732,26 @@ __global__ void tmpc_debug_eval_kernel(Dims d, int n, const double *z, const dou
     const double slack = d.slack ? ze[NV] : 0.0;
     // rows are reported in the reference's order [topology | ellipsoids | slack rows] (module order)
     auto ext = [&](int r) { return r < d.n_lin ? r : (r < d.n_up ? d.M + r : r - d.n_slk); };
-    CostOut co;
-    cost_eval(d, zz, pe, 1, co, true, slack);
-    cost[e] = co.val;
-    double Wc[NV][NV];
+    double Wc[NV][NV], cg[NV];
     for (int i = 0; i < NV; i++) for (int j = 0; j < NV; j++) Wc[i][j] = 0.0;
-    cost_add_hessian(co, 1.0, Wc);
+#ifndef TMPC_GENERATED_STAGE
+    if (d.cost_model == 1) {
+        CostOutCA co;
+        cost_eval_ca(d, zz, pe, 1, co, true, slack);
+        cost[e] = co.val;
+        cost_add_hessian_ca(co, 1.0, Wc);
+        for (int i = 0; i < NV; i++) cg[i] = co.g[i];
+    } else
+#endif
+    {
+        CostOut co;
+        cost_eval(d, zz, pe, 1, co, true, slack);
+        cost[e] = co.val;
+        cost_add_hessian(co, 1.0, Wc);
+        for (int i = 0; i < NV; i++) cg[i] = co.g[i];
+    }
     for (int i = 0; i < NV; i++) {
-        cgrad[(size_t)e * NV + i] = co.g[i];
+        cgrad[(size_t)e * NV + i] = cg[i];
         for (int j = 0; j < NV; j++) chess[(size_t)e * NV * NV + i * NV + j] = Wc[i][j];
     }
     double W[NV][NV], g[NV], BA[NX * NV], xn[NX];
@@ -750,6 +762,10 @@ __global__ void tmpc_debug_eval_kernel(Dims d, int n, const double *z, const dou
         for (int i = 0; i < NV; i++) J[i] = 0.0;
         J[ZX] = ro.gx; J[ZY] = ro.gy; J[ZPSI] = ro.gp;
     };
+#ifndef TMPC_GENERATED_STAGE
+    if (d.cost_model == 1) stage_linearise<1>(d, zz, pe, 1, pi ? pi[(size_t)e * NX] : 0.0, pi ? pi[(size_t)e * NX + 1] : 0.0, lam, sink, W, g, BA, xn, slack);
+    else
+#endif
     stage_linearise(d, zz, pe, 1, pi ? pi[(size_t)e * NX] : 0.0, pi ? pi[(size_t)e * NX + 1] : 0.0, lam, sink, W, g, BA, xn, slack);
     for (int i = 0; i < NX; i++) xnext[(size_t)e * NX + i] = xn[i];
     for (int i = 0; i < NX * NV; i++) xjac[(size_t)e * NX * NV + i] = BA[i];

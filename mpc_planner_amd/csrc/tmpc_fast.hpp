@@ -99,10 +99,11 @@ __device__ __forceinline__ double rcp_nr(double x)
 
 __device__ __forceinline__ void lds_add(double *p, double v) { atomicAdd(p, v); }   // ds_add_f64
 
-// ---- teams --------------------------------------------------------------------------------------------------------------
-// How one interior-point solve relates to the other trajectories of its workgroup.  Solo: there are none (fast and compact
-// kernels: a workgroup is one trajectory).  Team<NQ> (further down): NQ trajectories, one per wave, whose Riccati sweeps run
-// together in one wave, one 16-lane row each.
+// ---- Newton-solve policies ------------------------------------------------------------------------------------------------
+// How ipm_fast solves the interior-point Newton systems (and synchronises around them).  Solo: the sequential square-root Riccati
+// recursion (tmpc_riccati.hpp).  ScanSoloT (below): the parallel-in-time solve (tmpc_scan.hpp).  (Round 3 also had a Team<NQ> policy
+// -- several trajectories' sweeps packed into one wave -- measured 4-8 % slower and removed: profiles/round3_b_team_kernels_rejected.json,
+// HISTORY.md.)
 struct Solo {
     static constexpr int NQ = 1;
     __device__ __forceinline__ bool alive() const { return true; }
@@ -161,11 +162,7 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
     constexpr int NT = NTH;                         // threads per trajectory: 64 (one wave) or 128 (two waves; N > 21)
     using C = FastCfg<NLIN, MM, LPS>;
     constexpr int RPL = C::RPL;
-#ifdef TMPC_EXP_FASTDIET                            // experiment: the register diet in the fast-layout kernels too (A/B of the diet alone)
-    constexpr bool OCC2 = true;
-#else
     constexpr bool OCC2 = CP;                       // compact instantiations are built for two waves per SIMD (<= 256 registers)
-#endif
     // compile-time constants for the tuned shapes, kernel arguments for runtime-shape instantiations
     const int NH = C::RT ? L.nh : C::NH, NR = NH + 14, NLIN_ = C::RT ? d.n_up : NLIN;
     constexpr bool DIET = (LPS == 6 && NLIN == 8) || OCC2;                // 256-register budget (two waves per SIMD): recompute per-row values instead of storing them
@@ -560,7 +557,7 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
 
 // Two-wave instantiations with 6 lanes per stage are built for two waves per SIMD (<= 256 registers): four trajectories
 // per CU stay resident with two waves each.  The build refuses any instantiation that needs scratch.
-template <int NLIN, int MM, int LPS, int NTH = 64, bool PROF = false, typename TEAM = Solo>
+template <int NLIN, int MM, int LPS, int NTH = 64, bool PROF = false, typename TEAM = Solo, int CM = 0>
 __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu((NTH == 128 && LPS == 6 && NLIN == 8 && !PROF && std::is_same<TEAM, Solo>::value) ? 2 : 1,
                                                                     (NTH == 128 && LPS == 6 && NLIN == 8 && !PROF && std::is_same<TEAM, Solo>::value) ? 2 : 1)))
 void tmpc_solve_fast_kernel(Dims d, int B, const double *__restrict__ xinit,
@@ -607,7 +604,7 @@ void tmpc_solve_fast_kernel(Dims d, int B, const double *__restrict__ xinit,
     double lam[C::RPL];
     for (int it = 0; it < d.n_sqp; it++) {
         pf.start();
-        linearise<true, false, NTH>(L, d, tid, pb, slack_of(), pb_own);
+        linearise<true, false, NTH, CM>(L, d, tid, pb, slack_of(), pb_own);
         __syncthreads();
         pf.stop(PH_LIN);
         int iters = 0;
@@ -646,8 +643,8 @@ void tmpc_solve_fast_kernel(Dims d, int B, const double *__restrict__ xinit,
         for (int e = tid; e < N * NHk; e += NT) io.lamh[(size_t)slot_of(io, b) * N * NHk + e] = L.lamh[e];
         if (tid == 0) { if (sqp_iter > 0) io.stopped[slot_of(io, b)] = qp_status != 0; io.valid[slot_of(io, b)] = 1; }
     }
-    solve_epilogue(L, d, tid, b, xi, pb, slack_of(), status, qp_status, sqp_iter, qp_iter_total, xtraj, utraj, pobj, exit_code,
-                   qp_status_out, sqp_iter_out, res_eq_out, qp_iter_out, prof_out, pf, t_begin, NTH);
+    solve_epilogue<CM>(L, d, tid, b, xi, pb, slack_of(), status, qp_status, sqp_iter, qp_iter_total, xtraj, utraj, pobj, exit_code,
+                       qp_status_out, sqp_iter_out, res_eq_out, qp_iter_out, prof_out, pf, t_begin, NTH);
 }
 
 // ---- compact kernel: eight trajectories per CU ---------------------------------------------------------------------------
@@ -754,195 +751,5 @@ void tmpc_solve_compact_kernel(Dims d, int B, const double *__restrict__ xinit,
         __syncthreads();                                // the next trajectory reuses LDS and the workspace
     }
 }
-
-#ifdef TMPC_TEAM_KERNELS
-// ---- team kernel: NQ trajectories per workgroup, their Riccati sweeps packed into one wave ------------------------------------
-// MEASURED AND REJECTED (round 3, profiles/round3_b_team_kernels_rejected.json): correct (bitwise the compact kernel's results) but
-// 4 % (teams of two) / 8 % (teams of four) SLOWER than the compact kernel -- at eight trajectories per CU the solve is bound by the
-// latency of each trajectory's own Riccati chain, which a team does not shorten, while lock step and the barriers add to it.  Kept as
-// an experiment build (-DTMPC_TEAM_KERNELS, TMPC_TEAM=2|4); the row-based sweeps it needed are what all kernels use now.
-// The sequential sweeps use 7 lanes of a wave; all their cross-lane traffic is row-local (tmpc_riccati.hpp), so one wave can sweep
-// for up to four trajectories at once, one 16-lane row each -- the same instruction stream, a quarter of the issue slots per
-// trajectory.  A workgroup is NQ waves = NQ trajectories in the compact layout (NQ LDS regions); every wave runs the stage-parallel
-// phases of its own trajectory exactly as the compact kernel does, and at the three sequential phases of an interior-point
-// iteration (factorisation, predictor and corrector sweeps) the team meets at a barrier and ONE wave (rotating, so that the
-// sequential work spreads over the SIMDs) sweeps all rows.  The price is lock step: the team iterates until its slowest member's QP
-// has converged (+11 % interior-point iterations on the bench scenes for adjacent trajectories, teams of four).  Arithmetic per
-// trajectory is that of the compact kernel: results are bitwise identical to it.
-__device__ __forceinline__ void wave_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");        // (no barrier: one wave; LDS / memory operations of a wave are in order,
-    __builtin_amdgcn_wave_barrier();                              //  the fences drain them and pin the compiler's ordering)
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-template <int NQ_>
-struct Team {
-    static constexpr int NQ = NQ_;
-    int w;                      // wave in the workgroup (= trajectory slot); wave-uniform
-    int *flags;                 // LDS: [0, NQ) "still iterating" votes, [NQ, 2 NQ) factorisation failed
-    double *smem0;              // LDS base; trajectory q's region starts at smem0 + q * region
-    int region;
-    double *ws;                 // (any workspace pointer: the sweeps do not touch the global part of a view)
-    bool live;                  // this wave's trajectory takes part in the current QP
-    __device__ __forceinline__ bool alive() const { return live; }
-    __device__ __forceinline__ void sync() const { wave_sync(); }
-    // lane in the wave, re-derived (opaquely) wherever it is needed instead of being kept in a register across the client phases
-    __device__ __forceinline__ static int lane_now() { int l = threadIdx.x & 63; asm volatile("" : "+v"(l)); return l; }
-    __device__ __forceinline__ bool any(bool active) const
-    {
-        if (lane_now() == 0) flags[w] = active ? 1 : 0;
-        __syncthreads();
-        int r = 0;
-#pragma unroll
-        for (int q = 0; q < NQ; q++) r |= flags[q];
-        return r != 0;
-    }
-    // the sweeping wave's view of the trajectory in this lane's row (lane >> 4): LDS view, lane index in the row, stores enabled
-    __device__ __forceinline__ Lds row_view(const Dims &d, int *li, bool *wr) const
-    {
-        const int lane = lane_now(), row = lane >> 4;
-        *wr = row < NQ && flags[row < NQ ? row : 0] != 0;         // the row's trajectory voted "iterating" this iteration
-        *li = row < NQ ? (lane & 15) : 16;
-        return carve_compact(smem0 + (row < NQ ? row : 0) * region, ws, d);
-    }
-    template <int NTH, bool CP>
-    __device__ __forceinline__ bool factor(const Lds &, const Dims &d, int, int, int it) const
-    {
-        if (w == (3 * it) % NQ) {
-            int li; bool wr;
-            const Lds Lrow = row_view(d, &li, &wr);
-            const bool bad = riccati_factor_rows<CP, true>(Lrow, d, li, wr);
-            const unsigned long long m = __ballot(bad && wr);
-            const int lane = lane_now();
-            if (lane < NQ) flags[NQ + lane] = ((m >> (16 * lane)) & 0xffffull) ? 1 : 0;
-        }
-        __syncthreads();
-        return flags[NQ + w] != 0;
-    }
-    template <int NTH, bool CP>
-    __device__ __forceinline__ void solve(const Lds &L, const Dims &d, int tl, int, int it, int phase, bool active) const
-    {
-        if (active && phase != 1) riccati_solve_pre(L, d, tl, 64);
-        __syncthreads();
-        if (w == (3 * it + phase) % NQ) {
-            int li; bool wr;
-            const Lds Lrow = row_view(d, &li, &wr);
-            if (phase == 1) riccati_sweeps_rows<CP, false>(Lrow, d, li, wr, true, [] {});
-            else riccati_sweeps_rows<CP, true>(Lrow, d, li, wr, true, [] { wave_sync(); });
-        }
-        __syncthreads();
-        if (active) { if (phase == 1) riccati_solve_post<true>(L, d, tl, 64); else riccati_solve_post<false>(L, d, tl, 64); }
-        wave_sync();
-    }
-};
-
-template <int NLIN, int MM, int LPS, int NQ>
-__global__ __launch_bounds__(64 * NQ) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void tmpc_solve_team_kernel(Dims d, int B, const double *__restrict__ xinit,
-                            const double *__restrict__ x0, const double *__restrict__ params,
-                            double *__restrict__ xtraj, double *__restrict__ utraj,
-                            double *__restrict__ pobj, int *__restrict__ exit_code,
-                            int *__restrict__ qp_status_out, int *__restrict__ sqp_iter_out,
-                            double *__restrict__ res_eq_out, int *__restrict__ qp_iter_out,
-                            long long *__restrict__ prof_out, StateIO io)
-{
-    using C = FastCfg<NLIN, MM, LPS>;
-    constexpr int NT = 64;
-    const int NHk = C::RT ? d.n_up + d.M : C::NH, NLINk = C::RT ? d.n_up : NLIN;
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;      // (wave-uniform: the own trajectory's view stays in SGPRs)
-    const int N = d.N;
-    int tid = lane;
-    const int region = lds_doubles_compact(N, d.n_lin, d.n_up + d.M);
-    int *flags = (int *)(smem + NQ * region);                    // 2 NQ flags + the team's first ticket
-    double *wsb = io.ws + ((size_t)blockIdx.x * NQ + w) * ws_doubles(N);
-    const Lds L = carve_compact(smem + w * region, wsb, d);
-    ba_tab_init(L.tab, d, tid);
-    if (tid < 3) L.D[N * L.dstride + tid] = 0.0;
-    __syncthreads();
-    Team<NQ> team{w, flags, smem, region, wsb, false};
-    NoProf pf;
-    (void)prof_out;
-    for (;;) {
-        if (threadIdx.x == 0) flags[2 * NQ] = atomicAdd(io.ticket, NQ);
-        __syncthreads();
-        const int b0 = flags[2 * NQ];
-        if (b0 >= B) break;
-        asm volatile("" : "+v"(tid));
-        const bool exists = b0 + w < B;
-        const int b = exists ? b0 + w : B - 1;                     // (a team's spare waves read a valid trajectory and write nothing)
-        const bool did = exists && !((slot_flags(io, b) & ST_KEEP_ITERATE) && io.stopped[slot_of(io, b)]);
-        bool run = did;
-        const double *xi = xinit + (size_t)b * ext_nx(d);
-        const double *pb_own = params + (size_t)b * N * d.npar;
-        const double *pb = params + (size_t)param_base_of(io, b) * N * d.npar;
-        auto slack_of = [&]() { return d.slack ? __builtin_nontemporal_load(xi + NX) : 0.0; };
-
-        for (int e = tid; e < (N + 1) * NV; e += NT) {
-            const int k = e / NV, i = e - k * NV;
-            L.z[e] = (slot_flags(io, b) & ST_KEEP_ITERATE) ? io.z[(size_t)slot_of(io, b) * (N + 1) * NV + e] : x0[((size_t)b * (N + 1) + k) * ext_nv(d) + i];
-        }
-        for (int e = tid; e < (N + 1) * NX; e += NT) L.pi[e] = (slot_flags(io, b) & ST_KEEP_MULTIPLIERS) ? io.pi[(size_t)slot_of(io, b) * (N + 1) * NX + e] : 0.0;
-        for (int e = tid; e < N * NHk; e += NT) L.lamh[e] = (slot_flags(io, b) & ST_KEEP_MULTIPLIERS) ? io.lamh[(size_t)slot_of(io, b) * N * NHk + e] : 0.0;
-        wave_sync();
-        if (tid < NU) L.z[N * NV + tid] = 0.0;
-        wave_sync();
-
-        int status = 0, qp_status = 0, sqp_iter = 0, qp_iter_total = 0;
-        double lam[C::RPL];
-        for (int it = 0; it < d.n_sqp; it++) {
-            if (run) {
-                linearise<true, true>(L, d, tid, pb, slack_of(), pb_own);
-                wave_sync();
-            }
-            int iters = 0;
-            team.live = run;
-            const int qs = ipm_fast<NLIN, MM, LPS, 64, true>(L, d, tid, xi, &iters, pf, lam, team);
-            if (run) {
-                qp_status = qs;
-                sqp_iter = it + 1; qp_iter_total += iters;
-                if (qp_status != 0 && qp_status != 2) { status = 4; run = false; }
-                else {
-                    status = 0;
-                    wave_sync();
-                    int tid_w = tid;
-                    asm volatile("" : "+v"(tid_w));
-                    for (int e = tid_w; e < (N + 1) * NV; e += NT) {
-                        const int ks = e / NV, i = e - ks * NV;
-                        if (!(ks == N && i < NU)) L.z[e] += L.v[e];
-                    }
-                    for (int e = tid_w; e < N * NX; e += NT) L.pi[NX + e] = L.pq[NX + e];
-                    wave_sync();
-                    constexpr int SPW = 64 / LPS;
-                    const int wl = tid_w & 63;
-                    const int k = wl / LPS, c = wl % LPS;
-                    if (wl < SPW * LPS && k < N) {
-#pragma unroll
-                        for (int s = 0; s < C::RPL; s++) {
-                            const int r = c + LPS * s;
-                            if (r < NHk) L.lamh[k * NHk + r] = (r < NLINk) ? lam[s] : -lam[s];
-                        }
-                    }
-                    wave_sync();
-                    if (qp_status != 0) run = false;
-                }
-            }
-        }
-        asm volatile("" : "+v"(tid));
-        if (did) {
-            if (io.flags & ST_STORE) {
-                for (int e = tid; e < (N + 1) * NV; e += NT) io.z[(size_t)slot_of(io, b) * (N + 1) * NV + e] = L.z[e];
-                for (int e = tid; e < (N + 1) * NX; e += NT) io.pi[(size_t)slot_of(io, b) * (N + 1) * NX + e] = L.pi[e];
-                for (int e = tid; e < N * NHk; e += NT) io.lamh[(size_t)slot_of(io, b) * N * NHk + e] = L.lamh[e];
-                if (tid == 0) { if (sqp_iter > 0) io.stopped[slot_of(io, b)] = qp_status != 0; io.valid[slot_of(io, b)] = 1; }
-            }
-            solve_epilogue(L, d, tid, b, xi, pb, slack_of(), status, qp_status, sqp_iter, qp_iter_total, xtraj, utraj, pobj, exit_code,
-                           qp_status_out, sqp_iter_out, res_eq_out, qp_iter_out, prof_out, pf, 0ll, 64);
-        }
-        __syncthreads();                                // the next team reuses LDS, the workspace and the ticket slot
-    }
-}
-
-#endif  // TMPC_TEAM_KERNELS
 
 }  // namespace tmpc

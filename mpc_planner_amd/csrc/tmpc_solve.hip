@@ -312,9 +312,6 @@ __device__ __forceinline__ double readlane_d(double x, int src)
 // supports).  Unlike v_readlane the value stays in a VGPR: no SGPR-pair operand limit on its consumers, no VALU -> SGPR -> VALU
 // hazard waits, and the four rows of a wave stay independent.  The Riccati sweeps use rows of 16 lanes: lanes 0..6 of row 0
 // hold the trajectory, the other rows compute on copies and are ignored.
-#ifdef TMPC_RICCATI_READLANE            // A/B builds only: the round-2 cross-lane path (v_readlane, wave-uniform values)
-template <int LANE> __device__ __forceinline__ double bcast16(double x) { return readlane_d(x, LANE); }
-#else
 template <int LANE>
 __device__ __forceinline__ double bcast16(double x)
 {
@@ -322,7 +319,6 @@ __device__ __forceinline__ double bcast16(double x)
     const long long r = __builtin_amdgcn_mov_dpp(__builtin_bit_cast(long long, x), 0x150 + LANE, 0xf, 0xf, false);   // (no `old` value to materialise)
     return __builtin_bit_cast(double, r);
 }
-#endif
 // compile-time loop: f(std::integral_constant<int, I>) for I = A .. B-1 (lane numbers of DPP controls must be immediates)
 template <int A, int B, typename F>
 __device__ __forceinline__ void static_for(F &&f)
@@ -585,7 +581,7 @@ __device__ int ipm_solve(const Lds &L, const Dims &d, int tid, int *iters_out, P
 // (rollout with sensitivities, [B A], the multipliers' share of the Hessian) and half of the ellipsoid rows, wave 1 the cost, the halfspace
 // rows and the other ellipsoids -- which run as different code at the same time; the shares of W are exchanged through LDS and the
 // regularisation (MIRROR: more than half of a stage's chain) is shared too.  W = W_0 + W_1 associates differently from the one-wave sum (rounding level).
-template <bool FAST, bool CP = false, int NTH = 64>
+template <bool FAST, bool CP = false, int NTH = 64, int CM = 0>
 __device__ __forceinline__ void linearise(const Lds &L, const Dims &d, int tid, const double *params, double slack, const double *params_own = nullptr)
 {
     const int N = d.N;
@@ -618,7 +614,7 @@ __device__ __forceinline__ void linearise(const Lds &L, const Dims &d, int tid, 
         // bitwise what mirror7 computes.  A coupled W (any cross entry != 0) takes the 7 x 7 iteration on wave 0.
         double *W0s = L.scan + k * NP28;                     // (N * NP28 doubles behind the layout: every two-wave launch allocates them)
         if (wv == 1) {                                       // cost, halfspace rows, second half of the ellipsoid rows
-            stage_linearise(d, z, p, 1, 0.0, 0.0, lamh, sink, W, g, BA, xn, slack, nullptr, own_delta, 2);
+            stage_linearise<CM>(d, z, p, 1, 0.0, 0.0, lamh, sink, W, g, BA, xn, slack, nullptr, own_delta, 2);
             if (owner) {
 #pragma unroll
                 for (int i = 0; i < NV; i++) L.g[k * NV + i] = g[i];
@@ -628,7 +624,7 @@ __device__ __forceinline__ void linearise(const Lds &L, const Dims &d, int tid, 
                     for (int j = 0; j <= i; j++) L.W[k * NP28 + pidx(i, j)] = W[i][j];
             }
         } else {                                             // dynamics, first half of the ellipsoid rows
-            stage_linearise(d, z, p, 1, L.pi[(k + 1) * NX + 0], L.pi[(k + 1) * NX + 1], lamh, sink, W, g, BA, xn, slack, nullptr, own_delta, 1);
+            stage_linearise<CM>(d, z, p, 1, L.pi[(k + 1) * NX + 0], L.pi[(k + 1) * NX + 1], lamh, sink, W, g, BA, xn, slack, nullptr, own_delta, 1);
             if (owner) {
 #pragma unroll
                 for (int i = 0; i < NX * NV; i++) L.BA[k * NX * NV + i] = BA[i];
@@ -744,7 +740,7 @@ __device__ __forceinline__ void linearise(const Lds &L, const Dims &d, int tid, 
                 L.beta[k * nh + r] = bound - ro.h;
             }
         };
-        stage_linearise(d, z, p, 1, L.pi[(k + 1) * NX + 0], L.pi[(k + 1) * NX + 1], lamh, sink, W, g, BA, xn, slack,
+        stage_linearise<CM>(d, z, p, 1, L.pi[(k + 1) * NX + 0], L.pi[(k + 1) * NX + 1], lamh, sink, W, g, BA, xn, slack,
                         L.W + k * NP28, own_delta);         // (generated solvers park the cost Hessian in the stage's W slot)
         // everything but W leaves the registers BEFORE the register-hungry MIRROR
         // compact layout: g, b, W live in the global workspace (same [stage][entry] layout: a lane's stores of one array share
@@ -783,7 +779,7 @@ __device__ __forceinline__ void linearise(const Lds &L, const Dims &d, int tid, 
 }
 
 // ---- completeOneIteration (acados_solver_interface.cpp:162-204): cost, trajectories, res_eq, exit-code mapping ----
-template <typename PF>
+template <int CM = 0, typename PF>
 __device__ __forceinline__ void solve_epilogue(const Lds &L, const Dims &d, int tid, int b, const double *xi, const double *pb, double slack, int status,
                                int qp_status, int sqp_iter, int qp_iter_total, double *xtraj, double *utraj, double *pobj,
                                int *exit_code, int *qp_status_out, int *sqp_iter_out, double *res_eq_out, int *qp_iter_out,
@@ -799,14 +795,18 @@ __device__ __forceinline__ void solve_epilogue(const Lds &L, const Dims &d, int 
         double z[NV];
 #pragma unroll
         for (int i = 0; i < NV; i++) z[i] = L.z[ks * NV + i];
-        CostOut co;
-        cost_eval(d, z, pb + (size_t)ks * d.npar, 1, co, false, slack);
+        double cval;
+#ifndef TMPC_GENERATED_STAGE
+        if constexpr (CM == 1) { CostOutCA co; cost_eval_ca(d, z, pb + (size_t)ks * d.npar, 1, co, false, slack); cval = co.val; }
+        else
+#endif
+        { CostOut co; cost_eval(d, z, pb + (size_t)ks * d.npar, 1, co, false, slack); cval = co.val; }
         DynOut dy;
         dyn_eval(d, z, dy, false);
         double r = 0.0;
 #pragma unroll
         for (int i = 0; i < NX; i++) r = fmax(r, fabs(dy.xn[i] - L.z[(ks + 1) * NV + NU + i]));
-        if (tid < N) { cost = d.dt * co.val; res = r; }
+        if (tid < N) { cost = d.dt * cval; res = r; }
     }
     int tid_o = tid;
     asm volatile("" : "+v"(tid_o));
@@ -834,6 +834,7 @@ __device__ __forceinline__ void solve_epilogue(const Lds &L, const Dims &d, int 
 
 // ---- the solve kernel ---------------------------------------------------------------------------
 #ifndef TMPC_PROF_TU
+template <int CM>      // cost model (Dims::cost_model): 0 MPCC contouring, 1 curvature-aware contouring
 __global__ __launch_bounds__(NT) void tmpc_solve_kernel(Dims d, int B, const double *__restrict__ xinit,
                                                         const double *__restrict__ x0, const double *__restrict__ params,
                                                         double *__restrict__ xtraj, double *__restrict__ utraj,
@@ -877,7 +878,7 @@ __global__ __launch_bounds__(NT) void tmpc_solve_kernel(Dims d, int B, const dou
     int status = 0, qp_status = 0, sqp_iter = 0, qp_iter_total = 0;
     for (int it = 0; it < d.n_sqp; it++) {
         pf.start();
-        linearise<false>(L, d, tid, pb, slack, pb_own);
+        linearise<false, false, 64, CM>(L, d, tid, pb, slack, pb_own);
         // QP primal start: dz = 0 except dx_0 = xinit - x_0; duals 0
         for (int e = tid; e < (N + 1) * NV; e += NT) L.v[e] = 0.0;
         for (int e = tid; e < (N + 1) * NX; e += NT) L.pq[e] = 0.0;
@@ -906,8 +907,8 @@ __global__ __launch_bounds__(NT) void tmpc_solve_kernel(Dims d, int B, const dou
         for (int r = tid; r < L.NG; r += NT) io.lamh[(size_t)slot_of(io, b) * L.NG + r] = (((r % L.nh) < d.n_up) ? 1.0 : -1.0) * L.lam[r];
         if (tid == 0) { if (sqp_iter > 0) io.stopped[slot_of(io, b)] = qp_status != 0; io.valid[slot_of(io, b)] = 1; }
     }
-    solve_epilogue(L, d, tid, b, xi, pb, slack, status, qp_status, sqp_iter, qp_iter_total, xtraj, utraj, pobj, exit_code,
-                   qp_status_out, sqp_iter_out, res_eq_out, qp_iter_out, prof_out, pf, t_begin);
+    solve_epilogue<CM>(L, d, tid, b, xi, pb, slack, status, qp_status, sqp_iter, qp_iter_total, xtraj, utraj, pobj, exit_code,
+                       qp_status_out, sqp_iter_out, res_eq_out, qp_iter_out, prof_out, pf, t_begin);
 }
 
 #endif  // TMPC_PROF_TU
@@ -938,10 +939,6 @@ extern template __global__ void tmpc::tmpc_solve_fast_kernel<8, 8, 6, 128, true,
 #endif
 #endif
 #ifdef TMPC_PROF_TU
-#elif defined(TMPC_SINGLE_TEAM)
-template __global__ void tmpc::tmpc_solve_team_kernel<TMPC_SINGLE_TEAM>(tmpc::Dims, int, const double *, const double *, const double *,
-                                                                       double *, double *, double *, int *, int *, int *, double *, int *,
-                                                                       long long *, tmpc::StateIO);
 #elif defined(TMPC_SINGLE_COMPACT)
 template __global__ void tmpc::tmpc_solve_compact_kernel<TMPC_SINGLE_COMPACT>(tmpc::Dims, int, const double *, const double *, const double *,
                                                                              double *, double *, double *, int *, int *, int *, double *, int *,
@@ -974,6 +971,20 @@ static SolveKernel pick_fast_kernel(const Dims &d, int *threads, bool prof)
     *threads = NT;
     if (getenv("TMPC_FORCE_GENERIC")) return nullptr;
     const int lps = (3 * d.N <= NT) ? 3 : ((2 * d.N <= NT) ? 2 : 0);
+#ifndef TMPC_GENERATED_STAGE
+    if (d.cost_model == 1) {
+        // curvature-aware contouring (BASELINE configs[2]): the cfg-3 shape on the two-wave kernel, every other row mix of N <= 20 on the
+        // runtime-shape one-wave kernel, anything else on the generic kernel -- all instantiated with CM = 1 (no profiled twins)
+        if (prof) return nullptr;
+        const int nrc = d.n_up + d.M + 14;
+        if (lps != 3 && 4 * d.N <= 128 && d.n_up == 20 && d.M == 8 && !getenv("TMPC_NO_TWO_WAVE")) {
+            *threads = 128;
+            return (SolveKernel)tmpc_solve_fast_kernel<20, 8, 4, 128, false, Solo, 1>;
+        }
+        if (lps == 3 && nrc <= 3 * 13) return (SolveKernel)tmpc_solve_fast_kernel<-1, 13, 3, 64, false, Solo, 1>;
+        return nullptr;
+    }
+#endif
 #ifdef TMPC_GENERATED_STAGE
     // generated solver: one row shape (tmpc_gen::NH upper-bounded rows); the fast instantiations are compiled only when the
     // generator's build found them free of scratch (TMPC_GEN_FAST / TMPC_GEN_FAST2 set by codegen/build.py)
@@ -1017,22 +1028,13 @@ static SolveKernel pick_fast_kernel(const Dims &d, int *threads, bool prof)
 }
 // Compact variant (tmpc_fast.hpp: tmpc_solve_compact_kernel): two waves per SIMD, eight trajectories per CU, persistent
 // workgroups.  Bitwise the same results as the fast kernel of the shape (tools/ab_compare.py against TMPC_NO_COMPACT=1).
-// *team: trajectories per workgroup -- 1: compact kernel; 2 / 4: team kernel (the trajectories' Riccati sweeps packed into one wave;
-// measured slower than the compact kernel, profiles/round3_b_team_kernels_rejected.json -- compiled only with -DTMPC_TEAM_KERNELS).
 // Shapes with 13 rows per lane ((12,12) and (24,0) at three lanes per stage: cfg 4, cfg 5) do not fit 256 registers without scratch
 // and stay on the fast kernels.
-static SolveKernel pick_compact_kernel(const Dims &d, bool prof, int *team)
+static SolveKernel pick_compact_kernel(const Dims &d, bool prof)
 {
-    *team = 1;
 #ifndef TMPC_GENERATED_STAGE
-    if (getenv("TMPC_FORCE_GENERIC") || getenv("TMPC_NO_COMPACT") || prof || d.N > 20) return nullptr;
+    if (getenv("TMPC_FORCE_GENERIC") || getenv("TMPC_NO_COMPACT") || prof || d.N > 20 || d.cost_model != 0) return nullptr;
     const int nr = d.n_up + d.M + 14;                    // interior-point rows per stage
-#ifdef TMPC_TEAM_KERNELS
-    const char *e = getenv("TMPC_TEAM");                 // experiments / A-B: 1 = compact kernel, 2 / 4 = team kernels
-    const int nq = e ? atoi(e) : 1;
-    if (d.n_up == 8 && d.M == 8 && nq == 4) { *team = 4; return (SolveKernel)tmpc_solve_team_kernel<8, 8, 3, 4>; }
-    if (d.n_up == 8 && d.M == 8 && nq == 2) { *team = 2; return (SolveKernel)tmpc_solve_team_kernel<8, 8, 3, 2>; }
-#endif
     if (d.n_up == 8 && d.M == 8) return (SolveKernel)tmpc_solve_compact_kernel<8, 8, 3, false>;
     if (d.n_up == 0 && d.M == 4) return (SolveKernel)tmpc_solve_compact_kernel<0, 4, 3, false>;
     if (d.n_up == 12 && d.M == 12) return nullptr;
@@ -1051,7 +1053,7 @@ static SolveKernel pick_compact_kernel(const Dims &d, bool prof, int *team)
 static SolveKernel pick_latency_kernel(const Dims &d, bool prof)
 {
 #ifndef TMPC_GENERATED_STAGE
-    if (getenv("TMPC_FORCE_GENERIC") || getenv("TMPC_NO_TWO_WAVE") || d.N > 2 * (64 / 6)) return nullptr;
+    if (getenv("TMPC_FORCE_GENERIC") || getenv("TMPC_NO_TWO_WAVE") || d.N > 2 * (64 / 6) || d.cost_model != 0) return nullptr;
     if (d.n_up == 8 && d.M == 8) return TMPC_FAST(8, 8, 6, 128);
 #endif
     (void)d; (void)prof;
@@ -1066,7 +1068,7 @@ static SolveKernel pick_scan_kernel(const Dims &d, int *threads, int *sl)
 {
     *sl = 3;
 #ifndef TMPC_GENERATED_STAGE
-    if (getenv("TMPC_FORCE_GENERIC") || d.N > 31 || d.N < 2) return nullptr;
+    if (getenv("TMPC_FORCE_GENERIC") || d.N > 31 || d.N < 2 || d.cost_model != 0) return nullptr;
     if (d.N > 20) {                                              // 21 <= N <= 31 (cfg 3, the reference's N = 30 defaults): two lanes per stage in the
         if (d.n_up + d.M + 14 > 4 * 12) return nullptr;          // Newton solve, the runtime-shape two-wave kernel (4 lanes per stage, up to 34 rows) around it
         *threads = 128; *sl = 2;
@@ -1105,7 +1107,6 @@ struct tmpc_handle {
     size_t lds_bytes_fast = 0;                // LDS of the fast-layout kernels (the profiled twin) when `kernel` is compact
     size_t lds_bytes_fast2 = 0;               // ... of their two-wave variants (kernel_lat): + the W shares parked during the linearisation
     bool compact = false;                     // `kernel` is a compact persistent kernel: grid = resident workgroups, needs ws + ticket
-    int team = 1;                             // trajectories per workgroup of the compact / team kernel (1, 2 or 4 waves)
     int grid_max = 0;                         // resident workgroups of the compact kernel on this device
     double *ws = nullptr;                     // [grid_max][ws_doubles(N)] per-workgroup NLP workspace
     int *ticket = nullptr;
@@ -1119,6 +1120,7 @@ struct tmpc_handle {
     int *st_has = nullptr;           // [B_max] the slot holds state of an earlier tmpc_solve_iterations (set by the kernels' store)
     int *d_slot = nullptr;           // [B_max] state slot of every batch entry (tmpc_set_slots)
     bool slots_set = false;
+    int slots_B = 0;                 // batch size the slot map was given for: a map of another size is refused, never read past its end
     int *d_share = nullptr;          // [B_max] tmpc_set_param_sharing
     int share_B = 0;                 // batch size the sharing map was given for (0: none)
     bool st_valid = false;           // lane kernels (state = their workspace, per launch): it holds the result of a previous call ...
@@ -1189,10 +1191,10 @@ int tmpc_create(tmpc_handle **out, const tmpc_dims *dims, int32_t B_max, int32_t
         if (dims->N < 2 || dims->N > 62 || dims->S < 1 || dims->M < 0 || dims->n_lin < 0 || dims->n_slk < 0 ||
             (dims->slack != 0 && dims->slack != 1) || dims->npar != tmpc::expected_npar(t) || dims->erk_steps < 1 ||
             dims->n_sqp < 1 || dims->qp_iter_max < 1 || !(dims->dt > 0.0) || !(dims->qp_tol > 0.0) || !(dims->reg_eps > 0.0) ||
-            !(dims->ipm_mu0 > 0.0) || !(dims->ipm_thr0 > 0.0))
+            !(dims->ipm_mu0 > 0.0) || !(dims->ipm_thr0 > 0.0) || (dims->cost_model != 0 && dims->cost_model != 1))
             return TMPC_ERR_INVALID;
 #ifdef TMPC_GENERATED_STAGE
-        if (dims->n_lin != tmpc_gen::NH || dims->M != 0 || dims->n_slk != 0 || dims->slack != tmpc_gen::SLACK) return TMPC_ERR_INVALID;
+        if (dims->n_lin != tmpc_gen::NH || dims->M != 0 || dims->n_slk != 0 || dims->slack != tmpc_gen::SLACK || dims->cost_model != 0) return TMPC_ERR_INVALID;
 #endif
     }
     int ndev = 0;
@@ -1201,16 +1203,18 @@ int tmpc_create(tmpc_handle **out, const tmpc_dims *dims, int32_t B_max, int32_t
     h->device = device; h->B_max = B_max;
     tmpc::Dims &d = h->d;
     d.N = dims->N; d.S = dims->S; d.n_lin = dims->n_lin; d.M = dims->M; d.npar = dims->npar;
-    d.n_slk = dims->n_slk; d.slack = dims->slack;
+    d.n_slk = dims->n_slk; d.slack = dims->slack; d.cost_model = dims->cost_model;
     d.n_sqp = dims->n_sqp; d.qp_iter_max = dims->qp_iter_max; d.erk_steps = dims->erk_steps;
     d.dt = dims->dt; d.qp_tol = dims->qp_tol; d.reg_eps = dims->reg_eps; d.mu0 = dims->ipm_mu0; d.thr0 = dims->ipm_thr0;
     for (int i = 0; i < TMPC_NV; i++) { d.lb[i] = dims->lb[i]; d.ub[i] = dims->ub[i]; }
     tmpc::derive_dims(d);
     h->kernel = tmpc::pick_fast_kernel(d, &h->threads, false);
-    if (const char *lm = getenv("TMPC_LATENCY_MODE")) h->latency_mode = atoi(lm) == 2 ? 2 : 1;      // experiments: latency variant regardless of the caller
+    if (const char *lm = getenv("TMPC_LATENCY_MODE")) {      // experiments: latency variant regardless of the caller ("0", "1" or "2"; anything else is ignored)
+        if ((lm[0] == '0' || lm[0] == '1' || lm[0] == '2') && lm[1] == '\0') h->latency_mode = lm[0] - '0';
+    }
     h->fast = h->kernel != nullptr;
     if (h->fast) h->lds_bytes = sizeof(double) * (size_t)tmpc::lds_doubles_fast(d.N, d.n_up + d.M);
-    else { h->kernel = tmpc::tmpc_solve_kernel; h->lds_bytes = sizeof(double) * (size_t)tmpc::lds_doubles(d.N, d.n_up + d.M); }
+    else { h->kernel = d.cost_model == 1 ? tmpc::tmpc_solve_kernel<1> : tmpc::tmpc_solve_kernel<0>; h->lds_bytes = sizeof(double) * (size_t)tmpc::lds_doubles(d.N, d.n_up + d.M); }
     h->lds_bytes_fast = h->lds_bytes;
     // two-wave (128-thread) fast kernels park one share of W per stage behind the layout while they linearise (linearise<.., 128>)
     h->lds_bytes_fast2 = h->lds_bytes_fast + sizeof(double) * (size_t)d.N * tmpc::NP28;
@@ -1230,16 +1234,16 @@ int tmpc_create(tmpc_handle **out, const tmpc_dims *dims, int32_t B_max, int32_t
         if (hipFuncSetAttribute((const void *)h->kernel_scan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes_scan) != hipSuccess)
             h->kernel_scan = nullptr;
     }
-    if (tmpc::SolveKernel kc = (h->fast && h->threads == tmpc::NT) ? tmpc::pick_compact_kernel(d, false, &h->team) : nullptr) {
+    if (tmpc::SolveKernel kc = (h->fast && h->threads == tmpc::NT) ? tmpc::pick_compact_kernel(d, false) : nullptr) {
         h->kernel = kc; h->compact = true;
-        h->lds_bytes = sizeof(double) * (size_t)tmpc::lds_doubles_compact(d.N, d.n_lin, d.n_up + d.M) * h->team + (h->team > 1 ? 64 : 0);
+        h->lds_bytes = sizeof(double) * (size_t)tmpc::lds_doubles_compact(d.N, d.n_lin, d.n_up + d.M);
     }
     if (hipFuncSetAttribute((const void *)h->kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)h->lds_bytes) != hipSuccess)
         return fail(TMPC_ERR_NO_DEVICE);
     if (h->compact) {
         int per_cu = 0, cus = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)h->kernel, 64 * h->team, h->lds_bytes) != hipSuccess || per_cu <= 0 ||
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)h->kernel, 64, h->lds_bytes) != hipSuccess || per_cu <= 0 ||
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0)
             return fail(TMPC_ERR_HIP);
         if (const char *e = getenv("TMPC_COMPACT_PER_CU")) { const int v = atoi(e); if (v > 0 && v < per_cu) per_cu = v; }   // experiments
@@ -1264,7 +1268,7 @@ int tmpc_create(tmpc_handle **out, const tmpc_dims *dims, int32_t B_max, int32_t
     ok &= hipMalloc(&h->d_best, 4) == hipSuccess;
     ok &= hipMalloc(&h->d_disabled, B) == hipSuccess;
     if (h->compact) {
-        ok &= hipMalloc(&h->ws, (size_t)h->grid_max * h->team * tmpc::ws_doubles(d.N) * 8) == hipSuccess;
+        ok &= hipMalloc(&h->ws, (size_t)h->grid_max * tmpc::ws_doubles(d.N) * 8) == hipSuccess;
         ok &= hipMalloc(&h->ticket, 8 * 4) == hipSuccess;         // one work counter per XCD (next_trajectory)
     }
     if (!ok) { tmpc_destroy(h); return TMPC_ERR_HIP; }
@@ -1329,15 +1333,14 @@ static int launch_solve(tmpc_handle *h, int n_iter, int st_flags)
     } else {
         tmpc::Dims dd = h->d;
         dd.n_sqp = n_iter;
-        tmpc::StateIO io{h->st_z, h->st_pi, h->st_lamh, h->st_stopped, st_flags, h->ws, h->ticket, h->slots_set ? h->d_slot : nullptr, h->st_has,
+        tmpc::StateIO io{h->st_z, h->st_pi, h->st_lamh, h->st_stopped, st_flags, h->ws, h->ticket, (h->slots_set && h->slots_B == h->B) ? h->d_slot : nullptr, h->st_has,
                          (h->share_B == h->B) ? h->d_share : nullptr};      // (a map given for another batch size is not applied)
         const bool lat2 = h->kernel_scan && h->latency_mode == 2;
         const bool lat = !lat2 && h->kernel_lat && h->latency_mode != 0;          // (mode 2 without a scan variant falls back to the two-wave variant)
         const bool cp = h->compact && !lat && !lat2;
         if (cp) TMPC_HIP_CHECK(h, hipMemsetAsync(h->ticket, 0, 8 * 4, h->stream));    // the persistent launch's work counters (one per XCD)
-        const int teams = (h->B + h->team - 1) / h->team;                              // workgroups' worth of work of a persistent launch
-        hipLaunchKernelGGL(lat2 ? h->kernel_scan : lat ? h->kernel_lat : h->kernel, dim3(cp ? (teams < h->grid_max ? teams : h->grid_max) : h->B),
-                           dim3(lat2 ? h->scan_threads : lat ? 128 : (cp ? 64 * h->team : h->threads)), lat2 ? h->lds_bytes_scan : lat ? h->lds_bytes_fast2 : h->lds_bytes, h->stream, dd, h->B,
+        hipLaunchKernelGGL(lat2 ? h->kernel_scan : lat ? h->kernel_lat : h->kernel, dim3(cp ? (h->B < h->grid_max ? h->B : h->grid_max) : h->B),   // (persistent launch: at most the resident workgroups)
+                           dim3(lat2 ? h->scan_threads : lat ? 128 : (cp ? 64 : h->threads)), lat2 ? h->lds_bytes_scan : lat ? h->lds_bytes_fast2 : h->lds_bytes, h->stream, dd, h->B,
                            h->xinit, h->x0, h->params, h->xtraj, h->utraj, h->pobj, h->exit_code, h->qp_status,
                            h->sqp_iter, h->res_eq, h->qp_iter, (long long *)nullptr, io);
         TMPC_HIP_CHECK(h, hipGetLastError());
@@ -1345,7 +1348,7 @@ static int launch_solve(tmpc_handle *h, int n_iter, int st_flags)
             // a failed solve resets the reference's capsule (Solver_acados_reset, acados_solver_interface.cpp:187-191): zero multipliers
             const int n_pi = (h->d.N + 1) * tmpc::NX, n_lam = h->d.N * (h->d.n_up + h->d.M);
             hipLaunchKernelGGL(tmpc::tmpc_state_finalize_kernel, dim3(h->B), dim3(64), 0, h->stream, n_pi, n_lam, h->exit_code, h->st_pi, h->st_lamh,
-                               h->slots_set ? h->d_slot : nullptr);
+                               (h->slots_set && h->slots_B == h->B) ? h->d_slot : nullptr);
             TMPC_HIP_CHECK(h, hipGetLastError());
         }
     }
@@ -1374,6 +1377,12 @@ int tmpc_solve_iterations(tmpc_handle *h, int32_t n_iter, int32_t flags)
     if (!h || h->B <= 0 || !h->xinit || n_iter < 0 || (flags & ~15)) { if (h) h->err = "tmpc_solve_iterations: no batch set / bad argument"; return TMPC_ERR_INVALID; }
     TMPC_HIP_CHECK(h, hipSetDevice(h->device));
     if (h->throughput_mode && h->slots_set) { h->err = "tmpc_solve_iterations: slot maps (tmpc_set_slots) are not available with the lane kernels"; return TMPC_ERR_INVALID; }
+    if (h->slots_set && h->slots_B != h->B) {
+        // the map has one entry per batch entry: entries [slots_B, B) of a larger batch would be read from uninitialised memory
+        h->err = "tmpc_solve_iterations: the slot map was given for a batch of " + std::to_string(h->slots_B) + " entries, the current batch has " +
+                 std::to_string(h->B) + ": call tmpc_set_slots again after tmpc_set_batch (or clear it with a null map)";
+        return TMPC_ERR_INVALID;
+    }
     if (!h->throughput_mode && !h->st_z) {
         const size_t B = h->B_max, N = h->d.N, nh = h->d.n_up + h->d.M;
         const size_t sz[5] = {B * (N + 1) * tmpc::NV * 8, B * (N + 1) * tmpc::NX * 8, (B * N * nh + 1) * 8, B * 4, B * 4};
@@ -1436,7 +1445,7 @@ int tmpc_set_latency_mode(tmpc_handle *h, int32_t on)
 int tmpc_set_slots(tmpc_handle *h, const int32_t *slots)
 {
     if (!h) return TMPC_ERR_INVALID;
-    if (!slots) { h->slots_set = false; return TMPC_OK; }
+    if (!slots) { h->slots_set = false; h->slots_B = 0; return TMPC_OK; }
     if (h->B <= 0) { h->err = "tmpc_set_slots: set the batch first (the map has one entry per batch entry)"; return TMPC_ERR_INVALID; }
     std::vector<char> seen((size_t)h->B_max, 0);
     for (int b = 0; b < h->B; b++) {
@@ -1447,7 +1456,7 @@ int tmpc_set_slots(tmpc_handle *h, const int32_t *slots)
     if (!h->d_slot) TMPC_HIP_CHECK(h, hipMalloc(&h->d_slot, (size_t)h->B_max * 4));
     TMPC_HIP_CHECK(h, hipMemcpyAsync(h->d_slot, slots, (size_t)h->B * 4, hipMemcpyHostToDevice, h->stream));
     TMPC_HIP_CHECK(h, hipStreamSynchronize(h->stream));            // (the caller's array may go away)
-    h->slots_set = true;
+    h->slots_set = true; h->slots_B = h->B;
     return TMPC_OK;
 }
 
@@ -1455,6 +1464,12 @@ int tmpc_set_param_sharing(tmpc_handle *h, const int32_t *base_of)
 {
     if (!h) return TMPC_ERR_INVALID;
     if (!base_of) { h->share_B = 0; return TMPC_OK; }
+#ifdef TMPC_GENERATED_STAGE
+    // generated stage functions read every parameter -- halfspace rows included -- from ONE row block (tmpc_gen::rows has no notion of
+    // "own" rows), so the hint cannot be honoured: it is accepted and ignored, as include/tmpc_hip.h says
+    h->share_B = 0;
+    return TMPC_OK;
+#endif
     if (h->B <= 0) { h->err = "tmpc_set_param_sharing: set the batch first (the map has one entry per batch entry)"; return TMPC_ERR_INVALID; }
     for (int b = 0; b < h->B; b++)
         if (base_of[b] < 0 || base_of[b] >= h->B) { h->err = "tmpc_set_param_sharing: entries must be batch indices in [0, B)"; return TMPC_ERR_INVALID; }
@@ -1494,9 +1509,21 @@ int tmpc_copy_state(tmpc_handle *dst, tmpc_handle *src)
     return TMPC_OK;
 }
 
+int tmpc_clear_slot(tmpc_handle *h, int32_t slot)
+{
+    if (!h || slot < 0 || slot >= h->B_max) { if (h) h->err = "tmpc_clear_slot: slot out of range"; return TMPC_ERR_INVALID; }
+    if (h->throughput_mode) { h->err = "tmpc_clear_slot: the lane kernels keep their state per launch, not per slot"; return TMPC_ERR_INVALID; }
+    if (!h->st_has) return TMPC_OK;                                 // nothing stored yet: every slot is fresh
+    TMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    TMPC_HIP_CHECK(h, hipMemsetAsync(h->st_has + slot, 0, 4, h->stream));
+    TMPC_HIP_CHECK(h, hipMemsetAsync(h->st_stopped + slot, 0, 4, h->stream));
+    return TMPC_OK;
+}
+
 int tmpc_set_throughput_mode(tmpc_handle *h, int32_t on)
 {
     if (!h) return TMPC_ERR_INVALID;
+    if (on && h->d.cost_model != 0) { h->err = "tmpc_set_throughput_mode: the lane kernels have the MPCC contouring cost only"; return TMPC_ERR_INVALID; }
     if (on && !h->lanes) {
         TMPC_HIP_CHECK(h, hipSetDevice(h->device));
         h->lanes = tmpc::lanes::create(h->d, h->B_max, h->err);
@@ -1560,9 +1587,8 @@ int tmpc_kernel_info(const tmpc_handle *h, char *buf, int32_t capacity)
     const char *family = h->throughput_mode ? "lanes (one lane per trajectory)"
                          : !h->fast        ? "generic (one wave per trajectory, rows in LDS)"
                          : !h->compact     ? (h->threads == 128 ? "fast, two waves per trajectory" : "fast (one wave per trajectory)")
-                         : h->team > 1     ? "team (compact layout, Riccati sweeps of the workgroup's trajectories packed into one wave)"
                                            : "compact (one wave per trajectory, two waves per SIMD)";
-    const int n = snprintf(buf, (size_t)capacity, "%s; trajectories per workgroup %d; LDS %zu B per workgroup; %s", family, h->compact ? h->team : 1,
+    const int n = snprintf(buf, (size_t)capacity, "%s; trajectories per workgroup %d; LDS %zu B per workgroup; %s", family, 1,
                            h->lds_bytes, h->compact ? (std::string("persistent launch, resident workgroups ") + std::to_string(h->grid_max)).c_str()
                                                     : "one workgroup per trajectory");
     return n < capacity ? n : capacity - 1;
@@ -1847,6 +1873,7 @@ int tmpc_debug_profile(tmpc_handle *h, int64_t *cycles, int32_t n_phases)
     int thr = h->threads;
     size_t lds = h->fast ? h->lds_bytes_fast : h->lds_bytes;
     if (h->fast && h->threads == 128) lds = h->lds_bytes_fast2;
+    if (h->fast && h->d.cost_model != 0) { h->err = "tmpc_debug_profile: no profiled twin for the curvature-aware cost"; return TMPC_ERR_INVALID; }
     if (h->fast) {
         pk = tmpc::pick_fast_kernel(h->d, &thr, true);
 #ifndef TMPC_GENERATED_STAGE

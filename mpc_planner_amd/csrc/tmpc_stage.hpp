@@ -57,6 +57,8 @@ struct Dims {
     // loop-invariant VGPR copies alive across the whole solve:
     double erk_h, erk_eta, erk_w6;   // dt / erk_steps, its half, its sixth
     double hdt2;                     // dt^2 / 2
+    int cost_model;                  // 0: ContouringModule (contouring.py:48-98); 1: CurvatureAwareContouringModule (curvature_aware_contouring.py:48-105).
+                                     // Kernels are instantiated per cost model (template parameter CM): this field only selects the instantiation on the host
 };
 __host__ inline void derive_dims(Dims &d)
 {
@@ -295,6 +297,124 @@ TMPC_HD void cost_add_hessian(const CostOut &o, double scale, double (*W)[NV])
     W[ZX][ZS] += scale * o.Hxs; W[ZS][ZX] += scale * o.Hxs;
     W[ZY][ZS] += scale * o.Hys; W[ZS][ZY] += scale * o.Hys;
 }
+
+// ---- curvature-aware contouring (BASELINE configs[2] "CA-MPC") ------------------------------------------------------------
+// CurvatureAwareContouringObjective.get_value (curvature_aware_contouring.py:48-105) at stage_idx = 1, on top of the MPCBase terms:
+//   cost = w_a a^2 + w_w w^2 + w_v (v - v_ref)^2 [+ w_slack slack^2]                      mpc_base.py:47-60
+//        + w_contour ((x - X)^2 + (y - Y)^2)                                               :87-89  (no projection on the tangent frame)
+//        + w_v (s_dot - v_ref)^2,   s_dot = v (cos psi tx + sin psi ty) / q,               :82-84,90
+//          q = 1 - ((x - X) X'' + (y - Y) Y''),   X'' / Y'' = Spline.deriv2 (spline.py:52-56: the lambda blend of the segments' second derivatives)
+// Same parameter map as the MPCC stack (the module's C++ side leaves velocity / reference_velocity to MPCBaseModule,
+// curvature_aware_contouring.cpp:15-49; `lag` is defined but unused, :26).  The model keeps s' = v (route 1: the reference's
+// own CA model class needs Forces-style discrete dynamics and is rejected by its acados path, solver_model.py:217-221).
+// s_dot couples (psi, v) with (x, y, s): the cost Hessian is dense on those five variables, and MIRROR sees a full 7 x 7 matrix (mirror7's
+// coupled branch).  H: packed lower over (x, y, psi, v, s) = z[2..6].
+TMPC_HD J1 seg_deriv2(double a, double b, double t) { return {6.0 * a * t + 2.0 * b, 6.0 * a, 0.0}; }
+
+struct CostOutCA { double val; double g[NV]; double Haa, Hww; double H[15]; };
+
+TMPC_HD void cost_eval_ca(const Dims &d, const double *z, const double *p, int pstride, CostOutCA &o, bool derivs, double slack = 0.0)
+{
+    auto P = [&](int i) { return p[(size_t)i * pstride]; };
+    const int ws = d.slack;
+    const double w_a = P(0), w_w = P(1), w_v = P(2 + ws), v_ref = P(3 + ws), w_contour = P(4 + ws);
+    const double a = z[ZA], w = z[ZW], x = z[ZX], y = z[ZY], psi = z[ZPSI], v = z[ZV], s = z[ZS];
+    const int S = d.S;
+    int base = ip_spline(d, S - 1, 0);
+    double t = s - P(base + 8);
+    J1 X = seg_at(P(base + 0), P(base + 1), P(base + 2), P(base + 3), t);
+    J1 Y = seg_at(P(base + 4), P(base + 5), P(base + 6), P(base + 7), t);
+    J1 DX = seg_deriv(P(base + 0), P(base + 1), P(base + 2), t);
+    J1 DY = seg_deriv(P(base + 4), P(base + 5), P(base + 6), t);
+    J1 XPP = seg_deriv2(P(base + 0), P(base + 1), t);
+    J1 YPP = seg_deriv2(P(base + 4), P(base + 5), t);
+    for (int k = S - 1; k >= 1; k--) {
+        const double u = (s - P(ip_spline(d, k, 8)) + 0.02) / 0.1;
+        const double sig = 1.0 / (1.0 + exp(u));
+        const double sig1 = -sig * (1.0 - sig);
+        const double sig2 = sig1 * (2.0 * sig - 1.0);
+        const J1 lam = {sig, sig1 * 10.0, sig2 * 100.0};
+        const J1 oml = {1.0 - sig, -lam.d1, -lam.d2};
+        base = ip_spline(d, k - 1, 0);
+        t = s - P(base + 8);
+        X = j_add(j_mul(lam, seg_at(P(base + 0), P(base + 1), P(base + 2), P(base + 3), t)), j_mul(oml, X));
+        Y = j_add(j_mul(lam, seg_at(P(base + 4), P(base + 5), P(base + 6), P(base + 7), t)), j_mul(oml, Y));
+        DX = j_add(j_mul(lam, seg_deriv(P(base + 0), P(base + 1), P(base + 2), t)), j_mul(oml, DX));
+        DY = j_add(j_mul(lam, seg_deriv(P(base + 4), P(base + 5), P(base + 6), t)), j_mul(oml, DY));
+        XPP = j_add(j_mul(lam, seg_deriv2(P(base + 0), P(base + 1), t)), j_mul(oml, XPP));
+        YPP = j_add(j_mul(lam, seg_deriv2(P(base + 4), P(base + 5), t)), j_mul(oml, YPP));
+    }
+    const J1 n2 = j_add(j_mul(DX, DX), j_mul(DY, DY));
+    const double nrm = sqrt(n2.v);
+    const J1 nr = j_chain(n2, nrm, 0.5 / nrm, -0.25 / (nrm * n2.v));
+    const double rinv = 1.0 / nr.v;
+    const J1 inv = j_chain(nr, rinv, -rinv * rinv, 2.0 * rinv * rinv * rinv);
+    const J1 tx = j_mul(DX, inv), ty = j_mul(DY, inv);
+
+    const double ex = x - X.v, ey = y - Y.v;
+    const double q = 1.0 - (ex * XPP.v + ey * YPP.v);
+    const double rho = 1.0 / q;
+    double sp, cp;
+    sincos(psi, &sp, &cp);
+    const double c = cp * tx.v + sp * ty.v;
+    const double f = v * c * rho;                           // s_dot
+    const double df = f - v_ref, dv = v - v_ref;
+    o.val = w_a * a * a + w_w * w * w + w_v * dv * dv + w_contour * (ex * ex + ey * ey) + w_v * df * df;
+    if (ws) o.val += P(2) * slack * slack;
+    if (!derivs) return;
+
+    // q and rho = 1 / q in (x, y, s)
+    const double q_x = -XPP.v, q_y = -YPP.v;
+    const double q_s = X.d1 * XPP.v - ex * XPP.d1 + Y.d1 * YPP.v - ey * YPP.d1;
+    const double q_xs = -XPP.d1, q_ys = -YPP.d1;
+    const double q_ss = X.d2 * XPP.v + 2.0 * X.d1 * XPP.d1 - ex * XPP.d2 + Y.d2 * YPP.v + 2.0 * Y.d1 * YPP.d1 - ey * YPP.d2;
+    const double rho2 = rho * rho, rho3 = rho2 * rho;
+    const double r_x = -q_x * rho2, r_y = -q_y * rho2, r_s = -q_s * rho2;
+    const double r_xx = 2.0 * q_x * q_x * rho3, r_xy = 2.0 * q_x * q_y * rho3, r_yy = 2.0 * q_y * q_y * rho3;
+    const double r_xs = -q_xs * rho2 + 2.0 * q_x * q_s * rho3, r_ys = -q_ys * rho2 + 2.0 * q_y * q_s * rho3;
+    const double r_ss = -q_ss * rho2 + 2.0 * q_s * q_s * rho3;
+    // c = cos psi tx + sin psi ty in (psi, s)
+    const double c_p = -sp * tx.v + cp * ty.v, c_s = cp * tx.d1 + sp * ty.d1;
+    const double c_ps = -sp * tx.d1 + cp * ty.d1, c_ss = cp * tx.d2 + sp * ty.d2;      // (c_pp = -c)
+    // f = v c rho: gradient and packed lower Hessian over (x, y, psi, v, s)
+    double fg[5], fH[15];
+    fg[0] = v * c * r_x; fg[1] = v * c * r_y; fg[2] = v * c_p * rho; fg[3] = c * rho; fg[4] = v * (c_s * rho + c * r_s);
+    fH[0] = v * c * r_xx;                                                               // xx
+    fH[1] = v * c * r_xy; fH[2] = v * c * r_yy;                                         // yx yy
+    fH[3] = v * c_p * r_x; fH[4] = v * c_p * r_y; fH[5] = -v * c * rho;                 // px py pp
+    fH[6] = c * r_x; fH[7] = c * r_y; fH[8] = c_p * rho; fH[9] = 0.0;                   // vx vy vp vv
+    fH[10] = v * (c_s * r_x + c * r_xs); fH[11] = v * (c_s * r_y + c * r_ys);           // sx sy
+    fH[12] = v * (c_ps * rho + c_p * r_s); fH[13] = c_s * rho + c * r_s;                // sp sv
+    fH[14] = v * (c_ss * rho + 2.0 * c_s * r_s + c * r_ss);                             // ss
+    const double cv2 = 2.0 * w_v, cc = 2.0 * w_contour;
+#pragma unroll
+    for (int i = 0; i < 5; i++)
+#pragma unroll
+        for (int j = 0; j <= i; j++) o.H[i * (i + 1) / 2 + j] = cv2 * (fg[i] * fg[j] + df * fH[i * (i + 1) / 2 + j]);
+    o.g[ZA] = 2.0 * w_a * a; o.g[ZW] = 2.0 * w_w * w;
+    o.g[ZX] = cv2 * df * fg[0] + cc * ex;
+    o.g[ZY] = cv2 * df * fg[1] + cc * ey;
+    o.g[ZPSI] = cv2 * df * fg[2];
+    o.g[ZV] = cv2 * df * fg[3] + cv2 * dv;
+    o.g[ZS] = cv2 * df * fg[4] - cc * (ex * X.d1 + ey * Y.d1);
+    o.Haa = 2.0 * w_a; o.Hww = 2.0 * w_w;
+    o.H[0] += cc; o.H[2] += cc; o.H[9] += cv2;                                          // xx, yy (distance), vv (MPCBase velocity term)
+    o.H[10] -= cc * X.d1; o.H[11] -= cc * Y.d1;                                         // sx, sy
+    o.H[14] += cc * (X.d1 * X.d1 + Y.d1 * Y.d1 - ex * X.d2 - ey * Y.d2);                // ss
+}
+
+TMPC_HD void cost_add_hessian_ca(const CostOutCA &o, double scale, double (*W)[NV])
+{
+    W[ZA][ZA] += scale * o.Haa; W[ZW][ZW] += scale * o.Hww;
+#pragma unroll
+    for (int i = 0; i < 5; i++)
+#pragma unroll
+        for (int j = 0; j <= i; j++) {
+            const double h = scale * o.H[i * (i + 1) / 2 + j];
+            W[ZX + i][ZX + j] += h;
+            if (i != j) W[ZX + j][ZX + i] += h;
+        }
+}
 #endif  // TMPC_GENERATED_STAGE (hand-written cost)
 
 // =============================================================================================
@@ -495,7 +615,7 @@ TMPC_HD void mirror7(double (*A)[NV], double eps)
 // Lagrangian Hessian of one stage (before MIRROR): dt*hess(l) + pi_x hess(x+) + pi_y hess(y+) + sum_r lamh_r hess(h_r),
 // plus the linearisation data of the stage.  lamh(r) is supplied by a functor (zero for inactive rows).
 // Rows are numbered in the kernels' internal order [topology | slack rows | ellipsoids] (upper-bounded rows first).
-template <typename LamH, typename RowSink>
+template <int CM = 0, typename LamH, typename RowSink>
 TMPC_HD void stage_linearise(const Dims &d, const double *z, const double *p, int pstride,
                                                 double pix, double piy, LamH lamh, RowSink sink,
                                                 double (*W)[NV], double *g, double *BA, double *xn, double slack = 0.0,
@@ -562,12 +682,20 @@ TMPC_HD void stage_linearise(const Dims &d, const double *z, const double *p, in
 #else
     RowOut ro;
     if (part != 1) {
+        if constexpr (CM == 1) {
+            CostOutCA co;
+            cost_eval_ca(d, z, p, pstride, co, true, slack);
+#pragma unroll
+            for (int i = 0; i < NV; i++) g[i] = d.dt * co.g[i];
+            cost_add_hessian_ca(co, d.dt, W);
+        } else {
         CostOut co;
         cost_eval(d, z, p, pstride, co, true, slack);
 #pragma unroll
         for (int i = 0; i < NV; i++) g[i] = (i == ZPSI) ? 0.0 : d.dt * co.g[i];   // stage cost scaled by the shooting interval (the cost
                                                                             // does not depend on psi: literal 0, not a hoisted dt * 0)
         cost_add_hessian(co, d.dt, W);
+        }
         for (int j = 0; j < d.n_lin; j++) {
             lin_row_eval(d, z, p + own_delta, pstride, j, ro);
             sink(j, ro);

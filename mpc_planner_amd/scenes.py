@@ -124,6 +124,30 @@ def scenario_samples(rng, pos0, vel, N, n_samples):
     return pos0[:, None, None, :] + v[:, :, None, :] * DT * steps + noise
 
 
+def mixture_prediction(obs_pos, n_extra=0, dt=DT):
+    """The three-mode Gaussian-mixture prediction of scenario_samples (straight / veer left / veer right) as the tensor the device
+    sampler reads (tmpc_sample_scenarios): [M][3][N + n_extra][6] = (x, y, cos angle, sin angle, major, minor) per obstacle, mode and
+    prediction step; radii = integrated standard deviations growing along the horizon (data_preparation.cpp:170-186).
+    obs_pos [M][N][2]: the obstacles' mean predictions (make_scene()["obstacles"]["pos"])."""
+    M, N, _ = obs_pos.shape
+    T = N + n_extra
+    vel = (obs_pos[:, 1] - obs_pos[:, 0]) / dt
+    steps = np.arange(T)
+    out = np.zeros((M, 3, T, 6))
+    for j, turn in enumerate((0.0, 0.06, -0.06)):
+        c, s_ = np.cos(turn), np.sin(turn)
+        v = np.stack([c * vel[:, 0] - s_ * vel[:, 1], s_ * vel[:, 0] + c * vel[:, 1]], 1)
+        out[:, j, :, 0:2] = obs_pos[:, :1, :] + v[:, None, :] * dt * steps[None, :, None]
+        ang = np.arctan2(v[:, 1], v[:, 0])
+        out[:, j, :, 2] = np.cos(ang)[:, None]; out[:, j, :, 3] = np.sin(ang)[:, None]
+        out[:, j, :, 4] = 0.05 * dt * np.sqrt(steps + 1.0)[None]        # along-track
+        out[:, j, :, 5] = 0.03 * dt * np.sqrt(steps + 1.0)[None]        # cross-track
+    return out
+
+
+MIXTURE_WEIGHTS = (0.5, 0.25, 0.25)
+
+
 def make_scene(scene_idx, N=20, M=8, B=64, S=5, tmpc_pp=False, gaussian=False, guidance=True, slack=False,
                n_decomp=0, n_scenario=0, n_samples=256, chance=False):
     """Returns dict(xinit [Bt][nx], x0 [Bt][N+1][nv], params [Bt][N][npar], pm, guidance_id [Bt]); nx = 5, nv = 7, or

@@ -20,7 +20,7 @@ class TmpcDims(C.Structure):
                 ("n_sqp", C.c_int32), ("qp_iter_max", C.c_int32), ("erk_steps", C.c_int32),
                 ("dt", C.c_double), ("qp_tol", C.c_double), ("reg_eps", C.c_double), ("ipm_mu0", C.c_double),
                 ("ipm_thr0", C.c_double), ("lb", C.c_double * NV), ("ub", C.c_double * NV),
-                ("n_slk", C.c_int32), ("slack", C.c_int32)]
+                ("n_slk", C.c_int32), ("slack", C.c_int32), ("cost_model", C.c_int32)]
 
     @property
     def nx(self):            # external (model) state / variable counts: the slack model has one more state
@@ -42,7 +42,7 @@ EXPORTS = ["tmpc_default_dims", "tmpc_default_dims_ex", "tmpc_create", "tmpc_des
            "tmpc_linearize_topology", "tmpc_scenario_halfspaces", "tmpc_scenario_support", "tmpc_warmstart", "tmpc_init_with_guidance",
            "tmpc_debug_get_x0", "tmpc_debug_get_params", "tmpc_set_throughput_mode", "tmpc_solve_iterations",
            "tmpc_reset_multipliers", "tmpc_get_stream", "tmpc_kernel_info", "tmpc_set_slots", "tmpc_set_param_sharing", "tmpc_copy_state", "tmpc_scenario_empty_stages", "tmpc_sample_scenarios",
-           "tmpc_scenario_discard", "tmpc_scenario_discarded", "tmpc_linearize_topology_ex"]
+           "tmpc_scenario_discard", "tmpc_scenario_discarded", "tmpc_linearize_topology_ex", "tmpc_clear_slot"]
 
 class TmpcError(RuntimeError):
     pass
@@ -101,6 +101,8 @@ def load_library(path=None):
         lib.tmpc_scenario_discarded.argtypes = [vp, vp]
     if hasattr(lib, "tmpc_copy_state"):        # (absent from reference builds of earlier rounds used in A/B runs)
         lib.tmpc_copy_state.argtypes = [vp, vp]
+    if hasattr(lib, "tmpc_clear_slot"):
+        lib.tmpc_clear_slot.argtypes = [vp, C.c_int32]
     lib.tmpc_synchronize.argtypes = [vp]
     lib.tmpc_get.argtypes = [vp] + [vp] * 8
     lib.tmpc_select_best.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, C.POINTER(C.c_int32)]
@@ -255,6 +257,10 @@ class BatchedSolver:
         assert a.size == self.B
         self._check(self.lib.tmpc_set_param_sharing(self._h, a.ctypes.data_as(C.c_void_p)), "tmpc_set_param_sharing")
 
+    def clear_slot(self, slot):
+        """Forget one slot's persistent state (tmpc_clear_slot): the slot's next solve_iterations starts like a fresh capsule."""
+        self._check(self.lib.tmpc_clear_slot(self._h, int(slot)), "tmpc_clear_slot")
+
     def copy_state_from(self, other):
         self._check(self.lib.tmpc_copy_state(self._h, other._h), "tmpc_copy_state")
 
@@ -356,6 +362,11 @@ class BatchedSolver:
         self.synchronize()
         o = out.cpu().numpy()
         return o[0], o[1]
+
+    def scenario_support_async(self, n_scenarios, tol, d_support, d_active_rows):
+        """tmpc_scenario_support on raw device pointers (int32 [B] each), stream-ordered on the handle's stream, no synchronisation."""
+        self._check(self.lib.tmpc_scenario_support(self._h, int(n_scenarios), float(tol), C.c_void_p(d_support), C.c_void_p(d_active_rows)),
+                    "tmpc_scenario_support")
 
     def sample_scenarios(self, d_pred, d_prob, n_solvers, n_obstacles, n_modes, n_scenarios, seed, d_samples):
         """Device scenario sampler (tmpc_sample_scenarios): raw device pointers; d_samples [n_solvers][N][n_obstacles * n_scenarios][2]."""
@@ -462,6 +473,9 @@ def optimize_scenarios(solver, xinit, x0, params, n_iter=None, scenario=None):
     scenario = dict(d_samples, n_pts, n_rows, d_scene_of, d_state_x, radius, n_scenarios[, disc_offset, tol, max_support, n_discard]) builds
     the rows on device from the sampled scenarios (tmpc_scenario_halfspaces, scenario_module.update + setParameters) and adds the
     support bookkeeping of ScenarioSolver (scenario_constraints.h:38-40): res["support"], res["active_rows"], and with max_support
+    (the bound on the support of the solution AFTER the removal, i.e. NOT counting the n_discard removed scenarios: the removed ones
+    enter the certificate separately -- the sample size has to come from modules.scenario_sample_size(risk, max_support=max_support,
+    removed=n_discard), which is what makes `support <= max_support` certify the risk; tests/test_host_scenario_bound.py)
     res["scenario_status"] (0 = within the bound the sample size was chosen for, 1 = support exceeded: no certificate, 2 = a stage's
     scenario halfspaces contradicted each other -- an empty polygon; res["empty_polygon_stages"] counts them) -- a solver
     with status 1 is then not eligible as the best one."""

@@ -69,6 +69,7 @@ void orc_problem_init_ex(orc_problem *pb, int N, int S, int n_lin, int M, int n_
     pb->ipm_thr0 = 1e-2;
     pb->ipm_tau = 0.999;
     pb->erk_steps = 3;            /* generate_acados_solver.py:150 */
+    pb->cost_model = 0;
     /* solver_model.py:204-205 ContouringSecondOrderUnicycleModel bounds, order [a,w,x,y,psi,v,spline] */
     const double lb[ORC_NV] = {-2.0, -0.8, -2000.0, -2000.0, -M_PI * 4, -0.01, -1.0};
     const double ub[ORC_NV] = {2.0, 0.8, 2000.0, 2000.0, M_PI * 4, 3.0, 10000.0};
@@ -98,6 +99,12 @@ static jet seg_deriv(const seg_t *sg, jet s)
     r = jet_add(r, jet_scale(t, 2.0 * sg->b));
     return jet_addc(r, sg->c);
 }
+/* SplineSegment.deriv2 (spline.py:24-26) */
+static jet seg_deriv2(const seg_t *sg, jet s)
+{
+    jet t = jet_addc(s, -sg->start);
+    return jet_addc(jet_scale(t, 6.0 * sg->a), 2.0 * sg->b);
+}
 /* Spline.__init__ lambdas (spline.py:37): 1/(1+exp((s - start_i + 0.02)/0.1)), i = 1..S-1 */
 static jet glue_lambda(double start_i, jet s)
 {
@@ -106,11 +113,12 @@ static jet glue_lambda(double start_i, jet s)
 }
 /* Spline.at / Spline.deriv (spline.py:39-50): the SAME blend is applied to values and to segment
  * derivatives (deriv is not d/ds of at). */
+/* deriv = 2: Spline.deriv2 (spline.py:52-56), again the same blend, on the segments' second derivatives */
 static jet spline_blend(const seg_t *sg, const jet *lam, int S, jet s, int deriv)
 {
-    jet value = deriv ? seg_deriv(&sg[S - 1], s) : seg_at(&sg[S - 1], s);
+    jet value = deriv == 2 ? seg_deriv2(&sg[S - 1], s) : deriv ? seg_deriv(&sg[S - 1], s) : seg_at(&sg[S - 1], s);
     for (int k = S - 1; k >= 1; k--) {
-        jet prev = deriv ? seg_deriv(&sg[k - 1], s) : seg_at(&sg[k - 1], s);
+        jet prev = deriv == 2 ? seg_deriv2(&sg[k - 1], s) : deriv ? seg_deriv(&sg[k - 1], s) : seg_at(&sg[k - 1], s);
         jet one_minus = jet_addc(jet_neg(lam[k - 1]), 1.0);
         value = jet_add(jet_mul(lam[k - 1], prev), jet_mul(one_minus, value));
     }
@@ -173,6 +181,22 @@ void orc_stage_cost(const orc_problem *pb, const double *z, const double *p,
     jet dxn = jet_div(dx, norm), dyn = jet_div(dy, norm);
 
     jet ex = jet_sub(x, path_x), ey = jet_sub(y, path_y);
+    if (pb->cost_model == 1) {
+        /* CurvatureAwareContouringObjective.get_value (curvature_aware_contouring.py:48-105) at stage_idx = 1:
+         *   projection_ratio = 1 / (1 - ((x - X) X'' + (y - Y) Y''))                                  (:82-83, path.deriv2)
+         *   s_dot = v (cos psi X'n + sin psi Y'n) projection_ratio                                     (:84)
+         *   cost += contour ((x - X)^2 + (y - Y)^2) + velocity (s_dot - reference_velocity)^2         (:87-90)
+         * (`lag` is a parameter of the module but not used, :26; the terminal terms :93-105 are Forces-only like contouring.py:84-96) */
+        jet psi = jet_var(z[Z_PSI], Z_PSI);
+        jet ddx = spline_blend(sx, lam, pb->S, s, 2), ddy = spline_blend(sy, lam, pb->S, s, 2);
+        jet ratio = jet_recip(jet_addc(jet_neg(jet_add(jet_mul(ex, ddx), jet_mul(ey, ddy))), 1.0));
+        jet s_dot = jet_mul(jet_mul(v, jet_add(jet_mul(jet_cos(psi), dxn), jet_mul(jet_sin(psi), dyn))), ratio);
+        jet dist2 = jet_add(jet_sq(ex), jet_sq(ey));
+        cost = jet_add(cost, jet_scale(dist2, w_contour));
+        cost = jet_add(cost, jet_scale(jet_sq(jet_addc(s_dot, -v_ref)), w_v));
+        jet_out(&cost, val, grad, hess);
+        return;
+    }
     jet contour_error = jet_sub(jet_mul(dyn, ex), jet_mul(dxn, ey));  /* contouring.py:74 */
     jet lag_error = jet_add(jet_mul(dxn, ex), jet_mul(dyn, ey));      /* contouring.py:75 */
     cost = jet_add(cost, jet_scale(jet_sq(lag_error), w_lag));        /* :77 */

@@ -80,6 +80,11 @@ typedef struct {
      * textbook interior-point constants (0.995, mu0 = thr0 = 1) to show that its RTI iterate -- which tests/independent_rti.py
      * pins with an active-set QP solver -- does not depend on the constants the kernels were tuned with (0.999, 0.01, 0.01). */
     double ipm_tau;
+    /* 0: ContouringModule (contouring.py:48-98: lag / contour errors along the path's tangent frame);
+     * 1: CurvatureAwareContouringModule (curvature_aware_contouring.py:48-105: squared distance to the path point + tracking of the
+     *    projected path velocity s_dot) -- BASELINE configs[2] "CA-MPC".  Same parameter map (its C++ side leaves velocity /
+     *    reference_velocity to MPCBaseModule, curvature_aware_contouring.cpp:15-49), same model (s' = v, SURVEY Appendix D-8 route 1). */
+    int cost_model;
 } orc_problem;
 
 /* Fill sizes, default options and bounds for the Jackal contouring unicycle. */

@@ -182,6 +182,34 @@ int main(int argc, char **argv)
         ASSERT_TRUE(p->_info.pobj == p_ref3->_info.pobj);
         std::printf("batch contexts ok: capacity %d -> %d\n", cap0, c1.capacity());
     }
+    // ---- slot lifetime (round-3 advisor): a destroyed Solver releases its slot, the slot is CLEARED before it is reused (a new Solver
+    // -- also one that lands at the same address -- starts like a new capsule), and a Solver named twice is solved once ----
+    {
+        auto fresh = [&](int id, int like) { std::unique_ptr<Solver> s(new Solver(id)); *s = *batch[like]; return s; };
+        BatchContext c;
+        auto keep = fresh(60, 0);
+        keep->loadWarmstart();
+        // first tick of a FRESH solver on problem 1, alone in its own context: the reference value for "no inherited multipliers"
+        double first_tick;
+        { auto f = fresh(61, 1); BatchContext cf; f->loadWarmstart(); ASSERT_TRUE(Solver::solveBatch(cf, {f.get()})[0] == 1); first_tick = f->_info.pobj; }
+        int slot_a;
+        {
+            auto a = fresh(62, 1);
+            a->loadWarmstart();
+            ASSERT_TRUE(Solver::solveBatch(c, {keep.get(), a.get()})[1] == 1);
+            a->loadWarmstart();
+            ASSERT_TRUE(Solver::solveBatch(c, {keep.get(), a.get()})[1] == 1);        // second tick: a's slot now holds multipliers
+            slot_a = c.slotOf(a.get());
+            ASSERT_TRUE(slot_a == 1);
+        }                                                                           // ~Solver: the slot goes back to the context's pool
+        auto b = fresh(63, 1);
+        b->loadWarmstart(); keep->loadWarmstart();
+        std::vector<int> t = Solver::solveBatch(c, {keep.get(), b.get(), b.get()});    // (b twice: solved once, both mentions get its code)
+        ASSERT_TRUE(t.size() == 3 && t[1] == 1 && t[2] == t[1]);
+        ASSERT_TRUE(c.slotOf(b.get()) == slot_a);                                    // the freed slot, reused ...
+        ASSERT_TRUE(b->_info.pobj == first_tick);                                   // ... and cleared: bitwise a new capsule's first tick
+        std::printf("slot reuse ok: slot %d\n", slot_a);
+    }
     std::printf("solve ok: pobj %.6f %.6f %.6f\n", batch[0]->_info.pobj, batch[1]->_info.pobj, batch[2]->_info.pobj);
     return 0;
 }

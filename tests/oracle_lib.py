@@ -18,7 +18,7 @@ class Problem(C.Structure):
                 ("reg_eps", C.c_double), ("ipm_mu0", C.c_double), ("ipm_thr0", C.c_double),
                 ("erk_steps", C.c_int), ("lb", C.c_double * NV), ("ub", C.c_double * NV),
                 ("n_slk", C.c_int), ("slack", C.c_int), ("lb_slack", C.c_double), ("ub_slack", C.c_double),
-                ("n_gauss", C.c_int), ("ipm_tau", C.c_double)]
+                ("n_gauss", C.c_int), ("ipm_tau", C.c_double), ("cost_model", C.c_int)]
 
     @property
     def nxe(self):          # model dimensions (array strides): the slack build has one more state

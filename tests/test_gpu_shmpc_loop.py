@@ -84,23 +84,8 @@ def test_shmpc_closed_loop_on_device():
 
 
 def _mixture_prediction(obs_pos, n_extra, dt=0.2):
-    """A three-mode Gaussian-mixture prediction per obstacle (straight / veer left / veer right, like scenes.scenario_samples) as the
-    tensor the sampler reads: [M][3][N + n_extra][6] = (x, y, cos angle, sin angle, major, minor); radii = integrated standard
-    deviations growing along the horizon (data_preparation.cpp:170-186)."""
-    M, N, _ = obs_pos.shape
-    T = N + n_extra
-    vel = (obs_pos[:, 1] - obs_pos[:, 0]) / dt
-    steps = np.arange(T)
-    out = np.zeros((M, 3, T, 6))
-    for j, turn in enumerate((0.0, 0.06, -0.06)):
-        c, s_ = np.cos(turn), np.sin(turn)
-        v = np.stack([c * vel[:, 0] - s_ * vel[:, 1], s_ * vel[:, 0] + c * vel[:, 1]], 1)
-        out[:, j, :, 0:2] = obs_pos[:, :1, :] + v[:, None, :] * dt * steps[None, :, None]
-        ang = np.arctan2(v[:, 1], v[:, 0])
-        out[:, j, :, 2] = np.cos(ang)[:, None]; out[:, j, :, 3] = np.sin(ang)[:, None]
-        out[:, j, :, 4] = 0.05 * dt * np.sqrt(steps + 1.0)[None]        # along-track
-        out[:, j, :, 5] = 0.03 * dt * np.sqrt(steps + 1.0)[None]        # cross-track
-    return out
+    from mpc_planner_amd import scenes
+    return scenes.mixture_prediction(obs_pos, n_extra, dt)
 
 
 def test_device_sampler_and_removal_match_host_mirrors():

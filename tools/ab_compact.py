@@ -19,13 +19,12 @@ ap = argparse.ArgumentParser()
 ap.add_argument("ref", nargs="?", default="")
 ap.add_argument("--scenes", type=int, default=512)
 ap.add_argument("--per-cu", default="8")
-ap.add_argument("--teams", default="1,2,4")
 a = ap.parse_args()
 dims_kw = dict(N=20, S=5, n_lin=8, M=8)
 
 
 def run(lib, env, batch, reps=5):
-    for k in ("TMPC_NO_COMPACT", "TMPC_COMPACT_PER_CU", "TMPC_TEAM"):
+    for k in ("TMPC_NO_COMPACT", "TMPC_COMPACT_PER_CU"):
         os.environ.pop(k, None)
     os.environ.update(env)
     B = batch["xinit"].shape[0]
@@ -36,8 +35,7 @@ def run(lib, env, batch, reps=5):
 
 
 small = scenes.make_batch(range(700, 764), N=20, M=8, B=64)
-variants = [("new_fast", solver.LIB_PATH, {"TMPC_NO_COMPACT": "1"}), ("new_compact", solver.LIB_PATH, {"TMPC_TEAM": "1"}),
-            ("new_team2", solver.LIB_PATH, {"TMPC_TEAM": "2"}), ("new_team4", solver.LIB_PATH, {"TMPC_TEAM": "4"})]
+variants = [("new_fast", solver.LIB_PATH, {"TMPC_NO_COMPACT": "1"}), ("new_compact", solver.LIB_PATH, {})]
 if a.ref:
     variants.insert(0, ("ref", os.path.abspath(a.ref), {}))
 base = None
@@ -54,12 +52,12 @@ B = big["xinit"].shape[0]
 r0, ms0 = run(solver.LIB_PATH, {"TMPC_NO_COMPACT": "1"}, big, reps=3)
 print(json.dumps(dict(what="throughput", variant="new_fast", B=B, kernel_ms=ms0, solves_per_s=B / ms0 * 1e3)), flush=True)
 rc = None
-for team in a.teams.split(","):
-    for pc in a.per_cu.split(","):
-        r1, ms1 = run(solver.LIB_PATH, {"TMPC_COMPACT_PER_CU": pc, "TMPC_TEAM": team}, big, reps=3)
+for pc in a.per_cu.split(","):
+    if True:
+        r1, ms1 = run(solver.LIB_PATH, {"TMPC_COMPACT_PER_CU": pc}, big, reps=3)
         if rc is None:
             rc = r1
         same = all(np.array_equal(rc[k], r1[k], equal_nan=True) for k in rc)
-        print(json.dumps(dict(what="throughput", variant=f"team {team}, workgroups per CU <= {pc}", B=B, kernel_ms=ms1, solves_per_s=B / ms1 * 1e3,
+        print(json.dumps(dict(what="throughput", variant=f"compact, workgroups per CU <= {pc}", B=B, kernel_ms=ms1, solves_per_s=B / ms1 * 1e3,
                               identical_to_first_compact=bool(same), exit_codes_equal_fast=bool(np.array_equal(r0["exit_code"], r1["exit_code"])),
                               ipm_iters_equal_fast=bool(np.array_equal(r0["qp_iter_total"], r1["qp_iter_total"])), speedup_vs_fast=ms0 / ms1)), flush=True)
