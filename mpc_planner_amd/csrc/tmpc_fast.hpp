@@ -120,8 +120,8 @@ struct Solo {
 
 // Latency mode 2: the Newton systems go through the parallel-in-time solve (tmpc_scan.hpp) instead of the Riccati recursion.  Same
 // operands in LDS (Hh, [B A], gh, rb), same results (dv, dpi); Hh is left as it is (ipm_fast rebuilds it every iteration anyway).
-template <int SL, bool TF = false>                  // SL: lanes per stage of the Newton solve's stage phases: 3 (N <= 20) or 2 (N <= 31);
-struct ScanSoloT {                                   // TF: two-front block Cholesky of the multiplier blocks (tmpc_btc.hpp) instead of the cyclic reduction
+template <int SL>                                    // lanes per stage of the Newton solve's stage phases: 3 (N <= 20) or 2 (N <= 31)
+struct ScanSoloT {
     static constexpr int NQ = 1;
     __device__ __forceinline__ bool alive() const { return true; }
     __device__ __forceinline__ void sync() const { __syncthreads(); }
@@ -135,7 +135,7 @@ struct ScanSoloT {                                   // TF: two-front block Chol
         bool bad = false;
         if (NTH == 64 || (tl >> 6) == sw) {
             const scan::ViewT<SL> V{L.Hh, L.BA, L.gh, L.rb, L.dv, L.dpi, L.scan + d.N * NP28, d.N};      // (behind the W shares of the two-wave linearisation)
-            bad = scan::factor<SL, TF>(V, tl & 63);
+            bad = scan::factor(V, tl & 63);
             if (NTH > 64 && (tl & 63) == 0) L.scr[63] = bad ? 1.0 : 0.0;
         }
         __syncthreads();
@@ -148,13 +148,12 @@ struct ScanSoloT {                                   // TF: two-front block Chol
         asm volatile("" : "+v"(tl));
         if (NTH == 64 || (tl >> 6) == sw) {
             const scan::ViewT<SL> V{L.Hh, L.BA, L.gh, L.rb, L.dv, L.dpi, L.scan + d.N * NP28, d.N};      // (behind the W shares of the two-wave linearisation)
-            scan::solve<SL, TF>(V, tl & 63, phase == 1);     // the predictor's right-hand side went through the factorisation
+            scan::solve(V, tl & 63, phase == 1);     // the predictor's right-hand side went through the factorisation
         }
         __syncthreads();
     }
 };
 using ScanSolo = ScanSoloT<3>;
-using BtcSolo = ScanSoloT<3, true>;
 
 template <int NLIN, int MM, int LPS, int NTH, bool CP, typename PF, typename TEAM = Solo>
 __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, int *iters_out, PF &pf,

@@ -373,26 +373,21 @@ __device__ __forceinline__ bool reduce(const ViewT<SL> &V, int lane)
     fence();
     return bad;
 }
-}  // namespace scan
-}  // namespace tmpc
-#include "tmpc_btc.hpp"      // reduce_twofront / substitute_twofront: the two-front block Cholesky of the same blocks
-namespace tmpc {
-namespace scan {
-
 // Factorisation: chol(H_k) -> V.Ls, the reduced blocks -> V.blk.  Returns true (wave-uniform) on a non-positive pivot anywhere.
-// TF: the blocks are factorised by the two-front block Cholesky (tmpc_btc.hpp) instead of the cyclic reduction.
-template <int SL, bool TF = false>
+// (Round 4 measured a second factorisation of the same blocks -- a two-front block Cholesky on two DPP rows, a dozen registers and 45
+// doubles per block instead of ~100 and 95 -- correct, but its 10 sequential 5 x 5 steps are a longer chain than the 5 levels here:
+// +22 % per tick; profiles/round4_b_parallel_in_time_one_wave_and_twofront.json, HISTORY.md.)
+template <int SL>
 __device__ __forceinline__ bool factor(const ViewT<SL> &V, int lane)
 {
     bool bad = stage_phase(V, lane);
-    if constexpr (TF) bad |= reduce_twofront(V, lane);
-    else bad |= reduce(V, lane);
+    bad |= reduce(V, lane);
     return __any(bad);
 }
 
 // Solve with the factor of the last factor(): V.dv, V.dpi.  pred: the right-hand side is the one factor() saw (its P_k g_k is in
 // LDS already); otherwise (V.gh changed since: the corrector) P_k g_k is recomputed, one lane per stage.  V.rb as at factor().
-template <int SL, bool TF = false>
+template <int SL>
 __device__ __forceinline__ void solve(const ViewT<SL> &V, int lane, bool pred)
 {
     constexpr int CL = Cfg<SL>::CL, ZL = Cfg<SL>::ZL;
@@ -437,8 +432,6 @@ __device__ __forceinline__ void solve(const ViewT<SL> &V, int lane, bool pred)
     }
     fence();
     SCAN_T(5);
-    if constexpr (TF) substitute_twofront(V, lane);
-    else {
     const int m = lane / 5, i5 = lane - 5 * m;              // one lane per row of a block: 12 blocks per pass
 #pragma unroll 1
     for (int s = 1; s < N; s *= 2) {                         // forward elimination: beta_{o -+ s} -= W^T beta_o
@@ -493,7 +486,6 @@ __device__ __forceinline__ void solve(const ViewT<SL> &V, int lane, bool pred)
             if (act) blk[o * BS + OB + i5] = has_r ? x + y : x;  // (a lane reads and replaces its own entry of beta_o only)
         }
         fence();
-    }
     }
     SCAN_T(8);
     // dv_k = -P_k g_k - (P_k F_k^T) pi_k + (P_k E^T) pi_{k-1} from the columns the stage phase left in LDS: every lane of a stage sums its own

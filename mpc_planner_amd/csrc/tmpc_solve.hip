@@ -1075,10 +1075,6 @@ static SolveKernel pick_scan_kernel(const Dims &d, int *threads, int *sl)
         return (SolveKernel)tmpc_solve_fast_kernel<-1, 12, 4, 128, false, ScanSoloT<2>>;
     }
     const char *w = getenv("TMPC_SCAN_WAVES");               // A/B: "1" = one wave per trajectory
-    if (getenv("TMPC_SCAN_TWOFRONT") && d.n_up == 8 && d.M == 8) {       // A/B: two-front block Cholesky instead of the cyclic reduction (tmpc_btc.hpp)
-        if (d.N <= 2 * (64 / 6) && !(w && atoi(w) == 1)) { *threads = 128; return (SolveKernel)tmpc_solve_fast_kernel<8, 8, 6, 128, false, BtcSolo>; }
-        *threads = 64; return (SolveKernel)tmpc_solve_fast_kernel<8, 8, 3, 64, false, BtcSolo>;
-    }
     if (d.n_up == 8 && d.M == 8 && d.N <= 2 * (64 / 6) && !(w && atoi(w) == 1)) { *threads = 128; return (SolveKernel)tmpc_solve_fast_kernel<8, 8, 6, 128, false, ScanSolo>; }
     if (d.n_up == 8 && d.M == 8) { *threads = 64; return (SolveKernel)tmpc_solve_fast_kernel<8, 8, 3, 64, false, ScanSolo>; }
     if (d.N <= 2 * (64 / 6) && d.n_up + d.M + 14 <= 6 * 9) {     // every other row mix of the one-wave shapes (cfg 1, cfg 4, cfg 5, ...): runtime row counts, two waves

@@ -31,5 +31,8 @@ typedef struct {
 } orc_qp_sol;
 
 void orc_qp_solve(const orc_qp *qp, orc_qp_sol *sol, int iter_max, double tol, double mu0, double thr0, double tau);
+/* warm: 0 cold start; 1 primal start from `sol` as it stands (the previous QP's solution); 2 primal and dual (pi, lam, t) from `sol`.
+ * init_box: cold / primal start moved into the interior of the box rows by thr0 (HPIPM's d_ocp_qp_init_var). */
+void orc_qp_solve_ex(const orc_qp *qp, orc_qp_sol *sol, int iter_max, double tol, double mu0, double thr0, double tau, int warm, int init_box);
 
 #endif

@@ -183,6 +183,23 @@ static double max_step(const orc_qp *qp, const orc_qp_sol *s, const ipm_ws *w)
 
 void orc_qp_solve(const orc_qp *qp, orc_qp_sol *s, int iter_max, double tol, double mu0, double thr0, double tau)
 {
+    orc_qp_solve_ex(qp, s, iter_max, tol, mu0, thr0, tau, 0, 0);
+}
+
+/* A box row has exactly one non-zero coefficient, 1.0 (build_qp writes them after the general rows). */
+static int box_var(const orc_qp *qp, int k, int i)
+{
+    int var = -1;
+    for (int j = 0; j < ORC_NV; j++) {
+        if (qp->C[k][i][j] == 0.0) continue;
+        if (qp->C[k][i][j] != 1.0 || var >= 0) return -1;
+        var = j;
+    }
+    return var;
+}
+
+void orc_qp_solve_ex(const orc_qp *qp, orc_qp_sol *s, int iter_max, double tol, double mu0, double thr0, double tau, int warm, int init_box)
+{
     const int N = qp->N;
     /* per-thread workspace, reused across solves (a calloc/free pair per QP makes hundreds of OpenMP threads fight over
      * the kernel's page-fault path and says nothing about the algorithm) */
@@ -191,11 +208,38 @@ void orc_qp_solve(const orc_qp *qp, orc_qp_sol *s, int iter_max, double tol, dou
     ipm_ws *w = tls_w;
     memset(w, 0, sizeof(ipm_ws));
     int m = 0;
-    /* cold start: v = 0 (dx_0 = given), pi = 0, t = max(residual, thr0), lam = mu0 / t */
-    memset(s->v, 0, sizeof s->v); memset(s->pi, 0, sizeof s->pi);
+    /* cold start: v = 0 (dx_0 = given), pi = 0, t = max(residual, thr0), lam = mu0 / t.
+     * warm >= 1: v of the previous QP (dx_0 is this QP's); warm == 2: pi, lam, t of the previous QP as well. */
+    if (warm < 1) memset(s->v, 0, sizeof s->v);
+    if (warm < 2) memset(s->pi, 0, sizeof s->pi);
     for (int j = 0; j < ORC_NX; j++) s->v[0][ORC_NU + j] = qp->dx0[j];
+    s->v[N][0] = s->v[N][1] = 0.0;
+    if (init_box && warm < 2) {
+        /* HPIPM d_ocp_qp_init_var: a primal start that violates (or touches) a box by less than thr0 is moved inside by thr0, or to
+         * the middle of the box when it is narrower than 2 thr0.  Box rows come in (lower, upper) pairs per variable. */
+        for (int k = 0; k <= N; k++)
+            for (int i = 0; i + 1 < qp->nrow[k]; i++) {
+                const int var = box_var(qp, k, i);
+                if (var < 0 || box_var(qp, k, i + 1) != var || qp->sgn[k][i] != 1.0 || qp->sgn[k][i + 1] != -1.0) continue;
+                if (k == 0 && var >= ORC_NU) continue;                              /* dx_0 is fixed */
+                const double lb = qp->beta[k][i], ub = qp->beta[k][i + 1];
+                double x = s->v[k][var];
+                if (x - lb < thr0) x = (ub - (lb + thr0) < thr0) ? 0.5 * (lb + ub) : lb + thr0;
+                else if (ub - x < thr0) x = ub - thr0;
+                s->v[k][var] = x;
+                i++;
+            }
+    }
     for (int k = 0; k <= N; k++)
         for (int i = 0; i < qp->nrow[k]; i++, m++) {
+            if (warm == 2) {
+                /* a converged QP hands over t lam ~ 1e-10: started from there the method stalls on most QPs (measured: 14 % of the
+                 * bench trajectories keep their full iteration budget with a 1e-12 floor, 95 % with 1e-6) -- the floor plays the role
+                 * of HPIPM's t_min / lam_min arguments */
+                if (!(s->t[k][i] > 1e-6)) s->t[k][i] = 1e-6;
+                if (!(s->lam[k][i] > 1e-6)) s->lam[k][i] = 1e-6;
+                continue;
+            }
             double cv = 0.0;
             for (int j = 0; j < ORC_NV; j++) cv += qp->C[k][i][j] * s->v[k][j];
             double r = qp->sgn[k][i] * (cv - qp->beta[k][i]);

@@ -55,6 +55,12 @@ void orc_problem_set_gaussian(orc_problem *pb, int n_gauss)
 
 void orc_problem_init(orc_problem *pb, int N, int S, int n_lin, int M) { orc_problem_init_ex(pb, N, S, n_lin, M, 0); }
 
+void orc_problem_set_hpipm_like(orc_problem *pb, int warm_start)
+{
+    pb->ipm_mu0 = 10.0; pb->ipm_thr0 = 0.1; pb->ipm_tau = 0.995; pb->ipm_init_box = 1;
+    pb->qp_warm_start = warm_start;
+}
+
 void orc_problem_init_ex(orc_problem *pb, int N, int S, int n_lin, int M, int n_slk)
 {
     pb->N = N; pb->S = S; pb->n_lin = n_lin; pb->M = M; pb->n_slk = n_slk; pb->slack = ORC_SLACK; pb->n_gauss = 0;
@@ -70,6 +76,7 @@ void orc_problem_init_ex(orc_problem *pb, int N, int S, int n_lin, int M, int n_
     pb->ipm_tau = 0.999;
     pb->erk_steps = 3;            /* generate_acados_solver.py:150 */
     pb->cost_model = 0;
+    pb->qp_warm_start = 0; pb->ipm_init_box = 0;
     /* solver_model.py:204-205 ContouringSecondOrderUnicycleModel bounds, order [a,w,x,y,psi,v,spline] */
     const double lb[ORC_NV] = {-2.0, -0.8, -2000.0, -2000.0, -M_PI * 4, -0.01, -1.0};
     const double ub[ORC_NV] = {2.0, 0.8, 2000.0, 2000.0, M_PI * 4, 3.0, 10000.0};

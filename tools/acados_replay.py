@@ -3,7 +3,7 @@
 has what this build machine lacks: acados + acados_template + casadi, and a checkout of tud-amr/mpc_planner).
 
     export ACADOS_SOURCE_DIR=...; export LD_LIBRARY_PATH=$ACADOS_SOURCE_DIR/lib
-    python tools/acados_replay.py /path/to/mpc_planner [cfg2 cfg1 ...]
+    python tools/acados_replay.py /path/to/mpc_planner [--qp-tol 1e-9] [cfg2 cfg1 ...]
 
 For every fixture of the requested configurations it builds the reference's module stack with the reference's own scripts
 (mpc_planner_jackalsimulator/scripts/generate_jackalsimulator_solver.py: configuration_basic / configuration_tmpc /
@@ -16,6 +16,13 @@ It prints, per fixture, max relative per-stage differences to the three stored o
 active-set RTI).  Expected if U1-U9 hold: differences of the order the stored outputs have among themselves (<= ~1e-3 at
 qp_tol 1e-5, see tests/test_independent_rti.py); a structural disagreement (terminal cost, h at node 0, bounds at node N,
 stage-cost scaling) shows up as 1e-2 or more and names the assumption to fix.
+It ends with a PASS / FAIL table at the tolerance that is certifiable for the chosen QP tolerance (round-3 verdict item 5):
+    --qp-tol 1e-9   (overrides the generator's qp_tol = 1e-5: the iterate no longer depends on how the QP solver reaches its tolerance)
+                    PASS <=> max relative per-stage difference to `oracle_qp_tol_1e_9` and `active_set_rti` <= 1e-5 -- the north star's 1e-4 with a
+                    decade of margin; what this repository observes between its own two independent implementations there is 2e-7;
+    default 1e-5    PASS <=> difference to `oracle_qp_tol_1e_5` <= 2e-3: the spread that correct implementations of the reference's configuration
+                    show among themselves at that tolerance (profiles/round4_c_iterate_spread.json: 1e-4 .. 1e-3 on a few per cent of the
+                    trajectories); a pass here says "no structural disagreement (U1-U9)", not "1e-4".
 NOT run in this repository's CI: none of acados / casadi / the reference checkout exist on the build or GPU machines."""
 import json
 import os
@@ -25,6 +32,9 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 FIX = os.path.join(os.path.dirname(HERE), "tests", "golden", "solve_fixtures.json")
+
+
+QP_TOL = None            # --qp-tol: overrides the reference generator's qp_tol (generate_acados_solver.py:162) for the tight-tolerance check
 
 
 def build_reference_solver(ref, case):
@@ -50,6 +60,9 @@ def build_reference_solver(ref, case):
              "cfg5": "configuration_safe_horizon"}[cfg]
     model, modules = getattr(gen, stack)(settings)
     solver, _sim = generate_acados_solver(modules, settings, model, False)
+    if QP_TOL is not None:                                         # the generator hard-codes qp_tol = 1e-5 (:162); the solver object takes the override
+        for opt in ("qp_tol_stat", "qp_tol_eq", "qp_tol_ineq", "qp_tol_comp"):
+            solver.options_set(opt, QP_TOL)
     pm = settings["params"]._params                                # util/parameters.py:13,44: name -> index
     for name, idx in (case["parameter_map"] or {}).items():       # the fixture's rows must be in the generator's own order
         if pm.get(name) != idx:
@@ -83,8 +96,14 @@ def replay(solver, case, n_sqp=10):
 def main():
     if len(sys.argv) < 2:
         raise SystemExit(__doc__)
-    ref = os.path.abspath(sys.argv[1])
-    want = set(sys.argv[2:]) or None
+    global QP_TOL
+    args = sys.argv[1:]
+    if "--qp-tol" in args:
+        i = args.index("--qp-tol"); QP_TOL = float(args[i + 1]); del args[i:i + 2]
+    ref = os.path.abspath(args[0])
+    want = set(args[1:]) or None
+    tight = QP_TOL is not None and QP_TOL <= 1e-8
+    table = []
     cases = [c for c in json.load(open(FIX))["cases"] if want is None or c["config"] in want]
     solvers = {}
     for c in cases:
@@ -93,13 +112,24 @@ def main():
         xt, ut, cost, status = replay(solvers[c["config"]], c)
         N, nx = c["N"], c["nx"]
         line = [f"{c['config']} scene {c['scene']} trajectory {c['trajectory']}: acados status {status}, cost {cost:.9g}"]
+        diff = {}
         for key in ("oracle_qp_tol_1e_5", "oracle_qp_tol_1e_9", "active_set_rti"):
             xr = np.array(c[key]["xtraj"]).reshape(N + 1, nx); ur = np.array(c[key]["utraj"]).reshape(N, 2)
             sx = np.maximum(np.abs(xr).max(axis=1, keepdims=True), 1.0); su = np.maximum(np.abs(ur).max(axis=1, keepdims=True), 1.0)
+            diff[key] = max(float((np.abs(xt - xr) / sx).max()), float((np.abs(ut - ur) / su).max()))
             line.append(f"{key}: x {(np.abs(xt - xr) / sx).max():.2e} u {(np.abs(ut - ur) / su).max():.2e} "
                         f"cost {abs(cost - c[key]['pobj']) / max(1.0, abs(c[key]['pobj'])):.2e}")
         print(" | ".join(line))
+        worst = max(diff["oracle_qp_tol_1e_9"], diff["active_set_rti"]) if tight else diff["oracle_qp_tol_1e_5"]
+        table.append((f"{c['config']} scene {c['scene']} trajectory {c['trajectory']}", worst, worst <= (1e-5 if tight else 2e-3)))
+    tol = 1e-5 if tight else 2e-3
+    print(f"\n{'fixture':<40} {'max rel. per stage':>20}   verdict at {tol:g} ({'acados qp_tol ' + str(QP_TOL) + ': vs oracle 1e-9 and the active-set RTI' if tight else 'acados qp_tol 1e-5: vs oracle 1e-5'})")
+    for name, w, ok in table:
+        print(f"{name:<40} {w:>20.3e}   {'PASS' if ok else 'FAIL'}")
+    n_fail = sum(not ok for _, _, ok in table)
+    print(f"\n{'PASS' if n_fail == 0 else 'FAIL'}: {len(table) - n_fail} / {len(table)} fixtures within {tol:g}")
+    return 1 if n_fail else 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())
