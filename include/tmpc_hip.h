@@ -137,7 +137,10 @@ int tmpc_set_slots(tmpc_handle *h, const int32_t *slots);
  * modules write the same values into each (:312-318).  The kernels then read everything but those rows from entry base_of[b]: a set's
  * 64 copies of the obstacle / spline / weight rows are fetched once instead of 64 times (the parameter rows are 2/3 of the path's
  * algorithmic bytes, and at eight trajectories per CU they no longer fit the L2 next to the solve's workspace).  The CALLER guarantees
- * the equality; the map belongs to the batch it was given for: it stays in force until it is replaced, cleared (NULL) or a tmpc_set_batch* call
+ * the equality -- or, equivalently for the kernels that honour the hint, simply does not maintain the copies: a caller that keeps its
+ * parameter tensor on the device writes a tick's shared rows ONCE per set, into entry base_of[b] (what bench.py's end-to-end step does), and the
+ * other entries' shared columns are never read.  (The lane kernels and generated solvers ignore the hint and read every entry's own rows: such
+ * a caller must not use them.)  The map belongs to the batch it was given for: it stays in force until it is replaced, cleared (NULL) or a tmpc_set_batch* call
  * names new inputs (kernels of this library that rewrite a batch's rows in place -- tmpc_linearize_topology, tmpc_scenario_halfspaces --
  * touch the entries' own rows only and keep it valid).  Ignored by the lane kernels
  * (tmpc_set_throughput_mode) and by generated solvers. */
@@ -212,6 +215,14 @@ int tmpc_pack_records(tmpc_handle *h, void *d_records, const void *d_guidance_id
  * (init 1e10, strict '<').  d_best: device int32[n_scenes], -1 if none.  Runs on the handle's stream. */
 int tmpc_select_best_records(tmpc_handle *h, const void *d_records, int32_t n_ranks, int32_t n_scenes,
                              int32_t per_rank, void *d_best);
+
+/* The winners' trajectories in one compact buffer -- what GuidanceConstraints::optimize copies from the best planner into the main solver
+ * (`_solver->_output = best_solver->_output`, guidance_constraints.cpp:382-384), for every set of the launch at once, so that ONE small
+ * device-to-host copy brings a tick's (or many ticks') results back.  d_best: i32 [n_sets] as written by tmpc_select_best_records (index
+ * inside the set, -1: no successful trajectory).  The batch holds the entries [index_offset, index_offset + set_size) of every set (one
+ * rank's share; index_offset = rank * per_rank, 0 on one GPU): a winner outside that range is another rank's and its rows are left untouched,
+ * a set without a winner gets NaNs.  d_xtraj f64 [n_sets][(N + 1) nx], d_utraj f64 [n_sets][N nu] (device).  Runs on the handle's stream. */
+int tmpc_gather_best(tmpc_handle *h, const void *d_best, int32_t n_sets, int32_t set_size, int32_t index_offset, void *d_xtraj, void *d_utraj);
 
 /* Per-launch timing: when enabled, every tmpc_solve is bracketed by HIP events recorded on the handle's stream.
  * tmpc_get_timings synchronises and returns the durations [ms] of the launches since enable/last read. */

@@ -66,6 +66,19 @@ __global__ void tmpc_select_best_records_kernel(const tmpc_record *rec, int n_ra
     if (threadIdx.x == 0) best_out[s] = idx;
 }
 
+// the winners' trajectories, one workgroup per set (guidance_constraints.cpp:382-384 for every set of the launch)
+__global__ void tmpc_gather_best_kernel(const int *best, int set_size, int index_offset, int nx_doubles, int nu_doubles, const double *xtraj,
+                                        const double *utraj, double *out_x, double *out_u)
+{
+    const int s = blockIdx.x;
+    const int g = best[s], loc = g - index_offset;
+    if (g >= 0 && (loc < 0 || loc >= set_size)) return;                 // another rank's winner
+    const size_t b = (size_t)s * set_size + (g >= 0 ? loc : 0);
+    const double nan = __builtin_nan("");
+    for (int e = threadIdx.x; e < nx_doubles; e += blockDim.x) out_x[(size_t)s * nx_doubles + e] = g >= 0 ? xtraj[b * nx_doubles + e] : nan;
+    for (int e = threadIdx.x; e < nu_doubles; e += blockDim.x) out_u[(size_t)s * nu_doubles + e] = g >= 0 ? utraj[b * nu_doubles + e] : nan;
+}
+
 // ---- f-1: LinearizedConstraints::update + setParameters on device (linearized_constraints.cpp:49-189) ----------
 // one thread per (trajectory, stage)
 // n_obs dynamic obstacles (rows 0 .. n_obs-1), then n_static static halfspaces per stage copied as they are (linearized_constraints.cpp:

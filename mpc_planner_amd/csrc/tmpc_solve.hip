@@ -1622,6 +1622,19 @@ int tmpc_select_best_records(tmpc_handle *h, const void *d_records, int32_t n_ra
     return TMPC_OK;
 }
 
+int tmpc_gather_best(tmpc_handle *h, const void *d_best, int32_t n_sets, int32_t set_size, int32_t index_offset, void *d_xtraj, void *d_utraj)
+{
+    if (!h || !d_best || !d_xtraj || !d_utraj || n_sets <= 0 || set_size <= 0 || index_offset < 0 || (int64_t)n_sets * set_size > h->B) {
+        if (h) h->err = "tmpc_gather_best: bad argument (n_sets x set_size entries of the current batch)";
+        return TMPC_ERR_INVALID;
+    }
+    TMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    hipLaunchKernelGGL(tmpc::tmpc_gather_best_kernel, dim3(n_sets), dim3(64), 0, h->stream, (const int *)d_best, set_size, index_offset,
+                       (h->d.N + 1) * tmpc::ext_nx(h->d), h->d.N * tmpc::NU, h->xtraj, h->utraj, (double *)d_xtraj, (double *)d_utraj);
+    TMPC_HIP_CHECK(h, hipGetLastError());
+    return TMPC_OK;
+}
+
 int tmpc_linearize_topology_ex(tmpc_handle *h, const void *d_obstacle_pos, int32_t n_obstacles, const void *d_obstacle_radius,
                                const void *d_static_halfspaces, int32_t n_static, const void *d_scene_of, const void *d_state_x,
                                double robot_radius, const void *d_is_original)

@@ -335,4 +335,10 @@ def make_batch(scene_indices, workers=1, **kw):
     for key in ("xinit", "x0", "params", "guidance_id"):
         out[key] = np.concatenate([s[key] for s in scenes], 0)
     out["scene_of"] = np.concatenate([np.full(len(s["xinit"]), i, np.int32) for i, s in enumerate(scenes)])
+    # what a control tick hands over per scene / per trajectory (the end-to-end step of bench.py uploads exactly these):
+    # obstacle predictions [n_scenes][M][N][2], guidance position / velocity at t = k dt [B][N+1][2]
+    if all(s.get("guidance_pos") is not None for s in scenes):
+        out["guidance_pos"] = np.concatenate([s["guidance_pos"] for s in scenes], 0)
+        out["guidance_vel"] = np.concatenate([s["guidance_vel"] for s in scenes], 0)
+    out["obstacle_pos"] = np.stack([s["obstacles"]["pos"] for s in scenes])
     return out

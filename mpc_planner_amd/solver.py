@@ -42,7 +42,7 @@ EXPORTS = ["tmpc_default_dims", "tmpc_default_dims_ex", "tmpc_create", "tmpc_des
            "tmpc_linearize_topology", "tmpc_scenario_halfspaces", "tmpc_scenario_support", "tmpc_warmstart", "tmpc_init_with_guidance",
            "tmpc_debug_get_x0", "tmpc_debug_get_params", "tmpc_set_throughput_mode", "tmpc_solve_iterations",
            "tmpc_reset_multipliers", "tmpc_get_stream", "tmpc_kernel_info", "tmpc_set_slots", "tmpc_set_param_sharing", "tmpc_copy_state", "tmpc_scenario_empty_stages", "tmpc_sample_scenarios",
-           "tmpc_scenario_discard", "tmpc_scenario_discarded", "tmpc_linearize_topology_ex", "tmpc_clear_slot"]
+           "tmpc_scenario_discard", "tmpc_scenario_discarded", "tmpc_linearize_topology_ex", "tmpc_clear_slot", "tmpc_gather_best"]
 
 class TmpcError(RuntimeError):
     pass
@@ -101,6 +101,8 @@ def load_library(path=None):
         lib.tmpc_scenario_discarded.argtypes = [vp, vp]
     if hasattr(lib, "tmpc_copy_state"):        # (absent from reference builds of earlier rounds used in A/B runs)
         lib.tmpc_copy_state.argtypes = [vp, vp]
+    if hasattr(lib, "tmpc_gather_best"):
+        lib.tmpc_gather_best.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int32, vp, vp]
     if hasattr(lib, "tmpc_clear_slot"):
         lib.tmpc_clear_slot.argtypes = [vp, C.c_int32]
     lib.tmpc_synchronize.argtypes = [vp]
@@ -328,6 +330,11 @@ class BatchedSolver:
     def select_best_records(self, d_records, n_ranks, n_scenes, per_rank, d_best):
         self._check(self.lib.tmpc_select_best_records(self._h, C.c_void_p(d_records), int(n_ranks), int(n_scenes),
                                                       int(per_rank), C.c_void_p(d_best)), "tmpc_select_best_records")
+
+    def gather_best(self, d_best, n_sets, set_size, d_xtraj, d_utraj, index_offset=0):
+        """The winners' trajectories of every set in one compact device buffer (tmpc_gather_best; raw device pointers)."""
+        self._check(self.lib.tmpc_gather_best(self._h, C.c_void_p(d_best), int(n_sets), int(set_size), int(index_offset),
+                                              C.c_void_p(d_xtraj), C.c_void_p(d_utraj)), "tmpc_gather_best")
 
     def linearize_topology(self, d_obstacle_pos, d_scene_of, d_state_x, robot_radius, d_is_original=None):
         """Device LinearizedConstraints::update + setParameters (raw device pointers); modifies the batch params in place."""
