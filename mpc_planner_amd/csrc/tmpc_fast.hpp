@@ -19,6 +19,12 @@ struct FastCfg {
     static constexpr int NH = RT ? 0 : NLIN + MM;
     static constexpr int NR = NH + 14;                 // general rows + 4 input-box rows + 10 state-box rows
     static constexpr int RPL = RT ? MM : (NR + LPS - 1) / LPS;   // rows per lane
+    // Lane c of a stage owns the rows c, c + LPS, c + 2 LPS, ...  For the tuned shapes the KIND of row slot S is mostly a compile-time fact:
+    // 0 = a general row (Jacobian in LDS, no box part) for every lane, 1 = a box row (one variable, no Jacobian) for every lane,
+    // 2 = depends on the lane (the slot that straddles the boundary) or on run-time row counts.  The row passes skip the part a slot
+    // cannot have: a box row loaded the zero triple and multiplied it through, a general row read a dummy variable and multiplied it by 0 --
+    // both add exact zeros, so dropping them changes no result bit (signed zeros aside).
+    template <int S> static constexpr int KIND = RT ? 2 : ((LPS * S + LPS - 1 < NH) ? 0 : ((LPS * S >= NH) ? 1 : 2));
 };
 
 __host__ __device__ inline int lds_doubles_fast(int N, int nh)
@@ -166,6 +172,13 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
     // compile-time constants for the tuned shapes, kernel arguments for runtime-shape instantiations
     const int NH = C::RT ? L.nh : C::NH, NR = NH + 14, NLIN_ = C::RT ? d.n_up : NLIN;
     constexpr bool DIET = (LPS == 6 && NLIN == 8) || OCC2;                // 256-register budget (two waves per SIMD): recompute per-row values instead of storing them
+    // ... the row steps dt too, unless the instantiation has room for them (round 4: the row-kind specialisation freed ~27 registers of the
+    // compact kernels; keeping dt saves three of the five evaluations of c . dv + r_d per row and interior-point iteration)
+#ifdef TMPC_COMPACT_RECOMPUTE_DT
+    constexpr bool DIET_DT = DIET;
+#else
+    constexpr bool DIET_DT = DIET && !(CP && !C::RT && RPL <= 10);
+#endif
     const int N = d.N;
     // Opaque copy of the lane id: keeps the compiler from hoisting this QP's per-row setup (masks, LDS addresses) out of
     // the RTI loop of the caller, where it would stay live across the register-hungry linearisation and be spilled.
@@ -181,7 +194,7 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
     // Two-waves-per-SIMD instantiations (256 registers): the lane's indices are made opaque again before every row pass, so that
     // the passes' per-row invariants (LDS addresses, sign constants) are recomputed there instead of being hoisted out of the
     // interior-point loop and kept live -- ~7 registers per row otherwise.
-#define ROW_PASS_BEGIN() do { if constexpr (OCC2) asm volatile("" : "+v"(k), "+v"(c), "+v"(kk), "+v"(sl_), "+v"(act), "+v"(box), "+v"(upper), "+v"(neg), "+v"(varpack)); } while (0)
+#define ROW_PASS_BEGIN() do { if constexpr (OCC2) asm volatile("" : "+v"(k), "+v"(c), "+v"(kk), "+v"(sl_), "+v"(act), "+v"(box), "+v"(upper), "+v"(varpack)); } while (0)
 #define stage_lane (sl_ != 0)
     const double m_rows = (double)(N * NH + 4 * N + 10 * (N - 1));
 
@@ -189,7 +202,7 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
     // per row: signed coefficients on (x, y, psi), signed rhs; box rows: sign in `upper`, variable index packed 3 bits/slot
     double sb[RPL];
     int didx_[DIET ? 1 : RPL];                      // row's Jacobian triple in L.D (box rows: the zero triple)
-    unsigned act = 0, box = 0, upper = 0, neg = 0;  // neg: row sign is -1 (upper-bounded rows)
+    unsigned act = 0, box = 0, upper = 0;
     unsigned long long varpack = 0;
 #pragma unroll
     for (int s = 0; s < RPL; s++) {
@@ -199,7 +212,6 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
             if (r < NH) {
                 const double sgn = (r < NLIN_) ? -1.0 : 1.0;    // topology / slack rows: upper bound 0; ellipsoids: lower bound 1
                 if constexpr (!DIET) didx_[s] = (k * NH + r) * 3;
-                if (r < NLIN_) neg |= 1u << s;
                 sb[s] = sgn * L.beta[k * NH + r];
                 act |= 1u << s;
             } else {
@@ -210,7 +222,7 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
                 double bnd = 0.0;
 #pragma unroll
                 for (int i = 0; i < NV; i++) if (i == vr) bnd = up ? d.ub[i] : d.lb[i];
-                box |= 1u << s; if (up) { upper |= 1u << s; neg |= 1u << s; }
+                box |= 1u << s; if (up) upper |= 1u << s;
                 varpack |= (unsigned long long)vr << (3 * s);
                 sb[s] = sgn * (bnd - L.z[k * NV + vr]);
                 if (q < 4 || k >= 1) act |= 1u << s;            // x_0 is fixed, not boxed
@@ -233,10 +245,34 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
         if constexpr (CP) return (stage_lane && r < NH && r >= L.n_pair) ? DIDX(s) + 2 : N * L.dstride + 2;
         return DIDX(s) + 2;
     };
-#define ROW_C(s) const double sg_ = (neg >> (s) & 1) ? -1.0 : 1.0; const double *Dr_ = L.D + DIDX(s); \
-    const double c0s = sg_ * Dr_[0], c1s = sg_ * Dr_[1], c2s = sg_ * L.D[DIDX2(s)];
 #define INVT(s) (LEAN ? rcp_nr(t[s]) : invt_[(LEAN ? 0 : (s))])
     auto CU = [&](int s) { return (box >> s & 1) ? ((upper >> s & 1) ? -1.0 : 1.0) : 0.0; };   // signed unit coefficient
+    // box slots of the tuned shapes: with q = r - NH the row's variable is q >> 1 (inputs q = 0..3 -> a, w; states q = 4..13 -> x .. spline) and
+    // its side q & 1 -- plain arithmetic on the lane's sub-index instead of the packed masks (which pure shapes then do not carry at all)
+    auto VARK = [&](auto s_) {
+        constexpr int s = decltype(s_)::value;
+        if constexpr (C::template KIND<s> == 1) return (c + LPS * s - C::NH) >> 1;
+        else return VAR(s);
+    };
+    auto CUK = [&](auto s_) {
+        constexpr int s = decltype(s_)::value;
+        if constexpr (C::template KIND<s> == 1) return ((c + LPS * s - C::NH) & 1) ? -1.0 : 1.0;
+        else return CU(s);
+    };
+    // SIGNED Jacobian of row slot s: the linearisation's sink stores sgn * D (fast layouts), box slots have none
+    auto coef = [&](auto s_, double &c0, double &c1, double &c2) {
+        constexpr int s = decltype(s_)::value;
+        if constexpr (C::template KIND<s> == 1) { c0 = 0.0; c1 = 0.0; c2 = 0.0; }
+        else { const double *Dr_ = L.D + DIDX(s); c0 = Dr_[0]; c1 = Dr_[1]; c2 = L.D[DIDX2(s)]; }
+    };
+    // c . w for row slot s and a stage vector w = (.., x, y, p at ZX, ZY, ZPSI ..): Jacobian part + box part, whichever the slot can have
+    auto rowdot = [&](auto s_, double c0, double c1, double c2, double x, double y, double pp, const double *vec) {
+        constexpr int s = decltype(s_)::value;
+        constexpr int K = C::template KIND<s>;
+        if constexpr (K == 0) return c0 * x + c1 * y + c2 * pp;
+        else if constexpr (K == 1) return CUK(s_) * vec[VARK(s_)];
+        else return c0 * x + c1 * y + c2 * pp + CU(s) * vec[VAR(s)];
+    };
     team.sync();                                             // staging is dead from here on
     // QP start: dz = 0 except dx_0 = xinit - x_0; duals 0
     for (int e = tid_q; e < (N + 1) * NV; e += NT) L.v[e] = 0.0;
@@ -247,20 +283,25 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
 
     ROW_PASS_BEGIN();
     double t[RPL], qt[RPL];
-    constexpr bool LEAN = RPL > 10 || (LPS == 6 && NLIN == 8) || OCC2;    // recompute 1/t instead of keeping it: many rows per lane, or the 256-register
+#ifdef TMPC_COMPACT_RECOMPUTE_INVT
+    constexpr bool LEAN = RPL > 10 || (LPS == 6 && NLIN == 8) || OCC2;
+#else
+    constexpr bool LEAN = RPL > 10 || (LPS == 6 && NLIN == 8) || (OCC2 && !(CP && !C::RT && RPL <= 10));    // recompute 1/t instead of keeping it: many rows per lane, or the 256-register
+#endif
                                                     // budget of the two-waves-per-SIMD instantiations
     double invt_[LEAN ? 1 : RPL];               // the row residual r_d = c.v - sb - t is recomputed where needed
     {
         const double vx = L.v[kk * NV + ZX], vy = L.v[kk * NV + ZY], vp = L.v[kk * NV + ZPSI];
-#pragma unroll
-        for (int s = 0; s < RPL; s++) {
-            ROW_C(s)
-            const double r0 = c0s * vx + c1s * vy + c2s * vp + CU(s) * L.v[kk * NV + VAR(s)] - sb[s];
+        static_for<0, RPL>([&](auto s_) {
+            constexpr int s = decltype(s_)::value;
+            double c0s, c1s, c2s;
+            coef(s_, c0s, c1s, c2s);
+            const double r0 = rowdot(s_, c0s, c1s, c2s, vx, vy, vp, L.v + kk * NV) - sb[s];
             t[s] = r0 > d.thr0 ? r0 : d.thr0;
             if constexpr (!LEAN) invt_[s] = rcp_nr(t[s]);
             lam[s] = (act >> s & 1) ? d.mu0 / t[s] : 0.0;
             qt[s] = 0.0;
-        }
+        });
     }
     // `active`: this trajectory's QP is still iterating.  One trajectory per workgroup (Solo): the loop ends with it.  Teams: the
     // trajectories of a workgroup iterate in lock step (the Riccati sweeps of all of them run in one wave), so a finished one
@@ -379,30 +420,35 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
             const double vx = L.v[kk * NV + ZX], vy = L.v[kk * NV + ZY], vp = L.v[kk * NV + ZPSI];
             double gs0 = 0, gs1 = 0, gs2 = 0, rs0 = 0, rs1 = 0, rs2 = 0;
             double h00 = 0, h10 = 0, h11 = 0, h20 = 0, h21 = 0, h22 = 0;
-#pragma unroll
-            for (int s = 0; s < RPL; s++) {
+            static_for<0, RPL>([&](auto s_) {
+                constexpr int s = decltype(s_)::value;
+                constexpr int K = C::template KIND<s>;
                 const bool a = act >> s & 1;
-                const double vv = L.v[kk * NV + VAR(s)];
-                const double cus = CU(s);
-                ROW_C(s)
-                const double r = c0s * vx + c1s * vy + c2s * vp + cus * vv - sb[s] - t[s];
+                double c0s, c1s, c2s;
+                coef(s_, c0s, c1s, c2s);
+                const double r = rowdot(s_, c0s, c1s, c2s, vx, vy, vp, L.v + kk * NV) - sb[s] - t[s];
                 const double rds = a ? r : 0.0;
                 const double comp = lam[s] * t[s];
                 const double dd = lam[s] * INVT(s);
                 const double w = dd * rds;
                 if (a) { res_d = fmax(res_d, fabs(r)); res_m = fmax(res_m, comp); mu += comp; }
-                gs0 += lam[s] * c0s; gs1 += lam[s] * c1s; gs2 += lam[s] * c2s;
-                rs0 += w * c0s; rs1 += w * c1s; rs2 += w * c2s;
-                const double d0 = dd * c0s, d1 = dd * c1s, d2 = dd * c2s;
-                h00 += d0 * c0s; h10 += d1 * c0s; h11 += d1 * c1s;
-                h20 += d2 * c0s; h21 += d2 * c1s; h22 += d2 * c2s;
-                if (a && (box >> s & 1)) {                                // box row: one variable
-                    const int vr = VAR(s);
-                    lds_add(&L.rg[k * NV + vr], -lam[s] * cus);
-                    lds_add(&L.gh[k * NV + vr], w * cus);
-                    lds_add(&L.Hh[k * NP28 + pidx(vr, vr)], dd);
+                if constexpr (K != 1) {
+                    gs0 += lam[s] * c0s; gs1 += lam[s] * c1s; gs2 += lam[s] * c2s;
+                    rs0 += w * c0s; rs1 += w * c1s; rs2 += w * c2s;
+                    const double d0 = dd * c0s, d1 = dd * c1s, d2 = dd * c2s;
+                    h00 += d0 * c0s; h10 += d1 * c0s; h11 += d1 * c1s;
+                    h20 += d2 * c0s; h21 += d2 * c1s; h22 += d2 * c2s;
                 }
-            }
+                if constexpr (K != 0) {
+                    if (a && (K == 1 || (box >> s & 1))) {                // box row: one variable
+                        const int vr = VARK(s_);
+                        const double cus = CUK(s_);
+                        lds_add(&L.rg[k * NV + vr], -lam[s] * cus);
+                        lds_add(&L.gh[k * NV + vr], w * cus);
+                        lds_add(&L.Hh[k * NP28 + pidx(vr, vr)], dd);
+                    }
+                }
+            });
             if (stage_lane) {
                 lds_add(&L.rg[k * NV + ZX], -gs0); lds_add(&L.rg[k * NV + ZY], -gs1); lds_add(&L.rg[k * NV + ZPSI], -gs2);
                 lds_add(&L.gh[k * NV + ZX], rs0); lds_add(&L.gh[k * NV + ZY], rs1); lds_add(&L.gh[k * NV + ZPSI], rs2);
@@ -440,16 +486,16 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
         pf.stop(PH_SOLVE);
         // Row step dt = c.dv + r_d is recomputed from the direction in LDS wherever it is needed (no per-row storage:
         // the register budget decides how many waves a SIMD holds)
-        auto row_dt = [&](int s, double dx, double dy, double dp, double vx, double vy, double vp) {
+        auto row_dt = [&](auto s_, double dx, double dy, double dp, double vx, double vy, double vp) {
+            constexpr int s = decltype(s_)::value;
             const bool a = act >> s & 1;
-            const double dvv = L.dv[kk * NV + VAR(s)], vv = L.v[kk * NV + VAR(s)];
-            ROW_C(s)
-            const double cus = CU(s);
-            const double rds = c0s * vx + c1s * vy + c2s * vp + cus * vv - sb[s] - t[s];
-            const double ddot = c0s * dx + c1s * dy + c2s * dp + cus * dvv;
+            double c0s, c1s, c2s;
+            coef(s_, c0s, c1s, c2s);
+            const double rds = rowdot(s_, c0s, c1s, c2s, vx, vy, vp, L.v + kk * NV) - sb[s] - t[s];
+            const double ddot = rowdot(s_, c0s, c1s, c2s, dx, dy, dp, L.dv + kk * NV);
             return a ? ddot + rds : 0.0;
         };
-        double dt_[DIET ? 1 : RPL];                      // row steps (stored unless DIET)
+        double dt_[DIET_DT ? 1 : RPL];                   // row steps (stored unless DIET_DT)
         // Step lengths: alpha_max = min over rows of -t/dt (dt < 0) and -lam/dl (dl < 0) is taken as 1 / max of the reciprocal
         // ratios -dt (1/t) and -dl/lam: 1/t is at hand, and in the predictor dl = -lam (1 + dt/t), so -dl/lam = 1 + dt/t --
         // no division per row (there were four IEEE divisions per row and iteration), one per lane after the reduction.
@@ -461,24 +507,25 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
         {
             const double dx = L.dv[kk * NV + ZX], dy = L.dv[kk * NV + ZY], dp = L.dv[kk * NV + ZPSI];
             const double vx = L.v[kk * NV + ZX], vy = L.v[kk * NV + ZY], vp = L.v[kk * NV + ZPSI];
-#pragma unroll
-            for (int s = 0; s < RPL; s++) {
+            static_for<0, RPL>([&](auto s_) {
+                constexpr int s = decltype(s_)::value;
                 const bool a = act >> s & 1;
-                const double dt = row_dt(s, dx, dy, dp, vx, vy, vp);
-                if constexpr (!DIET) dt_[DIET ? 0 : s] = dt;
+                const double dt = row_dt(s_, dx, dy, dp, vx, vy, vp);
+                if constexpr (!DIET_DT) dt_[DIET_DT ? 0 : s] = dt;
                 const double q = dt * INVT(s);
                 gmax = fmax(gmax, a ? fmax(-q, 1.0 + q) : 0.0);
-            }
+            });
             gmax = blk_max<NTH>(gmax, L.scr, tl, 5);
             a_aff = gmax > 1.0 ? 1.0 / gmax : 1.0;          // min(1, alpha_max)
             ROW_PASS_BEGIN();
-#pragma unroll
-            for (int s = 0; s < RPL; s++)
+            static_for<0, RPL>([&](auto s_) {
+                constexpr int s = decltype(s_)::value;
                 if (act >> s & 1) {
-                    const double dt = DIET ? row_dt(s, dx, dy, dp, vx, vy, vp) : dt_[DIET ? 0 : s];
+                    const double dt = DIET_DT ? row_dt(s_, dx, dy, dp, vx, vy, vp) : dt_[DIET_DT ? 0 : s];
                     const double dl = -lam[s] - lam[s] * INVT(s) * dt;
                     mu_aff += (lam[s] + a_aff * dl) * (t[s] + a_aff * dt);
                 }
+            });
         }
         mu_aff = blk_sum<NTH>(mu_aff, L.scr, tl, 6) / m_rows;
         double sigma = mu > 0.0 ? mu_aff / mu : 0.0;
@@ -491,18 +538,20 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
             double cs0 = 0, cs1 = 0, cs2 = 0;
             const double dx = L.dv[kk * NV + ZX], dy = L.dv[kk * NV + ZY], dp = L.dv[kk * NV + ZPSI];   // predictor direction
             const double vx = L.v[kk * NV + ZX], vy = L.v[kk * NV + ZY], vp = L.v[kk * NV + ZPSI];
-#pragma unroll
-            for (int s = 0; s < RPL; s++) {
+            static_for<0, RPL>([&](auto s_) {
+                constexpr int s = decltype(s_)::value;
+                constexpr int K = C::template KIND<s>;
                 const bool a = act >> s & 1;
-                const double dta = DIET ? row_dt(s, dx, dy, dp, vx, vy, vp) : dt_[DIET ? 0 : s];
+                const double dta = DIET_DT ? row_dt(s_, dx, dy, dp, vx, vy, vp) : dt_[DIET_DT ? 0 : s];
                 const double dl = -lam[s] - lam[s] * INVT(s) * dta;
                 qt[s] = a ? lam[s] + (dta * dl - sigma * mu) * INVT(s) : 0.0;
-                ROW_C(s)
-                const double rr = c0s * vx + c1s * vy + c2s * vp + CU(s) * L.v[kk * NV + VAR(s)] - sb[s] - t[s];
+                double c0s, c1s, c2s;
+                coef(s_, c0s, c1s, c2s);
+                const double rr = rowdot(s_, c0s, c1s, c2s, vx, vy, vp, L.v + kk * NV) - sb[s] - t[s];
                 const double w = qt[s] + lam[s] * INVT(s) * (a ? rr : 0.0);
-                cs0 += w * c0s; cs1 += w * c1s; cs2 += w * c2s;
-                if (a && (box >> s & 1)) lds_add(&L.gh[k * NV + VAR(s)], w * CU(s));
-            }
+                if constexpr (K != 1) { cs0 += w * c0s; cs1 += w * c1s; cs2 += w * c2s; }
+                if constexpr (K != 0) { if (a && (K == 1 || (box >> s & 1))) lds_add(&L.gh[k * NV + VARK(s_)], w * CUK(s_)); }
+            });
             if (stage_lane) { lds_add(&L.gh[k * NV + ZX], cs0); lds_add(&L.gh[k * NV + ZY], cs1); lds_add(&L.gh[k * NV + ZPSI], cs2); }
         }
         team.sync();
@@ -515,15 +564,15 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
         ROW_PASS_BEGIN();
         const double dxc = L.dv[kk * NV + ZX], dyc = L.dv[kk * NV + ZY], dpc = L.dv[kk * NV + ZPSI];
         const double vxc = L.v[kk * NV + ZX], vyc = L.v[kk * NV + ZY], vpc = L.v[kk * NV + ZPSI];
-#pragma unroll
-        for (int s = 0; s < RPL; s++) {
+        static_for<0, RPL>([&](auto s_) {
+            constexpr int s = decltype(s_)::value;
             const bool a = act >> s & 1;
-            const double dt = row_dt(s, dxc, dyc, dpc, vxc, vyc, vpc);
-            if constexpr (!DIET) dt_[DIET ? 0 : s] = dt;
+            const double dt = row_dt(s_, dxc, dyc, dpc, vxc, vyc, vpc);
+            if constexpr (!DIET_DT) dt_[DIET_DT ? 0 : s] = dt;
             const double it_ = INVT(s);
             const double dl = -qt[s] - lam[s] * it_ * dt;
             gmax = fmax(gmax, a ? fmax(-dt * it_, -dl * rcp_nr(lam[s])) : 0.0);
-        }
+        });
         gmax = blk_max<NTH>(gmax, L.scr, tl, 7);
         const double alpha = 0.999 > gmax ? 1.0 : 0.999 / gmax;        // min(1, 0.999 alpha_max)
         pf.stop(PH_ROWS);
@@ -532,15 +581,15 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
         if (TEAM::NQ == 1 && !active) break;
         if (active) {
         ROW_PASS_BEGIN();
-#pragma unroll
-        for (int s = 0; s < RPL; s++) {
+        static_for<0, RPL>([&](auto s_) {
+            constexpr int s = decltype(s_)::value;
             if (act >> s & 1) {
-                const double dt = DIET ? row_dt(s, dxc, dyc, dpc, vxc, vyc, vpc) : dt_[DIET ? 0 : s];
+                const double dt = DIET_DT ? row_dt(s_, dxc, dyc, dpc, vxc, vyc, vpc) : dt_[DIET_DT ? 0 : s];
                 const double dl = -qt[s] - lam[s] * INVT(s) * dt;
                 t[s] += alpha * dt; lam[s] += alpha * dl;
                 if constexpr (!LEAN) invt_[s] = rcp_nr(t[s]);
             }
-        }
+        });
         team.sync();                                 // the rows read v / dv above; v changes below
         for (int e = tl; e < (N + 1) * NV; e += NT) L.v[e] += alpha * L.dv[e];
         for (int e = tl; e < N * NX; e += NT) L.pq[NX + e] += alpha * L.dpi[NX + e];

@@ -603,7 +603,8 @@ __device__ __forceinline__ void linearise(const Lds &L, const Dims &d, int tid, 
         auto sink = [&](int r, const RowOut &ro) {
             if (owner) {
                 double *Dr = L.D + (k * nh + r) * 3;
-                Dr[0] = ro.gx; Dr[1] = ro.gy; Dr[2] = ro.gp;
+                const double sg = (r < d.n_up) ? -1.0 : 1.0;     // fast layouts keep the SIGNED row Jacobian (ipm_fast reads it as it is)
+                Dr[0] = sg * ro.gx; Dr[1] = sg * ro.gy; Dr[2] = sg * ro.gp;
                 const double bound = (r < d.n_up) ? 0.0 : 1.0;
                 L.beta[k * nh + r] = bound - ro.h;
             }
@@ -727,14 +728,17 @@ __device__ __forceinline__ void linearise(const Lds &L, const Dims &d, int tid, 
         };
         auto sink = [&](int r, const RowOut &ro) {
             if (owner) {
+                // fast layouts (the register-row kernels) keep the SIGNED row Jacobian sgn D -- upper-bounded rows -1, lower-bounded +1 -- so that
+                // the row passes of ipm_fast read their coefficients as they are; the generic kernel keeps D and applies the sign itself
+                const double sg = FAST ? ((r < d.n_up) ? -1.0 : 1.0) : 1.0;
                 if constexpr (CP) {
                     // packed Jacobians: (gx, gy) for topology rows (gp == 0 exactly, lin_row_eval), triples for the others
                     double *Dr = L.D + k * L.dstride + (r < L.n_pair ? 2 * r : 3 * r - L.n_pair);
-                    Dr[0] = ro.gx; Dr[1] = ro.gy;
-                    if (r >= L.n_pair) Dr[2] = ro.gp;
+                    Dr[0] = sg * ro.gx; Dr[1] = sg * ro.gy;
+                    if (r >= L.n_pair) Dr[2] = sg * ro.gp;
                 } else {
                     double *Dr = L.D + (k * nh + r) * 3;
-                    Dr[0] = ro.gx; Dr[1] = ro.gy; Dr[2] = ro.gp;
+                    Dr[0] = sg * ro.gx; Dr[1] = sg * ro.gy; Dr[2] = sg * ro.gp;
                 }
                 const double bound = (r < d.n_up) ? 0.0 : 1.0;
                 L.beta[k * nh + r] = bound - ro.h;
@@ -1028,8 +1032,10 @@ static SolveKernel pick_fast_kernel(const Dims &d, int *threads, bool prof)
 }
 // Compact variant (tmpc_fast.hpp: tmpc_solve_compact_kernel): two waves per SIMD, eight trajectories per CU, persistent
 // workgroups.  Bitwise the same results as the fast kernel of the shape (tools/ab_compare.py against TMPC_NO_COMPACT=1).
-// Shapes with 13 rows per lane ((12,12) and (24,0) at three lanes per stage: cfg 4, cfg 5) do not fit 256 registers without scratch
-// and stay on the fast kernels.
+// Round 4: the shapes with 13 rows per lane ((12,12) and (24,0) at three lanes per stage: cfg 4, cfg 5) fit 256 registers too since the
+// row passes are specialised by the compile-time kind of each row slot (FastCfg::KIND): 238 registers, zero scratch; their larger row tables
+// allow 7 (cfg 4: 23.3 KB) and 6 (cfg 5: 25.2 KB) workgroups per CU.  The runtime-shape instantiation with 13 rows per lane still spills
+// (168 B) and is not registered.
 static SolveKernel pick_compact_kernel(const Dims &d, bool prof)
 {
 #ifndef TMPC_GENERATED_STAGE
@@ -1037,8 +1043,8 @@ static SolveKernel pick_compact_kernel(const Dims &d, bool prof)
     const int nr = d.n_up + d.M + 14;                    // interior-point rows per stage
     if (d.n_up == 8 && d.M == 8) return (SolveKernel)tmpc_solve_compact_kernel<8, 8, 3, false>;
     if (d.n_up == 0 && d.M == 4) return (SolveKernel)tmpc_solve_compact_kernel<0, 4, 3, false>;
-    if (d.n_up == 12 && d.M == 12) return nullptr;
-    if (d.n_up == 24 && d.M == 0) return nullptr;
+    if (d.n_up == 12 && d.M == 12) return (SolveKernel)tmpc_solve_compact_kernel<12, 12, 3, false>;
+    if (d.n_up == 24 && d.M == 0) return (SolveKernel)tmpc_solve_compact_kernel<24, 0, 3, false>;
     if (nr <= 3 * 7) return (SolveKernel)tmpc_solve_compact_kernel<-1, 7, 3, false>;       // runtime-shape instantiations
     if (nr <= 3 * 10) return (SolveKernel)tmpc_solve_compact_kernel<-1, 10, 3, false>;
 #endif
