@@ -174,11 +174,7 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
     constexpr bool DIET = (LPS == 6 && NLIN == 8) || OCC2;                // 256-register budget (two waves per SIMD): recompute per-row values instead of storing them
     // ... the row steps dt too, unless the instantiation has room for them (round 4: the row-kind specialisation freed ~27 registers of the
     // compact kernels; keeping dt saves three of the five evaluations of c . dv + r_d per row and interior-point iteration)
-#ifdef TMPC_COMPACT_RECOMPUTE_DT
-    constexpr bool DIET_DT = DIET;
-#else
     constexpr bool DIET_DT = DIET && !(CP && !C::RT && RPL <= 10);
-#endif
     const int N = d.N;
     // Opaque copy of the lane id: keeps the compiler from hoisting this QP's per-row setup (masks, LDS addresses) out of
     // the RTI loop of the caller, where it would stay live across the register-hungry linearisation and be spilled.
@@ -201,17 +197,32 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
     // ---- load this lane's rows (signed coefficients) from the staging area into registers ----
     // per row: signed coefficients on (x, y, psi), signed rhs; box rows: sign in `upper`, variable index packed 3 bits/slot
     double sb[RPL];
-    int didx_[DIET ? 1 : RPL];                      // row's Jacobian triple in L.D (box rows: the zero triple)
+    // row's Jacobian in L.D (box rows: the zero triple).  Stored unless DIET; the compact tuned shapes with <= 10 rows per lane have the
+    // registers to keep the offsets (and those of the third entry of packed rows) since round 4 -- recomputing them cost ~380 instructions per
+    // interior-point iteration
+    constexpr bool STORE_IDX = !DIET || (CP && !C::RT && RPL <= 10);
+    int didx_[STORE_IDX ? RPL : 1];
+    constexpr bool STORE_IDX2 = STORE_IDX && CP;
+    int didx2_[STORE_IDX2 ? RPL : 1];
     unsigned act = 0, box = 0, upper = 0;
     unsigned long long varpack = 0;
 #pragma unroll
     for (int s = 0; s < RPL; s++) {
         const int r = c + LPS * s;
-        sb[s] = 0.0; if constexpr (!DIET) didx_[s] = N * NH * 3;
+        sb[s] = 0.0;
+        if constexpr (STORE_IDX) {
+            didx_[s] = CP ? N * L.dstride : N * NH * 3;
+            if constexpr (STORE_IDX2) didx2_[s] = N * L.dstride + 2;
+        }
         if (stage_lane && r < NR) {
             if (r < NH) {
                 const double sgn = (r < NLIN_) ? -1.0 : 1.0;    // topology / slack rows: upper bound 0; ellipsoids: lower bound 1
-                if constexpr (!DIET) didx_[s] = (k * NH + r) * 3;
+                if constexpr (STORE_IDX) {
+                    if constexpr (CP) {
+                        didx_[s] = k * L.dstride + (r < L.n_pair ? 2 * r : 3 * r - L.n_pair);
+                        if constexpr (STORE_IDX2) didx2_[s] = r >= L.n_pair ? didx_[s] + 2 : N * L.dstride + 2;
+                    } else didx_[s] = (k * NH + r) * 3;
+                }
                 sb[s] = sgn * L.beta[k * NH + r];
                 act |= 1u << s;
             } else {
@@ -233,7 +244,7 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
     // signed Jacobian of row s (general rows: +-D from LDS; box rows: zero triple)
     // row's Jacobian triple in L.D (box rows and idle lanes: the zero triple behind the last row); recomputed, not stored
     auto DIDX = [&](int s) {
-        if constexpr (!DIET) return didx_[DIET ? 0 : s];
+        if constexpr (STORE_IDX) return didx_[STORE_IDX ? s : 0];
         const int r = c + LPS * s;
         if constexpr (CP) return (stage_lane && r < NH) ? k * L.dstride + (r < L.n_pair ? 2 * r : 3 * r - L.n_pair) : N * L.dstride;
         return (stage_lane && r < NH) ? (k * NH + r) * 3 : N * NH * 3;
@@ -241,6 +252,7 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
     // third entry of the row's Jacobian: packed rows (topology) have none -- they read the 0.0 of the zero triple, so that the
     // row's arithmetic (sg * 0.0 included) is that of the unpacked layout
     auto DIDX2 = [&](int s) {
+        if constexpr (STORE_IDX2) return didx2_[STORE_IDX2 ? s : 0];
         const int r = c + LPS * s;
         if constexpr (CP) return (stage_lane && r < NH && r >= L.n_pair) ? DIDX(s) + 2 : N * L.dstride + 2;
         return DIDX(s) + 2;
@@ -259,6 +271,15 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
         if constexpr (C::template KIND<s> == 1) return ((c + LPS * s - C::NH) & 1) ? -1.0 : 1.0;
         else return CU(s);
     };
+    // "this slot holds a live row": a general slot of a tuned shape is live on every stage lane, a box slot whose rows are all state boxes on
+    // every stage lane but stage 0 (x_0 is fixed, not boxed) -- one comparison per pass instead of a bit test per slot and pass
+    auto ACT = [&](auto s_) {
+        constexpr int s = decltype(s_)::value;
+        constexpr int K = C::template KIND<s>;
+        if constexpr (K == 0) return sl_ != 0;
+        else if constexpr (K == 1 && LPS * s - C::NH >= 4 && LPS * s + LPS - 1 < C::NR) return sl_ != 0 && k >= 1;
+        else return (act >> s & 1) != 0;
+    };
     // SIGNED Jacobian of row slot s: the linearisation's sink stores sgn * D (fast layouts), box slots have none
     auto coef = [&](auto s_, double &c0, double &c1, double &c2) {
         constexpr int s = decltype(s_)::value;
@@ -270,7 +291,12 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
         constexpr int s = decltype(s_)::value;
         constexpr int K = C::template KIND<s>;
         if constexpr (K == 0) return c0 * x + c1 * y + c2 * pp;
-        else if constexpr (K == 1) return CUK(s_) * vec[VARK(s_)];
+        else if constexpr (K == 1) {
+            // box slot of a tuned shape: q = r - NH, variable q >> 1, side q & 1: +-w[var] by flipping the sign bit (exactly (+-1.0) * w[var])
+            const int q = c + LPS * s - C::NH;
+            const unsigned long long u = __builtin_bit_cast(unsigned long long, vec[q >> 1]) ^ ((unsigned long long)((unsigned)q << 31) << 32);
+            return __builtin_bit_cast(double, u);
+        }
         else return c0 * x + c1 * y + c2 * pp + CU(s) * vec[VAR(s)];
     };
     team.sync();                                             // staging is dead from here on
@@ -283,11 +309,7 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
 
     ROW_PASS_BEGIN();
     double t[RPL], qt[RPL];
-#ifdef TMPC_COMPACT_RECOMPUTE_INVT
-    constexpr bool LEAN = RPL > 10 || (LPS == 6 && NLIN == 8) || OCC2;
-#else
-    constexpr bool LEAN = RPL > 10 || (LPS == 6 && NLIN == 8) || (OCC2 && !(CP && !C::RT && RPL <= 10));    // recompute 1/t instead of keeping it: many rows per lane, or the 256-register
-#endif
+    constexpr bool LEAN = RPL > 10 || (LPS == 6 && NLIN == 8) || OCC2;    // recompute 1/t instead of keeping it: many rows per lane, or the 256-register
                                                     // budget of the two-waves-per-SIMD instantiations
     double invt_[LEAN ? 1 : RPL];               // the row residual r_d = c.v - sb - t is recomputed where needed
     {
@@ -299,7 +321,7 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
             const double r0 = rowdot(s_, c0s, c1s, c2s, vx, vy, vp, L.v + kk * NV) - sb[s];
             t[s] = r0 > d.thr0 ? r0 : d.thr0;
             if constexpr (!LEAN) invt_[s] = rcp_nr(t[s]);
-            lam[s] = (act >> s & 1) ? d.mu0 / t[s] : 0.0;
+            lam[s] = ACT(s_) ? d.mu0 / t[s] : 0.0;
             qt[s] = 0.0;
         });
     }
@@ -315,21 +337,6 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
         double res_d = 0.0, res_m = 0.0, mu = 0.0;
         if (active) {
         // ---- stage parts of the residuals: rg0 = g + W v + [B A]^T pi_{k+1} - [0; pi_k];  rb;  Hh <- W ----
-        if constexpr (CP) {
-            // Hh <- W from the global workspace, all loads in flight before the first store;
-            // the residual below then reads W from Hh
-            constexpr int WR = (21 * NP28 + NT - 1) / NT;            // N <= 20 (21 nodes) for these instantiations
-            const int tot = (N + 1) * NP28;
-            double wv[WR];
-#pragma unroll
-            for (int j = 0; j < WR; j++) { const int e = tl + NT * j; wv[j] = L.W[e < tot ? e : tot - 1]; }
-#pragma unroll
-            for (int j = 0; j < WR; j++) {
-                const int e = tl + NT * j;
-                if (e < tot) L.Hh[e] = wv[j];
-            }
-            team.sync();
-        }
         double res_b = 0.0;
         if constexpr (!CP) {
             // Fast layout (one wave per SIMD: nothing else hides an LDS round trip): every operand of an element is loaded unconditionally
@@ -372,44 +379,73 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
                 res_b = fmax(res_b, fabs(acc));
             }
         } else {
-        for (int e = tl; e < (N + 1) * NV; e += NT) {
-            const int ks = e / NV, i = e - ks * NV;
-            double acc = 0.0;
-            const bool skip = (ks == N && i < NU) || (ks == 0 && i >= NU);
-            if (!skip) {
-                acc = L.g[e];
-                const double *Wk = (CP ? L.Hh : L.W) + ks * NP28; const double *vk = L.v + ks * NV;
+            // Compact layout (round 4): lane = NODE ks.  The node's W block comes straight from the global workspace into registers (and from
+            // there into Hh: no separate copy pass and no barrier before the residuals), and with the node fixed per lane every index of the
+            // residuals -- the packed-W entries, the structural non-zeros of [B A] (dyn8 entries, 1, dt, dt^2/2) -- is a compile-time constant:
+            // ~115 instructions where the element-parallel form (an integer division, seven symmetric-index computations and five / seven table
+            // decodes per element, three passes) spent ~700.  Sums in the same order as before; structural zeros of [B A] are skipped (they added
+            // exact zeros), its ones are additions.
+            const bool nd = tl <= N;
+            const int ks = nd ? tl : N;                    // (idle lanes redo node N and store nothing)
+            const int kb = ks < N ? ks : N - 1;            // stage whose [B A], pi_{k+1}, b the node reads
+            double w[NP28], vk[NV], pn[NX], po[NX], d8[8], gk[NV], bk[NX], vn[NX];
+            {
+                const double *Wg = L.W + ks * NP28;
 #pragma unroll
-                for (int j = 0; j < NV; j++) acc += Wk[sidx(i, j)] * vk[j];
-                if (ks < N) {
-                    if constexpr (CP) {
+                for (int e = 0; e < NP28; e++) w[e] = Wg[e];
 #pragma unroll
-                        for (int l = 0; l < NX; l++) acc += L.tab[ba_off(N, ks, l, i)] * L.pq[(ks + 1) * NX + l];
-                    } else {
-                        const double *BA = L.BA + ks * NX * NV;
+                for (int j = 0; j < NV; j++) { vk[j] = L.v[ks * NV + j]; gk[j] = L.g[ks * NV + j]; }
 #pragma unroll
-                        for (int l = 0; l < NX; l++) acc += BA[l * NV + i] * L.pq[(ks + 1) * NX + l];
-                    }
+                for (int l = 0; l < NX; l++) {
+                    pn[l] = L.pq[(kb + 1) * NX + l]; po[l] = L.pq[(ks >= 1 ? ks : 1) * NX + l];
+                    bk[l] = L.b[kb * NX + l]; vn[l] = L.v[(kb + 1) * NV + NU + l];
                 }
-                if (i >= NU && ks >= 1) acc -= L.pq[ks * NX + i - NU];
-            }
-            L.rg[e] = acc; L.gh[e] = acc;
-        }
-        for (int e = tl; e < N * NX; e += NT) {
-            const int ks = e / NX, i = e - ks * NX;
-            double acc = L.b[e] - L.v[(ks + 1) * NV + NU + i];
-            const double *vk = L.v + ks * NV;
-            if constexpr (CP) {
 #pragma unroll
-                for (int j = 0; j < NV; j++) acc += L.tab[ba_off(N, ks, i, j)] * vk[j];
-            } else {
-                const double *BA = L.BA + ks * NX * NV + i * NV;
-#pragma unroll
-                for (int j = 0; j < NV; j++) acc += BA[j] * vk[j];
+                for (int q = 0; q < 8; q++) d8[q] = L.tab[kb * 8 + q];
             }
-            L.rb[e] = acc;
-            res_b = fmax(res_b, fabs(acc));
-        }
+            if (nd) {
+#pragma unroll
+                for (int e = 0; e < NP28; e++) L.Hh[ks * NP28 + e] = w[e];
+            }
+            const double dtc = d.dt, hc = d.hdt2;
+            const double Xa = d8[D8_XA], Xw = d8[D8_XW], Xp = d8[D8_XP], Xv = d8[D8_XV], Ya = d8[D8_YA], Yw = d8[D8_YW], Yp = d8[D8_YP], Yv = d8[D8_YV];
+            double rgk[NV];
+#pragma unroll
+            for (int i = 0; i < NV; i++) {
+                double acc = gk[i];
+#pragma unroll
+                for (int j = 0; j < NV; j++) acc += w[sidx(i, j)] * vk[j];
+                rgk[i] = acc;
+            }
+            if (ks < N) {                                  // + [B A]^T pi_{k+1}, column by column
+                rgk[ZA] = ((rgk[ZA] + Xa * pn[0]) + Ya * pn[1] + dtc * pn[3]) + hc * pn[4];
+                rgk[ZW] = (rgk[ZW] + Xw * pn[0]) + Yw * pn[1] + dtc * pn[2];
+                rgk[ZX] += pn[0];
+                rgk[ZY] += pn[1];
+                rgk[ZPSI] = ((rgk[ZPSI] + Xp * pn[0]) + Yp * pn[1]) + pn[2];
+                rgk[ZV] = (((rgk[ZV] + Xv * pn[0]) + Yv * pn[1]) + pn[3]) + dtc * pn[4];
+                rgk[ZS] += pn[4];
+            }
+#pragma unroll
+            for (int i = 0; i < NV; i++) {
+                double acc = rgk[i];
+                if (i >= NU && ks >= 1) acc -= po[i - NU];
+                const bool skip = (ks == N && i < NU) || (ks == 0 && i >= NU);
+                acc = skip ? 0.0 : acc;
+                if (nd) { L.rg[ks * NV + i] = acc; L.gh[ks * NV + i] = acc; }
+            }
+            {                                              // rb = b + [B A] v_k - dx_{k+1}, row by row
+                double rbk[NX];
+                rbk[0] = (((((bk[0] - vn[0]) + Xa * vk[ZA]) + Xw * vk[ZW]) + vk[ZX]) + Xp * vk[ZPSI]) + Xv * vk[ZV];
+                rbk[1] = (((((bk[1] - vn[1]) + Ya * vk[ZA]) + Yw * vk[ZW]) + vk[ZY]) + Yp * vk[ZPSI]) + Yv * vk[ZV];
+                rbk[2] = ((bk[2] - vn[2]) + dtc * vk[ZW]) + vk[ZPSI];
+                rbk[3] = ((bk[3] - vn[3]) + dtc * vk[ZA]) + vk[ZV];
+                rbk[4] = (((bk[4] - vn[4]) + hc * vk[ZA]) + dtc * vk[ZV]) + vk[ZS];
+                if (tl < N) {
+#pragma unroll
+                    for (int i = 0; i < NX; i++) { L.rb[ks * NX + i] = rbk[i]; res_b = fmax(res_b, fabs(rbk[i])); }
+                }
+            }
         }
         if constexpr (!CP) for (int e = tl; e < (N + 1) * NP28; e += NT) L.Hh[e] = L.W[e];
         team.sync();
@@ -423,7 +459,7 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
             static_for<0, RPL>([&](auto s_) {
                 constexpr int s = decltype(s_)::value;
                 constexpr int K = C::template KIND<s>;
-                const bool a = act >> s & 1;
+                const bool a = ACT(s_);
                 double c0s, c1s, c2s;
                 coef(s_, c0s, c1s, c2s);
                 const double r = rowdot(s_, c0s, c1s, c2s, vx, vy, vp, L.v + kk * NV) - sb[s] - t[s];
@@ -488,7 +524,7 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
         // the register budget decides how many waves a SIMD holds)
         auto row_dt = [&](auto s_, double dx, double dy, double dp, double vx, double vy, double vp) {
             constexpr int s = decltype(s_)::value;
-            const bool a = act >> s & 1;
+            const bool a = ACT(s_);
             double c0s, c1s, c2s;
             coef(s_, c0s, c1s, c2s);
             const double rds = rowdot(s_, c0s, c1s, c2s, vx, vy, vp, L.v + kk * NV) - sb[s] - t[s];
@@ -509,7 +545,7 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
             const double vx = L.v[kk * NV + ZX], vy = L.v[kk * NV + ZY], vp = L.v[kk * NV + ZPSI];
             static_for<0, RPL>([&](auto s_) {
                 constexpr int s = decltype(s_)::value;
-                const bool a = act >> s & 1;
+                const bool a = ACT(s_);
                 const double dt = row_dt(s_, dx, dy, dp, vx, vy, vp);
                 if constexpr (!DIET_DT) dt_[DIET_DT ? 0 : s] = dt;
                 const double q = dt * INVT(s);
@@ -520,7 +556,7 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
             ROW_PASS_BEGIN();
             static_for<0, RPL>([&](auto s_) {
                 constexpr int s = decltype(s_)::value;
-                if (act >> s & 1) {
+                if (ACT(s_)) {
                     const double dt = DIET_DT ? row_dt(s_, dx, dy, dp, vx, vy, vp) : dt_[DIET_DT ? 0 : s];
                     const double dl = -lam[s] - lam[s] * INVT(s) * dt;
                     mu_aff += (lam[s] + a_aff * dl) * (t[s] + a_aff * dt);
@@ -541,7 +577,7 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
             static_for<0, RPL>([&](auto s_) {
                 constexpr int s = decltype(s_)::value;
                 constexpr int K = C::template KIND<s>;
-                const bool a = act >> s & 1;
+                const bool a = ACT(s_);
                 const double dta = DIET_DT ? row_dt(s_, dx, dy, dp, vx, vy, vp) : dt_[DIET_DT ? 0 : s];
                 const double dl = -lam[s] - lam[s] * INVT(s) * dta;
                 qt[s] = a ? lam[s] + (dta * dl - sigma * mu) * INVT(s) : 0.0;
@@ -566,7 +602,7 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
         const double vxc = L.v[kk * NV + ZX], vyc = L.v[kk * NV + ZY], vpc = L.v[kk * NV + ZPSI];
         static_for<0, RPL>([&](auto s_) {
             constexpr int s = decltype(s_)::value;
-            const bool a = act >> s & 1;
+            const bool a = ACT(s_);
             const double dt = row_dt(s_, dxc, dyc, dpc, vxc, vyc, vpc);
             if constexpr (!DIET_DT) dt_[DIET_DT ? 0 : s] = dt;
             const double it_ = INVT(s);
@@ -583,7 +619,7 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
         ROW_PASS_BEGIN();
         static_for<0, RPL>([&](auto s_) {
             constexpr int s = decltype(s_)::value;
-            if (act >> s & 1) {
+            if (ACT(s_)) {
                 const double dt = DIET_DT ? row_dt(s_, dxc, dyc, dpc, vxc, vyc, vpc) : dt_[DIET_DT ? 0 : s];
                 const double dl = -qt[s] - lam[s] * INVT(s) * dt;
                 t[s] += alpha * dt; lam[s] += alpha * dl;

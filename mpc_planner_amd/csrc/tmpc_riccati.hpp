@@ -97,6 +97,7 @@ __device__ __forceinline__ bool riccati_factor_rows(const Lds &L, const Dims &d,
     const int N = d.N;
     const bool rowl = li < NV && wr;
     const bool vec = VEC && li == NV;                // the right-hand-side row
+    const double vmask = vec ? 1.0 : 0.0;
     const int ls = li < NV ? li : 0;
     const int i5 = li - NU;                          // state index of lanes 2..6
     const double dt = d.dt, hdt2 = d.hdt2;
@@ -107,28 +108,39 @@ __device__ __forceinline__ bool riccati_factor_rows(const Lds &L, const Dims &d,
 #pragma unroll
         for (int m = 2; m < NX; m++) ba[m] = L.tab[ba_off(N, 0, m, ls)];
     }
-    // VEC: every lane loads hk[] / ba[] through per-lane (base, stride) pairs, so that the extra row reads gh / rb with the same loads
-    const double *hbase = vec ? L.gh : L.Hh;
-    const int hstride = vec ? NV : NP28;
+    // VEC: every lane loads hk[] / ba[] through per-lane (pointer, stride) pairs, so that the extra row reads gh / rb with the same loads.
+    // Running pointers, stepped back by the lane's stride once per stage (round 4: the k * stride multiplications and per-entry index
+    // arithmetic were ~17 of the stage loop's ~250 instructions): a lane reads hk[j] = row[j] at IMMEDIATE offsets from the start of its row of
+    // the packed Hh block -- the entries j > own row index belong to the next row and are never used (chol_rows reads the lower triangle only).
+    // (the same for ba[] -- running offsets or pointers, five more values live across the stage loop -- pushed the compact kernels into scratch
+    // twice: ba[] keeps its (base + k * stride) form, which the compiler rematerialises)
+    const double *hrow = nullptr;
+    int hstep = 0;
     const double *bbase = CP ? L.tab : L.BA;
     int bo[NX], bst[NX];
     if constexpr (VEC) {
+        hrow = vec ? L.gh : L.Hh + pidx(ls, 0);
+        hstep = vec ? NV : NP28;
 #pragma unroll
         for (int m = 0; m < NX; m++) {
             if constexpr (CP) { bo[m] = vec ? (int)(L.rb - L.tab) + m : ba_off(N, 0, m, ls); bst[m] = vec ? NX : (bo[m] < 8 ? 8 : 0); }
             else { bo[m] = vec ? (int)(L.rb - L.BA) + m : m * NV + ls; bst[m] = vec ? NX : NX * NV; }
         }
     }
-    auto load_stage = [&](int k) {
+    // (the running pointers are positioned by seek_stage and stepped by load_stage: stage k, then k - 1, ...; the last call re-loads stage 0)
+    auto seek_stage = [&](int k) {
+        if constexpr (VEC) hrow += k * hstep;
+    };
+    auto load_stage = [&](int k, bool step) {
         // unconditional loads (clamped indices): entries above the diagonal / of idle lanes are never used
         if constexpr (VEC) {
-            const double *Hk = hbase + k * hstride;
 #pragma unroll
-            for (int j = 0; j < NV; j++) hk[j] = Hk[vec ? j : pidx(ls, j <= ls ? j : ls)];
+            for (int j = 0; j < NV; j++) hk[j] = hrow[j];
 #pragma unroll
             for (int m = 0; m < NX; m++) ba[m] = bbase[bo[m] + k * bst[m]];
 #pragma unroll
             for (int q = 0; q < 8; q++) dn[q] = (CP ? L.tab : L.dyn8)[k * 8 + q];
+            if (step) hrow -= hstep;
         } else {
             const double *Hk = L.Hh + k * NP28;
 #pragma unroll
@@ -149,7 +161,8 @@ __device__ __forceinline__ bool riccati_factor_rows(const Lds &L, const Dims &d,
     // terminal node: Cholesky of the xx-block (rows/cols 2..6); the extra row starts as g_x of node N
 #pragma unroll
     for (int j = 0; j < NV; j++) f[j] = (j >= NU) ? (vec ? L.gh[N * NV + j] : L.Hh[N * NP28 + pidx(ls, j <= ls ? j : ls)]) : 0.0;
-    load_stage(N - 1);
+    seek_stage(N - 1);
+    load_stage(N - 1, true);
     bad |= chol_rows<NU>(f, li, nullptr, nullptr);
     if (vec && wr) {
 #pragma unroll
@@ -179,7 +192,9 @@ __device__ __forceinline__ bool riccati_factor_rows(const Lds &L, const Dims &d,
             double acc = 0.0;
 #pragma unroll
             for (int m = l; m < NX; m++) acc += Lp[m][l] * ba[m];
-            Go[l] = (VEC && vec) ? acc + f[NU + l] : acc;        // the extra row: (Lp^T rb)_l + lx_l of stage k + 1
+            // the extra row: (Lp^T rb)_l + lx_l of stage k + 1.  As fma(1.0 or 0.0, f, acc): exactly acc + f on the extra row and acc on the
+            // others (f is finite there), without the ten v_cndmask a select costs per stage
+            Go[l] = VEC ? fma(vmask, f[NU + l], acc) : acc;
         }
         const double Xa = dn[D8_XA], Xw = dn[D8_XW], Xp = dn[D8_XP], Xv = dn[D8_XV];
         const double Ya = dn[D8_YA], Yw = dn[D8_YW], Yp = dn[D8_YP], Yv = dn[D8_YV];
@@ -215,7 +230,8 @@ __device__ __forceinline__ bool riccati_factor_rows(const Lds &L, const Dims &d,
             }
             f[ZA] = a0; f[ZW] = a1; f[ZX] = a2; f[ZY] = a3; f[ZPSI] = a4; f[ZV] = a5; f[ZS] = a6;
         }
-        load_stage(k > 0 ? k - 1 : 0);                // operands of the next stage, hidden under the Cholesky (unconditional, clamped: a branch here costs a second register set)
+        load_stage(k > 0 ? k - 1 : 0, k > 1);         // operands of the next stage, hidden under the Cholesky (unconditional, clamped: a branch here costs a second register
+                                                      // set; the pointers stop at stage 0, which the last pass re-loads and discards)
         double r0 = 0.0, r1 = 0.0;
         bad |= chol_rows<0>(f, li, &r0, &r1);
         if (rowl) {
