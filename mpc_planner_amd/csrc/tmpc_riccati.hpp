@@ -404,13 +404,23 @@ __device__ __forceinline__ void riccati_sweeps_rows(const Lds &L, const Dims &d,
     // forward sweep; dx_0 = 0 (dx lives in lanes 2..6).  dx+ = A dx + B du + rb with A = I + E (E: columns psi, v).
     if (sweeper) {
         double dx = 0.0;
-        struct Ops { double lx0, lx1, y0, y1, r0, l10, r1, a_psi, a_v, b_a, b_w, rbi; };
+        // Lxu^T dx (two sums over the state lanes 2..6): every lane holds the stage's ten Lxu entries (row-uniform LDS reads) and gets the five
+        // dx components by row broadcasts -- 5 broadcasts + 10 fma, where folding the two sums with DPP row shifts cost 12 32-bit DPP moves, 6
+        // adds, 4 selects and 2 more broadcasts (round 4: -15 of the stage's 49 instructions); dpsi and dv are two of the five broadcasts
+        // The ten Lxu entries have ONE register set, re-loaded for stage k + 1 right after their last use in stage k (two sets, like the other
+        // operands, pushed the compact kernels into scratch); the loads pass underneath the rest of the stage.
+        struct Ops { double y0, y1, r0, l10, r1, a_psi, a_v, b_a, b_w, rbi; };
+        double lxu[2 * NX];
+        auto load_lxu = [&](int k) {
+            const double *Fb = L.Hh + k * NP28 + FB_LXU;
+#pragma unroll
+            for (int e = 0; e < 2 * NX; e++) lxu[e] = Fb[e];
+        };
         const double i_psi = li == ZPSI ? 1.0 : 0.0, i_v = li == ZV ? 1.0 : 0.0;
         double *dv_own = L.dv + ls;
         const BaLane br = ba_row4(N, i5);
         auto load_stage = [&](Ops &o, int k) {
             const double *Fb = L.Hh + k * NP28;
-            o.lx0 = Fb[FB_LXU + 2 * i5]; o.lx1 = Fb[FB_LXU + 2 * i5 + 1];
             o.y0 = L.y[k * NU]; o.y1 = L.y[k * NU + 1];
             o.r0 = Fb[FB_R0]; o.l10 = Fb[FB_L10]; o.r1 = Fb[FB_R1];
             if constexpr (CP) {
@@ -425,24 +435,24 @@ __device__ __forceinline__ void riccati_sweeps_rows(const Lds &L, const Dims &d,
             o.rbi = L.rb[k * NX + i5];
         };
         auto stage = [&](const Ops &o, int k) {
-            // du = -Luu^-T (Lxu^T dx + y).  (Lxu^T dx)_{0,1}: sums over lanes 2..6, folded with DPP row shifts (lanes 0, 1
-            // contribute zeros, vacated lanes read zeros; lane 6 ends up with the total)
-            const bool xv = li >= NU && li < NV;                           // (independent of `wr`: an idle row still shifts zeros only into itself)
-            double q0 = xv ? o.lx0 * dx : 0.0, q1 = xv ? o.lx1 * dx : 0.0;
-            q0 += dpp_shift_zero<0x111>(q0); q1 += dpp_shift_zero<0x111>(q1);
-            q0 += dpp_shift_zero<0x112>(q0); q1 += dpp_shift_zero<0x112>(q1);
-            q0 += dpp_shift_zero<0x114>(q0); q1 += dpp_shift_zero<0x114>(q1);
-            const double s0 = o.y0 + bcast16<NV - 1>(q0), s1 = o.y1 + bcast16<NV - 1>(q1);
+            // du = -Luu^-T (Lxu^T dx + y)
+            double dxs[NX];
+            static_for<0, NX>([&](auto m_) { constexpr int m = decltype(m_)::value; dxs[m] = bcast16<NU + m>(dx); });
+            double s0 = o.y0, s1 = o.y1;
+#pragma unroll
+            for (int m = 0; m < NX; m++) { s0 = fma(lxu[2 * m], dxs[m], s0); s1 = fma(lxu[2 * m + 1], dxs[m], s1); }
+            load_lxu(k + 1 < N ? k + 1 : N - 1);                           // (unconditional, clamped)
             const double u1 = -s1 * o.r1;
             const double u0 = (-s0 - o.l10 * u1) * o.r0;
             if (rowl && li == 0) { L.dv[k * NV] = u0; L.dv[k * NV + 1] = u1; }
             if (xl) dv_own[k * NV] = dx;
-            const double dpsi = bcast16<ZPSI>(dx), dvv = bcast16<ZV>(dx);
+            const double dpsi = dxs[ZPSI - NU], dvv = dxs[ZV - NU];
             const double e_psi = o.a_psi - i_psi, e_v = o.a_v - i_v;
             dx = dx + e_psi * dpsi + e_v * dvv + o.b_a * u0 + o.b_w * u1 + o.rbi;   // lanes 2..6 meaningful
         };
         Ops oa, ob;
         load_stage(oa, 0);
+        load_lxu(0);
         int k = 0;
         for (; k + 1 < N; k += 2) {
             load_stage(ob, k + 1);

@@ -529,15 +529,16 @@ TMPC_HD void mirror_n(double (&A)[NN][NN], double eps)
                     const double hyp = h2 * st_rsqrt(h2);
                     const double t = (tau >= 0.0 ? apq : -apq) * st_rcp(fabs(tau) + hyp);
                     const double c = st_rsqrt(t * t + 1.0), s = t * c;
+                    // A <- G^T A G on the symmetric matrix: the pivot block in closed form (a_pp - t a_pq, a_qq + t a_pq, 0), the other rows'
+                    // (p, q) entries once and mirrored -- (NN - 2) pairs where the two full passes over columns and rows (round 1-3) took
+                    // 2 NN: a third of the rotation's arithmetic (round 4; the rotation itself is unchanged)
+                    A[p][p] -= t * apq; A[q][q] += t * apq; A[p][q] = 0.0; A[q][p] = 0.0;
 #pragma unroll
                     for (int k = 0; k < NN; k++) {
+                        if (k == p || k == q) continue;
                         const double akp = A[k][p], akq = A[k][q];
-                        A[k][p] = c * akp - s * akq; A[k][q] = s * akp + c * akq;
-                    }
-#pragma unroll
-                    for (int k = 0; k < NN; k++) {
-                        const double apk = A[p][k], aqk = A[q][k];
-                        A[p][k] = c * apk - s * aqk; A[q][k] = s * apk + c * aqk;
+                        const double np_ = c * akp - s * akq, nq_ = s * akp + c * akq;
+                        A[k][p] = np_; A[p][k] = np_; A[k][q] = nq_; A[q][k] = nq_;
                     }
 #pragma unroll
                     for (int k = 0; k < NN; k++) {
