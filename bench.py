@@ -605,7 +605,7 @@ def main():
                        "kernel_variant": {"latency_mode": a.latency_mode, "accepted": lat_mode_ok,
                                           "what": ["throughput kernels", "two waves per trajectory", "parallel-in-time Newton solve (csrc/tmpc_scan.hpp)"][a.latency_mode]},
                        "parallelism": f"trajectory-sharded x{world}, one 16 B/trajectory all-gather" if world > 1 else "single GPU"},
-            "roofline": {"bound": "valu_fp64", "achieved": tflops, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "roofline": {"bound": "mfma", "bound_detail": "fp64: the dense f64 MFMA peak and the f64 vector (VALU) peak are the same 78.6 TFLOP/s on MI355X; the kernel issues VALU", "achieved": tflops, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": tflops / FP64_VALU_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_note,
                          "library_sha256": lib_hash,
                          "kernel": kernel_info, "kernel_ms_avg": k_avg * 1e3, "flops_per_solve": fl,
