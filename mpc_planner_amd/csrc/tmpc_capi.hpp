@@ -1,0 +1,1017 @@
+// tmpc_capi.hpp -- the C-ABI of libtmpc_hip.so (include/tmpc_hip.h): kernel dispatch tables, the handle, and every exported entry point.
+// Included once by tmpc_solve.hip, after the kernels (tmpc_solve.hip: LDS layout, linearisation and the solve kernels;
+// tmpc_fast.hpp / tmpc_riccati.hpp / tmpc_scan.hpp / tmpc_stage.hpp: their parts; tmpc_aux_kernels.hpp: selection, gather, debug kernels).
+// Not a standalone header: it sees the kernels' names and the build's -D switches (TMPC_GENERATED_STAGE, TMPC_GEN_FAST, ...).
+#pragma once
+
+// =================================================================================================
+// C-ABI
+// =================================================================================================
+namespace tmpc {
+typedef void (*SolveKernel)(Dims, int, const double *, const double *, const double *, double *, double *, double *, int *,
+                            int *, int *, double *, int *, long long *, StateIO);
+// Registered fast shapes (upper-bounded rows n_lin + n_slk, ellipsoids M) x lanes-per-stage; anything else runs the generic kernel.
+// Only instantiations that compile WITHOUT scratch (zero VGPR spills) are registered: __graft_entry__.build() checks
+// the compiler's resource remarks and fails otherwise.  Reason: with > ~100 spilled VGPRs this kernel was observed to
+// return wrong iterates (spill/reload around partially-masked regions), see DESIGN.md section 5.  Shapes with more rows
+// per lane ((8,8) at 2 lanes/stage for N > 21, (12,12) at 2 lanes/stage) therefore use the generic kernel for now.  The library is
+// built with -mllvm -disable-machine-licm: hoisted constant materialisations were what pushed (12,12,3) into scratch.
+// prof: the instrumented instantiation (tmpc_debug_profile) instead of the production one.
+#define TMPC_FAST(...) (prof ? (SolveKernel)tmpc_solve_fast_kernel<__VA_ARGS__, true> : (SolveKernel)tmpc_solve_fast_kernel<__VA_ARGS__, false>)
+static SolveKernel pick_fast_kernel(const Dims &d, int *threads, bool prof)
+{
+    *threads = NT;
+    if (getenv("TMPC_FORCE_GENERIC")) return nullptr;
+    const int lps = (3 * d.N <= NT) ? 3 : ((2 * d.N <= NT) ? 2 : 0);
+#ifndef TMPC_GENERATED_STAGE
+    if (d.cost_model == 1) {
+        // curvature-aware contouring (BASELINE configs[2]): the cfg-3 shape on the two-wave kernel, every other row mix of N <= 20 on the
+        // runtime-shape one-wave kernel, anything else on the generic kernel -- all instantiated with CM = 1 (no profiled twins)
+        if (prof) return nullptr;
+        const int nrc = d.n_up + d.M + 14;
+        if (lps != 3 && 4 * d.N <= 128 && d.n_up == 20 && d.M == 8 && !getenv("TMPC_NO_TWO_WAVE")) {
+            *threads = 128;
+            return (SolveKernel)tmpc_solve_fast_kernel<20, 8, 4, 128, false, Solo, 1>;
+        }
+        if (lps == 3 && nrc <= 3 * 13) return (SolveKernel)tmpc_solve_fast_kernel<-1, 13, 3, 64, false, Solo, 1>;
+        return nullptr;
+    }
+#endif
+#ifdef TMPC_GENERATED_STAGE
+    // generated solver: one row shape (tmpc_gen::NH upper-bounded rows); the fast instantiations are compiled only when the
+    // generator's build found them free of scratch (TMPC_GEN_FAST / TMPC_GEN_FAST2 set by codegen/build.py)
+#ifdef TMPC_GEN_FAST
+    if (lps == 3) return TMPC_FAST(tmpc_gen::NH, 0, 3, 64);
+#endif
+#ifdef TMPC_GEN_FAST2
+    if (lps != 3 && 4 * d.N <= 128) { *threads = 128; return TMPC_FAST(tmpc_gen::NH, 0, 4, 128); }
+#endif
+    return nullptr;
+#else
+    const int nr = d.n_up + d.M + 14;                    // interior-point rows per stage
+    if (lps != 3 && 4 * d.N <= 128 && !getenv("TMPC_NO_TWO_WAVE")) {
+        // two waves per trajectory, 4 lanes per stage (22 <= N <= 32: the reference's default N = 30 and BASELINE cfg 3)
+        SolveKernel k2 = nullptr;
+        if (d.n_up == 8 && d.M == 8) k2 = TMPC_FAST(8, 8, 4, 128);
+        else if (d.n_up == 12 && d.M == 12) k2 = TMPC_FAST(12, 12, 4, 128);  // mpc_planner_jackalsimulator defaults (N = 30, 12 obstacles)
+        else if (d.n_up == 20 && d.M == 8) k2 = TMPC_FAST(20, 8, 4, 128);    // cfg 3: 8 topology + 12 decomp rows + 8 ellipsoids
+        else if (nr <= 4 * 6) k2 = TMPC_FAST(-1, 6, 4, 128);                 // any other row mix: runtime-shape instantiations
+        else if (nr <= 4 * 9) k2 = TMPC_FAST(-1, 9, 4, 128);                 //   (e.g. mpc_planner_jackal: N = 30, 5 obstacles)
+        else if (nr <= 4 * 12) k2 = TMPC_FAST(-1, 12, 4, 128);
+        if (k2) { *threads = 128; return k2; }
+    }
+    if (lps == 3) {
+        if (d.n_up == 0 && d.M == 4) return TMPC_FAST(0, 4, 3, 64);
+        if (d.n_up == 8 && d.M == 8) return TMPC_FAST(8, 8, 3, 64);
+        if (d.n_up == 12 && d.M == 12) return TMPC_FAST(12, 12, 3, 64);      // zero scratch only with machine-LICM off (build flag)
+        if (d.n_up == 24 && d.M == 0) return TMPC_FAST(24, 0, 3, 64);        // SH-MPC: 24 scenario halfspaces (cfg 5)
+        if (nr <= 3 * 7) return TMPC_FAST(-1, 7, 3, 64);                     // runtime-shape instantiations
+        if (nr <= 3 * 10) return TMPC_FAST(-1, 10, 3, 64);
+        if (nr <= 3 * 13) return TMPC_FAST(-1, 13, 3, 64);
+        if (d.N <= 2 * (64 / 6) && nr <= 6 * 9 && !getenv("TMPC_NO_TWO_WAVE")) {   // more rows: two waves, 6 lanes per stage
+            *threads = 128;                                                  //   (mpc_planner_rosnavigation T-MPC: 24 + 12 rows)
+            return TMPC_FAST(-1, 9, 6, 128);
+        }
+    } else if (lps == 2) {
+        if (d.n_up == 0 && d.M == 4) return TMPC_FAST(0, 4, 2, 64);
+    }
+    return nullptr;
+#endif
+}
+// Compact variant (tmpc_fast.hpp: tmpc_solve_compact_kernel): two waves per SIMD, eight trajectories per CU, persistent
+// workgroups.  Bitwise the same results as the fast kernel of the shape (tools/ab_compare.py against TMPC_NO_COMPACT=1).
+// Round 4: the shapes with 13 rows per lane ((12,12) and (24,0) at three lanes per stage: cfg 4, cfg 5) fit 256 registers too since the
+// row passes are specialised by the compile-time kind of each row slot (FastCfg::KIND): 238 registers, zero scratch; their larger row tables
+// allow 7 (cfg 4: 23.3 KB) and 6 (cfg 5: 25.2 KB) workgroups per CU.  The runtime-shape instantiation with 13 rows per lane still spills
+// (168 B) and is not registered.
+static SolveKernel pick_compact_kernel(const Dims &d, bool prof)
+{
+#ifndef TMPC_GENERATED_STAGE
+    if (getenv("TMPC_FORCE_GENERIC") || getenv("TMPC_NO_COMPACT") || prof || d.N > 20 || d.cost_model != 0) return nullptr;
+    const int nr = d.n_up + d.M + 14;                    // interior-point rows per stage
+    if (d.n_up == 8 && d.M == 8) return (SolveKernel)tmpc_solve_compact_kernel<8, 8, 3, false>;
+    if (d.n_up == 0 && d.M == 4) return (SolveKernel)tmpc_solve_compact_kernel<0, 4, 3, false>;
+    if (d.n_up == 12 && d.M == 12) return (SolveKernel)tmpc_solve_compact_kernel<12, 12, 3, false>;
+    if (d.n_up == 24 && d.M == 0) return (SolveKernel)tmpc_solve_compact_kernel<24, 0, 3, false>;
+    if (nr <= 3 * 7) return (SolveKernel)tmpc_solve_compact_kernel<-1, 7, 3, false>;       // runtime-shape instantiations
+    if (nr <= 3 * 10) return (SolveKernel)tmpc_solve_compact_kernel<-1, 10, 3, false>;
+#endif
+    (void)d; (void)prof;
+    return nullptr;
+}
+// Latency variant (tmpc_set_latency_mode): two waves per trajectory at 6 lanes per stage, built for two waves per SIMD
+// (<= 256 registers, so four trajectories per CU stay resident).  The stage-parallel phases run on twice the lanes:
+// -8 % kernel time on a 64-trajectory control tick; on a saturated GPU the one-wave kernel is as fast or faster, which is
+// why it stays the default.  The variant is chosen by the caller, never by the batch size: a trajectory's result does
+// not depend on what else is in the launch.
+static SolveKernel pick_latency_kernel(const Dims &d, bool prof)
+{
+#ifndef TMPC_GENERATED_STAGE
+    if (getenv("TMPC_FORCE_GENERIC") || getenv("TMPC_NO_TWO_WAVE") || d.N > 2 * (64 / 6) || d.cost_model != 0) return nullptr;
+    if (d.n_up == 8 && d.M == 8) return TMPC_FAST(8, 8, 6, 128);
+#endif
+    (void)d; (void)prof;
+    return nullptr;
+}
+// Latency variant 2 (tmpc_set_latency_mode(h, 2)): one wave per trajectory like the fast kernels, the interior-point Newton systems
+// solved parallel in time (tmpc_scan.hpp) instead of by the sequential Riccati recursion.  One workgroup per CU is what a control
+// tick gives it anyway: built for one wave per SIMD (all 512 registers, 73 KB of LDS).  Another factorisation of the same systems:
+// steps agree with the recursion's to rounding (~1e-6 of a step on ill-conditioned late iterations, like the recursion itself
+// against an exact solve), so iteration counts can differ by one where a residual sits at the tolerance -- the caller opts in.
+static SolveKernel pick_scan_kernel(const Dims &d, int *threads, int *sl)
+{
+    *sl = 3;
+#ifndef TMPC_GENERATED_STAGE
+    if (getenv("TMPC_FORCE_GENERIC") || d.N > 31 || d.N < 2 || d.cost_model != 0) return nullptr;
+    if (d.N > 20) {                                              // 21 <= N <= 31 (cfg 3, the reference's N = 30 defaults): two lanes per stage in the
+        if (d.n_up + d.M + 14 > 4 * 12) return nullptr;          // Newton solve, the runtime-shape two-wave kernel (4 lanes per stage, up to 34 rows) around it
+        *threads = 128; *sl = 2;
+        return (SolveKernel)tmpc_solve_fast_kernel<-1, 12, 4, 128, false, ScanSoloT<2>>;
+    }
+    const char *w = getenv("TMPC_SCAN_WAVES");               // A/B: "1" = one wave per trajectory
+    if (d.n_up == 8 && d.M == 8 && d.N <= 2 * (64 / 6) && !(w && atoi(w) == 1)) { *threads = 128; return (SolveKernel)tmpc_solve_fast_kernel<8, 8, 6, 128, false, ScanSolo>; }
+    if (d.n_up == 8 && d.M == 8) { *threads = 64; return (SolveKernel)tmpc_solve_fast_kernel<8, 8, 3, 64, false, ScanSolo>; }
+    if (d.N <= 2 * (64 / 6) && d.n_up + d.M + 14 <= 6 * 9) {     // every other row mix of the one-wave shapes (cfg 1, cfg 4, cfg 5, ...): runtime row counts, two waves
+        *threads = 128;
+        return (SolveKernel)tmpc_solve_fast_kernel<-1, 9, 6, 128, false, ScanSolo>;
+    }
+#endif
+    (void)d; (void)threads;
+    return nullptr;
+}
+}  // namespace tmpc
+
+struct tmpc_handle {
+    tmpc::Dims d;
+    int B_max = 0, B = 0, device = 0;
+    hipStream_t stream = nullptr;
+    // inputs: owned staging buffers (tmpc_set_batch) or borrowed device pointers (tmpc_set_batch_device)
+    double *o_xinit = nullptr, *o_x0 = nullptr, *o_params = nullptr;
+    const double *xinit = nullptr, *x0 = nullptr, *params = nullptr;
+    double *xtraj = nullptr, *utraj = nullptr, *pobj = nullptr, *res_eq = nullptr, *d_weight = nullptr;
+    int *exit_code = nullptr, *qp_status = nullptr, *sqp_iter = nullptr, *qp_iter = nullptr, *d_best = nullptr;
+    uint8_t *d_disabled = nullptr;
+    size_t lds_bytes = 0;
+    tmpc::SolveKernel kernel = nullptr;
+    int threads = tmpc::NT;          // threads per trajectory (64, or 128 for the two-wave fast variant)
+    tmpc::SolveKernel kernel_lat = nullptr;   // optional latency variant (128 threads), used when latency_mode is 1
+    tmpc::SolveKernel kernel_scan = nullptr;  // optional latency variant 2 (parallel-in-time Newton solve, 64 threads)
+    size_t lds_bytes_scan = 0;
+    int scan_threads = 64, scan_sl = 3;
+    size_t lds_bytes_fast = 0;                // LDS of the fast-layout kernels (the profiled twin) when `kernel` is compact
+    size_t lds_bytes_fast2 = 0;               // ... of their two-wave variants (kernel_lat): + the W shares parked during the linearisation
+    bool compact = false;                     // `kernel` is a compact persistent kernel: grid = resident workgroups, needs ws + ticket
+    int grid_max = 0;                         // resident workgroups of the compact kernel on this device
+    double *ws = nullptr;                     // [grid_max][ws_doubles(N)] per-workgroup NLP workspace
+    int *ticket = nullptr;
+    int latency_mode = 0;                     // 0: throughput kernels, 1: two-wave variant, 2: parallel-in-time variant
+    bool throughput_mode = false;             // lane-per-trajectory kernels (tmpc_lanes.hip) instead of one wave per trajectory
+    tmpc::lanes::Context *lanes = nullptr;    // their HBM workspace, created when the mode is first enabled
+    bool fast = false;
+    // persistent per-slot solver state (tmpc_solve_iterations), allocated on first use
+    double *st_z = nullptr, *st_pi = nullptr, *st_lamh = nullptr;
+    int *st_stopped = nullptr;
+    int *st_has = nullptr;           // [B_max] the slot holds state of an earlier tmpc_solve_iterations (set by the kernels' store)
+    int *d_slot = nullptr;           // [B_max] state slot of every batch entry (tmpc_set_slots)
+    bool slots_set = false;
+    int slots_B = 0;                 // batch size the slot map was given for: a map of another size is refused, never read past its end
+    int *d_share = nullptr;          // [B_max] tmpc_set_param_sharing
+    int share_B = 0;                 // batch size the sharing map was given for (0: none)
+    bool st_valid = false;           // lane kernels (state = their workspace, per launch): it holds the result of a previous call ...
+    int st_B = 0;                    // ... for slots [0, st_B)
+    // SH-MPC bookkeeping: the sample behind each scenario row of the last tmpc_scenario_halfspaces (i32 [B][N][scn_rows])
+    unsigned char *scn_discard = nullptr;     // [B_max][scn_discard_S] scenarios discarded for each trajectory (tmpc_scenario_discard); applies to the next tmpc_scenario_halfspaces
+    int scn_discard_S = 0, scn_discard_B = 0, scn_discard_n = 0;
+    size_t scn_discard_cap = 0;
+    int *scn_sample = nullptr;
+    size_t scn_cap = 0;
+    int scn_rows = 0, scn_B = 0;
+    std::vector<hipEvent_t> ev;      // per-launch timing events (pairs)
+    int ev_used = 0;
+    bool timing = false;
+    std::string err;
+};
+
+#define TMPC_HIP_CHECK(h, expr)                                                                     \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess) {                                                                     \
+            (h)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                           \
+            return TMPC_ERR_HIP;                                                                    \
+        }                                                                                           \
+    } while (0)
+
+namespace {
+// Scratch device buffers / events of the diagnostic entry points: released on every return path.
+struct DevBufs {
+    std::vector<void *> p;
+    ~DevBufs() { for (void *q : p) if (q) (void)hipFree(q); }
+    hipError_t alloc(double **out, size_t bytes) { hipError_t e = hipMalloc(out, bytes ? bytes : 8); if (e == hipSuccess) p.push_back(*out); return e; }
+};
+struct Events {
+    std::vector<hipEvent_t> ev;
+    ~Events() { for (auto &e : ev) if (e) (void)hipEventDestroy(e); }
+};
+}  // namespace
+
+extern "C" {
+
+void tmpc_default_dims(tmpc_dims *d, int32_t N, int32_t S, int32_t n_lin, int32_t M) { tmpc_default_dims_ex(d, N, S, n_lin, M, 0, 0); }
+
+void tmpc_default_dims_ex(tmpc_dims *d, int32_t N, int32_t S, int32_t n_lin, int32_t M, int32_t n_slk, int32_t slack)
+{
+    memset(d, 0, sizeof *d);
+#ifdef TMPC_GENERATED_STAGE
+    // generated solver: the row / parameter structure is fixed by the generated stage functions
+    (void)n_lin; (void)M; (void)n_slk; (void)slack;
+    n_lin = tmpc_gen::NH; M = 0; n_slk = 0; slack = tmpc_gen::SLACK;
+#endif
+    d->N = N; d->S = S; d->n_lin = n_lin; d->M = M; d->n_slk = n_slk; d->slack = slack ? 1 : 0;
+    tmpc::Dims t; t.S = S; t.n_lin = n_lin; t.M = M; t.n_slk = n_slk; t.slack = d->slack;
+    d->npar = tmpc::expected_npar(t);
+    d->n_sqp = 10; d->qp_iter_max = 50; d->erk_steps = 3;
+    d->dt = 0.2; d->qp_tol = 1e-5; d->reg_eps = 1e-4; d->ipm_mu0 = 0.01; d->ipm_thr0 = 0.01;
+    const double lb[TMPC_NV] = {-2.0, -0.8, -2000.0, -2000.0, -M_PI * 4, -0.01, -1.0};
+    const double ub[TMPC_NV] = {2.0, 0.8, 2000.0, 2000.0, M_PI * 4, 3.0, 10000.0};
+    for (int i = 0; i < TMPC_NV; i++) { d->lb[i] = lb[i]; d->ub[i] = ub[i]; }
+}
+
+int tmpc_create(tmpc_handle **out, const tmpc_dims *dims, int32_t B_max, int32_t device)
+{
+    if (!out || !dims || B_max <= 0) return TMPC_ERR_INVALID;
+    *out = nullptr;
+    {
+        tmpc::Dims t; t.S = dims->S; t.n_lin = dims->n_lin; t.M = dims->M; t.n_slk = dims->n_slk; t.slack = dims->slack;
+        if (dims->N < 2 || dims->N > 62 || dims->S < 1 || dims->M < 0 || dims->n_lin < 0 || dims->n_slk < 0 ||
+            (dims->slack != 0 && dims->slack != 1) || dims->npar != tmpc::expected_npar(t) || dims->erk_steps < 1 ||
+            dims->n_sqp < 1 || dims->qp_iter_max < 1 || !(dims->dt > 0.0) || !(dims->qp_tol > 0.0) || !(dims->reg_eps > 0.0) ||
+            !(dims->ipm_mu0 > 0.0) || !(dims->ipm_thr0 > 0.0) || (dims->cost_model != 0 && dims->cost_model != 1))
+            return TMPC_ERR_INVALID;
+#ifdef TMPC_GENERATED_STAGE
+        if (dims->n_lin != tmpc_gen::NH || dims->M != 0 || dims->n_slk != 0 || dims->slack != tmpc_gen::SLACK || dims->cost_model != 0) return TMPC_ERR_INVALID;
+#endif
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return TMPC_ERR_NO_DEVICE;
+    tmpc_handle *h = new tmpc_handle();
+    h->device = device; h->B_max = B_max;
+    tmpc::Dims &d = h->d;
+    d.N = dims->N; d.S = dims->S; d.n_lin = dims->n_lin; d.M = dims->M; d.npar = dims->npar;
+    d.n_slk = dims->n_slk; d.slack = dims->slack; d.cost_model = dims->cost_model;
+    d.n_sqp = dims->n_sqp; d.qp_iter_max = dims->qp_iter_max; d.erk_steps = dims->erk_steps;
+    d.dt = dims->dt; d.qp_tol = dims->qp_tol; d.reg_eps = dims->reg_eps; d.mu0 = dims->ipm_mu0; d.thr0 = dims->ipm_thr0;
+    for (int i = 0; i < TMPC_NV; i++) { d.lb[i] = dims->lb[i]; d.ub[i] = dims->ub[i]; }
+    tmpc::derive_dims(d);
+    h->kernel = tmpc::pick_fast_kernel(d, &h->threads, false);
+    if (const char *lm = getenv("TMPC_LATENCY_MODE")) {      // experiments: latency variant regardless of the caller ("0", "1" or "2"; anything else is ignored)
+        if ((lm[0] == '0' || lm[0] == '1' || lm[0] == '2') && lm[1] == '\0') h->latency_mode = lm[0] - '0';
+    }
+    h->fast = h->kernel != nullptr;
+    if (h->fast) h->lds_bytes = sizeof(double) * (size_t)tmpc::lds_doubles_fast(d.N, d.n_up + d.M);
+    else { h->kernel = d.cost_model == 1 ? tmpc::tmpc_solve_kernel<1> : tmpc::tmpc_solve_kernel<0>; h->lds_bytes = sizeof(double) * (size_t)tmpc::lds_doubles(d.N, d.n_up + d.M); }
+    h->lds_bytes_fast = h->lds_bytes;
+    // two-wave (128-thread) fast kernels park one share of W per stage behind the layout while they linearise (linearise<.., 128>)
+    h->lds_bytes_fast2 = h->lds_bytes_fast + sizeof(double) * (size_t)d.N * tmpc::NP28;
+    if (h->fast && h->threads == 128) h->lds_bytes = h->lds_bytes_fast2;
+    auto fail = [&](int code) { delete h; return code; };
+    if (hipSetDevice(device) != hipSuccess) return fail(TMPC_ERR_HIP);
+    if (h->lds_bytes > 160 * 1024) return fail(TMPC_ERR_INVALID);
+    if (h->fast && h->threads == tmpc::NT && (h->kernel_lat = tmpc::pick_latency_kernel(d, false)) != nullptr) {
+        if (hipFuncSetAttribute((const void *)h->kernel_lat, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes_fast2) != hipSuccess)
+            h->kernel_lat = nullptr;
+    }
+    if (h->fast && (h->threads == tmpc::NT || d.N > 20) && (h->kernel_scan = tmpc::pick_scan_kernel(d, &h->scan_threads, &h->scan_sl)) != nullptr) {
+        h->lds_bytes_scan = h->lds_bytes_fast2 + sizeof(double) * (size_t)(h->scan_sl == 3 ? tmpc::scan::lds_doubles<3>(d.N) : tmpc::scan::lds_doubles<2>(d.N));
+        if (h->lds_bytes_scan > 160 * 1024) h->kernel_scan = nullptr;
+    }
+    if (h->kernel_scan) {
+        if (hipFuncSetAttribute((const void *)h->kernel_scan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes_scan) != hipSuccess)
+            h->kernel_scan = nullptr;
+    }
+    if (tmpc::SolveKernel kc = (h->fast && h->threads == tmpc::NT) ? tmpc::pick_compact_kernel(d, false) : nullptr) {
+        h->kernel = kc; h->compact = true;
+        h->lds_bytes = sizeof(double) * (size_t)tmpc::lds_doubles_compact(d.N, d.n_lin, d.n_up + d.M);
+    }
+    if (hipFuncSetAttribute((const void *)h->kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)h->lds_bytes) != hipSuccess)
+        return fail(TMPC_ERR_NO_DEVICE);
+    if (h->compact) {
+        int per_cu = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)h->kernel, 64, h->lds_bytes) != hipSuccess || per_cu <= 0 ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0)
+            return fail(TMPC_ERR_HIP);
+        if (const char *e = getenv("TMPC_COMPACT_PER_CU")) { const int v = atoi(e); if (v > 0 && v < per_cu) per_cu = v; }   // experiments
+        h->grid_max = per_cu * cus;
+    }
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return fail(TMPC_ERR_HIP);
+    const size_t N = d.N, B = B_max;
+    bool ok = true;
+    const size_t nxe = tmpc::ext_nx(d), nve = tmpc::ext_nv(d);
+    ok &= hipMalloc(&h->o_xinit, B * nxe * 8) == hipSuccess;
+    ok &= hipMalloc(&h->o_x0, B * (N + 1) * nve * 8) == hipSuccess;
+    ok &= hipMalloc(&h->o_params, B * N * d.npar * 8) == hipSuccess;
+    ok &= hipMalloc(&h->xtraj, B * (N + 1) * nxe * 8) == hipSuccess;
+    ok &= hipMalloc(&h->utraj, B * N * tmpc::NU * 8) == hipSuccess;
+    ok &= hipMalloc(&h->pobj, B * 8) == hipSuccess;
+    ok &= hipMalloc(&h->res_eq, B * 8) == hipSuccess;
+    ok &= hipMalloc(&h->d_weight, B * 8) == hipSuccess;
+    ok &= hipMalloc(&h->exit_code, B * 4) == hipSuccess;
+    ok &= hipMalloc(&h->qp_status, B * 4) == hipSuccess;
+    ok &= hipMalloc(&h->sqp_iter, B * 4) == hipSuccess;
+    ok &= hipMalloc(&h->qp_iter, B * 4) == hipSuccess;
+    ok &= hipMalloc(&h->d_best, 4) == hipSuccess;
+    ok &= hipMalloc(&h->d_disabled, B) == hipSuccess;
+    if (h->compact) {
+        ok &= hipMalloc(&h->ws, (size_t)h->grid_max * tmpc::ws_doubles(d.N) * 8) == hipSuccess;
+        ok &= hipMalloc(&h->ticket, 8 * 4) == hipSuccess;         // one work counter per XCD (next_trajectory)
+    }
+    if (!ok) { tmpc_destroy(h); return TMPC_ERR_HIP; }
+    *out = h;
+    return TMPC_OK;
+}
+
+void tmpc_destroy(tmpc_handle *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    void *ptrs[] = {h->o_xinit, h->o_x0, h->o_params, h->xtraj, h->utraj, h->pobj, h->res_eq, h->d_weight,
+                    h->exit_code, h->qp_status, h->sqp_iter, h->qp_iter, h->d_best, h->d_disabled,
+                    h->st_z, h->st_pi, h->st_lamh, h->st_stopped, h->st_has, h->d_slot, h->d_share, h->scn_sample, h->scn_discard, h->ws, h->ticket};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (auto &e : h->ev) (void)hipEventDestroy(e);
+    tmpc::lanes::destroy(h->lanes);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+const char *tmpc_last_error(const tmpc_handle *h) { return h ? h->err.c_str() : "null handle"; }
+
+int tmpc_set_batch(tmpc_handle *h, int32_t B, const double *xinit, const double *x0, const double *params)
+{
+    if (!h || B <= 0 || B > h->B_max || !xinit || !x0 || !params) { if (h) h->err = "tmpc_set_batch: bad argument"; return TMPC_ERR_INVALID; }
+    TMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    const size_t N = h->d.N;
+    TMPC_HIP_CHECK(h, hipMemcpyAsync(h->o_xinit, xinit, (size_t)B * tmpc::ext_nx(h->d) * 8, hipMemcpyHostToDevice, h->stream));
+    TMPC_HIP_CHECK(h, hipMemcpyAsync(h->o_x0, x0, (size_t)B * (N + 1) * tmpc::ext_nv(h->d) * 8, hipMemcpyHostToDevice, h->stream));
+    TMPC_HIP_CHECK(h, hipMemcpyAsync(h->o_params, params, (size_t)B * N * h->d.npar * 8, hipMemcpyHostToDevice, h->stream));
+    h->xinit = h->o_xinit; h->x0 = h->o_x0; h->params = h->o_params; h->B = B;
+    h->scn_B = 0;                      // new parameter rows: the scenario-row bookkeeping of the previous batch no longer describes them
+    h->scn_discard_B = 0;
+    h->share_B = 0;                    // ... nor does a parameter-sharing map given for them
+    return TMPC_OK;
+}
+
+int tmpc_set_batch_device(tmpc_handle *h, int32_t B, const void *d_xinit, const void *d_x0, const void *d_params)
+{
+    if (!h || B <= 0 || B > h->B_max || !d_xinit || !d_x0 || !d_params) { if (h) h->err = "tmpc_set_batch_device: bad argument"; return TMPC_ERR_INVALID; }
+    h->xinit = (const double *)d_xinit; h->x0 = (const double *)d_x0; h->params = (const double *)d_params; h->B = B;
+    h->scn_B = 0; h->scn_discard_B = 0; h->share_B = 0;
+    return TMPC_OK;
+}
+
+// One launch over the current batch: n_iter RTI iterations per trajectory + completeOneIteration.  st_flags: ST_* (0 = fresh
+// solver instances from the batch's warm start, nothing kept or stored: Solver::solve() of a new capsule).
+static int launch_solve(tmpc_handle *h, int n_iter, int st_flags)
+{
+    const bool rec = h->timing && h->ev_used + 2 <= (int)h->ev.size();
+    if (rec) TMPC_HIP_CHECK(h, hipEventRecord(h->ev[h->ev_used], h->stream));
+    if (h->throughput_mode) {
+        // lane-per-trajectory variant: transpose the reference-layout inputs into the lane-major workspace, then one launch of
+        // the scalar-per-lane SQP_RTI program; the workspace itself is the persistent state
+        if (tmpc::lanes::stage_in(h->lanes, h->stream, h->B, h->xinit, h->x0, h->params, !(st_flags & tmpc::ST_KEEP_ITERATE),
+                                  !(st_flags & tmpc::ST_KEEP_MULTIPLIERS), h->err)) return TMPC_ERR_HIP;
+        if (tmpc::lanes::solve(h->lanes, h->stream, h->B, n_iter, (st_flags & tmpc::ST_STORE) != 0, (st_flags & tmpc::ST_COMPLETE) != 0,
+                               h->xtraj, h->utraj, h->pobj,
+                               h->exit_code, h->qp_status, h->sqp_iter, h->res_eq, h->qp_iter, h->err)) return TMPC_ERR_HIP;
+    } else {
+        tmpc::Dims dd = h->d;
+        dd.n_sqp = n_iter;
+        tmpc::StateIO io{h->st_z, h->st_pi, h->st_lamh, h->st_stopped, st_flags, h->ws, h->ticket, (h->slots_set && h->slots_B == h->B) ? h->d_slot : nullptr, h->st_has,
+                         (h->share_B == h->B) ? h->d_share : nullptr};      // (a map given for another batch size is not applied)
+        const bool lat2 = h->kernel_scan && h->latency_mode == 2;
+        const bool lat = !lat2 && h->kernel_lat && h->latency_mode != 0;          // (mode 2 without a scan variant falls back to the two-wave variant)
+        const bool cp = h->compact && !lat && !lat2;
+        if (cp) TMPC_HIP_CHECK(h, hipMemsetAsync(h->ticket, 0, 8 * 4, h->stream));    // the persistent launch's work counters (one per XCD)
+        hipLaunchKernelGGL(lat2 ? h->kernel_scan : lat ? h->kernel_lat : h->kernel, dim3(cp ? (h->B < h->grid_max ? h->B : h->grid_max) : h->B),   // (persistent launch: at most the resident workgroups)
+                           dim3(lat2 ? h->scan_threads : lat ? 128 : (cp ? 64 : h->threads)), lat2 ? h->lds_bytes_scan : lat ? h->lds_bytes_fast2 : h->lds_bytes, h->stream, dd, h->B,
+                           h->xinit, h->x0, h->params, h->xtraj, h->utraj, h->pobj, h->exit_code, h->qp_status,
+                           h->sqp_iter, h->res_eq, h->qp_iter, (long long *)nullptr, io);
+        TMPC_HIP_CHECK(h, hipGetLastError());
+        if (st_flags & tmpc::ST_COMPLETE) {
+            // a failed solve resets the reference's capsule (Solver_acados_reset, acados_solver_interface.cpp:187-191): zero multipliers
+            const int n_pi = (h->d.N + 1) * tmpc::NX, n_lam = h->d.N * (h->d.n_up + h->d.M);
+            hipLaunchKernelGGL(tmpc::tmpc_state_finalize_kernel, dim3(h->B), dim3(64), 0, h->stream, n_pi, n_lam, h->exit_code, h->st_pi, h->st_lamh,
+                               (h->slots_set && h->slots_B == h->B) ? h->d_slot : nullptr);
+            TMPC_HIP_CHECK(h, hipGetLastError());
+        }
+    }
+    if (rec) { TMPC_HIP_CHECK(h, hipEventRecord(h->ev[h->ev_used + 1], h->stream)); h->ev_used += 2; }
+    return TMPC_OK;
+}
+
+// the slots' persistent state no longer describes what the handle last solved
+static int invalidate_state(tmpc_handle *h)
+{
+    h->st_valid = false; h->st_B = 0;
+    if (h->st_has) TMPC_HIP_CHECK(h, hipMemsetAsync(h->st_has, 0, (size_t)h->B_max * 4, h->stream));
+    return TMPC_OK;
+}
+
+int tmpc_solve(tmpc_handle *h)
+{
+    if (!h || h->B <= 0 || !h->xinit) { if (h) h->err = "tmpc_solve: no batch set"; return TMPC_ERR_INVALID; }
+    TMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    if (int rc = invalidate_state(h)) return rc;
+    return launch_solve(h, h->d.n_sqp, 0);
+}
+
+int tmpc_solve_iterations(tmpc_handle *h, int32_t n_iter, int32_t flags)
+{
+    if (!h || h->B <= 0 || !h->xinit || n_iter < 0 || (flags & ~15)) { if (h) h->err = "tmpc_solve_iterations: no batch set / bad argument"; return TMPC_ERR_INVALID; }
+    TMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    if (h->throughput_mode && h->slots_set) { h->err = "tmpc_solve_iterations: slot maps (tmpc_set_slots) are not available with the lane kernels"; return TMPC_ERR_INVALID; }
+    if (h->slots_set && h->slots_B != h->B) {
+        // the map has one entry per batch entry: entries [slots_B, B) of a larger batch would be read from uninitialised memory
+        h->err = "tmpc_solve_iterations: the slot map was given for a batch of " + std::to_string(h->slots_B) + " entries, the current batch has " +
+                 std::to_string(h->B) + ": call tmpc_set_slots again after tmpc_set_batch (or clear it with a null map)";
+        return TMPC_ERR_INVALID;
+    }
+    if (!h->throughput_mode && !h->st_z) {
+        const size_t B = h->B_max, N = h->d.N, nh = h->d.n_up + h->d.M;
+        const size_t sz[5] = {B * (N + 1) * tmpc::NV * 8, B * (N + 1) * tmpc::NX * 8, (B * N * nh + 1) * 8, B * 4, B * 4};
+        void **dst[5] = {(void **)&h->st_z, (void **)&h->st_pi, (void **)&h->st_lamh, (void **)&h->st_stopped, (void **)&h->st_has};
+        bool ok = true;
+        for (int i = 0; i < 5 && ok; i++) ok = hipMalloc(dst[i], sz[i]) == hipSuccess && hipMemsetAsync(*dst[i], 0, sz[i], h->stream) == hipSuccess;
+        if (!ok) {                          // all or nothing: a later call must not find half of the arrays
+            for (int i = 0; i < 5; i++) { if (*dst[i]) (void)hipFree(*dst[i]); *dst[i] = nullptr; }
+            h->err = "tmpc_solve_iterations: state allocation failed"; return TMPC_ERR_HIP;
+        }
+        h->st_valid = false; h->st_B = 0;
+    }
+    int st = tmpc::ST_STORE;
+    if (h->throughput_mode) {
+        // lane kernels keep their state per launch, not per slot: nothing to keep on the first call, and a grown batch starts fresh
+        if (!h->st_valid) h->st_B = 0;
+        if (h->B > h->st_B) h->st_valid = false;
+        if (h->st_valid) {
+            if (flags & TMPC_ITER_KEEP_ITERATE) st |= tmpc::ST_KEEP_ITERATE;
+            if (flags & TMPC_ITER_KEEP_MULTIPLIERS) st |= tmpc::ST_KEEP_MULTIPLIERS;
+        }
+    } else {
+        // wave kernels: the keep-flags apply per slot -- a slot without stored state (first call, grown batch, new slot of a map)
+        // starts like a fresh capsule (slot_flags in the kernels)
+        if (flags & TMPC_ITER_KEEP_ITERATE) st |= tmpc::ST_KEEP_ITERATE;
+        if (flags & TMPC_ITER_KEEP_MULTIPLIERS) st |= tmpc::ST_KEEP_MULTIPLIERS;
+    }
+    if (flags & TMPC_ITER_COMPLETE) st |= tmpc::ST_COMPLETE;
+    // a new solve() of the slots' Solvers: the "iteration loop has ended" marks belong to the previous solve (:105-106 is local to one solve())
+    if ((flags & TMPC_ITER_NEW_SOLVE) && !h->throughput_mode && h->st_stopped) TMPC_HIP_CHECK(h, hipMemsetAsync(h->st_stopped, 0, (size_t)h->B_max * 4, h->stream));
+    if ((flags & TMPC_ITER_NEW_SOLVE) && h->throughput_mode && h->lanes && tmpc::lanes::clear_stopped(h->lanes, h->stream, h->B_max, h->err)) return TMPC_ERR_HIP;
+    const int rc = launch_solve(h, n_iter, st);
+    if (rc == TMPC_OK && h->throughput_mode) { h->st_valid = true; if (h->B > h->st_B) h->st_B = h->B; }
+    return rc;
+}
+
+int tmpc_reset_multipliers(tmpc_handle *h)
+{
+    if (!h) return TMPC_ERR_INVALID;
+    TMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    if (h->throughput_mode) {
+        if (h->lanes && tmpc::lanes::reset_multipliers(h->lanes, h->stream, h->B_max, h->err)) return TMPC_ERR_HIP;
+    } else if (h->st_pi) {
+        const size_t B = h->B_max, N = h->d.N, nh = h->d.n_up + h->d.M;
+        TMPC_HIP_CHECK(h, hipMemsetAsync(h->st_pi, 0, B * (N + 1) * tmpc::NX * 8, h->stream));
+        TMPC_HIP_CHECK(h, hipMemsetAsync(h->st_lamh, 0, B * N * nh * 8, h->stream));
+    }
+    return TMPC_OK;
+}
+
+int tmpc_set_latency_mode(tmpc_handle *h, int32_t on)
+{
+    if (!h) return TMPC_ERR_INVALID;
+    if (on < 0 || on > 2) return TMPC_ERR_INVALID;
+    h->latency_mode = on;
+    if (on == 2) return h->kernel_scan ? TMPC_OK : 1;              // 1: accepted, but this shape has no such variant (mode 2 then runs as mode 1 if that exists)
+    return (on == 1 && !h->kernel_lat) ? 1 : TMPC_OK;
+}
+
+int tmpc_set_slots(tmpc_handle *h, const int32_t *slots)
+{
+    if (!h) return TMPC_ERR_INVALID;
+    if (!slots) { h->slots_set = false; h->slots_B = 0; return TMPC_OK; }
+    if (h->B <= 0) { h->err = "tmpc_set_slots: set the batch first (the map has one entry per batch entry)"; return TMPC_ERR_INVALID; }
+    std::vector<char> seen((size_t)h->B_max, 0);
+    for (int b = 0; b < h->B; b++) {
+        if (slots[b] < 0 || slots[b] >= h->B_max || seen[slots[b]]) { h->err = "tmpc_set_slots: slots must be distinct and in [0, B_max)"; return TMPC_ERR_INVALID; }
+        seen[slots[b]] = 1;
+    }
+    TMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    if (!h->d_slot) TMPC_HIP_CHECK(h, hipMalloc(&h->d_slot, (size_t)h->B_max * 4));
+    TMPC_HIP_CHECK(h, hipMemcpyAsync(h->d_slot, slots, (size_t)h->B * 4, hipMemcpyHostToDevice, h->stream));
+    TMPC_HIP_CHECK(h, hipStreamSynchronize(h->stream));            // (the caller's array may go away)
+    h->slots_set = true; h->slots_B = h->B;
+    return TMPC_OK;
+}
+
+int tmpc_set_param_sharing(tmpc_handle *h, const int32_t *base_of)
+{
+    if (!h) return TMPC_ERR_INVALID;
+    if (!base_of) { h->share_B = 0; return TMPC_OK; }
+#ifdef TMPC_GENERATED_STAGE
+    // generated stage functions read every parameter -- halfspace rows included -- from ONE row block (tmpc_gen::rows has no notion of
+    // "own" rows), so the hint cannot be honoured: it is accepted and ignored, as include/tmpc_hip.h says
+    h->share_B = 0;
+    return TMPC_OK;
+#endif
+    if (h->B <= 0) { h->err = "tmpc_set_param_sharing: set the batch first (the map has one entry per batch entry)"; return TMPC_ERR_INVALID; }
+    for (int b = 0; b < h->B; b++)
+        if (base_of[b] < 0 || base_of[b] >= h->B) { h->err = "tmpc_set_param_sharing: entries must be batch indices in [0, B)"; return TMPC_ERR_INVALID; }
+    TMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    if (!h->d_share) TMPC_HIP_CHECK(h, hipMalloc(&h->d_share, (size_t)h->B_max * 4));
+    TMPC_HIP_CHECK(h, hipMemcpyAsync(h->d_share, base_of, (size_t)h->B * 4, hipMemcpyHostToDevice, h->stream));
+    TMPC_HIP_CHECK(h, hipStreamSynchronize(h->stream));            // (the caller's array may go away)
+    h->share_B = h->B;
+    return TMPC_OK;
+}
+
+int tmpc_copy_state(tmpc_handle *dst, tmpc_handle *src)
+{
+    if (!dst || !src || dst == src) return TMPC_ERR_INVALID;
+    const tmpc::Dims &a = dst->d, &b = src->d;
+    if (a.N != b.N || a.n_up != b.n_up || a.M != b.M || dst->device != src->device || dst->throughput_mode || src->throughput_mode) {
+        dst->err = "tmpc_copy_state: handles of different shape / device / kernel family"; return TMPC_ERR_INVALID;
+    }
+    if (!src->st_z) return TMPC_OK;                                 // nothing stored yet
+    TMPC_HIP_CHECK(dst, hipSetDevice(dst->device));
+    TMPC_HIP_CHECK(dst, hipStreamSynchronize(src->stream));
+    if (!dst->st_z) {                                               // allocate through the regular path: an evaluation-only call on the (unset) batch is not possible, so inline it
+        const size_t B = dst->B_max, N = a.N, nh = a.n_up + a.M;
+        const size_t sz[5] = {B * (N + 1) * tmpc::NV * 8, B * (N + 1) * tmpc::NX * 8, (B * N * nh + 1) * 8, B * 4, B * 4};
+        void **p[5] = {(void **)&dst->st_z, (void **)&dst->st_pi, (void **)&dst->st_lamh, (void **)&dst->st_stopped, (void **)&dst->st_has};
+        bool ok = true;
+        for (int i = 0; i < 5 && ok; i++) ok = hipMalloc(p[i], sz[i]) == hipSuccess && hipMemsetAsync(*p[i], 0, sz[i], dst->stream) == hipSuccess;
+        if (!ok) { for (int i = 0; i < 5; i++) { if (*p[i]) (void)hipFree(*p[i]); *p[i] = nullptr; } dst->err = "tmpc_copy_state: allocation failed"; return TMPC_ERR_HIP; }
+    }
+    const size_t n = (size_t)(dst->B_max < src->B_max ? dst->B_max : src->B_max), N = a.N, nh = a.n_up + a.M;
+    TMPC_HIP_CHECK(dst, hipMemcpyAsync(dst->st_z, src->st_z, n * (N + 1) * tmpc::NV * 8, hipMemcpyDeviceToDevice, dst->stream));
+    TMPC_HIP_CHECK(dst, hipMemcpyAsync(dst->st_pi, src->st_pi, n * (N + 1) * tmpc::NX * 8, hipMemcpyDeviceToDevice, dst->stream));
+    TMPC_HIP_CHECK(dst, hipMemcpyAsync(dst->st_lamh, src->st_lamh, n * N * nh * 8, hipMemcpyDeviceToDevice, dst->stream));
+    TMPC_HIP_CHECK(dst, hipMemcpyAsync(dst->st_stopped, src->st_stopped, n * 4, hipMemcpyDeviceToDevice, dst->stream));
+    TMPC_HIP_CHECK(dst, hipMemcpyAsync(dst->st_has, src->st_has, n * 4, hipMemcpyDeviceToDevice, dst->stream));
+    TMPC_HIP_CHECK(dst, hipStreamSynchronize(dst->stream));
+    return TMPC_OK;
+}
+
+int tmpc_clear_slot(tmpc_handle *h, int32_t slot)
+{
+    if (!h || slot < 0 || slot >= h->B_max) { if (h) h->err = "tmpc_clear_slot: slot out of range"; return TMPC_ERR_INVALID; }
+    if (h->throughput_mode) { h->err = "tmpc_clear_slot: the lane kernels keep their state per launch, not per slot"; return TMPC_ERR_INVALID; }
+    if (!h->st_has) return TMPC_OK;                                 // nothing stored yet: every slot is fresh
+    TMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    TMPC_HIP_CHECK(h, hipMemsetAsync(h->st_has + slot, 0, 4, h->stream));
+    TMPC_HIP_CHECK(h, hipMemsetAsync(h->st_stopped + slot, 0, 4, h->stream));
+    return TMPC_OK;
+}
+
+int tmpc_set_throughput_mode(tmpc_handle *h, int32_t on)
+{
+    if (!h) return TMPC_ERR_INVALID;
+    if (on && h->d.cost_model != 0) { h->err = "tmpc_set_throughput_mode: the lane kernels have the MPCC contouring cost only"; return TMPC_ERR_INVALID; }
+    if (on && !h->lanes) {
+        TMPC_HIP_CHECK(h, hipSetDevice(h->device));
+        h->lanes = tmpc::lanes::create(h->d, h->B_max, h->err);
+        if (!h->lanes) return TMPC_ERR_HIP;
+    }
+    if (h->throughput_mode != (on != 0)) { if (int rc = invalidate_state(h)) return rc; }      // the two kernel families keep their persistent state separately
+    h->throughput_mode = on != 0;
+    return TMPC_OK;
+}
+
+int tmpc_synchronize(tmpc_handle *h)
+{
+    if (!h) return TMPC_ERR_INVALID;
+    TMPC_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    return TMPC_OK;
+}
+
+int tmpc_get(tmpc_handle *h, double *xtraj, double *utraj, double *pobj, int32_t *exit_code, int32_t *qp_status,
+             int32_t *sqp_iter, double *res_eq, int32_t *qp_iter_total)
+{
+    if (!h || h->B <= 0) return TMPC_ERR_INVALID;
+    TMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    const size_t N = h->d.N, B = h->B;
+    auto cp = [&](void *dst, const void *src, size_t n) { return dst ? hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, h->stream) : hipSuccess; };
+    TMPC_HIP_CHECK(h, cp(xtraj, h->xtraj, B * (N + 1) * tmpc::ext_nx(h->d) * 8));
+    TMPC_HIP_CHECK(h, cp(utraj, h->utraj, B * N * tmpc::NU * 8));
+    TMPC_HIP_CHECK(h, cp(pobj, h->pobj, B * 8));
+    TMPC_HIP_CHECK(h, cp(res_eq, h->res_eq, B * 8));
+    TMPC_HIP_CHECK(h, cp(exit_code, h->exit_code, B * 4));
+    TMPC_HIP_CHECK(h, cp(qp_status, h->qp_status, B * 4));
+    TMPC_HIP_CHECK(h, cp(sqp_iter, h->sqp_iter, B * 4));
+    TMPC_HIP_CHECK(h, cp(qp_iter_total, h->qp_iter, B * 4));
+    TMPC_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    return TMPC_OK;
+}
+
+int tmpc_select_best(tmpc_handle *h, int32_t first, int32_t count, const double *weight, const uint8_t *disabled, int32_t *best)
+{
+    if (!h || !best || first < 0 || count <= 0 || first + count > h->B) { if (h) h->err = "tmpc_select_best: bad range"; return TMPC_ERR_INVALID; }
+    TMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    if (weight) TMPC_HIP_CHECK(h, hipMemcpyAsync(h->d_weight, weight, (size_t)count * 8, hipMemcpyHostToDevice, h->stream));
+    if (disabled) TMPC_HIP_CHECK(h, hipMemcpyAsync(h->d_disabled, disabled, (size_t)count, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(tmpc::tmpc_select_best_kernel, dim3(1), dim3(256), 0, h->stream, first, count, h->pobj, h->exit_code,
+                       weight ? h->d_weight : nullptr, disabled ? h->d_disabled : nullptr, h->d_best);
+    TMPC_HIP_CHECK(h, hipGetLastError());
+    TMPC_HIP_CHECK(h, hipMemcpyAsync(best, h->d_best, 4, hipMemcpyDeviceToHost, h->stream));
+    TMPC_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    return TMPC_OK;
+}
+
+int tmpc_get_stream(tmpc_handle *h, void **stream)
+{
+    if (!h || !stream) return TMPC_ERR_INVALID;
+    *stream = (void *)h->stream;
+    return TMPC_OK;
+}
+
+int tmpc_kernel_info(const tmpc_handle *h, char *buf, int32_t capacity)
+{
+    if (!h || !buf || capacity <= 0) return TMPC_ERR_INVALID;
+    const char *family = h->throughput_mode ? "lanes (one lane per trajectory)"
+                         : !h->fast        ? "generic (one wave per trajectory, rows in LDS)"
+                         : !h->compact     ? (h->threads == 128 ? "fast, two waves per trajectory" : "fast (one wave per trajectory)")
+                                           : "compact (one wave per trajectory, two waves per SIMD)";
+    const int n = snprintf(buf, (size_t)capacity, "%s; trajectories per workgroup %d; LDS %zu B per workgroup; %s", family, 1,
+                           h->lds_bytes, h->compact ? (std::string("persistent launch, resident workgroups ") + std::to_string(h->grid_max)).c_str()
+                                                    : "one workgroup per trajectory");
+    return n < capacity ? n : capacity - 1;
+}
+
+int tmpc_result_device_ptrs(tmpc_handle *h, void **d_pobj, void **d_exit_code)
+{
+    if (!h) return TMPC_ERR_INVALID;
+    if (d_pobj) *d_pobj = h->pobj;
+    if (d_exit_code) *d_exit_code = h->exit_code;
+    return TMPC_OK;
+}
+
+int tmpc_pack_records(tmpc_handle *h, void *d_records, const void *d_guidance_id, const void *d_weight)
+{
+    if (!h || h->B <= 0 || !d_records) return TMPC_ERR_INVALID;
+    TMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    hipLaunchKernelGGL(tmpc::tmpc_pack_records_kernel, dim3((h->B + 255) / 256), dim3(256), 0, h->stream, h->B, h->pobj,
+                       h->exit_code, (const int *)d_guidance_id, (const double *)d_weight, (tmpc_record *)d_records);
+    TMPC_HIP_CHECK(h, hipGetLastError());
+    return TMPC_OK;
+}
+
+int tmpc_select_best_records(tmpc_handle *h, const void *d_records, int32_t n_ranks, int32_t n_scenes, int32_t per_rank, void *d_best)
+{
+    if (!h || !d_records || !d_best || n_ranks <= 0 || n_scenes <= 0 || per_rank <= 0) return TMPC_ERR_INVALID;
+    TMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    hipLaunchKernelGGL(tmpc::tmpc_select_best_records_kernel, dim3(n_scenes), dim3(64), 0, h->stream,
+                       (const tmpc_record *)d_records, n_ranks, n_scenes, per_rank, (int *)d_best);
+    TMPC_HIP_CHECK(h, hipGetLastError());
+    return TMPC_OK;
+}
+
+int tmpc_gather_best(tmpc_handle *h, const void *d_best, int32_t n_sets, int32_t set_size, int32_t index_offset, void *d_xtraj, void *d_utraj)
+{
+    if (!h || !d_best || !d_xtraj || !d_utraj || n_sets <= 0 || set_size <= 0 || index_offset < 0 || (int64_t)n_sets * set_size > h->B) {
+        if (h) h->err = "tmpc_gather_best: bad argument (n_sets x set_size entries of the current batch)";
+        return TMPC_ERR_INVALID;
+    }
+    TMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    hipLaunchKernelGGL(tmpc::tmpc_gather_best_kernel, dim3(n_sets), dim3(64), 0, h->stream, (const int *)d_best, set_size, index_offset,
+                       (h->d.N + 1) * tmpc::ext_nx(h->d), h->d.N * tmpc::NU, h->xtraj, h->utraj, (double *)d_xtraj, (double *)d_utraj);
+    TMPC_HIP_CHECK(h, hipGetLastError());
+    return TMPC_OK;
+}
+
+int tmpc_linearize_topology_ex(tmpc_handle *h, const void *d_obstacle_pos, int32_t n_obstacles, const void *d_obstacle_radius,
+                               const void *d_static_halfspaces, int32_t n_static, const void *d_scene_of, const void *d_state_x,
+                               double robot_radius, const void *d_is_original)
+{
+#ifdef TMPC_GENERATED_STAGE
+    if (h) h->err = "tmpc_linearize_topology: not available in a generated solver (its parameter layout is the module stack's)";
+    return TMPC_ERR_INVALID;
+#endif
+    if (!h || h->B <= 0 || !h->params || !d_scene_of || !d_state_x || h->d.n_lin <= 0 || n_obstacles < 0 || n_static < 0 ||
+        n_obstacles + n_static > h->d.n_lin || (n_obstacles > 0 && !d_obstacle_pos) || (n_static > 0 && !d_static_halfspaces)) {
+        if (h) h->err = "tmpc_linearize_topology: bad argument / no batch / more obstacle + static rows than the problem's topology rows";
+        return TMPC_ERR_INVALID;
+    }
+    TMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    const int n = h->B * h->d.N;
+    hipLaunchKernelGGL(tmpc::tmpc_linearize_topology_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->d, h->B,
+                       h->x0, const_cast<double *>(h->params), (const double *)d_obstacle_pos, (const int *)d_scene_of,
+                       (const double *)d_state_x, robot_radius, (const uint8_t *)d_is_original, n_obstacles, (const double *)d_obstacle_radius,
+                       (const double *)d_static_halfspaces, n_static);
+    TMPC_HIP_CHECK(h, hipGetLastError());
+    return TMPC_OK;
+}
+
+int tmpc_linearize_topology(tmpc_handle *h, const void *d_obstacle_pos, const void *d_scene_of, const void *d_state_x,
+                            double robot_radius, const void *d_is_original)
+{
+    if (!h || !d_obstacle_pos) { if (h) h->err = "tmpc_linearize_topology: bad argument"; return TMPC_ERR_INVALID; }
+    return tmpc_linearize_topology_ex(h, d_obstacle_pos, h->d.n_lin, nullptr, nullptr, 0, d_scene_of, d_state_x, robot_radius, d_is_original);
+}
+
+int tmpc_scenario_halfspaces(tmpc_handle *h, const void *d_samples, int32_t n_pts, int32_t n_rows, const void *d_scene_of,
+                             const void *d_state_x, double radius, double disc_offset)
+{
+#ifdef TMPC_GENERATED_STAGE
+    if (h) h->err = "tmpc_scenario_halfspaces: not available in a generated solver (its parameter layout is the module stack's)";
+    return TMPC_ERR_INVALID;
+#endif
+    if (!h || h->B <= 0 || !h->params || !d_samples || !d_scene_of || !d_state_x || n_pts <= 0 || n_rows <= 0 || n_rows > 64 ||
+        n_rows > h->d.n_slk) {
+        if (h) h->err = "tmpc_scenario_halfspaces: bad argument / no batch / more rows than the problem's slack rows";
+        return TMPC_ERR_INVALID;
+    }
+    TMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    const size_t per_entry = 3 * sizeof(double) + sizeof(int);                        // a candidate: normal, margin, index word
+    hipFuncAttributes fa;
+    TMPC_HIP_CHECK(h, hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(tmpc::tmpc_scenario_halfspaces_kernel)));
+    if ((size_t)n_pts * per_entry + fa.sharedSizeBytes > 160 * 1024) {      // the second pass's list (room for every sample) + the kernel's static tables
+        h->err = "tmpc_scenario_halfspaces: that many samples per stage do not fit a workgroup's LDS (160 KiB minus the kernel's static tables: about 5480)";
+        return TMPC_ERR_INVALID;
+    }
+    const size_t units = (size_t)h->B * h->d.N;
+    const size_t need = units * n_rows + 1 + units + (size_t)h->B;  // rows' samples, the first pass's overflow list (count, units), empty-polygon stages per trajectory
+    if (need > h->scn_cap) {
+        if (h->scn_sample) { TMPC_HIP_CHECK(h, hipStreamSynchronize(h->stream)); (void)hipFree(h->scn_sample); h->scn_sample = nullptr; h->scn_cap = 0; }
+        TMPC_HIP_CHECK(h, hipMalloc(&h->scn_sample, need * sizeof(int)));
+        h->scn_cap = need;
+    }
+    h->scn_rows = n_rows; h->scn_B = h->B;
+    // scenarios discarded for this batch (tmpc_scenario_discard after the batch was set) are left out of the polygons
+    const bool use_discard = h->scn_discard && h->scn_discard_B == h->B && h->scn_discard_S > 0 && n_pts % h->scn_discard_S == 0;
+    // first pass with a short candidate list (more workgroups per CU); second pass, with room for every sample, only for the
+    // units the first pass recorded as not fitting
+    int *overflow = h->scn_sample + units * n_rows;
+    int *empty_stages = overflow + 1 + units;
+    TMPC_HIP_CHECK(h, hipMemsetAsync(overflow, 0, sizeof(int), h->stream));
+    TMPC_HIP_CHECK(h, hipMemsetAsync(empty_stages, 0, sizeof(int) * (size_t)h->B, h->stream));
+    const int cap1 = n_pts < tmpc::POLY_LIST_CAP ? n_pts : tmpc::POLY_LIST_CAP;
+    for (int pass = 0; pass < (cap1 < n_pts ? 2 : 1); pass++) {
+        const int cap = pass == 0 ? cap1 : n_pts;
+        const size_t lds = (size_t)cap * per_entry;
+        if (lds > 48 * 1024)
+            TMPC_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(tmpc::tmpc_scenario_halfspaces_kernel),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(tmpc::tmpc_scenario_halfspaces_kernel, dim3(pass == 0 ? units : (units < 512 ? units : 512)), dim3(256), lds, h->stream, h->d, h->B, h->x0,
+                           const_cast<double *>(h->params), (const double *)d_samples, n_pts, n_rows, (const int *)d_scene_of,
+                           (const double *)d_state_x, radius, disc_offset, h->scn_sample, cap, overflow, pass, empty_stages,
+                           use_discard ? h->scn_discard : nullptr, use_discard ? h->scn_discard_S : 1);
+    }
+    TMPC_HIP_CHECK(h, hipGetLastError());
+    return TMPC_OK;
+}
+
+int tmpc_sample_scenarios(tmpc_handle *h, const void *d_pred, const void *d_prob, int32_t n_solvers, int32_t n_obstacles, int32_t n_modes,
+                          int32_t n_scenarios, uint64_t seed, void *d_samples)
+{
+    if (!h || !d_pred || !d_prob || !d_samples || n_solvers <= 0 || n_obstacles <= 0 || n_modes <= 0 || n_scenarios <= 0) {
+        if (h) h->err = "tmpc_sample_scenarios: bad argument";
+        return TMPC_ERR_INVALID;
+    }
+    TMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    const int n = n_solvers * n_obstacles * n_scenarios;
+    hipLaunchKernelGGL(tmpc::tmpc_sample_scenarios_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->d.N, n_solvers, n_obstacles, n_modes,
+                       n_scenarios, (unsigned long long)seed, (const double *)d_pred, (const double *)d_prob, (double *)d_samples);
+    TMPC_HIP_CHECK(h, hipGetLastError());
+    return TMPC_OK;
+}
+
+int tmpc_scenario_discard(tmpc_handle *h, const void *d_samples, int32_t n_pts, int32_t n_scenarios, int32_t n_discard, const void *d_scene_of, double radius)
+{
+    if (!h || h->B <= 0 || !h->x0 || !d_samples || !d_scene_of || n_pts <= 0 || n_scenarios <= 0 || n_pts % n_scenarios != 0 || n_discard < 0 ||
+        n_discard >= n_scenarios || n_scenarios > 16384) {
+        if (h) h->err = "tmpc_scenario_discard: bad argument / no batch (n_pts = obstacles x n_scenarios, 0 <= n_discard < n_scenarios <= 16384)";
+        return TMPC_ERR_INVALID;
+    }
+    TMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    const size_t need = (size_t)h->B_max * n_scenarios;
+    if (need > h->scn_discard_cap) {
+        if (h->scn_discard) { TMPC_HIP_CHECK(h, hipStreamSynchronize(h->stream)); (void)hipFree(h->scn_discard); h->scn_discard = nullptr; h->scn_discard_cap = 0; }
+        TMPC_HIP_CHECK(h, hipMalloc(&h->scn_discard, need));
+        h->scn_discard_cap = need;
+    }
+    const size_t lds = (size_t)n_scenarios * sizeof(double);
+    if (lds > 48 * 1024)
+        TMPC_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(tmpc::tmpc_scenario_discard_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(tmpc::tmpc_scenario_discard_kernel, dim3(h->B), dim3(256), lds, h->stream, h->d, h->B, h->x0, (const double *)d_samples, n_pts,
+                       n_scenarios, (const int *)d_scene_of, radius, n_discard, h->scn_discard);
+    TMPC_HIP_CHECK(h, hipGetLastError());
+    h->scn_discard_S = n_scenarios; h->scn_discard_B = h->B; h->scn_discard_n = n_discard;
+    return TMPC_OK;
+}
+
+int tmpc_scenario_discarded(tmpc_handle *h, void *d_mask)
+{
+    if (!h || !d_mask || !h->scn_discard || h->scn_discard_B != h->B) { if (h) h->err = "tmpc_scenario_discarded: no discard set for the current batch"; return TMPC_ERR_INVALID; }
+    TMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    TMPC_HIP_CHECK(h, hipMemcpyAsync(d_mask, h->scn_discard, (size_t)h->B * h->scn_discard_S, hipMemcpyDeviceToDevice, h->stream));
+    return TMPC_OK;
+}
+
+int tmpc_scenario_empty_stages(tmpc_handle *h, void *d_count)
+{
+    if (!h || !d_count) return TMPC_ERR_INVALID;
+    if (!h->scn_sample || h->scn_B != h->B || h->B <= 0) { h->err = "tmpc_scenario_empty_stages: the scenario rows of the current batch were not built by tmpc_scenario_halfspaces"; return TMPC_ERR_INVALID; }
+    TMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    const size_t units = (size_t)h->B * h->d.N;
+    TMPC_HIP_CHECK(h, hipMemcpyAsync(d_count, h->scn_sample + units * h->scn_rows + 1 + units, sizeof(int) * (size_t)h->B, hipMemcpyDeviceToDevice, h->stream));
+    return TMPC_OK;
+}
+
+int tmpc_scenario_support(tmpc_handle *h, int32_t n_scenarios, double tol, void *d_support, void *d_active_rows)
+{
+    if (!h || !d_support || n_scenarios <= 0 || n_scenarios > 8192 || !(tol >= 0.0)) {
+        if (h) h->err = "tmpc_scenario_support: bad argument (1 <= n_scenarios <= 8192, tol >= 0)";
+        return TMPC_ERR_INVALID;
+    }
+    if (!h->scn_sample || h->scn_B != h->B || h->B <= 0 || !h->params) {
+        h->err = "tmpc_scenario_support: the scenario rows of the current batch were not built by tmpc_scenario_halfspaces (call it after tmpc_set_batch)";
+        return TMPC_ERR_INVALID;
+    }
+    TMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    hipLaunchKernelGGL(tmpc::tmpc_scenario_support_kernel, dim3(h->B), dim3(64), 0, h->stream, h->d, h->B, h->params, h->xtraj,
+                       h->scn_sample, h->scn_rows, n_scenarios, tol, (int *)d_support, (int *)d_active_rows);
+    TMPC_HIP_CHECK(h, hipGetLastError());
+    return TMPC_OK;
+}
+
+int tmpc_warmstart(tmpc_handle *h, const void *d_state, const void *d_mode, const void *d_src, double deceleration)
+{
+    if (!h || h->B <= 0 || !h->x0 || !h->xinit || !d_state) { if (h) h->err = "tmpc_warmstart: bad argument / no batch"; return TMPC_ERR_INVALID; }
+    TMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    const int n = h->B * (h->d.N + 1);
+    hipLaunchKernelGGL(tmpc::tmpc_warmstart_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->d, h->B, (const double *)d_state,
+                       (const int *)d_mode, (const int *)d_src, h->xtraj, h->utraj, const_cast<double *>(h->x0),
+                       const_cast<double *>(h->xinit), deceleration);
+    TMPC_HIP_CHECK(h, hipGetLastError());
+    return TMPC_OK;
+}
+
+int tmpc_init_with_guidance(tmpc_handle *h, const void *d_gpos, const void *d_gvel, const void *d_enabled)
+{
+    if (!h || h->B <= 0 || !h->x0 || !d_gpos || !d_gvel) { if (h) h->err = "tmpc_init_with_guidance: bad argument / no batch"; return TMPC_ERR_INVALID; }
+    TMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    const int n = h->B * (h->d.N + 1);
+    hipLaunchKernelGGL(tmpc::tmpc_init_with_guidance_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->d, h->B,
+                       (const double *)d_gpos, (const double *)d_gvel, (const uint8_t *)d_enabled, const_cast<double *>(h->x0));
+    TMPC_HIP_CHECK(h, hipGetLastError());
+    return TMPC_OK;
+}
+
+int tmpc_debug_get_x0(tmpc_handle *h, double *x0, double *xinit)
+{
+    if (!h || h->B <= 0 || !h->x0) return TMPC_ERR_INVALID;
+    TMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    TMPC_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    if (x0) TMPC_HIP_CHECK(h, hipMemcpy(x0, h->x0, (size_t)h->B * (h->d.N + 1) * tmpc::ext_nv(h->d) * 8, hipMemcpyDeviceToHost));
+    if (xinit) TMPC_HIP_CHECK(h, hipMemcpy(xinit, h->xinit, (size_t)h->B * tmpc::ext_nx(h->d) * 8, hipMemcpyDeviceToHost));
+    return TMPC_OK;
+}
+
+int tmpc_enable_timing(tmpc_handle *h, int32_t max_records)
+{
+    if (!h || max_records < 0) return TMPC_ERR_INVALID;
+    TMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    for (auto &e : h->ev) (void)hipEventDestroy(e);
+    h->ev.clear(); h->ev_used = 0; h->timing = max_records > 0;
+    h->ev.resize(2 * (size_t)max_records);
+    for (auto &e : h->ev) TMPC_HIP_CHECK(h, hipEventCreate(&e));
+    return TMPC_OK;
+}
+
+int tmpc_get_timings(tmpc_handle *h, float *ms, int32_t capacity, int32_t *n_out)
+{
+    if (!h || !ms || !n_out) return TMPC_ERR_INVALID;
+    TMPC_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    int n = h->ev_used / 2; if (n > capacity) n = capacity;
+    for (int i = 0; i < n; i++) TMPC_HIP_CHECK(h, hipEventElapsedTime(&ms[i], h->ev[2 * i], h->ev[2 * i + 1]));
+    *n_out = n; h->ev_used = 0;
+    return TMPC_OK;
+}
+
+int tmpc_time_solve(tmpc_handle *h, int32_t reps, float *ms_each)
+{
+    if (!h || reps <= 0 || !ms_each) return TMPC_ERR_INVALID;
+    TMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    Events evs; evs.ev.assign(2 * (size_t)reps, nullptr);
+    std::vector<hipEvent_t> &ev = evs.ev;
+    for (auto &e : ev) TMPC_HIP_CHECK(h, hipEventCreate(&e));
+    for (int i = 0; i < reps; i++) {
+        TMPC_HIP_CHECK(h, hipEventRecord(ev[2 * i], h->stream));
+        int rc = tmpc_solve(h);
+        if (rc != TMPC_OK) return rc;
+        TMPC_HIP_CHECK(h, hipEventRecord(ev[2 * i + 1], h->stream));
+    }
+    TMPC_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    for (int i = 0; i < reps; i++) TMPC_HIP_CHECK(h, hipEventElapsedTime(&ms_each[i], ev[2 * i], ev[2 * i + 1]));
+    return TMPC_OK;
+}
+
+int tmpc_debug_get_params(tmpc_handle *h, double *params)
+{
+    if (!h || h->B <= 0 || !params || !h->params) return TMPC_ERR_INVALID;
+    TMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    TMPC_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    TMPC_HIP_CHECK(h, hipMemcpy(params, h->params, (size_t)h->B * h->d.N * h->d.npar * 8, hipMemcpyDeviceToHost));
+    return TMPC_OK;
+}
+
+int tmpc_debug_profile(tmpc_handle *h, int64_t *cycles, int32_t n_phases)
+{
+    if (!h || h->B <= 0 || !cycles || n_phases < tmpc::PH_COUNT) return TMPC_ERR_INVALID;
+    TMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    DevBufs bufs;
+    double *dp_ = nullptr;
+    const size_t n = (size_t)h->B * tmpc::PH_COUNT;
+    TMPC_HIP_CHECK(h, bufs.alloc(&dp_, n * 8));
+    long long *dp = (long long *)dp_;
+    TMPC_HIP_CHECK(h, hipMemset(dp, 0, n * 8));
+    tmpc::SolveKernel pk = h->kernel;                   // the generic kernel profiles itself; fast shapes have an instrumented twin
+    int thr = h->threads;
+    size_t lds = h->fast ? h->lds_bytes_fast : h->lds_bytes;
+    if (h->fast && h->threads == 128) lds = h->lds_bytes_fast2;
+    if (h->fast && h->d.cost_model != 0) { h->err = "tmpc_debug_profile: no profiled twin for the curvature-aware cost"; return TMPC_ERR_INVALID; }
+    if (h->fast) {
+        pk = tmpc::pick_fast_kernel(h->d, &thr, true);
+#ifndef TMPC_GENERATED_STAGE
+        // the latency variants of cfg 2 are profiled as themselves (tmpc_set_latency_mode before the call)
+        if (h->latency_mode == 2 && h->kernel_scan && h->scan_threads == 128 && h->scan_sl == 3 && h->d.n_up == 8 && h->d.M == 8) {
+            pk = (tmpc::SolveKernel)tmpc::tmpc_solve_fast_kernel<8, 8, 6, 128, true, tmpc::ScanSolo>; thr = 128; lds = h->lds_bytes_scan;
+        } else if (h->latency_mode != 0 && h->kernel_lat) {
+            pk = tmpc::pick_latency_kernel(h->d, true); thr = 128; lds = h->lds_bytes_fast2;
+        }
+#endif
+        TMPC_HIP_CHECK(h, hipFuncSetAttribute((const void *)pk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    // (a compact handle is profiled through the fast kernel of its shape: same phases and arithmetic, one wave per SIMD)
+    hipLaunchKernelGGL(pk, dim3(h->B), dim3(thr), lds, h->stream, h->d, h->B,
+                       h->xinit, h->x0, h->params, h->xtraj, h->utraj, h->pobj, h->exit_code, h->qp_status,
+                       h->sqp_iter, h->res_eq, h->qp_iter, dp, tmpc::StateIO{nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr});
+    TMPC_HIP_CHECK(h, hipGetLastError());
+    TMPC_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    std::vector<long long> host(n);
+    TMPC_HIP_CHECK(h, hipMemcpy(host.data(), dp, n * 8, hipMemcpyDeviceToHost));
+    for (int i = 0; i < tmpc::PH_COUNT; i++) {
+        double acc = 0.0;
+        for (int b = 0; b < h->B; b++) acc += (double)host[(size_t)b * tmpc::PH_COUNT + i];
+        cycles[i] = (int64_t)(acc / h->B);
+    }
+    return TMPC_OK;
+}
+
+int tmpc_debug_eval_stage(tmpc_handle *h, int32_t n, const double *z, const double *p, const double *pi, const double *lamh,
+                          double *cost, double *cost_grad, double *cost_hess, double *hval, double *h_jac,
+                          double *x_next, double *x_jac, double *lag_hess, double *mirror)
+{
+    if (!h || n <= 0 || !z || !p) return TMPC_ERR_INVALID;
+    TMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    const int nh = h->d.n_up + h->d.M;
+    const size_t sz_in[4] = {(size_t)n * tmpc::ext_nv(h->d) * 8, (size_t)n * h->d.npar * 8, (size_t)n * 5 * 8, (size_t)n * nh * 8};
+    const void *src[4] = {z, p, pi, lamh};
+    DevBufs bufs;
+    double *din[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (int i = 0; i < 4; i++) {
+        if (!src[i]) continue;
+        TMPC_HIP_CHECK(h, bufs.alloc(&din[i], sz_in[i]));
+        TMPC_HIP_CHECK(h, hipMemcpy(din[i], src[i], sz_in[i], hipMemcpyHostToDevice));
+    }
+    const size_t sz_out[9] = {(size_t)n * 8, (size_t)n * 7 * 8, (size_t)n * 49 * 8, (size_t)n * nh * 8, (size_t)n * nh * 7 * 8,
+                              (size_t)n * 5 * 8, (size_t)n * 35 * 8, (size_t)n * 49 * 8, (size_t)n * 49 * 8};
+    double *dout[9]; void *dst[9] = {cost, cost_grad, cost_hess, hval, h_jac, x_next, x_jac, lag_hess, mirror};
+    for (int i = 0; i < 9; i++) TMPC_HIP_CHECK(h, bufs.alloc(&dout[i], sz_out[i]));
+    hipLaunchKernelGGL(tmpc::tmpc_debug_eval_kernel, dim3((n + 63) / 64), dim3(64), 0, h->stream, h->d, n, din[0], din[1], din[2], din[3],
+                       dout[0], dout[1], dout[2], dout[3], dout[4], dout[5], dout[6], dout[7], dout[8]);
+    TMPC_HIP_CHECK(h, hipGetLastError());
+    TMPC_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    for (int i = 0; i < 9; i++)
+        if (dst[i]) TMPC_HIP_CHECK(h, hipMemcpy(dst[i], dout[i], sz_out[i], hipMemcpyDeviceToHost));
+    return TMPC_OK;
+}
+
+#ifdef TMPC_SWEEP_PROFILE
+// Profiling build only (not declared in tmpc_hip.h): read and reset the sweep clock accumulators.
+int tmpc_debug_sweep_profile(tmpc_handle *h, uint64_t *out, int32_t n)
+{
+    if (!h || !out || n < tmpc::SP_COUNT) return TMPC_ERR_INVALID;
+    TMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    TMPC_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    unsigned long long host[tmpc::SP_COUNT];
+    TMPC_HIP_CHECK(h, hipMemcpyFromSymbol(host, HIP_SYMBOL(tmpc::g_sweep_prof), sizeof host));
+    for (int i = 0; i < tmpc::SP_COUNT; i++) out[i] = host[i];
+    memset(host, 0, sizeof host);
+    TMPC_HIP_CHECK(h, hipMemcpyToSymbol(HIP_SYMBOL(tmpc::g_sweep_prof), host, sizeof host));
+    return TMPC_OK;
+}
+#endif
+
+}  // extern "C"
