@@ -39,6 +39,10 @@ WORKLOADS = {
     "cfg3_mpcc": dict(dims=dict(N=30, S=5, n_lin=8, M=8, n_slk=12, slack=1), scene=dict(N=30, M=8, slack=True, n_decomp=12), traj=512, nh=28, npar=172,
                       one_set=True, what="the rosnavigation T-MPC stack (MPCC contouring instead of the curvature-aware cost; rounds 1-3 ran configs[2] as this), "
                                          "slack model + guidance + 8 ellipsoids + 12 decomp rows, N=30, ONE set of 512 trajectories"),
+    "jackal": dict(dims=dict(N=30, S=3, n_lin=5, M=5, row_model=1), oracle_dims=dict(N=30, S=3, n_lin=5, M=0, n_gauss=5), scene=dict(N=30, M=5, S=3, chance=True),
+                   traj=64, nh=10, npar=82,
+                   what="mpc_planner_jackal's default (generate_jackal_solver.py:53-73; not a BASELINE config): T-MPC with Gaussian chance constraints "
+                        "(gaussian_constraints.py:66-113) as collision avoidance, N=30, 5 obstacles, 3 spline segments, 64 guidance trajectories per scene"),
     "cfg4": dict(dims=dict(N=20, S=5, n_lin=12, M=12), scene=dict(N=20, M=12), traj=4096, nh=24, npar=175, one_set=True,
                  what="configs[3]: T-MPC++ 4096 guidance trajectories, N=20, 12 obstacles, ONE guidance set split over the ranks"),
     "cfg5": dict(dims=dict(N=20, S=5, n_lin=0, M=0, n_slk=24, slack=1), scene=dict(N=20, M=8, slack=True, n_scenario=24), traj=32, nh=24,
@@ -136,7 +140,7 @@ def parity_block(O, wl, batch, res, n_check, opts):
     B = batch["xinit"].shape[0]
     idx = np.unique(np.linspace(0, B - 1, min(n_check, B)).round().astype(int))
     n = len(idx)
-    pbo = O.problem(**wl["dims"], **opts)
+    pbo = O.problem(**wl.get("oracle_dims", wl["dims"]), **opts)
     xt, ut, info = O.solve_batch(pbo, batch["xinit"][idx], batch["x0"][idx].reshape(n, -1), batch["params"][idx].reshape(n, -1),
                                  num_threads=usable_cpus())
     both = (info["exit_code"] == 1) & (res["exit_code"][idx] == 1)
@@ -162,7 +166,7 @@ def best_index_block(O, wl, batch, res, best, set_size, max_sets):
     which = np.unique(np.linspace(0, B // set_size - 1, n_sets).round().astype(int))
     idx = (which[:, None] * set_size + np.arange(set_size)[None, :]).ravel()
     n = len(idx)
-    pbo = O.problem(**wl["dims"])
+    pbo = O.problem(**wl.get("oracle_dims", wl["dims"]))
     _, _, info = O.solve_batch(pbo, batch["xinit"][idx], batch["x0"][idx].reshape(n, -1), batch["params"][idx].reshape(n, -1), num_threads=usable_cpus())
     mism_rule = mism_oracle = ties = 0
     worst = 0.0
@@ -499,7 +503,7 @@ def main():
     # ---- p50 latency of one control tick (64 trajectories, host call -> best index on host) --------------
     lat = None
     lanes = None
-    if rank == 0 and a.lanes and not use_dist and not dims.cost_model:
+    if rank == 0 and a.lanes and not use_dist and not dims.cost_model and not dims.row_model:
         # the lane-per-trajectory variant (tmpc_set_throughput_mode) on the same resident batch: the measured alternative design
         sv.set_throughput_mode(True)
         sv.solve(); sv.solve(sync=False)

@@ -70,6 +70,11 @@ typedef struct tmpc_dims {
     int32_t cost_model;   /* 0: ContouringModule (MPCC: contouring.py:48-98); 1: CurvatureAwareContouringModule (CA-MPC:
                              curvature_aware_contouring.py:48-105; same parameter map, spline ODE s' = v -- BASELINE configs[2]).  Set by
                              tmpc_default_dims* to 0.  Hand-written kernels only (a generated solver's cost is its module stack's). */
+    int32_t row_model;    /* what the M obstacle rows are.  0: EllipsoidConstraintModule (ellipsoid_constraints.py:66-110: 7 parameters per
+                             obstacle, h >= 1); 1: GaussianConstraintModule (gaussian_constraints.py:33-113: 6 parameters per obstacle -- x, y,
+                             major, minor, risk, r --, h >= 0; the collision-avoidance submodule of mpc_planner_jackal's default T-MPC,
+                             generate_jackal_solver.py:53-73).  npar follows: 6 instead of 7 entries per obstacle.  Set by tmpc_default_dims* to 0; not
+                             together with cost_model 1.  Hand-written kernels only. */
 } tmpc_dims;
 
 typedef struct tmpc_handle tmpc_handle;

@@ -14,6 +14,9 @@
 #ifndef SOLVER_COST_MODEL      // (dims headers written before round 4)
 #define SOLVER_COST_MODEL 0
 #endif
+#ifndef SOLVER_ROW_MODEL
+#define SOLVER_ROW_MODEL 0
+#endif
 
 namespace MPCPlanner
 {
@@ -155,7 +158,7 @@ namespace MPCPlanner
         if (_handle) return;
         tmpc_dims d;
         tmpc_default_dims_ex(&d, SOLVER_N, SOLVER_S, SOLVER_NLIN, SOLVER_M, SOLVER_NSLK, SOLVER_SLACK);
-        d.n_sqp = _num_iterations; d.dt = dt; d.cost_model = SOLVER_COST_MODEL;
+        d.n_sqp = _num_iterations; d.dt = dt; d.cost_model = SOLVER_COST_MODEL; d.row_model = SOLVER_ROW_MODEL; d.npar = SOLVER_NP;
         applyModelBounds(d, _model_map);
         int status = tmpc_create(&_handle, &d, 1, _device);
         if (status) {                                   // reference: exit(1) when the capsule cannot be created (:35-39)
@@ -283,7 +286,7 @@ namespace MPCPlanner
         if (_handle && !settings_changed && needed_slots <= _capacity) return;
         const int cap = settings_changed ? std::max(_capacity, needed_slots) : std::max(8, 2 * needed_slots);
         tmpc_dims d; tmpc_default_dims_ex(&d, SOLVER_N, SOLVER_S, SOLVER_NLIN, SOLVER_M, SOLVER_NSLK, SOLVER_SLACK);
-        d.n_sqp = s0->_num_iterations; d.dt = s0->dt; d.cost_model = SOLVER_COST_MODEL;
+        d.n_sqp = s0->_num_iterations; d.dt = s0->dt; d.cost_model = SOLVER_COST_MODEL; d.row_model = SOLVER_ROW_MODEL; d.npar = SOLVER_NP;
         applyModelBounds(d, s0->_model_map);
         tmpc_handle *h = nullptr;
         if (tmpc_create(&h, &d, cap, s0->_device)) { std::printf("tmpc_create() failed. Exiting.\n"); std::exit(1); }

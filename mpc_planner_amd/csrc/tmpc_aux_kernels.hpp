@@ -777,6 +777,7 @@ __global__ void tmpc_debug_eval_kernel(Dims d, int n, const double *z, const dou
     };
 #ifndef TMPC_GENERATED_STAGE
     if (d.cost_model == 1) stage_linearise<1>(d, zz, pe, 1, pi ? pi[(size_t)e * NX] : 0.0, pi ? pi[(size_t)e * NX + 1] : 0.0, lam, sink, W, g, BA, xn, slack);
+    else if (d.row_model == 1) stage_linearise<2>(d, zz, pe, 1, pi ? pi[(size_t)e * NX] : 0.0, pi ? pi[(size_t)e * NX + 1] : 0.0, lam, sink, W, g, BA, xn, slack);
     else
 #endif
     stage_linearise(d, zz, pe, 1, pi ? pi[(size_t)e * NX] : 0.0, pi ? pi[(size_t)e * NX + 1] : 0.0, lam, sink, W, g, BA, xn, slack);

@@ -36,6 +36,20 @@ static SolveKernel pick_fast_kernel(const Dims &d, int *threads, bool prof)
         if (lps == 3 && nrc <= 3 * 13) return (SolveKernel)tmpc_solve_fast_kernel<-1, 13, 3, 64, false, Solo, 1>;
         return nullptr;
     }
+    if (d.row_model == 1) {
+        // Gaussian chance-constraint rows instead of the ellipsoids (mpc_planner_jackal's default: N = 30, 5 topology + 5 Gaussian rows):
+        // runtime-shape instantiations with CM = 2 -- two-wave for 22 <= N <= 32, one-wave for N <= 21, else the generic kernel
+        if (prof) return nullptr;
+        const int nrg = d.n_up + d.M + 14;
+        if (lps != 3 && 4 * d.N <= 128 && !getenv("TMPC_NO_TWO_WAVE")) {
+            *threads = 128;
+            if (nrg <= 4 * 6) return (SolveKernel)tmpc_solve_fast_kernel<-1, 6, 4, 128, false, Solo, 2>;
+            if (nrg <= 4 * 12) return (SolveKernel)tmpc_solve_fast_kernel<-1, 12, 4, 128, false, Solo, 2>;
+            *threads = NT;
+        }
+        if (lps == 3 && nrg <= 3 * 13) return (SolveKernel)tmpc_solve_fast_kernel<-1, 13, 3, 64, false, Solo, 2>;
+        return nullptr;
+    }
 #endif
 #ifdef TMPC_GENERATED_STAGE
     // generated solver: one row shape (tmpc_gen::NH upper-bounded rows); the fast instantiations are compiled only when the
@@ -87,7 +101,7 @@ static SolveKernel pick_fast_kernel(const Dims &d, int *threads, bool prof)
 static SolveKernel pick_compact_kernel(const Dims &d, bool prof)
 {
 #ifndef TMPC_GENERATED_STAGE
-    if (getenv("TMPC_FORCE_GENERIC") || getenv("TMPC_NO_COMPACT") || prof || d.N > 20 || d.cost_model != 0) return nullptr;
+    if (getenv("TMPC_FORCE_GENERIC") || getenv("TMPC_NO_COMPACT") || prof || d.N > 20 || stage_model(d) != 0) return nullptr;
     const int nr = d.n_up + d.M + 14;                    // interior-point rows per stage
     if (d.n_up == 8 && d.M == 8) return (SolveKernel)tmpc_solve_compact_kernel<8, 8, 3, false>;
     if (d.n_up == 0 && d.M == 4) return (SolveKernel)tmpc_solve_compact_kernel<0, 4, 3, false>;
@@ -107,7 +121,7 @@ static SolveKernel pick_compact_kernel(const Dims &d, bool prof)
 static SolveKernel pick_latency_kernel(const Dims &d, bool prof)
 {
 #ifndef TMPC_GENERATED_STAGE
-    if (getenv("TMPC_FORCE_GENERIC") || getenv("TMPC_NO_TWO_WAVE") || d.N > 2 * (64 / 6) || d.cost_model != 0) return nullptr;
+    if (getenv("TMPC_FORCE_GENERIC") || getenv("TMPC_NO_TWO_WAVE") || d.N > 2 * (64 / 6) || stage_model(d) != 0) return nullptr;
     if (d.n_up == 8 && d.M == 8) return TMPC_FAST(8, 8, 6, 128);
 #endif
     (void)d; (void)prof;
@@ -122,7 +136,7 @@ static SolveKernel pick_scan_kernel(const Dims &d, int *threads, int *sl)
 {
     *sl = 3;
 #ifndef TMPC_GENERATED_STAGE
-    if (getenv("TMPC_FORCE_GENERIC") || d.N > 31 || d.N < 2 || d.cost_model != 0) return nullptr;
+    if (getenv("TMPC_FORCE_GENERIC") || d.N > 31 || d.N < 2 || stage_model(d) != 0) return nullptr;
     if (d.N > 20) {                                              // 21 <= N <= 31 (cfg 3, the reference's N = 30 defaults): two lanes per stage in the
         if (d.n_up + d.M + 14 > 4 * 12) return nullptr;          // Newton solve, the runtime-shape two-wave kernel (4 lanes per stage, up to 34 rows) around it
         *threads = 128; *sl = 2;
@@ -241,14 +255,16 @@ int tmpc_create(tmpc_handle **out, const tmpc_dims *dims, int32_t B_max, int32_t
     if (!out || !dims || B_max <= 0) return TMPC_ERR_INVALID;
     *out = nullptr;
     {
-        tmpc::Dims t; t.S = dims->S; t.n_lin = dims->n_lin; t.M = dims->M; t.n_slk = dims->n_slk; t.slack = dims->slack;
+        tmpc::Dims t; t.S = dims->S; t.n_lin = dims->n_lin; t.M = dims->M; t.n_slk = dims->n_slk; t.slack = dims->slack; t.row_model = dims->row_model;
+        if (dims->row_model != 0 && dims->row_model != 1) return TMPC_ERR_INVALID;
         if (dims->N < 2 || dims->N > 62 || dims->S < 1 || dims->M < 0 || dims->n_lin < 0 || dims->n_slk < 0 ||
             (dims->slack != 0 && dims->slack != 1) || dims->npar != tmpc::expected_npar(t) || dims->erk_steps < 1 ||
             dims->n_sqp < 1 || dims->qp_iter_max < 1 || !(dims->dt > 0.0) || !(dims->qp_tol > 0.0) || !(dims->reg_eps > 0.0) ||
-            !(dims->ipm_mu0 > 0.0) || !(dims->ipm_thr0 > 0.0) || (dims->cost_model != 0 && dims->cost_model != 1))
+            !(dims->ipm_mu0 > 0.0) || !(dims->ipm_thr0 > 0.0) || (dims->cost_model != 0 && dims->cost_model != 1) ||
+            (dims->cost_model == 1 && dims->row_model == 1))        // (no instantiation carries the curvature-aware cost AND Gaussian rows)
             return TMPC_ERR_INVALID;
 #ifdef TMPC_GENERATED_STAGE
-        if (dims->n_lin != tmpc_gen::NH || dims->M != 0 || dims->n_slk != 0 || dims->slack != tmpc_gen::SLACK || dims->cost_model != 0) return TMPC_ERR_INVALID;
+        if (dims->n_lin != tmpc_gen::NH || dims->M != 0 || dims->n_slk != 0 || dims->slack != tmpc_gen::SLACK || dims->cost_model != 0 || dims->row_model != 0) return TMPC_ERR_INVALID;
 #endif
     }
     int ndev = 0;
@@ -257,7 +273,7 @@ int tmpc_create(tmpc_handle **out, const tmpc_dims *dims, int32_t B_max, int32_t
     h->device = device; h->B_max = B_max;
     tmpc::Dims &d = h->d;
     d.N = dims->N; d.S = dims->S; d.n_lin = dims->n_lin; d.M = dims->M; d.npar = dims->npar;
-    d.n_slk = dims->n_slk; d.slack = dims->slack; d.cost_model = dims->cost_model;
+    d.n_slk = dims->n_slk; d.slack = dims->slack; d.cost_model = dims->cost_model; d.row_model = dims->row_model;
     d.n_sqp = dims->n_sqp; d.qp_iter_max = dims->qp_iter_max; d.erk_steps = dims->erk_steps;
     d.dt = dims->dt; d.qp_tol = dims->qp_tol; d.reg_eps = dims->reg_eps; d.mu0 = dims->ipm_mu0; d.thr0 = dims->ipm_thr0;
     for (int i = 0; i < TMPC_NV; i++) { d.lb[i] = dims->lb[i]; d.ub[i] = dims->ub[i]; }
@@ -268,7 +284,7 @@ int tmpc_create(tmpc_handle **out, const tmpc_dims *dims, int32_t B_max, int32_t
     }
     h->fast = h->kernel != nullptr;
     if (h->fast) h->lds_bytes = sizeof(double) * (size_t)tmpc::lds_doubles_fast(d.N, d.n_up + d.M);
-    else { h->kernel = d.cost_model == 1 ? tmpc::tmpc_solve_kernel<1> : tmpc::tmpc_solve_kernel<0>; h->lds_bytes = sizeof(double) * (size_t)tmpc::lds_doubles(d.N, d.n_up + d.M); }
+    else { h->kernel = d.cost_model == 1 ? tmpc::tmpc_solve_kernel<1> : (d.row_model == 1 ? tmpc::tmpc_solve_kernel<2> : tmpc::tmpc_solve_kernel<0>); h->lds_bytes = sizeof(double) * (size_t)tmpc::lds_doubles(d.N, d.n_up + d.M); }
     h->lds_bytes_fast = h->lds_bytes;
     // two-wave (128-thread) fast kernels park one share of W per stage behind the layout while they linearise (linearise<.., 128>)
     h->lds_bytes_fast2 = h->lds_bytes_fast + sizeof(double) * (size_t)d.N * tmpc::NP28;
@@ -577,7 +593,7 @@ int tmpc_clear_slot(tmpc_handle *h, int32_t slot)
 int tmpc_set_throughput_mode(tmpc_handle *h, int32_t on)
 {
     if (!h) return TMPC_ERR_INVALID;
-    if (on && h->d.cost_model != 0) { h->err = "tmpc_set_throughput_mode: the lane kernels have the MPCC contouring cost only"; return TMPC_ERR_INVALID; }
+    if (on && tmpc::stage_model(h->d) != 0) { h->err = "tmpc_set_throughput_mode: the lane kernels have the MPCC contouring cost and ellipsoid rows only"; return TMPC_ERR_INVALID; }
     if (on && !h->lanes) {
         TMPC_HIP_CHECK(h, hipSetDevice(h->device));
         h->lanes = tmpc::lanes::create(h->d, h->B_max, h->err);
@@ -940,7 +956,7 @@ int tmpc_debug_profile(tmpc_handle *h, int64_t *cycles, int32_t n_phases)
     int thr = h->threads;
     size_t lds = h->fast ? h->lds_bytes_fast : h->lds_bytes;
     if (h->fast && h->threads == 128) lds = h->lds_bytes_fast2;
-    if (h->fast && h->d.cost_model != 0) { h->err = "tmpc_debug_profile: no profiled twin for the curvature-aware cost"; return TMPC_ERR_INVALID; }
+    if (h->fast && tmpc::stage_model(h->d) != 0) { h->err = "tmpc_debug_profile: no profiled twin for the curvature-aware cost / Gaussian rows"; return TMPC_ERR_INVALID; }
     if (h->fast) {
         pk = tmpc::pick_fast_kernel(h->d, &thr, true);
 #ifndef TMPC_GENERATED_STAGE

@@ -606,7 +606,7 @@ __device__ __forceinline__ void linearise(const Lds &L, const Dims &d, int tid, 
                 double *Dr = L.D + (k * nh + r) * 3;
                 const double sg = (r < d.n_up) ? -1.0 : 1.0;     // fast layouts keep the SIGNED row Jacobian (ipm_fast reads it as it is)
                 Dr[0] = sg * ro.gx; Dr[1] = sg * ro.gy; Dr[2] = sg * ro.gp;
-                const double bound = (r < d.n_up) ? 0.0 : 1.0;
+                const double bound = (r < d.n_up || cm_gaussian_rows(CM)) ? 0.0 : 1.0;     // ellipsoid rows: h >= 1; Gaussian rows: h >= 0
                 L.beta[k * nh + r] = bound - ro.h;
             }
         };
@@ -741,7 +741,7 @@ __device__ __forceinline__ void linearise(const Lds &L, const Dims &d, int tid, 
                     double *Dr = L.D + (k * nh + r) * 3;
                     Dr[0] = sg * ro.gx; Dr[1] = sg * ro.gy; Dr[2] = sg * ro.gp;
                 }
-                const double bound = (r < d.n_up) ? 0.0 : 1.0;
+                const double bound = (r < d.n_up || cm_gaussian_rows(CM)) ? 0.0 : 1.0;     // ellipsoid rows: h >= 1; Gaussian rows: h >= 0
                 L.beta[k * nh + r] = bound - ro.h;
             }
         };
@@ -802,7 +802,7 @@ __device__ __forceinline__ void solve_epilogue(const Lds &L, const Dims &d, int 
         for (int i = 0; i < NV; i++) z[i] = L.z[ks * NV + i];
         double cval;
 #ifndef TMPC_GENERATED_STAGE
-        if constexpr (CM == 1) { CostOutCA co; cost_eval_ca(d, z, pb + (size_t)ks * d.npar, 1, co, false, slack); cval = co.val; }
+        if constexpr (cm_curvature_aware(CM)) { CostOutCA co; cost_eval_ca(d, z, pb + (size_t)ks * d.npar, 1, co, false, slack); cval = co.val; }
         else
 #endif
         { CostOut co; cost_eval(d, z, pb + (size_t)ks * d.npar, 1, co, false, slack); cval = co.val; }
@@ -839,7 +839,7 @@ __device__ __forceinline__ void solve_epilogue(const Lds &L, const Dims &d, int 
 
 // ---- the solve kernel ---------------------------------------------------------------------------
 #ifndef TMPC_PROF_TU
-template <int CM>      // cost model (Dims::cost_model): 0 MPCC contouring, 1 curvature-aware contouring
+template <int CM>      // stage model (stage_model(): Dims::cost_model + 2 * Dims::row_model): 0 MPCC contouring + ellipsoids, 1 curvature-aware contouring, 2 Gaussian rows
 __global__ __launch_bounds__(NT) void tmpc_solve_kernel(Dims d, int B, const double *__restrict__ xinit,
                                                         const double *__restrict__ x0, const double *__restrict__ params,
                                                         double *__restrict__ xtraj, double *__restrict__ utraj,

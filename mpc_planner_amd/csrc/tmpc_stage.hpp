@@ -59,7 +59,13 @@ struct Dims {
     double hdt2;                     // dt^2 / 2
     int cost_model;                  // 0: ContouringModule (contouring.py:48-98); 1: CurvatureAwareContouringModule (curvature_aware_contouring.py:48-105).
                                      // Kernels are instantiated per cost model (template parameter CM): this field only selects the instantiation on the host
+    int row_model;                   // the M lower-bounded rows: 0: EllipsoidConstraintModule (ellipsoid_constraints.py:66-110, h >= 1); 1: GaussianConstraintModule
+                                     // (gaussian_constraints.py:66-113, h >= 0; mpc_planner_jackal's default).  Compile-time in the kernels like cost_model:
+                                     // the template parameter CM carries both, CM = cost_model + 2 * row_model (stage_model())
 };
+__host__ TMPC_HD constexpr bool cm_curvature_aware(int CM) { return (CM & 1) != 0; }
+__host__ TMPC_HD constexpr bool cm_gaussian_rows(int CM) { return (CM & 2) != 0; }
+__host__ inline int stage_model(const Dims &d) { return d.cost_model + 2 * d.row_model; }
 __host__ inline void derive_dims(Dims &d)
 {
     d.n_up = d.n_lin + d.n_slk;
@@ -75,16 +81,19 @@ __host__ TMPC_HD constexpr int sidx(int i, int j) { return i >= j ? pidx(i, j) :
 
 // ---- parameter index map (reference rule: util/parameters.py:25-55, solver_definition.py:5-16) ----------
 // weights: acceleration, angular_velocity, [slack,] velocity, reference_velocity, contour, lag, terminal_angle,
-// terminal_contouring; then 9 per spline segment; topology rows; [ego_disc_radius, ego_disc_0_offset, 7 per ellipsoid];
-// [ego_disc_0_offset unless the ellipsoid module defined it,] 3 per slack row (scenario rows before decomp rows).
+// terminal_contouring; then 9 per spline segment; topology rows; [ego_disc_radius, ego_disc_0_offset, 7 per ellipsoid
+// (ellipsoid_constraints.py:33-49) or 6 per Gaussian obstacle (row_model 1: gaussian_constraints.py:40-52)];
+// [ego_disc_0_offset unless the obstacle module defined it,] 3 per slack row (scenario rows before decomp rows).
 __host__ TMPC_HD int ip_spline(const Dims &d, int seg, int which) { return 8 + d.slack + 9 * seg + which; }
 __host__ TMPC_HD int ip_lin(const Dims &d, int j, int which) { return 8 + d.slack + 9 * d.S + 3 * j + which; }
 __host__ TMPC_HD int ip_disc_radius(const Dims &d) { return 8 + d.slack + 9 * d.S + 3 * d.n_lin; }
 __host__ TMPC_HD int ip_disc_offset(const Dims &d) { return ip_disc_radius(d) + (d.M > 0 ? 1 : 0); }
 __host__ TMPC_HD int ip_ellipsoid(const Dims &d, int j, int which) { return ip_disc_radius(d) + 2 + 7 * j + which; }
+__host__ TMPC_HD int ip_gauss(const Dims &d, int j, int which) { return ip_disc_radius(d) + 2 + 6 * j + which; }   // x, y, major, minor, risk, r
+__host__ TMPC_HD int ip_obst_stride(const Dims &d) { return d.row_model == 1 ? 6 : 7; }
 __host__ TMPC_HD int ip_slk(const Dims &d, int j, int which)
 {
-    return (d.M > 0 ? ip_disc_radius(d) + 2 + 7 * d.M : ip_disc_radius(d) + 1) + 3 * j + which;
+    return (d.M > 0 ? ip_disc_radius(d) + 2 + ip_obst_stride(d) * d.M : ip_disc_radius(d) + 1) + 3 * j + which;
 }
 __host__ TMPC_HD int expected_npar(const Dims &d)
 {
@@ -92,7 +101,7 @@ __host__ TMPC_HD int expected_npar(const Dims &d)
     (void)d;
     return tmpc_gen::NPAR;
 #endif
-    return 8 + d.slack + 9 * d.S + 3 * d.n_lin + (d.M > 0 ? 2 + 7 * d.M : 0) + (d.n_slk > 0 ? (d.M > 0 ? 0 : 1) + 3 * d.n_slk : 0);
+    return 8 + d.slack + 9 * d.S + 3 * d.n_lin + (d.M > 0 ? 2 + ip_obst_stride(d) * d.M : 0) + (d.n_slk > 0 ? (d.M > 0 ? 0 : 1) + 3 * d.n_slk : 0);
 }
 
 // =============================================================================================
@@ -458,6 +467,45 @@ TMPC_HD void ellipsoid_row_eval(const Dims &d, const double *z, const double *p,
     o.Hpp = 2.0 * (m00 * qx * qx + 2.0 * m01 * qx * qy + m11 * qy * qy) - gx * qy + gy * qx;
 }
 
+// Gaussian chance constraint (gaussian_constraints.py:66-113; lower bound 0, :54-58):
+//   h = a . d - (r_disc + r) - erfinv(1 - 2 risk) sqrt(2 a^T diag(major^2, minor^2) a),   d = disc position - obstacle mean,  a = d / |d|
+// erfinv by the script's rational start and two Newton steps (:103-111); it depends on the parameters only.
+TMPC_HD double gauss_quantile(double risk)
+{
+    const double xe = 1.0 - 2.0 * risk;
+    const double zz = sqrt(-log((1.0 - xe) / 2.0));
+    double ye = (((1.641345311 * zz + 3.429567803) * zz - 1.624906493) * zz - 1.970840454) / ((1.637067800 * zz + 3.543889200) * zz + 1.0);
+    for (int it = 0; it < 2; it++) ye = ye - (erf(ye) - xe) / (1.1283791670955126 * exp(-ye * ye));       // 2 / sqrt(pi)
+    return ye;
+}
+// With q = |d|^2, u = (major^2 dx^2 + minor^2 dy^2) / q (the Rayleigh quotient of a) and f = sqrt(2 u):  h = sqrt(q) - R - ye f, and
+//   u_x = 2 dx (major^2 - u) / q,  u_xx = 2 (major^2 - u) / q - 8 dx^2 (major^2 - u) / q^2,  u_xy = -4 dx dy (major^2 + minor^2 - 2 u) / q^2,
+//   f f_x = u_x,  f f_xx = u_xx - f_x^2,  f f_xy = u_xy - f_x f_y;  psi enters through the disc offset exactly as in the ellipsoid row.
+TMPC_HD void gauss_row_eval(const Dims &d, const double *z, const double *p, int pstride, int j,
+                            double r_disc, double off, double spsi, double cpsi, double ye, RowOut &o)
+{
+    auto P = [&](int w) { return p[(size_t)ip_gauss(d, j, w) * pstride]; };
+    const double ox = P(0), oy = P(1), s0 = P(2) * P(2), s1 = P(3) * P(3), R = r_disc + P(5);
+    const double px = z[ZX] + off * cpsi - ox, py = z[ZY] + off * spsi - oy;
+    const double qx = -off * spsi, qy = off * cpsi;                        // d(px,py)/dpsi
+    const double q = px * px + py * py, iq = 1.0 / q, rho = sqrt(q), ir = rho * iq, ir3 = ir * iq;
+    const double u = (s0 * px * px + s1 * py * py) * iq, A = s0 - u, B = s1 - u;
+    const double f = sqrt(2.0 * u), jf = 1.0 / f;
+    const double ux = 2.0 * px * A * iq, uy = 2.0 * py * B * iq;
+    const double uxx = 2.0 * A * iq - 8.0 * px * px * A * iq * iq, uyy = 2.0 * B * iq - 8.0 * py * py * B * iq * iq;
+    const double uxy = -4.0 * px * py * (A + B) * iq * iq;
+    const double fx = ux * jf, fy = uy * jf;
+    const double fxx = (uxx - fx * fx) * jf, fxy = (uxy - fx * fy) * jf, fyy = (uyy - fy * fy) * jf;
+    const double gx = px * ir - ye * fx, gy = py * ir - ye * fy;
+    const double hxx = py * py * ir3 - ye * fxx, hxy = -px * py * ir3 - ye * fxy, hyy = px * px * ir3 - ye * fyy;
+    o.h = rho - R - ye * f;
+    o.gx = gx; o.gy = gy; o.gp = gx * qx + gy * qy;
+    o.Hxx = hxx; o.Hxy = hxy; o.Hyy = hyy;
+    o.Hxp = hxx * qx + hxy * qy;
+    o.Hyp = hxy * qx + hyy * qy;
+    o.Hpp = (hxx * qx * qx + 2.0 * hxy * qx * qy + hyy * qy * qy) - gx * qy + gy * qx;
+}
+
 // decomp / scenario halfspace (decomp_constraints.py:86-96, scenario_constraints.py:82-92):
 //   a1 (x + off cos psi) + a2 (y + off sin psi) - (b + slack)  <= 0
 TMPC_HD void slk_row_eval(const Dims &d, const double *z, const double *p, int pstride, int j, double off,
@@ -683,7 +731,7 @@ TMPC_HD void stage_linearise(const Dims &d, const double *z, const double *p, in
 #else
     RowOut ro;
     if (part != 1) {
-        if constexpr (CM == 1) {
+        if constexpr (cm_curvature_aware(CM)) {
             CostOutCA co;
             cost_eval_ca(d, z, p, pstride, co, true, slack);
 #pragma unroll
@@ -716,8 +764,16 @@ TMPC_HD void stage_linearise(const Dims &d, const double *z, const double *p, in
     {
         // the two parts share the ellipsoid rows (part 1 the first half, next to the dynamics)
         const int j0 = part == 2 ? d.M / 2 : 0, j1 = part == 1 ? d.M / 2 : d.M;
+        double risk_of = -1.0, ye = 0.0;                      // (Gaussian rows) the quantile of the last risk level seen: one level per configuration
+        (void)risk_of; (void)ye;                              // in the reference (CONFIG probabilistic/risk), so it is evaluated once per stage, not once per row
         for (int j = j0; j < j1; j++) {
-            ellipsoid_row_eval(d, z, p, pstride, j, r_disc, off, spsi, cpsi, ro);
+            if constexpr (cm_gaussian_rows(CM)) {
+                const double risk = p[(size_t)ip_gauss(d, j, 4) * pstride];
+                if (risk != risk_of) { ye = gauss_quantile(risk); risk_of = risk; }
+                gauss_row_eval(d, z, p, pstride, j, r_disc, off, spsi, cpsi, ye, ro);
+            } else {
+                ellipsoid_row_eval(d, z, p, pstride, j, r_disc, off, spsi, cpsi, ro);
+            }
             row_add_hessian(ro, lamh(d.n_up + j), W);
             sink(d.n_up + j, ro);
         }

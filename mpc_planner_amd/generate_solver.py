@@ -28,17 +28,19 @@ def _yaml_dump_flat(d):
 
 
 def generate_solver(out_dir, N=20, max_obstacles=8, num_segments=5, guidance=True, n_sqp=10, dt=0.2, slack=False,
-                    ellipsoids=True, n_scenario=0, n_decomp=0, curvature_aware=False):
+                    ellipsoids=True, n_scenario=0, n_decomp=0, curvature_aware=False, gaussian=False):
     """slack / n_scenario / n_decomp select the slack-model configurations (configuration_safe_horizon,
     generate_jackalsimulator_solver.py:67-90; rosnavigation configuration_tmpc, generate_rosnavigation_solver.py:86-108).
     curvature_aware: CurvatureAwareContouringModule instead of ContouringModule (same parameter map: its define_parameters adds
     contour, lag, terminal_*, the spline rows and leaves velocity / reference_velocity to MPCBaseModule,
-    curvature_aware_contouring.py:22-46) -> SOLVER_COST_MODEL 1 (tmpc_dims::cost_model)."""
-    pm = define_parameters(num_segments, max_obstacles, guidance=guidance, slack=slack, ellipsoids=ellipsoids,
-                           n_scenario=n_scenario, n_decomp=n_decomp)
+    curvature_aware_contouring.py:22-46) -> SOLVER_COST_MODEL 1 (tmpc_dims::cost_model).
+    gaussian: GaussianConstraintModule as the collision-avoidance module instead of the ellipsoids (mpc_planner_jackal's default,
+    generate_jackal_solver.py:53-73; gaussian_constraints.py:40-52 parameter layout) -> SOLVER_ROW_MODEL 1 (tmpc_dims::row_model)."""
+    pm = define_parameters(num_segments, max_obstacles, guidance=guidance, slack=slack, ellipsoids=ellipsoids and not gaussian,
+                           n_scenario=n_scenario, n_decomp=n_decomp, gaussian=gaussian)
     return _write_host_side(out_dir, pm, N, slack, n_sqp, dt, n_lin=(max_obstacles if guidance else 0),
-                            M=(max_obstacles if ellipsoids else 0), n_slk=n_scenario + n_decomp, num_segments=num_segments,
-                            max_obstacles=max_obstacles, cost_model=int(bool(curvature_aware)))
+                            M=(max_obstacles if (ellipsoids or gaussian) else 0), n_slk=n_scenario + n_decomp, num_segments=num_segments,
+                            max_obstacles=max_obstacles, cost_model=int(bool(curvature_aware)), row_model=int(bool(gaussian)))
 
 
 def generate_solver_from_modules(out_dir, name, modules, model, settings, n_sqp=10):
@@ -74,7 +76,7 @@ def _model_map(slack, model=None):
     return out
 
 
-def _write_host_side(out_dir, pm, N, slack, n_sqp, dt, n_lin, M, n_slk, num_segments, max_obstacles, model=None, cost_model=0):
+def _write_host_side(out_dir, pm, N, slack, n_sqp, dt, n_lin, M, n_slk, num_segments, max_obstacles, model=None, cost_model=0, row_model=0):
     npar = pm.length()
     nu, nx = 2, 5 + int(bool(slack))
     cfg = os.path.join(out_dir, "config"); inc = os.path.join(out_dir, "include", "mpc_planner_solver")
@@ -92,7 +94,7 @@ def _write_host_side(out_dir, pm, N, slack, n_sqp, dt, n_lin, M, n_slk, num_segm
                 f"#define SOLVER_N {N}\n#define SOLVER_NX {nx}\n#define SOLVER_NU {nu}\n#define SOLVER_NP {npar}\n"
                 f"#define SOLVER_NLIN {n_lin}\n#define SOLVER_M {M}\n"
                 f"#define SOLVER_NSLK {n_slk}\n#define SOLVER_SLACK {int(bool(slack))}\n#define SOLVER_MAX_OBSTACLES {max_obstacles}\n"
-                f"#define SOLVER_S {num_segments}\n#define SOLVER_NSQP {n_sqp}\n#define SOLVER_DT {dt}\n#define SOLVER_COST_MODEL {cost_model}\n#endif\n")
+                f"#define SOLVER_S {num_segments}\n#define SOLVER_NSQP {n_sqp}\n#define SOLVER_DT {dt}\n#define SOLVER_COST_MODEL {cost_model}\n#define SOLVER_ROW_MODEL {row_model}\n#endif\n")
     with open(os.path.join(inc, "mpc_planner_parameters.h"), "w") as h, \
             open(os.path.join(src, "mpc_planner_parameters.cpp"), "w") as c:
         h.write("/** autogenerated by mpc_planner_amd.generate_solver */\n#ifndef __MPC_PLANNER_PARAMETERS_H__\n"

@@ -20,7 +20,7 @@ class TmpcDims(C.Structure):
                 ("n_sqp", C.c_int32), ("qp_iter_max", C.c_int32), ("erk_steps", C.c_int32),
                 ("dt", C.c_double), ("qp_tol", C.c_double), ("reg_eps", C.c_double), ("ipm_mu0", C.c_double),
                 ("ipm_thr0", C.c_double), ("lb", C.c_double * NV), ("ub", C.c_double * NV),
-                ("n_slk", C.c_int32), ("slack", C.c_int32), ("cost_model", C.c_int32)]
+                ("n_slk", C.c_int32), ("slack", C.c_int32), ("cost_model", C.c_int32), ("row_model", C.c_int32)]
 
     @property
     def nx(self):            # external (model) state / variable counts: the slack model has one more state
@@ -133,6 +133,8 @@ def default_dims(N=20, S=5, n_lin=8, M=8, n_slk=0, slack=0, lib_path=None, **opt
     load_library(lib_path).tmpc_default_dims_ex(C.byref(d), N, S, n_lin, M, n_slk, int(bool(slack)))
     for k, v in opts.items():
         setattr(d, k, v)
+    if d.row_model == 1 and "npar" not in opts:              # Gaussian rows: 6 parameters per obstacle instead of the ellipsoid's 7
+        d.npar -= d.M
     return d
 
 
@@ -146,7 +148,7 @@ def own_parameter_columns(dims):
     base = 8 + dims.slack + 9 * dims.S
     lin = np.arange(base, base + 3 * dims.n_lin)
     disc = base + 3 * dims.n_lin
-    slk0 = (disc + 2 + 7 * dims.M) if dims.M > 0 else disc + 1
+    slk0 = (disc + 2 + (6 if dims.row_model == 1 else 7) * dims.M) if dims.M > 0 else disc + 1
     return np.concatenate([lin, np.arange(slk0, slk0 + 3 * dims.n_slk)]).astype(int)
 
 

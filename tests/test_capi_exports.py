@@ -34,6 +34,20 @@ def test_default_dims_match_reference_settings():
     assert d.dt == 0.2 and d.qp_tol == 1e-5
     assert solver.default_dims(N=20, S=5, n_lin=0, M=4).npar == 83
     assert solver.default_dims(N=20, S=5, n_lin=12, M=12).npar == 175
+    # Gaussian rows (tmpc_dims::row_model = 1): 6 parameters per obstacle; mpc_planner_jackal's default map has 82 entries
+    # (tests/golden/stage_functions_gaussian.json, made by the reference's own scripts), and the C++ side gets the same from generate_solver
+    dj = solver.default_dims(N=30, S=3, n_lin=5, M=5, row_model=1)
+    assert dj.npar == 82 and dj.row_model == 1
+    from mpc_planner_amd.parameters import define_parameters
+    assert define_parameters(3, 5, ellipsoids=False, gaussian=True).length() == 82
+
+
+def test_generate_solver_writes_the_row_model(tmp_path):
+    from mpc_planner_amd import generate_solver
+    generate_solver.generate_solver(str(tmp_path), N=30, max_obstacles=5, num_segments=3, gaussian=True)
+    hdr = open(tmp_path / "include" / "mpc_planner_solver" / "hip_solver_dims.h").read()
+    assert "#define SOLVER_ROW_MODEL 1" in hdr and "#define SOLVER_NP 82" in hdr and "#define SOLVER_M 5" in hdr
+    assert "gaussian_obst_4_risk" in open(tmp_path / "config" / "parameter_map.yaml").read()
 
 
 def test_no_silent_cpu_fallback():
@@ -52,6 +66,9 @@ def test_invalid_dims_rejected():
     d = solver.default_dims(); d.npar = 7
     h = C.c_void_p()
     assert lib.tmpc_create(C.byref(h), C.byref(d), 4, 0) == -1 and not h
+    for bad in (dict(row_model=2), dict(row_model=1, cost_model=1)):           # validated before a device is looked for
+        d = solver.default_dims(**bad)
+        assert lib.tmpc_create(C.byref(h), C.byref(d), 4, 0) == -1 and not h
 
 
 def test_product_never_imports_oracle():
