@@ -45,6 +45,7 @@ namespace MPCPlanner
         int n_discs{1};
         double robot_radius{0.325};
         double risk{0.05};                                   /* probabilistic/risk */
+        double obstacle_radius{0.35};                        /* obstacle_radius (GaussianConstraints uses the configured value, not the obstacle's own) */
         int max_obstacles{8};
         int n_other_halfspaces{0};                           /* linearized_constraints/add_halfspaces */
         std::map<std::string, double> weights;               /* weights/<name> */
@@ -103,7 +104,64 @@ namespace MPCPlanner
         std::vector<PathSegment> _segments;
     };
 
-#if SOLVER_M > 0
+#ifndef SOLVER_ROW_MODEL          /* (dims headers written before the Gaussian rows existed) */
+#define SOLVER_ROW_MODEL 0
+#endif
+
+#if SOLVER_M > 0 && SOLVER_ROW_MODEL == 1
+    /* ---- gaussian_constraints.cpp:22-79 (the solver was generated with gaussian=True: tmpc_dims::row_model = 1) ---- */
+    class GaussianConstraints
+    {
+    public:
+        GaussianConstraints(std::shared_ptr<Solver> solver, const ModuleConfig &cfg) : _solver(solver), _cfg(cfg) {}
+        void update(State &state, const RealTimeData &, ModuleData &)
+        {
+            _dummy_x = state.get("x") + 100.; _dummy_y = state.get("y") + 100.;
+        }
+        void setParameters(const RealTimeData &data, const ModuleData &, int k)
+        {
+            setSolverParameterEgoDiscRadius(k, _solver->_params, _cfg.robot_radius);
+            for (int d = 0; d < _cfg.n_discs; d++) setSolverParameterEgoDiscOffset(k, _solver->_params, data.robot_area[d].offset, d);
+            if (k == 0) {                                                        /* dummies (:41-54) */
+                for (size_t i = 0; i < data.dynamic_obstacles.size(); i++) {
+                    setSolverParameterGaussianObstX(k, _solver->_params, _dummy_x, i); setSolverParameterGaussianObstY(k, _solver->_params, _dummy_y, i);
+                    setSolverParameterGaussianObstMajor(k, _solver->_params, 0.1, i); setSolverParameterGaussianObstMinor(k, _solver->_params, 0.1, i);
+                    setSolverParameterGaussianObstRisk(k, _solver->_params, 0.05, i); setSolverParameterGaussianObstR(k, _solver->_params, 0.1, i);
+                }
+                return;
+            }
+            for (size_t i = 0; i < data.dynamic_obstacles.size(); i++) {
+                const auto &obstacle = data.dynamic_obstacles[i];
+                if (obstacle.prediction.type != PredictionType::GAUSSIAN) continue;                  /* (:62) */
+                const auto &mode = obstacle.prediction.modes[0];
+                setSolverParameterGaussianObstX(k, _solver->_params, mode[k - 1].position(0), i);
+                setSolverParameterGaussianObstY(k, _solver->_params, mode[k - 1].position(1), i);
+                const bool dynamic = obstacle.type == ObstacleType::DYNAMIC;                        /* static obstacles have no uncertainty (:72-76) */
+                setSolverParameterGaussianObstMajor(k, _solver->_params, dynamic ? mode[k - 1].major_radius : 0.001, i);
+                setSolverParameterGaussianObstMinor(k, _solver->_params, dynamic ? mode[k - 1].minor_radius : 0.001, i);
+                setSolverParameterGaussianObstRisk(k, _solver->_params, _cfg.risk, i);
+                setSolverParameterGaussianObstR(k, _solver->_params, _cfg.obstacle_radius, i);
+            }
+        }
+        bool isDataReady(const RealTimeData &data, std::string &missing_data) const                  /* :81-105 */
+        {
+            if ((int)data.dynamic_obstacles.size() != _cfg.max_obstacles) { missing_data += "Obstacles "; return false; }
+            for (const auto &o : data.dynamic_obstacles) {
+                if (o.prediction.modes.empty()) { missing_data += "Obstacle Prediction "; return false; }
+                if (o.prediction.type != PredictionType::GAUSSIAN) { missing_data += "Obstacle Prediction (Type is not Gaussian) "; return false; }
+            }
+            return true;
+        }
+        std::shared_ptr<Solver> _solver;
+    private:
+        ModuleConfig _cfg;
+        double _dummy_x{0.}, _dummy_y{0.};
+    };
+#define GUIDANCE_CONSTRAINTS_TYPE GaussianConstraints      /* what the reference's generator writes into modules.h (guidance_constraints.py:56-62) */
+#endif
+
+#if SOLVER_M > 0 && SOLVER_ROW_MODEL == 0
+#define GUIDANCE_CONSTRAINTS_TYPE EllipsoidConstraints
     /* ---- ellipsoid_constraints.cpp:23-90 ---- */
     class EllipsoidConstraints
     {
@@ -296,7 +354,7 @@ namespace MPCPlanner
         {
             int id;
             std::unique_ptr<LinearizedConstraints> guidance_constraints;        /* keep the solver in the topology */
-            std::unique_ptr<EllipsoidConstraints> safety_constraints;            /* avoid collisions */
+            std::unique_ptr<GUIDANCE_CONSTRAINTS_TYPE> safety_constraints;       /* avoid collisions (guidance_constraints.h:89) */
             std::shared_ptr<Solver> local_solver;                                /* distinct solver for each planner */
             SolverResult result;
             bool is_original_planner = false, disabled = true, taken = false, existing_guidance = false;
@@ -305,7 +363,7 @@ namespace MPCPlanner
                 local_solver = std::make_shared<Solver>(_id + 1);                /* guidance_constraints.cpp:18-27 */
                 guidance_constraints = std::make_unique<LinearizedConstraints>(local_solver, cfg);
                 guidance_constraints->setTopologyConstraints();
-                safety_constraints = std::make_unique<EllipsoidConstraints>(local_solver, cfg);
+                safety_constraints = std::make_unique<GUIDANCE_CONSTRAINTS_TYPE>(local_solver, cfg);
             }
         };
 

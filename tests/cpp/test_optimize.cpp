@@ -1,7 +1,9 @@
 // C++ end-to-end of the accelerated path: GuidanceConstraints::optimize restated with ONE batched launch
 // (mpc_planner_modules/modules_hip.h, the INTEGRATION.md section 4 patch as compiled code) on a scene written by
 // tests/test_cpp_optimize.py; prints every planner's result and the selected trajectory for comparison with the Python path.
-//   test_optimize <config dir> <scene.bin> [ticks]
+//   test_optimize <config dir> <scene.bin>
+// Scene header: N M B S tmpcpp gaussian; gaussian = 1: Gaussian predictions (per obstacle N x (x, y) then N x (major, minor)), the risk and the
+// configured obstacle radius -- for a solver generated with gaussian=True (GaussianConstraints as GUIDANCE_CONSTRAINTS_TYPE).
 #include <mpc_planner_modules/modules_hip.h>
 
 #include <cstdio>
@@ -28,7 +30,8 @@ int main(int argc, char **argv)
     const std::vector<double> in = read_all(argv[2]);
     size_t o = 0;
     auto next = [&]() { return in[o++]; };
-    const int N = (int)next(), M = (int)next(), B = (int)next(), S = (int)next(), tmpcpp = (int)next();
+    const int N = (int)next(), M = (int)next(), B = (int)next(), S = (int)next(), tmpcpp = (int)next(), gaussian = (int)next();
+    if (gaussian != SOLVER_ROW_MODEL) { std::printf("scene does not match the generated solver's row model\n"); return 2; }
     if (N != SOLVER_N || M != SOLVER_MAX_OBSTACLES || S != SOLVER_S) { std::printf("scene does not match the generated solver\n"); return 2; }
     ModuleConfig cfg;
     cfg.max_obstacles = M; cfg.num_segments = S; cfg.n_paths = B; cfg.use_tmpcpp = tmpcpp != 0;
@@ -43,11 +46,13 @@ int main(int argc, char **argv)
     data.robot_area.emplace_back(0., cfg.robot_radius);
     for (int j = 0; j < M; j++) {
         DynamicObstacle ob(j, Vector2d(0., 0.), 0., obstacle_radius);
-        ob.prediction = Prediction(PredictionType::DETERMINISTIC);
+        ob.prediction = Prediction(gaussian ? PredictionType::GAUSSIAN : PredictionType::DETERMINISTIC);
         for (int i = 0; i < N; i++) { const double x = next(), y = next(); ob.prediction.modes[0].emplace_back(Vector2d(x, y), 0., 0., 0.); }
+        if (gaussian) for (int i = 0; i < N; i++) { ob.prediction.modes[0][i].major_radius = next(); ob.prediction.modes[0][i].minor_radius = next(); }
         ob.position = ob.prediction.modes[0][0].position;
         data.dynamic_obstacles.push_back(ob);
     }
+    if (gaussian) { cfg.risk = next(); cfg.obstacle_radius = obstacle_radius; }
     ModuleData module_data;
     for (int i = 0; i < S; i++) {
         PathSegment sg;

@@ -15,33 +15,51 @@ BIN = os.path.join(ROOT, "build", "test_optimize")
 N, M, B, S = 20, 8, 12, 5
 
 
-def _build():
+GEN_J = os.path.join(ROOT, "build", "generated_jackal_gaussian")       # mpc_planner_jackal's default: N = 30, 5 obstacles, 3 segments, Gaussian rows
+BIN_J = os.path.join(ROOT, "build", "test_optimize_gaussian")
+NJ, MJ, SJ = 30, 5, 3
+
+
+def _build(gen=GEN, binary=BIN, **gen_kw):
     import __graft_entry__ as g
     g.build()
     from mpc_planner_amd.generate_solver import generate_solver
-    generate_solver(GEN, N=N, max_obstacles=M, num_segments=S, guidance=True)
+    generate_solver(gen, **(gen_kw or dict(N=N, max_obstacles=M, num_segments=S, guidance=True)))
     cpp = os.path.join(ROOT, "mpc_planner_amd", "cpp")
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(cpp, "include"), "-I", os.path.join(GEN, "include"),
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(cpp, "include"), "-I", os.path.join(gen, "include"),
                            "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "test_optimize.cpp"),
-                           os.path.join(cpp, "src", "solver_interface.cpp"), os.path.join(GEN, "src", "mpc_planner_parameters.cpp"),
+                           os.path.join(cpp, "src", "solver_interface.cpp"), os.path.join(gen, "src", "mpc_planner_parameters.cpp"),
                            "-L", os.path.join(ROOT, "mpc_planner_amd"), "-ltmpc_hip", "-Wl,-rpath," + os.path.join(ROOT, "mpc_planner_amd"),
-                           "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-lamdhip64", "-o", BIN])
+                           "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-lamdhip64", "-o", binary])
+
+
+def _build_gaussian():
+    _build(GEN_J, BIN_J, N=NJ, max_obstacles=MJ, num_segments=SJ, guidance=True, gaussian=True)
 
 
 def test_cpp_modules_compile():
-    """The C++ types + modules + batched optimize() compile against the generated setSolverParameter* functions (CPU)."""
+    """The C++ types + modules + batched optimize() compile against the generated setSolverParameter* functions (CPU) -- with the ellipsoid
+    module and with GaussianConstraints as GUIDANCE_CONSTRAINTS_TYPE (a solver generated with gaussian=True)."""
     _build()
     assert os.path.exists(BIN)
+    _build_gaussian()
+    assert os.path.exists(BIN_J)
 
 
-def _scene_file(sc, path, selected=-1):
+def _scene_file(sc, path, selected=-1, dims=None, gaussian=False):
     from mpc_planner_amd import scenes
     W = scenes.WEIGHTS
-    vals = [N, M, B, S, 1]
+    n, m, s_ = dims or (N, M, S)
+    vals = [n, m, B, s_, 1, int(gaussian)]
     vals += [W[k] for k in ("acceleration", "angular_velocity", "velocity", "reference_velocity", "contour", "lag", "terminal_angle", "terminal_contouring")]
     vals += [scenes.ROBOT_RADIUS, scenes.OBSTACLE_RADIUS]
     vals += list(sc["xinit"][0])
-    vals += list(sc["obstacles"]["pos"].ravel())                       # [M][N][2]
+    for j in range(m):                                                 # per obstacle: N x (x, y), then (Gaussian) N x (major, minor)
+        vals += list(sc["obstacles"]["pos"][j].ravel())
+        if gaussian:
+            vals += list(np.stack([sc["obstacles"]["major"][j], sc["obstacles"]["minor"][j]], 1).ravel())
+    if gaussian:
+        vals += [0.05]                                                 # probabilistic/risk
     vals += list(sc["segments"].ravel())                               # [S][9] = ax bx cx dx ay by cy dy start
     for b in range(B):
         vals += list(sc["guidance_pos"][b].ravel()) + list(sc["guidance_vel"][b].ravel())
@@ -204,3 +222,38 @@ def test_scenario_optimize_cpp_matches_python_driver(tmp_path):
             want = md.scenario_support(res["xtraj"][p_], sc["params"][p_], pm, whichs[p_], S_CEN, TOL)
             assert (int(row[7]), int(row[9])) == want
     np.testing.assert_allclose(c_x, res["xtraj"][best][:, :4], rtol=0, atol=1e-7)
+
+
+@pytest.mark.gpu
+def test_cpp_optimize_gaussian_matches_python_path(tmp_path):
+    """mpc_planner_jackal's default stack through the C++ boundary: a solver generated with gaussian=True (SOLVER_ROW_MODEL 1), the C++
+    GaussianConstraints::setParameters (gaussian_constraints.cpp:31-79) as GUIDANCE_CONSTRAINTS_TYPE inside the batched optimize(), against the
+    Python path (scenes.py chance=True + modules.gaussian_set_parameters + BatchedSolver with row_model = 1) on the same tick."""
+    from mpc_planner_amd import scenes, solver
+    if not os.path.exists(BIN_J) or os.path.getmtime(BIN_J) < os.path.getmtime(os.path.join(ROOT, "mpc_planner_amd", "libtmpc_hip.so")):
+        _build_gaussian()
+    sc = scenes.make_scene(23, N=NJ, M=MJ, S=SJ, B=B, tmpc_pp=True, chance=True)
+    selected = 2
+    f = str(tmp_path / "scene.bin")
+    _scene_file(sc, f, selected, dims=(NJ, MJ, SJ), gaussian=True)
+    out = subprocess.run([BIN_J, os.path.join(GEN_J, "config"), f], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = out.stdout.splitlines()
+    head = lines[0].split()
+    exit_code, best = int(head[1]), int(head[3])
+    planners = [l.split() for l in lines if l.startswith("planner")]
+    xs = np.array([[float(v) for v in l.split()[2:]] for l in lines if l.startswith("x ")])
+    ps = np.array([[float(v) for v in l.split()[2:]] for l in lines if l.startswith("p ")])
+    s = solver.BatchedSolver(solver.default_dims(N=NJ, S=SJ, n_lin=MJ, M=MJ, row_model=1), B_max=B + 1)
+    s.set_batch(sc["xinit"], sc["x0"], sc["params"]); s.solve(); g = s.get()
+    w = np.ones(B + 1); w[selected] = 0.75
+    py_best = s.select_best(weight=w)
+    s.close()
+    assert len(planners) == B + 1 and (g["exit_code"] == 1).sum() >= B // 2
+    for b, pl in enumerate(planners):
+        assert int(pl[3]) == 0 and int(pl[5]) == g["exit_code"][b], (b, pl)
+        if g["exit_code"][b] == 1:
+            assert abs(float(pl[7]) - g["pobj"][b] * w[b]) <= 1e-7 * max(1.0, abs(g["pobj"][b]))
+    assert best == py_best and exit_code == g["exit_code"][py_best]
+    np.testing.assert_allclose(ps, sc["params"][py_best], rtol=0, atol=1e-12)        # C++ GaussianConstraints rows == numpy mirror
+    np.testing.assert_allclose(xs, g["xtraj"][py_best], rtol=0, atol=1e-7)
