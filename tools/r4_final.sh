@@ -4,7 +4,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; cd $R
 ( time python bench.py ) > $O/round4_final_bench.json 2> $O/round4_final_bench.err
 python tools/collect_profiles.py round4_final > $O/round4_final_collect.log 2>&1
-for wl in cfg3 cfg3_mpcc cfg4 cfg5; do
+for wl in cfg3 cfg3_mpcc cfg4 cfg5 jackal; do
   timeout 400 python bench.py --workload $wl --no-tight --latency-reps 0 --no-cpu-baseline --steps 50 --warmup 5 > $O/round4_final_${wl}.json 2> /dev/null
 done
 timeout 400 python bench.py --workload cfg4 --share-of 8 --no-tight --latency-reps 0 --no-cpu-baseline --steps 50 --warmup 5 > $O/round4_final_cfg4_share8.json 2> /dev/null
