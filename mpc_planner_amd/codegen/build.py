@@ -55,7 +55,7 @@ def build_generated_solver(name, modules, model, settings, out_dir, method="symb
     iterates in this kernel family, so a build whose production wave kernels use scratch is not taken silently: the other
     code-generation back end is tried (its emitted code has a different register profile), the build with zero scratch -- else the
     one with the least -- is kept, and the outcome is written to <name>_meta.json: "wave_kernel_scratch" (empty = clean) and
-    "verified_under_spills" (false = the library passed its parity tests, but nothing guarantees that for other inputs).
+    "spill_free" (false = the library passed its parity tests, but nothing guarantees that for other inputs).
     strict=True raises GeneratedKernelSpills instead of keeping a spilling build."""
     os.makedirs(out_dir, exist_ok=True)
     out = os.path.join(os.path.abspath(out_dir), f"libtmpc_hip_{name}.so")
@@ -87,10 +87,10 @@ def build_generated_solver(name, modules, model, settings, out_dir, method="symb
         raise GeneratedKernelSpills(f"{name}: production wave kernels use scratch with every back end: {tried}")
     meta = dict(name=name, npar=gen["npar"], nh=gen["nh"], slack=gen["slack"], rows=gen["rows"],
                 parameter_map=dict(gen["params"]._params), kernel_resources=usage, codegen_method=m_used, codegen_methods_tried=tried,
-                wave_kernel_scratch=wave_kernel_scratch(usage), verified_under_spills=(worst == 0),
+                wave_kernel_scratch=wave_kernel_scratch(usage), spill_free=(worst == 0),
                 note="hand-written shapes of libtmpc_hip.so are held to zero scratch.  Generated stage functions are straight-line "
                      "code from symbolic differentiation / jets and may spill inside the linearisation phase: a build whose wave "
-                     "kernels use scratch is kept only after the other back end was tried, and is marked verified_under_spills = "
+                     "kernels use scratch is kept only after the other back end was tried, and is marked spill_free = "
                      "false (its parity tests pass, but spills under partial EXEC have produced wrong iterates in this kernel "
                      "family before: DESIGN 5)")
     with open(os.path.join(out_dir, f"{name}_meta.json"), "w") as fh:
