@@ -168,7 +168,9 @@ constexpr double POLY_EPS_PARALLEL = 1e-12, POLY_TOL_EDGE = 1e-9, POLY_SEED_MARG
 constexpr int POLY_IDX_MASK = 0x1fff, POLY_DROP_FLAG = 1 << 29;     // a candidate's index word during the second filter round
 constexpr int POLY_SEC1 = 256;                        // direction sectors of round 1 (32 per octant, in angular order)
 constexpr int POLY_NONE = 0x7fffffff;
-constexpr int POLY_LIST_CAP = 512;                  // candidate list of the first pass
+constexpr int POLY_LIST_CAP = 1024;                 // candidate list of the first pass.  512 until round 4: on the cfg-5 scenes (8 x 256 samples per stage) enough units kept
+                                                    // more than 512 candidates that the second pass cost another 250 us per tick; with 1024 none overflows there
+                                                    // (second pass 4 us, the tick 2.06 -> 1.80 ms), and 28 KB of list still leave 4 workgroups per CU
 
 __device__ __forceinline__ int poly_sector(double ax, double ay, int bins)        // octant x bins of min(|ax|,|ay|)/max: a partition of the directions
 {

@@ -771,7 +771,9 @@ int tmpc_scenario_halfspaces(tmpc_handle *h, const void *d_samples, int32_t n_pt
     int *empty_stages = overflow + 1 + units;
     TMPC_HIP_CHECK(h, hipMemsetAsync(overflow, 0, sizeof(int), h->stream));
     TMPC_HIP_CHECK(h, hipMemsetAsync(empty_stages, 0, sizeof(int) * (size_t)h->B, h->stream));
-    const int cap1 = n_pts < tmpc::POLY_LIST_CAP ? n_pts : tmpc::POLY_LIST_CAP;
+    int list_cap = tmpc::POLY_LIST_CAP;
+    if (const char *e = getenv("TMPC_POLY_LIST_CAP")) { const int v = atoi(e); if (v >= 64 && v <= 4096) list_cap = v; }   // experiments
+    const int cap1 = n_pts < list_cap ? n_pts : list_cap;
     for (int pass = 0; pass < (cap1 < n_pts ? 2 : 1); pass++) {
         const int cap = pass == 0 ? cap1 : n_pts;
         const size_t lds = (size_t)cap * per_entry;
