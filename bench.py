@@ -301,6 +301,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--sets", type=int, default=1, help="one-set workloads (cfg3, cfg4, cfg5): K independent sets per launch instead of the one BASELINE names "
+                                                         "(single GPU; shows the shape's kernels on a saturated GPU)")
     ap.add_argument("--scenes", type=int, default=512,
                     help="scenes (control ticks) per launch per GPU; 512 x 64 = 32768 trajectories keep the tail of uneven solve "
                          "times small (256 scenes: 497k solves/s, 1024: 514k, 2048: 516k on one MI355X)")
@@ -339,7 +341,12 @@ def main():
 
     # ---- synthetic inputs, generated before the GPU runtime is touched (forked workers) -------------------------
     from mpc_planner_amd import scenes
-    if wl.get("one_set"):
+    if wl.get("one_set") and a.sets > 1:
+        # NOT the BASELINE configuration (which names one set): `--sets K` independent sets of the same shape in one launch, to show the kernels
+        # of the shape on a saturated GPU (cfg 3: the two-wave compact kernel, four trajectories per CU, takes launches of more than 512)
+        batch = scenes.make_batch(range(7, 7 + a.sets), workers=a.gen_workers or usable_cpus(), B=TRAJ_SET, **wl["scene"])
+        n_sets, traj_local = a.sets, TRAJ_SET
+    elif wl.get("one_set"):
         # one set split over the ranks: every rank builds the same scene and keeps its contiguous share
         per_rank = TRAJ_SET // (a.share_of if (a.share_of > 0 and world == 1) else world)
         full = scenes.make_scene(7, B=TRAJ_SET, **wl["scene"])
@@ -600,7 +607,8 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if wl.get("one_set") else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{wl['what']}; {n_sets} set(s) x {traj_local} = {B} trajectories per launch per GPU, n_sqp=10, qp_tol=1e-5"
-                                   + (f" (rank 0's share of a {a.share_of}-rank split, solved on one GPU without the collective)" if a.share_of > 0 and world == 1 else ""),
+                                   + (f" (rank 0's share of a {a.share_of}-rank split, solved on one GPU without the collective)" if a.share_of > 0 and world == 1 else "")
+                                   + (f" (--sets {a.sets}: NOT the BASELINE configuration, which names ONE set; the shape on a saturated GPU)" if wl.get("one_set") and a.sets > 1 else ""),
                        "trajectories_per_launch_per_gpu": B, "scenes_per_launch": n_sets,
                        "success_fraction": float(ok.mean()), "mean_sqp_iter": n_sqp_mean, "mean_ipm_iter_per_qp": ipm_per_qp,
                        "value_counts": "successful solves (exit_code == 1) only",

@@ -113,6 +113,28 @@ static SolveKernel pick_compact_kernel(const Dims &d, bool prof)
     (void)d; (void)prof;
     return nullptr;
 }
+// Two-wave compact variant (round 4: 22 <= N <= 32, four lanes per stage -- the reference's N = 30 defaults, cfg 3): the same kernel with
+// NTH = 128.  236 / 251 registers, zero scratch, 27-39 KB of LDS: FOUR trajectories per CU (two waves each, two waves per SIMD) where the
+// fast two-wave kernel (57-70 KB of LDS) holds two.  Bitwise the same results; a trajectory takes longer on it (NLP data in the global
+// workspace, the linearisation on one of the two waves), so launch_solve uses it only for launches that the fast kernel could not hold
+// resident at once (more than two trajectories per CU).  The runtime-shape instantiation with 12 rows per lane spills (144 B): not registered.
+static SolveKernel pick_compact2_kernel(const Dims &d)
+{
+#ifndef TMPC_GENERATED_STAGE
+    if (getenv("TMPC_FORCE_GENERIC") || getenv("TMPC_NO_COMPACT") || getenv("TMPC_NO_TWO_WAVE") || 3 * d.N <= NT || 4 * d.N > 128) return nullptr;
+    const int nr = d.n_up + d.M + 14, sm = stage_model(d);
+    if (sm == 1) return (d.n_up == 20 && d.M == 8) ? (SolveKernel)tmpc_solve_compact_kernel<20, 8, 4, false, 128, 1> : nullptr;      // cfg 3 as named (CA-MPC)
+    if (sm == 2) return nr <= 4 * 6 ? (SolveKernel)tmpc_solve_compact_kernel<-1, 6, 4, false, 128, 2> : nullptr;                    // mpc_planner_jackal's default
+    if (sm != 0) return nullptr;
+    if (d.n_up == 20 && d.M == 8) return (SolveKernel)tmpc_solve_compact_kernel<20, 8, 4, false, 128>;
+    if (d.n_up == 12 && d.M == 12) return (SolveKernel)tmpc_solve_compact_kernel<12, 12, 4, false, 128>;
+    if (d.n_up == 8 && d.M == 8) return (SolveKernel)tmpc_solve_compact_kernel<8, 8, 4, false, 128>;
+    if (nr <= 4 * 6) return (SolveKernel)tmpc_solve_compact_kernel<-1, 6, 4, false, 128>;
+    if (nr <= 4 * 9) return (SolveKernel)tmpc_solve_compact_kernel<-1, 9, 4, false, 128>;
+#endif
+    (void)d;
+    return nullptr;
+}
 // Latency variant (tmpc_set_latency_mode): two waves per trajectory at 6 lanes per stage, built for two waves per SIMD
 // (<= 256 registers, so four trajectories per CU stay resident).  The stage-parallel phases run on twice the lanes:
 // -8 % kernel time on a 64-trajectory control tick; on a saturated GPU the one-wave kernel is as fast or faster, which is
@@ -178,6 +200,9 @@ struct tmpc_handle {
     int grid_max = 0;                         // resident workgroups of the compact kernel on this device
     double *ws = nullptr;                     // [grid_max][ws_doubles(N)] per-workgroup NLP workspace
     int *ticket = nullptr;
+    tmpc::SolveKernel kernel_cp2 = nullptr;   // optional two-wave compact variant (22 <= N <= 32): launches of more than cp2_min_B trajectories
+    size_t lds_bytes_cp2 = 0;
+    int cp2_min_B = 0;                        // what the fast two-wave kernel holds resident at once (workgroups per CU x CUs)
     int latency_mode = 0;                     // 0: throughput kernels, 1: two-wave variant, 2: parallel-in-time variant
     bool throughput_mode = false;             // lane-per-trajectory kernels (tmpc_lanes.hip) instead of one wave per trajectory
     tmpc::lanes::Context *lanes = nullptr;    // their HBM workspace, created when the mode is first enabled
@@ -311,6 +336,20 @@ int tmpc_create(tmpc_handle **out, const tmpc_dims *dims, int32_t B_max, int32_t
     if (hipFuncSetAttribute((const void *)h->kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)h->lds_bytes) != hipSuccess)
         return fail(TMPC_ERR_NO_DEVICE);
+    if (h->fast && h->threads == 128 && !h->compact && (h->kernel_cp2 = tmpc::pick_compact2_kernel(d)) != nullptr) {
+        h->lds_bytes_cp2 = sizeof(double) * (size_t)tmpc::lds_doubles_compact(d.N, d.n_lin, d.n_up + d.M, 128);
+        int per_cu = 0, fast_per_cu = 0, cus = 0;
+        if (hipFuncSetAttribute((const void *)h->kernel_cp2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes_cp2) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)h->kernel_cp2, 128, h->lds_bytes_cp2) != hipSuccess || per_cu <= 0 ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&fast_per_cu, (const void *)h->kernel, 128, h->lds_bytes) != hipSuccess || fast_per_cu <= 0 ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0 || per_cu <= fast_per_cu)
+            h->kernel_cp2 = nullptr;                         // (no gain in residency: the fast kernel stays alone)
+        else {
+            if (const char *e = getenv("TMPC_COMPACT_PER_CU")) { const int v = atoi(e); if (v > 0 && v < per_cu) per_cu = v; }   // experiments
+            h->grid_max = per_cu * cus; h->cp2_min_B = fast_per_cu * cus;
+            if (const char *e = getenv("TMPC_COMPACT2_MIN_B")) h->cp2_min_B = atoi(e);                                            // experiments
+        }
+    }
     if (h->compact) {
         int per_cu = 0, cus = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)h->kernel, 64, h->lds_bytes) != hipSuccess || per_cu <= 0 ||
@@ -337,7 +376,7 @@ int tmpc_create(tmpc_handle **out, const tmpc_dims *dims, int32_t B_max, int32_t
     ok &= hipMalloc(&h->qp_iter, B * 4) == hipSuccess;
     ok &= hipMalloc(&h->d_best, 4) == hipSuccess;
     ok &= hipMalloc(&h->d_disabled, B) == hipSuccess;
-    if (h->compact) {
+    if (h->compact || h->kernel_cp2) {
         ok &= hipMalloc(&h->ws, (size_t)h->grid_max * tmpc::ws_doubles(d.N) * 8) == hipSuccess;
         ok &= hipMalloc(&h->ticket, 8 * 4) == hipSuccess;         // one work counter per XCD (next_trajectory)
     }
@@ -407,10 +446,11 @@ static int launch_solve(tmpc_handle *h, int n_iter, int st_flags)
                          (h->share_B == h->B) ? h->d_share : nullptr};      // (a map given for another batch size is not applied)
         const bool lat2 = h->kernel_scan && h->latency_mode == 2;
         const bool lat = !lat2 && h->kernel_lat && h->latency_mode != 0;          // (mode 2 without a scan variant falls back to the two-wave variant)
-        const bool cp = h->compact && !lat && !lat2;
+        const bool cp2 = h->kernel_cp2 && !lat && !lat2 && h->B > h->cp2_min_B;   // (bitwise the same results as the fast kernel: the launch size may choose)
+        const bool cp = (h->compact && !lat && !lat2) || cp2;
         if (cp) TMPC_HIP_CHECK(h, hipMemsetAsync(h->ticket, 0, 8 * 4, h->stream));    // the persistent launch's work counters (one per XCD)
-        hipLaunchKernelGGL(lat2 ? h->kernel_scan : lat ? h->kernel_lat : h->kernel, dim3(cp ? (h->B < h->grid_max ? h->B : h->grid_max) : h->B),   // (persistent launch: at most the resident workgroups)
-                           dim3(lat2 ? h->scan_threads : lat ? 128 : (cp ? 64 : h->threads)), lat2 ? h->lds_bytes_scan : lat ? h->lds_bytes_fast2 : h->lds_bytes, h->stream, dd, h->B,
+        hipLaunchKernelGGL(lat2 ? h->kernel_scan : lat ? h->kernel_lat : cp2 ? h->kernel_cp2 : h->kernel, dim3(cp ? (h->B < h->grid_max ? h->B : h->grid_max) : h->B),   // (persistent launch: at most the resident workgroups)
+                           dim3(lat2 ? h->scan_threads : lat ? 128 : cp2 ? 128 : (cp ? 64 : h->threads)), lat2 ? h->lds_bytes_scan : lat ? h->lds_bytes_fast2 : cp2 ? h->lds_bytes_cp2 : h->lds_bytes, h->stream, dd, h->B,
                            h->xinit, h->x0, h->params, h->xtraj, h->utraj, h->pobj, h->exit_code, h->qp_status,
                            h->sqp_iter, h->res_eq, h->qp_iter, (long long *)nullptr, io);
         TMPC_HIP_CHECK(h, hipGetLastError());
@@ -658,9 +698,11 @@ int tmpc_kernel_info(const tmpc_handle *h, char *buf, int32_t capacity)
                          : !h->fast        ? "generic (one wave per trajectory, rows in LDS)"
                          : !h->compact     ? (h->threads == 128 ? "fast, two waves per trajectory" : "fast (one wave per trajectory)")
                                            : "compact (one wave per trajectory, two waves per SIMD)";
-    const int n = snprintf(buf, (size_t)capacity, "%s; trajectories per workgroup %d; LDS %zu B per workgroup; %s", family, 1,
+    const std::string cp2 = h->kernel_cp2 ? "; launches of more than " + std::to_string(h->cp2_min_B) + " trajectories: compact two-wave variant (LDS " +
+                                            std::to_string(h->lds_bytes_cp2) + " B, persistent launch, resident workgroups " + std::to_string(h->grid_max) + ")" : "";
+    const int n = snprintf(buf, (size_t)capacity, "%s; trajectories per workgroup %d; LDS %zu B per workgroup; %s%s", family, 1,
                            h->lds_bytes, h->compact ? (std::string("persistent launch, resident workgroups ") + std::to_string(h->grid_max)).c_str()
-                                                    : "one workgroup per trajectory");
+                                                    : "one workgroup per trajectory", cp2.c_str());
     return n < capacity ? n : capacity - 1;
 }
 

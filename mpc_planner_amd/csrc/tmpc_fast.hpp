@@ -62,16 +62,17 @@ __device__ __forceinline__ Lds carve_fast(double *s, const Dims &d)
 // QP iterate and the Riccati work arrays.  The NLP-level data -- iterate z, multipliers pi and the stage blocks W, g, b, written
 // once per RTI iteration and read once per interior-point iteration -- live in a per-workgroup workspace in global memory
 // (one slot per RESIDENT workgroup: ~9 KB x 8 per CU, L2-resident).  L.pr aliases L.dpi (tmpc_riccati.hpp).
-__host__ __device__ inline int lds_doubles_compact(int N, int n_pair, int nh)
+// nth = 128: the two-wave instantiations (21 <= N <= 32, four lanes per stage); their block-wide reductions need the 64-entry scratch
+__host__ __device__ inline int lds_doubles_compact(int N, int n_pair, int nh, int nth = 64)
 {
     const int dstride = 2 * n_pair + 3 * (nh - n_pair);
     const int persistent = N * 8 + BA_NCONST + N * dstride + 3;
-    const int work = (N + 1) * NV + (N + 1) * NX + (N + 1) * NP28 + 2 * (N + 1) * NV + N * NX + (N + 1) * NV + (N + 1) * NX + N * NU + 8;
+    const int work = (N + 1) * NV + (N + 1) * NX + (N + 1) * NP28 + 2 * (N + 1) * NV + N * NX + (N + 1) * NV + (N + 1) * NX + N * NU + (nth > 64 ? 64 : 8);
     const int staging = 2 * N * nh;
     return persistent + (work > staging ? work : staging);
 }
 
-__device__ __forceinline__ Lds carve_compact(double *s, double *ws, const Dims &d)
+__device__ __forceinline__ Lds carve_compact(double *s, double *ws, const Dims &d, int nth = 64)
 {
     Lds L;
     const int N = d.N;
@@ -82,13 +83,14 @@ __device__ __forceinline__ Lds carve_compact(double *s, double *ws, const Dims &
     auto takeg = [&](int n) { double *p = ws; ws += n; return p; };
     L.z = takeg((N + 1) * NV); L.pi = takeg((N + 1) * NX); L.W = takeg((N + 1) * NP28); L.g = takeg((N + 1) * NV);
     L.b = takeg((N + 1) * NX);
+    L.scan = takeg(N * NP28);                           // (two-wave instantiations: one wave's share of W while the stage is linearised)
     L.BA = nullptr; L.dyn8 = nullptr;
     L.tab = take(N * 8 + BA_NCONST);
     L.D = take(N * L.dstride + 3);                      // (+ one zero triple for box rows / the third entry of topology rows)
     double *w = s;
     L.v = take((N + 1) * NV); L.pq = take((N + 1) * NX); L.Hh = take((N + 1) * NP28);
     L.rg = take((N + 1) * NV); L.gh = take((N + 1) * NV); L.rb = take(N * NX); L.dv = take((N + 1) * NV);
-    L.dpi = take((N + 1) * NX); L.pr = L.dpi; L.y = take(N * NU); L.scr = take(8);
+    L.dpi = take((N + 1) * NX); L.pr = L.dpi; L.y = take(N * NU); L.scr = take(nth > 64 ? 64 : 8);
     s = w;
     L.beta = take(N * L.nh); L.lamh = take(N * L.nh);
     L.t = L.lam = L.invt = L.qt = L.rdiag = nullptr;
@@ -744,8 +746,8 @@ void tmpc_solve_fast_kernel(Dims d, int B, const double *__restrict__ xinit,
 // next): the L2 <-> fabric traffic did not move (FETCH 8.6 vs 9.0 GB, WRITE 2.87 GB per 32768-trajectory launch -- it is the
 // per-workgroup workspace, not the parameter rows), a saturated launch ran as fast (833 vs 836 k solves/s) and a
 // 4096-trajectory launch 4.5 % slower: rejected, profiles/round3_c_xcd_tickets_rejected.json.
-template <int NLIN, int MM, int LPS, bool PROF = false>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+template <int NLIN, int MM, int LPS, bool PROF = false, int NTH = 64, int CM = 0>
+__global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void tmpc_solve_compact_kernel(Dims d, int B, const double *__restrict__ xinit,
                                const double *__restrict__ x0, const double *__restrict__ params,
                                double *__restrict__ xtraj, double *__restrict__ utraj,
@@ -755,20 +757,26 @@ void tmpc_solve_compact_kernel(Dims d, int B, const double *__restrict__ xinit,
                                long long *__restrict__ prof_out, StateIO io)
 {
     using C = FastCfg<NLIN, MM, LPS>;
-    constexpr int NT = 64;
+    constexpr int NT = NTH;                         // 64: one wave per trajectory (N <= 21, three lanes per stage); 128: two waves (N <= 32, four lanes per stage)
     const int NHk = C::RT ? d.n_up + d.M : C::NH, NLINk = C::RT ? d.n_up : NLIN;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid0 = threadIdx.x;
     const int N = d.N;
     int tid = tid0;
-    const Lds L = carve_compact(smem, io.ws + (size_t)blockIdx.x * ws_doubles(N), d);
+    const Lds L = carve_compact(smem, io.ws + (size_t)blockIdx.x * ws_doubles(N), d, NTH);
     ba_tab_init(L.tab, d, tid);
     if (tid < 3) L.D[N * L.dstride + tid] = 0.0;        // zero triple read by box rows (and as the third entry of packed rows)
     __syncthreads();
     for (;;) {
         int b = 0;
         if (tid == 0) b = atomicAdd(io.ticket, 1);
-        b = __builtin_amdgcn_readfirstlane(b);
+        if constexpr (NTH == 64) b = __builtin_amdgcn_readfirstlane(b);
+        else {                                          // two waves: the ticket travels through LDS
+            if (tid == 0) L.scr[0] = (double)b;
+            __syncthreads();
+            b = (int)L.scr[0];
+            __syncthreads();                            // (scr is scratch of the solve below)
+        }
         if (b >= B) break;
         asm volatile("" : "+v"(tid));                   // opaque per trajectory: per-lane addresses are recomputed, not kept live (and spilled) across solves
         if ((slot_flags(io, b) & ST_KEEP_ITERATE) && io.stopped[slot_of(io, b)]) continue;      // this solver's loop has ended: outputs of its last call stand
@@ -794,11 +802,11 @@ void tmpc_solve_compact_kernel(Dims d, int B, const double *__restrict__ xinit,
         double lam[C::RPL];
         for (int it = 0; it < d.n_sqp; it++) {
             pf.start();
-            linearise<true, true>(L, d, tid, pb, slack_of(), pb_own);
+            linearise<true, true, NTH, CM>(L, d, tid, pb, slack_of(), pb_own);
             __syncthreads();
             pf.stop(PH_LIN);
             int iters = 0;
-            qp_status = ipm_fast<NLIN, MM, LPS, 64, true>(L, d, tid, xi, &iters, pf, lam);
+            qp_status = ipm_fast<NLIN, MM, LPS, NTH, true>(L, d, tid, xi, &iters, pf, lam);
             sqp_iter = it + 1; qp_iter_total += iters;
             if (qp_status != 0 && qp_status != 2) { status = 4; break; }
             status = 0;
@@ -813,7 +821,7 @@ void tmpc_solve_compact_kernel(Dims d, int B, const double *__restrict__ xinit,
             __syncthreads();
             constexpr int SPW = 64 / LPS;
             const int wl = tid_w & 63;
-            const int k = wl / LPS, c = wl % LPS;
+            const int k = (tid_w >> 6) * SPW + wl / LPS, c = wl % LPS;
             if (wl < SPW * LPS && k < N) {
 #pragma unroll
                 for (int s = 0; s < C::RPL; s++) {
@@ -831,8 +839,8 @@ void tmpc_solve_compact_kernel(Dims d, int B, const double *__restrict__ xinit,
             for (int e = tid; e < N * NHk; e += NT) io.lamh[(size_t)slot_of(io, b) * N * NHk + e] = L.lamh[e];
             if (tid == 0) { if (sqp_iter > 0) io.stopped[slot_of(io, b)] = qp_status != 0; io.valid[slot_of(io, b)] = 1; }
         }
-        solve_epilogue(L, d, tid, b, xi, pb, slack_of(), status, qp_status, sqp_iter, qp_iter_total, xtraj, utraj, pobj, exit_code,
-                       qp_status_out, sqp_iter_out, res_eq_out, qp_iter_out, prof_out, pf, t_begin, 64);
+        solve_epilogue<CM>(L, d, tid, b, xi, pb, slack_of(), status, qp_status, sqp_iter, qp_iter_total, xtraj, utraj, pobj, exit_code,
+                       qp_status_out, sqp_iter_out, res_eq_out, qp_iter_out, prof_out, pf, t_begin, NTH);
         __syncthreads();                                // the next trajectory reuses LDS and the workspace
     }
 }

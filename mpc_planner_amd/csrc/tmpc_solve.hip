@@ -129,7 +129,7 @@ __device__ __forceinline__ void ba_tab_init(double *tab, const Dims &d, int tid)
     }
 }
 // doubles of one workgroup's global workspace
-__host__ __device__ inline int ws_doubles(int N) { return (N + 1) * NV + (N + 1) * NX + (N + 1) * NP28 + (N + 1) * NV + (N + 1) * NX; }
+__host__ __device__ inline int ws_doubles(int N) { return (N + 1) * NV + (N + 1) * NX + (N + 1) * NP28 + (N + 1) * NV + (N + 1) * NX + N * NP28; }   // z, pi, W, g, b + the two-wave kernels' second share of W
 
 
 __host__ __device__ inline int lds_doubles(int N, int nh)
@@ -587,7 +587,7 @@ __device__ __forceinline__ void linearise(const Lds &L, const Dims &d, int tid, 
 {
     const int N = d.N;
 #ifndef TMPC_GENERATED_STAGE
-    if constexpr (FAST && !CP && NTH == 128) {
+    if constexpr (FAST && NTH == 128) {                  // (both layouts: the compact one differs in where the blocks go, not in the arithmetic)
         int tid_l = tid;
         asm volatile("" : "+v"(tid_l));
         const int wv = tid_l >> 6, ln = tid_l & 63;
@@ -603,9 +603,15 @@ __device__ __forceinline__ void linearise(const Lds &L, const Dims &d, int tid, 
         auto lamh = [&](int r) { return L.lamh[k * nh + r]; };
         auto sink = [&](int r, const RowOut &ro) {
             if (owner) {
-                double *Dr = L.D + (k * nh + r) * 3;
                 const double sg = (r < d.n_up) ? -1.0 : 1.0;     // fast layouts keep the SIGNED row Jacobian (ipm_fast reads it as it is)
-                Dr[0] = sg * ro.gx; Dr[1] = sg * ro.gy; Dr[2] = sg * ro.gp;
+                if constexpr (CP) {                               // packed: (gx, gy) for topology rows, triples for the others
+                    double *Dr = L.D + k * L.dstride + (r < L.n_pair ? 2 * r : 3 * r - L.n_pair);
+                    Dr[0] = sg * ro.gx; Dr[1] = sg * ro.gy;
+                    if (r >= L.n_pair) Dr[2] = sg * ro.gp;
+                } else {
+                    double *Dr = L.D + (k * nh + r) * 3;
+                    Dr[0] = sg * ro.gx; Dr[1] = sg * ro.gy; Dr[2] = sg * ro.gp;
+                }
                 const double bound = (r < d.n_up || cm_gaussian_rows(CM)) ? 0.0 : 1.0;     // ellipsoid rows: h >= 1; Gaussian rows: h >= 0
                 L.beta[k * nh + r] = bound - ro.h;
             }
@@ -614,7 +620,7 @@ __device__ __forceinline__ void linearise(const Lds &L, const Dims &d, int tid, 
         // work region), so that after the barrier each of them has the complete W and MIRROR can be shared as well: with a zero disc offset
         // W is block diagonal under {a, w, psi, v} | {x, y, spline} (mirror7), and the two blocks are regularised on different waves --
         // bitwise what mirror7 computes.  A coupled W (any cross entry != 0) takes the 7 x 7 iteration on wave 0.
-        double *W0s = L.scan + k * NP28;                     // (N * NP28 doubles behind the layout: every two-wave launch allocates them)
+        double *W0s = L.scan + k * NP28;                     // (N * NP28 doubles behind the layout: every two-wave launch allocates them; compact layout: in the global workspace)
         if (wv == 1) {                                       // cost, halfspace rows, second half of the ellipsoid rows
             stage_linearise<CM>(d, z, p, 1, 0.0, 0.0, lamh, sink, W, g, BA, xn, slack, nullptr, own_delta, 2);
             if (owner) {
@@ -628,9 +634,11 @@ __device__ __forceinline__ void linearise(const Lds &L, const Dims &d, int tid, 
         } else {                                             // dynamics, first half of the ellipsoid rows
             stage_linearise<CM>(d, z, p, 1, L.pi[(k + 1) * NX + 0], L.pi[(k + 1) * NX + 1], lamh, sink, W, g, BA, xn, slack, nullptr, own_delta, 1);
             if (owner) {
+                if constexpr (!CP) {
 #pragma unroll
-                for (int i = 0; i < NX * NV; i++) L.BA[k * NX * NV + i] = BA[i];
-                double *d8 = L.dyn8 + k * 8;
+                    for (int i = 0; i < NX * NV; i++) L.BA[k * NX * NV + i] = BA[i];
+                }
+                double *d8 = (CP ? L.tab : L.dyn8) + k * 8;
                 d8[D8_XA] = BA[0 * NV + ZA]; d8[D8_XW] = BA[0 * NV + ZW]; d8[D8_XP] = BA[0 * NV + ZPSI]; d8[D8_XV] = BA[0 * NV + ZV];
                 d8[D8_YA] = BA[1 * NV + ZA]; d8[D8_YW] = BA[1 * NV + ZW]; d8[D8_YP] = BA[1 * NV + ZPSI]; d8[D8_YV] = BA[1 * NV + ZV];
 #pragma unroll
@@ -943,7 +951,18 @@ TMPC_FAST_SHAPES(TMPC_X)
 extern template __global__ void tmpc::tmpc_solve_fast_kernel<8, 8, 6, 128, true, tmpc::ScanSolo>(TMPC_KARGS);
 #endif
 #endif
-#ifdef TMPC_PROF_TU
+// The two-wave compact instantiations (tmpc_capi.hpp: pick_compact2_kernel) have a translation unit of their own too (-DTMPC_CP2_TU).
+#define TMPC_CP2_SHAPES(X) X(20, 8, 4, 0) X(20, 8, 4, 1) X(12, 12, 4, 0) X(8, 8, 4, 0) X(-1, 6, 4, 0) X(-1, 9, 4, 0) X(-1, 6, 4, 2)
+#if defined(TMPC_CP2_TU) && !defined(TMPC_GENERATED_STAGE)
+#define TMPC_X(a, b, c, m) template __global__ void tmpc::tmpc_solve_compact_kernel<a, b, c, false, 128, m>(TMPC_KARGS);
+TMPC_CP2_SHAPES(TMPC_X)
+#undef TMPC_X
+#elif defined(TMPC_PROF_EXTERN) && !defined(TMPC_GENERATED_STAGE)
+#define TMPC_X(a, b, c, m) extern template __global__ void tmpc::tmpc_solve_compact_kernel<a, b, c, false, 128, m>(TMPC_KARGS);
+TMPC_CP2_SHAPES(TMPC_X)
+#undef TMPC_X
+#endif
+#if defined(TMPC_PROF_TU) || defined(TMPC_CP2_TU)
 #elif defined(TMPC_SINGLE_COMPACT)
 template __global__ void tmpc::tmpc_solve_compact_kernel<TMPC_SINGLE_COMPACT>(tmpc::Dims, int, const double *, const double *, const double *,
                                                                              double *, double *, double *, int *, int *, int *, double *, int *,

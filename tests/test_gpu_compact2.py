@@ -1,0 +1,107 @@
+"""GPU: the two-wave compact kernels (tmpc_solve_compact_kernel<..., NTH = 128>, 22 <= N <= 32: four trajectories per CU where the fast
+two-wave kernel holds two; csrc/tmpc_capi.hpp pick_compact2_kernel).  The library takes them for launches the fast kernel cannot hold
+resident at once -- which is only legitimate because the two compute bit for bit the same: asserted here on every registered shape
+(TMPC_COMPACT2_MIN_B=0 forces the compact kernel, TMPC_NO_COMPACT=1 the fast one; both are read when the handle is created), against
+the oracle, for the one-iteration protocol, and for the launch-size rule itself (a trajectory's result does not depend on what else
+is in the launch)."""
+import os
+
+import numpy as np
+import pytest
+
+from test_gpu_parity import _compare
+
+pytestmark = pytest.mark.gpu
+FIELDS = ("xtraj", "utraj", "pobj", "exit_code", "qp_status", "sqp_iter", "qp_iter_total", "res_eq")
+
+
+def _solver(force, B_max, **pkw):
+    """force: "compact" / "fast" / None (the library's own rule)."""
+    from mpc_planner_amd import solver
+    for k in ("TMPC_NO_COMPACT", "TMPC_COMPACT2_MIN_B"):
+        os.environ.pop(k, None)
+    if force == "compact":
+        os.environ["TMPC_COMPACT2_MIN_B"] = "0"
+    elif force == "fast":
+        os.environ["TMPC_NO_COMPACT"] = "1"
+    try:
+        return solver.BatchedSolver(solver.default_dims(**pkw), B_max=B_max)
+    finally:
+        for k in ("TMPC_NO_COMPACT", "TMPC_COMPACT2_MIN_B"):
+            os.environ.pop(k, None)
+
+
+SHAPES = {
+    # name: (scene kwargs, dims kwargs, oracle kwargs or None)
+    "cfg3_ca": (dict(N=30, M=8, slack=True, n_decomp=12), dict(N=30, S=5, n_lin=8, M=8, n_slk=12, slack=1, cost_model=1), dict(cost_model=1)),
+    "cfg3_mpcc": (dict(N=30, M=8, slack=True, n_decomp=12), dict(N=30, S=5, n_lin=8, M=8, n_slk=12, slack=1), {}),
+    "n30_8_8": (dict(N=30, M=8), dict(N=30, S=5, n_lin=8, M=8), {}),
+    "n30_12_12": (dict(N=30, M=12), dict(N=30, S=5, n_lin=12, M=12), {}),
+    "jackal_gaussian": (dict(N=30, M=5, S=3, chance=True), dict(N=30, S=3, n_lin=5, M=5, row_model=1), None),
+    "n30_runtime_10_10": (dict(N=30, M=10), dict(N=30, S=5, n_lin=10, M=10), {}),
+    "n22_8_8": (dict(N=22, M=8), dict(N=22, S=5, n_lin=8, M=8), {}),
+    "n32_8_8": (dict(N=32, M=8), dict(N=32, S=5, n_lin=8, M=8), {}),
+}
+
+
+@pytest.mark.parametrize("shape", sorted(SHAPES))
+def test_compact_two_wave_is_bitwise_the_fast_two_wave_kernel_and_matches_the_oracle(shape):
+    import oracle_lib as O
+    from mpc_planner_amd import scenes
+    skw, dkw, okw = SHAPES[shape]
+    B = 32
+    sc = scenes.make_scene(41, B=B, **skw)
+    out = {}
+    for force in ("fast", "compact"):
+        s = _solver(force, B, **dkw)
+        info = s.kernel_info()
+        assert ("compact two-wave variant" in info) == (force == "compact"), info
+        s.set_batch(sc["xinit"], sc["x0"], sc["params"]); s.solve(); out[force] = s.get(); s.close()
+    for k in FIELDS:
+        np.testing.assert_array_equal(out["compact"][k], out["fast"][k], err_msg=k)
+    if okw is None:                                                    # Gaussian rows: orc_problem_set_gaussian
+        pb = O.problem(N=dkw["N"], S=dkw["S"], n_lin=dkw["n_lin"], M=0, n_gauss=dkw["M"])
+    else:
+        pb = O.problem(**{k: v for k, v in dkw.items() if k != "cost_model"}, **okw)
+    xt, ut, info = O.solve_batch(pb, sc["xinit"], sc["x0"].reshape(B, -1), sc["params"].reshape(B, -1))
+    _compare(out["compact"], xt, ut, info)
+    assert (info["exit_code"] == 1).sum() >= B // 2
+
+
+def test_launch_size_rule_and_independence_of_the_launch():
+    """More trajectories than the fast kernel holds resident (two per CU) -> the compact kernel; at most that many -> the fast kernel.  Every
+    trajectory's result is the same in either launch."""
+    from mpc_planner_amd import scenes
+    dkw = dict(N=30, S=5, n_lin=8, M=8)
+    b = scenes.make_batch(range(50, 60), N=30, M=8, B=64)                # 640 trajectories
+    s = _solver(None, 640, **dkw)
+    info = s.kernel_info()
+    assert "compact two-wave variant" in info and "launches of more than" in info, info
+    min_b = int(info.split("launches of more than ")[1].split()[0])
+    assert 0 < min_b < 640 and min_b % 2 == 0, info                      # two workgroups per CU x CUs (512 on an MI355X)
+    s.set_batch(b["xinit"], b["x0"], b["params"]); s.solve(); big = s.get()
+    parts = []
+    for lo in range(0, 640, 320):                                        # two launches of 320 (<= min_b on a full MI355X): the fast kernel
+        s.set_batch(b["xinit"][lo:lo + 320], b["x0"][lo:lo + 320], b["params"][lo:lo + 320]); s.solve(); parts.append(s.get())
+    s.close()
+    for k in FIELDS:
+        np.testing.assert_array_equal(big[k], np.concatenate([p[k] for p in parts], 0), err_msg=k)
+    assert (big["exit_code"] == 1).mean() > 0.9
+
+
+def test_one_iteration_protocol_on_the_compact_two_wave_kernel():
+    """10 x solveOneIteration == solve(), bitwise, with the persistent state (slots) written and read by the two-wave compact kernel."""
+    from mpc_planner_amd import scenes
+    import test_gpu_parity as T
+    sc = T._make_infeasible(scenes.make_scene(7, N=30, M=8, B=48), [9, 33])
+    s = _solver("compact", 48, N=30, S=5, n_lin=8, M=8, qp_iter_max=6)
+    s.set_batch(sc["xinit"], sc["x0"], sc["params"]); s.solve(); ref = s.get()
+    assert (ref["exit_code"] != 1).any()
+    s.set_batch(sc["xinit"], sc["x0"], sc["params"])
+    s.solve_iterations(1, complete=False)
+    for i in range(9):
+        s.solve_iterations(1, keep_iterate=True, keep_multipliers=True, complete=(i == 8))
+    g = s.get()
+    for k in ("xtraj", "utraj", "pobj", "exit_code", "qp_status", "res_eq"):
+        np.testing.assert_array_equal(g[k], ref[k], err_msg=k)
+    s.close()
