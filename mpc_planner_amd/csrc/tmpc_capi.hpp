@@ -377,7 +377,7 @@ int tmpc_create(tmpc_handle **out, const tmpc_dims *dims, int32_t B_max, int32_t
     ok &= hipMalloc(&h->d_best, 4) == hipSuccess;
     ok &= hipMalloc(&h->d_disabled, B) == hipSuccess;
     if (h->compact || h->kernel_cp2) {
-        ok &= hipMalloc(&h->ws, (size_t)h->grid_max * tmpc::ws_doubles(d.N) * 8) == hipSuccess;
+        ok &= hipMalloc(&h->ws, (size_t)h->grid_max * tmpc::ws_doubles(d.N, h->kernel_cp2 != nullptr) * 8) == hipSuccess;
         ok &= hipMalloc(&h->ticket, 8 * 4) == hipSuccess;         // one work counter per XCD (next_trajectory)
     }
     if (!ok) { tmpc_destroy(h); return TMPC_ERR_HIP; }

@@ -763,7 +763,7 @@ void tmpc_solve_compact_kernel(Dims d, int B, const double *__restrict__ xinit,
     const int tid0 = threadIdx.x;
     const int N = d.N;
     int tid = tid0;
-    const Lds L = carve_compact(smem, io.ws + (size_t)blockIdx.x * ws_doubles(N), d, NTH);
+    const Lds L = carve_compact(smem, io.ws + (size_t)blockIdx.x * ws_doubles(N, NTH > 64), d, NTH);
     ba_tab_init(L.tab, d, tid);
     if (tid < 3) L.D[N * L.dstride + tid] = 0.0;        // zero triple read by box rows (and as the third entry of packed rows)
     __syncthreads();

@@ -129,7 +129,10 @@ __device__ __forceinline__ void ba_tab_init(double *tab, const Dims &d, int tid)
     }
 }
 // doubles of one workgroup's global workspace
-__host__ __device__ inline int ws_doubles(int N) { return (N + 1) * NV + (N + 1) * NX + (N + 1) * NP28 + (N + 1) * NV + (N + 1) * NX + N * NP28; }   // z, pi, W, g, b + the two-wave kernels' second share of W
+__host__ __device__ inline int ws_doubles(int N, bool two_wave = false)      // z, pi, W, g, b (+ the two-wave kernels' second share of W)
+{
+    return (N + 1) * NV + (N + 1) * NX + (N + 1) * NP28 + (N + 1) * NV + (N + 1) * NX + (two_wave ? N * NP28 : 0);
+}
 
 
 __host__ __device__ inline int lds_doubles(int N, int nh)
