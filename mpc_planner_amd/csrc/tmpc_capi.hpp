@@ -200,6 +200,9 @@ struct tmpc_handle {
     int grid_max = 0;                         // resident workgroups of the compact kernel on this device
     double *ws = nullptr;                     // [grid_max][ws_doubles(N)] per-workgroup NLP workspace
     int *ticket = nullptr;
+    tmpc::SolveKernel kernel_small = nullptr; // compact shapes (N <= 21): the fast one-wave kernel, for launches of at most cp_min_B trajectories
+    size_t lds_bytes_small = 0;
+    int cp_min_B = 0;                         // what the fast one-wave kernel holds resident at once (workgroups per CU x CUs)
     tmpc::SolveKernel kernel_cp2 = nullptr;   // optional two-wave compact variant (22 <= N <= 32): launches of more than cp2_min_B trajectories
     size_t lds_bytes_cp2 = 0;
     int cp2_min_B = 0;                        // what the fast two-wave kernel holds resident at once (workgroups per CU x CUs)
@@ -330,6 +333,15 @@ int tmpc_create(tmpc_handle **out, const tmpc_dims *dims, int32_t B_max, int32_t
             h->kernel_scan = nullptr;
     }
     if (tmpc::SolveKernel kc = (h->fast && h->threads == tmpc::NT) ? tmpc::pick_compact_kernel(d, false) : nullptr) {
+        // the fast kernel of the shape (everything in LDS, four per CU) stays for launches it holds resident at once: bitwise the same results
+        // (tests/test_gpu_compact2.py), a trajectory is ~10 % faster on it.  TMPC_COMPACT_MIN_B=0: the compact kernel for every launch (rounds 3-4)
+        int fast_per_cu = 0, cus = 0;
+        if (hipFuncSetAttribute((const void *)h->kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes) == hipSuccess &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&fast_per_cu, (const void *)h->kernel, 64, h->lds_bytes) == hipSuccess && fast_per_cu > 0 &&
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) {
+            h->kernel_small = h->kernel; h->lds_bytes_small = h->lds_bytes; h->cp_min_B = fast_per_cu * cus;
+            if (const char *e = getenv("TMPC_COMPACT_MIN_B")) h->cp_min_B = atoi(e);                                              // experiments
+        }
         h->kernel = kc; h->compact = true;
         h->lds_bytes = sizeof(double) * (size_t)tmpc::lds_doubles_compact(d.N, d.n_lin, d.n_up + d.M);
     }
@@ -446,11 +458,16 @@ static int launch_solve(tmpc_handle *h, int n_iter, int st_flags)
                          (h->share_B == h->B) ? h->d_share : nullptr};      // (a map given for another batch size is not applied)
         const bool lat2 = h->kernel_scan && h->latency_mode == 2;
         const bool lat = !lat2 && h->kernel_lat && h->latency_mode != 0;          // (mode 2 without a scan variant falls back to the two-wave variant)
-        const bool cp2 = h->kernel_cp2 && !lat && !lat2 && h->B > h->cp2_min_B;   // (bitwise the same results as the fast kernel: the launch size may choose)
-        const bool cp = (h->compact && !lat && !lat2) || cp2;
+        // compact <-> fast kernels of a shape compute bit for bit the same, so the launch size may choose between them: the fast kernel while it
+        // holds the whole launch resident (lower latency per trajectory), the compact one (twice the residency) above that
+        const bool cp2 = h->kernel_cp2 && !lat && !lat2 && h->B > h->cp2_min_B;
+        const bool small = h->compact && h->kernel_small && !lat && !lat2 && h->B <= h->cp_min_B;
+        const bool cp = (h->compact && !lat && !lat2 && !small) || cp2;
         if (cp) TMPC_HIP_CHECK(h, hipMemsetAsync(h->ticket, 0, 8 * 4, h->stream));    // the persistent launch's work counters (one per XCD)
-        hipLaunchKernelGGL(lat2 ? h->kernel_scan : lat ? h->kernel_lat : cp2 ? h->kernel_cp2 : h->kernel, dim3(cp ? (h->B < h->grid_max ? h->B : h->grid_max) : h->B),   // (persistent launch: at most the resident workgroups)
-                           dim3(lat2 ? h->scan_threads : lat ? 128 : cp2 ? 128 : (cp ? 64 : h->threads)), lat2 ? h->lds_bytes_scan : lat ? h->lds_bytes_fast2 : cp2 ? h->lds_bytes_cp2 : h->lds_bytes, h->stream, dd, h->B,
+        hipLaunchKernelGGL(lat2 ? h->kernel_scan : lat ? h->kernel_lat : cp2 ? h->kernel_cp2 : small ? h->kernel_small : h->kernel,
+                           dim3(cp ? (h->B < h->grid_max ? h->B : h->grid_max) : h->B),   // (persistent launch: at most the resident workgroups)
+                           dim3(lat2 ? h->scan_threads : lat ? 128 : cp2 ? 128 : ((cp || small) ? 64 : h->threads)),
+                           lat2 ? h->lds_bytes_scan : lat ? h->lds_bytes_fast2 : cp2 ? h->lds_bytes_cp2 : small ? h->lds_bytes_small : h->lds_bytes, h->stream, dd, h->B,
                            h->xinit, h->x0, h->params, h->xtraj, h->utraj, h->pobj, h->exit_code, h->qp_status,
                            h->sqp_iter, h->res_eq, h->qp_iter, (long long *)nullptr, io);
         TMPC_HIP_CHECK(h, hipGetLastError());
@@ -698,11 +715,13 @@ int tmpc_kernel_info(const tmpc_handle *h, char *buf, int32_t capacity)
                          : !h->fast        ? "generic (one wave per trajectory, rows in LDS)"
                          : !h->compact     ? (h->threads == 128 ? "fast, two waves per trajectory" : "fast (one wave per trajectory)")
                                            : "compact (one wave per trajectory, two waves per SIMD)";
+    const std::string sm = (h->compact && h->kernel_small && h->cp_min_B > 0) ? "; launches of at most " + std::to_string(h->cp_min_B) + " trajectories: fast one-wave variant (LDS " +
+                                                                                std::to_string(h->lds_bytes_small) + " B, one workgroup per trajectory)" : "";
     const std::string cp2 = h->kernel_cp2 ? "; launches of more than " + std::to_string(h->cp2_min_B) + " trajectories: compact two-wave variant (LDS " +
                                             std::to_string(h->lds_bytes_cp2) + " B, persistent launch, resident workgroups " + std::to_string(h->grid_max) + ")" : "";
     const int n = snprintf(buf, (size_t)capacity, "%s; trajectories per workgroup %d; LDS %zu B per workgroup; %s%s", family, 1,
                            h->lds_bytes, h->compact ? (std::string("persistent launch, resident workgroups ") + std::to_string(h->grid_max)).c_str()
-                                                    : "one workgroup per trajectory", cp2.c_str());
+                                                    : "one workgroup per trajectory", (cp2 + sm).c_str());
     return n < capacity ? n : capacity - 1;
 }
 

@@ -3,7 +3,8 @@ two-wave kernel holds two; csrc/tmpc_capi.hpp pick_compact2_kernel).  The librar
 resident at once -- which is only legitimate because the two compute bit for bit the same: asserted here on every registered shape
 (TMPC_COMPACT2_MIN_B=0 forces the compact kernel, TMPC_NO_COMPACT=1 the fast one; both are read when the handle is created), against
 the oracle, for the one-iteration protocol, and for the launch-size rule itself (a trajectory's result does not depend on what else
-is in the launch)."""
+is in the launch).  The same rule, the other way round, for the one-wave shapes (N <= 21): launches the fast one-wave kernel holds resident run on
+it, larger ones on the compact kernel; every compact one-wave instantiation is compared with its fast twin here."""
 import os
 
 import numpy as np
@@ -105,3 +106,33 @@ def test_one_iteration_protocol_on_the_compact_two_wave_kernel():
     for k in ("xtraj", "utraj", "pobj", "exit_code", "qp_status", "res_eq"):
         np.testing.assert_array_equal(g[k], ref[k], err_msg=k)
     s.close()
+
+
+@pytest.mark.parametrize("shape", ["cfg1", "cfg2", "cfg4", "cfg5", "runtime_7_rows_per_lane", "runtime_10_rows_per_lane"])
+def test_one_wave_shapes_fast_kernel_for_resident_launches_is_bitwise_the_compact_kernel(shape):
+    """N <= 21: launches the fast one-wave kernel holds resident at once (four per CU) run on it, larger ones on the compact kernel (eight per
+    CU, persistent) -- legitimate only because the two compute bit for bit the same (TMPC_COMPACT_MIN_B=0: the compact kernel for every launch)."""
+    from mpc_planner_amd import scenes, solver
+    skw, dkw = {"cfg1": (dict(N=20, M=4, guidance=False), dict(N=20, S=5, n_lin=0, M=4)),
+                "runtime_7_rows_per_lane": (dict(N=20, M=3), dict(N=20, S=5, n_lin=3, M=3)),
+                "runtime_10_rows_per_lane": (dict(N=20, M=6), dict(N=20, S=5, n_lin=6, M=6)),
+                "cfg2": (dict(N=20, M=8), dict(N=20, S=5, n_lin=8, M=8)),
+                "cfg4": (dict(N=20, M=12), dict(N=20, S=5, n_lin=12, M=12)),
+                "cfg5": (dict(N=20, M=8, slack=True, n_scenario=24), dict(N=20, S=5, n_lin=0, M=0, n_slk=24, slack=1))}[shape]
+    B = 32
+    sc = scenes.make_scene(43, B=B, **skw)
+    out = {}
+    for env in ("0", None):
+        os.environ.pop("TMPC_COMPACT_MIN_B", None)
+        if env is not None:
+            os.environ["TMPC_COMPACT_MIN_B"] = env
+        try:
+            s = solver.BatchedSolver(solver.default_dims(**dkw), B_max=B)
+        finally:
+            os.environ.pop("TMPC_COMPACT_MIN_B", None)
+        info = s.kernel_info()
+        assert "compact" in info and (("launches of at most 0 " in info or "fast one-wave variant" not in info) == (env == "0")), info
+        s.set_batch(sc["xinit"], sc["x0"], sc["params"]); s.solve(); out[env] = s.get(); s.close()
+    for k in FIELDS:
+        np.testing.assert_array_equal(out[None][k], out["0"][k], err_msg=k)
+    assert (out[None]["exit_code"] == 1).sum() >= B // 2
