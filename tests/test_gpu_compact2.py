@@ -136,3 +136,49 @@ def test_one_wave_shapes_fast_kernel_for_resident_launches_is_bitwise_the_compac
     for k in FIELDS:
         np.testing.assert_array_equal(out[None][k], out["0"][k], err_msg=k)
     assert (out[None]["exit_code"] == 1).sum() >= B // 2
+
+
+def _forced_compact(B_max, **dkw):
+    """The compact kernel of the shape for every launch size (one-wave: TMPC_COMPACT_MIN_B=0; two-wave: TMPC_COMPACT2_MIN_B=0)."""
+    from mpc_planner_amd import solver
+    os.environ["TMPC_COMPACT_MIN_B"] = "0"; os.environ["TMPC_COMPACT2_MIN_B"] = "0"
+    try:
+        return solver.BatchedSolver(solver.default_dims(**dkw), B_max=B_max)
+    finally:
+        os.environ.pop("TMPC_COMPACT_MIN_B", None); os.environ.pop("TMPC_COMPACT2_MIN_B", None)
+
+
+def test_one_iteration_protocol_on_the_compact_one_wave_kernel():
+    """Small launches run on the fast kernels since the launch-size rule: the persistent-state protocol on the COMPACT one-wave kernel (what a
+    launch of thousands of solver slots uses) is exercised here by forcing it."""
+    from mpc_planner_amd import scenes
+    import test_gpu_parity as T
+    sc = T._make_infeasible(scenes.make_scene(7, N=20, M=8, B=64), [9, 33])
+    s = _forced_compact(64, N=20, S=5, n_lin=8, M=8, qp_iter_max=6)
+    assert "fast one-wave variant" not in s.kernel_info()
+    s.set_batch(sc["xinit"], sc["x0"], sc["params"]); s.solve(); ref = s.get()
+    assert (ref["sqp_iter"] < 10).any() and (ref["exit_code"] != 1).any()
+    s.set_batch(sc["xinit"], sc["x0"], sc["params"])
+    s.solve_iterations(1, complete=False)
+    for i in range(9):
+        s.solve_iterations(1, keep_iterate=True, keep_multipliers=True, complete=(i == 8))
+    g = s.get()
+    for k in ("xtraj", "utraj", "pobj", "exit_code", "qp_status", "res_eq"):
+        np.testing.assert_array_equal(g[k], ref[k], err_msg=k)
+    s.close()
+
+
+@pytest.mark.parametrize("N", [20, 30])
+def test_param_sharing_hint_on_the_compact_kernels(N):
+    """tmpc_set_param_sharing on the compact kernels (one-wave N = 20, two-wave N = 30), forced for a two-set launch: bitwise neutral."""
+    from mpc_planner_amd import scenes, solver as S
+    b = scenes.make_batch(range(60, 62), N=N, M=8, B=64)
+    s = _forced_compact(128, N=N, S=5, n_lin=8, M=8)
+    base = S.param_sharing_map(b["params"], s.dims, 64)
+    assert (base != np.arange(128)).sum() == 126
+    s.set_batch(b["xinit"], b["x0"], b["params"]); s.solve(); ref = s.get()
+    s.set_param_sharing(base); s.solve(); got = s.get()
+    for k in FIELDS:
+        np.testing.assert_array_equal(got[k], ref[k], err_msg=k)
+    assert (ref["exit_code"] == 1).mean() > 0.9
+    s.close()
