@@ -88,6 +88,11 @@ void tmpc_default_dims_ex(tmpc_dims *d, int32_t N, int32_t S, int32_t n_lin, int
 /* Replaces Solver_acados_create_capsule + Solver_acados_create_with_discretization
  * (acados_solver_interface.cpp:17,33) for B_max solver instances at once.  Owns device buffers + stream. */
 int tmpc_create(tmpc_handle **out, const tmpc_dims *dims, int32_t B_max, int32_t device);
+/* Same, for callers that may have been built against another revision of this header: `dims_size` = the caller's sizeof(tmpc_dims).  Fields
+ * the caller's struct does not have (it is shorter: cost_model / row_model were appended in round 4) take their defaults (0) instead of being
+ * read from whatever follows the caller's struct; a longer struct is truncated (fields this library does not know are ignored).  New code
+ * should call this one: tmpc_create(out, dims, ..) == tmpc_create_v2(out, dims, sizeof(tmpc_dims), ..) of the SAME header revision. */
+int tmpc_create_v2(tmpc_handle **out, const tmpc_dims *dims, uint32_t dims_size, int32_t B_max, int32_t device);
 /* Replaces Solver_acados_free + Solver_acados_free_capsule (:54,60). */
 void tmpc_destroy(tmpc_handle *h);
 const char *tmpc_last_error(const tmpc_handle *h);
@@ -150,6 +155,13 @@ int tmpc_set_slots(tmpc_handle *h, const int32_t *slots);
  * touch the entries' own rows only and keep it valid).  Ignored by the lane kernels
  * (tmpc_set_throughput_mode) and by generated solvers. */
 int tmpc_set_param_sharing(tmpc_handle *h, const int32_t *base_of);
+/* The "copies are not maintained" mode, made explicit (round-4 advisor): with TMPC_SHARE_COPIES_NOT_MAINTAINED the caller declares that the
+ * shared columns of entries b != base_of[b] hold NO valid data.  From then on every path that would read them is an error instead of a silent
+ * fallback: tmpc_solve / tmpc_solve_iterations return TMPC_ERR_INVALID while the map is not in force for the current batch (every tmpc_set_batch*
+ * drops it: give it again), tmpc_set_throughput_mode (lane kernels) and tmpc_debug_profile (profiled twins) refuse, and generated solvers refuse
+ * the flag itself.  Cleared by a NULL map.  flags = 0: tmpc_set_param_sharing (a pure hint, copies equal). */
+#define TMPC_SHARE_COPIES_NOT_MAINTAINED 1
+int tmpc_set_param_sharing_ex(tmpc_handle *h, const int32_t *base_of, int32_t flags);
 /* Copy the persistent state of min(B_max) slots from another handle of the same shape and device (a caller that outgrew its handle). */
 int tmpc_copy_state(tmpc_handle *dst, tmpc_handle *src);
 /* Forget the persistent state of ONE slot: its next tmpc_solve_iterations starts like a fresh capsule whatever the keep-flags say
@@ -168,6 +180,11 @@ int tmpc_reset_multipliers(tmpc_handle *h);
  * ~1e-6 on ill-conditioned late iterations (each is that far from an exact solve), trajectories agree within the 1e-4 parity
  * tolerance, and the interior-point iteration count of a solve can differ by one where a residual sits at the tolerance. */
 int tmpc_set_latency_mode(tmpc_handle *h, int32_t on);
+/* How many trajectories ONE launch of kernel variant `mode` (0, 1, 2 as above) holds resident on this device (workgroups per CU x CUs), 0 if the
+ * handle's shape has no such variant, < 0 on error.  A latency variant pays off while the launch fits (one dependent chain deep); above it the
+ * throughput kernels win.  The library never switches variants by batch size (results would depend on the rest of the batch): the CALLER decides,
+ * e.g. the C++ BatchContext (cpp/src/solver_interface.cpp) asks for the tick variant only for batches within this capacity. */
+int tmpc_latency_mode_capacity(tmpc_handle *h, int32_t mode);
 /* Throughput variant for large batches (many control ticks / scenario solvers per launch): one LANE per trajectory instead of
  * one wavefront -- every lane runs the scalar SQP_RTI program on its own trajectory, the per-trajectory state is streamed from a
  * lane-major HBM workspace (allocated for B_max trajectories on the first call: about 8 (N+1) (175 + 6 nh) + 8 N npar bytes

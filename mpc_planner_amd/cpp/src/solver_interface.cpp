@@ -20,16 +20,33 @@
 
 namespace MPCPlanner
 {
-    /* Kernel variant of a control tick (tmpc_set_latency_mode).  Default (round 4): 2 = the interior-point Newton systems solved parallel in
-     * time (about 30 % less kernel time per tick; exit codes and iteration counts equal to the oracle's on every set tried, steps equal to
-     * ~1e-6, see include/tmpc_hip.h; shapes without that variant run variant 1).  MPC_PLANNER_HIP_TICK_VARIANT=1 opts out: two waves per
-     * trajectory with the same stage-by-stage Riccati recursion as acados / HPIPM (rounding-equal to the throughput kernels); =0 the
-     * throughput kernels themselves. */
+    /* Kernel variant of a control tick (tmpc_set_latency_mode).  A tick of a few planners is one dependent chain deep, and for that the
+     * latency variants are built: 2 = the interior-point Newton systems solved parallel in time (about 30 % less kernel time per tick; exit
+     * codes and iteration counts equal to the oracle's on every set tried, steps equal to ~1e-6, see include/tmpc_hip.h), 1 = two waves per
+     * trajectory with the same stage-by-stage Riccati recursion as acados / HPIPM (rounding-equal to the throughput kernels), 0 = the
+     * throughput kernels themselves.  MPC_PLANNER_HIP_TICK_VARIANT picks one (default 2).  The variant is asked for ONLY while the batch fits
+     * the variant's resident set (tmpc_latency_mode_capacity: one workgroup per CU for variant 2): a larger solveBatch() runs on the throughput
+     * kernels (round-4 advisor: variant 2 for every batch size was a throughput regression for large batches).  The rule looks at the batch
+     * size the CALLER handed over, so it is the caller's choice, not the library's: a given batch always gets the same kernels. */
     static int tickKernelVariant()
     {
         const char *v = std::getenv("MPC_PLANNER_HIP_TICK_VARIANT");
         if (v && (v[0] == '0' || v[0] == '1' || v[0] == '2') && v[1] == '\0') return v[0] - '0';
         return 2;
+    }
+    static void applyTickVariant(tmpc_handle *h, int batch)
+    {
+        int want = tickKernelVariant();
+        if (want != 0) {
+            const int cap = tmpc_latency_mode_capacity(h, want);
+            if (cap <= 0 || batch > cap) want = (want == 2 && tmpc_latency_mode_capacity(h, 1) >= batch) ? 1 : 0;
+        }
+        const int rc = tmpc_set_latency_mode(h, want);
+        static bool told = false;
+        if (rc == 1 && !told) {                          // accepted, but this shape has no such variant: say so once instead of dropping the return value
+            std::fprintf(stderr, "mpc_planner_solver (HIP): kernel variant %d is not available for this solver's shape; the library's fallback runs\n", want);
+            told = true;
+        } else if (rc < 0) { std::fprintf(stderr, "tmpc_set_latency_mode: %s\n", tmpc_last_error(h)); std::exit(1); }
     }
 
     static std::string g_config_dir = "config";
@@ -165,7 +182,7 @@ namespace MPCPlanner
             std::printf("tmpc_create() returned status %d (no MI355X / library not built). Exiting.\n", status);
             std::exit(1);
         }
-        tmpc_set_latency_mode(_handle, tickKernelVariant());   // a Solver serves control ticks of a few planners: latency variant
+        applyTickVariant(_handle, 1);                   // a Solver serves control ticks of a few planners: latency variant
         tmpc_enable_timing(_handle, 4);                 // HIP events around every launch -> _info.elapsed_time / solvetime / min_time
     }
 
@@ -290,7 +307,6 @@ namespace MPCPlanner
         applyModelBounds(d, s0->_model_map);
         tmpc_handle *h = nullptr;
         if (tmpc_create(&h, &d, cap, s0->_device)) { std::printf("tmpc_create() failed. Exiting.\n"); std::exit(1); }
-        tmpc_set_latency_mode(h, tickKernelVariant());  // same variant as solve(): solve() and solveBatch() stay bitwise equal
         tmpc_enable_timing(h, 4);
         if (_handle) {
             if (!settings_changed && tmpc_copy_state(h, _handle)) { std::fprintf(stderr, "tmpc_copy_state: %s\n", tmpc_last_error(h)); std::exit(1); }
@@ -343,6 +359,7 @@ namespace MPCPlanner
         // loses them after a failed solve); GuidanceConstraints::optimize loads every planner's warm start (:337), so the iterate comes
         // from x0.  A new solve() of every Solver: loop exits of the previous tick do not carry over.
         float ms[4] = {0.f, 0.f, 0.f, 0.f}; int32_t n_ms = 0;
+        applyTickVariant(_handle, B);                   // same variant as solve() while the batch is a tick (bitwise equal to it); throughput kernels above
         if (tmpc_set_batch(_handle, B, xinit.data(), x0.data(), par.data()) || tmpc_set_slots(_handle, slots.data()) ||
             tmpc_solve_iterations(_handle, s0->_num_iterations, TMPC_ITER_KEEP_MULTIPLIERS | TMPC_ITER_COMPLETE | TMPC_ITER_NEW_SOLVE) ||
             tmpc_get(_handle, xt.data(), ut.data(), pobj.data(), ec.data(), qs.data(), si.data(), res.data(), qi.data()) ||

@@ -219,6 +219,7 @@ struct tmpc_handle {
     int slots_B = 0;                 // batch size the slot map was given for: a map of another size is refused, never read past its end
     int *d_share = nullptr;          // [B_max] tmpc_set_param_sharing
     int share_B = 0;                 // batch size the sharing map was given for (0: none)
+    bool share_strict = false;       // tmpc_set_param_sharing_ex(.., TMPC_SHARE_COPIES_NOT_MAINTAINED): a solve that cannot honour the map is an error
     bool st_valid = false;           // lane kernels (state = their workspace, per launch): it holds the result of a previous call ...
     int st_B = 0;                    // ... for slots [0, st_B)
     // SH-MPC bookkeeping: the sample behind each scenario row of the last tmpc_scenario_halfspaces (i32 [B][N][scn_rows])
@@ -276,6 +277,17 @@ void tmpc_default_dims_ex(tmpc_dims *d, int32_t N, int32_t S, int32_t n_lin, int
     const double lb[TMPC_NV] = {-2.0, -0.8, -2000.0, -2000.0, -M_PI * 4, -0.01, -1.0};
     const double ub[TMPC_NV] = {2.0, 0.8, 2000.0, 2000.0, M_PI * 4, 3.0, 10000.0};
     for (int i = 0; i < TMPC_NV; i++) { d->lb[i] = lb[i]; d->ub[i] = ub[i]; }
+}
+
+int tmpc_create_v2(tmpc_handle **out, const tmpc_dims *dims_in, uint32_t dims_size, int32_t B_max, int32_t device)
+{
+    // a caller built against an older header passes a SHORTER struct: the fields it does not know are the defaults (0), never garbage
+    constexpr uint32_t kMinSize = offsetof(tmpc_dims, cost_model);           // the struct as it was before cost_model / row_model were added
+    if (!out || !dims_in || dims_size < kMinSize || dims_size > 4096) return TMPC_ERR_INVALID;
+    tmpc_dims d;
+    memset(&d, 0, sizeof d);
+    memcpy(&d, dims_in, dims_size < sizeof d ? dims_size : sizeof d);
+    return tmpc_create(out, &d, B_max, device);
 }
 
 int tmpc_create(tmpc_handle **out, const tmpc_dims *dims, int32_t B_max, int32_t device)
@@ -483,6 +495,17 @@ static int launch_solve(tmpc_handle *h, int n_iter, int st_flags)
     return TMPC_OK;
 }
 
+// A caller that declared "the copies are not maintained" must never reach a kernel that reads them: the map has to be in force for the
+// CURRENT batch (tmpc_set_batch* drops it) and the kernel family has to honour it.
+static int share_check(tmpc_handle *h, const char *who)
+{
+    if (!h->share_strict) return TMPC_OK;
+    if (h->share_B != h->B) { h->err = std::string(who) + ": the parameter-sharing map was declared with TMPC_SHARE_COPIES_NOT_MAINTAINED but is not in force for the "
+                                       "current batch (tmpc_set_batch* drops it: give it again, or clear it with a null map)"; return TMPC_ERR_INVALID; }
+    if (h->throughput_mode) { h->err = std::string(who) + ": the lane kernels read every entry's own parameter rows, the map says they are not maintained"; return TMPC_ERR_INVALID; }
+    return TMPC_OK;
+}
+
 // the slots' persistent state no longer describes what the handle last solved
 static int invalidate_state(tmpc_handle *h)
 {
@@ -494,6 +517,7 @@ static int invalidate_state(tmpc_handle *h)
 int tmpc_solve(tmpc_handle *h)
 {
     if (!h || h->B <= 0 || !h->xinit) { if (h) h->err = "tmpc_solve: no batch set"; return TMPC_ERR_INVALID; }
+    if (int rc = share_check(h, "tmpc_solve")) return rc;
     TMPC_HIP_CHECK(h, hipSetDevice(h->device));
     if (int rc = invalidate_state(h)) return rc;
     return launch_solve(h, h->d.n_sqp, 0);
@@ -502,6 +526,7 @@ int tmpc_solve(tmpc_handle *h)
 int tmpc_solve_iterations(tmpc_handle *h, int32_t n_iter, int32_t flags)
 {
     if (!h || h->B <= 0 || !h->xinit || n_iter < 0 || (flags & ~15)) { if (h) h->err = "tmpc_solve_iterations: no batch set / bad argument"; return TMPC_ERR_INVALID; }
+    if (int rc = share_check(h, "tmpc_solve_iterations")) return rc;
     TMPC_HIP_CHECK(h, hipSetDevice(h->device));
     if (h->throughput_mode && h->slots_set) { h->err = "tmpc_solve_iterations: slot maps (tmpc_set_slots) are not available with the lane kernels"; return TMPC_ERR_INVALID; }
     if (h->slots_set && h->slots_B != h->B) {
@@ -569,6 +594,24 @@ int tmpc_set_latency_mode(tmpc_handle *h, int32_t on)
     return (on == 1 && !h->kernel_lat) ? 1 : TMPC_OK;
 }
 
+int tmpc_latency_mode_capacity(tmpc_handle *h, int32_t mode)
+{
+    if (!h || mode < 0 || mode > 2) return TMPC_ERR_INVALID;
+    if (hipSetDevice(h->device) != hipSuccess) return TMPC_ERR_HIP;
+    const void *k = nullptr; int threads = 64; size_t lds = 0;
+    if (mode == 2) { if (!h->kernel_scan) return 0; k = (const void *)h->kernel_scan; threads = h->scan_threads; lds = h->lds_bytes_scan; }
+    else if (mode == 1) { if (!h->kernel_lat) return 0; k = (const void *)h->kernel_lat; threads = 128; lds = h->lds_bytes_fast2; }
+    else {
+        // the throughput kernels of the handle: the resident set of the persistent (compact) launch, or of the plain kernel
+        if (h->compact || h->kernel_cp2) return h->grid_max;
+        k = (const void *)h->kernel; threads = h->threads; lds = h->lds_bytes;
+    }
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, threads, lds) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess) { h->err = "tmpc_latency_mode_capacity: occupancy query failed"; return TMPC_ERR_HIP; }
+    return per_cu * cus;
+}
+
 int tmpc_set_slots(tmpc_handle *h, const int32_t *slots)
 {
     if (!h) return TMPC_ERR_INVALID;
@@ -587,16 +630,21 @@ int tmpc_set_slots(tmpc_handle *h, const int32_t *slots)
     return TMPC_OK;
 }
 
-int tmpc_set_param_sharing(tmpc_handle *h, const int32_t *base_of)
+int tmpc_set_param_sharing(tmpc_handle *h, const int32_t *base_of) { return tmpc_set_param_sharing_ex(h, base_of, 0); }
+
+int tmpc_set_param_sharing_ex(tmpc_handle *h, const int32_t *base_of, int32_t flags)
 {
-    if (!h) return TMPC_ERR_INVALID;
-    if (!base_of) { h->share_B = 0; return TMPC_OK; }
+    if (!h || (flags & ~TMPC_SHARE_COPIES_NOT_MAINTAINED)) return TMPC_ERR_INVALID;
+    if (!base_of) { h->share_B = 0; h->share_strict = false; return TMPC_OK; }
 #ifdef TMPC_GENERATED_STAGE
     // generated stage functions read every parameter -- halfspace rows included -- from ONE row block (tmpc_gen::rows has no notion of
-    // "own" rows), so the hint cannot be honoured: it is accepted and ignored, as include/tmpc_hip.h says
+    // "own" rows), so the hint cannot be honoured: as a pure hint it is accepted and ignored, as include/tmpc_hip.h says; a caller that
+    // does not maintain the copies is refused
+    if (flags & TMPC_SHARE_COPIES_NOT_MAINTAINED) { h->err = "tmpc_set_param_sharing_ex: generated solvers read every entry's own rows (copies must be maintained)"; return TMPC_ERR_INVALID; }
     h->share_B = 0;
     return TMPC_OK;
 #endif
+    if ((flags & TMPC_SHARE_COPIES_NOT_MAINTAINED) && h->throughput_mode) { h->err = "tmpc_set_param_sharing_ex: the lane kernels read every entry's own rows (copies must be maintained)"; return TMPC_ERR_INVALID; }
     if (h->B <= 0) { h->err = "tmpc_set_param_sharing: set the batch first (the map has one entry per batch entry)"; return TMPC_ERR_INVALID; }
     for (int b = 0; b < h->B; b++)
         if (base_of[b] < 0 || base_of[b] >= h->B) { h->err = "tmpc_set_param_sharing: entries must be batch indices in [0, B)"; return TMPC_ERR_INVALID; }
@@ -605,6 +653,7 @@ int tmpc_set_param_sharing(tmpc_handle *h, const int32_t *base_of)
     TMPC_HIP_CHECK(h, hipMemcpyAsync(h->d_share, base_of, (size_t)h->B * 4, hipMemcpyHostToDevice, h->stream));
     TMPC_HIP_CHECK(h, hipStreamSynchronize(h->stream));            // (the caller's array may go away)
     h->share_B = h->B;
+    h->share_strict = (flags & TMPC_SHARE_COPIES_NOT_MAINTAINED) != 0;
     return TMPC_OK;
 }
 
@@ -612,7 +661,8 @@ int tmpc_copy_state(tmpc_handle *dst, tmpc_handle *src)
 {
     if (!dst || !src || dst == src) return TMPC_ERR_INVALID;
     const tmpc::Dims &a = dst->d, &b = src->d;
-    if (a.N != b.N || a.n_up != b.n_up || a.M != b.M || dst->device != src->device || dst->throughput_mode || src->throughput_mode) {
+    if (a.N != b.N || a.n_up != b.n_up || a.M != b.M || a.npar != b.npar || a.slack != b.slack || a.cost_model != b.cost_model || a.row_model != b.row_model ||
+        dst->device != src->device || dst->throughput_mode || src->throughput_mode) {
         dst->err = "tmpc_copy_state: handles of different shape / device / kernel family"; return TMPC_ERR_INVALID;
     }
     if (!src->st_z) return TMPC_OK;                                 // nothing stored yet
@@ -651,6 +701,7 @@ int tmpc_set_throughput_mode(tmpc_handle *h, int32_t on)
 {
     if (!h) return TMPC_ERR_INVALID;
     if (on && tmpc::stage_model(h->d) != 0) { h->err = "tmpc_set_throughput_mode: the lane kernels have the MPCC contouring cost and ellipsoid rows only"; return TMPC_ERR_INVALID; }
+    if (on && h->share_strict) { h->err = "tmpc_set_throughput_mode: a parameter-sharing map with TMPC_SHARE_COPIES_NOT_MAINTAINED is registered and the lane kernels read every entry's own rows"; return TMPC_ERR_INVALID; }
     if (on && !h->lanes) {
         TMPC_HIP_CHECK(h, hipSetDevice(h->device));
         h->lanes = tmpc::lanes::create(h->d, h->B_max, h->err);
@@ -1008,6 +1059,7 @@ int tmpc_debug_get_params(tmpc_handle *h, double *params)
 int tmpc_debug_profile(tmpc_handle *h, int64_t *cycles, int32_t n_phases)
 {
     if (!h || h->B <= 0 || !cycles || n_phases < tmpc::PH_COUNT) return TMPC_ERR_INVALID;
+    if (h->share_strict) { h->err = "tmpc_debug_profile: the profiled twins read every entry's own parameter rows; a map with TMPC_SHARE_COPIES_NOT_MAINTAINED is registered"; return TMPC_ERR_INVALID; }
     TMPC_HIP_CHECK(h, hipSetDevice(h->device));
     DevBufs bufs;
     double *dp_ = nullptr;

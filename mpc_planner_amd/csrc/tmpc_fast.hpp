@@ -295,7 +295,11 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
         if constexpr (K == 0) return c0 * x + c1 * y + c2 * pp;
         else if constexpr (K == 1) {
             // box slot of a tuned shape: q = r - NH, variable q >> 1, side q & 1: +-w[var] by flipping the sign bit (exactly (+-1.0) * w[var])
-            const int q = c + LPS * s - C::NH;
+            // the LAST slot of a tuned shape can run past the stage's rows (r >= NR on its upper sub-lanes: q >> 1 would be NV, the next node's
+            // first entry): the index is clamped there -- one v_min on that one slot -- so that nothing outside the stage is read even though
+            // every consumer masks such a row with ACT() (invariant: a value returned for a row with ACT() == false is never used unmasked)
+            int q = c + LPS * s - C::NH;
+            if constexpr (LPS * s + LPS - 1 >= C::NR) q = q < 2 * NV - 1 ? q : 2 * NV - 1;
             const unsigned long long u = __builtin_bit_cast(unsigned long long, vec[q >> 1]) ^ ((unsigned long long)((unsigned)q << 31) << 32);
             return __builtin_bit_cast(double, u);
         }

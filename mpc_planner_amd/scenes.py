@@ -149,11 +149,16 @@ MIXTURE_WEIGHTS = (0.5, 0.25, 0.25)
 
 
 def make_scene(scene_idx, N=20, M=8, B=64, S=5, tmpc_pp=False, gaussian=False, guidance=True, slack=False,
-               n_decomp=0, n_scenario=0, n_samples=256, chance=False):
+               n_decomp=0, n_scenario=0, n_samples=256, chance=False, inside_share=0.0):
     """Returns dict(xinit [Bt][nx], x0 [Bt][N+1][nv], params [Bt][N][npar], pm, guidance_id [Bt]); nx = 5, nv = 7, or
     6 / 8 with the slack model.  n_scenario > 0 builds the SH-MPC problem (cfg 5): no ellipsoid / topology rows, 24
-    scenario halfspaces per stage from M obstacles x n_samples scenarios, one set per guidance trajectory."""
+    scenario halfspaces per stage from M obstacles x n_samples scenarios, one set per guidance trajectory.
+    inside_share > 0 (round-4 verdict, next-8): that share of the guidance trajectories (own seeded stream: the rest of the scene is bitwise
+    what inside_share = 0 gives) gets ONE guidance point moved INSIDE the disc of radius 1e-3 + robot_radius around the nearest obstacle
+    prediction -- what a guidance path computed on the previous tick's predictions looks like -- so that LinearizedConstraints::projectToSafety
+    (linearized_constraints.cpp:130-148) is NOT the identity there; `inside` [Bt] marks them, `inside_at` [Bt][2] = (stage, obstacle) or (-1, -1)."""
     rng = np.random.Generator(np.random.PCG64(1000 + scene_idx))
+    rng_in = np.random.Generator(np.random.PCG64(770000 + scene_idx))
     ellipsoids = n_scenario == 0 and not chance         # chance: GaussianConstraintModule instead of the ellipsoids (jackal default)
     if chance:
         gaussian = True
@@ -222,6 +227,7 @@ def make_scene(scene_idx, N=20, M=8, B=64, S=5, tmpc_pp=False, gaussian=False, g
     x0 = np.zeros((Bt, N + 1, nv)); params = np.zeros((Bt, N, npar))
     guidance_id = np.zeros(Bt, np.int32)
     guidance_pos = np.zeros((B, N + 1, 2)); guidance_vel = np.zeros((B, N + 1, 2))        # what the guidance planner hands over
+    inside = np.zeros(Bt, bool); inside_at = np.full((Bt, 2), -1, np.int32)
     T = N * DT; t = np.arange(N + 1) * DT
     v_ref = WEIGHTS["reference_velocity"]
     amps = np.linspace(-A_MAX, A_MAX, B) + rng.normal(0.0, 0.05, B) if B > 1 else np.array([rng.normal(0.0, 0.5)])
@@ -296,6 +302,14 @@ def make_scene(scene_idx, N=20, M=8, B=64, S=5, tmpc_pp=False, gaussian=False, g
                     if dist[j] >= r_s:
                         break
                     gpos[k] = cloud[j] + (dvec[j] / dist[j] if dist[j] > 1e-12 else np.array([0.0, 1.0])) * (r_s * 1.001)
+        if inside_share > 0.0 and guidance and samples is None and rng_in.uniform() < inside_share:
+            k_in = int(rng_in.integers(2, N - 1))                        # a stage whose row is built from prediction step k_in - 1
+            dist_k = np.hypot(*(gpos[k_in][None, :] - obs["pos"][:, k_in - 1]).T)
+            j_in = int(np.argmin(dist_k))
+            o = obs["pos"][j_in, k_in - 1]
+            ang = np.arctan2(gpos[k_in][1] - o[1], gpos[k_in][0] - o[0]) + rng_in.uniform(-0.6, 0.6)
+            gpos[k_in] = o + rng_in.uniform(0.2, 0.9) * (1e-3 + ROBOT_RADIUS) * np.array([np.cos(ang), np.sin(ang)])
+            inside[b] = True; inside_at[b] = (k_in, j_in)
         guidance_pos[b] = gpos; guidance_vel[b] = gvel
         x0[b] = md.initialize_solver_with_guidance(main_x0.copy(), gpos, gvel)
         params[b] = base
@@ -313,7 +327,8 @@ def make_scene(scene_idx, N=20, M=8, B=64, S=5, tmpc_pp=False, gaussian=False, g
         guidance_id[B] = 2 * B                                              # guidance_constraints.cpp:349
     return dict(xinit=xinit, x0=x0, params=params, pm=pm, guidance_id=guidance_id, obstacles=obs,
                 segments=segs, N=N, M=(M if ellipsoids else 0), S=S, n_lin=(M if guidance else 0), n_gauss=(M if chance else 0),
-                n_slk=n_scenario + n_decomp, slack=int(slack), samples=samples, guidance_pos=guidance_pos, guidance_vel=guidance_vel)
+                n_slk=n_scenario + n_decomp, slack=int(slack), samples=samples, guidance_pos=guidance_pos, guidance_vel=guidance_vel,
+                inside=inside, inside_at=inside_at)
 
 
 def _make_scene_kw(args):
@@ -332,7 +347,7 @@ def make_batch(scene_indices, workers=1, **kw):
     else:
         scenes = [make_scene(i, **kw) for i in scene_indices]
     out = dict(scenes[0])
-    for key in ("xinit", "x0", "params", "guidance_id"):
+    for key in ("xinit", "x0", "params", "guidance_id", "inside", "inside_at"):
         out[key] = np.concatenate([s[key] for s in scenes], 0)
     out["scene_of"] = np.concatenate([np.full(len(s["xinit"]), i, np.int32) for i, s in enumerate(scenes)])
     # what a control tick hands over per scene / per trajectory (the end-to-end step of bench.py uploads exactly these):

@@ -42,7 +42,8 @@ EXPORTS = ["tmpc_default_dims", "tmpc_default_dims_ex", "tmpc_create", "tmpc_des
            "tmpc_linearize_topology", "tmpc_scenario_halfspaces", "tmpc_scenario_support", "tmpc_warmstart", "tmpc_init_with_guidance",
            "tmpc_debug_get_x0", "tmpc_debug_get_params", "tmpc_set_throughput_mode", "tmpc_solve_iterations",
            "tmpc_reset_multipliers", "tmpc_get_stream", "tmpc_kernel_info", "tmpc_set_slots", "tmpc_set_param_sharing", "tmpc_copy_state", "tmpc_scenario_empty_stages", "tmpc_sample_scenarios",
-           "tmpc_scenario_discard", "tmpc_scenario_discarded", "tmpc_linearize_topology_ex", "tmpc_clear_slot", "tmpc_gather_best"]
+           "tmpc_scenario_discard", "tmpc_scenario_discarded", "tmpc_linearize_topology_ex", "tmpc_clear_slot", "tmpc_gather_best",
+           "tmpc_create_v2", "tmpc_set_param_sharing_ex", "tmpc_latency_mode_capacity"]
 
 class TmpcError(RuntimeError):
     pass
@@ -89,6 +90,10 @@ def load_library(path=None):
         lib.tmpc_set_slots.argtypes = [vp, vp]
     if hasattr(lib, "tmpc_set_param_sharing"):
         lib.tmpc_set_param_sharing.argtypes = [vp, vp]
+    if hasattr(lib, "tmpc_set_param_sharing_ex"):
+        lib.tmpc_set_param_sharing_ex.argtypes = [vp, vp, C.c_int32]
+        lib.tmpc_latency_mode_capacity.argtypes = [vp, C.c_int32]
+        lib.tmpc_create_v2.argtypes = [C.POINTER(C.c_void_p), C.POINTER(TmpcDims), C.c_uint32, C.c_int32, C.c_int32]
     if hasattr(lib, "tmpc_scenario_empty_stages"):        # (absent from reference builds of earlier rounds used in A/B runs)
         lib.tmpc_scenario_empty_stages.argtypes = [vp, vp]
     if hasattr(lib, "tmpc_sample_scenarios"):        # (absent from reference builds of earlier rounds used in A/B runs)
@@ -251,15 +256,24 @@ class BatchedSolver:
         assert a.size == self.B
         self._check(self.lib.tmpc_set_slots(self._h, a.ctypes.data_as(C.c_void_p)), "tmpc_set_slots")
 
-    def set_param_sharing(self, base_of):
+    def set_param_sharing(self, base_of, copies_not_maintained=False):
         """Hint (tmpc_set_param_sharing): entry b's parameter rows equal entry base_of[b]'s except for its own topology / scenario
-        halfspace rows; the kernels read the rest from base_of[b] (same results, 1/64 of a guidance set's parameter traffic).  None clears."""
+        halfspace rows; the kernels read the rest from base_of[b] (same results, 1/64 of a guidance set's parameter traffic).  None clears.
+        copies_not_maintained (tmpc_set_param_sharing_ex, TMPC_SHARE_COPIES_NOT_MAINTAINED): the caller writes a set's shared rows into the base
+        entry only; every path that would read the other entries' copies then fails instead of falling back."""
         if base_of is None:
             self._check(self.lib.tmpc_set_param_sharing(self._h, None), "tmpc_set_param_sharing")
             return
         a = np.ascontiguousarray(base_of, np.int32)
         assert a.size == self.B
-        self._check(self.lib.tmpc_set_param_sharing(self._h, a.ctypes.data_as(C.c_void_p)), "tmpc_set_param_sharing")
+        self._check(self.lib.tmpc_set_param_sharing_ex(self._h, a.ctypes.data_as(C.c_void_p), 1 if copies_not_maintained else 0), "tmpc_set_param_sharing_ex")
+
+    def latency_mode_capacity(self, mode):
+        """Trajectories one launch of kernel variant `mode` holds resident on this device (tmpc_latency_mode_capacity); 0: no such variant."""
+        rc = self.lib.tmpc_latency_mode_capacity(self._h, int(mode))
+        if rc < 0:
+            self._check(rc, "tmpc_latency_mode_capacity")
+        return rc
 
     def clear_slot(self, slot):
         """Forget one slot's persistent state (tmpc_clear_slot): the slot's next solve_iterations starts like a fresh capsule."""

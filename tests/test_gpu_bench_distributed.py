@@ -37,3 +37,18 @@ def test_bench_under_torch_distributed_world_size_one(workload, extra):
     assert p["exit_code_mismatch"] == 0 and p["sqp_iter_mismatch"] == 0 and p["ipm_iter_mismatch"] == 0 and p["parity_max_rel"] < 1e-4
     assert "all-gather" in d["config"]["parallelism"] or d["n_gpus"] == 1
     assert all(b >= -1 for b in d["best_index_sample"])
+
+
+def test_plain_command_n1():
+    """The driver's own form, `python bench.py --gpus 1 ...` (no torch.distributed environment), and the same form's N > 1 branch up to the
+    point where it would need a second GPU: the launcher command it builds (tests/test_bench_launcher.py runs that command at N = 2 on CPU)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--scenes", "16", "--no-cpu-baseline",
+           "--latency-reps", "0", "--no-tight", "--no-end-to-end", "--parity-check", "64", "--index-check-sets", "16"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["roofline"]["bound"] == "fp64_valu"
+    assert d["parity"]["exit_code_mismatch"] == 0 and d["parity"]["best_index"]["true_mismatches"] == 0
