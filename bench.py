@@ -664,7 +664,11 @@ def main():
         if a.parity_check > 0:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_lib as O
-            tight["parity"] = parity_block(O, wl, batch, r9, min(a.parity_check, 128), {"qp_tol": 1e-9})
+            # at this tolerance the interior-point method runs into the conditioning of the barrier systems and the FORM of the Riccati recursion
+            # decides a few outcomes (profiles/round5_riccati_form_study.json): the oracle runs the kernels' form here (riccati_form 1: the elimination
+            # stops after the input block); the default-tolerance parity block above is against the oracle's default, the square-root form
+            tight["parity"] = parity_block(O, wl, batch, r9, min(a.parity_check, 128), {"qp_tol": 1e-9, "riccati_form": 1})
+            tight["parity"]["against"] += " (oracle option riccati_form = 1: the same recursion form as the kernels)"
 
     # ---- end to end: per-tick inputs uploaded every step, x0 / halfspace rows built on device, winners copied back ----------
     e2e = None

@@ -73,6 +73,7 @@ namespace MPCPlanner
     class Solver
     {
     public:
+        enum class StageIndexing;
         struct AcadosInfo              /* :96-125 */
         {
             double min_time, kkt_norm_inf, elapsed_time;
@@ -103,6 +104,7 @@ namespace MPCPlanner
         std::vector<BatchContext *> _contexts;  // contexts this Solver owns a slot of: ~Solver releases the slots (a new Solver at the same
                                                 // address must not inherit this one's multipliers)
         double _iteration_time_estimate{0.};
+        StageIndexing _stage_indexing{StageIndexing::AcadosNodes};
         void ensureHandle();
         int runIterations(int n, bool complete);
 
@@ -164,6 +166,17 @@ namespace MPCPlanner
          * stage vector z_k = [u_k; x_k] of stage k = 0 .. N-1 -- the Forces flavour has N stages x01 .. xN, the acados flavour N + 1
          * nodes): callers written against the Forces interface index the same solution through this accessor. */
         double getForcesStyleOutput(int k, int index) const { return index < (int)nu ? _output.utraj[k * nu + index] : _output.xtraj[k * nx + index - nu]; }
+        /* Forces N-stage indexing as a MODE (forces_solver_interface.cpp:147-182, 241-244).  Callers written against the reference's
+         * Forces flavour see N stages z_0 .. z_{N-1} = [u_k; x_k] and nothing else: with the mode on, getOutput(k, name) accepts k in [0, N) only
+         * (the node N of this solver's horizon is not a Forces stage: asking for it is a caller error and aborts like an out-of-range Forces
+         * output would), stages() is N, and initializeWarmstart follows the Forces loops -- k < N, the terminal stage extrapolated from output
+         * N-1 (:159-160) resp. kept (:171-179) -- and fills this solver's extra node N with the same terminal value so that the horizon it
+         * actually solves stays defined.  The problem solved is unchanged (N intervals, ERK4 x 3, zero terminal cost: the acados flavour):
+         * this is an indexing / warm-start compatibility mode, not the Forces NLP (SURVEY Appendix D-1 lists what that would change). */
+        enum class StageIndexing { AcadosNodes, ForcesStages };
+        void setStageIndexing(StageIndexing mode) { _stage_indexing = mode; }
+        StageIndexing stageIndexing() const { return _stage_indexing; }
+        int stages() const { return _stage_indexing == StageIndexing::ForcesStages ? N : N + 1; }
         std::string explainExitFlag(int exitflag) const;
         void printIfBoundLimited() const;
     };

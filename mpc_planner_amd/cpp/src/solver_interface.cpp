@@ -418,6 +418,19 @@ namespace MPCPlanner
     }
     void Solver::initializeWarmstart(const State &initial_state, bool shift_previous_solution_forward)   // (:344-376)
     {
+        if (_stage_indexing == StageIndexing::ForcesStages) {
+            // forces_solver_interface.cpp:147-182: N stages; shifted: [state, x_2, ..., x_{N-1}, x_{N-1}], kept: [state, x_1, ..., x_{N-1}];
+            // this solver's node N (not a Forces stage) repeats the terminal stage
+            for (int k = 0; k < N; k++)
+                for (auto &e : _model_map) {
+                    std::string n = e.first;
+                    if (k == 0) setEgoPrediction(0, std::string(n), initial_state.get(std::string(n)));
+                    else if (!shift_previous_solution_forward || k == N - 1) setEgoPrediction(k, std::string(n), getOutput(k, std::string(n)));
+                    else setEgoPrediction(k, std::string(n), getOutput(k + 1, std::string(n)));
+                }
+            for (auto &e : _model_map) setEgoPrediction(N, std::string(e.first), getOutput(N - 1, std::string(e.first)));
+            return;
+        }
         if (shift_previous_solution_forward) {
             for (int k = 0; k <= N; k++)
                 for (auto &e : _model_map) {
@@ -432,8 +445,12 @@ namespace MPCPlanner
                 for (auto &e : _model_map) setEgoPrediction(k, std::string(e.first), getOutput(k, std::string(e.first)));
         }
     }
-    double Solver::getOutput(int k, std::string &&state_name) const      // (:379-389)
+    double Solver::getOutput(int k, std::string &&state_name) const      // (:379-389); Forces mode: forces_solver_interface.cpp:241-244
     {
+        if (_stage_indexing == StageIndexing::ForcesStages && (k < 0 || k >= N)) {
+            std::fprintf(stderr, "Solver::getOutput: stage %d requested, the Forces indexing has stages 0 .. %d\n", k, N - 1);
+            std::abort();
+        }
         const ModelEntry &m = _model_map.at(state_name);
         return m.type == "x" ? _output.xtraj[k * nx + m.index - nu] : _output.utraj[k * nu + m.index];
     }

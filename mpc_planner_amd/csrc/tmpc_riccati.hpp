@@ -19,19 +19,28 @@ __device__ unsigned long long g_sweep_prof[SP_COUNT];
 #define SWEEP_COUNT(i)
 #endif
 
-// ---- square-root Riccati: factorisation --------------------------------------------------------
-// Lane i (< 7) owns ROW i of the stage matrix F_k = Hh_k + G^T G (G = Lp^T [B A], Lp = trailing 5x5 of the
-// next stage's Cholesky factor) in registers f[0..i].  The 7x7 Cholesky runs entirely in registers: pivots
-// and column entries are broadcast with v_readlane, no LDS traffic and no barriers inside the factorisation.
+// ---- Riccati recursion: factorisation --------------------------------------------------------------
+// Lane i (< 7) owns ROW i of the stage matrix F_k = Hh_k + [B A]^T P_{k+1} [B A] in registers f[0..i].  The elimination runs entirely in
+// registers: pivots and column entries are broadcast inside the 16-lane row (v_mov_b64_dpp row_newbcast), no LDS traffic and no barriers.
+// Round 5: the elimination STOPS after the two input columns.  What is left in rows 2..6 is the Schur complement
+// P_k = F_xx - Lxu Lxu^T -- the cost-to-go Hessian itself --, and the next stage uses it as it is (w = P [B A]_.,i per lane, F_ij = Hh_ij +
+// sum_n w_n [B A]_nj) instead of re-factorising it into Lxx Lxx^T and forming G = Lxx^T [B A], F = Hh + G^T G (rounds 1-4: the square-root
+// form, 7 pivots per stage).  The first two column eliminations are THE SAME operations in both forms, so P_k is the same matrix; what goes
+// is the five state pivots (each: broadcast, v_rsq_f64 + Halley step, scale, column broadcasts, rank-1 update -- and v_rsq_f64 alone issues
+// for 16 cycles, profiles/round5_chain_floor.json) and the triangular products: 227 -> ~150 VALU instructions per stage, two pivots on
+// the chain instead of seven.  Numerics: tools/riccati_form_study.py ran both forms inside the oracle's interior-point method on the
+// bench scenes -- at the reference's qp_tol = 1e-5 no exit code, SQP or interior-point iteration count changes on 2560 trajectories and the
+// iterates agree to 4e-11 (the level of the kernels' rounding differences); profiles/round5_riccati_form_study.json.
 // In place of Hh_k the "factor block" (28 doubles) is written for the vector solves:
-//   [0..9]  Lxu (5x2, row-major)   [10] L10   [11] 1/L00   [12] 1/L11   [13..27] Lxx (packed lower 5x5; P_k = Lxx Lxx^T)
+//   [0..9]  Lxu (5x2, row-major)   [10] L10   [11] 1/L00   [12] 1/L11   [13..27] P_k (packed lower 5x5)
 constexpr int FB_LXU = 0, FB_L10 = 10, FB_R0 = 11, FB_R1 = 12, FB_P = 13;
 
-template <int C0>
+// right-looking elimination of columns C0 .. C1-1 of the row-per-lane matrix
+template <int C0, int C1 = NV>
 __device__ __forceinline__ bool chol_rows(double (&f)[NV], int lane, double *r0, double *r1)
 {
     bool bad = false;
-    static_for<C0, NV>([&](auto c_) {
+    static_for<C0, C1>([&](auto c_) {
         constexpr int c = decltype(c_)::value;
         const double dpiv = bcast16<c>(f[c]);
         if (!(dpiv > 0.0)) bad = true;
@@ -86,11 +95,11 @@ __device__ __forceinline__ BaLane ba_row4(int N, int i5)          // o0: base of
 // VEC (the register-row kernels): the PREDICTOR's right-hand side rides through the factorisation as an extra row.  Lane 7 of the row
 // holds the row [g_u g_x] of the bordered matrix [[F, g], [g^T, .]] (g = gh, the predictor right-hand side, complete before the
 // factorisation starts): it takes part in every column update like the rows below the pivot and never becomes a pivot, so after the
-// stage's Cholesky it is  l = [y0 y1 | lx] = [g_u g_x] L^-T  -- y is what the forward sweep needs, and lx carries the cost-to-go
-// gradient to the next stage (p_k = Lxx lx): there the row's "own column" is the dynamics residual rb and lx joins its G entries,
-// G_l,7 = (Lp^T rb)_l + lx_l, i.e. Lp G_.,7 = P rb + p.  The separate backward vector sweep of the predictor (and its stage-parallel
-// prologue P rb) disappear: one of the five sequential passes over the stages of an interior-point iteration.  Same algebra as the
-// separate sweep; the operations associate differently (rounding-level differences).
+// elimination of the two input columns it is  [y0 y1 | p_k]: y = Luu^-1 g_u is what the forward sweep needs, and the rest is the Schur
+// complement of the border, i.e. the cost-to-go gradient p_k itself.  At the next stage the row's "own column" is the dynamics residual rb
+// and p joins the product: w = P rb + p.  The separate backward vector sweep of the predictor (and its stage-parallel prologue P rb)
+// disappear: one of the five sequential passes over the stages of an interior-point iteration.  Same algebra as the separate sweep; the
+// operations associate differently (rounding-level differences).
 template <bool CP, bool VEC = false>
 __device__ __forceinline__ bool riccati_factor_rows(const Lds &L, const Dims &d, int li, bool wr)
 {
@@ -158,88 +167,62 @@ __device__ __forceinline__ bool riccati_factor_rows(const Lds &L, const Dims &d,
             }
         }
     };
-    // terminal node: Cholesky of the xx-block (rows/cols 2..6); the extra row starts as g_x of node N
+    // terminal node: P_N = the xx-block of Hh_N (rows/cols 2..6) as it is; the extra row starts as p_N = g_x of node N
 #pragma unroll
     for (int j = 0; j < NV; j++) f[j] = (j >= NU) ? (vec ? L.gh[N * NV + j] : L.Hh[N * NP28 + pidx(ls, j <= ls ? j : ls)]) : 0.0;
     seek_stage(N - 1);
     load_stage(N - 1, true);
-    bad |= chol_rows<NU>(f, li, nullptr, nullptr);
     if (vec && wr) {
 #pragma unroll
-        for (int l = 0; l < NX; l++) L.pr[N * NX + l] = f[NU + l];          // lx of node N
+        for (int l = 0; l < NX; l++) L.pr[N * NX + l] = f[NU + l];          // p_N
     }
     for (int k = N - 1; k >= 0; k--) {
-        // broadcast Lp (lower 5x5 of the factor of stage k+1) to every lane of the row
-        double Lp[NX][NX];
+        // broadcast P (lower triangle of the 5x5 cost-to-go Hessian of stage k+1: rows 2..6 after the elimination) to every lane of the row
+        double Pm[NX][NX];
         static_for<0, NX>([&](auto m_) {
             constexpr int m = decltype(m_)::value;
 #pragma unroll
-            for (int l = 0; l <= m; l++) Lp[m][l] = bcast16<NU + m>(f[NU + l]);
+            for (int l = 0; l <= m; l++) Pm[m][l] = bcast16<NU + m>(f[NU + l]);
         });
-        // Lxx of stage k+1 (own row of lanes 2..6) is kept for the vector solves: P_{k+1} = Lxx Lxx^T is never formed
+        // P_{k+1} (own row of lanes 2..6) is kept for the vector solves
         if (rowl && li >= NU) {
             double *Ln = L.Hh + (k + 1) * NP28 + FB_P;
 #pragma unroll
             for (int l = 0; l < NX; l++) *(l <= i5 ? Ln + i5 * (i5 + 1) / 2 + l : L.scr + (CP ? 0 : 56) + l) = f[NU + l];   // (entries above the diagonal go to a dummy slot: a select on the address instead of five masked stores)
         }
-        // G = Lp^T [B A] (5 x 7).  Own column densely from ba[]; all columns (row-uniform) from the sparse [B A]:
+        // w = P [B A]_.,own (the lane's own column of [B A], densely from ba[]); the extra row: P rb + p_{k+1} -- as fma(1.0 or 0.0, f, acc):
+        // exactly acc + f on the extra row and acc on the others (f is finite there), without the v_cndmask a select costs
+        double w[NX];
+#pragma unroll
+        for (int n = 0; n < NX; n++) {
+            double acc = Pm[n > 0 ? n : 0][0] * ba[0];
+#pragma unroll
+            for (int m = 1; m < NX; m++) acc = fma(Pm[m > n ? m : n][m > n ? n : m], ba[m], acc);
+            w[n] = VEC ? fma(vmask, f[NU + n], acc) : acc;
+        }
+        // F row `li`: F_ij = Hh_ij + sum_n w_n [B A]_nj with the sparse columns of [B A] (row-uniform):
         //   x: e0   y: e1   s: e4   psi: (Xp,Yp,1,0,0)   v: (Xv,Yv,0,1,dt)   a: (Xa,Ya,0,dt,dt^2/2)   w: (Xw,Yw,dt,0,0)
-        // Same operation order as the dense product (zeros skipped, ones exact), i.e. F = Hh + G^T G keeps the
-        // square-root structure (a factor-level perturbation only) -- do not replace by Hh + [B A]^T (P [B A]).
-        double Go[NX];
-#pragma unroll
-        for (int l = 0; l < NX; l++) {
-            double acc = 0.0;
-#pragma unroll
-            for (int m = l; m < NX; m++) acc += Lp[m][l] * ba[m];
-            // the extra row: (Lp^T rb)_l + lx_l of stage k + 1.  As fma(1.0 or 0.0, f, acc): exactly acc + f on the extra row and acc on the
-            // others (f is finite there), without the ten v_cndmask a select costs per stage
-            Go[l] = VEC ? fma(vmask, f[NU + l], acc) : acc;
-        }
-        const double Xa = dn[D8_XA], Xw = dn[D8_XW], Xp = dn[D8_XP], Xv = dn[D8_XV];
-        const double Ya = dn[D8_YA], Yw = dn[D8_YW], Yp = dn[D8_YP], Yv = dn[D8_YV];
-        double Ga[NX], Gw[NX], Gp[3], Gv[NX];
-        Ga[0] = ((Lp[0][0] * Xa + Lp[1][0] * Ya) + Lp[3][0] * dt) + Lp[4][0] * hdt2;
-        Ga[1] = (Lp[1][1] * Ya + Lp[3][1] * dt) + Lp[4][1] * hdt2;
-        Ga[2] = Lp[3][2] * dt + Lp[4][2] * hdt2;
-        Ga[3] = Lp[3][3] * dt + Lp[4][3] * hdt2;
-        Ga[4] = Lp[4][4] * hdt2;
-        Gw[0] = (Lp[0][0] * Xw + Lp[1][0] * Yw) + Lp[2][0] * dt;
-        Gw[1] = Lp[1][1] * Yw + Lp[2][1] * dt;
-        Gw[2] = Lp[2][2] * dt; Gw[3] = 0.0; Gw[4] = 0.0;
-        Gp[0] = (Lp[0][0] * Xp + Lp[1][0] * Yp) + Lp[2][0];
-        Gp[1] = Lp[1][1] * Yp + Lp[2][1];
-        Gp[2] = Lp[2][2];
-        Gv[0] = ((Lp[0][0] * Xv + Lp[1][0] * Yv) + Lp[3][0]) + Lp[4][0] * dt;
-        Gv[1] = (Lp[1][1] * Yv + Lp[3][1]) + Lp[4][1] * dt;
-        Gv[2] = Lp[3][2] + Lp[4][2] * dt;
-        Gv[3] = Lp[3][3] + Lp[4][3] * dt;
-        Gv[4] = Lp[4][4] * dt;
-        // F row `li`: F_ij = Hh_ij + sum_l G_l,li G_l,j
         {
-            double a0 = hk[ZA], a1 = hk[ZW], a2 = hk[ZX], a3 = hk[ZY], a4 = hk[ZPSI], a5 = hk[ZV], a6 = hk[ZS];
-#pragma unroll
-            for (int l = 0; l < NX; l++) {
-                a0 += Go[l] * Ga[l];
-                if (l < 3) a1 += Go[l] * Gw[l];
-                if (l < 1) a2 += Go[l] * Lp[0][0];
-                if (l < 2) a3 += Go[l] * Lp[1][l];
-                if (l < 3) a4 += Go[l] * Gp[l];
-                a5 += Go[l] * Gv[l];
-                a6 += Go[l] * Lp[4][l];
-            }
-            f[ZA] = a0; f[ZW] = a1; f[ZX] = a2; f[ZY] = a3; f[ZPSI] = a4; f[ZV] = a5; f[ZS] = a6;
+            const double Xa = dn[D8_XA], Xw = dn[D8_XW], Xp = dn[D8_XP], Xv = dn[D8_XV];
+            const double Ya = dn[D8_YA], Yw = dn[D8_YW], Yp = dn[D8_YP], Yv = dn[D8_YV];
+            f[ZA] = fma(w[4], hdt2, fma(w[3], dt, fma(w[1], Ya, fma(w[0], Xa, hk[ZA]))));
+            f[ZW] = fma(w[2], dt, fma(w[1], Yw, fma(w[0], Xw, hk[ZW])));
+            f[ZX] = hk[ZX] + w[0];
+            f[ZY] = hk[ZY] + w[1];
+            f[ZPSI] = fma(w[1], Yp, fma(w[0], Xp, hk[ZPSI])) + w[2];
+            f[ZV] = fma(w[4], dt, fma(w[1], Yv, fma(w[0], Xv, hk[ZV])) + w[3]);
+            f[ZS] = hk[ZS] + w[4];
         }
-        load_stage(k > 0 ? k - 1 : 0, k > 1);         // operands of the next stage, hidden under the Cholesky (unconditional, clamped: a branch here costs a second register
+        load_stage(k > 0 ? k - 1 : 0, k > 1);         // operands of the next stage, hidden under the elimination (unconditional, clamped: a branch here costs a second register
                                                       // set; the pointers stop at stage 0, which the last pass re-loads and discards)
         double r0 = 0.0, r1 = 0.0;
-        bad |= chol_rows<0>(f, li, &r0, &r1);
+        bad |= chol_rows<0, NU>(f, li, &r0, &r1);     // the two input columns; rows 2..6 now hold P_k (lanes 2..6) / p_k (the extra row)
         if (rowl) {
             double *Fb = L.Hh + k * NP28;
             if (li >= NU) { Fb[FB_LXU + 2 * i5] = f[0]; Fb[FB_LXU + 2 * i5 + 1] = f[1]; }
             if (li == 1) { Fb[FB_L10] = f[0]; Fb[FB_R0] = r0; Fb[FB_R1] = r1; }
         }
-        if (vec && wr) {                                           // [y0 y1 | lx] of stage k
+        if (vec && wr) {                                           // [y0 y1 | p_k] of stage k
             L.y[k * NU] = f[0]; L.y[k * NU + 1] = f[1];
 #pragma unroll
             for (int l = 0; l < NX; l++) L.pr[k * NX + l] = f[NU + l];
@@ -270,62 +253,47 @@ __device__ __forceinline__ bool riccati_factor(const Lds &L, const Dims &d, int 
 
 // ---- square-root Riccati: vector solve (backward + forward), rhs gh / rb -> dv, dpi ------------------
 // Stage-parallel parts (one lane per stage, `nth` lanes of the trajectory's own wave(s)):
-//   pre   q_k = P_{k+1} rb_k = Lxx (Lxx^T rb_k) for all stages at once (off the sequential chain); parked in dpi[k+1]
-//   post  dpi_k = P_k dx_k + p_k = Lxx (Lxx^T dx_k) + p_k, k = 1..N
+//   pre   q_k = P_{k+1} rb_k for all stages at once (off the sequential chain); parked in dpi[k+1]
+//   post  dpi_k = P_k dx_k + p_k, k = 1..N
 __device__ __forceinline__ void riccati_solve_pre(const Lds &L, const Dims &d, int tid, int nth)
 {
     const int N = d.N;
     for (int k = tid; k < N; k += nth) {
-        const double *Ln = L.Hh + (k + 1) * NP28 + FB_P;
+        const double *Pn = L.Hh + (k + 1) * NP28 + FB_P;              // P_{k+1}, packed lower triangle
         const double *r = L.rb + k * NX;
-        double ll[15], rr[NX], tl[NX];
+        double pp[15], rr[NX];
 #pragma unroll
-        for (int e = 0; e < 15; e++) ll[e] = Ln[e];
+        for (int e = 0; e < 15; e++) pp[e] = Pn[e];
 #pragma unroll
         for (int m = 0; m < NX; m++) rr[m] = r[m];
-#pragma unroll
-        for (int l = 0; l < NX; l++) {
-            double acc = 0.0;
-#pragma unroll
-            for (int m = l; m < NX; m++) acc += ll[m * (m + 1) / 2 + l] * rr[m];
-            tl[l] = acc;
-        }
 #pragma unroll
         for (int i = 0; i < NX; i++) {
             double acc = 0.0;
 #pragma unroll
-            for (int l = 0; l <= i; l++) acc += ll[i * (i + 1) / 2 + l] * tl[l];
+            for (int m = 0; m < NX; m++) acc += pp[(m > i ? m * (m + 1) / 2 + i : i * (i + 1) / 2 + m)] * rr[m];
             L.dpi[(k + 1) * NX + i] = acc;
         }
     }
 }
-// LX: L.pr holds lx (the fused predictor: p_k = Lxx lx, so dpi_k = Lxx (Lxx^T dx_k + lx_k)) instead of p_k
-template <bool LX = false>
+// dpi_k = P_k dx_k + p_k, k = 1..N (L.pr holds p_k: from the backward sweep, or from the extra row of a VEC factorisation)
 __device__ __forceinline__ void riccati_solve_post(const Lds &L, const Dims &d, int tid, int nth)
 {
     const int N = d.N;
     for (int kk = tid; kk < N; kk += nth) {
         const int k = kk + 1;
-        const double *Lk = L.Hh + k * NP28 + FB_P;
+        const double *Pk = L.Hh + k * NP28 + FB_P;
         const double *dxk = L.dv + k * NV + NU;
-        double ll[15], rr[NX], tl[NX], pk[NX];
+        double pp[15], rr[NX], pk[NX];
 #pragma unroll
-        for (int e = 0; e < 15; e++) ll[e] = Lk[e];
+        for (int e = 0; e < 15; e++) pp[e] = Pk[e];
 #pragma unroll
         for (int m = 0; m < NX; m++) { rr[m] = dxk[m]; pk[m] = L.pr[k * NX + m]; }
-#pragma unroll
-        for (int l = 0; l < NX; l++) {
-            double acc = 0.0;
-#pragma unroll
-            for (int m = l; m < NX; m++) acc += ll[m * (m + 1) / 2 + l] * rr[m];
-            tl[l] = LX ? acc + pk[l] : acc;
-        }
 #pragma unroll
         for (int i = 0; i < NX; i++) {
             double acc = 0.0;
 #pragma unroll
-            for (int l = 0; l <= i; l++) acc += ll[i * (i + 1) / 2 + l] * tl[l];
-            L.dpi[k * NX + i] = LX ? acc : acc + pk[i];
+            for (int m = 0; m < NX; m++) acc += pp[(m > i ? m * (m + 1) / 2 + i : i * (i + 1) / 2 + m)] * rr[m];
+            L.dpi[k * NX + i] = acc + pk[i];
         }
     }
 }
@@ -479,7 +447,7 @@ __device__ __forceinline__ void riccati_solve(const Lds &L, const Dims &d, int t
     __syncthreads();
     riccati_sweeps_rows<CP, true>(L, d, lane, true, sweeper, [] { __syncthreads(); });
     __syncthreads();
-    riccati_solve_post<false>(L, d, tid, NTH);
+    riccati_solve_post(L, d, tid, NTH);
     __syncthreads();
 }
 
@@ -493,7 +461,7 @@ __device__ __forceinline__ void riccati_forward(const Lds &L, const Dims &d, int
     SWEEP_COUNT(SP_CALLS_SOLVE);
     riccati_sweeps_rows<CP, false>(L, d, lane, true, sweeper, [] {});
     __syncthreads();
-    riccati_solve_post<true>(L, d, tid, NTH);
+    riccati_solve_post(L, d, tid, NTH);
     __syncthreads();
 }
 

@@ -34,5 +34,7 @@ void orc_qp_solve(const orc_qp *qp, orc_qp_sol *sol, int iter_max, double tol, d
 /* warm: 0 cold start; 1 primal start from `sol` as it stands (the previous QP's solution); 2 primal and dual (pi, lam, t) from `sol`.
  * init_box: cold / primal start moved into the interior of the box rows by thr0 (HPIPM's d_ocp_qp_init_var). */
 void orc_qp_solve_ex(const orc_qp *qp, orc_qp_sol *sol, int iter_max, double tol, double mu0, double thr0, double tau, int warm, int init_box);
+/* riccati_form: orc_problem::riccati_form (0 square-root, 1 input-block elimination only) */
+void orc_qp_solve_form(const orc_qp *qp, orc_qp_sol *sol, int iter_max, double tol, double mu0, double thr0, double tau, int warm, int init_box, int riccati_form);
 
 #endif

@@ -26,6 +26,8 @@ typedef struct {
     double q[ORC_MAX_N + 1][ORC_MAX_ROWS];
     /* Riccati */
     double Lp[ORC_MAX_N + 1][ORC_NX][ORC_NX];   /* P_k = Lp Lp^T */
+    double P[ORC_MAX_N + 1][ORC_NX][ORC_NX];    /* riccati_form 1: P_k itself */
+    int classical;
     double L[ORC_MAX_N][ORC_NV][ORC_NV];        /* chol of the stage matrix F_k */
     double p[ORC_MAX_N + 1][ORC_NX];
     double y[ORC_MAX_N][ORC_NU];
@@ -45,9 +47,47 @@ typedef struct {
  *     F = L L^T,  L = [Luu 0; Lxu Lxx]   =>   P_k = Lxx Lxx^T  (no subtraction of large numbers)
  * The factor L of every stage is kept for the vector solves.
  */
+/*
+ * orc_problem::riccati_form = 1: the same elimination stopped after the two input columns -- F = Hh + [B A]^T P [B A], Cholesky of the uu
+ * block only, P_k = F_xx - Lxu Lxu^T kept as it is instead of being re-factorised (HPIPM's square_root_alg = 0 [UPSTREAM]; what the HIP
+ * kernels run, csrc/tmpc_riccati.hpp).  tools/riccati_form_study.py measures what it does to the iterates (nothing at qp_tol = 1e-5).
+ */
+static void riccati_factor_classical(const orc_qp *qp, ipm_ws *w)
+{
+    const int N = qp->N;
+    for (int i = 0; i < ORC_NX; i++) for (int j = 0; j < ORC_NX; j++) w->P[N][i][j] = w->Hh[N][ORC_NU + (i > j ? i : j)][ORC_NU + (i > j ? j : i)];
+    for (int k = N - 1; k >= 0; k--) {
+        double PBA[ORC_NX][ORC_NV], F[ORC_NV][ORC_NV];
+        for (int n = 0; n < ORC_NX; n++)
+            for (int j = 0; j < ORC_NV; j++) {
+                double acc = 0.0;
+                for (int m = 0; m < ORC_NX; m++) acc += w->P[k + 1][n][m] * qp->BA[k][m][j];
+                PBA[n][j] = acc;                                  /* (P [B A])_nj : column j is what the lane of row j computes */
+            }
+        for (int i = 0; i < ORC_NV; i++)
+            for (int j = 0; j <= i; j++) {
+                double acc = w->Hh[k][i][j];
+                for (int n = 0; n < ORC_NX; n++) acc += PBA[n][i] * qp->BA[k][n][j];
+                F[i][j] = acc;
+            }
+        memset(w->L[k], 0, sizeof w->L[k]);
+        for (int c = 0; c < ORC_NU; c++) {                        /* right-looking elimination of the two input columns */
+            double d = F[c][c];
+            if (!(d > 0.0)) w->bad = 1;
+            double y = 1.0 / sqrt(d);
+            for (int i = c; i < ORC_NV; i++) w->L[k][i][c] = F[i][c] * y;
+            for (int i = c + 1; i < ORC_NV; i++)
+                for (int j = c + 1; j <= i; j++) F[i][j] -= w->L[k][i][c] * w->L[k][j][c];
+        }
+        for (int i = 0; i < ORC_NX; i++)
+            for (int j = 0; j <= i; j++) w->P[k][i][j] = w->P[k][j][i] = F[ORC_NU + i][ORC_NU + j];
+    }
+}
+
 static void riccati_factor(const orc_qp *qp, ipm_ws *w)
 {
     const int N = qp->N;
+    if (w->classical) { riccati_factor_classical(qp, w); return; }
     /* terminal: Lp = chol(Hh_N,xx) */
     {
         double A[ORC_NX][ORC_NX];
@@ -106,12 +146,18 @@ static void apply_P(const double Lp[ORC_NX][ORC_NX], const double *r, double *y)
     for (int i = 0; i < ORC_NX; i++) { double a = 0.0; for (int l = 0; l <= i; l++) a += Lp[i][l] * tmp[l]; y[i] = a; }
 }
 
+static void apply_Pm(const double P[ORC_NX][ORC_NX], const double *r, double *y)
+{
+    for (int i = 0; i < ORC_NX; i++) { double a = 0.0; for (int l = 0; l < ORC_NX; l++) a += P[i][l] * r[l]; y[i] = a; }
+}
+
 static void riccati_solve(const orc_qp *qp, ipm_ws *w)
 {
     const int N = qp->N;
     for (int i = 0; i < ORC_NX; i++) w->p[N][i] = w->gh[N][ORC_NU + i];
     for (int k = N - 1; k >= 0; k--) {
         double Pb[ORC_NX], f[ORC_NV];
+        if (w->classical) apply_Pm(w->P[k + 1], w->rb[k], Pb); else
         apply_P(w->Lp[k + 1], w->rb[k], Pb);
         for (int i = 0; i < ORC_NX; i++) Pb[i] += w->p[k + 1][i];
         for (int j = 0; j < ORC_NV; j++) {
@@ -141,6 +187,7 @@ static void riccati_solve(const orc_qp *qp, ipm_ws *w)
             for (int j = 0; j < ORC_NV; j++) acc += qp->BA[k][i][j] * w->dv[k][j];
             dxn[i] = acc;
         }
+        if (w->classical) apply_Pm(w->P[k + 1], dxn, w->dpi[k + 1]); else
         apply_P(w->Lp[k + 1], dxn, w->dpi[k + 1]);
         for (int i = 0; i < ORC_NX; i++) w->dpi[k + 1][i] += w->p[k + 1][i];
         memcpy(dx, dxn, sizeof dx);
@@ -200,6 +247,11 @@ static int box_var(const orc_qp *qp, int k, int i)
 
 void orc_qp_solve_ex(const orc_qp *qp, orc_qp_sol *s, int iter_max, double tol, double mu0, double thr0, double tau, int warm, int init_box)
 {
+    orc_qp_solve_form(qp, s, iter_max, tol, mu0, thr0, tau, warm, init_box, 0);
+}
+
+void orc_qp_solve_form(const orc_qp *qp, orc_qp_sol *s, int iter_max, double tol, double mu0, double thr0, double tau, int warm, int init_box, int riccati_form)
+{
     const int N = qp->N;
     /* per-thread workspace, reused across solves (a calloc/free pair per QP makes hundreds of OpenMP threads fight over
      * the kernel's page-fault path and says nothing about the algorithm) */
@@ -207,6 +259,7 @@ void orc_qp_solve_ex(const orc_qp *qp, orc_qp_sol *s, int iter_max, double tol, 
     if (!tls_w) tls_w = (ipm_ws *)malloc(sizeof(ipm_ws));
     ipm_ws *w = tls_w;
     memset(w, 0, sizeof(ipm_ws));
+    w->classical = riccati_form == 1;
     int m = 0;
     /* cold start: v = 0 (dx_0 = given), pi = 0, t = max(residual, thr0), lam = mu0 / t.
      * warm >= 1: v of the previous QP (dx_0 is this QP's); warm == 2: pi, lam, t of the previous QP as well. */

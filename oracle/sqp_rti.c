@@ -198,8 +198,8 @@ static void solve_impl(const orc_problem *pb, const double *xinit, const double 
         build_qp(pb, st, xinit, params, qp, row_lo, row_hi, (dbg && it == capture_sqp_iter) ? dbg : 0, dslack);
         /* the first QP of a solve is cold (the QP memory is reset with every `*solver = *_solver` and after a failure,
          * acados_solver_interface.cpp:70,190); later ones follow qp_warm_start (generate_acados_solver.py:173 sets 2) */
-        orc_qp_solve_ex(qp, sol, pb->qp_iter_max, pb->qp_tol, pb->ipm_mu0, pb->ipm_thr0, pb->ipm_tau,
-                        it > 0 ? pb->qp_warm_start : 0, pb->ipm_init_box);
+        orc_qp_solve_form(qp, sol, pb->qp_iter_max, pb->qp_tol, pb->ipm_mu0, pb->ipm_thr0, pb->ipm_tau,
+                          it > 0 ? pb->qp_warm_start : 0, pb->ipm_init_box, pb->riccati_form);
         info->qp_status = sol->status; info->sqp_iter = it + 1; info->qp_iter_total += sol->iters;
         if (tls_qp_iter_trace) tls_qp_iter_trace[it] = sol->iters;
         if (dbg && it == capture_sqp_iter) {

@@ -76,7 +76,7 @@ void orc_problem_init_ex(orc_problem *pb, int N, int S, int n_lin, int M, int n_
     pb->ipm_tau = 0.999;
     pb->erk_steps = 3;            /* generate_acados_solver.py:150 */
     pb->cost_model = 0;
-    pb->qp_warm_start = 0; pb->ipm_init_box = 0;
+    pb->qp_warm_start = 0; pb->ipm_init_box = 0; pb->riccati_form = 0;
     /* solver_model.py:204-205 ContouringSecondOrderUnicycleModel bounds, order [a,w,x,y,psi,v,spline] */
     const double lb[ORC_NV] = {-2.0, -0.8, -2000.0, -2000.0, -M_PI * 4, -0.01, -1.0};
     const double ub[ORC_NV] = {2.0, 0.8, 2000.0, 2000.0, M_PI * 4, 3.0, 10000.0};

@@ -96,6 +96,16 @@ typedef struct {
      *   initialised (d_ocp_qp_init_var: ux = lb + thr0 / ub - thr0 / the middle), instead of starting at dz = 0 whatever the boxes say. */
     int qp_warm_start;
     int ipm_init_box;
+    /* riccati_form: how the interior-point method's Riccati recursion carries the cost-to-go Hessian P_k from stage to stage.
+     *   0 (default): square-root form -- the 7x7 stage matrix is Cholesky-factorised completely, P_k = Lxx Lxx^T, F = Hh + (Lxx^T [B A])^T (Lxx^T [B A])
+     *      -- what HPIPM's default (mode BALANCE, square_root_alg = 1) does [UPSTREAM];
+     *   1: the same elimination stopped after the two input columns: P_k = F_xx - Lxu Lxu^T is used as it is, F = Hh + [B A]^T P [B A]
+     *      (HPIPM's square_root_alg = 0, its SPEED modes) -- what the HIP kernels run since round 5 (csrc/tmpc_riccati.hpp).
+     * The first two column eliminations are the same operations in both forms.  tools/riccati_form_study.py: at the reference's qp_tol = 1e-5
+     * the two forms give the same exit codes and iteration counts on every bench scene and iterates equal to 4e-11; at qp_tol = 1e-9, where the
+     * interior-point method runs into the conditioning of the barrier systems, 0.3 % (cfg 2) to 5 % (cfg 3) of the solves end differently --
+     * tests that compare the kernels with the oracle at such tolerances set this option so that both sides run the same algorithm. */
+    int riccati_form;
 } orc_problem;
 
 /* HPIPM-like interior-point settings on a problem (mode BALANCE as published in hpipm's d_ocp_qp_ipm_arg_set_default: mu0 = 1e1,

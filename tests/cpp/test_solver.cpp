@@ -117,6 +117,17 @@ int main(int argc, char **argv)
         // Forces-style indexing of the same solution (forces_solver_interface.cpp:241-244): entry i of z_k = [u_k; x_k], k < N
         ASSERT_TRUE(single.getForcesStyleOutput(3, 0) == single.getOutput(3, "a") && single.getForcesStyleOutput(3, 1) == single.getOutput(3, "w"));
         ASSERT_TRUE(single.getForcesStyleOutput(7, 2) == single.getOutput(7, "x") && single.getForcesStyleOutput(7, 5) == single.getOutput(7, "v"));
+        // ... and as a MODE: N stages, Forces warm-start loops (forces_solver_interface.cpp:147-182), this solver's node N repeats the terminal stage
+        ASSERT_TRUE(single.stages() == single.N + 1);
+        single.setStageIndexing(Solver::StageIndexing::ForcesStages);
+        ASSERT_TRUE(single.stages() == single.N && single.getOutput(single.N - 1, "x") == single.getForcesStyleOutput(single.N - 1, 2));
+        State now; now.set("x", 0.25); now.set("v", 1.5);
+        single.initializeWarmstart(now, true);
+        ASSERT_TRUE(single.getEgoPrediction(0, "x") == 0.25 && single.getEgoPrediction(3, "y") == single.getOutput(4, "y"));
+        ASSERT_TRUE(single.getEgoPrediction(single.N - 1, "x") == single.getOutput(single.N - 1, "x") && single.getEgoPrediction(single.N, "x") == single.getOutput(single.N - 1, "x"));
+        single.initializeWarmstart(now, false);
+        ASSERT_TRUE(single.getEgoPrediction(3, "y") == single.getOutput(3, "y") && single.getEgoPrediction(single.N, "v") == single.getOutput(single.N - 1, "v"));
+        single.setStageIndexing(Solver::StageIndexing::AcadosNodes);
     }
     // ---- the one-iteration protocol (initializeOneIteration / solveOneIteration x n / completeOneIteration, :121-204; what
     // SH-MPC's scenario module drives, scenario_constraints.cpp:85) gives bitwise what solve() gives ----

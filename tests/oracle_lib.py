@@ -19,7 +19,7 @@ class Problem(C.Structure):
                 ("erk_steps", C.c_int), ("lb", C.c_double * NV), ("ub", C.c_double * NV),
                 ("n_slk", C.c_int), ("slack", C.c_int), ("lb_slack", C.c_double), ("ub_slack", C.c_double),
                 ("n_gauss", C.c_int), ("ipm_tau", C.c_double), ("cost_model", C.c_int),
-                ("qp_warm_start", C.c_int), ("ipm_init_box", C.c_int)]
+                ("qp_warm_start", C.c_int), ("ipm_init_box", C.c_int), ("riccati_form", C.c_int)]
 
     @property
     def nxe(self):          # model dimensions (array strides): the slack build has one more state
