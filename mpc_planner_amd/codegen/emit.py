@@ -136,14 +136,20 @@ def generate(modules, model, settings, name="generated", method="symbolic"):
     npar = params.length()
     nvar = model.get_nvar()
     slack_model = "slack" in model.states
-    if model.inputs + model.states[:5] != CORE:
-        raise UnsupportedStack("the kernels integrate the contouring unicycle (solver_model.py:193-214); got "
+    # model 0: ContouringSecondOrderUnicycleModel (+ slack variant); model 1: SecondOrderUnicycleModel (solver_model.py:170-191: no spline
+    # state) -- same unicycle, the kernels' fifth state slot is inert for it (csrc/tmpc_stage.hpp Dims::model); nothing may depend on that slot,
+    # which holds by construction here: the model has no name for it, so no module expression can contain Z_6_
+    second_order_unicycle = model.inputs + model.states == CORE[:6]
+    if not second_order_unicycle and model.inputs + model.states[:5] != CORE:
+        raise UnsupportedStack("the kernels integrate the (contouring) second-order unicycle (solver_model.py:170-214); got "
                                f"inputs {model.inputs}, states {model.states}")
     z = [sp.Symbol(f"Z_{i}_", real=True) for i in range(7)]
     slack = sp.Symbol("slack", real=True)
-    zfull = z + ([slack] if slack_model else [])
+    zfull = (z[:6] if second_order_unicycle else z) + ([slack] if slack_model else [])
     if len(zfull) != nvar:
-        raise UnsupportedStack(f"model has {nvar} variables; the kernels support the unicycle (7) and its slack variant (8)")
+        raise UnsupportedStack(f"model has {nvar} variables; the kernels support the unicycle (6), the contouring unicycle (7) and its slack variant (8)")
+    lb7 = list(model.lower_bound[:6 if second_order_unicycle else 7]) + ([-1.0] if second_order_unicycle else [])
+    ub7 = list(model.upper_bound[:6 if second_order_unicycle else 7]) + ([10000.0] if second_order_unicycle else [])
     p = [sp.Symbol(f"P_{i}_", real=True) for i in range(npar)]
 
     cost = _stabilise(plugin.objective(modules, np.array(zfull, dtype=object), p, model, settings, 1))
@@ -227,6 +233,9 @@ namespace tmpc_gen {{
 constexpr int NPAR = {npar};
 constexpr int NH = {nh};
 constexpr int SLACK = {1 if slack_model else 0};
+constexpr int MODEL = {1 if second_order_unicycle else 0};   // 0: contouring unicycle (spline' = v); 1: SecondOrderUnicycleModel (z[6] is an inert padding slot)
+constexpr double LB[7] = {{{", ".join(repr(float(v)) for v in lb7)}}};   // the model's bounds, order [a, w, x, y, psi, v, spline / padding]
+constexpr double UB[7] = {{{", ".join(repr(float(v)) for v in ub7)}}};
 constexpr int ROW_SRC[{max(nh, 1)}] = {{{src_rows or "0"}}};
 constexpr int ROW_SIGN[{max(nh, 1)}] = {{{sgn or "0"}}};
 constexpr double ROW_BOUND[{max(nh, 1)}] = {{{off or "0.0"}}};
@@ -253,5 +262,5 @@ TMPC_GEN_FN void rows(const double *z, const double *p, int ps, double slack, Si
 }}
 }}  // namespace tmpc_gen
 """
-    return dict(header=header, params=params, npar=npar, nh=nh, slack=int(slack_model),
+    return dict(header=header, params=params, npar=npar, nh=nh, slack=int(slack_model), model=int(second_order_unicycle),
                 rows=[(r, kind) for r, kind, _ in rows], name=name)

@@ -151,6 +151,24 @@ class UnicycleContouringModel:
         return [v * math.cos(psi), v * math.sin(psi), w, a, v]
 
 
+class SecondOrderUnicycleModel(UnicycleContouringModel):
+    """SecondOrderUnicycleModel (solver_model.py:170-191): states x, y, psi, v -- no spline state; the stacks that track a goal instead of a
+    reference path use it.  The kernels run it on their 5-state layout with the fifth slot inert (s' = 0): emit.py marks the generated
+    library (tmpc_gen::MODEL = 1), callers pad xinit / x0 / read xtraj with stride 5 / 7 and a zero in the last slot."""
+
+    def __init__(self):
+        super().__init__()
+        self.nx = 4
+        self.states = ["x", "y", "psi", "v"]
+        self.lower_bound = [-2.0, -2.0, -200.0, -200.0, -math.pi * 4, -2.0]
+        self.upper_bound = [2.0, 2.0, 200.0, 200.0, math.pi * 4, 3.0]
+
+    def continuous_model(self, x, u):
+        a, w = u[0], u[1]
+        psi, v = x[2], x[3]
+        return [v * math.cos(psi), v * math.sin(psi), w, a]
+
+
 class UnicycleContouringSlackModel(UnicycleContouringModel):
     """ContouringSecondOrderUnicycleModelWithSlack (solver_model.py:274-298)."""
 

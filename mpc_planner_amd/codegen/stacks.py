@@ -62,6 +62,17 @@ def goal_gaussian(st):
     return P.UnicycleContouringModel(), mm
 
 
+def goal_ellipsoids_second_order_unicycle(st):
+    """Goal tracking with ellipsoidal collision avoidance on SecondOrderUnicycleModel (solver_model.py:170-191; goal_module.py:22-36,
+    ellipsoid_constraints.py:66-110): a stack on the model WITHOUT a spline state -- the kernels' fifth state slot is inert."""
+    mm = P.ModuleManager()
+    b = mm.add_module(L.MPCBaseModule(st))
+    b.weigh_variable("a", "acceleration"); b.weigh_variable("w", "angular_velocity")
+    b.weigh_variable("v", ["velocity", "reference_velocity"], cost_function=lambda x, w: w[0] * (x - w[1]) ** 2)
+    mm.add_module(L.GoalModule(st)); mm.add_module(L.EllipsoidConstraintModule(st))
+    return P.SecondOrderUnicycleModel(), mm
+
+
 def contouring_path_velocity_ellipsoids(st):
     """The stack of the reference's own generation test (solver_generator/test/test_acados.py:30-46): MPC base weights on
     a, w + contouring + path reference velocity + ellipsoids."""

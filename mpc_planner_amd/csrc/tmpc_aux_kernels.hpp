@@ -695,7 +695,7 @@ __global__ void tmpc_warmstart_kernel(Dims d, int B, const double *state, const 
         double sn, cs;
         sincos(psi, &sn, &cs);
         for (int j = 1; j <= k; j++) {                       // same recursion order as the reference's loop (:322-331)
-            x += v * d.dt * cs; y += v * d.dt * sn; spline += v * d.dt;
+            x += v * d.dt * cs; y += v * d.dt * sn; spline += v * d.sdt;      // (sdt = 0: the model without a spline state keeps its padded slot)
             v += a * d.dt; v = fmax(v, 0.0);
         }
         z[ZA] = a; z[ZW] = 0.0; z[ZX] = x; z[ZY] = y; z[ZPSI] = psi; z[ZV] = v; z[ZS] = spline;

@@ -43,6 +43,7 @@ static SolveKernel pick_fast_kernel(const Dims &d, int *threads, bool prof)
         const int nrg = d.n_up + d.M + 14;
         if (lps != 3 && 4 * d.N <= 128 && !getenv("TMPC_NO_TWO_WAVE")) {
             *threads = 128;
+            if (d.n_up == 5 && d.M == 5) return (SolveKernel)tmpc_solve_fast_kernel<5, 5, 4, 128, false, Solo, 2>;     // mpc_planner_jackal's default (generate_jackal_solver.py:53-73), tuned
             if (nrg <= 4 * 6) return (SolveKernel)tmpc_solve_fast_kernel<-1, 6, 4, 128, false, Solo, 2>;
             if (nrg <= 4 * 12) return (SolveKernel)tmpc_solve_fast_kernel<-1, 12, 4, 128, false, Solo, 2>;
             *threads = NT;
@@ -124,7 +125,10 @@ static SolveKernel pick_compact2_kernel(const Dims &d)
     if (getenv("TMPC_FORCE_GENERIC") || getenv("TMPC_NO_COMPACT") || getenv("TMPC_NO_TWO_WAVE") || 3 * d.N <= NT || 4 * d.N > 128) return nullptr;
     const int nr = d.n_up + d.M + 14, sm = stage_model(d);
     if (sm == 1) return (d.n_up == 20 && d.M == 8) ? (SolveKernel)tmpc_solve_compact_kernel<20, 8, 4, false, 128, 1> : nullptr;      // cfg 3 as named (CA-MPC)
-    if (sm == 2) return nr <= 4 * 6 ? (SolveKernel)tmpc_solve_compact_kernel<-1, 6, 4, false, 128, 2> : nullptr;                    // mpc_planner_jackal's default
+    if (sm == 2) {                                                                                                                   // Gaussian chance-constraint rows
+        if (d.n_up == 5 && d.M == 5) return (SolveKernel)tmpc_solve_compact_kernel<5, 5, 4, false, 128, 2>;                          // mpc_planner_jackal's default, tuned (round 5)
+        return nr <= 4 * 6 ? (SolveKernel)tmpc_solve_compact_kernel<-1, 6, 4, false, 128, 2> : nullptr;
+    }
     if (sm != 0) return nullptr;
     if (d.n_up == 20 && d.M == 8) return (SolveKernel)tmpc_solve_compact_kernel<20, 8, 4, false, 128>;
     if (d.n_up == 12 && d.M == 12) return (SolveKernel)tmpc_solve_compact_kernel<12, 12, 4, false, 128>;
@@ -178,7 +182,7 @@ static SolveKernel pick_scan_kernel(const Dims &d, int *threads, int *sl)
 }  // namespace tmpc
 
 struct tmpc_handle {
-    tmpc::Dims d;
+    tmpc::Dims d{};
     int B_max = 0, B = 0, device = 0;
     hipStream_t stream = nullptr;
     // inputs: owned staging buffers (tmpc_set_batch) or borrowed device pointers (tmpc_set_batch_device)
@@ -270,13 +274,16 @@ void tmpc_default_dims_ex(tmpc_dims *d, int32_t N, int32_t S, int32_t n_lin, int
     n_lin = tmpc_gen::NH; M = 0; n_slk = 0; slack = tmpc_gen::SLACK;
 #endif
     d->N = N; d->S = S; d->n_lin = n_lin; d->M = M; d->n_slk = n_slk; d->slack = slack ? 1 : 0;
-    tmpc::Dims t; t.S = S; t.n_lin = n_lin; t.M = M; t.n_slk = n_slk; t.slack = d->slack;
+    tmpc::Dims t{}; t.S = S; t.n_lin = n_lin; t.M = M; t.n_slk = n_slk; t.slack = d->slack;
     d->npar = tmpc::expected_npar(t);
     d->n_sqp = 10; d->qp_iter_max = 50; d->erk_steps = 3;
     d->dt = 0.2; d->qp_tol = 1e-5; d->reg_eps = 1e-4; d->ipm_mu0 = 0.01; d->ipm_thr0 = 0.01;
     const double lb[TMPC_NV] = {-2.0, -0.8, -2000.0, -2000.0, -M_PI * 4, -0.01, -1.0};
     const double ub[TMPC_NV] = {2.0, 0.8, 2000.0, 2000.0, M_PI * 4, 3.0, 10000.0};
     for (int i = 0; i < TMPC_NV; i++) { d->lb[i] = lb[i]; d->ub[i] = ub[i]; }
+#ifdef TMPC_GENERATED_STAGE
+    for (int i = 0; i < TMPC_NV; i++) { d->lb[i] = tmpc_gen::LB[i]; d->ub[i] = tmpc_gen::UB[i]; }     // the plugin model's own bounds (emit.py)
+#endif
 }
 
 int tmpc_create_v2(tmpc_handle **out, const tmpc_dims *dims_in, uint32_t dims_size, int32_t B_max, int32_t device)
@@ -295,7 +302,7 @@ int tmpc_create(tmpc_handle **out, const tmpc_dims *dims, int32_t B_max, int32_t
     if (!out || !dims || B_max <= 0) return TMPC_ERR_INVALID;
     *out = nullptr;
     {
-        tmpc::Dims t; t.S = dims->S; t.n_lin = dims->n_lin; t.M = dims->M; t.n_slk = dims->n_slk; t.slack = dims->slack; t.row_model = dims->row_model;
+        tmpc::Dims t{}; t.S = dims->S; t.n_lin = dims->n_lin; t.M = dims->M; t.n_slk = dims->n_slk; t.slack = dims->slack; t.row_model = dims->row_model;
         if (dims->row_model != 0 && dims->row_model != 1) return TMPC_ERR_INVALID;
         if (dims->N < 2 || dims->N > 62 || dims->S < 1 || dims->M < 0 || dims->n_lin < 0 || dims->n_slk < 0 ||
             (dims->slack != 0 && dims->slack != 1) || dims->npar != tmpc::expected_npar(t) || dims->erk_steps < 1 ||
@@ -317,6 +324,11 @@ int tmpc_create(tmpc_handle **out, const tmpc_dims *dims, int32_t B_max, int32_t
     d.n_sqp = dims->n_sqp; d.qp_iter_max = dims->qp_iter_max; d.erk_steps = dims->erk_steps;
     d.dt = dims->dt; d.qp_tol = dims->qp_tol; d.reg_eps = dims->reg_eps; d.mu0 = dims->ipm_mu0; d.thr0 = dims->ipm_thr0;
     for (int i = 0; i < TMPC_NV; i++) { d.lb[i] = dims->lb[i]; d.ub[i] = dims->ub[i]; }
+#ifdef TMPC_GENERATED_STAGE
+    d.model = tmpc_gen::MODEL;               // fixed by the module stack's model (emit.py): 1 = SecondOrderUnicycleModel, the fifth state slot inert
+#else
+    d.model = 0;
+#endif
     tmpc::derive_dims(d);
     h->kernel = tmpc::pick_fast_kernel(d, &h->threads, false);
     if (const char *lm = getenv("TMPC_LATENCY_MODE")) {      // experiments: latency variant regardless of the caller ("0", "1" or "2"; anything else is ignored)
@@ -701,6 +713,7 @@ int tmpc_set_throughput_mode(tmpc_handle *h, int32_t on)
 {
     if (!h) return TMPC_ERR_INVALID;
     if (on && tmpc::stage_model(h->d) != 0) { h->err = "tmpc_set_throughput_mode: the lane kernels have the MPCC contouring cost and ellipsoid rows only"; return TMPC_ERR_INVALID; }
+    if (on && h->d.model != 0) { h->err = "tmpc_set_throughput_mode: the lane kernels integrate the contouring model (spline state) only"; return TMPC_ERR_INVALID; }
     if (on && h->share_strict) { h->err = "tmpc_set_throughput_mode: a parameter-sharing map with TMPC_SHARE_COPIES_NOT_MAINTAINED is registered and the lane kernels read every entry's own rows"; return TMPC_ERR_INVALID; }
     if (on && !h->lanes) {
         TMPC_HIP_CHECK(h, hipSetDevice(h->device));

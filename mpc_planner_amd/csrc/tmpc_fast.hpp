@@ -413,7 +413,7 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
 #pragma unroll
                 for (int e = 0; e < NP28; e++) L.Hh[ks * NP28 + e] = w[e];
             }
-            const double dtc = d.dt, hc = d.hdt2;
+            const double dtc = d.dt, sdtc = d.sdt, shc = d.shdt2;      // (spline row of [B A]: zero for the model without a spline state)
             const double Xa = d8[D8_XA], Xw = d8[D8_XW], Xp = d8[D8_XP], Xv = d8[D8_XV], Ya = d8[D8_YA], Yw = d8[D8_YW], Yp = d8[D8_YP], Yv = d8[D8_YV];
             double rgk[NV];
 #pragma unroll
@@ -424,12 +424,12 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
                 rgk[i] = acc;
             }
             if (ks < N) {                                  // + [B A]^T pi_{k+1}, column by column
-                rgk[ZA] = ((rgk[ZA] + Xa * pn[0]) + Ya * pn[1] + dtc * pn[3]) + hc * pn[4];
+                rgk[ZA] = ((rgk[ZA] + Xa * pn[0]) + Ya * pn[1] + dtc * pn[3]) + shc * pn[4];
                 rgk[ZW] = (rgk[ZW] + Xw * pn[0]) + Yw * pn[1] + dtc * pn[2];
                 rgk[ZX] += pn[0];
                 rgk[ZY] += pn[1];
                 rgk[ZPSI] = ((rgk[ZPSI] + Xp * pn[0]) + Yp * pn[1]) + pn[2];
-                rgk[ZV] = (((rgk[ZV] + Xv * pn[0]) + Yv * pn[1]) + pn[3]) + dtc * pn[4];
+                rgk[ZV] = (((rgk[ZV] + Xv * pn[0]) + Yv * pn[1]) + pn[3]) + sdtc * pn[4];
                 rgk[ZS] += pn[4];
             }
 #pragma unroll
@@ -446,7 +446,7 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
                 rbk[1] = (((((bk[1] - vn[1]) + Ya * vk[ZA]) + Yw * vk[ZW]) + vk[ZY]) + Yp * vk[ZPSI]) + Yv * vk[ZV];
                 rbk[2] = ((bk[2] - vn[2]) + dtc * vk[ZW]) + vk[ZPSI];
                 rbk[3] = ((bk[3] - vn[3]) + dtc * vk[ZA]) + vk[ZV];
-                rbk[4] = (((bk[4] - vn[4]) + hc * vk[ZA]) + dtc * vk[ZV]) + vk[ZS];
+                rbk[4] = (((bk[4] - vn[4]) + shc * vk[ZA]) + sdtc * vk[ZV]) + vk[ZS];
                 if (tl < N) {
 #pragma unroll
                     for (int i = 0; i < NX; i++) { L.rb[ks * NX + i] = rbk[i]; res_b = fmax(res_b, fabs(rbk[i])); }
@@ -679,7 +679,7 @@ void tmpc_solve_fast_kernel(Dims d, int B, const double *__restrict__ xinit,
     // loadWarmstart, or the iterate the handle holds; fresh or kept multipliers (StateIO, tmpc_solve.hip)
     for (int e = tid; e < (N + 1) * NV; e += NT) {
         const int k = e / NV, i = e - k * NV;
-        L.z[e] = (slot_flags(io, b) & ST_KEEP_ITERATE) ? io.z[(size_t)slot_of(io, b) * (N + 1) * NV + e] : x0[((size_t)b * (N + 1) + k) * ext_nv(d) + i];
+        L.z[e] = (slot_flags(io, b) & ST_KEEP_ITERATE) ? io.z[(size_t)slot_of(io, b) * (N + 1) * NV + e] : TMPC_LD_IN(x0 + ((size_t)b * (N + 1) + k) * ext_nv(d) + i);
     }
     for (int e = tid; e < (N + 1) * NX; e += NT) L.pi[e] = (slot_flags(io, b) & ST_KEEP_MULTIPLIERS) ? io.pi[(size_t)slot_of(io, b) * (N + 1) * NX + e] : 0.0;
     for (int e = tid; e < N * NHk; e += NT) L.lamh[e] = (slot_flags(io, b) & ST_KEEP_MULTIPLIERS) ? io.lamh[(size_t)slot_of(io, b) * N * NHk + e] : 0.0;
@@ -791,7 +791,7 @@ void tmpc_solve_compact_kernel(Dims d, int B, const double *__restrict__ xinit,
 
         for (int e = tid; e < (N + 1) * NV; e += NT) {
             const int k = e / NV, i = e - k * NV;
-            L.z[e] = (slot_flags(io, b) & ST_KEEP_ITERATE) ? io.z[(size_t)slot_of(io, b) * (N + 1) * NV + e] : x0[((size_t)b * (N + 1) + k) * ext_nv(d) + i];
+            L.z[e] = (slot_flags(io, b) & ST_KEEP_ITERATE) ? io.z[(size_t)slot_of(io, b) * (N + 1) * NV + e] : TMPC_LD_IN(x0 + ((size_t)b * (N + 1) + k) * ext_nv(d) + i);
         }
         for (int e = tid; e < (N + 1) * NX; e += NT) L.pi[e] = (slot_flags(io, b) & ST_KEEP_MULTIPLIERS) ? io.pi[(size_t)slot_of(io, b) * (N + 1) * NX + e] : 0.0;
         for (int e = tid; e < N * NHk; e += NT) L.lamh[e] = (slot_flags(io, b) & ST_KEEP_MULTIPLIERS) ? io.lamh[(size_t)slot_of(io, b) * N * NHk + e] : 0.0;

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(LW) void lanes_solve_kernel(Dims d, Layout L, int B
 }
 
 struct Context {
-    Dims d;
+    Dims d{};
     Layout L;
     int B_max = 0, nblocks = 0;
     double *ws = nullptr;

@@ -76,7 +76,7 @@ __device__ __forceinline__ BaLane ba_column(int N, int j)
 __device__ __forceinline__ BaLane ba_row4(int N, int i5)          // o0: base of (b_a, b_w, a_psi, a_v) of row i5
 {
     BaLane c;
-    c.o0 = i5 < 2 ? 4 * i5 : N * 8 + 4 + 4 * (i5 - 2); c.o1 = 0;
+    c.o0 = i5 < 2 ? 4 * i5 : N * 8 + BA_NGROUP0 + 4 * (i5 - 2); c.o1 = 0;
     c.st = i5 < 2 ? 8 : 0;
     return c;
 }
@@ -109,7 +109,7 @@ __device__ __forceinline__ bool riccati_factor_rows(const Lds &L, const Dims &d,
     const double vmask = vec ? 1.0 : 0.0;
     const int ls = li < NV ? li : 0;
     const int i5 = li - NU;                          // state index of lanes 2..6
-    const double dt = d.dt, hdt2 = d.hdt2;
+    const double dt = d.dt, sdt = d.sdt, shdt2 = d.shdt2;      // (sdt, shdt2: the spline row of [B A]; zero for the model without a spline state)
     bool bad = false;
     double f[NV], hk[NV], ba[NX], dn[8];
     const BaLane bc = ba_column(N, ls);
@@ -205,12 +205,12 @@ __device__ __forceinline__ bool riccati_factor_rows(const Lds &L, const Dims &d,
         {
             const double Xa = dn[D8_XA], Xw = dn[D8_XW], Xp = dn[D8_XP], Xv = dn[D8_XV];
             const double Ya = dn[D8_YA], Yw = dn[D8_YW], Yp = dn[D8_YP], Yv = dn[D8_YV];
-            f[ZA] = fma(w[4], hdt2, fma(w[3], dt, fma(w[1], Ya, fma(w[0], Xa, hk[ZA]))));
+            f[ZA] = fma(w[4], shdt2, fma(w[3], dt, fma(w[1], Ya, fma(w[0], Xa, hk[ZA]))));
             f[ZW] = fma(w[2], dt, fma(w[1], Yw, fma(w[0], Xw, hk[ZW])));
             f[ZX] = hk[ZX] + w[0];
             f[ZY] = hk[ZY] + w[1];
             f[ZPSI] = fma(w[1], Yp, fma(w[0], Xp, hk[ZPSI])) + w[2];
-            f[ZV] = fma(w[4], dt, fma(w[1], Yv, fma(w[0], Xv, hk[ZV])) + w[3]);
+            f[ZV] = fma(w[4], sdt, fma(w[1], Yv, fma(w[0], Xv, hk[ZV])) + w[3]);
             f[ZS] = hk[ZS] + w[4];
         }
         load_stage(k > 0 ? k - 1 : 0, k > 1);         // operands of the next stage, hidden under the elimination (unconditional, clamped: a branch here costs a second register

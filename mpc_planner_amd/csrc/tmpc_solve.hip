@@ -91,11 +91,12 @@ struct Lds {
 
 // ---- sparse [B A] (compact kernels) ------------------------------------------------------------------------------
 // For the unicycle [B A] (5 x 7) has 8 stage-dependent entries (dyn8, tmpc_riccati.hpp) and constants 0, 1, dt, dt^2/2.  `tab` =
-// dyn8[N][8] followed by 16 constants; an entry is addressed by a 4-bit code: 0..7 = dyn8 entry of the stage, 8..11 = 0, 1, dt,
-// dt^2/2.  The remaining 12 constants are rows psi, v, s of [B A] in dyn8 column order (a, w, psi, v) for the forward sweep.
+// dyn8[N][8] followed by 20 constants; an entry is addressed by a 4-bit code: 0..7 = dyn8 entry of the stage, 8..13 = 0, 1, dt,
+// dt^2/2 and the spline row's own (sdt, shdt2) -- (dt, dt^2/2) for the contouring model, (0, 0) for SecondOrderUnicycleModel, whose fifth
+// state slot is inert (Dims::model).  The last 12 constants are rows psi, v, s of [B A] in dyn8 column order (a, w, psi, v) for the forward sweep.
 // Reading [B A] through the table returns exactly the values the dense copy held (zeros and ones included), so every sum that
 // runs over a row or column of [B A] keeps its operation order: results are bitwise those of the dense layout.
-constexpr int BAC_0 = 8, BAC_1 = 9, BAC_DT = 10, BAC_H = 11, BA_NCONST = 16;
+constexpr int BAC_0 = 8, BAC_1 = 9, BAC_DT = 10, BAC_H = 11, BAC_SDT = 12, BAC_SH = 13, BA_NGROUP0 = 8, BA_NCONST = 20;
 constexpr unsigned ba_pack(int a, int w, int x, int y, int p, int v, int s_)
 {
     return (unsigned)a | (unsigned)w << 4 | (unsigned)x << 8 | (unsigned)y << 12 | (unsigned)p << 16 | (unsigned)v << 20 | (unsigned)s_ << 24;
@@ -107,7 +108,7 @@ __device__ __forceinline__ constexpr unsigned ba_rowcode(int m)
          : m == 1 ? ba_pack(4, 5, BAC_0, BAC_1, 6, 7, BAC_0)
          : m == 2 ? ba_pack(BAC_0, BAC_DT, BAC_0, BAC_0, BAC_1, BAC_0, BAC_0)
          : m == 3 ? ba_pack(BAC_DT, BAC_0, BAC_0, BAC_0, BAC_0, BAC_1, BAC_0)
-                  : ba_pack(BAC_H, BAC_0, BAC_0, BAC_0, BAC_0, BAC_DT, BAC_1);
+                  : ba_pack(BAC_SH, BAC_0, BAC_0, BAC_0, BAC_0, BAC_SDT, BAC_1);
 }
 // offset (doubles) of entry (m, j) of stage k in `tab`
 __device__ __forceinline__ int ba_off(int N, int k, int m, int j)
@@ -119,9 +120,9 @@ __device__ __forceinline__ int ba_off(int N, int k, int m, int j)
 __device__ __forceinline__ void ba_tab_init(double *tab, const Dims &d, int tid)
 {
     if (tid < BA_NCONST) {
-        const double dt = d.dt, h = d.hdt2;
-        //                          0    1    dt  h  | psi: a  w   psi  v  | v: a   w    psi  v  | s: a  w    psi  v
-        const double c[BA_NCONST] = {0.0, 1.0, dt, h,   0.0, dt, 1.0, 0.0,   dt, 0.0, 0.0, 1.0,   h, 0.0, 0.0, dt};
+        const double dt = d.dt, h = d.hdt2, sdt = d.sdt, sh = d.shdt2;
+        //                          0    1    dt  h  sdt  sh  (pad)     | psi: a  w   psi  v  | v: a   w    psi  v  | s: a   w    psi  v
+        const double c[BA_NCONST] = {0.0, 1.0, dt, h, sdt, sh, 0.0, 0.0,   0.0, dt, 1.0, 0.0,   dt, 0.0, 0.0, 1.0,   sh, 0.0, 0.0, sdt};
         double val = 0.0;
 #pragma unroll
         for (int i = 0; i < BA_NCONST; i++) if (i == tid) val = c[i];
@@ -831,11 +832,11 @@ __device__ __forceinline__ void solve_epilogue(const Lds &L, const Dims &d, int 
     const int nxe = ext_nx(d);
     for (int e = tid_o; e < (N + 1) * nxe; e += nth) {
         const int k = e / nxe, i = e - k * nxe;
-        xtraj[(size_t)b * (N + 1) * nxe + e] = i < NX ? L.z[k * NV + NU + i] : slack;      // the pinned slack state
+        TMPC_ST_OUT(xtraj + (size_t)b * (N + 1) * nxe + e, i < NX ? L.z[k * NV + NU + i] : slack);      // the pinned slack state
     }
     for (int e = tid_o; e < N * NU; e += nth) {
         const int k = e / NU, i = e - k * NU;
-        utraj[(size_t)b * N * NU + e] = L.z[k * NV + i];
+        TMPC_ST_OUT(utraj + (size_t)b * N * NU + e, L.z[k * NV + i]);
     }
     if (tid == 0) {
         if (res > 1e-2 && status == 0) status = 4;
@@ -955,7 +956,7 @@ extern template __global__ void tmpc::tmpc_solve_fast_kernel<8, 8, 6, 128, true,
 #endif
 #endif
 // The two-wave compact instantiations (tmpc_capi.hpp: pick_compact2_kernel) have a translation unit of their own too (-DTMPC_CP2_TU).
-#define TMPC_CP2_SHAPES(X) X(20, 8, 4, 0) X(20, 8, 4, 1) X(12, 12, 4, 0) X(8, 8, 4, 0) X(-1, 6, 4, 0) X(-1, 9, 4, 0) X(-1, 6, 4, 2)
+#define TMPC_CP2_SHAPES(X) X(20, 8, 4, 0) X(20, 8, 4, 1) X(12, 12, 4, 0) X(8, 8, 4, 0) X(-1, 6, 4, 0) X(-1, 9, 4, 0) X(-1, 6, 4, 2) X(5, 5, 4, 2)
 #if defined(TMPC_CP2_TU) && !defined(TMPC_GENERATED_STAGE)
 #define TMPC_X(a, b, c, m) template __global__ void tmpc::tmpc_solve_compact_kernel<a, b, c, false, 128, m>(TMPC_KARGS);
 TMPC_CP2_SHAPES(TMPC_X)

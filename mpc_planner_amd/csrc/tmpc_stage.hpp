@@ -41,6 +41,26 @@
 #define TMPC_RCP_SEED(x) (1.0 / (x))
 #endif
 
+// ---- cache policy of the read-once / write-once global streams (round-4 verdict, next-5; tools/traffic_ab.sh builds the variants) ----
+// TMPC_EXP_NT = 0 (product): plain loads and stores.  1: the warm start, xinit and the output arrays -- touched once per solve -- go through
+// non-temporal accesses (`nt`: streaming, low retention priority in the L2), so that they do not compete with the per-workgroup NLP workspace
+// for L2 lines.  2: the parameter rows as well (read once per RTI iteration).  Measured: profiles/round5_c_traffic_nontemporal_ab.json.
+#ifndef TMPC_EXP_NT
+#define TMPC_EXP_NT 0
+#endif
+#if TMPC_EXP_NT >= 1 && defined(__HIP_DEVICE_COMPILE__)
+#define TMPC_LD_IN(ptr) __builtin_nontemporal_load(ptr)
+#define TMPC_ST_OUT(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#else
+#define TMPC_LD_IN(ptr) (*(ptr))
+#define TMPC_ST_OUT(ptr, val) (*(ptr) = (val))
+#endif
+#if TMPC_EXP_NT >= 2 && defined(__HIP_DEVICE_COMPILE__)
+#define TMPC_LDP(ptr) __builtin_nontemporal_load(ptr)
+#else
+#define TMPC_LDP(ptr) (*(ptr))
+#endif
+
 namespace tmpc {
 
 constexpr int NU = 2, NX = 5, NV = 7, NP28 = 28;
@@ -57,6 +77,12 @@ struct Dims {
     // loop-invariant VGPR copies alive across the whole solve:
     double erk_h, erk_eta, erk_w6;   // dt / erk_steps, its half, its sixth
     double hdt2;                     // dt^2 / 2
+    int model;                       // dynamics model.  0: ContouringSecondOrderUnicycleModel (solver_model.py:193-214: spline' = v), with or without the slack state;
+                                     // 1: SecondOrderUnicycleModel (solver_model.py:170-191: states x, y, psi, v).  The kernels keep their 5-state layout: the fifth
+                                     // slot is INERT for model 1 -- its ODE is s' = 0 (sdt = shdt2 = 0 below), no cost or row may depend on it (the generator checks),
+                                     // so it decouples exactly from every other variable; callers pad xinit / x0 with 0 there.  Generated solvers only: the emitted
+                                     // header fixes it (tmpc_gen::MODEL); the hand-written stage functions are the contouring stacks' (model 0).
+    double sdt, shdt2;               // the spline row of [B A]: (dt, dt^2 / 2) for model 0, (0, 0) for model 1
     int cost_model;                  // 0: ContouringModule (contouring.py:48-98); 1: CurvatureAwareContouringModule (curvature_aware_contouring.py:48-105).
                                      // Kernels are instantiated per cost model (template parameter CM): this field only selects the instantiation on the host
     int row_model;                   // the M lower-bounded rows: 0: EllipsoidConstraintModule (ellipsoid_constraints.py:66-110, h >= 1); 1: GaussianConstraintModule
@@ -71,6 +97,7 @@ __host__ inline void derive_dims(Dims &d)
     d.n_up = d.n_lin + d.n_slk;
     d.erk_h = d.dt / d.erk_steps; d.erk_eta = 0.5 * d.erk_h; d.erk_w6 = d.erk_h / 6.0;
     d.hdt2 = 0.5 * d.dt * d.dt;
+    d.sdt = d.model == 1 ? 0.0 : d.dt; d.shdt2 = d.model == 1 ? 0.0 : d.hdt2;
 }
 __host__ TMPC_HD int ext_nx(const Dims &d) { return NX + d.slack; }   // strides of xinit / xtraj
 __host__ TMPC_HD int ext_nv(const Dims &d) { return NV + d.slack; }   // stride of x0
@@ -141,7 +168,7 @@ TMPC_HD void dyn_eval(const Dims &d, const double *z, DynOut &o, bool second_ord
     o.xn[1] = z[ZY] + nS0;
     o.xn[2] = psi + d.dt * w;
     o.xn[3] = v + d.dt * a;
-    o.xn[4] = z[ZS] + d.dt * v + d.hdt2 * a;
+    o.xn[4] = z[ZS] + d.sdt * v + d.shdt2 * a;
     o.Xa = C1; o.Xw = -nS1; o.Xp = -nS0; o.Xv = C0;
     o.Ya = S1; o.Yw = nC1; o.Yp = nC0; o.Yv = S0;
     if (second_order) {
@@ -159,7 +186,7 @@ TMPC_HD void dyn_jacobian(const Dims &d, const DynOut &o, double *BA)
     BA[1 * NV + ZA] = o.Ya; BA[1 * NV + ZW] = o.Yw; BA[1 * NV + ZY] = 1.0; BA[1 * NV + ZPSI] = o.Yp; BA[1 * NV + ZV] = o.Yv;
     BA[2 * NV + ZW] = d.dt; BA[2 * NV + ZPSI] = 1.0;
     BA[3 * NV + ZA] = d.dt; BA[3 * NV + ZV] = 1.0;
-    BA[4 * NV + ZA] = d.hdt2; BA[4 * NV + ZV] = d.dt; BA[4 * NV + ZS] = 1.0;
+    BA[4 * NV + ZA] = d.shdt2; BA[4 * NV + ZV] = d.sdt; BA[4 * NV + ZS] = 1.0;
 }
 
 // W += pix * hess(x+) + piy * hess(y+)   (W full symmetric 7x7)
@@ -228,7 +255,7 @@ struct CostOut { double val; double g[NV]; double Hxx, Hxy, Hyy, Hxs, Hys, Hss, 
 TMPC_HD void cost_eval(const Dims &d, const double *z, const double *p, int pstride, CostOut &o,
                                           bool derivs, double slack = 0.0)
 {
-    auto P = [&](int i) { return p[(size_t)i * pstride]; };
+    auto P = [&](int i) { return TMPC_LDP(p + (size_t)i * pstride); };
     const int ws = d.slack;
     const double w_a = P(0), w_w = P(1), w_v = P(2 + ws), v_ref = P(3 + ws), w_contour = P(4 + ws), w_lag = P(5 + ws);
     const double a = z[ZA], w = z[ZW], x = z[ZX], y = z[ZY], v = z[ZV], s = z[ZS];
@@ -324,7 +351,7 @@ struct CostOutCA { double val; double g[NV]; double Haa, Hww; double H[15]; };
 
 TMPC_HD void cost_eval_ca(const Dims &d, const double *z, const double *p, int pstride, CostOutCA &o, bool derivs, double slack = 0.0)
 {
-    auto P = [&](int i) { return p[(size_t)i * pstride]; };
+    auto P = [&](int i) { return TMPC_LDP(p + (size_t)i * pstride); };
     const int ws = d.slack;
     const double w_a = P(0), w_w = P(1), w_v = P(2 + ws), v_ref = P(3 + ws), w_contour = P(4 + ws);
     const double a = z[ZA], w = z[ZW], x = z[ZX], y = z[ZY], psi = z[ZPSI], v = z[ZV], s = z[ZS];
@@ -435,8 +462,8 @@ struct RowOut { double h; double gx, gy, gp; double Hxx, Hxy, Hyy, Hxp, Hyp, Hpp
 
 TMPC_HD void lin_row_eval(const Dims &d, const double *z, const double *p, int pstride, int j, RowOut &o)
 {
-    const double a1 = p[(size_t)ip_lin(d, j, 0) * pstride], a2 = p[(size_t)ip_lin(d, j, 1) * pstride];
-    const double b = p[(size_t)ip_lin(d, j, 2) * pstride];
+    const double a1 = TMPC_LDP(p + (size_t)ip_lin(d, j, 0) * pstride), a2 = TMPC_LDP(p + (size_t)ip_lin(d, j, 1) * pstride);
+    const double b = TMPC_LDP(p + (size_t)ip_lin(d, j, 2) * pstride);
     o.h = a1 * z[ZX] + a2 * z[ZY] - b;
     o.gx = a1; o.gy = a2; o.gp = 0.0;
     o.Hxx = o.Hxy = o.Hyy = o.Hxp = o.Hyp = o.Hpp = 0.0;
@@ -445,7 +472,7 @@ TMPC_HD void lin_row_eval(const Dims &d, const double *z, const double *p, int p
 TMPC_HD void ellipsoid_row_eval(const Dims &d, const double *z, const double *p, int pstride, int j,
                                                    double r_disc, double off, double spsi, double cpsi, RowOut &o)
 {
-    auto P = [&](int w) { return p[(size_t)ip_ellipsoid(d, j, w) * pstride]; };
+    auto P = [&](int w) { return TMPC_LDP(p + (size_t)ip_ellipsoid(d, j, w) * pstride); };
     const double ox = P(0), oy = P(1), opsi = P(2), chi = P(5), r = P(6);
     const double sq = sqrt(chi);
     const double major = P(3) * sq, minor = P(4) * sq;                    // ellipsoid_constraints.py:94-95
@@ -484,7 +511,7 @@ TMPC_HD double gauss_quantile(double risk)
 TMPC_HD void gauss_row_eval(const Dims &d, const double *z, const double *p, int pstride, int j,
                             double r_disc, double off, double spsi, double cpsi, double ye, RowOut &o)
 {
-    auto P = [&](int w) { return p[(size_t)ip_gauss(d, j, w) * pstride]; };
+    auto P = [&](int w) { return TMPC_LDP(p + (size_t)ip_gauss(d, j, w) * pstride); };
     const double ox = P(0), oy = P(1), s0 = P(2) * P(2), s1 = P(3) * P(3), R = r_disc + P(5);
     const double px = z[ZX] + off * cpsi - ox, py = z[ZY] + off * spsi - oy;
     const double qx = -off * spsi, qy = off * cpsi;                        // d(px,py)/dpsi
@@ -511,8 +538,8 @@ TMPC_HD void gauss_row_eval(const Dims &d, const double *z, const double *p, int
 TMPC_HD void slk_row_eval(const Dims &d, const double *z, const double *p, int pstride, int j, double off,
                                              double spsi, double cpsi, double slack, RowOut &o)
 {
-    const double a1 = p[(size_t)ip_slk(d, j, 0) * pstride], a2 = p[(size_t)ip_slk(d, j, 1) * pstride];
-    const double b = p[(size_t)ip_slk(d, j, 2) * pstride];
+    const double a1 = TMPC_LDP(p + (size_t)ip_slk(d, j, 0) * pstride), a2 = TMPC_LDP(p + (size_t)ip_slk(d, j, 1) * pstride);
+    const double b = TMPC_LDP(p + (size_t)ip_slk(d, j, 2) * pstride);
     o.h = a1 * (z[ZX] + off * cpsi) + a2 * (z[ZY] + off * spsi) - (b + slack);
     o.gx = a1; o.gy = a2; o.gp = off * (a2 * cpsi - a1 * spsi);
     o.Hxx = o.Hxy = o.Hyy = o.Hxp = o.Hyp = 0.0;
@@ -751,7 +778,7 @@ TMPC_HD void stage_linearise(const Dims &d, const double *z, const double *p, in
         }
     }
     if (d.M == 0 && d.n_slk == 0) return;
-    const double r_disc = d.M > 0 ? p[(size_t)ip_disc_radius(d) * pstride] : 0.0, off = p[(size_t)ip_disc_offset(d) * pstride];
+    const double r_disc = d.M > 0 ? TMPC_LDP(p + (size_t)ip_disc_radius(d) * pstride) : 0.0, off = TMPC_LDP(p + (size_t)ip_disc_offset(d) * pstride);
     double spsi, cpsi;
     sincos(z[ZPSI], &spsi, &cpsi);
     if (part != 1) {
@@ -768,7 +795,7 @@ TMPC_HD void stage_linearise(const Dims &d, const double *z, const double *p, in
         (void)risk_of; (void)ye;                              // in the reference (CONFIG probabilistic/risk), so it is evaluated once per stage, not once per row
         for (int j = j0; j < j1; j++) {
             if constexpr (cm_gaussian_rows(CM)) {
-                const double risk = p[(size_t)ip_gauss(d, j, 4) * pstride];
+                const double risk = TMPC_LDP(p + (size_t)ip_gauss(d, j, 4) * pstride);
                 if (risk != risk_of) { ye = gauss_quantile(risk); risk_of = risk; }
                 gauss_row_eval(d, z, p, pstride, j, r_disc, off, spsi, cpsi, ye, ro);
             } else {

@@ -12,7 +12,7 @@ import numpy as np
 
 NU, NX, NV = 2, 5, 7
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtmpc_hip.so")
+LIB_PATH = os.environ.get("TMPC_HIP_LIBRARY") or os.path.join(_HERE, "libtmpc_hip.so")     # (TMPC_HIP_LIBRARY: lab switch, an A/B build of the same C-ABI)
 
 
 class TmpcDims(C.Structure):

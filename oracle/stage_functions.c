@@ -26,7 +26,7 @@ enum { Z_A = 0, Z_W = 1, Z_X = 2, Z_Y = 3, Z_PSI = 4, Z_V = 5, Z_S = 6, Z_SLACK 
  * (scenario_constraints.py:40-49, decomp_constraints.py:44-52) -> ego_disc_0_offset (skipped when the ellipsoid
  * module already defined it), then a1,a2,b per row, scenario rows before decomp rows.
  * --------------------------------------------------------------------------------------------- */
-static int w0(const orc_problem *pb) { return 8 + pb->slack; }     /* number of weight parameters */
+static int w0(const orc_problem *pb) { return pb->cost_model == 2 ? 7 : 8 + pb->slack; }     /* number of weight parameters (goal stack: 4 base + goal_weight, goal_x, goal_y) */
 int orc_idx_weight(const orc_problem *pb, int which)
 {
     if (which == 8) return 2;                                       /* slack weight (slack build) */
@@ -53,6 +53,17 @@ void orc_problem_set_gaussian(orc_problem *pb, int n_gauss)
     pb->npar = 8 + ORC_SLACK + 9 * pb->S + 3 * pb->n_lin + (n_gauss > 0 ? 2 + 6 * n_gauss : 0);
 }
 
+void orc_problem_set_goal_stack(orc_problem *pb, int model)
+{
+    if (pb->slack || pb->n_slk != 0 || pb->n_gauss != 0) abort();
+    pb->cost_model = 2; pb->model = model; pb->S = 0; pb->n_lin = 0;
+    pb->npar = 7 + (pb->M > 0 ? 2 + 7 * pb->M : 0);
+    if (model == 1) {        /* solver_model.py:179-180 SecondOrderUnicycleModel bounds [a, w, x, y, psi, v]; the padding slot keeps the spline's */
+        const double lb[6] = {-2.0, -2.0, -200.0, -200.0, -M_PI * 4, -2.0}, ub[6] = {2.0, 2.0, 200.0, 200.0, M_PI * 4, 3.0};
+        for (int i = 0; i < 6; i++) { pb->lb[i] = lb[i]; pb->ub[i] = ub[i]; }
+    }
+}
+
 void orc_problem_init(orc_problem *pb, int N, int S, int n_lin, int M) { orc_problem_init_ex(pb, N, S, n_lin, M, 0); }
 
 void orc_problem_set_hpipm_like(orc_problem *pb, int warm_start)
@@ -76,7 +87,7 @@ void orc_problem_init_ex(orc_problem *pb, int N, int S, int n_lin, int M, int n_
     pb->ipm_tau = 0.999;
     pb->erk_steps = 3;            /* generate_acados_solver.py:150 */
     pb->cost_model = 0;
-    pb->qp_warm_start = 0; pb->ipm_init_box = 0; pb->riccati_form = 0;
+    pb->qp_warm_start = 0; pb->ipm_init_box = 0; pb->riccati_form = 0; pb->model = 0;
     /* solver_model.py:204-205 ContouringSecondOrderUnicycleModel bounds, order [a,w,x,y,psi,v,spline] */
     const double lb[ORC_NV] = {-2.0, -0.8, -2000.0, -2000.0, -M_PI * 4, -0.01, -1.0};
     const double ub[ORC_NV] = {2.0, 0.8, 2000.0, 2000.0, M_PI * 4, 3.0, 10000.0};
@@ -177,6 +188,14 @@ void orc_stage_cost(const orc_problem *pb, const double *z, const double *p,
 #endif
     cost = jet_add(cost, jet_scale(jet_sq(jet_addc(v, -v_ref)), w_v));/* w[0] * (x - w[1])**2 */
 
+    if (pb->cost_model == 2) {
+        /* GoalObjective.get_value (goal_module.py:22-36): goal_weight ((x - goal_x)^2 + (y - goal_y)^2) / (goal_x^2 + goal_y^2 + 0.01) */
+        const double gw = p[4], gx = p[5], gy = p[6];
+        jet d2 = jet_add(jet_sq(jet_addc(x, -gx)), jet_sq(jet_addc(y, -gy)));
+        cost = jet_add(cost, jet_scale(jet_scale(d2, gw), 1.0 / (gx * gx + gy * gy + 0.01)));
+        jet_out(&cost, val, grad, hess);
+        return;
+    }
     seg_t sx[16], sy[16]; jet lam[16];
     load_segments(pb, p, sx, sy);
     for (int i = 1; i < pb->S; i++) lam[i - 1] = glue_lambda(sx[i].start, s);
@@ -309,13 +328,13 @@ void orc_continuous_dynamics(const double *z, double f[ORC_NXE])
 #endif
 }
 
-static void f_jet(const jet *x /* NX */, const jet *u /* NU */, jet *f)
+static void f_jet(const jet *x /* NX */, const jet *u /* NU */, jet *f, int model)
 {
     f[0] = jet_mul(x[3], jet_cos(x[2]));
     f[1] = jet_mul(x[3], jet_sin(x[2]));
     f[2] = u[1];
     f[3] = u[0];
-    f[4] = x[3];
+    f[4] = model == 1 ? jet_const(0.0) : x[3];        /* SecondOrderUnicycleModel (solver_model.py:183-191) has no fifth state: the padding slot stands still */
 #if ORC_SLACK
     f[5] = jet_const(0.0);
 #endif
@@ -330,13 +349,13 @@ void orc_discrete_dynamics(const orc_problem *pb, const double *z, double xnext[
     for (int i = 0; i < ORC_NXE; i++) x[i] = jet_var(z[ORC_NU + i], ORC_NU + i);
     const double h = pb->dt / pb->erk_steps;
     for (int step = 0; step < pb->erk_steps; step++) {
-        f_jet(x, u, k1);
+        f_jet(x, u, k1, pb->model);
         for (int i = 0; i < ORC_NXE; i++) xt[i] = jet_add(x[i], jet_scale(k1[i], 0.5 * h));
-        f_jet(xt, u, k2);
+        f_jet(xt, u, k2, pb->model);
         for (int i = 0; i < ORC_NXE; i++) xt[i] = jet_add(x[i], jet_scale(k2[i], 0.5 * h));
-        f_jet(xt, u, k3);
+        f_jet(xt, u, k3, pb->model);
         for (int i = 0; i < ORC_NXE; i++) xt[i] = jet_add(x[i], jet_scale(k3[i], h));
-        f_jet(xt, u, k4);
+        f_jet(xt, u, k4, pb->model);
         for (int i = 0; i < ORC_NXE; i++) {
             jet sum = jet_add(jet_add(k1[i], jet_scale(k2[i], 2.0)), jet_add(jet_scale(k3[i], 2.0), k4[i]));
             x[i] = jet_add(x[i], jet_scale(sum, h / 6.0));

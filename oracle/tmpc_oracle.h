@@ -106,6 +106,11 @@ typedef struct {
      * interior-point method runs into the conditioning of the barrier systems, 0.3 % (cfg 2) to 5 % (cfg 3) of the solves end differently --
      * tests that compare the kernels with the oracle at such tolerances set this option so that both sides run the same algorithm. */
     int riccati_form;
+    /* model: 0 ContouringSecondOrderUnicycleModel (solver_model.py:193-214: spline' = v); 1 SecondOrderUnicycleModel (solver_model.py:170-191:
+     * states x, y, psi, v).  The oracle keeps its 5-state arrays for model 1 with the fifth slot inert (its ODE is s' = 0 and no cost or row reads
+     * it): it decouples exactly from the four real states, which is how the HIP kernels run the model too (csrc/tmpc_stage.hpp Dims::model).
+     * Set by orc_problem_set_goal_stack together with cost_model 2 = MPCBase weights on (a, w, v) + GoalObjective (goal_module.py:22-36). */
+    int model;
 } orc_problem;
 
 /* HPIPM-like interior-point settings on a problem (mode BALANCE as published in hpipm's d_ocp_qp_ipm_arg_set_default: mu0 = 1e1,
@@ -113,6 +118,11 @@ typedef struct {
  * boundary 0.995; d_ocp_qp_init_var: thr0 = 0.1, primal start inside the boxes; acados passes qp_tol as all four res_*_max and
  * iter_max = 50).  warm_start: 0 or the reference's 2. */
 void orc_problem_set_hpipm_like(orc_problem *pb, int warm_start);
+/* The goal-tracking stack on SecondOrderUnicycleModel (model 1) or on the contouring model (model 0): MPCBaseModule(a, w, v) + GoalModule +
+ * EllipsoidConstraintModule(M obstacles, as given to orc_problem_init*): parameters acceleration, angular_velocity, velocity, reference_velocity,
+ * goal_weight, goal_x, goal_y, ego_disc_radius, ego_disc_0_offset, 7 per obstacle; no spline segments, no topology rows.  Model 1 also takes the
+ * model's own bounds (solver_model.py:179-180). */
+void orc_problem_set_goal_stack(orc_problem *pb, int model);
 
 /* Fill sizes, default options and bounds for the Jackal contouring unicycle. */
 void orc_problem_init(orc_problem *pb, int N, int S, int n_lin, int M);

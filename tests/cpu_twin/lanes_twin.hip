@@ -17,7 +17,7 @@ extern "C" int lanes_twin_solve(const tmpc_dims *dims, int32_t B, const double *
                                 double *xtraj, double *utraj, double *pobj, int32_t *exit_code, int32_t *qp_status,
                                 int32_t *sqp_iter, double *res_eq, int32_t *qp_iter)
 {
-    Dims d;
+    Dims d{};
     d.N = dims->N; d.S = dims->S; d.n_lin = dims->n_lin; d.M = dims->M; d.npar = dims->npar;
     d.n_slk = dims->n_slk; d.slack = dims->slack;
     d.n_sqp = dims->n_sqp; d.qp_iter_max = dims->qp_iter_max; d.erk_steps = dims->erk_steps;

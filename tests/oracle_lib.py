@@ -19,7 +19,7 @@ class Problem(C.Structure):
                 ("erk_steps", C.c_int), ("lb", C.c_double * NV), ("ub", C.c_double * NV),
                 ("n_slk", C.c_int), ("slack", C.c_int), ("lb_slack", C.c_double), ("ub_slack", C.c_double),
                 ("n_gauss", C.c_int), ("ipm_tau", C.c_double), ("cost_model", C.c_int),
-                ("qp_warm_start", C.c_int), ("ipm_init_box", C.c_int), ("riccati_form", C.c_int)]
+                ("qp_warm_start", C.c_int), ("ipm_init_box", C.c_int), ("riccati_form", C.c_int), ("model", C.c_int)]
 
     @property
     def nxe(self):          # model dimensions (array strides): the slack build has one more state
@@ -80,6 +80,9 @@ def problem(N=20, S=5, n_lin=8, M=8, n_slk=0, slack=0, n_gauss=0, **opts):
     assert pb.slack == int(bool(slack))
     if n_gauss:
         lib(slack).orc_problem_set_gaussian(C.byref(pb), n_gauss)
+    goal_stack = opts.pop("goal_stack", None)          # None, or the dynamics model (0 contouring unicycle / 1 SecondOrderUnicycleModel) of the goal-tracking stack
+    if goal_stack is not None:
+        lib(slack).orc_problem_set_goal_stack(C.byref(pb), int(goal_stack))
     hpipm_like = opts.pop("hpipm_like", None)          # None, or the QP warm-start level (0 / 2) of the HPIPM-like settings
     if hpipm_like is not None:
         lib(slack).orc_problem_set_hpipm_like(C.byref(pb), int(hpipm_like))

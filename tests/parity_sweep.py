@@ -11,6 +11,8 @@ SHAPES = [
     ("cfg1", dict(N=20, M=4, B=16, guidance=False), dict(N=20, S=5, n_lin=0, M=4), {}),
     ("cfg2", dict(N=20, M=8, B=64), dict(N=20, S=5, n_lin=8, M=8), {}),
     ("cfg2-latency", dict(N=20, M=8, B=64), dict(N=20, S=5, n_lin=8, M=8), dict(latency=True)),
+    # ~10 % of the guidance trajectories carry a point inside an obstacle's disc: LinearizedConstraints::projectToSafety acts (round-4 verdict, next-8)
+    ("cfg2-inside", dict(N=20, M=8, B=64, inside_share=0.1), dict(N=20, S=5, n_lin=8, M=8), {}),
     ("cfg4", dict(N=20, M=12, B=31, tmpc_pp=True), dict(N=20, S=5, n_lin=12, M=12), {}),
     ("N30", dict(N=30, M=8, B=32), dict(N=30, S=5, n_lin=8, M=8), {}),
     ("cfg3", dict(N=30, M=8, B=32, slack=True, n_decomp=12), dict(N=30, S=5, n_lin=8, M=8, n_slk=12, slack=1), {}),

@@ -263,3 +263,37 @@ def test_generated_model_map_carries_the_models_bounds(tmp_path):
     mm = _model_map(False, model)
     assert mm["a"] == ["u", 0, -1.2, 1.2] and mm["v"][3] == 2.5 and mm["w"] == ["u", 1, -0.8, 0.8]
     assert _model_map(True)["slack"] == ["x", 7, 0.0, 5000.0]
+
+
+def test_generated_goal_stack_on_second_order_unicycle_matches_reference_golden():
+    """a stack on the reference's model WITHOUT a spline state (SecondOrderUnicycleModel, solver_model.py:170-191) goes through the
+    generator: the emitted header is marked (tmpc_gen::MODEL = 1: the kernels' fifth state slot is inert), carries the model's bounds, and its
+    stage functions equal the reference's own (tests/golden/stage_functions_goal.json) on the six real variables with nothing on the padding slot."""
+    st = stacks.settings(N=20, max_obstacles=4)
+    model, mm = stacks.goal_ellipsoids_second_order_unicycle(st)
+    assert model.nx == 4 and model.get_nvar() == 6
+    for method in ("jets", "symbolic"):
+        gen = emit.generate(mm, model, st, "goal_so", method=method)
+        assert gen["model"] == 1 and gen["npar"] == 37 and gen["nh"] == 4 and gen["slack"] == 0
+        assert "constexpr int MODEL = 1;" in gen["header"] and "constexpr double LB[7] = {-2.0, -2.0, -200.0, -200.0," in gen["header"]
+        with open(os.path.join(HERE, "golden", "stage_functions_goal.json")) as fh:
+            gold = json.load(fh)
+        assert dict(gen["params"]._params) == gold["cases"][0]["parameter_map"]
+        hs = HostStageFunctions(gen["header"])
+        for case in gold["cases"]:
+            for pad in (0.0, 2.5):
+                z = np.array(case["z"] + [pad])
+                v, g, H = hs.cost(z, case["p"])
+                np.testing.assert_allclose(v, case["cost"], rtol=1e-12)
+                np.testing.assert_allclose(g[:6], case["cost_grad"], rtol=1e-10, atol=1e-11)
+                np.testing.assert_allclose(H[:6, :6], case["cost_hess"], rtol=1e-9, atol=1e-10)
+                assert g[6] == 0.0 and not H[6].any()
+                h, D, Hr = hs.rows(z, case["p"])
+                np.testing.assert_allclose(h, 1.0 - np.array(case["h"]), rtol=1e-11, atol=1e-12)          # ellipsoid rows h >= 1 as 1 - h <= 0
+                np.testing.assert_allclose(-D, np.array(case["h_jac"])[:, 2:5], rtol=1e-10, atol=1e-11)
+    # a model the kernels cannot integrate is still refused
+    class Bicycle(type(model)):
+        def __init__(self):
+            super().__init__(); self.states = ["x", "y", "psi", "v", "delta", "spline"]; self.inputs = ["a", "w", "slack"]; self.nu, self.nx = 3, 6
+    with pytest.raises(emit.UnsupportedStack):
+        emit.generate(mm, Bicycle(), st, "bicycle", method="jets")
