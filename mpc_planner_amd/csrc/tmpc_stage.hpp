@@ -152,11 +152,16 @@ TMPC_HD void dyn_eval(const Dims &d, const double *z, DynOut &o, bool second_ord
     const int last = 2 * d.erk_steps;
     double C0 = 0, C1 = 0, C2 = 0, S0 = 0, S1 = 0, S2 = 0;
     double nC0 = 0, nC1 = 0, nC2 = 0, nS0 = 0, nS1 = 0, nS2 = 0;
+    // cos / sin at the equally spaced nodes theta_m = psi + m (eta w) by the angle-addition recurrence from ONE sincos(psi) and ONE sincos(eta w)
+    // (round 5: seven library sincos calls per stage were ~900 of the linearisation's ~5.6 k VALU instructions; the recurrence's error grows by one
+    // rounding per node -- 6 ulp at the last of the 7 nodes --, far inside what the solve's parity tolerance sees)
+    double sn, cs, sd, cd;
+    sincos(psi, &sn, &cs);
+    sincos(eta * w, &sd, &cd);
     for (int m = 0; m <= last; m++) {
         const double om = w6 * ((m == 0 || m == last) ? 1.0 : ((m & 1) ? 4.0 : 2.0));
         const double tau = m == 0 ? 0.0 : m * eta;          // (literal 0 for the first node: nothing loop-invariant to keep in a VGPR)
-        double sn, cs;
-        sincos(psi + tau * w, &sn, &cs);
+        if (m > 0) { const double c1 = cs * cd - sn * sd, s1 = sn * cd + cs * sd; cs = c1; sn = s1; }
         const double nu = v + tau * a;
         const double oc = om * cs, os = om * sn;
         C0 += oc; C1 += oc * tau; C2 += oc * tau * tau;
