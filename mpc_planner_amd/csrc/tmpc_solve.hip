@@ -581,6 +581,73 @@ __device__ int ipm_solve(const Lds &L, const Dims &d, int tid, int *iters_out, P
     return status;
 }
 
+// MIRROR of the one-wave kernels (round 5).  Lane k < N linearises stage k; the other lanes of the wave are idle copies.  With a zero disc
+// offset the Lagrangian Hessian is block diagonal under {a, w, psi, v} | {x, y, spline} (mirror7), and the two blocks' Jacobi iterations are
+// independent: lane k keeps the 4 x 4 block, lane N + k takes the 3 x 3 block of stage k -- padded to 4 x 4 with a zero row / column, which the
+// cyclic sweep skips (a_pq = 0) and which changes neither the sweep's convergence sums nor the reconstruction (+ 0.0) -- so ONE mirror_n<4> call
+// regularises both blocks of all stages at once, where mirror7 ran mirror_n<4> and then mirror_n<3> on 20 of 64 lanes.  Bitwise what mirror7
+// computes.  A stage whose W couples the blocks (any cross entry != 0: the curvature-aware cost, a disc offset) takes the 7 x 7 iteration on its own
+// lane as before.  `xch`: N * 8 doubles of LDS that nothing else uses during the linearisation (the caller checks), exchanged under two barriers.
+__device__ __forceinline__ void mirror7_pair(double (*A)[NV], double eps, int lane, int N, bool owner, double *xch)
+{
+    constexpr int IA[4] = {ZA, ZW, ZPSI, ZV}, IB[3] = {ZX, ZY, ZS};
+    bool coupled = false;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) coupled |= (A[IA[i]][IB[j]] != 0.0) | (A[IB[j]][IA[i]] != 0.0);
+    if (owner) {
+        double *x = xch + lane * 8;
+        x[0] = A[ZX][ZX]; x[1] = A[ZY][ZX]; x[2] = A[ZY][ZY]; x[3] = A[ZS][ZX]; x[4] = A[ZS][ZY]; x[5] = A[ZS][ZS];
+        x[6] = coupled ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    const bool partner = lane >= N && lane < 2 * N;
+    double M[4][4];
+    bool skip = coupled;                                   // (idle lanes carry stage N - 1's W like its owner: they follow that lane)
+    if (partner) {
+        const double *x = xch + (lane - N) * 8;
+        M[0][0] = x[0]; M[1][0] = M[0][1] = x[1]; M[1][1] = x[2]; M[2][0] = M[0][2] = x[3]; M[2][1] = M[1][2] = x[4]; M[2][2] = x[5];
+#pragma unroll
+        for (int i = 0; i < 4; i++) { M[i][3] = 0.0; M[3][i] = 0.0; }
+        skip = x[6] != 0.0;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) M[i][j] = A[IA[i]][IA[j]];
+    }
+    if (!skip) mirror_n<4>(M, eps);
+    if (partner && !skip) {
+        double *x = xch + (lane - N) * 8;
+        x[0] = M[0][0]; x[1] = M[1][0]; x[2] = M[1][1]; x[3] = M[2][0]; x[4] = M[2][1]; x[5] = M[2][2];
+    }
+    __syncthreads();
+    if (!coupled) {
+        if (!partner) {
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) A[IA[i]][IA[j]] = M[i][j];
+        }
+        if (owner) {
+            const double *x = xch + lane * 8;
+            A[ZX][ZX] = x[0]; A[ZY][ZX] = A[ZX][ZY] = x[1]; A[ZY][ZY] = x[2]; A[ZS][ZX] = A[ZX][ZS] = x[3]; A[ZS][ZY] = A[ZY][ZS] = x[4]; A[ZS][ZS] = x[5];
+        }
+    } else {
+        double F[NV][NV];
+#pragma unroll
+        for (int i = 0; i < NV; i++)
+#pragma unroll
+            for (int j = 0; j < NV; j++) F[i][j] = A[i][j];
+        mirror_n<NV>(F, eps);
+#pragma unroll
+        for (int i = 0; i < NV; i++)
+#pragma unroll
+            for (int j = 0; j < NV; j++) A[i][j] = F[i][j];
+    }
+}
+
 // ---- stage linearisation by lane k --------------------------------------------------------------
 // NTH = 128 (fast layout, two waves per trajectory; hand-written stages): the stage evaluation is split over the waves -- wave 0 the dynamics
 // (rollout with sensitivities, [B A], the multipliers' share of the Hessian) and half of the ellipsoid rows, wave 1 the cost, the halfspace
@@ -777,7 +844,11 @@ __device__ __forceinline__ void linearise(const Lds &L, const Dims &d, int tid, 
 #pragma unroll
             for (int i = 0; i < NX; i++) L.b[bk + i * es] = xn[i] - L.z[(k + 1) * NV + NU + i];
         }
-        mirror7(W, d.reg_eps);
+        // MIRROR: the two diagonal blocks of every stage in different lanes at the same time where the wave has the lanes (2 N <= 64) and the
+        // exchange buffer -- the tail of the interior-point work region, dead while the stage blocks are built -- lies clear of the staging
+        // region (beta, lamh) the rows are being written into; the generic kernel keeps the one-lane form
+        if (FAST && NTH == 64 && 2 * N <= 64 && L.dv >= L.beta + 2 * N * L.nh) mirror7_pair(W, d.reg_eps, tid_l, N, owner, L.dv);
+        else mirror7(W, d.reg_eps);
         if (owner) {
 #pragma unroll
             for (int i = 0; i < NV; i++)
