@@ -680,7 +680,7 @@ def main():
     # ---- p50 latency of one control tick (64 trajectories, host call -> best index on host) --------------
     lat = None
     lanes = None
-    if rank == 0 and a.lanes and not use_dist and not dims.cost_model and not dims.row_model:
+    if rank == 0 and a.lanes and not use_dist and not dims.cost_model and not dims.row_model and solver.has_lane_kernels():
         # the lane-per-trajectory variant (tmpc_set_throughput_mode) on the same resident batch: the measured alternative design
         sv.set_throughput_mode(True)
         sv.solve(); sv.solve(sync=False)

@@ -194,6 +194,9 @@ int tmpc_latency_mode_capacity(tmpc_handle *h, int32_t mode);
  * planners; the mode is chosen by the caller, never by the batch size.  Returns 0, or <0 if the workspace cannot be allocated or if
  * this build of the lane kernel spills registers to scratch (possible in generated solvers: refused, tmpc_last_error says so). */
 int tmpc_set_throughput_mode(tmpc_handle *h, int32_t on);
+/* 1 if this build of the library contains the lane-per-trajectory kernels, 0 if not (the default build since round 5: the family is optional,
+ * -DTMPC_WITH_LANES; tmpc_set_throughput_mode(h, 1) then fails with a message that says so). */
+int tmpc_has_lane_kernels(void);
 
 /* Replaces ocp_nlp_out_get / ocp_nlp_get / ocp_nlp_eval_cost of completeOneIteration (:162-204).
  * Any pointer may be NULL.  Synchronises the stream.  Host pointers. */

@@ -15,14 +15,16 @@ import subprocess
 from . import emit
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-CSRC = os.path.join(os.path.dirname(HERE), "csrc", "tmpc_solve.hip")
-CSRC_LANES = os.path.join(os.path.dirname(HERE), "csrc", "tmpc_lanes.hip")      # second translation unit (throughput kernels)
+CSRC = os.path.join(os.path.dirname(HERE), "csrc", "tmpc_capi.hip")            # a generated solver is ONE translation unit: the C-ABI unit instantiates what it dispatches
+CSRC_LANES = os.path.join(os.path.dirname(HERE), "csrc", "tmpc_lanes.hip")      # optional second unit (lane-per-trajectory kernels; TMPC_BUILD_LANES=1)
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 
 def _compile(header, out, extra):
+    lanes = os.environ.get("TMPC_BUILD_LANES", "0") == "1"
     cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-mllvm", "-disable-machine-licm",
-           "-Rpass-analysis=kernel-resource-usage", f'-DTMPC_GENERATED_STAGE="{header}"', *extra, "-o", out, CSRC, CSRC_LANES]
+           "-Rpass-analysis=kernel-resource-usage", f'-DTMPC_GENERATED_STAGE="{header}"', *extra, *(["-DTMPC_WITH_LANES"] if lanes else []),
+           "-o", out, CSRC, *([CSRC_LANES] if lanes else [])]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError("hipcc failed:\n" + res.stderr[-4000:])

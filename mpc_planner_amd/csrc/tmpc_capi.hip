@@ -1,8 +1,35 @@
-// tmpc_capi.hpp -- the C-ABI of libtmpc_hip.so (include/tmpc_hip.h): kernel dispatch tables, the handle, and every exported entry point.
-// Included once by tmpc_solve.hip, after the kernels (tmpc_solve.hip: LDS layout, linearisation and the solve kernels;
-// tmpc_fast.hpp / tmpc_riccati.hpp / tmpc_scan.hpp / tmpc_stage.hpp: their parts; tmpc_aux_kernels.hpp: selection, gather, debug kernels).
-// Not a standalone header: it sees the kernels' names and the build's -D switches (TMPC_GENERATED_STAGE, TMPC_GEN_FAST, ...).
-#pragma once
+// mpc_planner_amd/csrc/tmpc_capi.hip -- the C-ABI translation unit of libtmpc_hip.so (include/tmpc_hip.h): kernel dispatch tables, the handle, every
+// exported entry point, and the small kernels around the solve (tmpc_aux_kernels.hpp: selection, records, gather, f-1 / f-2 / f-3 helpers).
+// The solve kernels themselves are templates (tmpc_kernels.hpp) instantiated in the units of tmpc_solve.hip; this unit declares them `extern`
+// (tmpc_instances.hpp) and only takes their addresses.  A GENERATED solver (-DTMPC_GENERATED_STAGE, mpc_planner_amd/codegen/build.py) and the
+// experiment builds that pass -DTMPC_SINGLE_TU compile this file ALONE: without the extern declarations every kernel the tables name is
+// instantiated here.
+#include "tmpc_kernels.hpp"
+#include "tmpc_instances.hpp"
+#if !defined(TMPC_GENERATED_STAGE) && !defined(TMPC_SINGLE_TU)
+TMPC_ALL_INSTANCES(EXT)
+extern template __global__ void tmpc::tmpc_solve_fast_kernel<8, 8, 6, 128, true, tmpc::ScanSolo>(TMPC_KARGS);
+#endif
+#include "tmpc_aux_kernels.hpp"
+// The lane-per-trajectory kernel family (tmpc_lanes.hip, tmpc_set_throughput_mode) is an OPTIONAL part of the library since round 5: it loses to
+// the wave kernels on every shape measured and is kept for its persistent-state protocol on arbitrary shapes.  -DTMPC_WITH_LANES links
+// it (__graft_entry__.build(with_lanes=True) / TMPC_BUILD_LANES=1); without it tmpc_set_throughput_mode reports that the build has no such kernels.
+#ifdef TMPC_WITH_LANES
+#include "tmpc_lanes_api.hpp"
+#else
+namespace tmpc {
+namespace lanes {
+struct Context;
+static const char *const kAbsent = "this build of the library does not contain the lane-per-trajectory kernels (build with TMPC_BUILD_LANES=1 / build(with_lanes=True))";
+static inline Context *create(const Dims &, int, std::string &err) { err = kAbsent; return nullptr; }
+static inline void destroy(Context *) {}
+static inline int stage_in(Context *, hipStream_t, int, const double *, const double *, const double *, bool, bool, std::string &err) { err = kAbsent; return 1; }
+static inline int solve(Context *, hipStream_t, int, int, bool, bool, double *, double *, double *, int *, int *, int *, double *, int *, std::string &err) { err = kAbsent; return 1; }
+static inline int reset_multipliers(Context *, hipStream_t, int, std::string &err) { err = kAbsent; return 1; }
+static inline int clear_stopped(Context *, hipStream_t, int, std::string &err) { err = kAbsent; return 1; }
+}  // namespace lanes
+}  // namespace tmpc
+#endif
 
 // =================================================================================================
 // C-ABI
@@ -707,6 +734,15 @@ int tmpc_clear_slot(tmpc_handle *h, int32_t slot)
     TMPC_HIP_CHECK(h, hipMemsetAsync(h->st_has + slot, 0, 4, h->stream));
     TMPC_HIP_CHECK(h, hipMemsetAsync(h->st_stopped + slot, 0, 4, h->stream));
     return TMPC_OK;
+}
+
+int tmpc_has_lane_kernels(void)
+{
+#ifdef TMPC_WITH_LANES
+    return 1;
+#else
+    return 0;
+#endif
 }
 
 int tmpc_set_throughput_mode(tmpc_handle *h, int32_t on)

@@ -43,10 +43,16 @@ EXPORTS = ["tmpc_default_dims", "tmpc_default_dims_ex", "tmpc_create", "tmpc_des
            "tmpc_debug_get_x0", "tmpc_debug_get_params", "tmpc_set_throughput_mode", "tmpc_solve_iterations",
            "tmpc_reset_multipliers", "tmpc_get_stream", "tmpc_kernel_info", "tmpc_set_slots", "tmpc_set_param_sharing", "tmpc_copy_state", "tmpc_scenario_empty_stages", "tmpc_sample_scenarios",
            "tmpc_scenario_discard", "tmpc_scenario_discarded", "tmpc_linearize_topology_ex", "tmpc_clear_slot", "tmpc_gather_best",
-           "tmpc_create_v2", "tmpc_set_param_sharing_ex", "tmpc_latency_mode_capacity"]
+           "tmpc_create_v2", "tmpc_set_param_sharing_ex", "tmpc_latency_mode_capacity", "tmpc_has_lane_kernels"]
 
 class TmpcError(RuntimeError):
     pass
+
+
+def has_lane_kernels(lib_path=None):
+    """Does this build of the library carry the optional lane-per-trajectory kernels (tmpc_set_throughput_mode)?"""
+    lib = load_library(lib_path)
+    return hasattr(lib, "tmpc_has_lane_kernels") and lib.tmpc_has_lane_kernels() == 1
 
 
 _libs = {}

@@ -10,3 +10,16 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "lanes: needs the optional lane-per-trajectory kernel family (csrc/tmpc_lanes.hip): runs only with TMPC_BUILD_LANES=1 "
+                                       "in the environment (build() then builds and links the family and its CPU twin); skipped otherwise")
+
+
+def pytest_collection_modifyitems(config, items):
+    """The lane-per-trajectory family is an optional part of the library since round 5 (it loses to the wave kernels on every shape): its tests
+    run when the build contains it."""
+    if os.environ.get("TMPC_BUILD_LANES", "0") == "1":
+        return
+    skip = pytest.mark.skip(reason="optional lane-per-trajectory kernels not built (TMPC_BUILD_LANES=1 builds and tests them)")
+    for item in items:
+        if item.get_closest_marker("lanes") is not None:
+            item.add_marker(skip)

@@ -18,7 +18,7 @@ def _solver(mode, B_max, **pkw):
     return s
 
 
-@pytest.mark.parametrize("mode", ["wave", "latency", "latency2", "lanes"])
+@pytest.mark.parametrize("mode", ["wave", "latency", "latency2", pytest.param("lanes", marks=pytest.mark.lanes)])
 def test_one_iteration_calls_equal_one_solve(mode):
     """10 x solveOneIteration == solve(): bitwise, including trajectories whose loop ends early (QP at its iteration limit)
     and infeasible ones."""
@@ -41,7 +41,7 @@ def test_one_iteration_calls_equal_one_solve(mode):
     s.close()
 
 
-@pytest.mark.parametrize("mode", ["wave", "lanes"])
+@pytest.mark.parametrize("mode", ["wave", pytest.param("lanes", marks=pytest.mark.lanes)])
 def test_multipliers_carried_across_ticks_match_oracle(mode):
     """Closed loop of 6 control ticks: every tick loads a shifted warm start (loadWarmstart: primal only) and keeps the
     multipliers of the slot's previous solve, like the reference's capsules; a trajectory made infeasible at tick 2 gets its
@@ -110,7 +110,7 @@ def test_reset_multipliers_and_other_iteration_budget():
     s.close()
 
 
-@pytest.mark.parametrize("mode", ["wave", "lanes"])
+@pytest.mark.parametrize("mode", ["wave", pytest.param("lanes", marks=pytest.mark.lanes)])
 def test_new_solve_reopens_loops_that_ended(mode):
     """Advisor (round 2): a slot whose last QP stopped with qp_status != 0 must iterate again in the NEXT solve() even without a
     loadWarmstart -- the reference's loop exit (:105-106) is local to one solve().  Without TMPC_ITER_NEW_SOLVE the slot would be

@@ -197,6 +197,7 @@ def test_failure_paths_and_edge_batches():
     s.close()
 
 
+@pytest.mark.lanes
 @pytest.mark.parametrize("cfg", ["cfg1", "cfg2", "cfg3", "cfg4", "cfg5"])
 def test_throughput_mode_matches_oracle(cfg):
     """tmpc_set_throughput_mode: the lane-per-trajectory kernels (one lane per trajectory, state streamed from HBM) against the
@@ -247,6 +248,7 @@ def test_select_best_index_convention_with_offset():
     s.close()
 
 
+@pytest.mark.lanes
 @pytest.mark.parametrize("shape", ["N2", "N32", "ellipsoids_only", "many_rows", "three_segments"])
 def test_throughput_mode_edge_shapes(shape):
     """Lane kernels on edge shapes (minimal / long horizon, one row class, 36 rows per stage with the slack model, 3 segments):

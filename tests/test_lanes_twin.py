@@ -11,6 +11,8 @@ import pytest
 import oracle_lib as O
 from mpc_planner_amd import scenes, solver
 
+pytestmark = pytest.mark.lanes          # the optional lane-per-trajectory family: collected only with TMPC_BUILD_LANES=1 (tests/conftest.py)
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TWIN = os.path.join(ROOT, "tests", "cpu_twin", "liblanes_twin.so")
 

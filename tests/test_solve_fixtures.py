@@ -31,7 +31,7 @@ def test_oracle_reproduces_fixtures():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["wave", "lanes"])
+@pytest.mark.parametrize("mode", ["wave", pytest.param("lanes", marks=pytest.mark.lanes)])
 def test_hip_path_reproduces_fixtures(mode):
     from mpc_planner_amd import solver
     for c in _cases():

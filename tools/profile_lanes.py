@@ -20,8 +20,9 @@ def build():
     obj = os.path.join(ROOT, "build", "obj", "tmpc_lanes_prof.o")
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", "-mllvm", "-disable-machine-licm",
                            "-DTMPC_LANES_PROF", "-o", obj, os.path.join(csrc, "tmpc_lanes.hip")])
+    o = os.path.join(ROOT, "build", "obj")                                       # (needs a build with the lane kernels: TMPC_BUILD_LANES=1)
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT,
-                           os.path.join(ROOT, "build", "obj", "tmpc_solve.o"), obj])
+                           *[os.path.join(o, f"{u}.o") for u in ("tmpc_solve_fast", "tmpc_solve_compact", "tmpc_solve_prof", "tmpc_solve_cp2", "tmpc_capi_lanes")], obj])
 
 
 if __name__ == "__main__":

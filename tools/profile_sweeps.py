@@ -19,9 +19,9 @@ NAMES = ["factor_terminal", "factor_loop", "solve_prologue", "solve_backward", "
 
 def build():
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    src = os.path.join(ROOT, "mpc_planner_amd", "csrc", "tmpc_solve.hip")
+    src = os.path.join(ROOT, "mpc_planner_amd", "csrc", "tmpc_capi.hip")        # one translation unit (-DTMPC_SINGLE_TU: the C-ABI unit instantiates what it dispatches)
     subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
-                           "-shared", "-mllvm", "-disable-machine-licm", "-DTMPC_SWEEP_PROFILE", "-o", LIB, src])
+                           "-shared", "-mllvm", "-disable-machine-licm", "-DTMPC_SWEEP_PROFILE", "-DTMPC_SINGLE_TU", "-o", LIB, src])
 
 
 def main():

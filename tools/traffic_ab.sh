@@ -7,12 +7,12 @@ R=$(cd "$(dirname "$0")/.." && pwd); cd $R
 if [ "$1" != "measure" ]; then
   mkdir -p build/exp
   for v in 1 2; do
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c -mllvm -disable-machine-licm -DTMPC_PROF_EXTERN -DTMPC_EXP_NT=$v \
-        -o build/exp/tmpc_solve_nt$v.o mpc_planner_amd/csrc/tmpc_solve.hip &
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c -mllvm -disable-machine-licm -DTMPC_TU_COMPACT -DTMPC_EXP_NT=$v \
+        -o build/exp/tmpc_solve_nt$v.o mpc_planner_amd/csrc/tmpc_solve.hip &      # (the compact one-wave kernels: what the cfg 2 bench launch runs)
   done
   wait
   for v in 1 2; do
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/exp/libtmpc_hip_nt$v.so build/exp/tmpc_solve_nt$v.o build/obj/tmpc_solve_prof.o build/obj/tmpc_solve_cp2.o build/obj/tmpc_lanes.o
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/exp/libtmpc_hip_nt$v.so build/exp/tmpc_solve_nt$v.o build/obj/tmpc_solve_fast.o build/obj/tmpc_solve_prof.o build/obj/tmpc_solve_cp2.o build/obj/tmpc_capi.o
   done
   ls -la build/exp/*.so
   exit 0
