@@ -69,7 +69,11 @@ def _model_map(slack, model=None):
     if model is None or not hasattr(model, "lower_bound"):
         return base
     out = type(base)()
+    names = list(getattr(model, "inputs", [])) + list(getattr(model, "states", []))
     for name, (kind, idx, lb, ub) in base.items():
+        if names and name not in names:
+            continue            # a model without this variable (SecondOrderUnicycleModel has no `spline`: solver_model.py:170-191): its model_map.yaml has no
+                                # such row -- module code that loops over the map never names the kernels' inert padding slot; strides stay nx = 5, nvar = 7
         if idx < len(model.lower_bound):
             lb, ub = float(model.lower_bound[idx]), float(model.upper_bound[idx])
         out[name] = [kind, idx, lb, ub]

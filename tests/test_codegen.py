@@ -263,6 +263,9 @@ def test_generated_model_map_carries_the_models_bounds(tmp_path):
     mm = _model_map(False, model)
     assert mm["a"] == ["u", 0, -1.2, 1.2] and mm["v"][3] == 2.5 and mm["w"] == ["u", 1, -0.8, 0.8]
     assert _model_map(True)["slack"] == ["x", 7, 0.0, 5000.0]
+    # SecondOrderUnicycleModel (round 5): the map has the model's six variables and bounds, no `spline` row (the kernels' padding slot has no name)
+    so = _model_map(False, plugin.SecondOrderUnicycleModel())
+    assert list(so) == ["a", "w", "x", "y", "psi", "v"] and so["w"] == ["u", 1, -2.0, 2.0] and so["v"] == ["x", 5, -2.0, 3.0] and so["x"][2:] == [-200.0, 200.0]
 
 
 def test_generated_goal_stack_on_second_order_unicycle_matches_reference_golden():

@@ -1,7 +1,7 @@
 """profiles/round5_chain_floor.json (round-4 verdict, next-1a): the measured costs of the primitives of the Riccati sweeps on gfx950
 (tools/chain_floor.hip -> profiles/round5_chain_floor_raw.json), and from them the dependent-chain length and the issue time of ONE stage step of
 riccati_factor_rows (csrc/tmpc_riccati.hpp), set against the cycles the real kernel takes per stage (tmpc_debug_profile: profiles/round4_final_phases.jsonl
-for the square-root form of rounds 1-4, profiles/round5_b_phases.jsonl for the input-block form of round 5).  Instruction mixes are those of the bench
+for the square-root form of rounds 1-4, profiles/round5_final_phases.jsonl for the input-block form of round 5).  Instruction mixes are those of the bench
 kernel's factor loop (tools/isa_loops.py on tmpc_solve_compact_kernel<8,8,3>).
 Usage: python tools/chain_floor_report.py > profiles/round5_chain_floor.json"""
 import json
@@ -27,7 +27,7 @@ def phases(path, mode=0):
         if d["latency_mode"] == mode:
             return d
     return None
-p4 = phases("round4_final_phases.jsonl"); p5 = phases("round5_b_phases.jsonl")
+p4 = phases("round4_final_phases.jsonl"); p5 = phases("round5_final_phases.jsonl")
 N = 20
 def per_stage(p, key):
     return p["cycles"][key] / p["mean_ipm_total"] / N
@@ -46,7 +46,7 @@ def chain_cycles(pivots):
 out = {
     "what": "measured floor of the Riccati chain on gfx950 (MI355X): primitive costs, critical path and issue time of one stage step of the factorisation vs the kernel's measured cycles",
     "sources": {"microbenchmark": "profiles/round5_chain_floor_raw.json (tools/chain_floor.hip, one workgroup on one CU, s_memtime of the slowest wave; 2.4 GHz)",
-                "kernel_phase_clocks": ["profiles/round4_final_phases.jsonl", "profiles/round5_b_phases.jsonl"], "instruction_mix": "tools/isa_loops.py on tmpc_solve_compact_kernel<8,8,3,false,64,0>"},
+                "kernel_phase_clocks": ["profiles/round4_final_phases.jsonl", "profiles/round5_final_phases.jsonl"], "instruction_mix": "tools/isa_loops.py on tmpc_solve_compact_kernel<8,8,3,false,64,0>"},
     "primitive_costs_cycles": {
         "v_fma_f64 dependent (one wave)": fma_dep, "v_fma_f64 independent, per instruction (one wave, 8 chains)": fma_issue_1w,
         "v_fma_f64 per instruction per SIMD with two waves": fma_issue_2w, "v_mul_f64 dependent": c("mul_f64"), "v_add_f64 dependent": c("add_f64"),
