@@ -506,11 +506,12 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
             const double r = L.rg[e];                                          // (load, then select: see the residual loops above)
             res_g = fmax(res_g, (e >= NU && e < NV) ? 0.0 : fabs(r));          // dx_0 is fixed: its stationarity row is not a residual
         }
-        blk_residuals<NTH>(res_g, res_b, res_d, res_m, mu, L.scr, tl);
+        double res_worst;
+        blk_residuals<NTH>(res_worst, res_g, res_b, res_d, res_m, mu, L.scr, tl);
         mu = mu / m_rows;
         pf.stop(PH_RES);
-        if (!(isfinite(res_g) && isfinite(res_b) && isfinite(res_d) && isfinite(res_m))) { status = 4; active = false; }
-        else if (res_g <= d.qp_tol && res_b <= d.qp_tol && res_d <= d.qp_tol && res_m <= d.qp_tol) { status = 0; active = false; }
+        if (!isfinite(res_worst)) { status = 4; active = false; }
+        else if (res_worst <= d.qp_tol) { status = 0; active = false; }
         else if (it >= d.qp_iter_max) { status = 2; active = false; }
         else iters = it + 1;
         }
@@ -806,10 +807,12 @@ void tmpc_solve_compact_kernel(Dims d, int B, const double *__restrict__ xinit,
         double lam[C::RPL];
         for (int it = 0; it < d.n_sqp; it++) {
             pf.start();
+            TMPC_PRIO_LINEARISE();
             linearise<true, true, NTH, CM>(L, d, tid, pb, slack_of(), pb_own);
             __syncthreads();
             pf.stop(PH_LIN);
             int iters = 0;
+            TMPC_PRIO_LOW();
             qp_status = ipm_fast<NLIN, MM, LPS, NTH, true>(L, d, tid, xi, &iters, pf, lam);
             sqp_iter = it + 1; qp_iter_total += iters;
             if (qp_status != 0 && qp_status != 2) { status = 4; break; }

@@ -255,19 +255,22 @@ template <int NTH> __device__ __forceinline__ double blk_sum(double x, double *s
     return blk_combine<NTH>(wave_sum(x), scr, tid, slot, [](double a, double b) { return a + b; });
 }
 
-// The five convergence quantities of an interior-point iteration at once: one LDS exchange and one barrier in the two-wave kernels
-// instead of five (same slots, same combination order as five blk_max / blk_sum calls: bitwise the same values).
+// The convergence quantities of an interior-point iteration at once.  The four residual norms (stationarity, dynamics, rows, complementarity) are
+// used for exactly two decisions -- "all finite?" and "all <= qp_tol?" -- and both are decisions about their MAXIMUM, so each lane folds its four
+// partial maxima into one before the wave reduction (round 5: one wave_max instead of four, ~60 VALU instructions per interior-point iteration;
+// the decisions, and with them every result, are unchanged).  `worst` returns that maximum, `mu` the complementarity sum.  Two-wave kernels: one
+// LDS exchange and one barrier.
 template <int NTH>
-__device__ __forceinline__ void blk_residuals(double &g, double &b, double &dd, double &m, double &mu, double *scr, int tid)
+__device__ __forceinline__ void blk_residuals(double &worst, double g, double b, double dd, double m, double &mu, double *scr, int tid)
 {
-    g = wave_max(g); b = wave_max(b); dd = wave_max(dd); m = wave_max(m); mu = wave_sum(mu);
+    worst = wave_max(fmax(fmax(g, b), fmax(dd, m))); mu = wave_sum(mu);
     if constexpr (NTH > 64) {
-        if ((tid & 63) == 0) { const int w = tid >> 6; scr[w] = g; scr[2 + w] = b; scr[4 + w] = dd; scr[6 + w] = m; scr[8 + w] = mu; }
+        if ((tid & 63) == 0) { const int w = tid >> 6; scr[w] = worst; scr[2 + w] = mu; }
         __syncthreads();
-        double v[10];
+        double v[4];
 #pragma unroll
-        for (int i = 0; i < 10; i++) v[i] = scr[i];
-        g = fmax(v[0], v[1]); b = fmax(v[2], v[3]); dd = fmax(v[4], v[5]); m = fmax(v[6], v[7]); mu = v[8] + v[9];
+        for (int i = 0; i < 4; i++) v[i] = scr[i];
+        worst = fmax(v[0], v[1]); mu = v[2] + v[3];
     }
 }
 

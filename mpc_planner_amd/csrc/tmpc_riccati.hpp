@@ -19,6 +19,27 @@ __device__ unsigned long long g_sweep_prof[SP_COUNT];
 #define SWEEP_COUNT(i)
 #endif
 
+// Issue priority of the wave (s_setprio, round 5).  Two waves share a SIMD; when both have an instruction ready the one with the higher priority issues.
+// A wave inside a SEQUENTIAL phase (the Riccati factorisation and sweeps: 8 of 64 lanes, every instruction on the trajectory's critical path) gets
+// TMPC_PRIO_SEQ, the rest of an interior-point iteration TMPC_PRIO_IPM, the linearisation 0 -- measured on the cfg 2 bench launch
+// (profiles/round5_g_setprio_ab{,2}.jsonl): no priorities 27.53 ms, (3, 0) 27.15, (3, 1) 27.07, **(3, 2) 27.01** (+1.9 %), (3, 3) 27.20, (1, 1) 27.19,
+// the reverse assignment (0, 3) 27.63.  Results are unaffected (it only orders issue between the waves of a SIMD).
+#ifndef TMPC_PRIO_SEQ
+#define TMPC_PRIO_SEQ 3
+#endif
+#ifndef TMPC_PRIO_IPM
+#define TMPC_PRIO_IPM 2
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TMPC_PRIO_HIGH() __builtin_amdgcn_s_setprio(TMPC_PRIO_SEQ)
+#define TMPC_PRIO_LOW() __builtin_amdgcn_s_setprio(TMPC_PRIO_IPM)
+#define TMPC_PRIO_LINEARISE() __builtin_amdgcn_s_setprio(0)
+#else
+#define TMPC_PRIO_HIGH()
+#define TMPC_PRIO_LOW()
+#define TMPC_PRIO_LINEARISE()
+#endif
+
 // ---- Riccati recursion: factorisation --------------------------------------------------------------
 // Lane i (< 7) owns ROW i of the stage matrix F_k = Hh_k + [B A]^T P_{k+1} [B A] in registers f[0..i].  The elimination runs entirely in
 // registers: pivots and column entries are broadcast inside the 16-lane row (v_mov_b64_dpp row_newbcast), no LDS traffic and no barriers.
@@ -241,7 +262,9 @@ __device__ __forceinline__ bool riccati_factor(const Lds &L, const Dims &d, int 
     SWEEP_T0(); SWEEP_COUNT(SP_CALLS_FACTOR);
     if (NTH == 64 || (tid >> 6) == sw) {
         const int lane = tid & 63;
+        TMPC_PRIO_HIGH();
         const bool bad = riccati_factor_rows<CP, VEC>(L, d, lane, true);
+        TMPC_PRIO_LOW();
         anybad = __any(bad && lane < 16);             // (rows 1..3 of the wave compute on copies: their pivots mean nothing)
         if (NTH > 64 && lane == 0) L.scr[63] = anybad ? 1.0 : 0.0;
     }
@@ -445,7 +468,9 @@ __device__ __forceinline__ void riccati_solve(const Lds &L, const Dims &d, int t
     SWEEP_COUNT(SP_CALLS_SOLVE);
     riccati_solve_pre(L, d, tid, NTH);
     __syncthreads();
+    TMPC_PRIO_HIGH();
     riccati_sweeps_rows<CP, true>(L, d, lane, true, sweeper, [] { __syncthreads(); });
+    TMPC_PRIO_LOW();
     __syncthreads();
     riccati_solve_post(L, d, tid, NTH);
     __syncthreads();
@@ -459,7 +484,9 @@ __device__ __forceinline__ void riccati_forward(const Lds &L, const Dims &d, int
     const bool sweeper = NTH == 64 || (tid >> 6) == sw;
     const int lane = NTH == 64 ? tid : (sweeper ? (tid & 63) : 64);
     SWEEP_COUNT(SP_CALLS_SOLVE);
+    TMPC_PRIO_HIGH();
     riccati_sweeps_rows<CP, false>(L, d, lane, true, sweeper, [] {});
+    TMPC_PRIO_LOW();
     __syncthreads();
     riccati_solve_post(L, d, tid, NTH);
     __syncthreads();

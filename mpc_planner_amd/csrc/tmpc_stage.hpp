@@ -579,6 +579,11 @@ TMPC_HD double st_rcp(double x)
 }
 
 // MIRROR of an n x n symmetric matrix held in registers (fully unrolled cyclic Jacobi): A <- V max(|e|, eps) V^T.
+// A sweep starts while the squared off-diagonal norm exceeds TMPC_MIRROR_TOL2 times the squared Frobenius norm (1e-32: the oracle's; looser
+// thresholds were measured in round 5 and buy 0.1-0.2 %: profiles/round5_h_mirror_tol_ab.jsonl -- not taken).
+#ifndef TMPC_MIRROR_TOL2
+#define TMPC_MIRROR_TOL2 1e-32
+#endif
 template <int NN>
 TMPC_HD void mirror_n(double (&A)[NN][NN], double eps)
 {
@@ -595,7 +600,7 @@ TMPC_HD void mirror_n(double (&A)[NN][NN], double eps)
 #pragma unroll
             for (int j = i + 1; j < NN; j++) off += A[i][j] * A[i][j];
         }
-        if (off <= 1e-32 * (dg + off) || off == 0.0) break;
+        if (off <= TMPC_MIRROR_TOL2 * (dg + off) || off == 0.0) break;
 #pragma unroll
         for (int p = 0; p < NN - 1; p++) {
 #pragma unroll
