@@ -237,6 +237,8 @@ struct tmpc_handle {
     tmpc::SolveKernel kernel_cp2 = nullptr;   // optional two-wave compact variant (22 <= N <= 32): launches of more than cp2_min_B trajectories
     size_t lds_bytes_cp2 = 0;
     int cp2_min_B = 0;                        // what the fast two-wave kernel holds resident at once (workgroups per CU x CUs)
+    bool prio_cp = false, prio_cp2 = false;   // wave issue priorities (Dims::prio) for the compact one-wave / two-wave kernel: only when its residency puts two waves on
+                                              // every SIMD (8 waves per CU) -- with an odd count the waves that share a SIMD starve and set the makespan (tmpc_riccati.hpp)
     int latency_mode = 0;                     // 0: throughput kernels, 1: two-wave variant, 2: parallel-in-time variant
     bool throughput_mode = false;             // lane-per-trajectory kernels (tmpc_lanes.hip) instead of one wave per trajectory
     tmpc::lanes::Context *lanes = nullptr;    // their HBM workspace, created when the mode is first enabled
@@ -409,7 +411,7 @@ int tmpc_create(tmpc_handle **out, const tmpc_dims *dims, int32_t B_max, int32_t
             h->kernel_cp2 = nullptr;                         // (no gain in residency: the fast kernel stays alone)
         else {
             if (const char *e = getenv("TMPC_COMPACT_PER_CU")) { const int v = atoi(e); if (v > 0 && v < per_cu) per_cu = v; }   // experiments
-            h->grid_max = per_cu * cus; h->cp2_min_B = fast_per_cu * cus;
+            h->grid_max = per_cu * cus; h->cp2_min_B = fast_per_cu * cus; h->prio_cp2 = per_cu * 2 == 8;
             if (const char *e = getenv("TMPC_COMPACT2_MIN_B")) h->cp2_min_B = atoi(e);                                            // experiments
         }
     }
@@ -419,7 +421,7 @@ int tmpc_create(tmpc_handle **out, const tmpc_dims *dims, int32_t B_max, int32_t
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0)
             return fail(TMPC_ERR_HIP);
         if (const char *e = getenv("TMPC_COMPACT_PER_CU")) { const int v = atoi(e); if (v > 0 && v < per_cu) per_cu = v; }   // experiments
-        h->grid_max = per_cu * cus;
+        h->grid_max = per_cu * cus; h->prio_cp = per_cu == 8;
     }
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return fail(TMPC_ERR_HIP);
     const size_t N = d.N, B = B_max;
@@ -514,6 +516,7 @@ static int launch_solve(tmpc_handle *h, int n_iter, int st_flags)
         const bool cp2 = h->kernel_cp2 && !lat && !lat2 && h->B > h->cp2_min_B;
         const bool small = h->compact && h->kernel_small && !lat && !lat2 && h->B <= h->cp_min_B;
         const bool cp = (h->compact && !lat && !lat2 && !small) || cp2;
+        dd.prio = cp2 ? h->prio_cp2 : (cp ? h->prio_cp : false);
         if (cp) TMPC_HIP_CHECK(h, hipMemsetAsync(h->ticket, 0, 8 * 4, h->stream));    // the persistent launch's work counters (one per XCD)
         hipLaunchKernelGGL(lat2 ? h->kernel_scan : lat ? h->kernel_lat : cp2 ? h->kernel_cp2 : small ? h->kernel_small : h->kernel,
                            dim3(cp ? (h->B < h->grid_max ? h->B : h->grid_max) : h->B),   // (persistent launch: at most the resident workgroups)

@@ -797,7 +797,17 @@ __device__ __forceinline__ void linearise(const Lds &L, const Dims &d, int tid, 
     int tid_l = tid;
     asm volatile("" : "+v"(tid_l));                       // opaque: no hoisting of per-stage addresses out of the RTI loop
     const bool owner = tid_l < N;
-    const int k = owner ? tid_l : N - 1;
+    // Round 5, one-wave fast / compact kernels: lanes N .. 3N-1 do not idle on a copy of stage N-1 any more -- lane g N + k (g = 1, 2) linearises a copy
+    // of stage k as well and the three lanes of a stage take every third ROW of each class (obstacle rows: ~75 instructions and seven L2-latency
+    // parameter loads per row, a fifth of the linearisation's time at 8 rows; halfspace and scenario rows); the helpers write their rows' Jacobians themselves and
+    // hand their share of the rows' Hessian to the owner through LDS (their W is that share and nothing else: everything else that enters W is
+    // multiplied by zero on a helper).  The rest of the stage (dynamics, cost, halfspace rows) is computed redundantly by all three -- same
+    // instructions, no extra issue slots.  The sum of the three shares associates differently from the sequential
+    // sum over the rows (rounding level).  `split`: the wave has the lanes and the exchange buffer lies clear of the staging region.
+    const bool split = FAST && NTH == 64 && 3 * N <= 64 && L.nh >= 3 && L.dv >= L.beta + 2 * N * L.nh;
+    const bool helper = split && tid_l >= N && tid_l < 3 * N;
+    const int k = owner ? tid_l : (helper ? (tid_l >= 2 * N ? tid_l - 2 * N : tid_l - N) : N - 1);
+    auto ell_first = [&]() { return split ? (tid_l >= N ? 1 : 0) + (tid_l >= 2 * N ? 1 : 0) : 0; };     // the lane's group: owner 0, helpers 1 and 2
     {
         double z[NV];
 #pragma unroll
@@ -812,7 +822,7 @@ __device__ __forceinline__ void linearise(const Lds &L, const Dims &d, int tid, 
             return -sgn * L.lam[k * nh + r];
         };
         auto sink = [&](int r, const RowOut &ro) {
-            if (owner) {
+            if (owner || helper) {                            // (every row is evaluated by exactly one of a stage's three lanes, which writes it)
                 // fast layouts (the register-row kernels) keep the SIGNED row Jacobian sgn D -- upper-bounded rows -1, lower-bounded +1 -- so that
                 // the row passes of ipm_fast read their coefficients as they are; the generic kernel keeps D and applies the sign itself
                 const double sg = FAST ? ((r < d.n_up) ? -1.0 : 1.0) : 1.0;
@@ -830,7 +840,24 @@ __device__ __forceinline__ void linearise(const Lds &L, const Dims &d, int tid, 
             }
         };
         stage_linearise<CM>(d, z, p, 1, L.pi[(k + 1) * NX + 0], L.pi[(k + 1) * NX + 1], lamh, sink, W, g, BA, xn, slack,
-                        L.W + k * NP28, own_delta);         // (generated solvers park the cost Hessian in the stage's W slot)
+                        L.W + k * NP28, own_delta, 0, ell_first, split ? 3 : 1, helper);   // (generated solvers park the cost Hessian in the stage's W slot)
+        if (split) {                                        // the helpers' W = their share of the obstacle rows' Hessian (x, y, psi block) -> the owner
+            double *xe = L.dv;                              // 2 N x 6 doubles (dv and dpi are contiguous: 252 doubles at N = 20)
+            if (helper) {
+                double *x = xe + (tid_l - N) * 6;                      // ((group - 1) N + k)
+                x[0] = W[ZX][ZX]; x[1] = W[ZX][ZY]; x[2] = W[ZY][ZY]; x[3] = W[ZX][ZPSI]; x[4] = W[ZY][ZPSI]; x[5] = W[ZPSI][ZPSI];
+            }
+            __syncthreads();
+            if (owner) {
+                const double *x1 = xe + k * 6, *x2 = xe + (N + k) * 6;
+                const double e0 = x1[0] + x2[0], e1 = x1[1] + x2[1], e2 = x1[2] + x2[2], e3 = x1[3] + x2[3], e4 = x1[4] + x2[4], e5 = x1[5] + x2[5];
+                W[ZX][ZX] += e0; W[ZY][ZY] += e2; W[ZPSI][ZPSI] += e5;
+                W[ZX][ZY] += e1; W[ZY][ZX] += e1;
+                W[ZX][ZPSI] += e3; W[ZPSI][ZX] += e3;
+                W[ZY][ZPSI] += e4; W[ZPSI][ZY] += e4;
+            }
+            __syncthreads();                                // (the exchange buffer is MIRROR's next)
+        }
         // everything but W leaves the registers BEFORE the register-hungry MIRROR
         // compact layout: g, b, W live in the global workspace (same [stage][entry] layout: a lane's stores of one array share
         // one address register and differ in the immediate offset); [B A] is kept as its 8 non-constant entries only

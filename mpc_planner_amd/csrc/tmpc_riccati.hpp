@@ -23,7 +23,10 @@ __device__ unsigned long long g_sweep_prof[SP_COUNT];
 // A wave inside a SEQUENTIAL phase (the Riccati factorisation and sweeps: 8 of 64 lanes, every instruction on the trajectory's critical path) gets
 // TMPC_PRIO_SEQ, the rest of an interior-point iteration TMPC_PRIO_IPM, the linearisation 0 -- measured on the cfg 2 bench launch
 // (profiles/round5_g_setprio_ab{,2}.jsonl): no priorities 27.53 ms, (3, 0) 27.15, (3, 1) 27.07, **(3, 2) 27.01** (+1.9 %), (3, 3) 27.20, (1, 1) 27.19,
-// the reverse assignment (0, 3) 27.63.  Results are unaffected (it only orders issue between the waves of a SIMD).
+// the reverse assignment (0, 3) 27.63; at 2-4 rounds per launch the same shape gains 4-8 % (round5_k_prio_vs_launch_size.jsonl).  Results are
+// unaffected (it only orders issue between the waves of a SIMD).  Only where every SIMD hosts two waves: at 7 workgroups per CU (cfg 4's shape) one
+// SIMD hosts a single wave, the priorities make the launch 6 % SLOWER (round5_j_prio_other_configs.jsonl: the starved waves set the makespan) --
+// the host sets Dims::prio per launch (launch_solve) and the macros test it (a scalar branch).
 #ifndef TMPC_PRIO_SEQ
 #define TMPC_PRIO_SEQ 3
 #endif
@@ -31,9 +34,9 @@ __device__ unsigned long long g_sweep_prof[SP_COUNT];
 #define TMPC_PRIO_IPM 2
 #endif
 #if defined(__HIP_DEVICE_COMPILE__)
-#define TMPC_PRIO_HIGH() __builtin_amdgcn_s_setprio(TMPC_PRIO_SEQ)
-#define TMPC_PRIO_LOW() __builtin_amdgcn_s_setprio(TMPC_PRIO_IPM)
-#define TMPC_PRIO_LINEARISE() __builtin_amdgcn_s_setprio(0)
+#define TMPC_PRIO_HIGH() do { if (d.prio) __builtin_amdgcn_s_setprio(TMPC_PRIO_SEQ); } while (0)
+#define TMPC_PRIO_LOW() do { if (d.prio) __builtin_amdgcn_s_setprio(TMPC_PRIO_IPM); } while (0)
+#define TMPC_PRIO_LINEARISE() do { if (d.prio) __builtin_amdgcn_s_setprio(0); } while (0)
 #else
 #define TMPC_PRIO_HIGH()
 #define TMPC_PRIO_LOW()

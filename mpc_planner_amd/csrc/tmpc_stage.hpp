@@ -83,6 +83,8 @@ struct Dims {
                                      // so it decouples exactly from every other variable; callers pad xinit / x0 with 0 there.  Generated solvers only: the emitted
                                      // header fixes it (tmpc_gen::MODEL); the hand-written stage functions are the contouring stacks' (model 0).
     double sdt, shdt2;               // the spline row of [B A]: (dt, dt^2 / 2) for model 0, (0, 0) for model 1
+    int prio;                        // 1: the kernel raises its wave's issue priority inside the latency-critical phases (csrc/tmpc_riccati.hpp TMPC_PRIO_*);
+                                     // set per LAUNCH by the host (launch_solve): only for kernels that put two waves on every SIMD
     int cost_model;                  // 0: ContouringModule (contouring.py:48-98); 1: CurvatureAwareContouringModule (curvature_aware_contouring.py:48-105).
                                      // Kernels are instantiated per cost model (template parameter CM): this field only selects the instantiation on the host
     int row_model;                   // the M lower-bounded rows: 0: EllipsoidConstraintModule (ellipsoid_constraints.py:66-110, h >= 1); 1: GaussianConstraintModule
@@ -701,12 +703,20 @@ TMPC_HD void mirror7(double (*A)[NV], double eps)
 // Lagrangian Hessian of one stage (before MIRROR): dt*hess(l) + pi_x hess(x+) + pi_y hess(y+) + sum_r lamh_r hess(h_r),
 // plus the linearisation data of the stage.  lamh(r) is supplied by a functor (zero for inactive rows).
 // Rows are numbered in the kernels' internal order [topology | slack rows | ellipsoids] (upper-bounded rows first).
-template <int CM = 0, typename LamH, typename RowSink>
+struct EllAll { TMPC_HD int operator()() const { return 0; } };      // default obstacle-row share: start at the first row (with ell_step = 1: all of them)
+template <int CM = 0, typename LamH, typename RowSink, typename EllFirst = EllAll>
 TMPC_HD void stage_linearise(const Dims &d, const double *z, const double *p, int pstride,
                                                 double pix, double piy, LamH lamh, RowSink sink,
                                                 double (*W)[NV], double *g, double *BA, double *xn, double slack = 0.0,
-                                                double *stash = nullptr, long long own_delta = 0, int part = 0)
+                                                double *stash = nullptr, long long own_delta = 0, int part = 0,
+                                                EllFirst ell_first = EllFirst(), int ell_step = 1, bool rows_only = false)
 {
+    // ell_first / ell_step / rows_only (round 5, the one-wave kernels): this lane evaluates every ell_step-th row of each row class (halfspace, scenario /
+    // decomp, obstacle rows), starting at ell_first() (a functor, called where a loop starts: its value is not held in a register across the stage);
+    // with rows_only everything ELSE that enters W (dynamics curvature, cost Hessian) is multiplied by zero, so that
+    // W comes back as exactly this lane's share of the rows' Hessian -- three lanes of a stage take a third of the rows each (linearise,
+    // tmpc_kernels.hpp) and the owner adds the helpers' shares to its W.  (A lane mask, turned into 0.0 / 1.0 where it is used: no register held
+    // across the stage.)  Defaults: every row, everything in W.
     // part (hand-written stages; compile-time at every call site): 0 = the whole stage; 1 = dynamics and the first half of the ellipsoid rows
     // (W = their share of the Lagrangian Hessian, BA, xn; g untouched); 2 = cost, topology and scenario / decomp rows, the other ellipsoid
     // rows (W = their share, g; BA, xn untouched).  The two-wave kernels run 1 and 2 on different waves at the same time and add the two W
@@ -741,7 +751,7 @@ TMPC_HD void stage_linearise(const Dims &d, const double *z, const double *p, in
         dyn_jacobian(d, dy, BA);
 #pragma unroll
         for (int i = 0; i < NX; i++) xn[i] = dy.xn[i];
-        dyn_add_hessian(dy, pix, piy, W);
+        dyn_add_hessian(dy, rows_only ? 0.0 : pix, rows_only ? 0.0 : piy, W);
     }
 #ifdef TMPC_GENERATED_STAGE
     if (stash) {
@@ -773,16 +783,16 @@ TMPC_HD void stage_linearise(const Dims &d, const double *z, const double *p, in
             cost_eval_ca(d, z, p, pstride, co, true, slack);
 #pragma unroll
             for (int i = 0; i < NV; i++) g[i] = d.dt * co.g[i];
-            cost_add_hessian_ca(co, d.dt, W);
+            cost_add_hessian_ca(co, rows_only ? 0.0 : d.dt, W);
         } else {
         CostOut co;
         cost_eval(d, z, p, pstride, co, true, slack);
 #pragma unroll
         for (int i = 0; i < NV; i++) g[i] = (i == ZPSI) ? 0.0 : d.dt * co.g[i];   // stage cost scaled by the shooting interval (the cost
                                                                             // does not depend on psi: literal 0, not a hoisted dt * 0)
-        cost_add_hessian(co, d.dt, W);
+        cost_add_hessian(co, rows_only ? 0.0 : d.dt, W);
         }
-        for (int j = 0; j < d.n_lin; j++) {
+        for (int j = ell_first(); j < d.n_lin; j += ell_step) {   // (halfspace rows have no curvature: nothing of them enters W)
             lin_row_eval(d, z, p + own_delta, pstride, j, ro);
             sink(j, ro);
         }
@@ -792,7 +802,7 @@ TMPC_HD void stage_linearise(const Dims &d, const double *z, const double *p, in
     double spsi, cpsi;
     sincos(z[ZPSI], &spsi, &cpsi);
     if (part != 1) {
-        for (int j = 0; j < d.n_slk; j++) {
+        for (int j = ell_first(); j < d.n_slk; j += ell_step) {
             slk_row_eval(d, z, p + own_delta, pstride, j, off, spsi, cpsi, slack, ro);
             W[ZPSI][ZPSI] += lamh(d.n_lin + j) * ro.Hpp;          // the row is linear in (x, y); psi enters through the disc offset
             sink(d.n_lin + j, ro);
@@ -803,7 +813,7 @@ TMPC_HD void stage_linearise(const Dims &d, const double *z, const double *p, in
         const int j0 = part == 2 ? d.M / 2 : 0, j1 = part == 1 ? d.M / 2 : d.M;
         double risk_of = -1.0, ye = 0.0;                      // (Gaussian rows) the quantile of the last risk level seen: one level per configuration
         (void)risk_of; (void)ye;                              // in the reference (CONFIG probabilistic/risk), so it is evaluated once per stage, not once per row
-        for (int j = j0; j < j1; j++) {
+        for (int j = j0 + ell_first(); j < j1; j += ell_step) {
             if constexpr (cm_gaussian_rows(CM)) {
                 const double risk = TMPC_LDP(p + (size_t)ip_gauss(d, j, 4) * pstride);
                 if (risk != risk_of) { ye = gauss_quantile(risk); risk_of = risk; }
