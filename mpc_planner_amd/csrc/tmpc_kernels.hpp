@@ -804,7 +804,11 @@ __device__ __forceinline__ void linearise(const Lds &L, const Dims &d, int tid, 
     // multiplied by zero on a helper).  The rest of the stage (dynamics, cost, halfspace rows) is computed redundantly by all three -- same
     // instructions, no extra issue slots.  The sum of the three shares associates differently from the sequential
     // sum over the rows (rounding level).  `split`: the wave has the lanes and the exchange buffer lies clear of the staging region.
+#ifdef TMPC_GENERATED_STAGE
+    const bool split = false;                            // (emitted stage functions evaluate all their rows in one piece: tmpc_gen::rows has no notion of a share)
+#else
     const bool split = FAST && NTH == 64 && 3 * N <= 64 && L.nh >= 3 && L.dv >= L.beta + 2 * N * L.nh;
+#endif
     const bool helper = split && tid_l >= N && tid_l < 3 * N;
     const int k = owner ? tid_l : (helper ? (tid_l >= 2 * N ? tid_l - 2 * N : tid_l - N) : N - 1);
     auto ell_first = [&]() { return split ? (tid_l >= N ? 1 : 0) + (tid_l >= 2 * N ? 1 : 0) : 0; };     // the lane's group: owner 0, helpers 1 and 2
