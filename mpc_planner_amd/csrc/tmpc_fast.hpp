@@ -221,7 +221,7 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
                 const double sgn = (r < NLIN_) ? -1.0 : 1.0;    // topology / slack rows: upper bound 0; ellipsoids: lower bound 1
                 if constexpr (STORE_IDX) {
                     if constexpr (CP) {
-                        didx_[s] = k * L.dstride + (r < L.n_pair ? 2 * r : 3 * r - L.n_pair);
+                        didx_[s] = mul24(k, L.dstride) + (r < L.n_pair ? 2 * r : 3 * r - L.n_pair);
                         if constexpr (STORE_IDX2) didx2_[s] = r >= L.n_pair ? didx_[s] + 2 : N * L.dstride + 2;
                     } else didx_[s] = (k * NH + r) * 3;
                 }
@@ -237,7 +237,7 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
                 for (int i = 0; i < NV; i++) if (i == vr) bnd = up ? d.ub[i] : d.lb[i];
                 box |= 1u << s; if (up) upper |= 1u << s;
                 varpack |= (unsigned long long)vr << (3 * s);
-                sb[s] = sgn * (bnd - L.z[k * NV + vr]);
+                sb[s] = sgn * (bnd - L.z[mul24(k, NV) + vr]);
                 if (q < 4 || k >= 1) act |= 1u << s;            // x_0 is fixed, not boxed
             }
         }
@@ -248,7 +248,7 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
     auto DIDX = [&](int s) {
         if constexpr (STORE_IDX) return didx_[STORE_IDX ? s : 0];
         const int r = c + LPS * s;
-        if constexpr (CP) return (stage_lane && r < NH) ? k * L.dstride + (r < L.n_pair ? 2 * r : 3 * r - L.n_pair) : N * L.dstride;
+        if constexpr (CP) return (stage_lane && r < NH) ? mul24(k, L.dstride) + (r < L.n_pair ? 2 * r : 3 * r - L.n_pair) : N * L.dstride;
         return (stage_lane && r < NH) ? (k * NH + r) * 3 : N * NH * 3;
     };
     // third entry of the row's Jacobian: packed rows (topology) have none -- they read the 0.0 of the zero triple, so that the
@@ -319,12 +319,12 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
                                                     // budget of the two-waves-per-SIMD instantiations
     double invt_[LEAN ? 1 : RPL];               // the row residual r_d = c.v - sb - t is recomputed where needed
     {
-        const double vx = L.v[kk * NV + ZX], vy = L.v[kk * NV + ZY], vp = L.v[kk * NV + ZPSI];
+        const double vx = L.v[mul24(kk, NV) + ZX], vy = L.v[mul24(kk, NV) + ZY], vp = L.v[mul24(kk, NV) + ZPSI];
         static_for<0, RPL>([&](auto s_) {
             constexpr int s = decltype(s_)::value;
             double c0s, c1s, c2s;
             coef(s_, c0s, c1s, c2s);
-            const double r0 = rowdot(s_, c0s, c1s, c2s, vx, vy, vp, L.v + kk * NV) - sb[s];
+            const double r0 = rowdot(s_, c0s, c1s, c2s, vx, vy, vp, L.v + mul24(kk, NV)) - sb[s];
             t[s] = r0 > d.thr0 ? r0 : d.thr0;
             if constexpr (!LEAN) invt_[s] = rcp_nr(t[s]);
             lam[s] = ACT(s_) ? d.mu0 / t[s] : 0.0;
@@ -349,16 +349,16 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
             // (clamped indices) ahead of the arithmetic and pinned there -- a `cond ? lds[i] : 0` is a branch and a wait per load, and
             // the scheduler sinks unpinned loads next to their uses.  Same sums in the same order as the compact form below.
             for (int e = tl; e < (N + 1) * NV; e += NT) {
-                const int ks = e / NV, i = e - ks * NV;
+                const int ks = e / NV, i = e - mul24(ks, NV);
                 const bool skip = (ks == N && i < NU) || (ks == 0 && i >= NU);
                 const int kb = ks < N ? ks : N - 1;
-                const double *Wk = L.W + ks * NP28, *vk = L.v + ks * NV, *BA = L.BA + kb * NX * NV, *pn = L.pq + (kb + 1) * NX;
+                const double *Wk = L.W + mul24(ks, NP28), *vk = L.v + mul24(ks, NV), *BA = L.BA + mul24(kb, NX) * NV, *pn = L.pq + mul24(kb + 1, NX);
                 double ge = L.g[e], wv[NV], vv[NV], bav[NX], pv[NX];
 #pragma unroll
                 for (int j = 0; j < NV; j++) { wv[j] = Wk[sidx(i, j)]; vv[j] = vk[j]; }
 #pragma unroll
                 for (int l = 0; l < NX; l++) { bav[l] = BA[l * NV + i]; pv[l] = pn[l]; }
-                const double pm = L.pq[(ks >= 1 ? ks : 1) * NX + (i >= NU ? i - NU : 0)];
+                const double pm = L.pq[mul24(ks >= 1 ? ks : 1, NX) + (i >= NU ? i - NU : 0)];
                 scan::loads_done();
                 double acc = ge;
 #pragma unroll
@@ -372,8 +372,8 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
                 L.rg[e] = acc; L.gh[e] = acc;
             }
             for (int e = tl; e < N * NX; e += NT) {
-                const int ks = e / NX, i = e - ks * NX;
-                const double *vk = L.v + ks * NV, *BA = L.BA + ks * NX * NV + i * NV;
+                const int ks = e / NX, i = e - mul24(ks, NX);
+                const double *vk = L.v + mul24(ks, NV), *BA = L.BA + mul24(ks, NX) * NV + i * NV;
                 double be = L.b[e], vn = L.v[(ks + 1) * NV + NU + i], bav[NV], vv[NV];
 #pragma unroll
                 for (int j = 0; j < NV; j++) { bav[j] = BA[j]; vv[j] = vk[j]; }
@@ -396,22 +396,22 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
             const int kb = ks < N ? ks : N - 1;            // stage whose [B A], pi_{k+1}, b the node reads
             double w[NP28], vk[NV], pn[NX], po[NX], d8[8], gk[NV], bk[NX], vn[NX];
             {
-                const double *Wg = L.W + ks * NP28;
+                const double *Wg = L.W + mul24(ks, NP28);
 #pragma unroll
                 for (int e = 0; e < NP28; e++) w[e] = Wg[e];
 #pragma unroll
-                for (int j = 0; j < NV; j++) { vk[j] = L.v[ks * NV + j]; gk[j] = L.g[ks * NV + j]; }
+                for (int j = 0; j < NV; j++) { vk[j] = L.v[mul24(ks, NV) + j]; gk[j] = L.g[mul24(ks, NV) + j]; }
 #pragma unroll
                 for (int l = 0; l < NX; l++) {
-                    pn[l] = L.pq[(kb + 1) * NX + l]; po[l] = L.pq[(ks >= 1 ? ks : 1) * NX + l];
-                    bk[l] = L.b[kb * NX + l]; vn[l] = L.v[(kb + 1) * NV + NU + l];
+                    pn[l] = L.pq[mul24(kb + 1, NX) + l]; po[l] = L.pq[mul24(ks >= 1 ? ks : 1, NX) + l];
+                    bk[l] = L.b[mul24(kb, NX) + l]; vn[l] = L.v[mul24(kb + 1, NV) + NU + l];
                 }
 #pragma unroll
                 for (int q = 0; q < 8; q++) d8[q] = L.tab[kb * 8 + q];
             }
             if (nd) {
 #pragma unroll
-                for (int e = 0; e < NP28; e++) L.Hh[ks * NP28 + e] = w[e];
+                for (int e = 0; e < NP28; e++) L.Hh[mul24(ks, NP28) + e] = w[e];
             }
             const double dtc = d.dt, sdtc = d.sdt, shc = d.shdt2;      // (spline row of [B A]: zero for the model without a spline state)
             const double Xa = d8[D8_XA], Xw = d8[D8_XW], Xp = d8[D8_XP], Xv = d8[D8_XV], Ya = d8[D8_YA], Yw = d8[D8_YW], Yp = d8[D8_YP], Yv = d8[D8_YV];
@@ -438,7 +438,7 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
                 if (i >= NU && ks >= 1) acc -= po[i - NU];
                 const bool skip = (ks == N && i < NU) || (ks == 0 && i >= NU);
                 acc = skip ? 0.0 : acc;
-                if (nd) { L.rg[ks * NV + i] = acc; L.gh[ks * NV + i] = acc; }
+                if (nd) { L.rg[mul24(ks, NV) + i] = acc; L.gh[mul24(ks, NV) + i] = acc; }
             }
             {                                              // rb = b + [B A] v_k - dx_{k+1}, row by row
                 double rbk[NX];
@@ -449,7 +449,7 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
                 rbk[4] = (((bk[4] - vn[4]) + shc * vk[ZA]) + sdtc * vk[ZV]) + vk[ZS];
                 if (tl < N) {
 #pragma unroll
-                    for (int i = 0; i < NX; i++) { L.rb[ks * NX + i] = rbk[i]; res_b = fmax(res_b, fabs(rbk[i])); }
+                    for (int i = 0; i < NX; i++) { L.rb[mul24(ks, NX) + i] = rbk[i]; res_b = fmax(res_b, fabs(rbk[i])); }
                 }
             }
         }
@@ -459,7 +459,7 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
         // ---- row pass R (registers): residuals, rg -= lam c, Hh += d c c^T, gh += d rd c ----
         ROW_PASS_BEGIN();
         {
-            const double vx = L.v[kk * NV + ZX], vy = L.v[kk * NV + ZY], vp = L.v[kk * NV + ZPSI];
+            const double vx = L.v[mul24(kk, NV) + ZX], vy = L.v[mul24(kk, NV) + ZY], vp = L.v[mul24(kk, NV) + ZPSI];
             double gs0 = 0, gs1 = 0, gs2 = 0, rs0 = 0, rs1 = 0, rs2 = 0;
             double h00 = 0, h10 = 0, h11 = 0, h20 = 0, h21 = 0, h22 = 0;
             static_for<0, RPL>([&](auto s_) {
@@ -468,7 +468,7 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
                 const bool a = ACT(s_);
                 double c0s, c1s, c2s;
                 coef(s_, c0s, c1s, c2s);
-                const double r = rowdot(s_, c0s, c1s, c2s, vx, vy, vp, L.v + kk * NV) - sb[s] - t[s];
+                const double r = rowdot(s_, c0s, c1s, c2s, vx, vy, vp, L.v + mul24(kk, NV)) - sb[s] - t[s];
                 const double rds = a ? r : 0.0;
                 const double comp = lam[s] * t[s];
                 const double dd = lam[s] * INVT(s);
@@ -485,16 +485,16 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
                     if (a && (K == 1 || (box >> s & 1))) {                // box row: one variable
                         const int vr = VARK(s_);
                         const double cus = CUK(s_);
-                        lds_add(&L.rg[k * NV + vr], -lam[s] * cus);
-                        lds_add(&L.gh[k * NV + vr], w * cus);
-                        lds_add(&L.Hh[k * NP28 + pidx(vr, vr)], dd);
+                        lds_add(&L.rg[mul24(k, NV) + vr], -lam[s] * cus);
+                        lds_add(&L.gh[mul24(k, NV) + vr], w * cus);
+                        lds_add(&L.Hh[mul24(k, NP28) + pidx(vr, vr)], dd);
                     }
                 }
             });
             if (stage_lane) {
-                lds_add(&L.rg[k * NV + ZX], -gs0); lds_add(&L.rg[k * NV + ZY], -gs1); lds_add(&L.rg[k * NV + ZPSI], -gs2);
-                lds_add(&L.gh[k * NV + ZX], rs0); lds_add(&L.gh[k * NV + ZY], rs1); lds_add(&L.gh[k * NV + ZPSI], rs2);
-                double *Hk = L.Hh + k * NP28;
+                lds_add(&L.rg[mul24(k, NV) + ZX], -gs0); lds_add(&L.rg[mul24(k, NV) + ZY], -gs1); lds_add(&L.rg[mul24(k, NV) + ZPSI], -gs2);
+                lds_add(&L.gh[mul24(k, NV) + ZX], rs0); lds_add(&L.gh[mul24(k, NV) + ZY], rs1); lds_add(&L.gh[mul24(k, NV) + ZPSI], rs2);
+                double *Hk = L.Hh + mul24(k, NP28);
                 lds_add(&Hk[pidx(ZX, ZX)], h00); lds_add(&Hk[pidx(ZY, ZX)], h10); lds_add(&Hk[pidx(ZY, ZY)], h11);
                 lds_add(&Hk[pidx(ZPSI, ZX)], h20); lds_add(&Hk[pidx(ZPSI, ZY)], h21); lds_add(&Hk[pidx(ZPSI, ZPSI)], h22);
             }
@@ -534,8 +534,8 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
             const bool a = ACT(s_);
             double c0s, c1s, c2s;
             coef(s_, c0s, c1s, c2s);
-            const double rds = rowdot(s_, c0s, c1s, c2s, vx, vy, vp, L.v + kk * NV) - sb[s] - t[s];
-            const double ddot = rowdot(s_, c0s, c1s, c2s, dx, dy, dp, L.dv + kk * NV);
+            const double rds = rowdot(s_, c0s, c1s, c2s, vx, vy, vp, L.v + mul24(kk, NV)) - sb[s] - t[s];
+            const double ddot = rowdot(s_, c0s, c1s, c2s, dx, dy, dp, L.dv + mul24(kk, NV));
             return a ? ddot + rds : 0.0;
         };
         double dt_[DIET_DT ? 1 : RPL];                   // row steps (stored unless DIET_DT)
@@ -548,8 +548,8 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
         if (active) {
         ROW_PASS_BEGIN();
         {
-            const double dx = L.dv[kk * NV + ZX], dy = L.dv[kk * NV + ZY], dp = L.dv[kk * NV + ZPSI];
-            const double vx = L.v[kk * NV + ZX], vy = L.v[kk * NV + ZY], vp = L.v[kk * NV + ZPSI];
+            const double dx = L.dv[mul24(kk, NV) + ZX], dy = L.dv[mul24(kk, NV) + ZY], dp = L.dv[mul24(kk, NV) + ZPSI];
+            const double vx = L.v[mul24(kk, NV) + ZX], vy = L.v[mul24(kk, NV) + ZY], vp = L.v[mul24(kk, NV) + ZPSI];
             static_for<0, RPL>([&](auto s_) {
                 constexpr int s = decltype(s_)::value;
                 const bool a = ACT(s_);
@@ -579,8 +579,8 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
         ROW_PASS_BEGIN();
         {
             double cs0 = 0, cs1 = 0, cs2 = 0;
-            const double dx = L.dv[kk * NV + ZX], dy = L.dv[kk * NV + ZY], dp = L.dv[kk * NV + ZPSI];   // predictor direction
-            const double vx = L.v[kk * NV + ZX], vy = L.v[kk * NV + ZY], vp = L.v[kk * NV + ZPSI];
+            const double dx = L.dv[mul24(kk, NV) + ZX], dy = L.dv[mul24(kk, NV) + ZY], dp = L.dv[mul24(kk, NV) + ZPSI];   // predictor direction
+            const double vx = L.v[mul24(kk, NV) + ZX], vy = L.v[mul24(kk, NV) + ZY], vp = L.v[mul24(kk, NV) + ZPSI];
             static_for<0, RPL>([&](auto s_) {
                 constexpr int s = decltype(s_)::value;
                 constexpr int K = C::template KIND<s>;
@@ -590,12 +590,12 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
                 qt[s] = a ? lam[s] + (dta * dl - sigma * mu) * INVT(s) : 0.0;
                 double c0s, c1s, c2s;
                 coef(s_, c0s, c1s, c2s);
-                const double rr = rowdot(s_, c0s, c1s, c2s, vx, vy, vp, L.v + kk * NV) - sb[s] - t[s];
+                const double rr = rowdot(s_, c0s, c1s, c2s, vx, vy, vp, L.v + mul24(kk, NV)) - sb[s] - t[s];
                 const double w = qt[s] + lam[s] * INVT(s) * (a ? rr : 0.0);
                 if constexpr (K != 1) { cs0 += w * c0s; cs1 += w * c1s; cs2 += w * c2s; }
-                if constexpr (K != 0) { if (a && (K == 1 || (box >> s & 1))) lds_add(&L.gh[k * NV + VARK(s_)], w * CUK(s_)); }
+                if constexpr (K != 0) { if (a && (K == 1 || (box >> s & 1))) lds_add(&L.gh[mul24(k, NV) + VARK(s_)], w * CUK(s_)); }
             });
-            if (stage_lane) { lds_add(&L.gh[k * NV + ZX], cs0); lds_add(&L.gh[k * NV + ZY], cs1); lds_add(&L.gh[k * NV + ZPSI], cs2); }
+            if (stage_lane) { lds_add(&L.gh[mul24(k, NV) + ZX], cs0); lds_add(&L.gh[mul24(k, NV) + ZY], cs1); lds_add(&L.gh[mul24(k, NV) + ZPSI], cs2); }
         }
         team.sync();
         }
@@ -605,8 +605,8 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
         if (active) {
         gmax = 0.0;
         ROW_PASS_BEGIN();
-        const double dxc = L.dv[kk * NV + ZX], dyc = L.dv[kk * NV + ZY], dpc = L.dv[kk * NV + ZPSI];
-        const double vxc = L.v[kk * NV + ZX], vyc = L.v[kk * NV + ZY], vpc = L.v[kk * NV + ZPSI];
+        const double dxc = L.dv[mul24(kk, NV) + ZX], dyc = L.dv[mul24(kk, NV) + ZY], dpc = L.dv[mul24(kk, NV) + ZPSI];
+        const double vxc = L.v[mul24(kk, NV) + ZX], vyc = L.v[mul24(kk, NV) + ZY], vpc = L.v[mul24(kk, NV) + ZPSI];
         static_for<0, RPL>([&](auto s_) {
             constexpr int s = decltype(s_)::value;
             const bool a = ACT(s_);

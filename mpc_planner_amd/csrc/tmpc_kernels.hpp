@@ -335,6 +335,17 @@ __device__ __forceinline__ void static_for(F &&f)
 {
     if constexpr (A < B) { f(std::integral_constant<int, A>{}); static_for<A + 1, B>(f); }
 }
+// Index arithmetic of the sequential sweeps.  A 32-bit integer multiply (v_mul_lo_u32, and the v_mad_u64_u32 the compiler picks for
+// `uniform * constant + per-lane offset`) is a QUARTER-rate instruction: 16 cycles of a SIMD that issues an f64 FMA in 4.  The sweeps' stage loops
+// had 2-5 of them per stage step (5 of the factor loop's 138 instructions, but 80 of its ~630 issue cycles).  mul24: per-lane stride x stage
+// index, both far below 2^24 -> v_mul_u32_u24 / v_mad_u32_u24 (full rate).  uni: a wave-uniform product is kept in an SGPR (s_mul_i32) and only
+// added on the vector side.
+__device__ __forceinline__ int mul24(int a, int b) { return (int)__umul24((unsigned)a, (unsigned)b); }
+#ifdef TMPC_EXP_NO_UNI
+__device__ __forceinline__ int uni(int x) { return x; }
+#else
+__device__ __forceinline__ int uni(int x) { asm volatile("" : "+s"(x)); return x; }
+#endif
 // 1/sqrt(d) for d > 0: v_rsq_f64 seed (5e-8 relative, measured) + one third-order (Halley) step: with e = 1 - d y^2,
 // y (1 + e/2 + 3 e^2/8) leaves an error of order e^3 -- full double precision in five dependent operations, where two Newton steps
 // take eight (this sits on the critical chain of the Cholesky: seven pivots per stage)
@@ -938,7 +949,8 @@ __device__ __forceinline__ void solve_epilogue(const Lds &L, const Dims &d, int 
     cost = wave_sum(cost); res = wave_max(res);              // contributions live in lanes < N + NX <= 64: wave 0 holds the totals
     const int nxe = ext_nx(d);
     for (int e = tid_o; e < (N + 1) * nxe; e += nth) {
-        const int k = e / nxe, i = e - k * nxe;
+        const int k = d.slack ? e / (NX + 1) : e / NX, i = e - k * nxe;     // (two divisions by constants: a division by the run-time nxe keeps its
+                                                                             //  reciprocal live across the persistent kernels' whole trajectory loop)
         TMPC_ST_OUT(xtraj + (size_t)b * (N + 1) * nxe + e, i < NX ? L.z[k * NV + NU + i] : slack);      // the pinned slack state
     }
     for (int e = tid_o; e < N * NU; e += nth) {

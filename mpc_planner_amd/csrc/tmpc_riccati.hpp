@@ -59,6 +59,17 @@ __device__ unsigned long long g_sweep_prof[SP_COUNT];
 //   [0..9]  Lxu (5x2, row-major)   [10] L10   [11] 1/L00   [12] 1/L11   [13..27] P_k (packed lower 5x5)
 constexpr int FB_LXU = 0, FB_L10 = 10, FB_R0 = 11, FB_R1 = 12, FB_P = 13;
 
+// (The sequential sweeps use lanes 0..7 of the wave and rows 1..3 run along on copies.  Switching those rows off for the sweeps -- the LDS unit is
+// busy 70 % of the kernel time at eight trajectories per CU and the sweeps issue two thirds of its instructions -- was measured in round 5: 1.3 %
+// SLOWER, profiles/round5_o_sweep_rows_ab.jsonl; an LDS instruction costs the same with 16 lanes as with 64 and the EXEC changes are not free.)
+#ifndef TMPC_FACTOR_UNROLL
+#if defined(TMPC_TU_COMPACT) || defined(TMPC_TU_CP2) || defined(TMPC_SINGLE_COMPACT)
+#define TMPC_FACTOR_UNROLL 0                         // two waves per SIMD: see riccati_factor_rows
+#else
+#define TMPC_FACTOR_UNROLL 1
+#endif
+#endif
+
 // right-looking elimination of columns C0 .. C1-1 of the row-per-lane matrix
 template <int C0, int C1 = NV>
 __device__ __forceinline__ bool chol_rows(double (&f)[NV], int lane, double *r0, double *r1)
@@ -135,18 +146,26 @@ __device__ __forceinline__ bool riccati_factor_rows(const Lds &L, const Dims &d,
     const int i5 = li - NU;                          // state index of lanes 2..6
     const double dt = d.dt, sdt = d.sdt, shdt2 = d.shdt2;      // (sdt, shdt2: the spline row of [B A]; zero for the model without a spline state)
     bool bad = false;
-    double f[NV], hk[NV], ba[NX], dn[8];
+    // Operands of a stage.  The operands of stage k - 1 are loaded while stage k still needs some of its own (the scheduler computes rows 2..6 of
+    // F after the pivots), so two register sets are live and the compiler copies the shadow set over at the back edge: 11 v_mov_b64 of the loop's
+    // 138 instructions.  TMPC_FACTOR_UNROLL = 1 names the two sets and unrolls the stage loop by two (like the vector sweeps): no copies, 129
+    // instructions per stage, 4 % fewer cycles per factorisation on a lone wave -- and 0.7 % LESS throughput on the saturated compact kernel
+    // (profiles/round5_m_factor_unroll_rotation_ab.jsonl).  So the translation units of the one-wave-per-SIMD kernels (fast, profiled twins)
+    // build the unrolled loop, those of the compact kernels (two waves per SIMD) the rolled one; the arithmetic is the same.
+    struct Opnd { double hk[NV], ba[NX], dn[8]; };
+    double f[NV];
     const BaLane bc = ba_column(N, ls);
+    double bac[NX];
     if constexpr (CP && !VEC) {                          // constant entries of the own column of [B A]
 #pragma unroll
-        for (int m = 2; m < NX; m++) ba[m] = L.tab[ba_off(N, 0, m, ls)];
+        for (int m = 2; m < NX; m++) bac[m] = L.tab[ba_off(N, 0, m, ls)];
     }
     // VEC: every lane loads hk[] / ba[] through per-lane (pointer, stride) pairs, so that the extra row reads gh / rb with the same loads.
     // Running pointers, stepped back by the lane's stride once per stage (round 4: the k * stride multiplications and per-entry index
     // arithmetic were ~17 of the stage loop's ~250 instructions): a lane reads hk[j] = row[j] at IMMEDIATE offsets from the start of its row of
     // the packed Hh block -- the entries j > own row index belong to the next row and are never used (chol_rows reads the lower triangle only).
     // (the same for ba[] -- running offsets or pointers, five more values live across the stage loop -- pushed the compact kernels into scratch
-    // twice: ba[] keeps its (base + k * stride) form, which the compiler rematerialises)
+    // twice: ba[] keeps its (base + k * stride) form, which the compiler rematerialises; mul24: tmpc_kernels.hpp)
     const double *hrow = nullptr;
     int hstep = 0;
     const double *bbase = CP ? L.tab : L.BA;
@@ -164,43 +183,46 @@ __device__ __forceinline__ bool riccati_factor_rows(const Lds &L, const Dims &d,
     auto seek_stage = [&](int k) {
         if constexpr (VEC) hrow += k * hstep;
     };
-    auto load_stage = [&](int k, bool step) {
+    auto load_stage = [&](Opnd &o, int k, bool step) {
         // unconditional loads (clamped indices): entries above the diagonal / of idle lanes are never used
         if constexpr (VEC) {
 #pragma unroll
-            for (int j = 0; j < NV; j++) hk[j] = hrow[j];
+            for (int j = 0; j < NV; j++) o.hk[j] = hrow[j];
 #pragma unroll
-            for (int m = 0; m < NX; m++) ba[m] = bbase[bo[m] + k * bst[m]];
+            for (int m = 0; m < NX; m++) o.ba[m] = bbase[bo[m] + mul24(k, bst[m])];
 #pragma unroll
-            for (int q = 0; q < 8; q++) dn[q] = (CP ? L.tab : L.dyn8)[k * 8 + q];
+            for (int q = 0; q < 8; q++) o.dn[q] = (CP ? L.tab : L.dyn8)[k * 8 + q];
             if (step) hrow -= hstep;
         } else {
             const double *Hk = L.Hh + k * NP28;
 #pragma unroll
-            for (int j = 0; j < NV; j++) hk[j] = Hk[pidx(ls, j <= ls ? j : ls)];
+            for (int j = 0; j < NV; j++) o.hk[j] = Hk[pidx(ls, j <= ls ? j : ls)];
             if constexpr (CP) {
-                ba[0] = L.tab[bc.o0 + k * bc.st]; ba[1] = L.tab[bc.o1 + k * bc.st];
+                o.ba[0] = L.tab[bc.o0 + mul24(k, bc.st)]; o.ba[1] = L.tab[bc.o1 + mul24(k, bc.st)];
 #pragma unroll
-                for (int q = 0; q < 8; q++) dn[q] = L.tab[k * 8 + q];
+                for (int m = 2; m < NX; m++) o.ba[m] = bac[m];
+#pragma unroll
+                for (int q = 0; q < 8; q++) o.dn[q] = L.tab[k * 8 + q];
             } else {
                 const double *BA = L.BA + k * NX * NV;
 #pragma unroll
-                for (int m = 0; m < NX; m++) ba[m] = BA[m * NV + ls];
+                for (int m = 0; m < NX; m++) o.ba[m] = BA[m * NV + ls];
 #pragma unroll
-                for (int q = 0; q < 8; q++) dn[q] = L.dyn8[k * 8 + q];
+                for (int q = 0; q < 8; q++) o.dn[q] = L.dyn8[k * 8 + q];
             }
         }
     };
     // terminal node: P_N = the xx-block of Hh_N (rows/cols 2..6) as it is; the extra row starts as p_N = g_x of node N
 #pragma unroll
     for (int j = 0; j < NV; j++) f[j] = (j >= NU) ? (vec ? L.gh[N * NV + j] : L.Hh[N * NP28 + pidx(ls, j <= ls ? j : ls)]) : 0.0;
+    Opnd oa, ob;
     seek_stage(N - 1);
-    load_stage(N - 1, true);
+    load_stage(oa, N - 1, true);
     if (vec && wr) {
 #pragma unroll
         for (int l = 0; l < NX; l++) L.pr[N * NX + l] = f[NU + l];          // p_N
     }
-    for (int k = N - 1; k >= 0; k--) {
+    auto stage = [&](const Opnd &o, Opnd &nx, int k) {
         // broadcast P (lower triangle of the 5x5 cost-to-go Hessian of stage k+1: rows 2..6 after the elimination) to every lane of the row
         double Pm[NX][NX];
         static_for<0, NX>([&](auto m_) {
@@ -219,26 +241,26 @@ __device__ __forceinline__ bool riccati_factor_rows(const Lds &L, const Dims &d,
         double w[NX];
 #pragma unroll
         for (int n = 0; n < NX; n++) {
-            double acc = Pm[n > 0 ? n : 0][0] * ba[0];
+            double acc = Pm[n > 0 ? n : 0][0] * o.ba[0];
 #pragma unroll
-            for (int m = 1; m < NX; m++) acc = fma(Pm[m > n ? m : n][m > n ? n : m], ba[m], acc);
+            for (int m = 1; m < NX; m++) acc = fma(Pm[m > n ? m : n][m > n ? n : m], o.ba[m], acc);
             w[n] = VEC ? fma(vmask, f[NU + n], acc) : acc;
         }
         // F row `li`: F_ij = Hh_ij + sum_n w_n [B A]_nj with the sparse columns of [B A] (row-uniform):
         //   x: e0   y: e1   s: e4   psi: (Xp,Yp,1,0,0)   v: (Xv,Yv,0,1,dt)   a: (Xa,Ya,0,dt,dt^2/2)   w: (Xw,Yw,dt,0,0)
         {
-            const double Xa = dn[D8_XA], Xw = dn[D8_XW], Xp = dn[D8_XP], Xv = dn[D8_XV];
-            const double Ya = dn[D8_YA], Yw = dn[D8_YW], Yp = dn[D8_YP], Yv = dn[D8_YV];
-            f[ZA] = fma(w[4], shdt2, fma(w[3], dt, fma(w[1], Ya, fma(w[0], Xa, hk[ZA]))));
-            f[ZW] = fma(w[2], dt, fma(w[1], Yw, fma(w[0], Xw, hk[ZW])));
-            f[ZX] = hk[ZX] + w[0];
-            f[ZY] = hk[ZY] + w[1];
-            f[ZPSI] = fma(w[1], Yp, fma(w[0], Xp, hk[ZPSI])) + w[2];
-            f[ZV] = fma(w[4], sdt, fma(w[1], Yv, fma(w[0], Xv, hk[ZV])) + w[3]);
-            f[ZS] = hk[ZS] + w[4];
+            const double Xa = o.dn[D8_XA], Xw = o.dn[D8_XW], Xp = o.dn[D8_XP], Xv = o.dn[D8_XV];
+            const double Ya = o.dn[D8_YA], Yw = o.dn[D8_YW], Yp = o.dn[D8_YP], Yv = o.dn[D8_YV];
+            f[ZA] = fma(w[4], shdt2, fma(w[3], dt, fma(w[1], Ya, fma(w[0], Xa, o.hk[ZA]))));
+            f[ZW] = fma(w[2], dt, fma(w[1], Yw, fma(w[0], Xw, o.hk[ZW])));
+            f[ZX] = o.hk[ZX] + w[0];
+            f[ZY] = o.hk[ZY] + w[1];
+            f[ZPSI] = fma(w[1], Yp, fma(w[0], Xp, o.hk[ZPSI])) + w[2];
+            f[ZV] = fma(w[4], sdt, fma(w[1], Yv, fma(w[0], Xv, o.hk[ZV])) + w[3]);
+            f[ZS] = o.hk[ZS] + w[4];
         }
-        load_stage(k > 0 ? k - 1 : 0, k > 1);         // operands of the next stage, hidden under the elimination (unconditional, clamped: a branch here costs a second register
-                                                      // set; the pointers stop at stage 0, which the last pass re-loads and discards)
+        load_stage(nx, k > 0 ? k - 1 : 0, k > 1);     // operands of the next stage, hidden under the elimination (unconditional, clamped;
+                                                      // the pointers stop at stage 0, which the last pass re-loads and discards)
         double r0 = 0.0, r1 = 0.0;
         bad |= chol_rows<0, NU>(f, li, &r0, &r1);     // the two input columns; rows 2..6 now hold P_k (lanes 2..6) / p_k (the extra row)
         if (rowl) {
@@ -251,7 +273,17 @@ __device__ __forceinline__ bool riccati_factor_rows(const Lds &L, const Dims &d,
 #pragma unroll
             for (int l = 0; l < NX; l++) L.pr[k * NX + l] = f[NU + l];
         }
+    };
+#if TMPC_FACTOR_UNROLL
+    int k = N - 1;
+    for (; k >= 1; k -= 2) {
+        stage(oa, ob, k);
+        stage(ob, oa, k - 1);
     }
+    if (k == 0) stage(oa, ob, 0);
+#else
+    for (int k = N - 1; k >= 0; k--) stage(oa, oa, k);      // (one named set, re-loaded after its last use in source order)
+#endif
     return bad;
 }
 
@@ -285,8 +317,8 @@ __device__ __forceinline__ void riccati_solve_pre(const Lds &L, const Dims &d, i
 {
     const int N = d.N;
     for (int k = tid; k < N; k += nth) {
-        const double *Pn = L.Hh + (k + 1) * NP28 + FB_P;              // P_{k+1}, packed lower triangle
-        const double *r = L.rb + k * NX;
+        const double *Pn = L.Hh + mul24(k + 1, NP28) + FB_P;              // P_{k+1}, packed lower triangle
+        const double *r = L.rb + mul24(k, NX);
         double pp[15], rr[NX];
 #pragma unroll
         for (int e = 0; e < 15; e++) pp[e] = Pn[e];
@@ -297,7 +329,7 @@ __device__ __forceinline__ void riccati_solve_pre(const Lds &L, const Dims &d, i
             double acc = 0.0;
 #pragma unroll
             for (int m = 0; m < NX; m++) acc += pp[(m > i ? m * (m + 1) / 2 + i : i * (i + 1) / 2 + m)] * rr[m];
-            L.dpi[(k + 1) * NX + i] = acc;
+            L.dpi[mul24(k + 1, NX) + i] = acc;
         }
     }
 }
@@ -307,19 +339,19 @@ __device__ __forceinline__ void riccati_solve_post(const Lds &L, const Dims &d, 
     const int N = d.N;
     for (int kk = tid; kk < N; kk += nth) {
         const int k = kk + 1;
-        const double *Pk = L.Hh + k * NP28 + FB_P;
-        const double *dxk = L.dv + k * NV + NU;
+        const double *Pk = L.Hh + mul24(k, NP28) + FB_P;
+        const double *dxk = L.dv + mul24(k, NV) + NU;
         double pp[15], rr[NX], pk[NX];
 #pragma unroll
         for (int e = 0; e < 15; e++) pp[e] = Pk[e];
 #pragma unroll
-        for (int m = 0; m < NX; m++) { rr[m] = dxk[m]; pk[m] = L.pr[k * NX + m]; }
+        for (int m = 0; m < NX; m++) { rr[m] = dxk[m]; pk[m] = L.pr[mul24(k, NX) + m]; }
 #pragma unroll
         for (int i = 0; i < NX; i++) {
             double acc = 0.0;
 #pragma unroll
             for (int m = 0; m < NX; m++) acc += pp[(m > i ? m * (m + 1) / 2 + i : i * (i + 1) / 2 + m)] * rr[m];
-            L.dpi[k * NX + i] = acc + pk[i];
+            L.dpi[mul24(k, NX) + i] = acc + pk[i];
         }
     }
 }
@@ -354,9 +386,9 @@ __device__ __forceinline__ void riccati_sweeps_rows(const Lds &L, const Dims &d,
         }
         auto load_stage = [&](Ops &o, int k) {
             const double *Fb = L.Hh + k * NP28;
-            o.ghj = L.gh[k * NV + ls];
+            o.ghj = L.gh[uni(k * NV) + ls];
             if constexpr (CP) {
-                o.ba[0] = L.tab[bc.o0 + k * bc.st]; o.ba[1] = L.tab[bc.o1 + k * bc.st];
+                o.ba[0] = L.tab[bc.o0 + mul24(k, bc.st)]; o.ba[1] = L.tab[bc.o1 + mul24(k, bc.st)];
 #pragma unroll
                 for (int l = 2; l < NX; l++) o.ba[l] = bac[l];
             } else {
@@ -366,7 +398,7 @@ __device__ __forceinline__ void riccati_sweeps_rows(const Lds &L, const Dims &d,
             }
             o.r0 = Fb[FB_R0]; o.l10 = Fb[FB_L10]; o.r1 = Fb[FB_R1];
             o.lx0 = Fb[FB_LXU + 2 * i5]; o.lx1 = Fb[FB_LXU + 2 * i5 + 1];
-            o.q = L.dpi[(k + 1) * NX + i5];
+            o.q = L.dpi[uni((k + 1) * NX) + i5];
         };
         auto stage = [&](const Ops &o, int k) {
             const double Pb = p + o.q;                                     // (P_{k+1} rb_k + p_{k+1}), lane 2+i
@@ -418,7 +450,7 @@ __device__ __forceinline__ void riccati_sweeps_rows(const Lds &L, const Dims &d,
             o.y0 = L.y[k * NU]; o.y1 = L.y[k * NU + 1];
             o.r0 = Fb[FB_R0]; o.l10 = Fb[FB_L10]; o.r1 = Fb[FB_R1];
             if constexpr (CP) {
-                const double *Tr = L.tab + br.o0 + k * br.st;              // own row of [B A] as (b_a, b_w, a_psi, a_v)
+                const double *Tr = L.tab + br.o0 + mul24(k, br.st);              // own row of [B A] as (b_a, b_w, a_psi, a_v)
                 o.a_psi = Tr[2]; o.a_v = Tr[3];
                 o.b_a = Tr[0]; o.b_w = Tr[1];
             } else {
@@ -426,7 +458,7 @@ __device__ __forceinline__ void riccati_sweeps_rows(const Lds &L, const Dims &d,
                 o.a_psi = BAr[ZPSI]; o.a_v = BAr[ZV];                      // loads only: arithmetic here would wait for them
                 o.b_a = BAr[ZA]; o.b_w = BAr[ZW];
             }
-            o.rbi = L.rb[k * NX + i5];
+            o.rbi = L.rb[uni(k * NX) + i5];
         };
         auto stage = [&](const Ops &o, int k) {
             // du = -Luu^-T (Lxu^T dx + y)

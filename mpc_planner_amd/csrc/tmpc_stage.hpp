@@ -608,6 +608,9 @@ TMPC_HD void mirror_n(double (&A)[NN][NN], double eps)
 #pragma unroll
             for (int q = p + 1; q < NN; q++) {
                 const double apq = A[p][q];
+                // (a branch, not an identity rotation: the joins cost ~25 register copies per rotation, a third of MIRROR's instructions, and a
+                // branch-free form -- t = 0, c = 1 by selects -- removes them; measured in round 5 it is 3.6 % faster on a lone wave and 0.4 % SLOWER
+                // on the saturated compact kernel, profiles/round5_m_factor_unroll_rotation_ab.jsonl: not taken)
                 if (fabs(apq) > 1e-150) {                       // (also keeps tau^2 + apq^2 away from underflow)
                     // t = sgn(theta) / (|theta| + sqrt(theta^2 + 1)), theta = (aqq - app) / (2 apq), written division-free:
                     // t = apq sgn(tau) / (|tau| + sqrt(tau^2 + apq^2)), tau = (aqq - app)/2
