@@ -4,6 +4,7 @@
 // (tmpc_instances.hpp) and only takes their addresses.  A GENERATED solver (-DTMPC_GENERATED_STAGE, mpc_planner_amd/codegen/build.py) and the
 // experiment builds that pass -DTMPC_SINGLE_TU compile this file ALONE: without the extern declarations every kernel the tables name is
 // instantiated here.
+#include <algorithm>
 #include "tmpc_kernels.hpp"
 #include "tmpc_instances.hpp"
 #if !defined(TMPC_GENERATED_STAGE) && !defined(TMPC_SINGLE_TU)
@@ -126,17 +127,22 @@ static SolveKernel pick_fast_kernel(const Dims &d, int *threads, bool prof)
 // row passes are specialised by the compile-time kind of each row slot (FastCfg::KIND): 238 registers, zero scratch; their larger row tables
 // allow 7 (cfg 4: 23.3 KB) and 6 (cfg 5: 25.2 KB) workgroups per CU.  The runtime-shape instantiation with 13 rows per lane still spills
 // (168 B) and is not registered.
-static SolveKernel pick_compact_kernel(const Dims &d, bool prof)
+// *hs29: whether the instantiation keeps its Hh blocks at a stride of 29 doubles (compact_hs29, tmpc_fast.hpp) -- evaluated on the template arguments
+// where they are written, so that the host's LDS size and the kernel's layout cannot disagree
+#define TMPC_CP(a, b, c) (*hs29 = compact_hs29(a, b, 64), (SolveKernel)tmpc_solve_compact_kernel<a, b, c, false>)
+#define TMPC_CP2(a, b, c, m) (*hs29 = compact_hs29(a, b, 128), (SolveKernel)tmpc_solve_compact_kernel<a, b, c, false, 128, m>)
+static SolveKernel pick_compact_kernel(const Dims &d, bool prof, bool *hs29)
 {
+    *hs29 = false;
 #ifndef TMPC_GENERATED_STAGE
     if (getenv("TMPC_FORCE_GENERIC") || getenv("TMPC_NO_COMPACT") || prof || d.N > 20 || stage_model(d) != 0) return nullptr;
     const int nr = d.n_up + d.M + 14;                    // interior-point rows per stage
-    if (d.n_up == 8 && d.M == 8) return (SolveKernel)tmpc_solve_compact_kernel<8, 8, 3, false>;
-    if (d.n_up == 0 && d.M == 4) return (SolveKernel)tmpc_solve_compact_kernel<0, 4, 3, false>;
-    if (d.n_up == 12 && d.M == 12) return (SolveKernel)tmpc_solve_compact_kernel<12, 12, 3, false>;
-    if (d.n_up == 24 && d.M == 0) return (SolveKernel)tmpc_solve_compact_kernel<24, 0, 3, false>;
-    if (nr <= 3 * 7) return (SolveKernel)tmpc_solve_compact_kernel<-1, 7, 3, false>;       // runtime-shape instantiations
-    if (nr <= 3 * 10) return (SolveKernel)tmpc_solve_compact_kernel<-1, 10, 3, false>;
+    if (d.n_up == 8 && d.M == 8) return TMPC_CP(8, 8, 3);
+    if (d.n_up == 0 && d.M == 4) return TMPC_CP(0, 4, 3);
+    if (d.n_up == 12 && d.M == 12) return TMPC_CP(12, 12, 3);
+    if (d.n_up == 24 && d.M == 0) return TMPC_CP(24, 0, 3);
+    if (nr <= 3 * 7) return TMPC_CP(-1, 7, 3);       // runtime-shape instantiations
+    if (nr <= 3 * 10) return TMPC_CP(-1, 10, 3);
 #endif
     (void)d; (void)prof;
     return nullptr;
@@ -146,22 +152,23 @@ static SolveKernel pick_compact_kernel(const Dims &d, bool prof)
 // fast two-wave kernel (57-70 KB of LDS) holds two.  Bitwise the same results; a trajectory takes longer on it (NLP data in the global
 // workspace, the linearisation on one of the two waves), so launch_solve uses it only for launches that the fast kernel could not hold
 // resident at once (more than two trajectories per CU).  The runtime-shape instantiation with 12 rows per lane spills (144 B): not registered.
-static SolveKernel pick_compact2_kernel(const Dims &d)
+static SolveKernel pick_compact2_kernel(const Dims &d, bool *hs29)
 {
+    *hs29 = false;
 #ifndef TMPC_GENERATED_STAGE
     if (getenv("TMPC_FORCE_GENERIC") || getenv("TMPC_NO_COMPACT") || getenv("TMPC_NO_TWO_WAVE") || 3 * d.N <= NT || 4 * d.N > 128) return nullptr;
     const int nr = d.n_up + d.M + 14, sm = stage_model(d);
-    if (sm == 1) return (d.n_up == 20 && d.M == 8) ? (SolveKernel)tmpc_solve_compact_kernel<20, 8, 4, false, 128, 1> : nullptr;      // cfg 3 as named (CA-MPC)
+    if (sm == 1) return (d.n_up == 20 && d.M == 8) ? TMPC_CP2(20, 8, 4, 1) : nullptr;      // cfg 3 as named (CA-MPC)
     if (sm == 2) {                                                                                                                   // Gaussian chance-constraint rows
-        if (d.n_up == 5 && d.M == 5) return (SolveKernel)tmpc_solve_compact_kernel<5, 5, 4, false, 128, 2>;                          // mpc_planner_jackal's default, tuned (round 5)
-        return nr <= 4 * 6 ? (SolveKernel)tmpc_solve_compact_kernel<-1, 6, 4, false, 128, 2> : nullptr;
+        if (d.n_up == 5 && d.M == 5) return TMPC_CP2(5, 5, 4, 2);                          // mpc_planner_jackal's default, tuned (round 5)
+        return nr <= 4 * 6 ? TMPC_CP2(-1, 6, 4, 2) : nullptr;
     }
     if (sm != 0) return nullptr;
-    if (d.n_up == 20 && d.M == 8) return (SolveKernel)tmpc_solve_compact_kernel<20, 8, 4, false, 128>;
-    if (d.n_up == 12 && d.M == 12) return (SolveKernel)tmpc_solve_compact_kernel<12, 12, 4, false, 128>;
-    if (d.n_up == 8 && d.M == 8) return (SolveKernel)tmpc_solve_compact_kernel<8, 8, 4, false, 128>;
-    if (nr <= 4 * 6) return (SolveKernel)tmpc_solve_compact_kernel<-1, 6, 4, false, 128>;
-    if (nr <= 4 * 9) return (SolveKernel)tmpc_solve_compact_kernel<-1, 9, 4, false, 128>;
+    if (d.n_up == 20 && d.M == 8) return TMPC_CP2(20, 8, 4, 0);
+    if (d.n_up == 12 && d.M == 12) return TMPC_CP2(12, 12, 4, 0);
+    if (d.n_up == 8 && d.M == 8) return TMPC_CP2(8, 8, 4, 0);
+    if (nr <= 4 * 6) return TMPC_CP2(-1, 6, 4, 0);
+    if (nr <= 4 * 9) return TMPC_CP2(-1, 9, 4, 0);
 #endif
     (void)d;
     return nullptr;
@@ -206,6 +213,55 @@ static SolveKernel pick_scan_kernel(const Dims &d, int *threads, int *sl)
     (void)d; (void)threads;
     return nullptr;
 }
+// ---- stage stride of the row Jacobians in LDS (Dims::dpad) --------------------------------------------------------------------
+// LDS bank-conflict model of the row passes' coefficient loads (ipm_fast: coef()).  Lane (stage k, sub-lane c) of a wave owns the rows c, c + LPS, ...;
+// per row slot the lanes read the row's three entries as three 8-byte accesses at  k * dstride + offset(row)  (rows without a Jacobian read the
+// zero triple: one address, a broadcast).  64 banks of 4 bytes; an access costs as many passes as the most loaded bank has DISTINCT dwords.
+// Returns the passes summed over the row slots and the three entries: with the bare strides (48 doubles for 8 + 8 rows, 40 packed) every second
+// / fourth stage falls on the same banks -- 180 passes where 36 would do (fast (8,8) layout), 83 / 36 packed.  The model only ranks strides; the
+// measured effect is in profiles/round5_p_dpad_ab.jsonl.
+static int d_load_passes(int N, int n_pair, int nh, int threads, int dstride)
+{
+    const int lps = threads == 64 ? (3 * N <= 64 ? 3 : 2) : (N <= 21 ? 6 : 4);       // lanes per stage of the kernel families (pick_*_kernel)
+    const int spw = 64 / lps, nk = N < spw ? N : spw;                                 // stages of one wave (two-wave kernels: each wave loads for its own)
+    const int rpl = (nh + 14 + lps - 1) / lps;
+    int total = 0;
+    std::vector<int> dw;
+    for (int s = 0; s < rpl && lps * s < nh; s++)
+        for (int part = 0; part < 3; part++) {
+            dw.clear();
+            for (int k = 0; k < nk; k++)
+                for (int c = 0; c < lps; c++) {
+                    const int r = c + lps * s;
+                    int a = N * dstride + part;                                       // zero triple
+                    if (r < nh) {
+                        const int off = r < n_pair ? 2 * r : 3 * r - n_pair;
+                        if (part < 2 || r >= n_pair) a = k * dstride + off + part; else a = N * dstride + 2;
+                    }
+                    dw.push_back(2 * a); dw.push_back(2 * a + 1);
+                }
+            std::sort(dw.begin(), dw.end());
+            dw.erase(std::unique(dw.begin(), dw.end()), dw.end());
+            int load[64] = {0}, worst = 0;
+            for (int x : dw) { const int b = ++load[x & 63]; if (b > worst) worst = b; }
+            total += worst;
+        }
+    return total;
+}
+// the padding in 0 .. max_pad that the model likes best (ties: the smaller); `allowed(pad)`: the layout still fits what it has to fit
+template <typename Allowed>
+static int pick_d_pad(int N, int n_pair, int nh, int threads, int max_pad, Allowed allowed)
+{
+    if (const char *e = getenv("TMPC_EXP_DPAD")) { const int v = atoi(e); return v >= 0 && v <= max_pad && allowed(v) ? v : 0; }   // experiments ("0": the bare strides)
+    const int base = 2 * n_pair + 3 * (nh - n_pair);
+    int best = 0, best_cost = d_load_passes(N, n_pair, nh, threads, base);
+    for (int pad = 1; pad <= max_pad; pad++) {
+        if (!allowed(pad)) continue;
+        const int c = d_load_passes(N, n_pair, nh, threads, base + pad);
+        if (c < best_cost) { best = pad; best_cost = c; }
+    }
+    return best;
+}
 }  // namespace tmpc
 
 struct tmpc_handle {
@@ -237,6 +293,8 @@ struct tmpc_handle {
     tmpc::SolveKernel kernel_cp2 = nullptr;   // optional two-wave compact variant (22 <= N <= 32): launches of more than cp2_min_B trajectories
     size_t lds_bytes_cp2 = 0;
     int cp2_min_B = 0;                        // what the fast two-wave kernel holds resident at once (workgroups per CU x CUs)
+    int dpad_cp = 0, dpad_cp2 = 0;            // Dims::dpad of the compact one-wave / two-wave kernel (pick_d_pad); the fast layouts do not pad
+    bool hs29_cp = false, hs29_cp2 = false;                                      // the compact kernels' Hh stride (pick_compact*_kernel)
     bool prio_cp = false, prio_cp2 = false;   // wave issue priorities (Dims::prio) for the compact one-wave / two-wave kernel: only when its residency puts two waves on
                                               // every SIMD (8 waves per CU) -- with an odd count the waves that share a SIMD starve and set the makespan (tmpc_riccati.hpp)
     int latency_mode = 0;                     // 0: throughput kernels, 1: two-wave variant, 2: parallel-in-time variant
@@ -385,7 +443,7 @@ int tmpc_create(tmpc_handle **out, const tmpc_dims *dims, int32_t B_max, int32_t
         if (hipFuncSetAttribute((const void *)h->kernel_scan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes_scan) != hipSuccess)
             h->kernel_scan = nullptr;
     }
-    if (tmpc::SolveKernel kc = (h->fast && h->threads == tmpc::NT) ? tmpc::pick_compact_kernel(d, false) : nullptr) {
+    if (tmpc::SolveKernel kc = (h->fast && h->threads == tmpc::NT) ? tmpc::pick_compact_kernel(d, false, &h->hs29_cp) : nullptr) {
         // the fast kernel of the shape (everything in LDS, four per CU) stays for launches it holds resident at once: bitwise the same results
         // (tests/test_gpu_compact2.py), a trajectory is ~10 % faster on it.  TMPC_COMPACT_MIN_B=0: the compact kernel for every launch (rounds 3-4)
         int fast_per_cu = 0, cus = 0;
@@ -396,13 +454,34 @@ int tmpc_create(tmpc_handle **out, const tmpc_dims *dims, int32_t B_max, int32_t
             if (const char *e = getenv("TMPC_COMPACT_MIN_B")) h->cp_min_B = atoi(e);                                              // experiments
         }
         h->kernel = kc; h->compact = true;
-        h->lds_bytes = sizeof(double) * (size_t)tmpc::lds_doubles_compact(d.N, d.n_lin, d.n_up + d.M);
+        // padding of the packed rows' stage stride: only what keeps the residency (LDS is what bounds it: 8 x 20 KB at cfg 2)
+        auto lds_cp = [&](int pad) { return sizeof(double) * (size_t)tmpc::lds_doubles_compact(d.N, d.n_lin, d.n_up + d.M, 64, pad, h->hs29_cp); };
+        auto per_cu_cp = [&](int pad) {
+            int n = 0;
+            if (hipFuncSetAttribute((const void *)kc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cp(pad)) != hipSuccess ||
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)kc, 64, lds_cp(pad)) != hipSuccess) return 0;
+            return n;
+        };
+        const int per_cu0 = per_cu_cp(0);
+        h->dpad_cp = tmpc::pick_d_pad(d.N, d.n_lin, d.n_up + d.M, 64, tmpc::DPAD_MAX, [&](int pad) { return pad == 0 || (per_cu0 > 0 && per_cu_cp(pad) == per_cu0); });
+        h->lds_bytes = lds_cp(h->dpad_cp);
     }
     if (hipFuncSetAttribute((const void *)h->kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)h->lds_bytes) != hipSuccess)
         return fail(TMPC_ERR_NO_DEVICE);
-    if (h->fast && h->threads == 128 && !h->compact && (h->kernel_cp2 = tmpc::pick_compact2_kernel(d)) != nullptr) {
-        h->lds_bytes_cp2 = sizeof(double) * (size_t)tmpc::lds_doubles_compact(d.N, d.n_lin, d.n_up + d.M, 128);
+    if (h->fast && h->threads == 128 && !h->compact && (h->kernel_cp2 = tmpc::pick_compact2_kernel(d, &h->hs29_cp2)) != nullptr) {
+        {
+            auto lds_cp2 = [&](int pad) { return sizeof(double) * (size_t)tmpc::lds_doubles_compact(d.N, d.n_lin, d.n_up + d.M, 128, pad, h->hs29_cp2); };
+            auto per_cu_cp2 = [&](int pad) {
+                int n = 0;
+                if (hipFuncSetAttribute((const void *)h->kernel_cp2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cp2(pad)) != hipSuccess ||
+                    hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)h->kernel_cp2, 128, lds_cp2(pad)) != hipSuccess) return 0;
+                return n;
+            };
+            const int per_cu0 = per_cu_cp2(0);
+            h->dpad_cp2 = tmpc::pick_d_pad(d.N, d.n_lin, d.n_up + d.M, 128, tmpc::DPAD_MAX, [&](int pad) { return pad == 0 || (per_cu0 > 0 && per_cu_cp2(pad) == per_cu0); });
+            h->lds_bytes_cp2 = lds_cp2(h->dpad_cp2);
+        }
         int per_cu = 0, fast_per_cu = 0, cus = 0;
         if (hipFuncSetAttribute((const void *)h->kernel_cp2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes_cp2) != hipSuccess ||
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)h->kernel_cp2, 128, h->lds_bytes_cp2) != hipSuccess || per_cu <= 0 ||
@@ -517,6 +596,7 @@ static int launch_solve(tmpc_handle *h, int n_iter, int st_flags)
         const bool small = h->compact && h->kernel_small && !lat && !lat2 && h->B <= h->cp_min_B;
         const bool cp = (h->compact && !lat && !lat2 && !small) || cp2;
         dd.prio = cp2 ? h->prio_cp2 : (cp ? h->prio_cp : false);
+        dd.dpad = cp2 ? h->dpad_cp2 : (cp ? h->dpad_cp : 0);      // (layout only: results do not depend on it)
         if (cp) TMPC_HIP_CHECK(h, hipMemsetAsync(h->ticket, 0, 8 * 4, h->stream));    // the persistent launch's work counters (one per XCD)
         hipLaunchKernelGGL(lat2 ? h->kernel_scan : lat ? h->kernel_lat : cp2 ? h->kernel_cp2 : small ? h->kernel_small : h->kernel,
                            dim3(cp ? (h->B < h->grid_max ? h->B : h->grid_max) : h->B),   // (persistent launch: at most the resident workgroups)

@@ -27,6 +27,12 @@ struct FastCfg {
     template <int S> static constexpr int KIND = RT ? 2 : ((LPS * S + LPS - 1 < NH) ? 0 : ((LPS * S >= NH) ? 1 : 2));
 };
 
+// Row Jacobians (both register-row layouts): stage k's rows start at k * dstride.  Compact layout: dstride = the stage's packed entries + Dims::dpad -- the
+// bare stride (40 doubles for cfg 2) puts every fourth stage on the same LDS banks, and the row passes' coefficient loads (five to six passes per
+// interior-point iteration) ran into 5-way bank conflicts: +1.0 % at cfg 2 with the padding the host's model picks (tmpc_capi.hip pick_d_pad).  The fast
+// layout keeps its bare stride 3 nh: the same padding was measured there too (one wave per SIMD: cfg 3, cfg 5, the ticks) and changed nothing
+// (profiles/round5_p_dpad_ab.jsonl).  DPAD_MAX: the range the host searches.
+constexpr int DPAD_MAX = 5;
 __host__ __device__ inline int lds_doubles_fast(int N, int nh)
 {
     const int persistent = (N + 1) * NV + (N + 1) * NX + (N + 1) * NP28 + (N + 1) * NV + N * NX * NV + N * NX + N * 8 + (N * nh + 1) * 3;
@@ -45,6 +51,7 @@ __device__ __forceinline__ Lds carve_fast(double *s, const Dims &d)
     auto take = [&](int n) { double *p = s; s += n; return p; };
     L.z = take((N + 1) * NV); L.pi = take((N + 1) * NX); L.W = take((N + 1) * NP28); L.g = take((N + 1) * NV);
     L.BA = take(N * NX * NV); L.b = take(N * NX); L.dyn8 = take(N * 8);
+    L.n_pair = 0; L.dstride = 3 * L.nh;                // (the packed layout's addressing with no packed rows; no padding: see DPAD_MAX)
     L.D = take((N * L.nh + 1) * 3);                    // rows' Jacobians stay resident (+ one zero triple for box rows)
     double *w = s;                                      // work region (IPM) ...
     L.v = take((N + 1) * NV); L.pq = take((N + 1) * NX); L.Hh = take((N + 1) * NP28);
@@ -63,22 +70,26 @@ __device__ __forceinline__ Lds carve_fast(double *s, const Dims &d)
 // once per RTI iteration and read once per interior-point iteration -- live in a per-workgroup workspace in global memory
 // (one slot per RESIDENT workgroup: ~9 KB x 8 per CU, L2-resident).  L.pr aliases L.dpi (tmpc_riccati.hpp).
 // nth = 128: the two-wave instantiations (21 <= N <= 32, four lanes per stage); their block-wide reductions need the 64-entry scratch
-__host__ __device__ inline int lds_doubles_compact(int N, int n_pair, int nh, int nth = 64)
+// hs29: the instantiation keeps its Hh blocks at a stride of 29 doubles (hoff<2>, tmpc_riccati.hpp): the tuned one-wave shapes, except (12,12)
+// (seven per CU with 69 bytes to spare).  Not the two-wave instantiations: a wave of theirs holds 16 stages (two-way conflicts at most), measured
+// 0 ((20,8), cfg 3) and -2 % ((5,5), the jackal default) with the padded stride (profiles/round5_r_layout_check.jsonl against round5_final_*).
+__host__ __device__ constexpr bool compact_hs29(int NLIN, int MM, int NTH) { return NLIN >= 0 && NTH == 64 && !(NLIN == 12 && MM == 12); }
+__host__ __device__ inline int lds_doubles_compact(int N, int n_pair, int nh, int nth = 64, int dpad = 0, bool hs29 = false)
 {
-    const int dstride = 2 * n_pair + 3 * (nh - n_pair);
+    const int dstride = 2 * n_pair + 3 * (nh - n_pair) + dpad;
     const int persistent = N * 8 + BA_NCONST + N * dstride + 3;
-    const int work = (N + 1) * NV + (N + 1) * NX + (N + 1) * NP28 + 2 * (N + 1) * NV + N * NX + (N + 1) * NV + (N + 1) * NX + N * NU + (nth > 64 ? 64 : 8);
+    const int work = (N + 1) * NV + (N + 1) * NX + (N + 1) * (NP28 + (hs29 ? 1 : 0)) + 2 * (N + 1) * NV + N * NX + (N + 1) * NV + (N + 1) * NX + N * NU + (nth > 64 ? 64 : 8);
     const int staging = 2 * N * nh;
     return persistent + (work > staging ? work : staging);
 }
 
-__device__ __forceinline__ Lds carve_compact(double *s, double *ws, const Dims &d, int nth = 64)
+__device__ __forceinline__ Lds carve_compact(double *s, double *ws, const Dims &d, int nth = 64, bool hs29 = false)
 {
     Lds L;
     const int N = d.N;
     L.nh = d.n_up + d.M;
     L.NG = N * L.nh; L.GB = L.NG; L.XB = L.NG + 4 * N; L.nrows = L.XB + 10 * (N - 1);
-    L.n_pair = d.n_lin; L.dstride = 2 * d.n_lin + 3 * (L.nh - d.n_lin);
+    L.n_pair = d.n_lin; L.dstride = 2 * d.n_lin + 3 * (L.nh - d.n_lin) + d.dpad;
     auto take = [&](int n) { double *p = s; s += n; return p; };
     auto takeg = [&](int n) { double *p = ws; ws += n; return p; };
     L.z = takeg((N + 1) * NV); L.pi = takeg((N + 1) * NX); L.W = takeg((N + 1) * NP28); L.g = takeg((N + 1) * NV);
@@ -88,7 +99,7 @@ __device__ __forceinline__ Lds carve_compact(double *s, double *ws, const Dims &
     L.tab = take(N * 8 + BA_NCONST);
     L.D = take(N * L.dstride + 3);                      // (+ one zero triple for box rows / the third entry of topology rows)
     double *w = s;
-    L.v = take((N + 1) * NV); L.pq = take((N + 1) * NX); L.Hh = take((N + 1) * NP28);
+    L.v = take((N + 1) * NV); L.pq = take((N + 1) * NX); L.Hh = take((N + 1) * (NP28 + (hs29 ? 1 : 0)));      // (hoff<CP>: tmpc_riccati.hpp)
     L.rg = take((N + 1) * NV); L.gh = take((N + 1) * NV); L.rb = take(N * NX); L.dv = take((N + 1) * NV);
     L.dpi = take((N + 1) * NX); L.pr = L.dpi; L.y = take(N * NU); L.scr = take(nth > 64 ? 64 : 8);
     s = w;
@@ -117,9 +128,9 @@ struct Solo {
     __device__ __forceinline__ bool alive() const { return true; }
     __device__ __forceinline__ void sync() const { __syncthreads(); }
     __device__ __forceinline__ bool any(bool active) const { return active; }
-    template <int NTH, bool CP>
+    template <int NTH, int CP>
     __device__ __forceinline__ bool factor(const Lds &L, const Dims &d, int tl, int sw, int) const { return riccati_factor<NTH, CP, true>(L, d, tl, sw); }   // (the predictor's backward sweep rides along)
-    template <int NTH, bool CP>
+    template <int NTH, int CP>
     __device__ __forceinline__ void solve(const Lds &L, const Dims &d, int tl, int sw, int, int phase, bool) const
     {
         if (phase == 1) riccati_forward<NTH, CP>(L, d, tl, sw); else riccati_solve<NTH, CP>(L, d, tl, sw);
@@ -135,7 +146,7 @@ struct ScanSoloT {
     __device__ __forceinline__ void sync() const { __syncthreads(); }
     __device__ __forceinline__ bool any(bool active) const { return active; }
     // NTH = 128 (two waves per trajectory, the row phases on twice the lanes): the Newton solve runs on the wave `sw`, the other waits
-    template <int NTH, bool CP>
+    template <int NTH, int CP>
     __device__ __forceinline__ bool factor(const Lds &L, const Dims &d, int tl, int sw, int) const
     {
         static_assert(!CP, "fast layout");
@@ -150,7 +161,7 @@ struct ScanSoloT {
         if (NTH > 64) bad = L.scr[63] != 0.0;
         return bad;
     }
-    template <int NTH, bool CP>
+    template <int NTH, int CP>
     __device__ __forceinline__ void solve(const Lds &L, const Dims &d, int tl, int sw, int, int phase, bool) const
     {
         asm volatile("" : "+v"(tl));
@@ -163,7 +174,7 @@ struct ScanSoloT {
 };
 using ScanSolo = ScanSoloT<3>;
 
-template <int NLIN, int MM, int LPS, int NTH, bool CP, typename PF, typename TEAM = Solo>
+template <int NLIN, int MM, int LPS, int NTH, int CP, typename PF, typename TEAM = Solo>
 __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, int *iters_out, PF &pf,
                         double (&lam)[FastCfg<NLIN, MM, LPS>::RPL], const TEAM &team = TEAM())
 {
@@ -213,7 +224,7 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
         const int r = c + LPS * s;
         sb[s] = 0.0;
         if constexpr (STORE_IDX) {
-            didx_[s] = CP ? N * L.dstride : N * NH * 3;
+            didx_[s] = N * L.dstride;
             if constexpr (STORE_IDX2) didx2_[s] = N * L.dstride + 2;
         }
         if (stage_lane && r < NR) {
@@ -223,7 +234,7 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
                     if constexpr (CP) {
                         didx_[s] = mul24(k, L.dstride) + (r < L.n_pair ? 2 * r : 3 * r - L.n_pair);
                         if constexpr (STORE_IDX2) didx2_[s] = r >= L.n_pair ? didx_[s] + 2 : N * L.dstride + 2;
-                    } else didx_[s] = (k * NH + r) * 3;
+                    } else didx_[s] = mul24(k, L.dstride) + 3 * r;
                 }
                 sb[s] = sgn * L.beta[k * NH + r];
                 act |= 1u << s;
@@ -249,7 +260,7 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
         if constexpr (STORE_IDX) return didx_[STORE_IDX ? s : 0];
         const int r = c + LPS * s;
         if constexpr (CP) return (stage_lane && r < NH) ? mul24(k, L.dstride) + (r < L.n_pair ? 2 * r : 3 * r - L.n_pair) : N * L.dstride;
-        return (stage_lane && r < NH) ? (k * NH + r) * 3 : N * NH * 3;
+        return (stage_lane && r < NH) ? mul24(k, L.dstride) + 3 * r : N * L.dstride;
     };
     // third entry of the row's Jacobian: packed rows (topology) have none -- they read the 0.0 of the zero triple, so that the
     // row's arithmetic (sg * 0.0 included) is that of the unpacked layout
@@ -411,7 +422,7 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
             }
             if (nd) {
 #pragma unroll
-                for (int e = 0; e < NP28; e++) L.Hh[mul24(ks, NP28) + e] = w[e];
+                for (int e = 0; e < NP28; e++) L.Hh[hoff_lane<CP>(ks) + e] = w[e];
             }
             const double dtc = d.dt, sdtc = d.sdt, shc = d.shdt2;      // (spline row of [B A]: zero for the model without a spline state)
             const double Xa = d8[D8_XA], Xw = d8[D8_XW], Xp = d8[D8_XP], Xv = d8[D8_XV], Ya = d8[D8_YA], Yw = d8[D8_YW], Yp = d8[D8_YP], Yv = d8[D8_YV];
@@ -487,14 +498,14 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
                         const double cus = CUK(s_);
                         lds_add(&L.rg[mul24(k, NV) + vr], -lam[s] * cus);
                         lds_add(&L.gh[mul24(k, NV) + vr], w * cus);
-                        lds_add(&L.Hh[mul24(k, NP28) + pidx(vr, vr)], dd);
+                        lds_add(&L.Hh[hoff_lane<CP>(k) + pidx(vr, vr)], dd);
                     }
                 }
             });
             if (stage_lane) {
                 lds_add(&L.rg[mul24(k, NV) + ZX], -gs0); lds_add(&L.rg[mul24(k, NV) + ZY], -gs1); lds_add(&L.rg[mul24(k, NV) + ZPSI], -gs2);
                 lds_add(&L.gh[mul24(k, NV) + ZX], rs0); lds_add(&L.gh[mul24(k, NV) + ZY], rs1); lds_add(&L.gh[mul24(k, NV) + ZPSI], rs2);
-                double *Hk = L.Hh + mul24(k, NP28);
+                double *Hk = L.Hh + hoff_lane<CP>(k);
                 lds_add(&Hk[pidx(ZX, ZX)], h00); lds_add(&Hk[pidx(ZY, ZX)], h10); lds_add(&Hk[pidx(ZY, ZY)], h11);
                 lds_add(&Hk[pidx(ZPSI, ZX)], h20); lds_add(&Hk[pidx(ZPSI, ZY)], h21); lds_add(&Hk[pidx(ZPSI, ZPSI)], h22);
             }
@@ -684,7 +695,7 @@ void tmpc_solve_fast_kernel(Dims d, int B, const double *__restrict__ xinit,
     }
     for (int e = tid; e < (N + 1) * NX; e += NT) L.pi[e] = (slot_flags(io, b) & ST_KEEP_MULTIPLIERS) ? io.pi[(size_t)slot_of(io, b) * (N + 1) * NX + e] : 0.0;
     for (int e = tid; e < N * NHk; e += NT) L.lamh[e] = (slot_flags(io, b) & ST_KEEP_MULTIPLIERS) ? io.lamh[(size_t)slot_of(io, b) * N * NHk + e] : 0.0;
-    if (tid < 3) L.D[N * NHk * 3 + tid] = 0.0;      // zero triple read by box rows
+    if (tid < 3) L.D[N * L.dstride + tid] = 0.0;    // zero triple read by box rows
     __syncthreads();
     if (tid < NU) L.z[N * NV + tid] = 0.0;
     __syncthreads();
@@ -768,7 +779,8 @@ void tmpc_solve_compact_kernel(Dims d, int B, const double *__restrict__ xinit,
     const int tid0 = threadIdx.x;
     const int N = d.N;
     int tid = tid0;
-    const Lds L = carve_compact(smem, io.ws + (size_t)blockIdx.x * ws_doubles(N, NTH > 64), d, NTH);
+    constexpr int CPV = compact_hs29(NLIN, MM, NTH) ? 2 : 1;     // layout parameter of ipm_fast and the Riccati routines (hoff<CP>)
+    const Lds L = carve_compact(smem, io.ws + (size_t)blockIdx.x * ws_doubles(N, NTH > 64), d, NTH, CPV == 2);
     ba_tab_init(L.tab, d, tid);
     if (tid < 3) L.D[N * L.dstride + tid] = 0.0;        // zero triple read by box rows (and as the third entry of packed rows)
     __syncthreads();
@@ -813,7 +825,7 @@ void tmpc_solve_compact_kernel(Dims d, int B, const double *__restrict__ xinit,
             pf.stop(PH_LIN);
             int iters = 0;
             TMPC_PRIO_LOW();
-            qp_status = ipm_fast<NLIN, MM, LPS, NTH, true>(L, d, tid, xi, &iters, pf, lam);
+            qp_status = ipm_fast<NLIN, MM, LPS, NTH, CPV>(L, d, tid, xi, &iters, pf, lam);
             sqp_iter = it + 1; qp_iter_total += iters;
             if (qp_status != 0 && qp_status != 2) { status = 4; break; }
             status = 0;

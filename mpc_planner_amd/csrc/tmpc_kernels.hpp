@@ -696,7 +696,7 @@ __device__ __forceinline__ void linearise(const Lds &L, const Dims &d, int tid, 
                     Dr[0] = sg * ro.gx; Dr[1] = sg * ro.gy;
                     if (r >= L.n_pair) Dr[2] = sg * ro.gp;
                 } else {
-                    double *Dr = L.D + (k * nh + r) * 3;
+                    double *Dr = FAST ? L.D + k * L.dstride + 3 * r : L.D + (k * nh + r) * 3;      // (fast layout: padded stage stride, carve_fast)
                     Dr[0] = sg * ro.gx; Dr[1] = sg * ro.gy; Dr[2] = sg * ro.gp;
                 }
                 const double bound = (r < d.n_up || cm_gaussian_rows(CM)) ? 0.0 : 1.0;     // ellipsoid rows: h >= 1; Gaussian rows: h >= 0
@@ -847,7 +847,7 @@ __device__ __forceinline__ void linearise(const Lds &L, const Dims &d, int tid, 
                     Dr[0] = sg * ro.gx; Dr[1] = sg * ro.gy;
                     if (r >= L.n_pair) Dr[2] = sg * ro.gp;
                 } else {
-                    double *Dr = L.D + (k * nh + r) * 3;
+                    double *Dr = FAST ? L.D + k * L.dstride + 3 * r : L.D + (k * nh + r) * 3;      // (fast layout: padded stage stride, carve_fast)
                     Dr[0] = sg * ro.gx; Dr[1] = sg * ro.gy; Dr[2] = sg * ro.gp;
                 }
                 const double bound = (r < d.n_up || cm_gaussian_rows(CM)) ? 0.0 : 1.0;     // ellipsoid rows: h >= 1; Gaussian rows: h >= 0

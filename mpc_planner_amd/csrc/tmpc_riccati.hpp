@@ -59,6 +59,15 @@ __device__ unsigned long long g_sweep_prof[SP_COUNT];
 //   [0..9]  Lxu (5x2, row-major)   [10] L10   [11] 1/L00   [12] 1/L11   [13..27] P_k (packed lower 5x5)
 constexpr int FB_LXU = 0, FB_L10 = 10, FB_R0 = 11, FB_R1 = 12, FB_P = 13;
 
+// Offset of stage k's block in Hh.  A stride of 28 doubles (56 dwords) puts the stages k, k + 8, k + 16 on the same LDS banks: the stage-parallel loops
+// (one lane per stage: the node's 28 stores of Hh <- W, the 15 + 15 loads of P in the vector solves' prologue / epilogue, the row passes' ds_add_f64)
+// ran every access in three passes; 29 is conflict-free and costs (N + 1) doubles of LDS.  The stride is a COMPILE-TIME fact of the instantiation --
+// the layout parameter CP of the routines below: 0 fast / generic layouts (28), 1 compact (28), 2 compact with 29 (compact_hs29(): the tuned shapes
+// whose LDS budget has the room at every N they run) -- because a run-time stride, one more live SGPR in kernels that spill 250 of them, cost the
+// two-wave compact kernels 3.7 %, and a bank swizzle k * 28 + (k >> 3) (no extra LDS) more than it saved (profiles/round5_q_*).  Measured: +2.4 % at cfg 2.
+template <int CP> __device__ __forceinline__ int hoff(int k) { return k * (CP == 2 ? NP28 + 1 : NP28); }
+template <int CP> __device__ __forceinline__ int hoff_lane(int k) { return mul24(k, CP == 2 ? NP28 + 1 : NP28); }                 // (k per lane)
+
 // (The sequential sweeps use lanes 0..7 of the wave and rows 1..3 run along on copies.  Switching those rows off for the sweeps -- the LDS unit is
 // busy 70 % of the kernel time at eight trajectories per CU and the sweeps issue two thirds of its instructions -- was measured in round 5: 1.3 %
 // SLOWER, profiles/round5_o_sweep_rows_ab.jsonl; an LDS instruction costs the same with 16 lanes as with 64 and the EXEC changes are not free.)
@@ -135,7 +144,7 @@ __device__ __forceinline__ BaLane ba_row4(int N, int i5)          // o0: base of
 // and p joins the product: w = P rb + p.  The separate backward vector sweep of the predictor (and its stage-parallel prologue P rb)
 // disappear: one of the five sequential passes over the stages of an interior-point iteration.  Same algebra as the separate sweep; the
 // operations associate differently (rounding-level differences).
-template <bool CP, bool VEC = false>
+template <int CP, bool VEC = false>
 __device__ __forceinline__ bool riccati_factor_rows(const Lds &L, const Dims &d, int li, bool wr)
 {
     const int N = d.N;
@@ -171,8 +180,8 @@ __device__ __forceinline__ bool riccati_factor_rows(const Lds &L, const Dims &d,
     const double *bbase = CP ? L.tab : L.BA;
     int bo[NX], bst[NX];
     if constexpr (VEC) {
-        hrow = vec ? L.gh : L.Hh + pidx(ls, 0);
-        hstep = vec ? NV : NP28;
+        hrow = vec ? L.gh : L.Hh + pidx(ls, 0);       // (row start inside a stage's block; the block's offset is added per stage: hoff<CP>)
+        hstep = 0;
 #pragma unroll
         for (int m = 0; m < NX; m++) {
             if constexpr (CP) { bo[m] = vec ? (int)(L.rb - L.tab) + m : ba_off(N, 0, m, ls); bst[m] = vec ? NX : (bo[m] < 8 ? 8 : 0); }
@@ -180,21 +189,20 @@ __device__ __forceinline__ bool riccati_factor_rows(const Lds &L, const Dims &d,
         }
     }
     // (the running pointers are positioned by seek_stage and stepped by load_stage: stage k, then k - 1, ...; the last call re-loads stage 0)
-    auto seek_stage = [&](int k) {
-        if constexpr (VEC) hrow += k * hstep;
-    };
+    auto seek_stage = [&](int) {};
     auto load_stage = [&](Opnd &o, int k, bool step) {
         // unconditional loads (clamped indices): entries above the diagonal / of idle lanes are never used
         if constexpr (VEC) {
+            const double *hr = hrow + (vec ? k * NV : hoff<CP>(k));          // (two wave-uniform offsets, one select per stage)
 #pragma unroll
-            for (int j = 0; j < NV; j++) o.hk[j] = hrow[j];
+            for (int j = 0; j < NV; j++) o.hk[j] = hr[j];
 #pragma unroll
             for (int m = 0; m < NX; m++) o.ba[m] = bbase[bo[m] + mul24(k, bst[m])];
 #pragma unroll
             for (int q = 0; q < 8; q++) o.dn[q] = (CP ? L.tab : L.dyn8)[k * 8 + q];
-            if (step) hrow -= hstep;
+            (void)step;
         } else {
-            const double *Hk = L.Hh + k * NP28;
+            const double *Hk = L.Hh + hoff<CP>(k);
 #pragma unroll
             for (int j = 0; j < NV; j++) o.hk[j] = Hk[pidx(ls, j <= ls ? j : ls)];
             if constexpr (CP) {
@@ -214,7 +222,7 @@ __device__ __forceinline__ bool riccati_factor_rows(const Lds &L, const Dims &d,
     };
     // terminal node: P_N = the xx-block of Hh_N (rows/cols 2..6) as it is; the extra row starts as p_N = g_x of node N
 #pragma unroll
-    for (int j = 0; j < NV; j++) f[j] = (j >= NU) ? (vec ? L.gh[N * NV + j] : L.Hh[N * NP28 + pidx(ls, j <= ls ? j : ls)]) : 0.0;
+    for (int j = 0; j < NV; j++) f[j] = (j >= NU) ? (vec ? L.gh[N * NV + j] : L.Hh[hoff<CP>(N) + pidx(ls, j <= ls ? j : ls)]) : 0.0;
     Opnd oa, ob;
     seek_stage(N - 1);
     load_stage(oa, N - 1, true);
@@ -232,7 +240,7 @@ __device__ __forceinline__ bool riccati_factor_rows(const Lds &L, const Dims &d,
         });
         // P_{k+1} (own row of lanes 2..6) is kept for the vector solves
         if (rowl && li >= NU) {
-            double *Ln = L.Hh + (k + 1) * NP28 + FB_P;
+            double *Ln = L.Hh + hoff<CP>(k + 1) + FB_P;
 #pragma unroll
             for (int l = 0; l < NX; l++) *(l <= i5 ? Ln + i5 * (i5 + 1) / 2 + l : L.scr + (CP ? 0 : 56) + l) = f[NU + l];   // (entries above the diagonal go to a dummy slot: a select on the address instead of five masked stores)
         }
@@ -264,7 +272,7 @@ __device__ __forceinline__ bool riccati_factor_rows(const Lds &L, const Dims &d,
         double r0 = 0.0, r1 = 0.0;
         bad |= chol_rows<0, NU>(f, li, &r0, &r1);     // the two input columns; rows 2..6 now hold P_k (lanes 2..6) / p_k (the extra row)
         if (rowl) {
-            double *Fb = L.Hh + k * NP28;
+            double *Fb = L.Hh + hoff<CP>(k);
             if (li >= NU) { Fb[FB_LXU + 2 * i5] = f[0]; Fb[FB_LXU + 2 * i5 + 1] = f[1]; }
             if (li == 1) { Fb[FB_L10] = f[0]; Fb[FB_R0] = r0; Fb[FB_R1] = r1; }
         }
@@ -289,7 +297,7 @@ __device__ __forceinline__ bool riccati_factor_rows(const Lds &L, const Dims &d,
 
 // NTH = threads per trajectory: 64, or 128 for the two-wave variant, in which the sweeps run on one wave (the other waits at the
 // closing barrier) and only the stage-parallel loops use all threads.  `sw`: which of the two waves sweeps.
-template <int NTH, bool CP = false, bool VEC = false>
+template <int NTH, int CP = 0, bool VEC = false>
 __device__ __forceinline__ bool riccati_factor(const Lds &L, const Dims &d, int tid, int sw = 0)
 {
     asm volatile("" : "+v"(tid));                    // opaque per call: lane-derived addresses are not shared with (kept live until) other phases
@@ -313,11 +321,12 @@ __device__ __forceinline__ bool riccati_factor(const Lds &L, const Dims &d, int 
 // Stage-parallel parts (one lane per stage, `nth` lanes of the trajectory's own wave(s)):
 //   pre   q_k = P_{k+1} rb_k for all stages at once (off the sequential chain); parked in dpi[k+1]
 //   post  dpi_k = P_k dx_k + p_k, k = 1..N
+template <int CP>
 __device__ __forceinline__ void riccati_solve_pre(const Lds &L, const Dims &d, int tid, int nth)
 {
     const int N = d.N;
     for (int k = tid; k < N; k += nth) {
-        const double *Pn = L.Hh + mul24(k + 1, NP28) + FB_P;              // P_{k+1}, packed lower triangle
+        const double *Pn = L.Hh + hoff_lane<CP>(k + 1) + FB_P;              // P_{k+1}, packed lower triangle
         const double *r = L.rb + mul24(k, NX);
         double pp[15], rr[NX];
 #pragma unroll
@@ -334,12 +343,13 @@ __device__ __forceinline__ void riccati_solve_pre(const Lds &L, const Dims &d, i
     }
 }
 // dpi_k = P_k dx_k + p_k, k = 1..N (L.pr holds p_k: from the backward sweep, or from the extra row of a VEC factorisation)
+template <int CP>
 __device__ __forceinline__ void riccati_solve_post(const Lds &L, const Dims &d, int tid, int nth)
 {
     const int N = d.N;
     for (int kk = tid; kk < N; kk += nth) {
         const int k = kk + 1;
-        const double *Pk = L.Hh + mul24(k, NP28) + FB_P;
+        const double *Pk = L.Hh + hoff_lane<CP>(k) + FB_P;
         const double *dxk = L.dv + mul24(k, NV) + NU;
         double pp[15], rr[NX], pk[NX];
 #pragma unroll
@@ -359,7 +369,7 @@ __device__ __forceinline__ void riccati_solve_post(const Lds &L, const Dims &d, 
 // The two sequential sweeps on rows (see riccati_factor_rows for li / L / wr).  Lane j (< 7) of a row = component j of the stage
 // vector [u; x]; the cost-to-go gradient p lives in lanes 2..6.  MID: what separates the sweeps (the forward sweep reads the y the
 // backward sweep stored): a workgroup barrier in the one-trajectory kernels, a wave-level fence when one wave sweeps for a team.
-template <bool CP, bool BWD = true, typename MID>
+template <int CP, bool BWD = true, typename MID>
 __device__ __forceinline__ void riccati_sweeps_rows(const Lds &L, const Dims &d, int li, bool wr, bool sweeper, MID mid)
 {
     const int N = d.N;
@@ -385,7 +395,7 @@ __device__ __forceinline__ void riccati_sweeps_rows(const Lds &L, const Dims &d,
             for (int m = 2; m < NX; m++) bac[m] = L.tab[ba_off(N, 0, m, ls)];
         }
         auto load_stage = [&](Ops &o, int k) {
-            const double *Fb = L.Hh + k * NP28;
+            const double *Fb = L.Hh + hoff<CP>(k);
             o.ghj = L.gh[uni(k * NV) + ls];
             if constexpr (CP) {
                 o.ba[0] = L.tab[bc.o0 + mul24(k, bc.st)]; o.ba[1] = L.tab[bc.o1 + mul24(k, bc.st)];
@@ -438,7 +448,7 @@ __device__ __forceinline__ void riccati_sweeps_rows(const Lds &L, const Dims &d,
         struct Ops { double y0, y1, r0, l10, r1, a_psi, a_v, b_a, b_w, rbi; };
         double lxu[2 * NX];
         auto load_lxu = [&](int k) {
-            const double *Fb = L.Hh + k * NP28 + FB_LXU;
+            const double *Fb = L.Hh + hoff<CP>(k) + FB_LXU;
 #pragma unroll
             for (int e = 0; e < 2 * NX; e++) lxu[e] = Fb[e];
         };
@@ -446,7 +456,7 @@ __device__ __forceinline__ void riccati_sweeps_rows(const Lds &L, const Dims &d,
         double *dv_own = L.dv + ls;
         const BaLane br = ba_row4(N, i5);
         auto load_stage = [&](Ops &o, int k) {
-            const double *Fb = L.Hh + k * NP28;
+            const double *Fb = L.Hh + hoff<CP>(k);
             o.y0 = L.y[k * NU]; o.y1 = L.y[k * NU + 1];
             o.r0 = Fb[FB_R0]; o.l10 = Fb[FB_L10]; o.r1 = Fb[FB_R1];
             if constexpr (CP) {
@@ -492,7 +502,7 @@ __device__ __forceinline__ void riccati_sweeps_rows(const Lds &L, const Dims &d,
     SWEEP_T(SP_SOLVE_FWD);
 }
 
-template <int NTH, bool CP = false>
+template <int NTH, int CP = 0>
 __device__ __forceinline__ void riccati_solve(const Lds &L, const Dims &d, int tid, int sw = 1)
 {
     asm volatile("" : "+v"(tid));                    // opaque per call (see riccati_factor): the two solves of an iteration do not share address registers
@@ -501,18 +511,18 @@ __device__ __forceinline__ void riccati_solve(const Lds &L, const Dims &d, int t
     const bool sweeper = NTH == 64 || (tid >> 6) == sw;
     const int lane = NTH == 64 ? tid : (sweeper ? (tid & 63) : 64);
     SWEEP_COUNT(SP_CALLS_SOLVE);
-    riccati_solve_pre(L, d, tid, NTH);
+    riccati_solve_pre<CP>(L, d, tid, NTH);
     __syncthreads();
     TMPC_PRIO_HIGH();
     riccati_sweeps_rows<CP, true>(L, d, lane, true, sweeper, [] { __syncthreads(); });
     TMPC_PRIO_LOW();
     __syncthreads();
-    riccati_solve_post(L, d, tid, NTH);
+    riccati_solve_post<CP>(L, d, tid, NTH);
     __syncthreads();
 }
 
 // The rest of the predictor solve after a VEC factorisation: forward sweep + stage-parallel closing loop.
-template <int NTH, bool CP = false>
+template <int NTH, int CP = 0>
 __device__ __forceinline__ void riccati_forward(const Lds &L, const Dims &d, int tid, int sw = 1)
 {
     asm volatile("" : "+v"(tid));
@@ -523,7 +533,7 @@ __device__ __forceinline__ void riccati_forward(const Lds &L, const Dims &d, int
     riccati_sweeps_rows<CP, false>(L, d, lane, true, sweeper, [] {});
     TMPC_PRIO_LOW();
     __syncthreads();
-    riccati_solve_post(L, d, tid, NTH);
+    riccati_solve_post<CP>(L, d, tid, NTH);
     __syncthreads();
 }
 

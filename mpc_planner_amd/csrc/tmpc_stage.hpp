@@ -83,6 +83,8 @@ struct Dims {
                                      // so it decouples exactly from every other variable; callers pad xinit / x0 with 0 there.  Generated solvers only: the emitted
                                      // header fixes it (tmpc_gen::MODEL); the hand-written stage functions are the contouring stacks' (model 0).
     double sdt, shdt2;               // the spline row of [B A]: (dt, dt^2 / 2) for model 0, (0, 0) for model 1
+    int dpad;                        // padding (doubles) of the stage stride of the row Jacobians in LDS (fast and compact layouts): chosen per LAUNCH by the host
+                                     // from an LDS bank-conflict model of the kernel's lane map (tmpc_capi.hip pick_d_pad); layout only, no effect on results
     int prio;                        // 1: the kernel raises its wave's issue priority inside the latency-critical phases (csrc/tmpc_riccati.hpp TMPC_PRIO_*);
                                      // set per LAUNCH by the host (launch_solve): only for kernels that put two waves on every SIMD
     int cost_model;                  // 0: ContouringModule (contouring.py:48-98); 1: CurvatureAwareContouringModule (curvature_aware_contouring.py:48-105).

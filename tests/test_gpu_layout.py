@@ -1,0 +1,56 @@
+"""GPU: the LDS layout paddings are layout only.  In the compact kernels the stage stride of the row Jacobians gets a padding chosen by a bank-conflict
+model of the kernel's lane map (Dims::dpad, csrc/tmpc_capi.hip pick_d_pad; TMPC_EXP_DPAD forces a value when the handle is created; a value the residency
+does not allow falls back to 0) -- every choice must give bit for bit the same results, and the kernel families that do not pad (fast one-wave and two-wave,
+the tick variants) must ignore the switch."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+FIELDS = ("xtraj", "utraj", "pobj", "exit_code", "qp_status", "sqp_iter", "qp_iter_total", "res_eq")
+
+CASES = {
+    # name: (scene kwargs, dims kwargs, batch, environment that picks the kernel family, latency mode)
+    "cfg2_fast": (dict(N=20, M=8), dict(N=20, S=5, n_lin=8, M=8), 64, {}, 0),
+    "cfg2_compact": (dict(N=20, M=8), dict(N=20, S=5, n_lin=8, M=8), 96, {"TMPC_COMPACT_MIN_B": "0"}, 0),
+    "cfg2_tick_riccati": (dict(N=20, M=8), dict(N=20, S=5, n_lin=8, M=8), 64, {}, 1),
+    "cfg2_tick_parallel_in_time": (dict(N=20, M=8), dict(N=20, S=5, n_lin=8, M=8), 64, {}, 2),
+    "cfg4_compact": (dict(N=20, M=12), dict(N=20, S=5, n_lin=12, M=12), 96, {"TMPC_COMPACT_MIN_B": "0"}, 0),
+    "runtime_shape_compact": (dict(N=20, M=6), dict(N=20, S=5, n_lin=6, M=6), 96, {"TMPC_COMPACT_MIN_B": "0"}, 0),
+    "cfg3_fast_two_wave": (dict(N=30, M=8, slack=True, n_decomp=12), dict(N=30, S=5, n_lin=8, M=8, n_slk=12, slack=1, cost_model=1), 32, {"TMPC_NO_COMPACT": "1"}, 0),
+    "cfg3_compact_two_wave": (dict(N=30, M=8, slack=True, n_decomp=12), dict(N=30, S=5, n_lin=8, M=8, n_slk=12, slack=1, cost_model=1), 32, {"TMPC_COMPACT2_MIN_B": "0"}, 0),
+}
+KEYS = ("TMPC_EXP_DPAD", "TMPC_COMPACT_MIN_B", "TMPC_COMPACT2_MIN_B", "TMPC_NO_COMPACT")
+
+
+def _solve(sc, dkw, B, env, mode, dpad):
+    from mpc_planner_amd import solver
+    for k in KEYS:
+        os.environ.pop(k, None)
+    os.environ.update(env)
+    if dpad is not None:
+        os.environ["TMPC_EXP_DPAD"] = str(dpad)
+    try:
+        s = solver.BatchedSolver(solver.default_dims(**dkw), B_max=B)
+    finally:
+        for k in KEYS:
+            os.environ.pop(k, None)
+    if mode:
+        s.set_latency_mode(mode)
+    info = s.kernel_info()
+    s.set_batch(sc["xinit"], sc["x0"], sc["params"]); s.solve(); out = s.get(); s.close()
+    return out, info
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_row_jacobian_padding_changes_no_bit(case):
+    from mpc_planner_amd import scenes
+    skw, dkw, B, env, mode = CASES[case]
+    sc = scenes.make_scene(77, B=B, **skw)
+    ref, info = _solve(sc, dkw, B, env, mode, 0)                 # the bare strides
+    assert (ref["exit_code"] == 1).mean() > 0.5, (info, ref["exit_code"])
+    for dpad in (None, 1, 2, 5):                                 # the model's choice, then forced values (a forced value the residency does not allow falls back to 0)
+        out, _ = _solve(sc, dkw, B, env, mode, dpad)
+        for f in FIELDS:
+            assert np.array_equal(ref[f], out[f]), (case, dpad, f, info)
