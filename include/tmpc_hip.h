@@ -364,6 +364,12 @@ int tmpc_debug_get_params(tmpc_handle *h, double *params);
  * linearise, residuals, barrier Hessian, Riccati factor, rhs build, Riccati solve, row passes, update, final, total. */
 int tmpc_debug_profile(tmpc_handle *h, int64_t *cycles, int32_t n_phases);
 
+/* The LDS bank-conflict model behind the compact kernels' layout padding (no handle, no GPU): the passes the row passes' coefficient loads
+ * take per wave and interior-point row pass for a stage stride of `dstride` doubles -- N stages, nh general rows per stage of which the first
+ * n_pair are stored as pairs, a kernel of `threads` (64 or 128) threads per trajectory.  tmpc_create picks, among the strides that keep the
+ * kernel's residency, the one this function likes best (diagnostics: TMPC_EXP_DPAD in INTEGRATION.md section 7); results never depend on it. */
+int tmpc_debug_lds_passes(int32_t N, int32_t n_pair, int32_t nh, int32_t threads, int32_t dstride);
+
 int tmpc_debug_eval_stage(tmpc_handle *h, int32_t n, const double *z, const double *p, const double *pi,
                           const double *lamh, double *cost, double *cost_grad, double *cost_hess,
                           double *hval, double *h_jac, double *x_next, double *x_jac, double *lag_hess,

@@ -819,6 +819,12 @@ int tmpc_clear_slot(tmpc_handle *h, int32_t slot)
     return TMPC_OK;
 }
 
+int tmpc_debug_lds_passes(int32_t N, int32_t n_pair, int32_t nh, int32_t threads, int32_t dstride)
+{
+    if (N < 1 || N > 64 || nh < 0 || n_pair < 0 || n_pair > nh || (threads != 64 && threads != 128) || dstride < 2 * n_pair + 3 * (nh - n_pair)) return TMPC_ERR_INVALID;
+    return tmpc::d_load_passes(N, n_pair, nh, threads, dstride);
+}
+
 int tmpc_has_lane_kernels(void)
 {
 #ifdef TMPC_WITH_LANES

@@ -97,3 +97,45 @@ def test_param_sharing_map_checks_equality():
     assert base[5] == 0 and base[9] == 9 and base[10] == 0
     d5 = solver.default_dims(N=20, S=5, n_lin=0, M=0, n_slk=24, slack=1)       # scenario rows after the disc offset
     assert solver.own_parameter_columns(d5).tolist() == list(range(8 + 1 + 45 + 1, 8 + 1 + 45 + 1 + 72))
+
+
+def test_lds_bank_conflict_model_of_the_layout_padding():
+    """tmpc_debug_lds_passes: the model tmpc_create ranks the row Jacobians' stage strides with (csrc/tmpc_capi.hip d_load_passes) -- pure host code.
+    Pinned against an independent restatement: lane (stage k, sub-lane c) of a wave reads the three entries of its row c + LPS s at k dstride + offset;
+    an 8-byte access takes as many passes as the most loaded of the 64 four-byte banks has distinct dwords."""
+    import __graft_entry__ as g
+    g.build()
+    from mpc_planner_amd import solver
+    lib = C.CDLL(solver.LIB_PATH)
+    lib.tmpc_debug_lds_passes.argtypes = [C.c_int32] * 5
+    lib.tmpc_debug_lds_passes.restype = C.c_int
+
+    def model(N, n_pair, nh, threads, dstride):
+        lps = (3 if 3 * N <= 64 else 2) if threads == 64 else (6 if N <= 21 else 4)
+        nk = min(N, 64 // lps)
+        rpl = (nh + 14 + lps - 1) // lps
+        total = 0
+        for s in range(rpl):
+            if lps * s >= nh:
+                break
+            for part in range(3):
+                banks = {}
+                for k in range(nk):
+                    for c in range(lps):
+                        r = c + lps * s
+                        a = N * dstride + part
+                        if r < nh:
+                            off = 2 * r if r < n_pair else 3 * r - n_pair
+                            a = k * dstride + off + part if (part < 2 or r >= n_pair) else N * dstride + 2
+                        for dw in (2 * a, 2 * a + 1):
+                            banks.setdefault(dw % 64, set()).add(dw)
+                total += max(len(v) for v in banks.values())
+        return total
+
+    # cfg 2's compact layout: 8 packed topology rows + 8 ellipsoid rows = 40 doubles per stage; the padding the library takes is +1
+    assert lib.tmpc_debug_lds_passes(20, 8, 16, 64, 40) == 83 and lib.tmpc_debug_lds_passes(20, 8, 16, 64, 41) == 37
+    for (N, n_pair, nh, threads) in [(20, 8, 16, 64), (20, 12, 24, 64), (20, 24, 24, 64), (20, 0, 4, 64), (30, 8, 28, 128), (30, 5, 10, 128), (20, 0, 16, 128)]:
+        base = 2 * n_pair + 3 * (nh - n_pair)
+        for pad in range(6):
+            assert lib.tmpc_debug_lds_passes(N, n_pair, nh, threads, base + pad) == model(N, n_pair, nh, threads, base + pad), (N, n_pair, nh, threads, pad)
+    assert lib.tmpc_debug_lds_passes(20, 8, 16, 64, 39) < 0 and lib.tmpc_debug_lds_passes(20, 8, 16, 96, 40) < 0      # below the bare stride / no such kernel
