@@ -127,13 +127,13 @@ static SolveKernel pick_fast_kernel(const Dims &d, int *threads, bool prof)
 // row passes are specialised by the compile-time kind of each row slot (FastCfg::KIND): 238 registers, zero scratch; their larger row tables
 // allow 7 (cfg 4: 23.3 KB) and 6 (cfg 5: 25.2 KB) workgroups per CU.  The runtime-shape instantiation with 13 rows per lane still spills
 // (168 B) and is not registered.
-// *hs29: whether the instantiation keeps its Hh blocks at a stride of 29 doubles (compact_hs29, tmpc_fast.hpp) -- evaluated on the template arguments
+// *lay: the instantiation's Hh layout (compact_layout, tmpc_fast.hpp) -- evaluated on the template arguments
 // where they are written, so that the host's LDS size and the kernel's layout cannot disagree
-#define TMPC_CP(a, b, c) (*hs29 = compact_hs29(a, b, 64), (SolveKernel)tmpc_solve_compact_kernel<a, b, c, false>)
-#define TMPC_CP2(a, b, c, m) (*hs29 = compact_hs29(a, b, 128), (SolveKernel)tmpc_solve_compact_kernel<a, b, c, false, 128, m>)
-static SolveKernel pick_compact_kernel(const Dims &d, bool prof, bool *hs29)
+#define TMPC_CP(a, b, c) (*lay = compact_layout(a, b, 64), (SolveKernel)tmpc_solve_compact_kernel<a, b, c, false>)
+#define TMPC_CP2(a, b, c, m) (*lay = compact_layout(a, b, 128), (SolveKernel)tmpc_solve_compact_kernel<a, b, c, false, 128, m>)
+static SolveKernel pick_compact_kernel(const Dims &d, bool prof, int *lay)
 {
-    *hs29 = false;
+    *lay = 1;
 #ifndef TMPC_GENERATED_STAGE
     if (getenv("TMPC_FORCE_GENERIC") || getenv("TMPC_NO_COMPACT") || prof || d.N > 20 || stage_model(d) != 0) return nullptr;
     const int nr = d.n_up + d.M + 14;                    // interior-point rows per stage
@@ -152,9 +152,9 @@ static SolveKernel pick_compact_kernel(const Dims &d, bool prof, bool *hs29)
 // fast two-wave kernel (57-70 KB of LDS) holds two.  Bitwise the same results; a trajectory takes longer on it (NLP data in the global
 // workspace, the linearisation on one of the two waves), so launch_solve uses it only for launches that the fast kernel could not hold
 // resident at once (more than two trajectories per CU).  The runtime-shape instantiation with 12 rows per lane spills (144 B): not registered.
-static SolveKernel pick_compact2_kernel(const Dims &d, bool *hs29)
+static SolveKernel pick_compact2_kernel(const Dims &d, int *lay)
 {
-    *hs29 = false;
+    *lay = 1;
 #ifndef TMPC_GENERATED_STAGE
     if (getenv("TMPC_FORCE_GENERIC") || getenv("TMPC_NO_COMPACT") || getenv("TMPC_NO_TWO_WAVE") || 3 * d.N <= NT || 4 * d.N > 128) return nullptr;
     const int nr = d.n_up + d.M + 14, sm = stage_model(d);
@@ -294,7 +294,7 @@ struct tmpc_handle {
     size_t lds_bytes_cp2 = 0;
     int cp2_min_B = 0;                        // what the fast two-wave kernel holds resident at once (workgroups per CU x CUs)
     int dpad_cp = 0, dpad_cp2 = 0;            // Dims::dpad of the compact one-wave / two-wave kernel (pick_d_pad); the fast layouts do not pad
-    bool hs29_cp = false, hs29_cp2 = false;                                      // the compact kernels' Hh stride (pick_compact*_kernel)
+    int lay_cp = 1, lay_cp2 = 1;              // the compact kernels' Hh layout (pick_compact*_kernel)
     bool prio_cp = false, prio_cp2 = false;   // wave issue priorities (Dims::prio) for the compact one-wave / two-wave kernel: only when its residency puts two waves on
                                               // every SIMD (8 waves per CU) -- with an odd count the waves that share a SIMD starve and set the makespan (tmpc_riccati.hpp)
     int latency_mode = 0;                     // 0: throughput kernels, 1: two-wave variant, 2: parallel-in-time variant
@@ -443,7 +443,7 @@ int tmpc_create(tmpc_handle **out, const tmpc_dims *dims, int32_t B_max, int32_t
         if (hipFuncSetAttribute((const void *)h->kernel_scan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes_scan) != hipSuccess)
             h->kernel_scan = nullptr;
     }
-    if (tmpc::SolveKernel kc = (h->fast && h->threads == tmpc::NT) ? tmpc::pick_compact_kernel(d, false, &h->hs29_cp) : nullptr) {
+    if (tmpc::SolveKernel kc = (h->fast && h->threads == tmpc::NT) ? tmpc::pick_compact_kernel(d, false, &h->lay_cp) : nullptr) {
         // the fast kernel of the shape (everything in LDS, four per CU) stays for launches it holds resident at once: bitwise the same results
         // (tests/test_gpu_compact2.py), a trajectory is ~10 % faster on it.  TMPC_COMPACT_MIN_B=0: the compact kernel for every launch (rounds 3-4)
         int fast_per_cu = 0, cus = 0;
@@ -455,7 +455,7 @@ int tmpc_create(tmpc_handle **out, const tmpc_dims *dims, int32_t B_max, int32_t
         }
         h->kernel = kc; h->compact = true;
         // padding of the packed rows' stage stride: only what keeps the residency (LDS is what bounds it: 8 x 20 KB at cfg 2)
-        auto lds_cp = [&](int pad) { return sizeof(double) * (size_t)tmpc::lds_doubles_compact(d.N, d.n_lin, d.n_up + d.M, 64, pad, h->hs29_cp); };
+        auto lds_cp = [&](int pad) { return sizeof(double) * (size_t)tmpc::lds_doubles_compact(d.N, d.n_lin, d.n_up + d.M, 64, pad, h->lay_cp); };
         auto per_cu_cp = [&](int pad) {
             int n = 0;
             if (hipFuncSetAttribute((const void *)kc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cp(pad)) != hipSuccess ||
@@ -469,9 +469,9 @@ int tmpc_create(tmpc_handle **out, const tmpc_dims *dims, int32_t B_max, int32_t
     if (hipFuncSetAttribute((const void *)h->kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)h->lds_bytes) != hipSuccess)
         return fail(TMPC_ERR_NO_DEVICE);
-    if (h->fast && h->threads == 128 && !h->compact && (h->kernel_cp2 = tmpc::pick_compact2_kernel(d, &h->hs29_cp2)) != nullptr) {
+    if (h->fast && h->threads == 128 && !h->compact && (h->kernel_cp2 = tmpc::pick_compact2_kernel(d, &h->lay_cp2)) != nullptr) {
         {
-            auto lds_cp2 = [&](int pad) { return sizeof(double) * (size_t)tmpc::lds_doubles_compact(d.N, d.n_lin, d.n_up + d.M, 128, pad, h->hs29_cp2); };
+            auto lds_cp2 = [&](int pad) { return sizeof(double) * (size_t)tmpc::lds_doubles_compact(d.N, d.n_lin, d.n_up + d.M, 128, pad, h->lay_cp2); };
             auto per_cu_cp2 = [&](int pad) {
                 int n = 0;
                 if (hipFuncSetAttribute((const void *)h->kernel_cp2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cp2(pad)) != hipSuccess ||

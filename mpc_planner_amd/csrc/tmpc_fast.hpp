@@ -70,20 +70,22 @@ __device__ __forceinline__ Lds carve_fast(double *s, const Dims &d)
 // once per RTI iteration and read once per interior-point iteration -- live in a per-workgroup workspace in global memory
 // (one slot per RESIDENT workgroup: ~9 KB x 8 per CU, L2-resident).  L.pr aliases L.dpi (tmpc_riccati.hpp).
 // nth = 128: the two-wave instantiations (21 <= N <= 32, four lanes per stage); their block-wide reductions need the 64-entry scratch
-// hs29: the instantiation keeps its Hh blocks at a stride of 29 doubles (hoff<2>, tmpc_riccati.hpp): the tuned one-wave shapes, except (12,12)
-// (seven per CU with 69 bytes to spare).  Not the two-wave instantiations: a wave of theirs holds 16 stages (two-way conflicts at most), measured
-// 0 ((20,8), cfg 3) and -2 % ((5,5), the jackal default) with the padded stride (profiles/round5_r_layout_check.jsonl against round5_final_*).
-__host__ __device__ constexpr bool compact_hs29(int NLIN, int MM, int NTH) { return NLIN >= 0 && NTH == 64 && !(NLIN == 12 && MM == 12); }
-__host__ __device__ inline int lds_doubles_compact(int N, int n_pair, int nh, int nth = 64, int dpad = 0, bool hs29 = false)
+// The compact instantiation's Hh layout (the Riccati routines' parameter CP, tmpc_riccati.hpp hstride<CP>): 2 -- blocks at a stride of 29 doubles -- for the tuned
+// one-wave shapes; 3 -- 30 doubles, y inside the block, no y array -- for (12,12) (seven per CU with 69 bytes to spare: 29 does not fit, 30 minus the y array does);
+// 1 -- the bare 28 -- for the run-time shapes (their LDS size is not known here) and the two-wave instantiations: a wave of theirs holds 16 stages (two-way
+// conflicts at most), measured 0 ((20,8), cfg 3) and -2 % ((5,5), the jackal default) with the padded stride (profiles/round5_r_layout_check.jsonl).
+__host__ __device__ constexpr int compact_layout(int NLIN, int MM, int NTH) { return (NLIN >= 0 && NTH == 64) ? ((NLIN == 12 && MM == 12) ? 3 : 2) : 1; }
+__host__ __device__ constexpr int compact_hstride(int layout) { return layout == 2 ? NP28 + 1 : (layout == 3 ? NP28 + 2 : NP28); }
+__host__ __device__ inline int lds_doubles_compact(int N, int n_pair, int nh, int nth = 64, int dpad = 0, int layout = 1)
 {
     const int dstride = 2 * n_pair + 3 * (nh - n_pair) + dpad;
     const int persistent = N * 8 + BA_NCONST + N * dstride + 3;
-    const int work = (N + 1) * NV + (N + 1) * NX + (N + 1) * (NP28 + (hs29 ? 1 : 0)) + 2 * (N + 1) * NV + N * NX + (N + 1) * NV + (N + 1) * NX + N * NU + (nth > 64 ? 64 : 8);
+    const int work = (N + 1) * NV + (N + 1) * NX + (N + 1) * compact_hstride(layout) + 2 * (N + 1) * NV + N * NX + (N + 1) * NV + (N + 1) * NX + (layout == 3 ? 0 : N * NU) + (nth > 64 ? 64 : 8);
     const int staging = 2 * N * nh;
     return persistent + (work > staging ? work : staging);
 }
 
-__device__ __forceinline__ Lds carve_compact(double *s, double *ws, const Dims &d, int nth = 64, bool hs29 = false)
+__device__ __forceinline__ Lds carve_compact(double *s, double *ws, const Dims &d, int nth = 64, int layout = 1)
 {
     Lds L;
     const int N = d.N;
@@ -99,9 +101,9 @@ __device__ __forceinline__ Lds carve_compact(double *s, double *ws, const Dims &
     L.tab = take(N * 8 + BA_NCONST);
     L.D = take(N * L.dstride + 3);                      // (+ one zero triple for box rows / the third entry of topology rows)
     double *w = s;
-    L.v = take((N + 1) * NV); L.pq = take((N + 1) * NX); L.Hh = take((N + 1) * (NP28 + (hs29 ? 1 : 0)));      // (hoff<CP>: tmpc_riccati.hpp)
+    L.v = take((N + 1) * NV); L.pq = take((N + 1) * NX); L.Hh = take((N + 1) * compact_hstride(layout));      // (hoff<CP>: tmpc_riccati.hpp)
     L.rg = take((N + 1) * NV); L.gh = take((N + 1) * NV); L.rb = take(N * NX); L.dv = take((N + 1) * NV);
-    L.dpi = take((N + 1) * NX); L.pr = L.dpi; L.y = take(N * NU); L.scr = take(nth > 64 ? 64 : 8);
+    L.dpi = take((N + 1) * NX); L.pr = L.dpi; L.y = layout == 3 ? nullptr : take(N * NU); L.scr = take(nth > 64 ? 64 : 8);
     s = w;
     L.beta = take(N * L.nh); L.lamh = take(N * L.nh);
     L.t = L.lam = L.invt = L.qt = L.rdiag = nullptr;
@@ -779,8 +781,8 @@ void tmpc_solve_compact_kernel(Dims d, int B, const double *__restrict__ xinit,
     const int tid0 = threadIdx.x;
     const int N = d.N;
     int tid = tid0;
-    constexpr int CPV = compact_hs29(NLIN, MM, NTH) ? 2 : 1;     // layout parameter of ipm_fast and the Riccati routines (hoff<CP>)
-    const Lds L = carve_compact(smem, io.ws + (size_t)blockIdx.x * ws_doubles(N, NTH > 64), d, NTH, CPV == 2);
+    constexpr int CPV = compact_layout(NLIN, MM, NTH);           // layout parameter of ipm_fast and the Riccati routines (hoff<CP>)
+    const Lds L = carve_compact(smem, io.ws + (size_t)blockIdx.x * ws_doubles(N, NTH > 64), d, NTH, CPV);
     ba_tab_init(L.tab, d, tid);
     if (tid < 3) L.D[N * L.dstride + tid] = 0.0;        // zero triple read by box rows (and as the third entry of packed rows)
     __syncthreads();

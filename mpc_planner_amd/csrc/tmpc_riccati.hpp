@@ -62,11 +62,16 @@ constexpr int FB_LXU = 0, FB_L10 = 10, FB_R0 = 11, FB_R1 = 12, FB_P = 13;
 // Offset of stage k's block in Hh.  A stride of 28 doubles (56 dwords) puts the stages k, k + 8, k + 16 on the same LDS banks: the stage-parallel loops
 // (one lane per stage: the node's 28 stores of Hh <- W, the 15 + 15 loads of P in the vector solves' prologue / epilogue, the row passes' ds_add_f64)
 // ran every access in three passes; 29 is conflict-free and costs (N + 1) doubles of LDS.  The stride is a COMPILE-TIME fact of the instantiation --
-// the layout parameter CP of the routines below: 0 fast / generic layouts (28), 1 compact (28), 2 compact with 29 (compact_hs29(): the tuned shapes
-// whose LDS budget has the room at every N they run) -- because a run-time stride, one more live SGPR in kernels that spill 250 of them, cost the
-// two-wave compact kernels 3.7 %, and a bank swizzle k * 28 + (k >> 3) (no extra LDS) more than it saved (profiles/round5_q_*).  Measured: +2.4 % at cfg 2.
-template <int CP> __device__ __forceinline__ int hoff(int k) { return k * (CP == 2 ? NP28 + 1 : NP28); }
-template <int CP> __device__ __forceinline__ int hoff_lane(int k) { return mul24(k, CP == 2 ? NP28 + 1 : NP28); }                 // (k per lane)
+// the layout parameter CP of the routines below: 0 fast / generic layouts (28), 1 compact (28), 2 compact with 29, 3 compact with 30 doubles of which the
+// last two hold the stage's y (compact_layout(), tmpc_fast.hpp: the tuned one-wave shapes; 3 is (12,12)'s, whose seven-per-CU budget has 69 bytes to spare --
+// 30 k is 2-way at worst for 21 stages, and dropping the y array pays for it) -- because a run-time stride, one more live SGPR in kernels that spill 250 of
+// them, cost the two-wave compact kernels 3.7 %, and a bank swizzle k * 28 + (k >> 3) (no extra LDS) more than it saved (profiles/round5_q_*).  Measured: +2.4 % at cfg 2.
+template <int CP> __host__ __device__ constexpr int hstride() { return CP == 2 ? NP28 + 1 : (CP == 3 ? NP28 + 2 : NP28); }
+template <int CP> __device__ __forceinline__ int hoff(int k) { return k * hstride<CP>(); }
+template <int CP> __device__ __forceinline__ int hoff_lane(int k) { return mul24(k, hstride<CP>()); }                             // (k per lane)
+// y = Luu^-1 (...) of stage k, handed from the backward sweep (or the factorisation's extra row) to the forward sweep: its own array, or -- layout 3 --
+// the two spare doubles of the stage's 30-double block
+template <int CP> __device__ __forceinline__ double *ysl(const Lds &L, int k) { return CP == 3 ? L.Hh + hoff<CP>(k) + NP28 : L.y + k * NU; }
 
 // (The sequential sweeps use lanes 0..7 of the wave and rows 1..3 run along on copies.  Switching those rows off for the sweeps -- the LDS unit is
 // busy 70 % of the kernel time at eight trajectories per CU and the sweeps issue two thirds of its instructions -- was measured in round 5: 1.3 %
@@ -277,7 +282,7 @@ __device__ __forceinline__ bool riccati_factor_rows(const Lds &L, const Dims &d,
             if (li == 1) { Fb[FB_L10] = f[0]; Fb[FB_R0] = r0; Fb[FB_R1] = r1; }
         }
         if (vec && wr) {                                           // [y0 y1 | p_k] of stage k
-            L.y[k * NU] = f[0]; L.y[k * NU + 1] = f[1];
+            ysl<CP>(L, k)[0] = f[0]; ysl<CP>(L, k)[1] = f[1];
 #pragma unroll
             for (int l = 0; l < NX; l++) L.pr[k * NX + l] = f[NU + l];
         }
@@ -417,7 +422,7 @@ __device__ __forceinline__ void riccati_sweeps_rows(const Lds &L, const Dims &d,
             const double y0 = bcast16<0>(fj) * o.r0;
             const double y1 = (bcast16<1>(fj) - o.l10 * y0) * o.r1;
             p = fj - o.lx0 * y0 - o.lx1 * y1;
-            if (rowl && li == 0) { L.y[k * NU] = y0; L.y[k * NU + 1] = y1; }
+            if (rowl && li == 0) { ysl<CP>(L, k)[0] = y0; ysl<CP>(L, k)[1] = y1; }
             if (xl) L.pr[k * NX + i5] = p;
         };
         Ops oa, ob;
@@ -457,7 +462,7 @@ __device__ __forceinline__ void riccati_sweeps_rows(const Lds &L, const Dims &d,
         const BaLane br = ba_row4(N, i5);
         auto load_stage = [&](Ops &o, int k) {
             const double *Fb = L.Hh + hoff<CP>(k);
-            o.y0 = L.y[k * NU]; o.y1 = L.y[k * NU + 1];
+            o.y0 = ysl<CP>(L, k)[0]; o.y1 = ysl<CP>(L, k)[1];
             o.r0 = Fb[FB_R0]; o.l10 = Fb[FB_L10]; o.r1 = Fb[FB_R1];
             if constexpr (CP) {
                 const double *Tr = L.tab + br.o0 + mul24(k, br.st);              // own row of [B A] as (b_a, b_w, a_psi, a_v)
