@@ -104,7 +104,7 @@ def usable_cpus():
     return n
 
 
-def cpu_baseline(n_scenes):
+def cpu_baseline(n_scenes, quick=False):
     """Reported baseline (NOT the target): the restated acados-equivalent CPU path (oracle/, kind 'port'), OpenMP over trajectories like
     guidance_constraints.cpp:279, on all host cores.  Protocol = BASELINE.md section 3: steady clock around the whole batch call, 20 warm-up
     calls, 200 timed repetitions, p50 / p90, solves/s = B / p50 -- on a BOUNDED batch (16 solves per core per call, tiled from `n_scenes`
@@ -118,7 +118,9 @@ def cpu_baseline(n_scenes):
     batch = scenes.make_batch(range(n_scenes), N=N_H, M=M_OBS, B=TRAJ)
     B = 16 * cores
     n_have = batch["xinit"].shape[0]
-    pick = (np.arange(B) * 7) % n_have                                   # spread over the scenes (7 is coprime to 64 x n_scenes)
+    import math
+    stride = next(c for c in (7, 11, 13, 17, 19, 23, 1) if math.gcd(c, n_have) == 1)    # coprime to the sample size: every scene is visited
+    pick = (np.arange(B) * stride) % n_have
     args = (pb, batch["xinit"][pick], batch["x0"][pick].reshape(B, -1), batch["params"][pick].reshape(B, -1))
 
     def timed(call, warm, reps, budget_s):
@@ -131,21 +133,22 @@ def cpu_baseline(n_scenes):
                 break
         return np.array(ts)
 
-    ts = timed(lambda: O.solve_batch(*args, num_threads=cores), 20, 200, 40.0)
+    warm, reps = (1, 3) if quick else (20, 200)                      # quick: the launcher self-test (tests/test_bench_launcher.py), not a measurement
+    ts = timed(lambda: O.solve_batch(*args, num_threads=cores), warm, reps, 40.0)
     sl = slice(0, TRAJ)
-    tick = timed(lambda: O.solve_batch(pb, batch["xinit"][sl], batch["x0"][sl].reshape(TRAJ, -1), batch["params"][sl].reshape(TRAJ, -1), num_threads=cores), 20, 200, 15.0)
+    tick = timed(lambda: O.solve_batch(pb, batch["xinit"][sl], batch["x0"][sl].reshape(TRAJ, -1), batch["params"][sl].reshape(TRAJ, -1), num_threads=cores), warm, reps, 15.0)
     one = []                                                         # single-thread latency of ONE Solver::solve()
-    for i in range(64):
+    for i in range(4 if quick else 64):
         s1 = slice(i, i + 1)
         t1 = time.perf_counter(); O.solve_batch(pb, args[1][s1], args[2][s1], args[3][s1], num_threads=1); one.append(time.perf_counter() - t1)
     p50, p90 = float(np.percentile(ts, 50)), float(np.percentile(ts, 90))
     return {"value": B / p50, "unit": "solves/s", "cores": cores, "kind": "port",
-            "protocol": "BASELINE.md section 3: 20 warm-up calls, 200 repetitions of the whole batch call, solves/s = B / p50",
+            "protocol": f"BASELINE.md section 3: {warm} warm-up calls, {reps} repetitions of the whole batch call, solves/s = B / p50",
             "batch": B, "repetitions": int(len(ts)), "batch_ms_p50": p50 * 1e3, "batch_ms_p90": p90 * 1e3,
             "tick_b64": {"repetitions": int(len(tick)), "ms_p50": float(np.percentile(tick, 50) * 1e3), "ms_p90": float(np.percentile(tick, 90) * 1e3),
                          "solves_per_s": float(TRAJ / np.percentile(tick, 50)), "what": "one 64-trajectory guidance set per call (the reference's OpenMP loop as it runs per control tick)"},
             "single_thread_solve_ms_p50": float(np.percentile(one, 50) * 1e3),
-            "sample": f"{B} solves per call (16 per core) drawn from {n_scenes} scenes x {TRAJ} trajectories of the same workload, {len(ts)} timed calls after 20 warm-ups "
+            "sample": f"{B} solves per call (16 per core) drawn from {n_scenes} scenes x {TRAJ} trajectories of the same workload, {len(ts)} timed calls after {warm} warm-ups "
                       f"({float(ts.sum()):.1f} s), restated acados-equivalent C oracle (oracle/), OpenMP over trajectories on the {cores} CPUs usable by this "
                       f"process (affinity / cgroup quota; {os.cpu_count()} logical CPUs visible)"}
 
@@ -406,6 +409,55 @@ def end_to_end_leg(a, dims, sv, batch, t_xinit, t_x0, t_params, dev, n_sets, tra
             "winners_copied_back_equal_device_trajectories": winners_ok}
 
 
+# keys every bench line carries, at every N (the driver's contract + this tier's roofline / cpu_baseline objects)
+REQUIRED_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                 "config", "roofline", "cpu_baseline", "parity")
+
+
+def gathered_index_inputs(dist, host_pg, batch, n_traj, rank, world):
+    """Every rank's first n_traj trajectories (inputs) -> rank 0, over the host (gloo) group.  Returns on rank 0 a list over ranks of
+    (xinit, x0, params) arrays, None elsewhere."""
+    import torch
+    parts = [np.ascontiguousarray(batch[k][:n_traj]).reshape(n_traj, -1) for k in ("xinit", "x0", "params")]
+    mine = torch.from_numpy(np.concatenate(parts, axis=1))
+    into = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
+    dist.gather(mine, into, dst=0, group=host_pg)
+    if rank != 0:
+        return None
+    w = [p.shape[1] for p in parts]
+    return [tuple(np.ascontiguousarray(a) for a in np.split(t.numpy(), np.cumsum(w)[:-1], axis=1)) for t in into]
+
+
+def best_index_block_gathered(O, wl, inputs, rec, best, world, per_rank, n_chk):
+    """FindBestPlanner on the all-gathered records (N > 1).  rec: [world][n_sets][per_rank] tmpc_record as the collective left them on rank 0;
+    best: the device's index per set in the gathered numbering (rank * per_rank + t).  (i) the reference's rule (orc_find_best: init 1e10,
+    strict '<', lowest index) on the gathered DEVICE objectives, ALL sets: integer work, must be 0 mismatches; (ii) the oracle's own pick
+    from its solves of every rank's inputs, first n_chk sets; ties at rounding counted separately (see best_index_block)."""
+    n_sets = rec.shape[1]
+    obj = np.transpose(rec["objective"], (1, 0, 2)).reshape(n_sets, world * per_rank)
+    ec = np.transpose(rec["exit_code"], (1, 0, 2)).reshape(n_sets, world * per_rank)
+    mism_rule = sum(int(int(best[s]) != O.find_best(obj[s], ec[s])) for s in range(n_sets))
+    pbo = O.problem(**wl.get("oracle_dims", wl["dims"]))
+    pobj_o, ec_o = [], []
+    for xi, x0, pr in inputs:                                   # one oracle batch per rank
+        _, _, info = O.solve_batch(pbo, xi, x0, pr, num_threads=usable_cpus())
+        pobj_o.append(info["pobj"].reshape(n_chk, per_rank)); ec_o.append(info["exit_code"].reshape(n_chk, per_rank))
+    pobj_o = np.concatenate(pobj_o, axis=1); ec_o = np.concatenate(ec_o, axis=1)        # [n_chk][world * per_rank]: the gathered numbering
+    mism_oracle = ties = 0
+    worst = 0.0
+    for s in range(n_chk):
+        dev_best, ref = int(best[s]), O.find_best(pobj_o[s], ec_o[s])
+        if dev_best != ref:
+            mism_oracle += 1
+            if dev_best >= 0 and ref >= 0:
+                rel = abs(float(obj[s][dev_best]) - float(pobj_o[s][ref])) / max(1.0, abs(float(pobj_o[s][ref])))
+                worst = max(worst, rel); ties += int(rel <= 1e-9)
+    return {"on": "the all-gathered records (selection domain = world x per-rank trajectories per set)", "sets_checked_vs_rule": int(n_sets),
+            "sets_checked_vs_oracle": int(n_chk), "set_size": int(world * per_rank), "trajectories_solved_by_the_oracle": int(n_chk * world * per_rank),
+            "best_index_mismatch_vs_rule_on_device_objectives": mism_rule, "best_index_mismatch_vs_oracle": mism_oracle,
+            "of_which_objective_ties_at_rounding": ties, "true_mismatches": mism_oracle - ties, "worst_relative_objective_gap_among_mismatches": worst}
+
+
 def _free_port():
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
@@ -431,23 +483,62 @@ def self_launch(n, argv):
 
 
 def launcher_selftest(a, world, rank):
-    """`--launcher-selftest`: the launch path alone (no GPU): every rank joins a gloo group, the ranks all-gather their 16-byte records the way a
-    step does, and rank 0 prints the one JSON line.  tests/test_bench_launcher.py drives this at N = 2 through the plain command."""
+    """`--launcher-selftest`: the N > 1 control flow of main() without a GPU (gloo in RCCL's place): scene-generation workers divided by the world
+    size, the host group's barriers around rank 0's CPU baseline, `steps` timed all-gathers of 16-byte records the way a step does them, the
+    selection rule on the gathered records, the gather of every rank's inputs to rank 0, the ranks held at the host barrier until rank 0 is
+    done -- and rank 0 prints ONE JSON line with the full key set of a real line (REQUIRED_KEYS; the values that need a GPU are null and the line
+    says so).  tests/test_bench_launcher.py drives this at N = 2 through the plain command."""
+    import datetime
     import torch
     import torch.distributed as dist
-    from mpc_planner_amd import distributed as D
+    from mpc_planner_amd import distributed as D, scenes
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29511")
+    gen_workers = a.gen_workers or max(1, usable_cpus() // world)
+    n_sets, per = 2, 8
+    batch = scenes.make_batch(range(100000 * rank, 100000 * rank + n_sets), workers=min(gen_workers, n_sets), N=N_H, M=M_OBS, B=per)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    per = 8
-    rec = D.pack_records_host(np.arange(per, dtype=np.float64) + 100.0 * (world - rank), np.ones(per, np.int32), np.arange(per) + per * rank)
-    t = torch.from_numpy(rec.view(np.int64).reshape(per, 2).copy())
-    g = D.all_gather_records(t, world)
+    host_pg = dist.new_group(backend="gloo", timeout=datetime.timedelta(minutes=60))
+    cpu_base = None
+    if not a.no_cpu_baseline:
+        dist.barrier(group=host_pg)
+        if rank == 0:
+            cpu_base = cpu_baseline(1, quick=True)
+        dist.barrier(group=host_pg)
+    # stand-in records (no solve without a GPU): a deterministic objective per (rank, set, trajectory), every fifth trajectory failed
+    g = np.arange(n_sets * per).reshape(n_sets, per)
+    objective = 50.0 + ((g * 37 + 11 * rank) % 23).astype(np.float64)
+    exit_code = np.where((g + rank) % 5 == 0, 4, 1).astype(np.int32)
+    rec = D.pack_records_host(objective.ravel(), exit_code.ravel(), (g + n_sets * per * rank).ravel())
+    t = torch.from_numpy(rec.view(np.int64).reshape(n_sets * per, 2).copy())
     dist.barrier()
-    allrec = g.numpy().reshape(-1).view(D.RECORD_DTYPE)
-    best = int(np.argmin(allrec["objective"]))
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        gathered = D.all_gather_records(t, world)
+    dist.barrier()
+    elapsed = time.perf_counter() - t0
+    allrec = gathered.numpy().reshape(-1).view(D.RECORD_DTYPE).reshape(world, n_sets, per)
+    best = D.find_best_planner_records(allrec)                  # what tmpc_select_best_records computes on device
+    blk = gathered_index_inputs(dist, host_pg, batch, n_sets * per, rank, world)
     if rank == 0:
-        print(json.dumps({"launcher_selftest": True, "n_gpus": world, "records": int(allrec.shape[0]), "best": best,
-                          "self_launched": os.environ.get("TMPC_BENCH_SELF_LAUNCHED") == "1"}))
+        obj = np.transpose(allrec["objective"], (1, 0, 2)).reshape(n_sets, world * per)
+        ec = np.transpose(allrec["exit_code"], (1, 0, 2)).reshape(n_sets, world * per)
+        rule = [int(np.argmin(np.where((ec[s] == 1) & (obj[s] < 1e10), obj[s], np.inf))) if ((ec[s] == 1) & (obj[s] < 1e10)).any() else -1 for s in range(n_sets)]
+        out = {"launcher_selftest": True, "self_launched": os.environ.get("TMPC_BENCH_SELF_LAUNCHED") == "1",
+               "metric": "launcher self-test (no GPU: records all-gathered per second over gloo; NOT the benchmark)", "value": world * n_sets * per * a.steps / elapsed,
+               "unit": "records/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": f"launcher self-test: {n_sets} sets x {per} stand-in records per rank", "gen_workers_per_rank": gen_workers,
+                          "omp_num_threads": os.environ.get("OMP_NUM_THREADS")},
+               "roofline": None, "records": int(allrec.size), "best": [int(b) for b in best],
+               "parity": {"best_index": {"on": "the all-gathered records", "sets_checked_vs_rule": n_sets,
+                                         "best_index_mismatch_vs_rule_on_device_objectives": int(sum(int(best[s]) != rule[s] for s in range(n_sets))),
+                                         "inputs_gathered_from_ranks": len(blk), "input_shapes_rank_last": [list(x.shape) for x in blk[-1]]}}}
+        if cpu_base is not None:
+            out["cpu_baseline"] = cpu_base
+        missing = [k for k in REQUIRED_KEYS if k not in out and not (k == "cpu_baseline" and a.no_cpu_baseline)]
+        assert not missing, missing
+        print(json.dumps(out))
+    dist.barrier(group=host_pg)
     dist.destroy_process_group()
 
 
@@ -499,13 +590,14 @@ def main():
         return launcher_selftest(a, world, rank)
     wl = WORKLOADS[a.workload]
     TRAJ_SET = wl["traj"]                                 # trajectories of one guidance / scenario set (one FindBestPlanner domain)
+    gen_workers = a.gen_workers or max(1, usable_cpus() // world)      # the ranks of one node generate their scenes side by side: share the host cores
 
     # ---- synthetic inputs, generated before the GPU runtime is touched (forked workers) -------------------------
     from mpc_planner_amd import scenes
     if wl.get("one_set") and a.sets > 1:
         # NOT the BASELINE configuration (which names one set): `--sets K` independent sets of the same shape in one launch, to show the kernels
         # of the shape on a saturated GPU (cfg 3: the two-wave compact kernel, four trajectories per CU, takes launches of more than 512)
-        batch = scenes.make_batch(range(7, 7 + a.sets), workers=a.gen_workers or usable_cpus(), B=TRAJ_SET, **wl["scene"])
+        batch = scenes.make_batch(range(7, 7 + a.sets), workers=gen_workers, B=TRAJ_SET, **wl["scene"])
         n_sets, traj_local = a.sets, TRAJ_SET
     elif wl.get("one_set"):
         # one set split over the ranks: every rank builds the same scene and keeps its contiguous share
@@ -521,7 +613,7 @@ def main():
         if cache and os.path.exists(cache):
             batch = dict(np.load(cache))
         else:
-            batch = scenes.make_batch(range(first_scene, first_scene + a.scenes), workers=a.gen_workers or usable_cpus(), B=TRAJ_SET, **wl["scene"])
+            batch = scenes.make_batch(range(first_scene, first_scene + a.scenes), workers=gen_workers, B=TRAJ_SET, **wl["scene"])
             if cache:
                 np.savez(cache, **{k: batch[k] for k in ("xinit", "x0", "params", "guidance_id", "guidance_pos", "guidance_vel", "obstacle_pos") if k in batch})
         n_sets, traj_local = a.scenes, TRAJ_SET
@@ -529,7 +621,7 @@ def main():
     batch_in = None
     if a.workload == "cfg2" and not a.no_end_to_end and world == 1 and "RANK" not in os.environ and a.scenes >= 32 and not a.latency_mode:
         # scenes on which projectToSafety acts, for the end-to-end leg (generated before the GPU runtime is touched: forked workers)
-        batch_in = scenes.make_batch(range(900000, 900016), workers=a.gen_workers or usable_cpus(), B=TRAJ_SET, inside_share=0.1, **wl["scene"])
+        batch_in = scenes.make_batch(range(900000, 900016), workers=gen_workers, B=TRAJ_SET, inside_share=0.1, **wl["scene"])
 
     import torch
     import torch.distributed as dist
@@ -544,6 +636,22 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    # Host-side waits (rank 0's CPU baseline before the timed region, its oracle legs after it) go through a gloo group with a long timeout:
+    # the other ranks block on sockets there, nothing is left pending on the GPUs and nothing depends on RCCL's watchdog.
+    import datetime
+    host_pg = dist.new_group(backend="gloo", timeout=datetime.timedelta(minutes=60)) if use_dist else None
+
+    def host_barrier():
+        if use_dist:
+            dist.barrier(group=host_pg)
+
+    # ---- reported CPU baseline (rank 0, at every N): before the timed region, while the other ranks wait and the host cores are free -------
+    cpu_base = None
+    if not a.no_cpu_baseline:
+        host_barrier()                                      # every rank's scene generation is done
+        if rank == 0:
+            cpu_base = cpu_baseline(a.cpu_scenes)
+        host_barrier()
 
     t_xinit = torch.from_numpy(batch["xinit"]).to(dev)
     t_x0 = torch.from_numpy(batch["x0"].reshape(B, -1)).to(dev)
@@ -646,6 +754,19 @@ def main():
         parity = parity_block(O, wl, batch, res, a.parity_check, {})
         if a.index_check_sets > 0 and not use_dist:
             parity["best_index"] = best_index_block(O, wl, batch, res, best, traj_local, a.index_check_sets)
+    if use_dist and a.index_check_sets > 0:
+        # N > 1 (and N = 1 under the launcher): the selection ran on the GATHERED records -- check it there.  Every rank hands rank 0 the inputs of
+        # its first sets over the host group; rank 0 re-solves them with the oracle and applies the reference's rule to the gathered records.
+        n_chk = min(n_sets, 16)
+        blk = gathered_index_inputs(dist, host_pg, batch, n_chk * traj_local, rank, world)
+        if rank == 0:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_lib as O
+            rec_host = step.keep.cpu().numpy().reshape(-1).view(D.RECORD_DTYPE).reshape(world, n_sets, traj_local)
+            bi = best_index_block_gathered(O, wl, blk, rec_host, best, world, traj_local, n_chk)
+            if parity is None:
+                parity = {}
+            parity["best_index"] = bi
     n_sqp_mean = float(res["sqp_iter"].mean())
     ipm_per_qp = float(res["qp_iter_total"].sum() / max(res["sqp_iter"].sum(), 1))
 
@@ -809,10 +930,13 @@ def main():
             "best_index_sample": best[:4].tolist(),
             "scenario_pipeline": scenario_info,
         }
-        if not a.no_cpu_baseline and world == 1:                      # reported baseline: rank 0 at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(a.cpu_scenes)
+        if cpu_base is not None:                                      # reported baseline: rank 0's host cores, measured before the timed region (at every N)
+            out["cpu_baseline"] = cpu_base
+        missing = [k for k in REQUIRED_KEYS if k not in out and not (k == "cpu_baseline" and a.no_cpu_baseline)]
+        assert not missing, missing
         print(json.dumps(out))
     sv.close()
+    host_barrier()                                          # ranks != 0 wait HERE (gloo, on sockets) while rank 0 runs its oracle / latency legs
     if use_dist:
         dist.destroy_process_group()
 

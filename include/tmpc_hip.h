@@ -75,7 +75,20 @@ typedef struct tmpc_dims {
                              major, minor, risk, r --, h >= 0; the collision-avoidance submodule of mpc_planner_jackal's default T-MPC,
                              generate_jackal_solver.py:53-73).  npar follows: 6 instead of 7 entries per obstacle.  Set by tmpc_default_dims* to 0; not
                              together with cost_model 1.  Hand-written kernels only. */
+    int32_t riccati_form; /* form of the Riccati recursion inside the interior-point QP solver (round 6).  TMPC_RICCATI_SCHUR (0, what
+                             tmpc_default_dims* sets): the cost-to-go Hessian P_k is kept as the Schur complement F_xx - Lxu Lxu^T (HPIPM's
+                             square_root_alg = 0 [UPSTREAM]) -- every kernel family, every latency mode.  TMPC_RICCATI_SQUARE_ROOT (1): P_k is
+                             re-factorised at every stage (P_k = Lxx Lxx^T: HPIPM's square_root_alg = 1 [UPSTREAM], the default of the mode
+                             acados configures, solver_generator/generate_acados_solver.py:171) -- the run-time-shape fast kernels only (N <= 32,
+                             any row mix of cost_model 0; cost_model 1 at N > 20; no compact / latency variants: tmpc_set_latency_mode answers 1).
+                             SUPPORTED qp_tol RANGE: at qp_tol >= 1e-7 the two forms give the same exit codes, iteration counts and iterates to
+                             rounding (profiles/round5_riccati_form_study.json: 0 of 6400 solves differ at the reference's 1e-5); below that the
+                             interior-point method runs into the conditioning of the barrier systems and 0.4-3.4 % of the solves end differently
+                             at 1e-9 -- a comparison with a real acados at such a tolerance (tools/acados_replay.py --qp-tol 1e-9) should run form 1.
+                             (The CPU oracle numbers its option the other way round: orc_problem.riccati_form 0 = square-root, 1 = Schur.) */
 } tmpc_dims;
+#define TMPC_RICCATI_SCHUR 0
+#define TMPC_RICCATI_SQUARE_ROOT 1
 
 typedef struct tmpc_handle tmpc_handle;
 
@@ -89,9 +102,12 @@ void tmpc_default_dims_ex(tmpc_dims *d, int32_t N, int32_t S, int32_t n_lin, int
  * (acados_solver_interface.cpp:17,33) for B_max solver instances at once.  Owns device buffers + stream. */
 int tmpc_create(tmpc_handle **out, const tmpc_dims *dims, int32_t B_max, int32_t device);
 /* Same, for callers that may have been built against another revision of this header: `dims_size` = the caller's sizeof(tmpc_dims).  Fields
- * the caller's struct does not have (it is shorter: cost_model / row_model were appended in round 4) take their defaults (0) instead of being
- * read from whatever follows the caller's struct; a longer struct is truncated (fields this library does not know are ignored).  New code
- * should call this one: tmpc_create(out, dims, ..) == tmpc_create_v2(out, dims, sizeof(tmpc_dims), ..) of the SAME header revision. */
+ * the caller's struct does not have (it is shorter: cost_model / row_model were appended in round 4, riccati_form in round 6) take their
+ * defaults (0) instead of being read from whatever follows the caller's struct.  Accepted sizes are exactly the struct's REVISION BOUNDARIES
+ * (the size up to n_slk / slack, up to row_model, the current one): a size that ends inside a field is refused.  A LONGER struct (a newer header
+ * than this library) is accepted only if every byte beyond this library's struct is zero -- a non-zero field the library does not know is an
+ * option it cannot honour, and is refused (TMPC_ERR_INVALID) instead of being ignored.  New code should call this one:
+ * tmpc_create(out, dims, ..) == tmpc_create_v2(out, dims, sizeof(tmpc_dims), ..) of the SAME header revision. */
 int tmpc_create_v2(tmpc_handle **out, const tmpc_dims *dims, uint32_t dims_size, int32_t B_max, int32_t device);
 /* Replaces Solver_acados_free + Solver_acados_free_capsule (:54,60). */
 void tmpc_destroy(tmpc_handle *h);

@@ -399,58 +399,85 @@ namespace MPCPlanner
         const std::map<int, int> &guidanceToPlannerMap() const { return _map_homotopy_class_to_planner; }
         int NumberOfGuidanceTrajectories() const { return (int)_guidance.size(); }
 
-        int optimize(State &state, const RealTimeData &data, ModuleData &module_data)
+        /* the OpenMP loop's body up to solve() (:281-337): false if the planner is disabled this tick */
+        bool preparePlanner(LocalPlanner &planner, State &state, const RealTimeData &data, ModuleData &module_data)
         {
-            if (!_use_tmpcpp && _guidance.empty()) return 0;                                  /* :273-274 */
-            const bool shift_forward = _cfg.shift_previous_solution_forward;
-            std::vector<Solver *> active;
-            std::vector<LocalPlanner *> active_planners;
-            for (auto &planner : planners_) {                                                  /* the OpenMP loop's body up to solve(), :279-337 */
-                planner.result.Reset();
-                planner.disabled = false;
-                if (planner.id >= NumberOfGuidanceTrajectories() && !planner.is_original_planner) { planner.disabled = true; continue; }
-                auto &solver = planner.local_solver;
-                *solver = *_solver;                                                            /* copy the main solver */
-                if (planner.is_original_planner || !_enable_constraints) {
-                    planner.guidance_constraints->update(state, empty_data_, module_data);
-                    planner.safety_constraints->update(state, data, module_data);
-                } else {
-                    if (_cfg.warmstart_with_mpc_solution && planner.existing_guidance) planner.local_solver->initializeWarmstart(state, shift_forward);
-                    else initializeSolverWithGuidance(planner);
-                    planner.guidance_constraints->update(state, data, module_data);
-                    planner.safety_constraints->update(state, data, module_data);
-                }
-                for (int k = 0; k < _solver->N; k++) {
-                    if (planner.is_original_planner) planner.guidance_constraints->setParameters(empty_data_, module_data, k);
-                    else planner.guidance_constraints->setParameters(data, module_data, k);
-                    planner.safety_constraints->setParameters(data, module_data, k);
-                }
-                planner.local_solver->loadWarmstart();
-                active.push_back(solver.get()); active_planners.push_back(&planner);
+            planner.result.Reset();
+            planner.disabled = false;
+            if (planner.id >= NumberOfGuidanceTrajectories() && !planner.is_original_planner) { planner.disabled = true; return false; }
+            auto &solver = planner.local_solver;
+            *solver = *_solver;                                                            /* copy the main solver */
+            if (planner.is_original_planner || !_enable_constraints) {
+                planner.guidance_constraints->update(state, empty_data_, module_data);
+                planner.safety_constraints->update(state, data, module_data);
+            } else {
+                if (_cfg.warmstart_with_mpc_solution && planner.existing_guidance) planner.local_solver->initializeWarmstart(state, _cfg.shift_previous_solution_forward);
+                else initializeSolverWithGuidance(planner);
+                planner.guidance_constraints->update(state, data, module_data);
+                planner.safety_constraints->update(state, data, module_data);
             }
-            const std::vector<int> codes = Solver::solveBatch(_batch, active);                 /* ONE launch instead of solver->solve() per thread (:339); every planner on its own slot */
-            for (size_t i = 0; i < active.size(); i++) {                                       /* ANALYSIS AND PROCESSING (:343-360) */
-                LocalPlanner &planner = *active_planners[i];
-                planner.result.exit_code = codes[i];
-                planner.result.success = planner.result.exit_code == 1;
-                planner.result.objective = planner.local_solver->_info.pobj;
-                if (planner.is_original_planner) {
-                    planner.result.guidance_ID = 2 * _cfg.n_paths;
-                    planner.result.color = -1;
-                } else {
-                    const GuidanceTrajectory &g = _guidance[planner.id];
-                    planner.result.guidance_ID = g.topology_class;
-                    planner.result.color = g.color;
-                    if (g.previously_selected) planner.result.objective *= _cfg.selection_weight_consistency;
-                }
+            for (int k = 0; k < _solver->N; k++) {
+                if (planner.is_original_planner) planner.guidance_constraints->setParameters(empty_data_, module_data, k);
+                else planner.guidance_constraints->setParameters(data, module_data, k);
+                planner.safety_constraints->setParameters(data, module_data, k);
             }
-            best_planner_index_ = FindBestPlanner();                                           /* DECISION MAKING (:366-387) */
+            planner.local_solver->loadWarmstart();
+            return true;
+        }
+        /* ANALYSIS AND PROCESSING (:343-360) */
+        void recordResult(LocalPlanner &planner, int exit_code)
+        {
+            planner.result.exit_code = exit_code;
+            planner.result.success = planner.result.exit_code == 1;
+            planner.result.objective = planner.local_solver->_info.pobj;
+            if (planner.is_original_planner) {
+                planner.result.guidance_ID = 2 * _cfg.n_paths;
+                planner.result.color = -1;
+            } else {
+                const GuidanceTrajectory &g = _guidance[planner.id];
+                planner.result.guidance_ID = g.topology_class;
+                planner.result.color = g.color;
+                if (g.previously_selected) planner.result.objective *= _cfg.selection_weight_consistency;
+            }
+        }
+        /* DECISION MAKING (:366-387) */
+        int decide()
+        {
+            best_planner_index_ = FindBestPlanner();
             if (best_planner_index_ == -1) return planners_[0].result.exit_code;
             auto &best_planner = planners_[best_planner_index_];
             _solver->_output = best_planner.local_solver->_output;
             _solver->_info = best_planner.local_solver->_info;
             _solver->_params = best_planner.local_solver->_params;
             return best_planner.result.exit_code;
+        }
+        int optimize(State &state, const RealTimeData &data, ModuleData &module_data)
+        {
+            if (!_use_tmpcpp && _guidance.empty()) return 0;                                  /* :273-274 */
+            std::vector<Solver *> active;
+            std::vector<LocalPlanner *> active_planners;
+            for (auto &planner : planners_)
+                if (preparePlanner(planner, state, data, module_data)) { active.push_back(planner.local_solver.get()); active_planners.push_back(&planner); }
+            const std::vector<int> codes = Solver::solveBatch(_batch, active);                 /* ONE launch instead of solver->solve() per thread (:339); every planner on its own slot */
+            for (size_t i = 0; i < active.size(); i++) recordResult(*active_planners[i], codes[i]);
+            return decide();
+        }
+        /* The UN-PATCHED drop-in: the reference's loop as it stands (guidance_constraints.cpp:279-361) -- every planner's own Solver solves on its
+         * own handle and stream from its own OpenMP thread (`num_threads(8)`, no locks: SURVEY 8b threading contract).  Same results as optimize(),
+         * bit for bit (a trajectory's result does not depend on what else runs); slower per tick, because every thread pays its own upload, launch
+         * and download where optimize() pays one of each (tests/cpp/test_omp_solvers.cpp measures both). */
+        int optimizeOpenMP(State &state, const RealTimeData &data, ModuleData &module_data, int num_threads = 8)
+        {
+            if (!_use_tmpcpp && _guidance.empty()) return 0;
+            const int n = (int)planners_.size();
+            (void)num_threads;
+#pragma omp parallel for num_threads(num_threads)
+            for (int i = 0; i < n; i++) {
+                LocalPlanner &planner = planners_[i];
+                if (!preparePlanner(planner, state, data, module_data)) continue;
+                recordResult(planner, planner.local_solver->solve());                          /* :339 */
+            }
+            return decide();
         }
         void initializeSolverWithGuidance(LocalPlanner &planner)                               /* :390-414 */
         {

@@ -42,10 +42,9 @@ namespace MPCPlanner
             if (cap <= 0 || batch > cap) want = (want == 2 && tmpc_latency_mode_capacity(h, 1) >= batch) ? 1 : 0;
         }
         const int rc = tmpc_set_latency_mode(h, want);
-        static bool told = false;
-        if (rc == 1 && !told) {                          // accepted, but this shape has no such variant: say so once instead of dropping the return value
-            std::fprintf(stderr, "mpc_planner_solver (HIP): kernel variant %d is not available for this solver's shape; the library's fallback runs\n", want);
-            told = true;
+        static std::once_flag told;                      // (Solver instances solve concurrently from OpenMP threads, guidance_constraints.cpp:279: no plain static flag)
+        if (rc == 1) {                                   // accepted, but this shape has no such variant: say so once instead of dropping the return value
+            std::call_once(told, [want] { std::fprintf(stderr, "mpc_planner_solver (HIP): kernel variant %d is not available for this solver's shape; the library's fallback runs\n", want); });
         } else if (rc < 0) { std::fprintf(stderr, "tmpc_set_latency_mode: %s\n", tmpc_last_error(h)); std::exit(1); }
     }
 

@@ -121,6 +121,26 @@ static SolveKernel pick_fast_kernel(const Dims &d, int *threads, bool prof)
     return nullptr;
 #endif
 }
+// Square-root form of the Riccati recursion (tmpc_dims.riccati_form = TMPC_RICCATI_SQUARE_ROOT; csrc/tmpc_riccati.hpp SQ): run-time-shape fast kernels only
+// -- a comparison aid (HPIPM's default recursion) with one instantiation per kernel family member that the BASELINE shapes need, not a throughput path.
+static SolveKernel pick_sqrt_kernel(const Dims &d, int *threads)
+{
+    *threads = NT;
+#ifndef TMPC_GENERATED_STAGE
+    const int nr = d.n_up + d.M + 14, sm = stage_model(d);
+    if (3 * d.N <= NT) {
+        if (sm == 0 && nr <= 3 * 13) return (SolveKernel)tmpc_solve_fast_kernel<-1, 13, 3, 64, false, SoloSqrt>;
+        return nullptr;
+    }
+    if (4 * d.N <= 128 && nr <= 4 * 12) {
+        *threads = 128;
+        if (sm == 0) return (SolveKernel)tmpc_solve_fast_kernel<-1, 12, 4, 128, false, SoloSqrt>;
+        if (sm == 1 && d.n_up == 20 && d.M == 8) return (SolveKernel)tmpc_solve_fast_kernel<20, 8, 4, 128, false, SoloSqrt, 1>;      // cfg 3 as named (CA-MPC)
+    }
+#endif
+    (void)d;
+    return nullptr;
+}
 // Compact variant (tmpc_fast.hpp: tmpc_solve_compact_kernel): two waves per SIMD, eight trajectories per CU, persistent
 // workgroups.  Bitwise the same results as the fast kernel of the shape (tools/ab_compare.py against TMPC_NO_COMPACT=1).
 // Round 4: the shapes with 13 rows per lane ((12,12) and (24,0) at three lanes per stage: cfg 4, cfg 5) fit 256 registers too since the
@@ -375,9 +395,20 @@ void tmpc_default_dims_ex(tmpc_dims *d, int32_t N, int32_t S, int32_t n_lin, int
 
 int tmpc_create_v2(tmpc_handle **out, const tmpc_dims *dims_in, uint32_t dims_size, int32_t B_max, int32_t device)
 {
-    // a caller built against an older header passes a SHORTER struct: the fields it does not know are the defaults (0), never garbage
-    constexpr uint32_t kMinSize = offsetof(tmpc_dims, cost_model);           // the struct as it was before cost_model / row_model were added
-    if (!out || !dims_in || dims_size < kMinSize || dims_size > 4096) return TMPC_ERR_INVALID;
+    // a caller built against an older header passes a SHORTER struct: the fields it does not know are the defaults (0), never garbage.  Only the
+    // struct's revision boundaries are sizes a header of this library ever had (round-5 advisor: a size ending inside a field copied part of it)
+    constexpr uint32_t kRev[] = {(uint32_t)offsetof(tmpc_dims, cost_model),         // rounds 1-3: up to n_slk / slack
+                                 (uint32_t)offsetof(tmpc_dims, riccati_form),       // rounds 4-5: + cost_model, row_model
+                                 (uint32_t)sizeof(tmpc_dims)};                      // round 6: + riccati_form
+    if (!out || !dims_in || dims_size > 4096) return TMPC_ERR_INVALID;
+    if (out) *out = nullptr;
+    bool known = dims_size > sizeof(tmpc_dims);
+    for (uint32_t r : kRev) known |= dims_size == r;
+    if (!known) return TMPC_ERR_INVALID;
+    if (dims_size > sizeof(tmpc_dims)) {                                           // a NEWER header: fields this library does not know must be unset
+        const unsigned char *tail = (const unsigned char *)dims_in + sizeof(tmpc_dims);
+        for (uint32_t i = 0; i < dims_size - (uint32_t)sizeof(tmpc_dims); i++) if (tail[i] != 0) return TMPC_ERR_INVALID;
+    }
     tmpc_dims d;
     memset(&d, 0, sizeof d);
     memcpy(&d, dims_in, dims_size < sizeof d ? dims_size : sizeof d);
@@ -395,7 +426,8 @@ int tmpc_create(tmpc_handle **out, const tmpc_dims *dims, int32_t B_max, int32_t
             (dims->slack != 0 && dims->slack != 1) || dims->npar != tmpc::expected_npar(t) || dims->erk_steps < 1 ||
             dims->n_sqp < 1 || dims->qp_iter_max < 1 || !(dims->dt > 0.0) || !(dims->qp_tol > 0.0) || !(dims->reg_eps > 0.0) ||
             !(dims->ipm_mu0 > 0.0) || !(dims->ipm_thr0 > 0.0) || (dims->cost_model != 0 && dims->cost_model != 1) ||
-            (dims->cost_model == 1 && dims->row_model == 1))        // (no instantiation carries the curvature-aware cost AND Gaussian rows)
+            (dims->cost_model == 1 && dims->row_model == 1) ||      // (no instantiation carries the curvature-aware cost AND Gaussian rows)
+            (dims->riccati_form != TMPC_RICCATI_SCHUR && dims->riccati_form != TMPC_RICCATI_SQUARE_ROOT))
             return TMPC_ERR_INVALID;
 #ifdef TMPC_GENERATED_STAGE
         if (dims->n_lin != tmpc_gen::NH || dims->M != 0 || dims->n_slk != 0 || dims->slack != tmpc_gen::SLACK || dims->cost_model != 0 || dims->row_model != 0) return TMPC_ERR_INVALID;
@@ -416,8 +448,11 @@ int tmpc_create(tmpc_handle **out, const tmpc_dims *dims, int32_t B_max, int32_t
 #else
     d.model = 0;
 #endif
+    d.riccati_form = dims->riccati_form;
     tmpc::derive_dims(d);
-    h->kernel = tmpc::pick_fast_kernel(d, &h->threads, false);
+    d.split_rows = tmpc::split_rows_for(d.N, d.n_up + d.M) ? 1 : 0;
+    h->kernel = d.riccati_form == TMPC_RICCATI_SQUARE_ROOT ? tmpc::pick_sqrt_kernel(d, &h->threads) : tmpc::pick_fast_kernel(d, &h->threads, false);
+    if (d.riccati_form == TMPC_RICCATI_SQUARE_ROOT && !h->kernel) { delete h; return TMPC_ERR_INVALID; }       // (no square-root instantiation for this shape: never a silent other form)
     if (const char *lm = getenv("TMPC_LATENCY_MODE")) {      // experiments: latency variant regardless of the caller ("0", "1" or "2"; anything else is ignored)
         if ((lm[0] == '0' || lm[0] == '1' || lm[0] == '2') && lm[1] == '\0') h->latency_mode = lm[0] - '0';
     }
@@ -431,11 +466,12 @@ int tmpc_create(tmpc_handle **out, const tmpc_dims *dims, int32_t B_max, int32_t
     auto fail = [&](int code) { delete h; return code; };
     if (hipSetDevice(device) != hipSuccess) return fail(TMPC_ERR_HIP);
     if (h->lds_bytes > 160 * 1024) return fail(TMPC_ERR_INVALID);
-    if (h->fast && h->threads == tmpc::NT && (h->kernel_lat = tmpc::pick_latency_kernel(d, false)) != nullptr) {
+    const bool schur = d.riccati_form == TMPC_RICCATI_SCHUR;      // the square-root form has its fast kernels only: no latency / compact variants
+    if (schur && h->fast && h->threads == tmpc::NT && (h->kernel_lat = tmpc::pick_latency_kernel(d, false)) != nullptr) {
         if (hipFuncSetAttribute((const void *)h->kernel_lat, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes_fast2) != hipSuccess)
             h->kernel_lat = nullptr;
     }
-    if (h->fast && (h->threads == tmpc::NT || d.N > 20) && (h->kernel_scan = tmpc::pick_scan_kernel(d, &h->scan_threads, &h->scan_sl)) != nullptr) {
+    if (schur && h->fast && (h->threads == tmpc::NT || d.N > 20) && (h->kernel_scan = tmpc::pick_scan_kernel(d, &h->scan_threads, &h->scan_sl)) != nullptr) {
         h->lds_bytes_scan = h->lds_bytes_fast2 + sizeof(double) * (size_t)(h->scan_sl == 3 ? tmpc::scan::lds_doubles<3>(d.N) : tmpc::scan::lds_doubles<2>(d.N));
         if (h->lds_bytes_scan > 160 * 1024) h->kernel_scan = nullptr;
     }
@@ -443,7 +479,7 @@ int tmpc_create(tmpc_handle **out, const tmpc_dims *dims, int32_t B_max, int32_t
         if (hipFuncSetAttribute((const void *)h->kernel_scan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes_scan) != hipSuccess)
             h->kernel_scan = nullptr;
     }
-    if (tmpc::SolveKernel kc = (h->fast && h->threads == tmpc::NT) ? tmpc::pick_compact_kernel(d, false, &h->lay_cp) : nullptr) {
+    if (tmpc::SolveKernel kc = (schur && h->fast && h->threads == tmpc::NT) ? tmpc::pick_compact_kernel(d, false, &h->lay_cp) : nullptr) {
         // the fast kernel of the shape (everything in LDS, four per CU) stays for launches it holds resident at once: bitwise the same results
         // (tests/test_gpu_compact2.py), a trajectory is ~10 % faster on it.  TMPC_COMPACT_MIN_B=0: the compact kernel for every launch (rounds 3-4)
         int fast_per_cu = 0, cus = 0;
@@ -469,7 +505,7 @@ int tmpc_create(tmpc_handle **out, const tmpc_dims *dims, int32_t B_max, int32_t
     if (hipFuncSetAttribute((const void *)h->kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)h->lds_bytes) != hipSuccess)
         return fail(TMPC_ERR_NO_DEVICE);
-    if (h->fast && h->threads == 128 && !h->compact && (h->kernel_cp2 = tmpc::pick_compact2_kernel(d, &h->lay_cp2)) != nullptr) {
+    if (schur && h->fast && h->threads == 128 && !h->compact && (h->kernel_cp2 = tmpc::pick_compact2_kernel(d, &h->lay_cp2)) != nullptr) {
         {
             auto lds_cp2 = [&](int pad) { return sizeof(double) * (size_t)tmpc::lds_doubles_compact(d.N, d.n_lin, d.n_up + d.M, 128, pad, h->lay_cp2); };
             auto per_cu_cp2 = [&](int pad) {

@@ -125,19 +125,23 @@ __device__ __forceinline__ void lds_add(double *p, double v) { atomicAdd(p, v); 
 // recursion (tmpc_riccati.hpp).  ScanSoloT (below): the parallel-in-time solve (tmpc_scan.hpp).  (Round 3 also had a Team<NQ> policy
 // -- several trajectories' sweeps packed into one wave -- measured 4-8 % slower and removed: profiles/round3_b_team_kernels_rejected.json,
 // HISTORY.md.)
-struct Solo {
+// SQ: the square-root form of the recursion (tmpc_riccati.hpp; tmpc_dims.riccati_form = TMPC_RICCATI_SQUARE_ROOT) -- SoloSqrt, two run-time-shape instantiations.
+template <bool SQ>
+struct SoloT {
     static constexpr int NQ = 1;
     __device__ __forceinline__ bool alive() const { return true; }
     __device__ __forceinline__ void sync() const { __syncthreads(); }
     __device__ __forceinline__ bool any(bool active) const { return active; }
     template <int NTH, int CP>
-    __device__ __forceinline__ bool factor(const Lds &L, const Dims &d, int tl, int sw, int) const { return riccati_factor<NTH, CP, true>(L, d, tl, sw); }   // (the predictor's backward sweep rides along)
+    __device__ __forceinline__ bool factor(const Lds &L, const Dims &d, int tl, int sw, int) const { return riccati_factor<NTH, CP, true, SQ>(L, d, tl, sw); }   // (the predictor's backward sweep rides along)
     template <int NTH, int CP>
     __device__ __forceinline__ void solve(const Lds &L, const Dims &d, int tl, int sw, int, int phase, bool) const
     {
-        if (phase == 1) riccati_forward<NTH, CP>(L, d, tl, sw); else riccati_solve<NTH, CP>(L, d, tl, sw);
+        if (phase == 1) riccati_forward<NTH, CP, SQ>(L, d, tl, sw); else riccati_solve<NTH, CP, SQ>(L, d, tl, sw);
     }
 };
+using Solo = SoloT<false>;
+using SoloSqrt = SoloT<true>;
 
 // Latency mode 2: the Newton systems go through the parallel-in-time solve (tmpc_scan.hpp) instead of the Riccati recursion.  Same
 // operands in LDS (Hh, [B A], gh, rb), same results (dv, dpi); Hh is left as it is (ipm_fast rebuilds it every iteration anyway).

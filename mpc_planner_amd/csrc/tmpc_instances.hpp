@@ -12,6 +12,8 @@
 #define TMPC_FAST_CM_SHAPES(X) X(20, 8, 4, 128, 1) X(-1, 13, 3, 64, 1) X(5, 5, 4, 128, 2) X(-1, 6, 4, 128, 2) X(-1, 12, 4, 128, 2) X(-1, 13, 3, 64, 2)
 // latency mode 2: the parallel-in-time Newton solve (NLIN, MM, LPS, NTH, policy)
 #define TMPC_SCAN_SHAPES(X) X(-1, 12, 4, 128, tmpc::ScanSoloT<2>) X(8, 8, 6, 128, tmpc::ScanSolo) X(8, 8, 3, 64, tmpc::ScanSolo) X(-1, 9, 6, 128, tmpc::ScanSolo)
+// square-root form of the Riccati recursion (tmpc_dims.riccati_form = 1): run-time-shape fast kernels (NLIN, MM, LPS, NTH, CM)
+#define TMPC_SQRT_SHAPES(X) X(-1, 13, 3, 64, 0) X(-1, 12, 4, 128, 0) X(20, 8, 4, 128, 1)
 // compact kernels, one wave per trajectory (NLIN, MM, LPS)
 #define TMPC_COMPACT_SHAPES(X) X(8, 8, 3) X(0, 4, 3) X(12, 12, 3) X(24, 0, 3) X(-1, 7, 3) X(-1, 10, 3)
 // compact kernels, two waves per trajectory (NLIN, MM, LPS, CM)
@@ -21,7 +23,7 @@
 
 #define TMPC_ALL_INSTANCES(KW)                                                                                                                     \
     TMPC_FAST_SHAPES(TMPC_I_FAST_##KW) TMPC_FAST_SHAPES(TMPC_I_PROF_##KW) TMPC_FAST_CM_SHAPES(TMPC_I_FASTCM_##KW) TMPC_SCAN_SHAPES(TMPC_I_SCAN_##KW) \
-    TMPC_COMPACT_SHAPES(TMPC_I_CP_##KW) TMPC_CP2_SHAPES(TMPC_I_CP2_##KW) TMPC_GENERIC_MODELS(TMPC_I_GEN_##KW)
+    TMPC_COMPACT_SHAPES(TMPC_I_CP_##KW) TMPC_CP2_SHAPES(TMPC_I_CP2_##KW) TMPC_GENERIC_MODELS(TMPC_I_GEN_##KW) TMPC_SQRT_SHAPES(TMPC_I_SQRT_##KW)
 // KW = DEF: explicit instantiation definition; KW = EXT: extern declaration
 #define TMPC_I_FAST_DEF(a, b, c, e) template __global__ void tmpc::tmpc_solve_fast_kernel<a, b, c, e, false>(TMPC_KARGS);
 #define TMPC_I_FAST_EXT(a, b, c, e) extern template __global__ void tmpc::tmpc_solve_fast_kernel<a, b, c, e, false>(TMPC_KARGS);
@@ -31,6 +33,8 @@
 #define TMPC_I_FASTCM_EXT(a, b, c, e, m) extern template __global__ void tmpc::tmpc_solve_fast_kernel<a, b, c, e, false, tmpc::Solo, m>(TMPC_KARGS);
 #define TMPC_I_SCAN_DEF(a, b, c, e, t) template __global__ void tmpc::tmpc_solve_fast_kernel<a, b, c, e, false, t>(TMPC_KARGS);
 #define TMPC_I_SCAN_EXT(a, b, c, e, t) extern template __global__ void tmpc::tmpc_solve_fast_kernel<a, b, c, e, false, t>(TMPC_KARGS);
+#define TMPC_I_SQRT_DEF(a, b, c, e, m) template __global__ void tmpc::tmpc_solve_fast_kernel<a, b, c, e, false, tmpc::SoloSqrt, m>(TMPC_KARGS);
+#define TMPC_I_SQRT_EXT(a, b, c, e, m) extern template __global__ void tmpc::tmpc_solve_fast_kernel<a, b, c, e, false, tmpc::SoloSqrt, m>(TMPC_KARGS);
 #define TMPC_I_CP_DEF(a, b, c) template __global__ void tmpc::tmpc_solve_compact_kernel<a, b, c, false>(TMPC_KARGS);
 #define TMPC_I_CP_EXT(a, b, c) extern template __global__ void tmpc::tmpc_solve_compact_kernel<a, b, c, false>(TMPC_KARGS);
 #define TMPC_I_CP2_DEF(a, b, c, m) template __global__ void tmpc::tmpc_solve_compact_kernel<a, b, c, false, 128, m>(TMPC_KARGS);

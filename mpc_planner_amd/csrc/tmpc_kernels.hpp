@@ -149,6 +149,16 @@ __host__ __device__ inline int lds_doubles(int N, int nh)
     return n;
 }
 
+// Dims::split_rows.  The one-wave kernels' linearisation exchanges the helpers' share of the rows' Hessian (2 N x 6 doubles) and MIRROR's 3 x 3 blocks
+// (N x 8 doubles) through L.dv, which every layout follows with L.dpi: 12 (N + 1) contiguous doubles >= 12 N.  The staging region (beta, lamh: 2 N nh
+// doubles from the start of the work region) is being written at that time and must end before L.dv.  Offset of L.dv from the start of the work region:
+// (N + 1) (NV + NX + hstride + NV + NV) + N NX with hstride >= NP28 (carve_fast, carve_compact) -- the bare stride gives the tightest bound, so one
+// answer holds for the fast and all compact layouts of a shape.
+__host__ __device__ inline bool split_rows_for(int N, int nh)
+{
+    return 2 * N * nh <= (N + 1) * (NV + NX + NP28 + NV + NV) + N * NX && 12 * (N + 1) >= 12 * N;
+}
+
 __device__ __forceinline__ Lds carve(double *s, const Dims &d)
 {
     Lds L;
@@ -814,11 +824,12 @@ __device__ __forceinline__ void linearise(const Lds &L, const Dims &d, int tid, 
     // hand their share of the rows' Hessian to the owner through LDS (their W is that share and nothing else: everything else that enters W is
     // multiplied by zero on a helper).  The rest of the stage (dynamics, cost, halfspace rows) is computed redundantly by all three -- same
     // instructions, no extra issue slots.  The sum of the three shares associates differently from the sequential
-    // sum over the rows (rounding level).  `split`: the wave has the lanes and the exchange buffer lies clear of the staging region.
+    // sum over the rows (rounding level).  `split`: the wave has the lanes and the exchange buffer lies clear of the staging region -- a fact of the
+    // SHAPE, computed once on the host (split_rows_for below) so that the fast and the compact kernel of a shape always take the same path.
 #ifdef TMPC_GENERATED_STAGE
     const bool split = false;                            // (emitted stage functions evaluate all their rows in one piece: tmpc_gen::rows has no notion of a share)
 #else
-    const bool split = FAST && NTH == 64 && 3 * N <= 64 && L.nh >= 3 && L.dv >= L.beta + 2 * N * L.nh;
+    const bool split = FAST && NTH == 64 && 3 * N <= 64 && L.nh >= 3 && d.split_rows;       // (Dims::split_rows: the exchange buffer -- dv and dpi, 12 (N + 1) contiguous doubles -- lies clear of the staging region in EVERY layout of the shape)
 #endif
     const bool helper = split && tid_l >= N && tid_l < 3 * N;
     const int k = owner ? tid_l : (helper ? (tid_l >= 2 * N ? tid_l - 2 * N : tid_l - N) : N - 1);
@@ -894,7 +905,7 @@ __device__ __forceinline__ void linearise(const Lds &L, const Dims &d, int tid, 
         // MIRROR: the two diagonal blocks of every stage in different lanes at the same time where the wave has the lanes (2 N <= 64) and the
         // exchange buffer -- the tail of the interior-point work region, dead while the stage blocks are built -- lies clear of the staging
         // region (beta, lamh) the rows are being written into; the generic kernel keeps the one-lane form
-        if (FAST && NTH == 64 && 2 * N <= 64 && L.dv >= L.beta + 2 * N * L.nh) mirror7_pair(W, d.reg_eps, tid_l, N, owner, L.dv);
+        if (FAST && NTH == 64 && 2 * N <= 64 && d.split_rows) mirror7_pair(W, d.reg_eps, tid_l, N, owner, L.dv);
         else mirror7(W, d.reg_eps);
         if (owner) {
 #pragma unroll

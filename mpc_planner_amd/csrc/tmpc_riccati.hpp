@@ -76,13 +76,18 @@ template <int CP> __device__ __forceinline__ double *ysl(const Lds &L, int k) { 
 // (The sequential sweeps use lanes 0..7 of the wave and rows 1..3 run along on copies.  Switching those rows off for the sweeps -- the LDS unit is
 // busy 70 % of the kernel time at eight trajectories per CU and the sweeps issue two thirds of its instructions -- was measured in round 5: 1.3 %
 // SLOWER, profiles/round5_o_sweep_rows_ab.jsonl; an LDS instruction costs the same with 16 lanes as with 64 and the EXEC changes are not free.)
-#ifndef TMPC_FACTOR_UNROLL
-#if defined(TMPC_TU_COMPACT) || defined(TMPC_TU_CP2) || defined(TMPC_SINGLE_COMPACT)
-#define TMPC_FACTOR_UNROLL 0                         // two waves per SIMD: see riccati_factor_rows
+// The stage loop of the factorisation is unrolled by two in the one-wave-per-SIMD kernels and rolled in the two-waves-per-SIMD (compact) ones -- a
+// property of the INSTANTIATION (its layout parameter CP: 0 = fast / generic layouts, >= 1 = compact), so that every translation unit -- the four
+// instantiation units, a generated solver's single unit, experiment builds -- gives a kernel the same body (round-5 advisor: a per-unit macro made
+// the same template differ between units).  -DTMPC_FACTOR_UNROLL=0/1 forces one form everywhere (A/B builds only).
+template <int CP> __host__ __device__ constexpr bool factor_unrolled()
+{
+#ifdef TMPC_FACTOR_UNROLL
+    return TMPC_FACTOR_UNROLL != 0;
 #else
-#define TMPC_FACTOR_UNROLL 1
+    return CP == 0;
 #endif
-#endif
+}
 
 // right-looking elimination of columns C0 .. C1-1 of the row-per-lane matrix
 template <int C0, int C1 = NV>
@@ -149,7 +154,14 @@ __device__ __forceinline__ BaLane ba_row4(int N, int i5)          // o0: base of
 // and p joins the product: w = P rb + p.  The separate backward vector sweep of the predictor (and its stage-parallel prologue P rb)
 // disappear: one of the five sequential passes over the stages of an interior-point iteration.  Same algebra as the separate sweep; the
 // operations associate differently (rounding-level differences).
-template <int CP, bool VEC = false>
+// SQ (Dims::riccati_form = 1, tmpc_dims.riccati_form = TMPC_RICCATI_SQUARE_ROOT): the SQUARE-ROOT form of rounds 1-4 -- what acados' HPIPM runs in its
+// default mode (square_root_alg = 1 [UPSTREAM]; solver_generator/generate_acados_solver.py:171 takes the defaults) -- kept as a selectable
+// instantiation (round 6): all seven columns are eliminated, rows 2..6 hold Lxx with P_k = Lxx Lxx^T, the next stage forms G = Lxx^T [B A] and
+// F = Hh + G^T G (no subtraction of large numbers), FB_P holds Lxx, and the extra row ends as [y0 y1 | lx] with p_k = Lxx lx.  At the
+// reference's qp_tol = 1e-5 both forms give the same exit codes, iteration counts and iterates (profiles/round5_riccati_form_study.json); at
+// qp_tol = 1e-9 a few solves per thousand end differently, which is why a run against a real acados at that tolerance (tools/acados_replay.py)
+// should use this form.
+template <int CP, bool VEC = false, bool SQ = false>
 __device__ __forceinline__ bool riccati_factor_rows(const Lds &L, const Dims &d, int li, bool wr)
 {
     const int N = d.N;
@@ -231,9 +243,10 @@ __device__ __forceinline__ bool riccati_factor_rows(const Lds &L, const Dims &d,
     Opnd oa, ob;
     seek_stage(N - 1);
     load_stage(oa, N - 1, true);
+    if constexpr (SQ) bad |= chol_rows<NU>(f, li, nullptr, nullptr);       // square-root form: Cholesky of the xx block of node N
     if (vec && wr) {
 #pragma unroll
-        for (int l = 0; l < NX; l++) L.pr[N * NX + l] = f[NU + l];          // p_N
+        for (int l = 0; l < NX; l++) L.pr[N * NX + l] = f[NU + l];          // p_N (square-root form: lx of node N)
     }
     auto stage = [&](const Opnd &o, Opnd &nx, int k) {
         // broadcast P (lower triangle of the 5x5 cost-to-go Hessian of stage k+1: rows 2..6 after the elimination) to every lane of the row
@@ -249,6 +262,65 @@ __device__ __forceinline__ bool riccati_factor_rows(const Lds &L, const Dims &d,
 #pragma unroll
             for (int l = 0; l < NX; l++) *(l <= i5 ? Ln + i5 * (i5 + 1) / 2 + l : L.scr + (CP ? 0 : 56) + l) = f[NU + l];   // (entries above the diagonal go to a dummy slot: a select on the address instead of five masked stores)
         }
+        if constexpr (SQ) {
+            // G = Lp^T [B A] (5 x 7), Lp = Pm (the lower triangle holds Lxx of stage k + 1).  Own column densely from ba[]; all columns (row-uniform)
+            // from the sparse [B A]:  x: e0   y: e1   s: e4   psi: (Xp,Yp,1,0,0)   v: (Xv,Yv,0,1,sdt)   a: (Xa,Ya,0,dt,shdt2)   w: (Xw,Yw,dt,0,0)
+            // F = Hh + G^T G keeps the square-root structure (a factor-level perturbation only).  The extra row: (Lp^T rb)_l + lx_l of stage k + 1.
+            double Go[NX];
+#pragma unroll
+            for (int l = 0; l < NX; l++) {
+                double acc = 0.0;
+#pragma unroll
+                for (int m = l; m < NX; m++) acc += Pm[m][l] * o.ba[m];
+                Go[l] = VEC ? fma(vmask, f[NU + l], acc) : acc;
+            }
+            const double Xa = o.dn[D8_XA], Xw = o.dn[D8_XW], Xp = o.dn[D8_XP], Xv = o.dn[D8_XV];
+            const double Ya = o.dn[D8_YA], Yw = o.dn[D8_YW], Yp = o.dn[D8_YP], Yv = o.dn[D8_YV];
+            double Ga[NX], Gw[NX], Gp[3], Gv[NX];
+            Ga[0] = ((Pm[0][0] * Xa + Pm[1][0] * Ya) + Pm[3][0] * dt) + Pm[4][0] * shdt2;
+            Ga[1] = (Pm[1][1] * Ya + Pm[3][1] * dt) + Pm[4][1] * shdt2;
+            Ga[2] = Pm[3][2] * dt + Pm[4][2] * shdt2;
+            Ga[3] = Pm[3][3] * dt + Pm[4][3] * shdt2;
+            Ga[4] = Pm[4][4] * shdt2;
+            Gw[0] = (Pm[0][0] * Xw + Pm[1][0] * Yw) + Pm[2][0] * dt;
+            Gw[1] = Pm[1][1] * Yw + Pm[2][1] * dt;
+            Gw[2] = Pm[2][2] * dt; Gw[3] = 0.0; Gw[4] = 0.0;
+            Gp[0] = (Pm[0][0] * Xp + Pm[1][0] * Yp) + Pm[2][0];
+            Gp[1] = Pm[1][1] * Yp + Pm[2][1];
+            Gp[2] = Pm[2][2];
+            Gv[0] = ((Pm[0][0] * Xv + Pm[1][0] * Yv) + Pm[3][0]) + Pm[4][0] * sdt;
+            Gv[1] = (Pm[1][1] * Yv + Pm[3][1]) + Pm[4][1] * sdt;
+            Gv[2] = Pm[3][2] + Pm[4][2] * sdt;
+            Gv[3] = Pm[3][3] + Pm[4][3] * sdt;
+            Gv[4] = Pm[4][4] * sdt;
+            double a0 = o.hk[ZA], a1 = o.hk[ZW], a2 = o.hk[ZX], a3 = o.hk[ZY], a4 = o.hk[ZPSI], a5 = o.hk[ZV], a6 = o.hk[ZS];
+#pragma unroll
+            for (int l = 0; l < NX; l++) {                       // F row `li`: F_ij = Hh_ij + sum_l G_l,li G_l,j
+                a0 += Go[l] * Ga[l];
+                if (l < 3) a1 += Go[l] * Gw[l];
+                if (l < 1) a2 += Go[l] * Pm[0][0];
+                if (l < 2) a3 += Go[l] * Pm[1][l];
+                if (l < 3) a4 += Go[l] * Gp[l];
+                a5 += Go[l] * Gv[l];
+                a6 += Go[l] * Pm[4][l];
+            }
+            f[ZA] = a0; f[ZW] = a1; f[ZX] = a2; f[ZY] = a3; f[ZPSI] = a4; f[ZV] = a5; f[ZS] = a6;
+            load_stage(nx, k > 0 ? k - 1 : 0, k > 1);
+            double r0 = 0.0, r1 = 0.0;
+            bad |= chol_rows<0>(f, li, &r0, &r1);                 // all seven columns: rows 2..6 now hold Lxx of stage k (the extra row: lx)
+            if (rowl) {
+                double *Fb = L.Hh + hoff<CP>(k);
+                if (li >= NU) { Fb[FB_LXU + 2 * i5] = f[0]; Fb[FB_LXU + 2 * i5 + 1] = f[1]; }
+                if (li == 1) { Fb[FB_L10] = f[0]; Fb[FB_R0] = r0; Fb[FB_R1] = r1; }
+            }
+            if (vec && wr) {                                       // [y0 y1 | lx] of stage k
+                ysl<CP>(L, k)[0] = f[0]; ysl<CP>(L, k)[1] = f[1];
+#pragma unroll
+                for (int l = 0; l < NX; l++) L.pr[k * NX + l] = f[NU + l];
+            }
+            return;
+        }
+        // Schur-complement form (default): P_{k+1} enters the next stage's F unfactorised (its diagonal is tested after the loop, riccati_factor)
         // w = P [B A]_.,own (the lane's own column of [B A], densely from ba[]); the extra row: P rb + p_{k+1} -- as fma(1.0 or 0.0, f, acc):
         // exactly acc + f on the extra row and acc on the others (f is finite there), without the v_cndmask a select costs
         double w[NX];
@@ -287,22 +359,22 @@ __device__ __forceinline__ bool riccati_factor_rows(const Lds &L, const Dims &d,
             for (int l = 0; l < NX; l++) L.pr[k * NX + l] = f[NU + l];
         }
     };
-#if TMPC_FACTOR_UNROLL
-    int k = N - 1;
-    for (; k >= 1; k -= 2) {
-        stage(oa, ob, k);
-        stage(ob, oa, k - 1);
+    if constexpr (factor_unrolled<CP>()) {
+        int k = N - 1;
+        for (; k >= 1; k -= 2) {
+            stage(oa, ob, k);
+            stage(ob, oa, k - 1);
+        }
+        if (k == 0) stage(oa, ob, 0);
+    } else {
+        for (int k = N - 1; k >= 0; k--) stage(oa, oa, k);      // (one named set, re-loaded after its last use in source order)
     }
-    if (k == 0) stage(oa, ob, 0);
-#else
-    for (int k = N - 1; k >= 0; k--) stage(oa, oa, k);      // (one named set, re-loaded after its last use in source order)
-#endif
     return bad;
 }
 
 // NTH = threads per trajectory: 64, or 128 for the two-wave variant, in which the sweeps run on one wave (the other waits at the
 // closing barrier) and only the stage-parallel loops use all threads.  `sw`: which of the two waves sweeps.
-template <int NTH, int CP = 0, bool VEC = false>
+template <int NTH, int CP = 0, bool VEC = false, bool SQ = false>
 __device__ __forceinline__ bool riccati_factor(const Lds &L, const Dims &d, int tid, int sw = 0)
 {
     asm volatile("" : "+v"(tid));                    // opaque per call: lane-derived addresses are not shared with (kept live until) other phases
@@ -311,9 +383,19 @@ __device__ __forceinline__ bool riccati_factor(const Lds &L, const Dims &d, int 
     if (NTH == 64 || (tid >> 6) == sw) {
         const int lane = tid & 63;
         TMPC_PRIO_HIGH();
-        const bool bad = riccati_factor_rows<CP, VEC>(L, d, lane, true);
+        const bool bad = riccati_factor_rows<CP, VEC, SQ>(L, d, lane, true);
         TMPC_PRIO_LOW();
-        anybad = __any(bad && lane < 16);             // (rows 1..3 of the wave compute on copies: their pivots mean nothing)
+        bool bad_p = false;
+        if constexpr (!SQ) {
+            // Schur-complement form: P_k = F_xx - Lxu Lxu^T enters the next stage unfactorised, so nothing downstream would notice a diagonal entry that
+            // cancellation has driven NEGATIVE (the square-root form's state pivots did; round-5 advisor).  Tested here, off the sequential chain: lane
+            // k reads the sign bits of diag(P_{k+1}) from the factor blocks the loop has just written (same wave: LDS operations execute in order) --
+            // five ds_read_b32 and three integer operations per factorisation.  (Inside the stage loop the same test cost the compact kernels, at 254
+            // of 256 registers, their zero-scratch build.)  The oracle tests the same bits (oracle/qp_ipm.c riccati_factor_classical).
+            const unsigned *Pd = reinterpret_cast<const unsigned *>(L.Hh + hoff_lane<CP>(lane < d.N ? lane + 1 : d.N) + FB_P) + 1;      // (high dwords)
+            bad_p = (int)(Pd[2 * 0] | Pd[2 * 2] | Pd[2 * 5] | Pd[2 * 9] | Pd[2 * 14]) < 0;
+        }
+        anybad = __any((bad && lane < 16) || bad_p);  // (rows 1..3 of the wave compute on copies: their pivots mean nothing)
         if (NTH > 64 && lane == 0) L.scr[63] = anybad ? 1.0 : 0.0;
     }
     __syncthreads();
@@ -326,7 +408,8 @@ __device__ __forceinline__ bool riccati_factor(const Lds &L, const Dims &d, int 
 // Stage-parallel parts (one lane per stage, `nth` lanes of the trajectory's own wave(s)):
 //   pre   q_k = P_{k+1} rb_k for all stages at once (off the sequential chain); parked in dpi[k+1]
 //   post  dpi_k = P_k dx_k + p_k, k = 1..N
-template <int CP>
+// SQ (square-root form): FB_P holds Lxx, P x = Lxx (Lxx^T x)
+template <int CP, bool SQ = false>
 __device__ __forceinline__ void riccati_solve_pre(const Lds &L, const Dims &d, int tid, int nth)
 {
     const int N = d.N;
@@ -338,6 +421,24 @@ __device__ __forceinline__ void riccati_solve_pre(const Lds &L, const Dims &d, i
         for (int e = 0; e < 15; e++) pp[e] = Pn[e];
 #pragma unroll
         for (int m = 0; m < NX; m++) rr[m] = r[m];
+        if constexpr (SQ) {
+            double tl[NX];
+#pragma unroll
+            for (int l = 0; l < NX; l++) {
+                double acc = 0.0;
+#pragma unroll
+                for (int m = l; m < NX; m++) acc += pp[m * (m + 1) / 2 + l] * rr[m];
+                tl[l] = acc;
+            }
+#pragma unroll
+            for (int i = 0; i < NX; i++) {
+                double acc = 0.0;
+#pragma unroll
+                for (int l = 0; l <= i; l++) acc += pp[i * (i + 1) / 2 + l] * tl[l];
+                L.dpi[mul24(k + 1, NX) + i] = acc;
+            }
+            continue;
+        }
 #pragma unroll
         for (int i = 0; i < NX; i++) {
             double acc = 0.0;
@@ -348,7 +449,8 @@ __device__ __forceinline__ void riccati_solve_pre(const Lds &L, const Dims &d, i
     }
 }
 // dpi_k = P_k dx_k + p_k, k = 1..N (L.pr holds p_k: from the backward sweep, or from the extra row of a VEC factorisation)
-template <int CP>
+// SQ: dpi_k = Lxx (Lxx^T dx_k) + p_k; LX (the fused predictor of the square-root form): L.pr holds lx with p_k = Lxx lx, so dpi_k = Lxx (Lxx^T dx_k + lx_k)
+template <int CP, bool SQ = false, bool LX = false>
 __device__ __forceinline__ void riccati_solve_post(const Lds &L, const Dims &d, int tid, int nth)
 {
     const int N = d.N;
@@ -361,6 +463,24 @@ __device__ __forceinline__ void riccati_solve_post(const Lds &L, const Dims &d, 
         for (int e = 0; e < 15; e++) pp[e] = Pk[e];
 #pragma unroll
         for (int m = 0; m < NX; m++) { rr[m] = dxk[m]; pk[m] = L.pr[mul24(k, NX) + m]; }
+        if constexpr (SQ) {
+            double tl[NX];
+#pragma unroll
+            for (int l = 0; l < NX; l++) {
+                double acc = 0.0;
+#pragma unroll
+                for (int m = l; m < NX; m++) acc += pp[m * (m + 1) / 2 + l] * rr[m];
+                tl[l] = LX ? acc + pk[l] : acc;
+            }
+#pragma unroll
+            for (int i = 0; i < NX; i++) {
+                double acc = 0.0;
+#pragma unroll
+                for (int l = 0; l <= i; l++) acc += pp[i * (i + 1) / 2 + l] * tl[l];
+                L.dpi[mul24(k, NX) + i] = LX ? acc : acc + pk[i];
+            }
+            continue;
+        }
 #pragma unroll
         for (int i = 0; i < NX; i++) {
             double acc = 0.0;
@@ -507,7 +627,7 @@ __device__ __forceinline__ void riccati_sweeps_rows(const Lds &L, const Dims &d,
     SWEEP_T(SP_SOLVE_FWD);
 }
 
-template <int NTH, int CP = 0>
+template <int NTH, int CP = 0, bool SQ = false>
 __device__ __forceinline__ void riccati_solve(const Lds &L, const Dims &d, int tid, int sw = 1)
 {
     asm volatile("" : "+v"(tid));                    // opaque per call (see riccati_factor): the two solves of an iteration do not share address registers
@@ -516,18 +636,18 @@ __device__ __forceinline__ void riccati_solve(const Lds &L, const Dims &d, int t
     const bool sweeper = NTH == 64 || (tid >> 6) == sw;
     const int lane = NTH == 64 ? tid : (sweeper ? (tid & 63) : 64);
     SWEEP_COUNT(SP_CALLS_SOLVE);
-    riccati_solve_pre<CP>(L, d, tid, NTH);
+    riccati_solve_pre<CP, SQ>(L, d, tid, NTH);
     __syncthreads();
     TMPC_PRIO_HIGH();
     riccati_sweeps_rows<CP, true>(L, d, lane, true, sweeper, [] { __syncthreads(); });
     TMPC_PRIO_LOW();
     __syncthreads();
-    riccati_solve_post<CP>(L, d, tid, NTH);
+    riccati_solve_post<CP, SQ, false>(L, d, tid, NTH);
     __syncthreads();
 }
 
 // The rest of the predictor solve after a VEC factorisation: forward sweep + stage-parallel closing loop.
-template <int NTH, int CP = 0>
+template <int NTH, int CP = 0, bool SQ = false>
 __device__ __forceinline__ void riccati_forward(const Lds &L, const Dims &d, int tid, int sw = 1)
 {
     asm volatile("" : "+v"(tid));
@@ -538,7 +658,7 @@ __device__ __forceinline__ void riccati_forward(const Lds &L, const Dims &d, int
     riccati_sweeps_rows<CP, false>(L, d, lane, true, sweeper, [] {});
     TMPC_PRIO_LOW();
     __syncthreads();
-    riccati_solve_post<CP>(L, d, tid, NTH);
+    riccati_solve_post<CP, SQ, SQ>(L, d, tid, NTH);      // (square-root form: the extra row left lx, not p)
     __syncthreads();
 }
 

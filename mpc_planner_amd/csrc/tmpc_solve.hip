@@ -5,6 +5,7 @@
 //   -DTMPC_TU_COMPACT   compact one-wave kernels and the parallel-in-time (latency mode 2) kernels
 //   -DTMPC_TU_PROF      profiled twins of the fast kernels (tmpc_debug_profile) + the profiled latency-mode-2 kernel
 //   -DTMPC_TU_CP2       compact two-wave kernels
+//   -DTMPC_TU_SQRT      the square-root-Riccati instantiations (tmpc_dims.riccati_form = 1)
 // The C-ABI -- dispatch tables, handle, entry points -- is tmpc_capi.hip; it declares every instantiation `extern`.
 // Experiment builds (tools/kernel_probe.sh): -DTMPC_SINGLE_KERNEL=<fast template arguments> / -DTMPC_SINGLE_COMPACT=<compact template arguments>
 // compile ONE instantiation and nothing else -- seconds instead of minutes when looking at one kernel's registers / ISA.
@@ -29,6 +30,8 @@ TMPC_FAST_SHAPES(TMPC_I_PROF_DEF)
 template __global__ void tmpc::tmpc_solve_fast_kernel<8, 8, 6, 128, true, tmpc::ScanSolo>(TMPC_KARGS);      // profiled twin of latency mode 2 (cfg 2)
 #elif defined(TMPC_TU_CP2)
 TMPC_CP2_SHAPES(TMPC_I_CP2_DEF)
+#elif defined(TMPC_TU_SQRT)
+TMPC_SQRT_SHAPES(TMPC_I_SQRT_DEF)
 #else
-#error "tmpc_solve.hip: name the group to instantiate (-DTMPC_TU_FAST / _COMPACT / _PROF / _CP2) or one kernel (-DTMPC_SINGLE_KERNEL= / -DTMPC_SINGLE_COMPACT=)"
+#error "tmpc_solve.hip: name the group to instantiate (-DTMPC_TU_FAST / _COMPACT / _PROF / _CP2 / _SQRT) or one kernel (-DTMPC_SINGLE_KERNEL= / -DTMPC_SINGLE_COMPACT=)"
 #endif

@@ -92,6 +92,11 @@ struct Dims {
     int row_model;                   // the M lower-bounded rows: 0: EllipsoidConstraintModule (ellipsoid_constraints.py:66-110, h >= 1); 1: GaussianConstraintModule
                                      // (gaussian_constraints.py:66-113, h >= 0; mpc_planner_jackal's default).  Compile-time in the kernels like cost_model:
                                      // the template parameter CM carries both, CM = cost_model + 2 * row_model (stage_model())
+    int riccati_form;                // 0: Schur-complement recursion (every kernel); 1: square-root recursion (tmpc_riccati.hpp SQ; the SoloSqrt instantiations).
+                                     // Selects the instantiation on the host only (tmpc_dims.riccati_form)
+    int split_rows;                  // one-wave fast / compact kernels: the stage's rows are split over its three lanes in the linearisation and MIRROR's two blocks
+                                     // run in different lanes -- decided on the HOST from the shape alone (tmpc_capi.hip split_rows_for), the same for the fast and
+                                     // the compact kernel of a shape, which must stay bitwise equal (round-5 advisor: it was a layout-dependent pointer test)
 };
 __host__ TMPC_HD constexpr bool cm_curvature_aware(int CM) { return (CM & 1) != 0; }
 __host__ TMPC_HD constexpr bool cm_gaussian_rows(int CM) { return (CM & 2) != 0; }

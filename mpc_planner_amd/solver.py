@@ -20,7 +20,8 @@ class TmpcDims(C.Structure):
                 ("n_sqp", C.c_int32), ("qp_iter_max", C.c_int32), ("erk_steps", C.c_int32),
                 ("dt", C.c_double), ("qp_tol", C.c_double), ("reg_eps", C.c_double), ("ipm_mu0", C.c_double),
                 ("ipm_thr0", C.c_double), ("lb", C.c_double * NV), ("ub", C.c_double * NV),
-                ("n_slk", C.c_int32), ("slack", C.c_int32), ("cost_model", C.c_int32), ("row_model", C.c_int32)]
+                ("n_slk", C.c_int32), ("slack", C.c_int32), ("cost_model", C.c_int32), ("row_model", C.c_int32),
+                ("riccati_form", C.c_int32)]        # 0: Schur-complement recursion (default), 1: square-root recursion (include/tmpc_hip.h)
 
     @property
     def nx(self):            # external (model) state / variable counts: the slack model has one more state

@@ -58,6 +58,9 @@ static void riccati_factor_classical(const orc_qp *qp, ipm_ws *w)
     for (int i = 0; i < ORC_NX; i++) for (int j = 0; j < ORC_NX; j++) w->P[N][i][j] = w->Hh[N][ORC_NU + (i > j ? i : j)][ORC_NU + (i > j ? j : i)];
     for (int k = N - 1; k >= 0; k--) {
         double PBA[ORC_NX][ORC_NV], F[ORC_NV][ORC_NV];
+        /* P_{k+1} enters unfactorised: a diagonal entry that cancellation has driven negative would go unnoticed -- the square-root form's pivot
+         * tests would have caught it -- so the sign bits of the five diagonal entries are tested (the kernels test the same bits, csrc/tmpc_riccati.hpp) */
+        for (int i = 0; i < ORC_NX; i++) if (signbit(w->P[k + 1][i][i])) w->bad = 1;
         for (int n = 0; n < ORC_NX; n++)
             for (int j = 0; j < ORC_NV; j++) {
                 double acc = 0.0;
@@ -333,7 +336,7 @@ void orc_qp_solve_form(const orc_qp *qp, orc_qp_sol *s, int iter_max, double tol
                 }
         }
         mu = m > 0 ? mu / m : 0.0;
-        if (getenv("ORC_IPM_TRACE")) fprintf(stderr, "ipm it %d res_g %.3e res_b %.3e res_d %.3e res_m %.3e mu %.3e\n", it, res_g, res_b, res_d, res_m, mu);
+        if (getenv("ORC_IPM_TRACE")) fprintf(stderr, "ipm it %d res_g %.17g res_b %.17g res_d %.17g res_m %.17g mu %.17g\n", it, res_g, res_b, res_d, res_m, mu);
         if (!(isfinite(res_g) && isfinite(res_b) && isfinite(res_d) && isfinite(res_m))) { s->status = 4; break; }
         if (res_g <= tol && res_b <= tol && res_d <= tol && res_m <= tol) { s->status = 0; break; }
         if (it >= iter_max) { s->status = 2; break; }

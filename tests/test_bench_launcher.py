@@ -33,8 +33,16 @@ def test_plain_command_at_two_ranks_prints_one_json_line():
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout
     d = json.loads(lines[0])
-    assert d["launcher_selftest"] and d["n_gpus"] == 2 and d["self_launched"] and d["records"] == 16
-    assert d["best"] == 8                                   # rank 1's first record carries the lowest objective: the gather kept rank order
+    import bench
+    assert d["launcher_selftest"] and d["n_gpus"] == 2 and d["self_launched"] and d["records"] == 32
+    # the N > 1 line is as complete as the N = 1 line (round-5 verdict, next-4): every key of a real line, the CPU baseline included
+    assert all(k in d for k in bench.REQUIRED_KEYS), [k for k in bench.REQUIRED_KEYS if k not in d]
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
+    bi = d["parity"]["best_index"]
+    assert bi["best_index_mismatch_vs_rule_on_device_objectives"] == 0 and bi["sets_checked_vs_rule"] == 2
+    assert bi["inputs_gathered_from_ranks"] == 2 and bi["input_shapes_rank_last"][0] == [16, 5]      # every rank's inputs reached rank 0
+    assert all(0 <= b < 16 for b in d["best"])              # an index in the gathered numbering (rank * per_rank + t)
+    assert d["config"]["gen_workers_per_rank"] == max(1, bench.usable_cpus() // 2)      # scene-generation workers divided by the world size
 
 
 def test_mismatched_world_size_is_refused():
