@@ -570,9 +570,10 @@ def main():
     ap.add_argument("--no-param-sharing", action="store_true",
                     help="do not give the tmpc_set_param_sharing hint (A/B: every trajectory reads its own copy of its set's parameter rows)")
     ap.add_argument("--latency-reps", type=int, default=100)
-    ap.add_argument("--latency-mode", type=int, default=0, choices=[0, 1, 2],
+    ap.add_argument("--latency-mode", type=int, default=0, choices=[0, 1, 2, 3],
                     help="kernel variant of the timed launch (tmpc_set_latency_mode): 0 throughput kernels (default, what `value` of cfg 2 is quoted on), "
-                         "1 two waves per trajectory, 2 parallel-in-time Newton solve -- for the small one-set workloads (cfg 4 share, cfg 5), which are one dependent chain deep")
+                         "1 two waves per trajectory, 2 parallel-in-time Newton solve, 3 four waves per trajectory (N <= 20) -- for the small one-set workloads "
+                         "(cfg 4 share, cfg 5), which are one dependent chain deep")
     ap.add_argument("--parity-check", type=int, default=256,
                     help="trajectories of the timed launch re-solved by the CPU oracle after timing (0 = skip)")
     ap.add_argument("--launcher-selftest", action="store_true", help="exercise the N > 1 launch path on CPU (gloo) and exit; no GPU needed")
@@ -770,26 +771,33 @@ def main():
     n_sqp_mean = float(res["sqp_iter"].mean())
     ipm_per_qp = float(res["qp_iter_total"].sum() / max(res["sqp_iter"].sum(), 1))
 
-    # ---- the same launch at qp_tol = 1e-9: the tolerance at which the RTI iterate no longer depends on the QP solver ------
-    # (tests/test_independent_rti.py: oracle <-> exact active-set RTI 2e-7 there, up to 1e-3 at the reference's 1e-5)
+    # ---- the same launch at a tight QP tolerance: the RTI iterate no longer depends on how the QP solver reaches its tolerance ------
+    # (tests/test_independent_rti.py).  1e-8 since round 6: at 1e-9 a float64 interior-point method is below the noise floor of its own stationarity
+    # residual on these QPs and two correct implementations disagree on integers in ~0.6 % of the solves, in either Riccati form
+    # (profiles/round6_tight_tolerance_study.json names trajectory, iteration, stopping test and both sides' residuals); the 1e-9 numbers stay beside it
     tight = None
     if rank == 0 and not a.no_tight and not use_dist:
-        dims9 = solver.default_dims(**wl["dims"], qp_tol=1e-9)
-        s9 = solver.BatchedSolver(dims9, B_max=B, device=local_rank)
-        s9.set_batch_device(B, t_xinit.data_ptr(), t_x0.data_ptr(), t_params.data_ptr())
-        s9.solve(); ms9 = s9.time_solve(3); r9 = s9.get(); s9.close()
-        ok9 = r9["exit_code"] == 1
-        tight = {"qp_tol": 1e-9, "kernel_ms": float(np.median(ms9)), "success_fraction": float(ok9.mean()),
-                 "value": float(B * ok9.mean() / (np.median(ms9) * 1e-3)), "unit": "successful solves/s (kernel time, same resident batch)",
-                 "mean_ipm_iter_per_qp": float(r9["qp_iter_total"].sum() / max(r9["sqp_iter"].sum(), 1))}
-        if a.parity_check > 0:
-            sys.path.insert(0, os.path.join(ROOT, "tests"))
-            import oracle_lib as O
-            # at this tolerance the interior-point method runs into the conditioning of the barrier systems and the FORM of the Riccati recursion
-            # decides a few outcomes (profiles/round5_riccati_form_study.json): the oracle runs the kernels' form here (riccati_form 1: the elimination
-            # stops after the input block); the default-tolerance parity block above is against the oracle's default, the square-root form
-            tight["parity"] = parity_block(O, wl, batch, r9, min(a.parity_check, 128), {"qp_tol": 1e-9, "riccati_form": 1})
-            tight["parity"]["against"] += " (oracle option riccati_form = 1: the same recursion form as the kernels)"
+        def tight_leg(tol):
+            dims_t = solver.default_dims(**wl["dims"], qp_tol=tol)
+            st = solver.BatchedSolver(dims_t, B_max=B, device=local_rank)
+            st.set_batch_device(B, t_xinit.data_ptr(), t_x0.data_ptr(), t_params.data_ptr())
+            st.solve(); ms_t = st.time_solve(3); rt = st.get(); st.close()
+            okt = rt["exit_code"] == 1
+            blk = {"qp_tol": tol, "kernel_ms": float(np.median(ms_t)), "success_fraction": float(okt.mean()),
+                   "value": float(B * okt.mean() / (np.median(ms_t) * 1e-3)), "unit": "successful solves/s (kernel time, same resident batch)",
+                   "mean_ipm_iter_per_qp": float(rt["qp_iter_total"].sum() / max(rt["sqp_iter"].sum(), 1))}
+            if a.parity_check > 0:
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                import oracle_lib as O
+                # like for like: the oracle runs the kernels' Riccati form (its option riccati_form 1: the elimination stops after the input block)
+                blk["parity"] = parity_block(O, wl, batch, rt, min(a.parity_check, 128), {"qp_tol": tol, "riccati_form": 1})
+                blk["parity"]["against"] += " (oracle option riccati_form = 1: the same recursion form as the kernels)"
+            return blk
+        tight = tight_leg(1e-8)
+        tight["why_1e_8"] = "the tightest tolerance above the float64 noise floor of the interior-point method on these QPs: profiles/round6_tight_tolerance_study.json"
+        tight["beyond_the_noise_floor_1e_9"] = tight_leg(1e-9)
+        tight["beyond_the_noise_floor_1e_9"]["note"] = ("integer disagreements here are the stopping test deciding on rounding noise (res_g ~ 1e-9 from terms of magnitude 1e6 .. 1e7), "
+                                                        "at the same rate in both Riccati forms; both sides also break down on ~0.5 % of the solves: see the study")
 
     # ---- end to end: per-tick inputs uploaded every step, x0 / halfspace rows built on device, winners copied back ----------
     e2e = None
@@ -800,6 +808,7 @@ def main():
 
     # ---- p50 latency of one control tick (64 trajectories, host call -> best index on host) --------------
     lat = None
+    lat5 = None
     lanes = None
     if rank == 0 and a.lanes and not use_dist and not dims.cost_model and not dims.row_model and solver.has_lane_kernels():
         # the lane-per-trajectory variant (tmpc_set_throughput_mode) on the same resident batch: the measured alternative design
@@ -815,55 +824,63 @@ def main():
                  "ipm_iter_mismatch_vs_default": int((rl["qp_iter_total"][okl] != res["qp_iter_total"][okl]).sum()),
                  "max_abs_traj_diff_vs_default": float(np.abs(rl["xtraj"][okl] - res["xtraj"][okl]).max()) if okl.any() else None}
     if rank == 0 and a.latency_reps > 0 and a.workload == "cfg2":
-        one = solver.BatchedSolver(dims, B_max=TRAJ, device=local_rank)
-        lat_variant = one.set_latency_mode(True)          # two-waves-per-trajectory kernel variant for small ticks
-        sl = slice(0, TRAJ)
-        hx, h0, hp = batch["xinit"][sl], batch["x0"][sl], batch["params"][sl]
-        ts = []
-        for i in range(a.latency_reps + 10):
-            t1 = time.perf_counter()
-            one.set_batch(hx, h0, hp); one.solve(sync=False); b1 = one.select_best()
-            ts.append(time.perf_counter() - t1)
-        ts = np.array(ts[10:]) * 1e3
-        one.enable_timing(32)
-        for _ in range(20):
-            one.solve(sync=False)
-        k64 = one.get_timings()
-        lat = {"p50_ms": float(np.percentile(ts, 50)), "p90_ms": float(np.percentile(ts, 90)),
-               "kernel_ms_b64": float(np.median(k64)), "solves_per_s_b64": float(TRAJ / (np.percentile(ts, 50) * 1e-3)),
-               "kernel_variant": "latency (two waves per trajectory)" if lat_variant else "default",
-               "includes": "H2D of params/warm start, solve kernel, FindBestPlanner, D2H of the index"}
-        # latency mode 2: the Newton systems solved parallel in time (csrc/tmpc_scan.hpp) -- same tick, its own parity block
-        if one.set_latency_mode(2):
-            ts2 = []
-            for i in range(a.latency_reps + 10):
-                t1 = time.perf_counter()
-                one.set_batch(hx, h0, hp); one.solve(sync=False); b2 = one.select_best()
-                ts2.append(time.perf_counter() - t1)
-            ts2 = np.array(ts2[10:]) * 1e3
-            one.enable_timing(32)
-            for _ in range(20):
-                one.solve(sync=False)
-            k64s = one.get_timings()
-            r2 = one.get()
-            one.set_latency_mode(1); one.solve(); r1 = one.get()
-            both = (r1["exit_code"] == 1) & (r2["exit_code"] == 1)
-            scan = {"p50_ms": float(np.percentile(ts2, 50)), "p90_ms": float(np.percentile(ts2, 90)), "kernel_ms_b64": float(np.median(k64s)),
-                    "kernel_variant": "latency 2 (two waves per trajectory, parallel-in-time Newton solve: Schur complement + block cyclic reduction)",
-                    "best_index_equal_mode_1": bool(b1 == b2),
-                    "vs_mode_1": {"exit_code_mismatch": int((r1["exit_code"] != r2["exit_code"]).sum()),
-                                  "ipm_iter_mismatch": int((r1["qp_iter_total"] != r2["qp_iter_total"]).sum()),
-                                  "ipm_iter_max_abs_diff": int(np.abs(r1["qp_iter_total"] - r2["qp_iter_total"]).max()),
-                                  "max_abs_xtraj_diff": float(np.abs(r1["xtraj"][both] - r2["xtraj"][both]).max()) if both.any() else None}}
-            if a.parity_check > 0:
-                scan["parity"] = parity_block(O, wl, {"xinit": hx, "x0": h0, "params": hp}, r2, min(a.parity_check, TRAJ), {})
-            lat["parallel_in_time"] = scan
-            # the tick's headline figures are those of the fastest variant the library offers for it (the caller's opt-in, parity block
-            # above); the two-wave Riccati variant's stay next to them
-            lat["two_wave_riccati"] = {k: lat[k] for k in ("p50_ms", "p90_ms", "kernel_ms_b64", "solves_per_s_b64", "kernel_variant")}
-            lat.update({"p50_ms": scan["p50_ms"], "p90_ms": scan["p90_ms"], "kernel_ms_b64": scan["kernel_ms_b64"],
-                        "solves_per_s_b64": float(TRAJ / (scan["p50_ms"] * 1e-3)), "kernel_variant": scan["kernel_variant"]})
-        one.close()
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as O
+        VARIANT = {1: "latency 1 (two waves per trajectory, sequential Riccati recursion)",
+                   2: "latency 2 (two waves per trajectory, parallel-in-time Newton solve: Schur complement + block cyclic reduction)",
+                   3: "latency 3 (FOUR waves per trajectory: stage evaluation split four ways, row passes at twelve lanes per stage, the wide phases of the "
+                      "parallel-in-time factorisation on all four waves)"}
+
+        def tick_block(nb, label):
+            """One control tick of `nb` planners, host call -> best index on host, in every kernel variant the library offers for it."""
+            one = solver.BatchedSolver(dims, B_max=nb, device=local_rank)
+            hx, h0, hp = batch["xinit"][:nb], batch["x0"][:nb], batch["params"][:nb]
+            out_modes, res_modes, best_modes = {}, {}, {}
+            for mode in (1, 2, 3):
+                if not one.set_latency_mode(mode):
+                    continue
+                ts = []
+                for i in range(a.latency_reps + 10):
+                    t1 = time.perf_counter()
+                    one.set_batch(hx, h0, hp); one.solve(sync=False); b_ = one.select_best()
+                    ts.append(time.perf_counter() - t1)
+                ts = np.array(ts[10:]) * 1e3
+                one.get_timings(); one.enable_timing(32)
+                for _ in range(20):
+                    one.solve(sync=False)
+                k_ms = one.get_timings()
+                r_ = one.get()
+                res_modes[mode], best_modes[mode] = r_, b_
+                out_modes[mode] = {"p50_ms": float(np.percentile(ts, 50)), "p90_ms": float(np.percentile(ts, 90)), "kernel_ms": float(np.median(k_ms)),
+                                   "solves_per_s": float(nb / (np.percentile(ts, 50) * 1e-3)), "kernel_variant": VARIANT[mode]}
+                if a.parity_check > 0:
+                    out_modes[mode]["parity"] = parity_block(O, wl, {"xinit": hx, "x0": h0, "params": hp}, r_, min(a.parity_check, nb), {})
+            one.close()
+            if not out_modes:
+                return None
+            fastest = min(out_modes, key=lambda m: out_modes[m]["p50_ms"])
+            blk = {"planners": nb, "what": label, "includes": "H2D of params/warm start, solve kernel, FindBestPlanner, D2H of the index",
+                   **{k: out_modes[fastest][k] for k in ("p50_ms", "p90_ms", "kernel_ms", "solves_per_s", "kernel_variant")},
+                   "fastest_mode": fastest, "by_mode": {f"mode_{m}": v for m, v in out_modes.items()},
+                   "best_index_equal_across_modes": bool(len(set(best_modes.values())) == 1)}
+            if 1 in res_modes:
+                r1 = res_modes[1]
+                blk["vs_mode_1"] = {}
+                for m, r2 in res_modes.items():
+                    if m == 1:
+                        continue
+                    both = (r1["exit_code"] == 1) & (r2["exit_code"] == 1)
+                    blk["vs_mode_1"][f"mode_{m}"] = {"exit_code_mismatch": int((r1["exit_code"] != r2["exit_code"]).sum()),
+                                                     "ipm_iter_mismatch": int((r1["qp_iter_total"] != r2["qp_iter_total"]).sum()),
+                                                     "max_abs_xtraj_diff": float(np.abs(r1["xtraj"][both] - r2["xtraj"][both]).max()) if both.any() else None}
+            return blk
+
+        lat = tick_block(TRAJ, "configs[1] as named: one 64-trajectory guidance set per tick")
+        if lat is not None:
+            lat["kernel_ms_b64"] = lat["kernel_ms"]; lat["solves_per_s_b64"] = lat["solves_per_s"]          # (the key names of rounds 1-5)
+        # the reference's DEPLOYED size: 4 guidance planners + the non-guided T-MPC++ planner (mpc_planner_jackalsimulator/config/guidance_planner.yaml:11,
+        # guidance_constraints.cpp:40-52): the first five trajectories of the same set
+        lat5 = tick_block(5, "the reference's deployed size: n_paths = 4 guidance planners + the non-guided planner (guidance_planner.yaml:11)")
 
     if rank == 0:
         solves = B * world * a.steps
@@ -906,7 +923,8 @@ def main():
                        "param_sharing": {"hint": share_map is not None, "entries_reading_a_shared_row": int((share_map != np.arange(B)).sum()) if share_map is not None else 0,
                                          "what": "tmpc_set_param_sharing: a set's copies of the obstacle / spline / weight rows are read from the set's first entry (checked equal on the host); results bitwise unchanged"},
                        "kernel_variant": {"latency_mode": a.latency_mode, "accepted": lat_mode_ok,
-                                          "what": ["throughput kernels", "two waves per trajectory", "parallel-in-time Newton solve (csrc/tmpc_scan.hpp)"][a.latency_mode]},
+                                          "what": ["throughput kernels", "two waves per trajectory", "parallel-in-time Newton solve (csrc/tmpc_scan.hpp)",
+                                                   "four waves per trajectory (parallel-in-time solve, split stage evaluation, twelve lanes per stage)"][a.latency_mode]},
                        "parallelism": f"trajectory-sharded x{world}, one 16 B/trajectory all-gather" if world > 1 else "single GPU"},
             "roofline": {"bound": "fp64_valu", "bound_detail": "FP64 vector (VALU) peak; the kernel issues no MFMA instruction (the dense f64 MFMA peak is the same 78.6 TFLOP/s on MI355X, so the schema's 'mfma' label would give the same number)", "achieved": tflops, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": tflops / FP64_VALU_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_note,
@@ -923,10 +941,12 @@ def main():
             "parity": parity,
             "value_end_to_end": e2e["value_end_to_end"] if e2e else None,
             "end_to_end": e2e,
-            "value_qp_tol_1e_9": tight["value"] if tight else None,
-            "qp_tol_1e_9": tight,
+            "value_qp_tol_1e_8": tight["value"] if tight else None,
+            "qp_tol_1e_8": tight,
+            "value_qp_tol_1e_9": tight["beyond_the_noise_floor_1e_9"]["value"] if tight else None,
             "lanes_variant": lanes,
             "latency_b64": lat,
+            "latency_b5": lat5,
             "best_index_sample": best[:4].tolist(),
             "scenario_pipeline": scenario_info,
         }

@@ -233,6 +233,25 @@ static SolveKernel pick_scan_kernel(const Dims &d, int *threads, int *sl)
     (void)d; (void)threads;
     return nullptr;
 }
+// Latency variant 3 (tmpc_set_latency_mode(h, 3), round 6): FOUR waves per trajectory -- a control tick of a few planners leaves a whole CU (four SIMDs,
+// 160 KB of LDS) to every trajectory.  The stage evaluation is split four ways by content (dynamics | cost + halfspace rows | obstacle rows on two waves),
+// the interior-point row passes run at twelve lanes per stage (three rows per lane instead of five), and the wide phases of the parallel-in-time
+// factorisation (the stage phase: one column per lane instead of four; level 0 of the cyclic reduction: one instead of two) use all 256 lanes
+// (csrc/tmpc_scan.hpp factor4).  Same algorithm as variant 2 (sums associate differently: rounding level).  N <= 20, hand-written MPCC stages.
+// `ab`: TMPC_QUAD_AB=1 in a lab build picks the twin whose factorisation stays on one wave (A/B of the factorisation split alone).
+static SolveKernel pick_quad_kernel(const Dims &d, bool prof, bool ab)
+{
+#ifndef TMPC_GENERATED_STAGE
+    if (d.N > 20 || d.N < 2 || stage_model(d) != 0) return nullptr;
+    if (d.n_up == 8 && d.M == 8) {
+        if (prof) return (SolveKernel)tmpc_solve_fast_kernel<8, 8, 12, 256, true, ScanQuad>;
+        return ab ? (SolveKernel)tmpc_solve_fast_kernel<8, 8, 12, 256, false, ScanSolo> : (SolveKernel)tmpc_solve_fast_kernel<8, 8, 12, 256, false, ScanQuad>;
+    }
+    if (!prof && d.n_up + d.M + 14 <= 12 * 4) return (SolveKernel)tmpc_solve_fast_kernel<-1, 4, 12, 256, false, ScanQuad>;      // cfg 1, cfg 4, cfg 5, any row mix up to 34 rows
+#endif
+    (void)d; (void)prof; (void)ab;
+    return nullptr;
+}
 // ---- stage stride of the row Jacobians in LDS (Dims::dpad) --------------------------------------------------------------------
 // LDS bank-conflict model of the row passes' coefficient loads (ipm_fast: coef()).  Lane (stage k, sub-lane c) of a wave owns the rows c, c + LPS, ...;
 // per row slot the lanes read the row's three entries as three 8-byte accesses at  k * dstride + offset(row)  (rows without a Jacobian read the
@@ -299,6 +318,8 @@ struct tmpc_handle {
     int threads = tmpc::NT;          // threads per trajectory (64, or 128 for the two-wave fast variant)
     tmpc::SolveKernel kernel_lat = nullptr;   // optional latency variant (128 threads), used when latency_mode is 1
     tmpc::SolveKernel kernel_scan = nullptr;  // optional latency variant 2 (parallel-in-time Newton solve, 64 threads)
+    tmpc::SolveKernel kernel_quad = nullptr;  // optional latency variant 3 (four waves per trajectory, 256 threads; LDS = lds_bytes_scan3)
+    size_t lds_bytes_quad = 0;
     size_t lds_bytes_scan = 0;
     int scan_threads = 64, scan_sl = 3;
     size_t lds_bytes_fast = 0;                // LDS of the fast-layout kernels (the profiled twin) when `kernel` is compact
@@ -453,8 +474,8 @@ int tmpc_create(tmpc_handle **out, const tmpc_dims *dims, int32_t B_max, int32_t
     d.split_rows = tmpc::split_rows_for(d.N, d.n_up + d.M) ? 1 : 0;
     h->kernel = d.riccati_form == TMPC_RICCATI_SQUARE_ROOT ? tmpc::pick_sqrt_kernel(d, &h->threads) : tmpc::pick_fast_kernel(d, &h->threads, false);
     if (d.riccati_form == TMPC_RICCATI_SQUARE_ROOT && !h->kernel) { delete h; return TMPC_ERR_INVALID; }       // (no square-root instantiation for this shape: never a silent other form)
-    if (const char *lm = getenv("TMPC_LATENCY_MODE")) {      // experiments: latency variant regardless of the caller ("0", "1" or "2"; anything else is ignored)
-        if ((lm[0] == '0' || lm[0] == '1' || lm[0] == '2') && lm[1] == '\0') h->latency_mode = lm[0] - '0';
+    if (const char *lm = getenv("TMPC_LATENCY_MODE")) {      // experiments: latency variant regardless of the caller ("0" .. "3"; anything else is ignored)
+        if (lm[0] >= '0' && lm[0] <= '3' && lm[1] == '\0') h->latency_mode = lm[0] - '0';
     }
     h->fast = h->kernel != nullptr;
     if (h->fast) h->lds_bytes = sizeof(double) * (size_t)tmpc::lds_doubles_fast(d.N, d.n_up + d.M);
@@ -478,6 +499,13 @@ int tmpc_create(tmpc_handle **out, const tmpc_dims *dims, int32_t B_max, int32_t
     if (h->kernel_scan) {
         if (hipFuncSetAttribute((const void *)h->kernel_scan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes_scan) != hipSuccess)
             h->kernel_scan = nullptr;
+    }
+    if (schur && h->fast && h->threads == tmpc::NT && (h->kernel_quad = tmpc::pick_quad_kernel(d, false, getenv("TMPC_QUAD_AB") != nullptr)) != nullptr) {
+        // fast layout + the W shares of the split linearisation (wave 0's N x 28, the obstacle lanes' 36 N: they lie inside the scan scratch, which is dead then) + the scan scratch
+        h->lds_bytes_quad = h->lds_bytes_fast2 + sizeof(double) * (size_t)tmpc::scan::lds_doubles<3>(d.N);
+        if (h->lds_bytes_quad > 160 * 1024 ||
+            hipFuncSetAttribute((const void *)h->kernel_quad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes_quad) != hipSuccess)
+            h->kernel_quad = nullptr;
     }
     if (tmpc::SolveKernel kc = (schur && h->fast && h->threads == tmpc::NT) ? tmpc::pick_compact_kernel(d, false, &h->lay_cp) : nullptr) {
         // the fast kernel of the shape (everything in LDS, four per CU) stays for launches it holds resident at once: bitwise the same results
@@ -624,20 +652,21 @@ static int launch_solve(tmpc_handle *h, int n_iter, int st_flags)
         dd.n_sqp = n_iter;
         tmpc::StateIO io{h->st_z, h->st_pi, h->st_lamh, h->st_stopped, st_flags, h->ws, h->ticket, (h->slots_set && h->slots_B == h->B) ? h->d_slot : nullptr, h->st_has,
                          (h->share_B == h->B) ? h->d_share : nullptr};      // (a map given for another batch size is not applied)
-        const bool lat2 = h->kernel_scan && h->latency_mode == 2;
-        const bool lat = !lat2 && h->kernel_lat && h->latency_mode != 0;          // (mode 2 without a scan variant falls back to the two-wave variant)
+        const bool lat3 = h->kernel_quad && h->latency_mode == 3;
+        const bool lat2 = !lat3 && h->kernel_scan && h->latency_mode >= 2;        // (mode 3 without a four-wave variant runs as mode 2, ...
+        const bool lat = !lat3 && !lat2 && h->kernel_lat && h->latency_mode != 0; //  ... mode 2 without a scan variant as the two-wave variant)
         // compact <-> fast kernels of a shape compute bit for bit the same, so the launch size may choose between them: the fast kernel while it
         // holds the whole launch resident (lower latency per trajectory), the compact one (twice the residency) above that
-        const bool cp2 = h->kernel_cp2 && !lat && !lat2 && h->B > h->cp2_min_B;
-        const bool small = h->compact && h->kernel_small && !lat && !lat2 && h->B <= h->cp_min_B;
-        const bool cp = (h->compact && !lat && !lat2 && !small) || cp2;
+        const bool cp2 = h->kernel_cp2 && !lat && !lat2 && !lat3 && h->B > h->cp2_min_B;
+        const bool small = h->compact && h->kernel_small && !lat && !lat2 && !lat3 && h->B <= h->cp_min_B;
+        const bool cp = (h->compact && !lat && !lat2 && !lat3 && !small) || cp2;
         dd.prio = cp2 ? h->prio_cp2 : (cp ? h->prio_cp : false);
         dd.dpad = cp2 ? h->dpad_cp2 : (cp ? h->dpad_cp : 0);      // (layout only: results do not depend on it)
         if (cp) TMPC_HIP_CHECK(h, hipMemsetAsync(h->ticket, 0, 8 * 4, h->stream));    // the persistent launch's work counters (one per XCD)
-        hipLaunchKernelGGL(lat2 ? h->kernel_scan : lat ? h->kernel_lat : cp2 ? h->kernel_cp2 : small ? h->kernel_small : h->kernel,
+        hipLaunchKernelGGL(lat3 ? h->kernel_quad : lat2 ? h->kernel_scan : lat ? h->kernel_lat : cp2 ? h->kernel_cp2 : small ? h->kernel_small : h->kernel,
                            dim3(cp ? (h->B < h->grid_max ? h->B : h->grid_max) : h->B),   // (persistent launch: at most the resident workgroups)
-                           dim3(lat2 ? h->scan_threads : lat ? 128 : cp2 ? 128 : ((cp || small) ? 64 : h->threads)),
-                           lat2 ? h->lds_bytes_scan : lat ? h->lds_bytes_fast2 : cp2 ? h->lds_bytes_cp2 : small ? h->lds_bytes_small : h->lds_bytes, h->stream, dd, h->B,
+                           dim3(lat3 ? 256 : lat2 ? h->scan_threads : lat ? 128 : cp2 ? 128 : ((cp || small) ? 64 : h->threads)),
+                           lat3 ? h->lds_bytes_quad : lat2 ? h->lds_bytes_scan : lat ? h->lds_bytes_fast2 : cp2 ? h->lds_bytes_cp2 : small ? h->lds_bytes_small : h->lds_bytes, h->stream, dd, h->B,
                            h->xinit, h->x0, h->params, h->xtraj, h->utraj, h->pobj, h->exit_code, h->qp_status,
                            h->sqp_iter, h->res_eq, h->qp_iter, (long long *)nullptr, io);
         TMPC_HIP_CHECK(h, hipGetLastError());
@@ -746,18 +775,20 @@ int tmpc_reset_multipliers(tmpc_handle *h)
 int tmpc_set_latency_mode(tmpc_handle *h, int32_t on)
 {
     if (!h) return TMPC_ERR_INVALID;
-    if (on < 0 || on > 2) return TMPC_ERR_INVALID;
+    if (on < 0 || on > 3) return TMPC_ERR_INVALID;
     h->latency_mode = on;
-    if (on == 2) return h->kernel_scan ? TMPC_OK : 1;              // 1: accepted, but this shape has no such variant (mode 2 then runs as mode 1 if that exists)
+    if (on == 3) return h->kernel_quad ? TMPC_OK : 1;              // 1: accepted, but this shape has no such variant (mode 3 then runs as mode 2, mode 2 as mode 1, if those exist)
+    if (on == 2) return h->kernel_scan ? TMPC_OK : 1;
     return (on == 1 && !h->kernel_lat) ? 1 : TMPC_OK;
 }
 
 int tmpc_latency_mode_capacity(tmpc_handle *h, int32_t mode)
 {
-    if (!h || mode < 0 || mode > 2) return TMPC_ERR_INVALID;
+    if (!h || mode < 0 || mode > 3) return TMPC_ERR_INVALID;
     if (hipSetDevice(h->device) != hipSuccess) return TMPC_ERR_HIP;
     const void *k = nullptr; int threads = 64; size_t lds = 0;
-    if (mode == 2) { if (!h->kernel_scan) return 0; k = (const void *)h->kernel_scan; threads = h->scan_threads; lds = h->lds_bytes_scan; }
+    if (mode == 3) { if (!h->kernel_quad) return 0; k = (const void *)h->kernel_quad; threads = 256; lds = h->lds_bytes_quad; }
+    else if (mode == 2) { if (!h->kernel_scan) return 0; k = (const void *)h->kernel_scan; threads = h->scan_threads; lds = h->lds_bytes_scan; }
     else if (mode == 1) { if (!h->kernel_lat) return 0; k = (const void *)h->kernel_lat; threads = 128; lds = h->lds_bytes_fast2; }
     else {
         // the throughput kernels of the handle: the resident set of the persistent (compact) launch, or of the plain kernel
@@ -1250,7 +1281,9 @@ int tmpc_debug_profile(tmpc_handle *h, int64_t *cycles, int32_t n_phases)
         pk = tmpc::pick_fast_kernel(h->d, &thr, true);
 #ifndef TMPC_GENERATED_STAGE
         // the latency variants of cfg 2 are profiled as themselves (tmpc_set_latency_mode before the call)
-        if (h->latency_mode == 2 && h->kernel_scan && h->scan_threads == 128 && h->scan_sl == 3 && h->d.n_up == 8 && h->d.M == 8) {
+        if (h->latency_mode == 3 && h->kernel_quad && tmpc::pick_quad_kernel(h->d, true, false)) {
+            pk = tmpc::pick_quad_kernel(h->d, true, false); thr = 256; lds = h->lds_bytes_quad;
+        } else if (h->latency_mode >= 2 && h->kernel_scan && h->scan_threads == 128 && h->scan_sl == 3 && h->d.n_up == 8 && h->d.M == 8) {
             pk = (tmpc::SolveKernel)tmpc::tmpc_solve_fast_kernel<8, 8, 6, 128, true, tmpc::ScanSolo>; thr = 128; lds = h->lds_bytes_scan;
         } else if (h->latency_mode != 0 && h->kernel_lat) {
             pk = tmpc::pick_latency_kernel(h->d, true); thr = 128; lds = h->lds_bytes_fast2;

@@ -180,6 +180,33 @@ struct ScanSoloT {
 };
 using ScanSolo = ScanSoloT<3>;
 
+// Four waves per trajectory (NTH = 256, N <= 20; round 6): the factorisation's wide phases -- the stage phase and level 0 of the cyclic reduction -- run
+// on all four waves (scan::factor4), the solves on wave 0 (their levels are a few lanes wide: more waves have nothing to do there).
+struct ScanQuad {
+    static constexpr int NQ = 1;
+    __device__ __forceinline__ bool alive() const { return true; }
+    __device__ __forceinline__ void sync() const { __syncthreads(); }
+    __device__ __forceinline__ bool any(bool active) const { return active; }
+    template <int NTH, int CP>
+    __device__ __forceinline__ bool factor(const Lds &L, const Dims &d, int tl, int, int) const
+    {
+        static_assert(!CP && NTH == 256, "fast layout, four waves");
+        asm volatile("" : "+v"(tl));
+        const scan::ViewT<3> V{L.Hh, L.BA, L.gh, L.rb, L.dv, L.dpi, L.scan + d.N * NP28, d.N};
+        return scan::factor4(V, tl, L.scr + 48);
+    }
+    template <int NTH, int CP>
+    __device__ __forceinline__ void solve(const Lds &L, const Dims &d, int tl, int, int, int phase, bool) const
+    {
+        asm volatile("" : "+v"(tl));
+        if (tl < 64) {
+            const scan::ViewT<3> V{L.Hh, L.BA, L.gh, L.rb, L.dv, L.dpi, L.scan + d.N * NP28, d.N};
+            scan::solve(V, tl, phase == 1);
+        }
+        __syncthreads();
+    }
+};
+
 template <int NLIN, int MM, int LPS, int NTH, int CP, typename PF, typename TEAM = Solo>
 __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, int *iters_out, PF &pf,
                         double (&lam)[FastCfg<NLIN, MM, LPS>::RPL], const TEAM &team = TEAM())
@@ -508,7 +535,15 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
                     }
                 }
             });
-            if (stage_lane) {
+            // Twelve lanes per stage (the four-wave kernel): a ds_add_f64 whose lanes hit the same address is serialised, and twelve lanes of a stage adding to
+            // one entry cost that phase twice what six did (measured: 328 k instead of 164 k cycles per solve).  The stage's lanes 12 s .. 12 s + 11 are three
+            // aligned quads: two DPP quad permutations sum each quad in registers, its first lane adds -- three-way conflicts, like the one-wave kernels.
+            if constexpr (LPS == 12) {
+                auto quad = [](double x) { x += dpp_move<0xB1, 0xf>(x, 0.0); x += dpp_move<0x4E, 0xf>(x, 0.0); return x; };      // quad_perm [1,0,3,2], then [2,3,0,1]
+                gs0 = quad(gs0); gs1 = quad(gs1); gs2 = quad(gs2); rs0 = quad(rs0); rs1 = quad(rs1); rs2 = quad(rs2);
+                h00 = quad(h00); h10 = quad(h10); h11 = quad(h11); h20 = quad(h20); h21 = quad(h21); h22 = quad(h22);
+            }
+            if (stage_lane && (LPS != 12 || (c & 3) == 0)) {
                 lds_add(&L.rg[mul24(k, NV) + ZX], -gs0); lds_add(&L.rg[mul24(k, NV) + ZY], -gs1); lds_add(&L.rg[mul24(k, NV) + ZPSI], -gs2);
                 lds_add(&L.gh[mul24(k, NV) + ZX], rs0); lds_add(&L.gh[mul24(k, NV) + ZY], rs1); lds_add(&L.gh[mul24(k, NV) + ZPSI], rs2);
                 double *Hk = L.Hh + hoff_lane<CP>(k);
@@ -536,7 +571,7 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
 
         // two-wave variant: the sweeping wave alternates with the iteration (and differs between neighbouring trajectories),
         // so that co-resident trajectories seldom run the same sweep on the same SIMD
-        const int sw = NTH == 128 ? ((it + (int)(blockIdx.x >> 8)) & 1) : 0;
+        const int sw = NTH >= 128 ? ((it + (int)(blockIdx.x >> 8)) & 1) : 0;
         const bool fbad = team.template factor<NTH, CP>(L, d, tl, sw, it);
         pf.stop(PH_FACTOR);
         if (active && fbad) { status = 4; active = false; }
@@ -612,7 +647,11 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
                 if constexpr (K != 1) { cs0 += w * c0s; cs1 += w * c1s; cs2 += w * c2s; }
                 if constexpr (K != 0) { if (a && (K == 1 || (box >> s & 1))) lds_add(&L.gh[mul24(k, NV) + VARK(s_)], w * CUK(s_)); }
             });
-            if (stage_lane) { lds_add(&L.gh[mul24(k, NV) + ZX], cs0); lds_add(&L.gh[mul24(k, NV) + ZY], cs1); lds_add(&L.gh[mul24(k, NV) + ZPSI], cs2); }
+            if constexpr (LPS == 12) {
+                auto quad = [](double x) { x += dpp_move<0xB1, 0xf>(x, 0.0); x += dpp_move<0x4E, 0xf>(x, 0.0); return x; };
+                cs0 = quad(cs0); cs1 = quad(cs1); cs2 = quad(cs2);
+            }
+            if (stage_lane && (LPS != 12 || (c & 3) == 0)) { lds_add(&L.gh[mul24(k, NV) + ZX], cs0); lds_add(&L.gh[mul24(k, NV) + ZY], cs1); lds_add(&L.gh[mul24(k, NV) + ZPSI], cs2); }
         }
         team.sync();
         }

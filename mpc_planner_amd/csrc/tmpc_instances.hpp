@@ -14,6 +14,9 @@
 #define TMPC_SCAN_SHAPES(X) X(-1, 12, 4, 128, tmpc::ScanSoloT<2>) X(8, 8, 6, 128, tmpc::ScanSolo) X(8, 8, 3, 64, tmpc::ScanSolo) X(-1, 9, 6, 128, tmpc::ScanSolo)
 // square-root form of the Riccati recursion (tmpc_dims.riccati_form = 1): run-time-shape fast kernels (NLIN, MM, LPS, NTH, CM)
 #define TMPC_SQRT_SHAPES(X) X(-1, 13, 3, 64, 0) X(-1, 12, 4, 128, 0) X(20, 8, 4, 128, 1)
+// latency mode 3 (round 6): four waves per trajectory, twelve lanes per stage, the wide phases of the parallel-in-time factorisation on all four waves
+// (NLIN, MM, PROF, policy): the tuned cfg 2 shape + its profiled twin + its A/B twin whose factorisation stays on one wave; run-time shapes up to 48 rows
+#define TMPC_QUAD_SHAPES(X) X(8, 8, false, tmpc::ScanQuad) X(8, 8, true, tmpc::ScanQuad) X(8, 8, false, tmpc::ScanSolo) X(-1, 4, false, tmpc::ScanQuad)
 // compact kernels, one wave per trajectory (NLIN, MM, LPS)
 #define TMPC_COMPACT_SHAPES(X) X(8, 8, 3) X(0, 4, 3) X(12, 12, 3) X(24, 0, 3) X(-1, 7, 3) X(-1, 10, 3)
 // compact kernels, two waves per trajectory (NLIN, MM, LPS, CM)
@@ -23,7 +26,7 @@
 
 #define TMPC_ALL_INSTANCES(KW)                                                                                                                     \
     TMPC_FAST_SHAPES(TMPC_I_FAST_##KW) TMPC_FAST_SHAPES(TMPC_I_PROF_##KW) TMPC_FAST_CM_SHAPES(TMPC_I_FASTCM_##KW) TMPC_SCAN_SHAPES(TMPC_I_SCAN_##KW) \
-    TMPC_COMPACT_SHAPES(TMPC_I_CP_##KW) TMPC_CP2_SHAPES(TMPC_I_CP2_##KW) TMPC_GENERIC_MODELS(TMPC_I_GEN_##KW) TMPC_SQRT_SHAPES(TMPC_I_SQRT_##KW)
+    TMPC_COMPACT_SHAPES(TMPC_I_CP_##KW) TMPC_CP2_SHAPES(TMPC_I_CP2_##KW) TMPC_GENERIC_MODELS(TMPC_I_GEN_##KW) TMPC_SQRT_SHAPES(TMPC_I_SQRT_##KW) TMPC_QUAD_SHAPES(TMPC_I_QUAD_##KW)
 // KW = DEF: explicit instantiation definition; KW = EXT: extern declaration
 #define TMPC_I_FAST_DEF(a, b, c, e) template __global__ void tmpc::tmpc_solve_fast_kernel<a, b, c, e, false>(TMPC_KARGS);
 #define TMPC_I_FAST_EXT(a, b, c, e) extern template __global__ void tmpc::tmpc_solve_fast_kernel<a, b, c, e, false>(TMPC_KARGS);
@@ -35,6 +38,8 @@
 #define TMPC_I_SCAN_EXT(a, b, c, e, t) extern template __global__ void tmpc::tmpc_solve_fast_kernel<a, b, c, e, false, t>(TMPC_KARGS);
 #define TMPC_I_SQRT_DEF(a, b, c, e, m) template __global__ void tmpc::tmpc_solve_fast_kernel<a, b, c, e, false, tmpc::SoloSqrt, m>(TMPC_KARGS);
 #define TMPC_I_SQRT_EXT(a, b, c, e, m) extern template __global__ void tmpc::tmpc_solve_fast_kernel<a, b, c, e, false, tmpc::SoloSqrt, m>(TMPC_KARGS);
+#define TMPC_I_QUAD_DEF(a, b, pf, t) template __global__ void tmpc::tmpc_solve_fast_kernel<a, b, 12, 256, pf, t>(TMPC_KARGS);
+#define TMPC_I_QUAD_EXT(a, b, pf, t) extern template __global__ void tmpc::tmpc_solve_fast_kernel<a, b, 12, 256, pf, t>(TMPC_KARGS);
 #define TMPC_I_CP_DEF(a, b, c) template __global__ void tmpc::tmpc_solve_compact_kernel<a, b, c, false>(TMPC_KARGS);
 #define TMPC_I_CP_EXT(a, b, c) extern template __global__ void tmpc::tmpc_solve_compact_kernel<a, b, c, false>(TMPC_KARGS);
 #define TMPC_I_CP2_DEF(a, b, c, m) template __global__ void tmpc::tmpc_solve_compact_kernel<a, b, c, false, 128, m>(TMPC_KARGS);

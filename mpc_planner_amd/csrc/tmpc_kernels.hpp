@@ -240,17 +240,21 @@ __device__ __forceinline__ double wave_sum(double x)
     return wave_reduce(x, 0.0, [](double a, double b) { return a + b; });
 }
 
-// Workgroup reductions for the two-wave (128-thread) variant of the fast kernel: wave reduction, then one LDS exchange.
-// `scr` = L.scr (64 doubles); slots [base, base + 2 * n) are used.  NTH == 64 reduces to the wave reduction.
+// Workgroup reductions for the multi-wave variants of the fast kernel (NTH = 128: two waves, 256: four): wave reduction, then one LDS exchange.
+// `scr` = L.scr (64 doubles); slots [slot * NW, slot * NW + NW) are used (NW = NTH / 64).  NTH == 64 reduces to the wave reduction.
 template <int NTH, typename Op>
 __device__ __forceinline__ double blk_combine(double x, double *scr, int tid, int slot, Op op)
 {
     if constexpr (NTH == 64) return x;
+    constexpr int NW = NTH / 64;
     // every call site has its own slot and is reached once per interior-point iteration, with barriers in between:
     // the previous readers of the slot are long done
-    if ((tid & 63) == 0) scr[slot * 2 + (tid >> 6)] = x;
+    if ((tid & 63) == 0) scr[slot * NW + (tid >> 6)] = x;
     __syncthreads();
-    return op(scr[slot * 2], scr[slot * 2 + 1]);
+    double r = scr[slot * NW];
+#pragma unroll
+    for (int w = 1; w < NW; w++) r = op(r, scr[slot * NW + w]);      // (fixed order: wave 0, 1, ...)
+    return r;
 }
 template <int NTH> __device__ __forceinline__ double blk_max(double x, double *scr, int tid, int slot = 0)
 {
@@ -268,19 +272,22 @@ template <int NTH> __device__ __forceinline__ double blk_sum(double x, double *s
 // The convergence quantities of an interior-point iteration at once.  The four residual norms (stationarity, dynamics, rows, complementarity) are
 // used for exactly two decisions -- "all finite?" and "all <= qp_tol?" -- and both are decisions about their MAXIMUM, so each lane folds its four
 // partial maxima into one before the wave reduction (round 5: one wave_max instead of four, ~60 VALU instructions per interior-point iteration;
-// the decisions, and with them every result, are unchanged).  `worst` returns that maximum, `mu` the complementarity sum.  Two-wave kernels: one
-// LDS exchange and one barrier.
+// the decisions, and with them every result, are unchanged).  `worst` returns that maximum, `mu` the complementarity sum.  Multi-wave kernels: one
+// LDS exchange and one barrier (slots 0 .. 2 NW - 1 of scr: the blk_* call sites use slots >= 5).
 template <int NTH>
 __device__ __forceinline__ void blk_residuals(double &worst, double g, double b, double dd, double m, double &mu, double *scr, int tid)
 {
     worst = wave_max(fmax(fmax(g, b), fmax(dd, m))); mu = wave_sum(mu);
     if constexpr (NTH > 64) {
-        if ((tid & 63) == 0) { const int w = tid >> 6; scr[w] = worst; scr[2 + w] = mu; }
+        constexpr int NW = NTH / 64;
+        if ((tid & 63) == 0) { const int w = tid >> 6; scr[w] = worst; scr[NW + w] = mu; }
         __syncthreads();
-        double v[4];
+        double v[2 * NW];
 #pragma unroll
-        for (int i = 0; i < 4; i++) v[i] = scr[i];
-        worst = fmax(v[0], v[1]); mu = v[2] + v[3];
+        for (int i = 0; i < 2 * NW; i++) v[i] = scr[i];
+        worst = v[0]; mu = v[NW];
+#pragma unroll
+        for (int w = 1; w < NW; w++) { worst = fmax(worst, v[w]); mu = mu + v[NW + w]; }
     }
 }
 
@@ -684,6 +691,155 @@ __device__ __forceinline__ void linearise(const Lds &L, const Dims &d, int tid, 
 {
     const int N = d.N;
 #ifndef TMPC_GENERATED_STAGE
+    if constexpr (FAST && NTH == 256) {
+        // Four waves per trajectory (round 6, the control-tick kernel: a whole CU serves one trajectory, one wave per SIMD).  The stage evaluation is
+        // split FOUR ways, by what is computed rather than by stage: wave 0 the dynamics (rollout with sensitivities, [B A], defects, the multipliers'
+        // share of the Hessian), wave 1 the cost and the halfspace / scenario rows, waves 2 and 3 the obstacle rows -- three lanes per stage each, so a
+        // lane evaluates at most ceil(M / 6) rows.  The shares of W meet in LDS (the scan scratch behind the layout is dead while the stage blocks are
+        // built); MIRROR's two diagonal blocks then run on waves 0 and 1 as in the two-wave kernels.  W = W_dyn + W_cost + sum of the six obstacle
+        // shares, in that order (associates differently from the one-wave sum: rounding level).  Fast layout only (N <= 20: 3 N <= 64 lanes per wave).
+        static_assert(!CP, "four-wave linearisation: fast layout");
+        int tid_l = tid;
+        asm volatile("" : "+v"(tid_l));
+        const int wv = tid_l >> 6, ln = tid_l & 63;
+        const int grp = ln >= 2 * N ? 2 : (ln >= N ? 1 : 0);       // lane group inside the wave: 0 owner, 1 / 2 helpers (waves 2, 3 only)
+        const bool owner = ln < N;                                  // (full EXEC mask: other lanes redo a stage and do not store)
+        const bool rowlane = wv >= 2 && ln < 3 * N;                 // an obstacle-row lane
+        const int k = ln < 3 * N ? ln - grp * N : N - 1;
+        double z[NV];
+#pragma unroll
+        for (int i = 0; i < NV; i++) z[i] = L.z[k * NV + i];
+        const double *p = params + (size_t)k * d.npar;
+        const long long own_delta = params_own ? (long long)(params_own - params) : 0;
+        const int nh = L.nh;
+        double W[NV][NV], g[NV], BA[NX * NV], xn[NX];
+        auto lamh = [&](int r) { return L.lamh[k * nh + r]; };
+        const bool writes = wv >= 2 ? rowlane : owner;
+        auto sink = [&](int r, const RowOut &ro) {
+            if (writes) {
+                const double sg = (r < d.n_up) ? -1.0 : 1.0;     // fast layouts keep the SIGNED row Jacobian (ipm_fast reads it as it is)
+                double *Dr = L.D + k * L.dstride + 3 * r;
+                Dr[0] = sg * ro.gx; Dr[1] = sg * ro.gy; Dr[2] = sg * ro.gp;
+                const double bound = (r < d.n_up || cm_gaussian_rows(CM)) ? 0.0 : 1.0;
+                L.beta[k * nh + r] = bound - ro.h;
+            }
+        };
+        // exchange region: [0, N 28): wave 0's share of W (as in the two-wave kernels); [N 28, N 28 + 6 N 6): the obstacle lanes' shares (x, y, psi block)
+        double *W0s = L.scan + k * NP28;
+        double *Wes = L.scan + N * NP28;
+        if (wv == 0) {                                           // dynamics
+            stage_linearise<CM>(d, z, p, 1, L.pi[(k + 1) * NX + 0], L.pi[(k + 1) * NX + 1], lamh, sink, W, g, BA, xn, slack, nullptr, own_delta, 3);
+            if (owner) {
+#pragma unroll
+                for (int i = 0; i < NX * NV; i++) L.BA[k * NX * NV + i] = BA[i];
+                double *d8 = L.dyn8 + k * 8;
+                d8[D8_XA] = BA[0 * NV + ZA]; d8[D8_XW] = BA[0 * NV + ZW]; d8[D8_XP] = BA[0 * NV + ZPSI]; d8[D8_XV] = BA[0 * NV + ZV];
+                d8[D8_YA] = BA[1 * NV + ZA]; d8[D8_YW] = BA[1 * NV + ZW]; d8[D8_YP] = BA[1 * NV + ZPSI]; d8[D8_YV] = BA[1 * NV + ZV];
+#pragma unroll
+                for (int i = 0; i < NX; i++) L.b[k * NX + i] = xn[i] - L.z[(k + 1) * NV + NU + i];
+#pragma unroll
+                for (int i = 0; i < NV; i++)
+#pragma unroll
+                    for (int j = 0; j <= i; j++) W0s[pidx(i, j)] = W[i][j];
+            }
+        } else if (wv == 1) {                                    // cost, halfspace and scenario / decomp rows
+            stage_linearise<CM>(d, z, p, 1, 0.0, 0.0, lamh, sink, W, g, BA, xn, slack, nullptr, own_delta, 4);
+            if (owner) {
+#pragma unroll
+                for (int i = 0; i < NV; i++) L.g[k * NV + i] = g[i];
+#pragma unroll
+                for (int i = 0; i < NV; i++)
+#pragma unroll
+                    for (int j = 0; j <= i; j++) L.W[k * NP28 + pidx(i, j)] = W[i][j];
+            }
+        } else {                                                 // obstacle rows: lane (wave, group) takes rows first, first + 6, ...
+            const int first_ = (wv - 2) * 3 + grp;
+            stage_linearise<CM>(d, z, p, 1, 0.0, 0.0, lamh, sink, W, g, BA, xn, slack, nullptr, own_delta, 5, [&]() { return first_; }, 6, true);
+            if (rowlane) {
+                double *x = Wes + (first_ * N + k) * 6;
+                x[0] = W[ZX][ZX]; x[1] = W[ZX][ZY]; x[2] = W[ZY][ZY]; x[3] = W[ZX][ZPSI]; x[4] = W[ZY][ZPSI]; x[5] = W[ZPSI][ZPSI];
+            }
+        }
+        __syncthreads();                                         // every share of W is in LDS
+        if (wv >= 2) { __syncthreads(); return; }               // (the obstacle waves are done: they only attend the barrier below)
+        {
+            double w0[NP28], w1[NP28];
+#pragma unroll
+            for (int e = 0; e < NP28; e++) { w0[e] = W0s[e]; w1[e] = L.W[k * NP28 + e]; }
+#pragma unroll
+            for (int i = 0; i < NV; i++)
+#pragma unroll
+                for (int j = 0; j <= i; j++) { W[i][j] = w0[pidx(i, j)] + w1[pidx(i, j)]; W[j][i] = W[i][j]; }
+            double e6[6];
+#pragma unroll
+            for (int q = 0; q < 6; q++) e6[q] = 0.0;
+#pragma unroll
+            for (int s6 = 0; s6 < 6; s6++) {
+                const double *x = Wes + (s6 * N + k) * 6;
+#pragma unroll
+                for (int q = 0; q < 6; q++) e6[q] += x[q];
+            }
+            W[ZX][ZX] += e6[0]; W[ZY][ZY] += e6[2]; W[ZPSI][ZPSI] += e6[5];
+            W[ZX][ZY] += e6[1]; W[ZY][ZX] += e6[1];
+            W[ZX][ZPSI] += e6[3]; W[ZPSI][ZX] += e6[3];
+            W[ZY][ZPSI] += e6[4]; W[ZPSI][ZY] += e6[4];
+        }
+        __syncthreads();                                         // ... and read by both waves: the W slot may be overwritten
+        constexpr int IA[4] = {ZA, ZW, ZPSI, ZV}, IB[3] = {ZX, ZY, ZS};
+        bool coupled = false;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) coupled |= (W[IA[i]][IB[j]] != 0.0) | (W[IB[j]][IA[i]] != 0.0);
+        if (wv == 0) {
+            if (coupled) {
+                mirror_n<NV>(W, d.reg_eps);
+                if (owner) {
+#pragma unroll
+                    for (int i = 0; i < NV; i++)
+#pragma unroll
+                        for (int j = 0; j <= i; j++) L.W[k * NP28 + pidx(i, j)] = W[i][j];
+                }
+            } else {
+                double Ba[4][4];
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) Ba[i][j] = W[IA[i]][IA[j]];
+                mirror_n<4>(Ba, d.reg_eps);
+                if (owner) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+#pragma unroll
+                        for (int j = 0; j < 4; j++) if (IA[i] >= IA[j]) L.W[k * NP28 + pidx(IA[i], IA[j])] = Ba[i][j];
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+#pragma unroll
+                        for (int j = 0; j < 3; j++) L.W[k * NP28 + sidx(IA[i], IB[j])] = 0.0;      // (the cross entries: exactly zero here)
+                }
+            }
+            if (tid_l == N) {                                // terminal node: zero cost, no rows: MIRROR(0) = eps I on the state block
+                const int wN = N * NP28, gN = N * NV;
+                for (int e = 0; e < NP28; e++) L.W[wN + e] = 0.0;
+                for (int i = NU; i < NV; i++) L.W[wN + pidx(i, i)] = d.reg_eps;
+                for (int i = 0; i < NV; i++) L.g[gN + i] = 0.0;
+            }
+        } else if (!coupled) {
+            double Bb[3][3];
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int j = 0; j < 3; j++) Bb[i][j] = W[IB[i]][IB[j]];
+            mirror_n<3>(Bb, d.reg_eps);
+            if (owner) {
+#pragma unroll
+                for (int i = 0; i < 3; i++)
+#pragma unroll
+                    for (int j = 0; j < 3; j++) if (IB[i] >= IB[j]) L.W[k * NP28 + pidx(IB[i], IB[j])] = Bb[i][j];
+            }
+        }
+        return;
+    }
     if constexpr (FAST && NTH == 128) {                  // (both layouts: the compact one differs in where the blocks go, not in the arithmetic)
         int tid_l = tid;
         asm volatile("" : "+v"(tid_l));

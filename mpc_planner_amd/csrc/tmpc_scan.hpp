@@ -257,7 +257,9 @@ __device__ __forceinline__ bool stage_phase(const ViewT<SL> &V, int lane)
 }
 
 // ---- factor: one level of cyclic reduction (stride s); CPL columns of [Lc Rc] per lane ----
-template <int CPL, int SL>
+// MW (four-wave kernels, level 0): the lanes of the level span several waves -- `lane` is the thread index in the workgroup, every wave of the
+// workgroup calls (lanes beyond the level's blocks are inactive) and the two fences are workgroup barriers.
+template <int CPL, int SL, bool MW = false>
 __device__ __forceinline__ bool cr_level(const ViewT<SL> &V, int lane, int s)
 {
     constexpr int LPB = (10 + CPL - 1) / CPL;                // lanes per eliminated block (CPL = 3: 4 lanes, column slots 10 and 11 idle)
@@ -310,8 +312,33 @@ __device__ __forceinline__ bool cr_level(const ViewT<SL> &V, int lane, int s)
 #pragma unroll
                 for (int i = 0; i < SNX; i++) { a[t][i] = fma(lc[i][r], w[t][r], a[t][i]); b[t][i] = fma(rc[i][r], w[t][r], b[t][i]); }
     }
-    fence();                                                 // every read of the old couplings is done
+    if constexpr (MW) __syncthreads(); else fence();         // every read of the old couplings is done
     SCAN_T(12);
+    if constexpr (MW) {
+        // several waves: a diagonal block receives one update from its right neighbour's elimination (-Lc^T D^-1 Lc, columns cid < 5) and one from its left
+        // neighbour's (-Rc^T D^-1 Rc, cid >= 5), possibly from lanes of different waves -- the two kinds are separated by a barrier, so that every entry sees
+        // its two additions in a fixed order (one wave: program order does that)
+        static_assert(!MW || CPL == 1, "multi-wave level: one column per lane");
+        const int cid = q, c = cid < 5 ? cid : cid - 5;
+        if (act) {
+#pragma unroll
+            for (int i = 0; i < SNX; i++) bo[(cid < 5 ? OL : ORR) + c * 5 + i] = w[0][i];            // W = D^-1 [Lc Rc]
+            if (cid < 5) {
+#pragma unroll
+                for (int i = 0; i < SNX; i++) add_lds(&blk[el * BS + OD + c * 5 + i], -a[0][i]);
+            }
+        }
+        __syncthreads();
+        if (act && cid >= 5 && has_r) {
+#pragma unroll
+            for (int i = 0; i < SNX; i++) {
+                blk[er * BS + OL + i * 5 + c] = -a[0][i];
+                add_lds(&blk[er * BS + OD + c * 5 + i], -b[0][i]);
+            }
+        }
+        __syncthreads();
+        return bad;
+    }
     if (act) {
 #pragma unroll
         for (int t = 0; t < CPL; t++) {
@@ -331,7 +358,7 @@ __device__ __forceinline__ bool cr_level(const ViewT<SL> &V, int lane, int s)
             }
         }
     }
-    fence();
+    if constexpr (MW) __syncthreads(); else fence();
     SCAN_T(13);
     return bad;
 }
@@ -383,6 +410,117 @@ __device__ __forceinline__ bool factor(const ViewT<SL> &V, int lane)
     bool bad = stage_phase(V, lane);
     bad |= reduce(V, lane);
     return __any(bad);
+}
+
+// ---- four waves per trajectory (round 6, the control-tick kernel): the factorisation's wide phases on 256 lanes --------------------------------
+// Stage phase: ONE column of P_k [F_k^T E^T g_k] per lane instead of four -- wave w holds the stages 5 w .. 5 w + 4 at 11 lanes each (55 lanes); node
+// 20 (N = 20 only: it has no F, six columns) sits on the spare lanes 55 .. 60 of wave 3.  Every lane still factorises its stage's H_k (the lanes of
+// a wave issue together: redundant lanes cost nothing) but solves and applies F for one column: 56 + 17 instructions where the one-wave phase has
+// 224 + 68.  The columns land where the one-wave phase puts them (Z per (stage, column), chol(H_k), P g, the blocks), so reduce() levels >= 1 and
+// solve() run unchanged on one wave.  Every block entry is STORED by exactly one lane and then ADDED to by exactly one lane, with a workgroup
+// barrier in between: the result does not depend on how the waves interleave.
+template <int SL>
+__device__ __forceinline__ bool stage_phase4(const ViewT<SL> &V, int tid)
+{
+    constexpr int CL = Cfg<SL>::CL, ZL = Cfg<SL>::ZL;
+    const int N = V.N;
+    double *blk = V.blk;
+    if (tid < 25) V.zeros()[tid] = 0.0;
+    const int wv = tid >> 6, l = tid & 63;
+    const bool reg = l < 55;
+    const int k = reg ? 5 * wv + l / 11 : 20;
+    const int cid = reg ? l % 11 : 5 + (l - 55);
+    const bool live = reg ? k <= N : (wv == 3 && l < 61 && N == 20);
+    const int kc = live ? k : 0;
+    bool bad = false;
+    double z[1][SNV], o[SNX];
+    {
+        double L[28];
+        const double *Hk = V.Hh + kc * 28;
+#pragma unroll
+        for (int i = 0; i < SNV; i++)
+#pragma unroll
+            for (int j = 0; j <= i; j++) L[tri(i, j)] = h_entry(Hk, kc, N, i, j);
+        BaRow F;
+        ba_load(V.BA + (kc < N ? kc : 0) * SNX * SNV, F, kc < N);
+        double gk[SNV];
+#pragma unroll
+        for (int i = 0; i < SNV; i++) gk[i] = V.gh[kc * SNV + i];
+        loads_done();
+        bad = chol_inlane<SNV>(L) && live;
+        if (live && cid == (reg ? 0 : 5)) {                          // one lane per stage keeps chol(H_k)
+#pragma unroll
+            for (int e = 0; e < 28; e++) V.Ls()[kc * LS + e] = L[e];
+        }
+        double fc[SNV];
+        ba_column(F, cid < 5 ? cid : 0, fc);
+#pragma unroll
+        for (int i = 0; i < SNV; i++) {
+            const double e = (i == cid - 5 + SNU) ? 1.0 : 0.0;
+            z[0][i] = cid < 5 ? fc[i] : (cid == 10 ? (g_live(kc, N, i) ? gk[i] : 0.0) : e);
+        }
+        chol_solve<SNV, 1>(L, z);
+        ba_apply(F, z[0], o);
+    }
+    if (live) {
+        double *Zl = V.Zs() + (SL * kc + cid / CL) * ZL + (cid % CL) * SNV;      // (the one-wave phase's layout: lane 3 k + s holds its CL columns)
+#pragma unroll
+        for (int i = 0; i < SNV; i++) Zl[i] = z[0][i];
+        if (cid == 10) {
+#pragma unroll
+            for (int i = 0; i < SNV; i++) V.zg()[kc * SNV + i] = z[0][i];
+        }
+        if (cid < 5 && kc < N) {                                              // D_k = F P F^T: stored, every column of every block exactly once
+#pragma unroll
+            for (int i = 0; i < SNX; i++) blk[kc * BS + OD + cid * 5 + i] = o[i];
+        }
+        if (!reg && cid < 10) {                                               // node 20 on the spare lanes: its columns 0 .. 4 (F^T, no F there) are zero --
+            double *Z0 = V.Zs() + (SL * kc + (cid - 5) / CL) * ZL + ((cid - 5) % CL) * SNV;      // stored, because solve() multiplies them (by zero)
+#pragma unroll
+            for (int i = 0; i < SNV; i++) Z0[i] = 0.0;
+        }
+    }
+    __syncthreads();
+    if (live && cid >= 5 && cid < 10 && kc >= 1) {                            // ... + E P_{k+1} E^T (added), and the couplings Y_{k,k-1} = -F_k P_k E^T
+        const int c = cid - 5;
+#pragma unroll
+        for (int i = 0; i < SNX; i++) add_lds(&blk[(kc - 1) * BS + OD + c * 5 + i], z[0][SNU + i]);
+        if (kc < N) {
+#pragma unroll
+            for (int i = 0; i < SNX; i++) blk[kc * BS + OL + c * 5 + i] = -o[i];
+        }
+    }
+    __syncthreads();
+    return bad;
+}
+
+// Four-wave factorisation.  `flag`: four doubles of LDS for the waves' pivot flags.  Level 0 of the cyclic reduction eliminates ten blocks with ten
+// coupling columns each: one column per lane on 100 lanes (waves 0 and 1) instead of two per lane on 50; the later levels fit one wave and run there
+// while the others wait.  Returns true (workgroup-uniform) on a non-positive pivot anywhere.  N <= 20.
+template <int SL>
+__device__ __forceinline__ bool factor4(const ViewT<SL> &V, int tid, double *flag)
+{
+    const int N = V.N;
+    bool bad = stage_phase4(V, tid);
+    bad |= cr_level<1, SL, true>(V, tid, 1);
+    if (tid < 64) {
+#pragma unroll 1
+        for (int s = 2; s < N; s *= 2) bad |= cr_level<1>(V, tid, s);
+        if (tid == 0) {                                          // what is left: block 0
+            double L[15];
+#pragma unroll
+            for (int i = 0; i < SNX; i++)
+#pragma unroll
+                for (int j = 0; j <= i; j++) L[tri(i, j)] = V.blk[OD + j * 5 + i];
+            bad |= chol_inlane<SNX>(L);
+#pragma unroll
+            for (int e = 0; e < 15; e++) V.blk[OLD + e] = L[e];
+        }
+    }
+    const bool wbad = __any(bad);
+    if ((tid & 63) == 0) flag[tid >> 6] = wbad ? 1.0 : 0.0;
+    __syncthreads();
+    return (flag[0] != 0.0) | (flag[1] != 0.0) | (flag[2] != 0.0) | (flag[3] != 0.0);
 }
 
 // Solve with the factor of the last factor(): V.dv, V.dpi.  pred: the right-hand side is the one factor() saw (its P_k g_k is in

@@ -732,6 +732,8 @@ TMPC_HD void stage_linearise(const Dims &d, const double *z, const double *p, in
     // rows (W = their share, g; BA, xn untouched).  The two-wave kernels run 1 and 2 on different waves at the same time and add the two W
     // (linearise, tmpc_solve.hip).  Measured shares of a stage's 46 k cycles (cfg 2): dynamics 5.5 k, eight ellipsoid rows 10.2 k, cost and
     // halfspace rows 8.3 k -- and 22.3 k for MIRROR, which needs the complete W and stays on one wave.
+    // Round 6, the four-wave kernels: 3 = dynamics alone; 4 = cost, topology and scenario / decomp rows (no obstacle rows); 5 = obstacle rows alone
+    // (this lane's share of them: ell_first / ell_step; call with rows_only).
     // own_delta (doubles, wave-uniform): distance from `p` to the trajectory's OWN parameter row when `p` is a row it shares with others
     // (tmpc_set_param_sharing): the topology and scenario halfspaces (ip_lin / ip_slk) are read from p + own_delta, everything else
     // from p.  A delta, not a second pointer: the second address then lives only across the halfspace loads (the linearisation is the
@@ -753,7 +755,7 @@ TMPC_HD void stage_linearise(const Dims &d, const double *z, const double *p, in
 #pragma unroll
         for (int j = 0; j < NV; j++) W[i][j] = 0.0;
 #ifndef TMPC_GENERATED_STAGE
-    if (part != 2)
+    if (part != 2 && part != 4 && part != 5)
 #endif
     {
         DynOut dy;
@@ -787,7 +789,8 @@ TMPC_HD void stage_linearise(const Dims &d, const double *z, const double *p, in
     });
 #else
     RowOut ro;
-    if (part != 1) {
+    if (part == 3) return;
+    if (part != 1 && part != 5) {
         if constexpr (cm_curvature_aware(CM)) {
             CostOutCA co;
             cost_eval_ca(d, z, p, pstride, co, true, slack);
@@ -811,14 +814,14 @@ TMPC_HD void stage_linearise(const Dims &d, const double *z, const double *p, in
     const double r_disc = d.M > 0 ? TMPC_LDP(p + (size_t)ip_disc_radius(d) * pstride) : 0.0, off = TMPC_LDP(p + (size_t)ip_disc_offset(d) * pstride);
     double spsi, cpsi;
     sincos(z[ZPSI], &spsi, &cpsi);
-    if (part != 1) {
-        for (int j = ell_first(); j < d.n_slk; j += ell_step) {
+    if (part != 1 && part != 5) {
+        for (int j = (part == 4 ? 0 : ell_first()); j < d.n_slk; j += (part == 4 ? 1 : ell_step)) {
             slk_row_eval(d, z, p + own_delta, pstride, j, off, spsi, cpsi, slack, ro);
             W[ZPSI][ZPSI] += lamh(d.n_lin + j) * ro.Hpp;          // the row is linear in (x, y); psi enters through the disc offset
             sink(d.n_lin + j, ro);
         }
     }
-    {
+    if (part != 4) {
         // the two parts share the ellipsoid rows (part 1 the first half, next to the dynamics)
         const int j0 = part == 2 ? d.M / 2 : 0, j1 = part == 1 ? d.M / 2 : d.M;
         double risk_of = -1.0, ye = 0.0;                      // (Gaussian rows) the quantile of the last risk level seen: one level per configuration

@@ -236,8 +236,9 @@ class BatchedSolver:
             self._check(self.lib.tmpc_synchronize(self._h), "tmpc_synchronize")
 
     def set_latency_mode(self, on=True):
-        """Kernel variant for small control ticks: True / 1 = two waves per trajectory, 2 = one wave per trajectory with the Newton systems
-        solved parallel in time (csrc/tmpc_scan.hpp), False / 0 = the throughput kernels; returns False if the shape has no such variant."""
+        """Kernel variant for small control ticks: True / 1 = two waves per trajectory, 2 = the Newton systems solved parallel in time
+        (csrc/tmpc_scan.hpp), 3 = four waves per trajectory (round 6: the parallel-in-time solve with its wide phases, the stage evaluation and the
+        row passes on 256 lanes; N <= 20), False / 0 = the throughput kernels; returns False if the shape has no such variant."""
         rc = self.lib.tmpc_set_latency_mode(self._h, int(on))
         if rc < 0:
             self._check(rc, "tmpc_set_latency_mode")

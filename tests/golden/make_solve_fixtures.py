@@ -2,7 +2,8 @@
 [UPSTREAM] assumptions U1-U9 of DESIGN.md can be closed by anyone with an acados installation (tools/acados_replay.py replays
 the inputs through the reference's own generated solver and compares).  Per trajectory:
   inputs   xinit [nx], x0 [(N+1) nvar] (AcadosParameters::x0 layout), params [N npar] (all_parameters layout)
-  outputs  oracle at the reference's qp_tol = 1e-5, oracle at qp_tol = 1e-9, and the independent active-set RTI
+  outputs  oracle at the reference's qp_tol = 1e-5, oracle at qp_tol = 1e-8 (the tightest tolerance above the float64 noise floor of the
+           interior-point method on these QPs: profiles/round6_tight_tolerance_study.json) and 1e-9, and the independent active-set RTI
            (tests/independent_rti.py): xtraj, utraj, pobj, exit codes / iteration counts
 Run from the repository root:  python tests/golden/make_solve_fixtures.py"""
 import json
@@ -34,7 +35,7 @@ CASES = {
 out = {"about": __doc__, "layout": "xinit [nx]; x0 [(N+1)*nvar] = [u_k; x_k] per node; params [N*npar] row k = stage k "
        "(acados_solver_interface.h:53-56); nvar = 7 (a, w | x, y, psi, v, spline) or 8 with the slack state last", "cases": []}
 for name, (skw, pkw, picks, what) in CASES.items():
-    pb = O.problem(**pkw); tight = O.problem(qp_tol=1e-9, **pkw)
+    pb = O.problem(**pkw); tight = O.problem(qp_tol=1e-9, **pkw); tight8 = O.problem(qp_tol=1e-8, **pkw)
     for scene, b in picks:
         for scene in range(scene, scene + 40):            # first scene from the nominal one whose pick is a full-length success
             sc = scenes.make_scene(scene, **skw)
@@ -43,6 +44,9 @@ for name, (skw, pkw, picks, what) in CASES.items():
             if io.exit_code == 1 and io.sqp_iter == pb.n_sqp:
                 break
         xt, ut, it_ = O.solve(tight, xi, x0, pa)
+        x8, u8, i8 = O.solve(tight8, xi, x0, pa)
+        print(name, scene, b, "1e-8:", i8.exit_code, i8.sqp_iter, "1e-9:", it_.exit_code, it_.sqp_iter, "max |x(1e-8) - x(1e-9)|", np.abs(x8 - xt).max())
+        assert i8.exit_code == 1 and i8.sqp_iter == pb.n_sqp and np.abs(x8 - xt).max() < 1e-5
         assert io.exit_code == 1 and io.sqp_iter == pb.n_sqp, (name, scene, b, io.exit_code, io.sqp_iter)
         xa, ua, pobj_a, _ = I.rti_solve(pb, xi, x0, pa)
         assert np.abs(xa - xt).max() < 1e-6
@@ -52,6 +56,8 @@ for name, (skw, pkw, picks, what) in CASES.items():
             xinit=xi.tolist(), x0=x0.ravel().tolist(), params=pa.ravel().tolist(),
             oracle_qp_tol_1e_5=dict(xtraj=xo.ravel().tolist(), utraj=uo.ravel().tolist(), pobj=io.pobj, exit_code=io.exit_code,
                                     sqp_iter=io.sqp_iter, qp_iter_total=io.qp_iter_total, res_eq=io.res_eq),
+            oracle_qp_tol_1e_8=dict(xtraj=x8.ravel().tolist(), utraj=u8.ravel().tolist(), pobj=i8.pobj, exit_code=i8.exit_code, sqp_iter=i8.sqp_iter,
+                                    qp_iter_total=i8.qp_iter_total),
             oracle_qp_tol_1e_9=dict(xtraj=xt.ravel().tolist(), utraj=ut.ravel().tolist(), pobj=it_.pobj),
             active_set_rti=dict(xtraj=xa.ravel().tolist(), utraj=ua.ravel().tolist(), pobj=float(pobj_a))))
 with open(os.path.join(HERE, "solve_fixtures.json"), "w") as fh:

@@ -71,6 +71,36 @@ def test_invalid_dims_rejected():
         assert lib.tmpc_create(C.byref(h), C.byref(d), 4, 0) == -1 and not h
 
 
+def test_create_v2_accepts_only_revision_boundaries():
+    """Round-5 advisor: a dims_size that ends inside a field copied part of that field, and a longer struct from a newer header was truncated
+    silently.  Sizes are validated before a device is looked for: -1 (TMPC_ERR_INVALID) for anything that is not a revision boundary of
+    tmpc_dims, or a longer struct with a non-zero tail; the accepted sizes get as far as the device query (no GPU here: -2 / -3, not -1)."""
+    from mpc_planner_amd import solver
+    lib = solver.load_library()
+    d = solver.default_dims()
+    rev = [solver.TmpcDims.cost_model.offset, solver.TmpcDims.riccati_form.offset, C.sizeof(d)]
+    h = C.c_void_p()
+    for size in rev:
+        assert lib.tmpc_create_v2(C.byref(h), C.byref(d), size, 4, 0) != -1 or _has_gpu() is None, size
+    for size in (rev[0] - 4, rev[0] + 4, rev[1] + 2, rev[2] - 1, 0, 5000):
+        assert lib.tmpc_create_v2(C.byref(h), C.byref(d), size, 4, 0) == -1 and not h, size
+    # a newer, longer header: accepted only with a zero tail
+    raw = (C.c_char * (C.sizeof(d) + 16)).from_buffer_copy(bytes(d) + b"\0" * 16)
+    assert lib.tmpc_create_v2(C.byref(h), C.cast(raw, C.POINTER(solver.TmpcDims)), C.sizeof(d) + 16, 4, 0) != -1 or _has_gpu() is None
+    if h:
+        lib.tmpc_destroy(h); h = C.c_void_p()
+    raw[C.sizeof(d) + 3] = b"\x01"
+    assert lib.tmpc_create_v2(C.byref(h), C.cast(raw, C.POINTER(solver.TmpcDims)), C.sizeof(d) + 16, 4, 0) == -1 and not h
+    # the Riccati form is validated like the other model fields
+    d2 = solver.default_dims(riccati_form=2)
+    assert lib.tmpc_create(C.byref(h), C.byref(d2), 4, 0) == -1 and not h
+
+
+def _has_gpu():
+    import torch
+    return torch.cuda.is_available()
+
+
 def test_product_never_imports_oracle():
     for dirpath, _, files in os.walk(os.path.join(ROOT, "mpc_planner_amd")):
         for f in files:

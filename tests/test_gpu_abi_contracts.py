@@ -67,6 +67,10 @@ def test_create_v2_accepts_the_shorter_struct_of_an_older_header():
     lib.tmpc_destroy(h)
     h = C.c_void_p()
     assert lib.tmpc_create_v2(C.byref(h), C.byref(d), old_size - 4, 4, 0) == -1 and not h      # shorter than any revision of the header
+    assert lib.tmpc_create_v2(C.byref(h), C.byref(d), old_size + 4, 4, 0) == -1 and not h      # ends inside a field (round-5 advisor): refused, not half-copied
+    r5_size = solver.TmpcDims.riccati_form.offset                                               # the round 4-5 header: + cost_model, row_model
+    assert lib.tmpc_create_v2(C.byref(h), C.byref(d), r5_size, 4, 0) == 0
+    lib.tmpc_destroy(h); h = C.c_void_p()
     assert lib.tmpc_create_v2(C.byref(h), C.byref(d), C.sizeof(d), 4, 0) == 0
     lib.tmpc_destroy(h)
 

@@ -3,7 +3,7 @@
 has what this build machine lacks: acados + acados_template + casadi, and a checkout of tud-amr/mpc_planner).
 
     export ACADOS_SOURCE_DIR=...; export LD_LIBRARY_PATH=$ACADOS_SOURCE_DIR/lib
-    python tools/acados_replay.py /path/to/mpc_planner [--qp-tol 1e-9] [cfg2 cfg1 ...]
+    python tools/acados_replay.py /path/to/mpc_planner [--qp-tol 1e-8] [cfg2 cfg1 ...]
 
 For every fixture of the requested configurations it builds the reference's module stack with the reference's own scripts
 (mpc_planner_jackalsimulator/scripts/generate_jackalsimulator_solver.py: configuration_basic / configuration_tmpc /
@@ -12,14 +12,20 @@ solver_generator/generate_acados_solver.py:generate_acados_solver does, and then
 mpc_planner_solver/src/acados_solver_interface.cpp does:
     lbx_0 = ubx_0 = xinit (:124-125); p_k = all_parameters[k] (k = N reuses row N-1, :127-135); x/u warm start (:274-284);
     rti_phase 0; n_sqp x solve() with the loop exit on qp_status != 0 (:99-117); cost via get_cost(); x, u out (:171-174).
-It prints, per fixture, max relative per-stage differences to the three stored outputs (oracle at qp_tol 1e-5 / 1e-9 and the
+It prints, per fixture, max relative per-stage differences to the stored outputs (oracle at qp_tol 1e-5 / 1e-8 / 1e-9 and the
 active-set RTI).  Expected if U1-U9 hold: differences of the order the stored outputs have among themselves (<= ~1e-3 at
 qp_tol 1e-5, see tests/test_independent_rti.py); a structural disagreement (terminal cost, h at node 0, bounds at node N,
 stage-cost scaling) shows up as 1e-2 or more and names the assumption to fix.
 It ends with a PASS / FAIL table at the tolerance that is certifiable for the chosen QP tolerance (round-3 verdict item 5):
-    --qp-tol 1e-9   (overrides the generator's qp_tol = 1e-5: the iterate no longer depends on how the QP solver reaches its tolerance)
-                    PASS <=> max relative per-stage difference to `oracle_qp_tol_1e_9` and `active_set_rti` <= 1e-5 -- the north star's 1e-4 with a
-                    decade of margin; what this repository observes between its own two independent implementations there is 2e-7;
+    --qp-tol 1e-8   (overrides the generator's qp_tol = 1e-5: the iterate no longer depends on how the QP solver reaches its tolerance)
+                    PASS <=> max relative per-stage difference to `oracle_qp_tol_1e_8` and `active_set_rti` <= 1e-5 -- the north star's 1e-4 with a
+                    decade of margin; what this repository observes between its own independent implementations there is <= 2e-6.
+                    USE 1e-8, NOT 1e-9 (round 6, profiles/round6_tight_tolerance_study.json): at 1e-9 a float64 interior-point method is below the
+                    noise floor of its own stationarity residual on these QPs -- two correct implementations then disagree on iteration counts in
+                    0.6 % (cfg 2) to 13 % (cfg 3) of the solves and 0.5 - 13 % of the solves break down, whatever the Riccati form; at 1e-8 this
+                    repository's two implementations agree on every integer in 2042 of 2042 cfg 2 solves.  (--qp-tol 1e-9 is still accepted and
+                    compares with `oracle_qp_tol_1e_9`.)  The Riccati form HPIPM runs (square_root_alg = 1 in its default mode) is available on
+                    the device as tmpc_dims.riccati_form = 1 and is the oracle's default; at 1e-8 the two forms give the same iterates.
     default 1e-5    PASS <=> difference to `oracle_qp_tol_1e_5` <= 2e-3: the spread that correct implementations of the reference's configuration
                     show among themselves at that tolerance (profiles/round4_c_iterate_spread.json: 1e-4 .. 1e-3 on a few per cent of the
                     trajectories); a pass here says "no structural disagreement (U1-U9)", not "1e-4".
@@ -113,17 +119,18 @@ def main():
         N, nx = c["N"], c["nx"]
         line = [f"{c['config']} scene {c['scene']} trajectory {c['trajectory']}: acados status {status}, cost {cost:.9g}"]
         diff = {}
-        for key in ("oracle_qp_tol_1e_5", "oracle_qp_tol_1e_9", "active_set_rti"):
+        for key in ("oracle_qp_tol_1e_5", "oracle_qp_tol_1e_8", "oracle_qp_tol_1e_9", "active_set_rti"):
             xr = np.array(c[key]["xtraj"]).reshape(N + 1, nx); ur = np.array(c[key]["utraj"]).reshape(N, 2)
             sx = np.maximum(np.abs(xr).max(axis=1, keepdims=True), 1.0); su = np.maximum(np.abs(ur).max(axis=1, keepdims=True), 1.0)
             diff[key] = max(float((np.abs(xt - xr) / sx).max()), float((np.abs(ut - ur) / su).max()))
             line.append(f"{key}: x {(np.abs(xt - xr) / sx).max():.2e} u {(np.abs(ut - ur) / su).max():.2e} "
                         f"cost {abs(cost - c[key]['pobj']) / max(1.0, abs(c[key]['pobj'])):.2e}")
         print(" | ".join(line))
-        worst = max(diff["oracle_qp_tol_1e_9"], diff["active_set_rti"]) if tight else diff["oracle_qp_tol_1e_5"]
+        tight_key = "oracle_qp_tol_1e_9" if (QP_TOL is not None and QP_TOL < 5e-9) else "oracle_qp_tol_1e_8"
+        worst = max(diff[tight_key], diff["active_set_rti"]) if tight else diff["oracle_qp_tol_1e_5"]
         table.append((f"{c['config']} scene {c['scene']} trajectory {c['trajectory']}", worst, worst <= (1e-5 if tight else 2e-3)))
     tol = 1e-5 if tight else 2e-3
-    print(f"\n{'fixture':<40} {'max rel. per stage':>20}   verdict at {tol:g} ({'acados qp_tol ' + str(QP_TOL) + ': vs oracle 1e-9 and the active-set RTI' if tight else 'acados qp_tol 1e-5: vs oracle 1e-5'})")
+    print(f"\n{'fixture':<40} {'max rel. per stage':>20}   verdict at {tol:g} ({'acados qp_tol ' + str(QP_TOL) + ': vs the oracle at the same tolerance and the active-set RTI' if tight else 'acados qp_tol 1e-5: vs oracle 1e-5'})")
     for name, w, ok in table:
         print(f"{name:<40} {w:>20.3e}   {'PASS' if ok else 'FAIL'}")
     n_fail = sum(not ok for _, _, ok in table)

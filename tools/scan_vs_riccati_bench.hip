@@ -84,6 +84,68 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         for (int i = 0; i < PH_COUNT; i++) cycles[(size_t)blockIdx.x * PH_COUNT + i] = acc[i];
 }
 
+// -DSCAN_QUAD (round 6): the four-wave factorisation of the tick kernel (latency mode 3: tmpc_scan.hpp stage_phase4 / factor4) on the same systems,
+// 256 threads per system, phases timed on wave 0: stage phase | level 0 of the cyclic reduction on two waves | the later levels on wave 0.
+#ifdef SCAN_QUAD
+enum { Q_STAGE = 0, Q_CR0, Q_CR, Q_SOLVE1, Q_SOLVE2, Q_COUNT };
+__global__ __launch_bounds__(256) void scan_kernel4(const System *__restrict__ sys, int n_sys, double *__restrict__ dz_out, long long *__restrict__ cycles, int reps)
+{
+    __shared__ __attribute__((aligned(16))) double smem[LDS_DOUBLES + 8];
+    double *Hh = smem, *BA = Hh + NS * 28, *gh = BA + N * 35, *rb = gh + 2 * NS * 7, *dv = rb + N * 5, *dpi = dv + NS * 7, *scr = dpi + NS * 5;
+    double *flag = smem + LDS_DOUBLES;
+    const int tid = threadIdx.x;
+    const System &P = sys[blockIdx.x % n_sys];
+    for (int e = tid; e < NS * 28; e += 256) {
+        const int k = e / 28, r = e - k * 28;
+        int i = 0; while ((i + 1) * (i + 2) / 2 <= r) i++;
+        Hh[e] = P.H[k][i * 7 + (r - i * (i + 1) / 2)];
+    }
+    for (int e = tid; e < N * 35; e += 256) BA[e] = P.BA[0][e];
+    for (int e = tid; e < 2 * NS * 7; e += 256) gh[e] = P.g[0][0][e];
+    for (int e = tid; e < N * 5; e += 256) rb[e] = P.rb[0][e];
+    __syncthreads();
+    tmpc::scan::ViewT<3> V{Hh, BA, gh, rb, dv, dpi, scr, N};
+    tmpc::scan::ViewT<3> V2 = V; V2.gh = gh + NS * 7;
+    double *out = dz_out + (size_t)blockIdx.x * 2 * NS * NV;
+    long long acc[Q_COUNT] = {0, 0, 0, 0, 0};
+    bool bad = false;
+    for (int rep = 0; rep < reps; rep++) {
+        long long t0 = clock64(), t1;
+        bad |= tmpc::scan::stage_phase4(V, tid);
+        t1 = clock64(); acc[Q_STAGE] += t1 - t0; t0 = t1;
+        bad |= tmpc::scan::cr_level<1, 3, true>(V, tid, 1);
+        t1 = clock64(); acc[Q_CR0] += t1 - t0; t0 = t1;
+        if (tid < 64) {
+            for (int s = 2; s < N; s *= 2) bad |= tmpc::scan::cr_level<1>(V, tid, s);
+            if (tid == 0) {
+                double L[15];
+                for (int i = 0; i < 5; i++) for (int j = 0; j <= i; j++) L[tmpc::scan::tri(i, j)] = V.blk[tmpc::scan::OD + j * 5 + i];
+                bad |= tmpc::scan::chol_inlane<5>(L);
+                for (int e = 0; e < 15; e++) V.blk[tmpc::scan::OLD + e] = L[e];
+            }
+        }
+        __syncthreads();
+        t1 = clock64(); acc[Q_CR] += t1 - t0; t0 = t1;
+        if (tid < 64) {
+            tmpc::scan::solve(V, tid, true);
+            for (int e = tid; e < NS * NV; e += 64) out[e] = dv[e];
+        }
+        __syncthreads();
+        t1 = clock64(); acc[Q_SOLVE1] += t1 - t0; t0 = t1;
+        if (tid < 64) {
+            tmpc::scan::solve(V2, tid, false);
+            for (int e = tid; e < NS * NV; e += 64) out[NS * NV + e] = dv[e];
+        }
+        __syncthreads();
+        t1 = clock64(); acc[Q_SOLVE2] += t1 - t0;
+    }
+    (void)flag;
+    if (__any(bad) && (tid & 63) == 0) out[0] = __builtin_nan("");
+    if (tid == 0 && cycles)
+        for (int i = 0; i < Q_COUNT; i++) cycles[(size_t)blockIdx.x * Q_COUNT + i] = acc[i];
+}
+#endif
+
 // ---------------- host ----------------
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
@@ -218,6 +280,30 @@ int main(int argc, char **argv)
         static const char *nm[14] = {"stage_zero_fill", "stage_chol7", "stage_columns", "stage_stores", "solve_rb", "solve_Pg", "solve_forward_levels", "solve_Dinv_beta", "solve_back_levels", "solve_recover", "cr_loads", "cr_chol5", "cr_solve_matvec", "cr_writes"};
         printf("{\"scan_profile_cycles\": {");
         for (int i = 0; i < 14; i++) printf("\"%s\": %.0f%s", nm[i], (double)c16[i] / B / reps / ((i >= 4 && i < 10) ? 2 : 1), i < 13 ? ", " : "}}\n");
+    }
+#endif
+#ifdef SCAN_QUAD
+    {
+        long long *d_c4; CK(hipMalloc(&d_c4, sizeof(long long) * (size_t)B * Q_COUNT));
+        scan_kernel4<<<B, 256>>>(d_sys, B, d_dz, d_c4, 2);
+        CK(hipDeviceSynchronize());
+        scan_kernel4<<<B, 256>>>(d_sys, B, d_dz, d_c4, reps);
+        CK(hipDeviceSynchronize());
+        std::vector<long long> c4((size_t)B * Q_COUNT); std::vector<double> dz4((size_t)B * 2 * NS * NV);
+        CK(hipMemcpy(c4.data(), d_c4, c4.size() * 8, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(dz4.data(), d_dz, dz4.size() * 8, hipMemcpyDeviceToHost));
+        double q[Q_COUNT] = {0, 0, 0, 0, 0}, e4 = 0, e4b = 0, e41 = 0; int bad4 = 0;
+        for (int b = 0; b < B; b++) {
+            for (int i = 0; i < Q_COUNT; i++) q[i] += (double)c4[(size_t)b * Q_COUNT + i] / reps / B;
+            const double *a4 = &dz4[(size_t)b * 2 * NS * NV], *a1 = &dz[(size_t)b * 2 * NS * NV];
+            double e = rel_err(a4, &ref[(size_t)b * NS * 7]);
+            if (!(e == e)) { bad4++; e = 1e300; }
+            e4 = fmax(e4, e); e41 = fmax(e41, rel_err(a4, a1)); e4b = fmax(e4b, rel_err(a4 + NS * NV, a1 + NS * NV));
+        }
+        printf("{\"four_wave_factorisation\": {\"cycles_per_system\": {\"stage_phase_4_waves\": %.0f, \"cr_level_0_two_waves\": %.0f, \"cr_levels_1_up_wave_0\": %.0f, \"solve_predictor_wave_0\": %.0f, "
+               "\"solve_corrector_wave_0\": %.0f, \"total\": %.0f}, \"max_rel_err_vs_reference\": %.3e, \"vs_one_wave_scan_max_rel\": %.3e, \"second_rhs_vs_one_wave_scan_max_rel\": %.3e, \"nan_systems\": %d}}\n",
+               q[0], q[1], q[2], q[3], q[4], q[0] + q[1] + q[2] + q[3] + q[4], e4, e41, e4b, bad4);
+        CK(hipFree(d_c4));
     }
 #endif
     int occ = 0; CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, scan_kernel, 64, 0));

@@ -56,24 +56,28 @@ def main():
     ap.add_argument("--sample", type=int, default=128, help="the bench's parity sample of the launch (np.linspace over the batch)")
     ap.add_argument("--more", type=int, default=1920, help="further evenly spread trajectories, for a rate")
     ap.add_argument("--qp-tol", type=float, default=1e-9)
+    ap.add_argument("--form", type=int, default=0, choices=[0, 1],
+                    help="Riccati form on BOTH sides: 0 = Schur complement (tmpc_dims.riccati_form 0, the oracle's riccati_form 1), 1 = square root (1 / 0)")
+    ap.add_argument("--workload", default="cfg2")
+    ap.add_argument("--max-cases", type=int, default=16, help="mismatching trajectories traced in detail (all are counted)")
     ap.add_argument("--out", default="")
     a = ap.parse_args()
     from mpc_planner_amd import scenes, solver
     import oracle_lib as O
     import bench
-    wl = bench.WORKLOADS["cfg2"]
-    batch = scenes.make_batch(range(0, a.scenes), workers=bench.usable_cpus(), B=wl["traj"], **wl["scene"])
+    wl = bench.WORKLOADS[a.workload]
+    batch = scenes.make_batch(range(0, a.scenes), workers=bench.usable_cpus(), B=min(wl["traj"], 64), **wl["scene"])
     B = batch["xinit"].shape[0]
     idx_bench = np.unique(np.linspace(0, B - 1, min(a.sample, B)).round().astype(int))
     idx_more = np.unique(np.linspace(0, B - 1, min(a.more, B)).round().astype(int)) if a.more > 0 else np.zeros(0, int)
     idx = np.unique(np.concatenate([idx_bench, idx_more]))
     n = len(idx)
     tol = a.qp_tol
-    dims = solver.default_dims(**wl["dims"], qp_tol=tol)
+    dims = solver.default_dims(**wl["dims"], qp_tol=tol, riccati_form=a.form)
     xi, x0, pr = batch["xinit"][idx], batch["x0"][idx], batch["params"][idx]
     s = solver.BatchedSolver(dims, B_max=n)
     s.set_batch(xi, x0, pr); s.solve(); g = s.get(); info_kernel = s.kernel_info(); s.close()
-    pb = O.problem(**wl["dims"], qp_tol=tol, riccati_form=1)
+    pb = O.problem(**wl.get("oracle_dims", wl["dims"]), qp_tol=tol, riccati_form=1 - a.form)
     xt, ut, o = O.solve_batch(pb, xi, x0.reshape(n, -1), pr.reshape(n, -1), num_threads=bench.usable_cpus())
     mism = np.where((g["exit_code"] != o["exit_code"]) | (g["sqp_iter"] != o["sqp_iter"]) | (g["qp_iter_total"] != o["qp_iter_total"]))[0]
     both = (g["exit_code"] == 1) & (o["exit_code"] == 1)
@@ -81,7 +85,7 @@ def main():
     sx = np.maximum(np.abs(xt).max(axis=2, keepdims=True), 1.0)
     rel = (np.abs(g["xtraj"] - xt) / sx).max(axis=(1, 2))
     cases = []
-    for m in mism:
+    for m in mism[:a.max_cases]:
         c = {"trajectory_in_launch": int(idx[m]), "in_bench_parity_sample": bool(idx[m] in set(idx_bench.tolist())),
              "device": {k: int(g[k][m]) for k in ("exit_code", "qp_status", "sqp_iter", "qp_iter_total")},
              "oracle": {k: int(o[k][m]) for k in ("exit_code", "qp_status", "sqp_iter", "qp_iter_total")}}
@@ -111,7 +115,7 @@ def main():
         if jstar > 0:
             base.solve_iterations(jstar, complete=True, new_solve=True)
         def count_at(t):
-            d2 = solver.default_dims(**wl["dims"], qp_tol=float(t))
+            d2 = solver.default_dims(**wl["dims"], qp_tol=float(t), riccati_form=a.form)
             h = solver.BatchedSolver(d2, B_max=1)
             h.set_batch(xi[m:m + 1], x0[m:m + 1], pr[m:m + 1])
             if jstar > 0:
@@ -121,11 +125,11 @@ def main():
                 h.solve_iterations(1, complete=True, new_solve=True)
             k = int(h.get()["qp_iter_total"][0]); h.close()
             return k
-        lo, hi = tol * 0.5, tol * 2.0
+        lo, hi = tol * 1e-5, tol * 1e5
         ok_bracket = count_at(lo) > it_dec and count_at(hi) <= it_dec
         if ok_bracket:
-            for _ in range(60):
-                mid = 0.5 * (lo + hi)
+            for _ in range(80):
+                mid = (lo * hi) ** 0.5
                 if count_at(mid) <= it_dec:
                     hi = mid
                 else:
@@ -144,8 +148,14 @@ def main():
             "oracle_margin_to_tolerance_relative": (orc_res[worst_name] - tol) / tol,
             "device_margin_to_tolerance_relative": ((dev_worst - tol) / tol) if dev_worst else None}
         cases.append(c)
-    out = {"what": "integer disagreements device <-> oracle (riccati_form 1) at a tight QP tolerance, each traced to the stopping test that flips",
-           "workload": f"cfg2 bench launch ({a.scenes} scenes x 64), sample = the bench's {len(idx_bench)}-trajectory parity sample + {len(idx) - len(idx_bench)} more",
+    kinds = {"exit_code": int((g["exit_code"] != o["exit_code"]).sum()), "sqp_iter": int((g["sqp_iter"] != o["sqp_iter"]).sum()),
+             "qp_iter_total": int((g["qp_iter_total"] != o["qp_iter_total"]).sum()),
+             "device_failed_oracle_ok": int(((g["exit_code"] != 1) & (o["exit_code"] == 1)).sum()), "oracle_failed_device_ok": int(((g["exit_code"] == 1) & (o["exit_code"] != 1)).sum()),
+             "device_success_fraction": float((g["exit_code"] == 1).mean()), "oracle_success_fraction": float((o["exit_code"] == 1).mean())}
+    out = {"what": "integer disagreements device <-> oracle (same Riccati form on both sides) at a tight QP tolerance, each traced to the stopping test that flips",
+           "riccati_form": ["Schur complement (tmpc_dims.riccati_form 0 / oracle riccati_form 1)", "square root (tmpc_dims.riccati_form 1 / oracle riccati_form 0)"][a.form],
+           "mismatch_kinds": kinds,
+           "workload": f"{a.workload} bench launch ({a.scenes} scenes x {min(wl['traj'], 64)}), sample = the bench's {len(idx_bench)}-trajectory parity sample + {len(idx) - len(idx_bench)} more",
            "qp_tol": tol, "kernel": info_kernel, "library_sha256": bench.library_sha256(),
            "trajectories": int(n), "mismatching": int(len(mism)), "mismatching_in_bench_sample": int(sum(c["in_bench_parity_sample"] for c in cases)),
            "parity_max_rel_where_counts_agree": float(rel[agree].max()) if agree.any() else None,
