@@ -385,6 +385,12 @@ int tmpc_debug_profile(tmpc_handle *h, int64_t *cycles, int32_t n_phases);
  * n_pair are stored as pairs, a kernel of `threads` (64 or 128) threads per trajectory.  tmpc_create picks, among the strides that keep the
  * kernel's residency, the one this function likes best (diagnostics: TMPC_EXP_DPAD in INTEGRATION.md section 7); results never depend on it. */
 int tmpc_debug_lds_passes(int32_t N, int32_t n_pair, int32_t nh, int32_t threads, int32_t dstride);
+/* Test aid (no reference counterpart): fills the LDS of every CU of the handle's device with signalling-NaN bit patterns (one 160 KB workgroup
+ * per CU, several rounds) and waits.  LDS keeps its contents between kernels, so a solve kernel that reads a word it never wrote gives results
+ * that depend on what ran before it -- in a fresh test process that is usually zeros and the bug stays invisible (round 6: a column slot the
+ * four-wave factorisation multiplied by zero without ever writing it).  tests/test_gpu_lds_poison.py solves after this call and demands the
+ * un-poisoned results bit for bit, for every kernel family. */
+int tmpc_debug_poison_lds(tmpc_handle *h);
 
 int tmpc_debug_eval_stage(tmpc_handle *h, int32_t n, const double *z, const double *p, const double *pi,
                           const double *lamh, double *cost, double *cost_grad, double *cost_hess,

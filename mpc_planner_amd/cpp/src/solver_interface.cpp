@@ -21,25 +21,28 @@
 namespace MPCPlanner
 {
     /* Kernel variant of a control tick (tmpc_set_latency_mode).  A tick of a few planners is one dependent chain deep, and for that the
-     * latency variants are built: 2 = the interior-point Newton systems solved parallel in time (about 30 % less kernel time per tick; exit
+     * latency variants are built: 3 = four waves per trajectory (round 6: the stage evaluation, the row passes and the wide phases of the
+     * parallel-in-time Newton solve on 256 lanes; N <= 20), 2 = the interior-point Newton systems solved parallel in time on two waves (exit
      * codes and iteration counts equal to the oracle's on every set tried, steps equal to ~1e-6, see include/tmpc_hip.h), 1 = two waves per
      * trajectory with the same stage-by-stage Riccati recursion as acados / HPIPM (rounding-equal to the throughput kernels), 0 = the
-     * throughput kernels themselves.  MPC_PLANNER_HIP_TICK_VARIANT picks one (default 2).  The variant is asked for ONLY while the batch fits
-     * the variant's resident set (tmpc_latency_mode_capacity: one workgroup per CU for variant 2): a larger solveBatch() runs on the throughput
-     * kernels (round-4 advisor: variant 2 for every batch size was a throughput regression for large batches).  The rule looks at the batch
-     * size the CALLER handed over, so it is the caller's choice, not the library's: a given batch always gets the same kernels. */
+     * throughput kernels themselves.  MPC_PLANNER_HIP_TICK_VARIANT picks one (default 3).  A variant is asked for ONLY while the batch fits
+     * its resident set (tmpc_latency_mode_capacity: one workgroup per CU for variants 2 and 3) and the shape has it; otherwise the next lower
+     * one is tried: a larger solveBatch() runs on the throughput kernels (round-4 advisor: variant 2 for every batch size was a throughput
+     * regression for large batches).  The rule looks at the batch size the CALLER handed over, so it is the caller's choice, not the
+     * library's: a given batch always gets the same kernels. */
     static int tickKernelVariant()
     {
         const char *v = std::getenv("MPC_PLANNER_HIP_TICK_VARIANT");
-        if (v && (v[0] == '0' || v[0] == '1' || v[0] == '2') && v[1] == '\0') return v[0] - '0';
-        return 2;
+        if (v && v[0] >= '0' && v[0] <= '3' && v[1] == '\0') return v[0] - '0';
+        return 3;
     }
     static void applyTickVariant(tmpc_handle *h, int batch)
     {
         int want = tickKernelVariant();
-        if (want != 0) {
+        while (want > 0) {
             const int cap = tmpc_latency_mode_capacity(h, want);
-            if (cap <= 0 || batch > cap) want = (want == 2 && tmpc_latency_mode_capacity(h, 1) >= batch) ? 1 : 0;
+            if (cap > 0 && batch <= cap) break;
+            want--;
         }
         const int rc = tmpc_set_latency_mode(h, want);
         static std::once_flag told;                      // (Solver instances solve concurrently from OpenMP threads, guidance_constraints.cpp:279: no plain static flag)

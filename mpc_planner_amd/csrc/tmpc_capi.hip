@@ -798,6 +798,10 @@ int tmpc_latency_mode_capacity(tmpc_handle *h, int32_t mode)
     int per_cu = 0, cus = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, threads, lds) != hipSuccess ||
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess) { h->err = "tmpc_latency_mode_capacity: occupancy query failed"; return TMPC_ERR_HIP; }
+    // variant 3 is built for ONE workgroup per CU (a wave on every SIMD): a second one fits (LDS, registers) but shares the SIMDs, and the launch is then
+    // slower than variant 2's (measured, cfg 4's share of 8 = 512 trajectories: 1.79 ms against 1.31 ms, profiles/round6_cfg4_share8_*): its capacity is what
+    // it serves well, not what the hardware would hold
+    if (mode == 3 && per_cu > 1) per_cu = 1;
     return per_cu * cus;
 }
 
@@ -883,6 +887,31 @@ int tmpc_clear_slot(tmpc_handle *h, int32_t slot)
     TMPC_HIP_CHECK(h, hipSetDevice(h->device));
     TMPC_HIP_CHECK(h, hipMemsetAsync(h->st_has + slot, 0, 4, h->stream));
     TMPC_HIP_CHECK(h, hipMemsetAsync(h->st_stopped + slot, 0, 4, h->stream));
+    return TMPC_OK;
+}
+
+__global__ __launch_bounds__(256) void tmpc_poison_lds_kernel(int n_doubles)
+{
+    extern __shared__ __attribute__((aligned(16))) double poison_smem[];
+    const unsigned long long pat = 0x7ff4dead0000beefull;                 // a signalling NaN
+    for (int i = threadIdx.x; i < n_doubles; i += blockDim.x) poison_smem[i] = __builtin_bit_cast(double, pat);
+    __syncthreads();
+    if (poison_smem[(threadIdx.x * 97) % n_doubles] == 0.0) poison_smem[0] = 1.0;      // (keeps the stores alive)
+}
+
+int tmpc_debug_poison_lds(tmpc_handle *h)
+{
+    if (!h) return TMPC_ERR_INVALID;
+    TMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    int cus = 0;
+    TMPC_HIP_CHECK(h, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
+    const int bytes = 160 * 1024;
+    TMPC_HIP_CHECK(h, hipFuncSetAttribute((const void *)tmpc_poison_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    for (int round = 0; round < 4; round++) {                               // (one workgroup per CU fits at a time: a few rounds reach every CU whatever the dispatch order)
+        hipLaunchKernelGGL(tmpc_poison_lds_kernel, dim3(cus * 2), dim3(256), bytes, h->stream, bytes / 8);
+        TMPC_HIP_CHECK(h, hipGetLastError());
+    }
+    TMPC_HIP_CHECK(h, hipStreamSynchronize(h->stream));
     return TMPC_OK;
 }
 

@@ -52,14 +52,15 @@ template <int SL> struct Cfg {
     static constexpr int ZL = CL * 7 + ((CL * 7) % 2 == 0 ? 1 : 0);         // per LANE: its columns of P_k [F_k^T E^T g_k] (odd stride)
     static constexpr int NMAX = 64 / SL - 1;                                // 20 / 31
 };
+constexpr int ZBLK = 36;                                                   // a block of zeros: the coupling of a block without right neighbour (25), [B A] of node N (35)
 template <int SL>
-__host__ __device__ constexpr int lds_doubles(int N) { return N * BS + (N + 1) * LS + SL * (N + 1) * Cfg<SL>::ZL + (N + 1) * SNV + 25; }     // (+ 25 zeros: the coupling of a block without right neighbour)
+__host__ __device__ constexpr int lds_doubles(int N) { return N * BS + (N + 1) * LS + SL * (N + 1) * Cfg<SL>::ZL + (N + 1) * SNV + ZBLK; }
 
 // operands in LDS: Hh packed lower (28 per stage, row-major), BA dense (5 x 7 per stage), gh (7 per stage), rb (5 per stage);
 // results dv (7 per stage), dpi (5 per stage, dpi_{j+1} = pi_j); scratch of lds_doubles<SL>(N) at `blk`
 template <int SL>
 struct ViewT {
-    const double *Hh, *BA, *gh, *rb; double *dv, *dpi, *blk; int N;
+    double *Hh; const double *BA, *gh, *rb; double *dv, *dpi, *blk; int N;
     __device__ __forceinline__ double *Ls() const { return blk + N * BS; }
     __device__ __forceinline__ double *Zs() const { return blk + N * BS + (N + 1) * LS; }
     __device__ __forceinline__ double *zg() const { return blk + N * BS + (N + 1) * LS + SL * (N + 1) * Cfg<SL>::ZL; }
@@ -170,6 +171,23 @@ __device__ __forceinline__ double h_entry(const double *Hk, int k, int N, int i,
     return h;
 }
 __device__ __forceinline__ bool g_live(int k, int N, int i) { return !((k == 0 && i >= SNU) || (k == N && i < SNU)); }
+// The same entries written INTO Hh once per factorisation (round 6), so that the stage phases load H_k as it is: 25 entries of the state block of
+// node 0 (lanes 0 .. 24) and 13 entries of node N touching its inputs (lanes 25 .. 37) instead of two selects on each of the 28 entries in every
+// lane (~110 of the stage phase's ~570 instructions).  Hh is rebuilt by the interior-point iteration before every factorisation and nothing
+// else reads these entries (dx_0 is fixed, node N has no inputs), so overwriting them changes nothing else.  Followed by a fence / barrier.
+template <int SL>
+__device__ __forceinline__ void pin_structural_entries(const ViewT<SL> &V, int lane)
+{
+    if (lane < ZBLK) V.zeros()[lane] = 0.0;
+    if (lane < 25) {                                                        // node 0: rows 2 .. 6 of the packed lower triangle = entries 3 .. 27
+        const int e = 3 + lane;
+        V.Hh[e] = (e == tri(2, 2) || e == tri(3, 3) || e == tri(4, 4) || e == tri(5, 5) || e == tri(6, 6)) ? 1e40 : 0.0;
+    } else if (lane < 38) {                                                 // node N: (0,0), (1,0), (1,1), then (i,0), (i,1) for i = 2 .. 6
+        const int q = lane - 25;
+        const int e = q < 3 ? q : tri(2 + (q - 3) / 2, (q - 3) % 2);
+        V.Hh[V.N * 28 + e] = (e == tri(0, 0) || e == tri(1, 1)) ? 1.0 : 0.0;
+    }
+}
 
 // ---- factor: stage phase ----
 // The right-hand side V.gh of the call (the predictor's: complete before the factorisation) rides along as an eleventh column.
@@ -180,18 +198,17 @@ __device__ __forceinline__ bool stage_phase(const ViewT<SL> &V, int lane)
     const int N = V.N;
     double *blk = V.blk;
     SCAN_T0();
-    if (lane < 25) V.zeros()[lane] = 0.0;
+    pin_structural_entries(V, lane);
+    fence();
     const int k = lane / SL, s = lane - SL * k;
     bool bad = false;
     if (lane < SL * (N + 1)) {
         double L[28];
         const double *Hk = V.Hh + k * 28;
 #pragma unroll
-        for (int i = 0; i < SNV; i++)
-#pragma unroll
-            for (int j = 0; j <= i; j++) L[tri(i, j)] = h_entry(Hk, k, N, i, j);
+        for (int e = 0; e < 28; e++) L[e] = Hk[e];
         BaRow F;
-        ba_load(V.BA + (k < N ? k : 0) * SNX * SNV, F, k < N);
+        ba_load(k < N ? V.BA + k * SNX * SNV : V.zeros(), F, true);       // (node N has no [B A]: the zero block, no selects)
         double gk[SNV];
 #pragma unroll
         for (int i = 0; i < SNV; i++) gk[i] = V.gh[k * SNV + i];
@@ -425,7 +442,8 @@ __device__ __forceinline__ bool stage_phase4(const ViewT<SL> &V, int tid)
     constexpr int CL = Cfg<SL>::CL, ZL = Cfg<SL>::ZL;
     const int N = V.N;
     double *blk = V.blk;
-    if (tid < 25) V.zeros()[tid] = 0.0;
+    pin_structural_entries(V, tid);
+    __syncthreads();
     const int wv = tid >> 6, l = tid & 63;
     const bool reg = l < 55;
     const int k = reg ? 5 * wv + l / 11 : 20;
@@ -438,11 +456,9 @@ __device__ __forceinline__ bool stage_phase4(const ViewT<SL> &V, int tid)
         double L[28];
         const double *Hk = V.Hh + kc * 28;
 #pragma unroll
-        for (int i = 0; i < SNV; i++)
-#pragma unroll
-            for (int j = 0; j <= i; j++) L[tri(i, j)] = h_entry(Hk, kc, N, i, j);
+        for (int e = 0; e < 28; e++) L[e] = Hk[e];
         BaRow F;
-        ba_load(V.BA + (kc < N ? kc : 0) * SNX * SNV, F, kc < N);
+        ba_load(kc < N ? V.BA + kc * SNX * SNV : V.zeros(), F, true);
         double gk[SNV];
 #pragma unroll
         for (int i = 0; i < SNV; i++) gk[i] = V.gh[kc * SNV + i];
@@ -469,6 +485,12 @@ __device__ __forceinline__ bool stage_phase4(const ViewT<SL> &V, int tid)
         if (cid == 10) {
 #pragma unroll
             for (int i = 0; i < SNV; i++) V.zg()[kc * SNV + i] = z[0][i];
+            // column slot 11 of the stage does not exist (eleven columns in SL * CL = 12 slots) but solve() multiplies it -- by zero: it has to be FINITE.
+            // The one-wave phase computes and stores zeros there; here nobody owns it, so the lane of column 10 clears it (left to whatever the LDS held
+            // it turned 17 % of a launch into failures in a process whose earlier kernels had left NaN bit patterns behind: round 6, found by bench.py).
+            double *Z11 = V.Zs() + (SL * kc + 11 / CL) * ZL + (11 % CL) * SNV;
+#pragma unroll
+            for (int i = 0; i < SNV; i++) Z11[i] = 0.0;
         }
         if (cid < 5 && kc < N) {                                              // D_k = F P F^T: stored, every column of every block exactly once
 #pragma unroll
@@ -553,7 +575,7 @@ __device__ __forceinline__ void solve(const ViewT<SL> &V, int lane, bool pred)
     {                                                        // beta_j = rb_j - F_j P_j g_j + E P_{j+1} g_{j+1}
         const int kc = stage_lane ? k : 0;
         BaRow F;
-        ba_load(V.BA + (kc < N ? kc : 0) * SNX * SNV, F, kc < N);
+        ba_load(kc < N ? V.BA + kc * SNX * SNV : V.zeros(), F, true);
         double z[SNV], o[SNX];
 #pragma unroll
         for (int i = 0; i < SNV; i++) z[i] = V.zg()[kc * SNV + i];

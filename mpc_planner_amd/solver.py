@@ -44,7 +44,7 @@ EXPORTS = ["tmpc_default_dims", "tmpc_default_dims_ex", "tmpc_create", "tmpc_des
            "tmpc_debug_get_x0", "tmpc_debug_get_params", "tmpc_set_throughput_mode", "tmpc_solve_iterations",
            "tmpc_reset_multipliers", "tmpc_get_stream", "tmpc_kernel_info", "tmpc_set_slots", "tmpc_set_param_sharing", "tmpc_copy_state", "tmpc_scenario_empty_stages", "tmpc_sample_scenarios",
            "tmpc_scenario_discard", "tmpc_scenario_discarded", "tmpc_linearize_topology_ex", "tmpc_clear_slot", "tmpc_gather_best",
-           "tmpc_create_v2", "tmpc_set_param_sharing_ex", "tmpc_latency_mode_capacity", "tmpc_has_lane_kernels", "tmpc_debug_lds_passes"]
+           "tmpc_create_v2", "tmpc_set_param_sharing_ex", "tmpc_latency_mode_capacity", "tmpc_has_lane_kernels", "tmpc_debug_lds_passes", "tmpc_debug_poison_lds"]
 
 class TmpcError(RuntimeError):
     pass
@@ -289,6 +289,10 @@ class BatchedSolver:
 
     def copy_state_from(self, other):
         self._check(self.lib.tmpc_copy_state(self._h, other._h), "tmpc_copy_state")
+
+    def debug_poison_lds(self):
+        """Test aid: fill every CU's LDS with NaN bit patterns (tmpc_debug_poison_lds): a kernel that reads a word it never wrote shows."""
+        self._check(self.lib.tmpc_debug_poison_lds(self._h), "tmpc_debug_poison_lds")
 
     def kernel_info(self):
         """Which solve kernel the handle dispatches and how it is launched (text)."""

@@ -114,8 +114,8 @@ def test_cpp_optimize_matches_python_path(tmp_path):
 
 @pytest.mark.gpu
 def test_cpp_optimize_parallel_in_time_variant(tmp_path):
-    """MPC_PLANNER_HIP_TICK_VARIANT=2: the C++ Solver mirror serves the tick with latency mode 2 (Newton systems solved parallel in time).
-    Same best planner, exit codes and objectives (to 1e-7) as the default variant of the same binary."""
+    """MPC_PLANNER_HIP_TICK_VARIANT: the C++ Solver mirror serves the tick with latency mode 1 (two-wave Riccati), 2 (Newton systems solved parallel in
+    time) or 3 (four waves per trajectory, the default since round 6).  Same best planner, exit codes and objectives (to 1e-7) in all three."""
     from mpc_planner_amd import scenes
     if not os.path.exists(BIN) or os.path.getmtime(BIN) < os.path.getmtime(os.path.join(ROOT, "mpc_planner_amd", "libtmpc_hip.so")):
         _build()
@@ -123,7 +123,7 @@ def test_cpp_optimize_parallel_in_time_variant(tmp_path):
     f = str(tmp_path / "scene.bin")
     _scene_file(sc, f, 1)
     runs = []
-    for variant in ("1", "2"):
+    for variant in ("1", "2", "3"):
         out = subprocess.run([BIN, os.path.join(GEN, "config"), f], capture_output=True, text=True, timeout=300,
                              env=dict(os.environ, MPC_PLANNER_HIP_TICK_VARIANT=variant))
         assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
@@ -132,13 +132,14 @@ def test_cpp_optimize_parallel_in_time_variant(tmp_path):
         planners = [l.split() for l in lines if l.startswith("planner")]
         xs = np.array([[float(v) for v in l.split()[2:]] for l in lines if l.startswith("x ")])
         runs.append((int(head[1]), int(head[3]), [(int(pl[5]), float(pl[7])) for pl in planners], xs))
-    (e1, b1, p1, x1), (e2, b2, p2, x2) = runs
-    assert (e1, b1) == (e2, b2) and len(p1) == len(p2) == B + 1
-    for (c1, o1), (c2, o2) in zip(p1, p2):
-        assert c1 == c2
-        if c1 == 1:
-            assert abs(o1 - o2) <= 1e-7 * max(1.0, abs(o1))
-    np.testing.assert_allclose(x1, x2, rtol=0, atol=1e-7)
+    (e1, b1, p1, x1) = runs[0]
+    for (e2, b2, p2, x2) in runs[1:]:
+        assert (e1, b1) == (e2, b2) and len(p1) == len(p2) == B + 1
+        for (c1, o1), (c2, o2) in zip(p1, p2):
+            assert c1 == c2
+            if c1 == 1:
+                assert abs(o1 - o2) <= 1e-7 * max(1.0, abs(o1))
+        np.testing.assert_allclose(x1, x2, rtol=0, atol=1e-7)
 
 
 # ---- SH-MPC: ScenarioConstraints::optimize (scenario_constraints.cpp:58-108), C++ batched restatement vs the Python driver ----
