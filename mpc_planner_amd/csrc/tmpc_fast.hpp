@@ -74,7 +74,13 @@ __device__ __forceinline__ Lds carve_fast(double *s, const Dims &d)
 // one-wave shapes; 3 -- 30 doubles, y inside the block, no y array -- for (12,12) (seven per CU with 69 bytes to spare: 29 does not fit, 30 minus the y array does);
 // 1 -- the bare 28 -- for the run-time shapes (their LDS size is not known here) and the two-wave instantiations: a wave of theirs holds 16 stages (two-way
 // conflicts at most), measured 0 ((20,8), cfg 3) and -2 % ((5,5), the jackal default) with the padded stride (profiles/round5_r_layout_check.jsonl).
+// (-DTMPC_EXP_Y_IN_BLOCK, A/B builds of the compact translation unit only: layout 3 for every tuned one-wave shape -- round-5 verdict next-2 (b): for (8,8)
+// the 30-double blocks cost 21 doubles and retire the 40-double y array, so the eight-per-CU budget holds; profiles/round6_saturated_levers_ab.jsonl)
+#ifdef TMPC_EXP_Y_IN_BLOCK
+__host__ __device__ constexpr int compact_layout(int NLIN, int MM, int NTH) { return (NLIN >= 0 && NTH == 64) ? 3 : 1; }
+#else
 __host__ __device__ constexpr int compact_layout(int NLIN, int MM, int NTH) { return (NLIN >= 0 && NTH == 64) ? ((NLIN == 12 && MM == 12) ? 3 : 2) : 1; }
+#endif
 __host__ __device__ constexpr int compact_hstride(int layout) { return layout == 2 ? NP28 + 1 : (layout == 3 ? NP28 + 2 : NP28); }
 __host__ __device__ inline int lds_doubles_compact(int N, int n_pair, int nh, int nth = 64, int dpad = 0, int layout = 1)
 {
@@ -330,7 +336,15 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
     auto coef = [&](auto s_, double &c0, double &c1, double &c2) {
         constexpr int s = decltype(s_)::value;
         if constexpr (C::template KIND<s> == 1) { c0 = 0.0; c1 = 0.0; c2 = 0.0; }
-        else { const double *Dr_ = L.D + DIDX(s); c0 = Dr_[0]; c1 = Dr_[1]; c2 = L.D[DIDX2(s)]; }
+        else {
+            const double *Dr_ = L.D + DIDX(s); c0 = Dr_[0]; c1 = Dr_[1];
+#ifdef TMPC_EXP_C2_LITERAL
+            // A/B (round 6): a slot whose rows are all packed topology rows has no third entry -- the load of the zero triple's 0.0 is an LDS instruction per slot
+            // and pass; the literal is the same value (valid only while n_lin == NLIN: the tuned shapes without scenario / decomp rows)
+            if constexpr (CP && !C::RT && C::template KIND<s> == 0 && LPS * s + LPS - 1 < NLIN) c2 = 0.0; else
+#endif
+            c2 = L.D[DIDX2(s)];
+        }
     };
     // c . w for row slot s and a stage vector w = (.., x, y, p at ZX, ZY, ZPSI ..): Jacobian part + box part, whichever the slot can have
     auto rowdot = [&](auto s_, double c0, double c1, double c2, double x, double y, double pp, const double *vec) {

@@ -244,10 +244,39 @@ __device__ __forceinline__ bool riccati_factor_rows(const Lds &L, const Dims &d,
     seek_stage(N - 1);
     load_stage(oa, N - 1, true);
     if constexpr (SQ) bad |= chol_rows<NU>(f, li, nullptr, nullptr);       // square-root form: Cholesky of the xx block of node N
+#ifdef TMPC_EXP_NO_MERGE_FACTOR
     if (vec && wr) {
 #pragma unroll
         for (int l = 0; l < NX; l++) L.pr[N * NX + l] = f[NU + l];          // p_N (square-root form: lx of node N)
     }
+#endif
+    // Store merging (round 6, A/B builds: -DTMPC_EXP_NO_MERGE_FACTOR / -DTMPC_EXP_MERGE_FWD / -DTMPC_EXP_MERGE_BWD).  Stores of disjoint lane sets that hold the same
+    // registers at the same point of the loop can leave in ONE LDS instruction with a per-lane address.  In the FACTORISATION -- p_{k+1} of the extra row with the rows
+    // of P_{k+1}, its [y0 y1] with the Lxu pairs: four LDS instructions per stage fewer, nothing else changes -- that is +1.4 % on the saturated cfg 2 launch and taken.
+    // In the vector sweeps (du of lanes 0, 1 with dx of lanes 2..6; y with p) the merged store's value needs a select on the END of the stage's dependent chain,
+    // which holds the store back: -3.4 % (forward) and -2.0 % (backward) -- not taken.  profiles/round6_saturated_levers_ab.jsonl; results are bitwise the same either way.
+    // End of stage k: the Lxu pairs of lanes 2..6 and the extra row's [y0 y1] are the registers f[0], f[1] of their lanes: ONE store for both (per-lane
+    // address); lane 1 adds L10 and the two reciprocal pivots.  (p_k follows at the top of stage k - 1; p_0 is never read.)
+    auto store_pairs = [&](int k, double r0, double r1) {
+        double *Fb = L.Hh + hoff<CP>(k);
+#ifndef TMPC_EXP_NO_MERGE_FACTOR
+        if ((rowl && li >= NU) || (vec && wr)) {
+            double *pp = vec ? ysl<CP>(L, k) : Fb + FB_LXU + 2 * i5;
+            pp[0] = f[0]; pp[1] = f[1];
+        }
+        if (rowl && li == 1) { Fb[FB_L10] = f[0]; Fb[FB_R0] = r0; Fb[FB_R1] = r1; }
+#else
+        if (rowl) {
+            if (li >= NU) { Fb[FB_LXU + 2 * i5] = f[0]; Fb[FB_LXU + 2 * i5 + 1] = f[1]; }
+            if (li == 1) { Fb[FB_L10] = f[0]; Fb[FB_R0] = r0; Fb[FB_R1] = r1; }
+        }
+        if (vec && wr) {                                           // [y0 y1 | p_k] of stage k (square-root form: lx)
+            ysl<CP>(L, k)[0] = f[0]; ysl<CP>(L, k)[1] = f[1];
+#pragma unroll
+            for (int l = 0; l < NX; l++) L.pr[k * NX + l] = f[NU + l];
+        }
+#endif
+    };
     auto stage = [&](const Opnd &o, Opnd &nx, int k) {
         // broadcast P (lower triangle of the 5x5 cost-to-go Hessian of stage k+1: rows 2..6 after the elimination) to every lane of the row
         double Pm[NX][NX];
@@ -256,12 +285,23 @@ __device__ __forceinline__ bool riccati_factor_rows(const Lds &L, const Dims &d,
 #pragma unroll
             for (int l = 0; l <= m; l++) Pm[m][l] = bcast16<NU + m>(f[NU + l]);
         });
-        // P_{k+1} (own row of lanes 2..6) is kept for the vector solves
+        // P_{k+1} (own row of lanes 2..6) is kept for the vector solves -- and the extra row's p_{k+1} (square-root form: lx) leaves in the SAME five store
+        // instructions (round 6: the LDS unit is the busy one at eight trajectories per CU, and an LDS instruction costs the same with one lane as with six):
+        // lane 7 holds it in the same registers f[2..6] at the same point of the loop; only the address differs per lane
+#ifndef TMPC_EXP_NO_MERGE_FACTOR
+        if ((rowl && li >= NU) || (vec && wr)) {
+            double *Ln = vec ? L.pr + (k + 1) * NX : L.Hh + hoff<CP>(k + 1) + FB_P + i5 * (i5 + 1) / 2;
+            const int lim = vec ? NX : i5;
+#pragma unroll
+            for (int l = 0; l < NX; l++) *(l <= lim ? Ln + l : L.scr + (CP ? 0 : 56) + l) = f[NU + l];   // (entries above the diagonal go to a dummy slot: a select on the address instead of five masked stores)
+        }
+#else
         if (rowl && li >= NU) {
             double *Ln = L.Hh + hoff<CP>(k + 1) + FB_P;
 #pragma unroll
             for (int l = 0; l < NX; l++) *(l <= i5 ? Ln + i5 * (i5 + 1) / 2 + l : L.scr + (CP ? 0 : 56) + l) = f[NU + l];   // (entries above the diagonal go to a dummy slot: a select on the address instead of five masked stores)
         }
+#endif
         if constexpr (SQ) {
             // G = Lp^T [B A] (5 x 7), Lp = Pm (the lower triangle holds Lxx of stage k + 1).  Own column densely from ba[]; all columns (row-uniform)
             // from the sparse [B A]:  x: e0   y: e1   s: e4   psi: (Xp,Yp,1,0,0)   v: (Xv,Yv,0,1,sdt)   a: (Xa,Ya,0,dt,shdt2)   w: (Xw,Yw,dt,0,0)
@@ -308,16 +348,7 @@ __device__ __forceinline__ bool riccati_factor_rows(const Lds &L, const Dims &d,
             load_stage(nx, k > 0 ? k - 1 : 0, k > 1);
             double r0 = 0.0, r1 = 0.0;
             bad |= chol_rows<0>(f, li, &r0, &r1);                 // all seven columns: rows 2..6 now hold Lxx of stage k (the extra row: lx)
-            if (rowl) {
-                double *Fb = L.Hh + hoff<CP>(k);
-                if (li >= NU) { Fb[FB_LXU + 2 * i5] = f[0]; Fb[FB_LXU + 2 * i5 + 1] = f[1]; }
-                if (li == 1) { Fb[FB_L10] = f[0]; Fb[FB_R0] = r0; Fb[FB_R1] = r1; }
-            }
-            if (vec && wr) {                                       // [y0 y1 | lx] of stage k
-                ysl<CP>(L, k)[0] = f[0]; ysl<CP>(L, k)[1] = f[1];
-#pragma unroll
-                for (int l = 0; l < NX; l++) L.pr[k * NX + l] = f[NU + l];
-            }
+            store_pairs(k, r0, r1);
             return;
         }
         // Schur-complement form (default): P_{k+1} enters the next stage's F unfactorised (its diagonal is tested after the loop, riccati_factor)
@@ -348,16 +379,7 @@ __device__ __forceinline__ bool riccati_factor_rows(const Lds &L, const Dims &d,
                                                       // the pointers stop at stage 0, which the last pass re-loads and discards)
         double r0 = 0.0, r1 = 0.0;
         bad |= chol_rows<0, NU>(f, li, &r0, &r1);     // the two input columns; rows 2..6 now hold P_k (lanes 2..6) / p_k (the extra row)
-        if (rowl) {
-            double *Fb = L.Hh + hoff<CP>(k);
-            if (li >= NU) { Fb[FB_LXU + 2 * i5] = f[0]; Fb[FB_LXU + 2 * i5 + 1] = f[1]; }
-            if (li == 1) { Fb[FB_L10] = f[0]; Fb[FB_R0] = r0; Fb[FB_R1] = r1; }
-        }
-        if (vec && wr) {                                           // [y0 y1 | p_k] of stage k
-            ysl<CP>(L, k)[0] = f[0]; ysl<CP>(L, k)[1] = f[1];
-#pragma unroll
-            for (int l = 0; l < NX; l++) L.pr[k * NX + l] = f[NU + l];
-        }
+        store_pairs(k, r0, r1);
     };
     if constexpr (factor_unrolled<CP>()) {
         int k = N - 1;
@@ -542,8 +564,12 @@ __device__ __forceinline__ void riccati_sweeps_rows(const Lds &L, const Dims &d,
             const double y0 = bcast16<0>(fj) * o.r0;
             const double y1 = (bcast16<1>(fj) - o.l10 * y0) * o.r1;
             p = fj - o.lx0 * y0 - o.lx1 * y1;
+#ifdef TMPC_EXP_MERGE_BWD
+            if (rowl) *(li < NU ? ysl<CP>(L, k) + ls : L.pr + k * NX + i5) = li == 0 ? y0 : (li == 1 ? y1 : p);      // (one store: y from lanes 0, 1, p_k from lanes 2..6)
+#else
             if (rowl && li == 0) { ysl<CP>(L, k)[0] = y0; ysl<CP>(L, k)[1] = y1; }
             if (xl) L.pr[k * NX + i5] = p;
+#endif
         };
         Ops oa, ob;
         load_stage(oa, N - 1);
@@ -573,9 +599,14 @@ __device__ __forceinline__ void riccati_sweeps_rows(const Lds &L, const Dims &d,
         struct Ops { double y0, y1, r0, l10, r1, a_psi, a_v, b_a, b_w, rbi; };
         double lxu[2 * NX];
         auto load_lxu = [&](int k) {
+#ifndef TMPC_EXP_LXU_ALL
+            const double *Fb = L.Hh + hoff<CP>(k) + FB_LXU + 2 * i5;       // the lane's own pair
+            lxu[0] = Fb[0]; lxu[1] = Fb[1];
+#else
             const double *Fb = L.Hh + hoff<CP>(k) + FB_LXU;
 #pragma unroll
             for (int e = 0; e < 2 * NX; e++) lxu[e] = Fb[e];
+#endif
         };
         const double i_psi = li == ZPSI ? 1.0 : 0.0, i_v = li == ZV ? 1.0 : 0.0;
         double *dv_own = L.dv + ls;
@@ -597,16 +628,35 @@ __device__ __forceinline__ void riccati_sweeps_rows(const Lds &L, const Dims &d,
         };
         auto stage = [&](const Ops &o, int k) {
             // du = -Luu^-T (Lxu^T dx + y)
+#ifndef TMPC_EXP_LXU_ALL
+            // Round 6 (round-5 verdict next-2 (a)): a lane keeps ITS OWN pair of Lxu -- one LDS load per stage instead of the five row-uniform ones that gave
+            // every lane all ten entries --, multiplies it by its own dx, and the ten products are summed by row broadcasts: 22 VALU instructions where the
+            // product form (round 4; -DTMPC_EXP_LXU_ALL rebuilds it) has 13, four LDS instructions fewer.  At eight trajectories per CU the LDS unit is the
+            // busier one (65 % of the kernel time, most of it these sweeps): cfg 2 1.288 -> 1.343 M solves/s (+4.3 %, profiles/round6_saturated_levers_ab.jsonl).
+            // Every kernel family takes it (the fast and the compact kernel of a shape stay bitwise equal); the sums associate differently: rounding level.
+            const double xm = (li >= NU && li < NV) ? 1.0 : 0.0;
+            const double p0 = xm * (lxu[0] * dx), p1 = xm * (lxu[1] * dx);
+            double s0 = o.y0, s1 = o.y1;
+            static_for<0, NX>([&](auto m_) { constexpr int m = decltype(m_)::value; s0 += bcast16<NU + m>(p0); s1 += bcast16<NU + m>(p1); });
+            double dxs[NX];
+            dxs[ZPSI - NU] = bcast16<ZPSI>(dx); dxs[ZV - NU] = bcast16<ZV>(dx);
+            load_lxu(k + 1 < N ? k + 1 : N - 1);
+#else
             double dxs[NX];
             static_for<0, NX>([&](auto m_) { constexpr int m = decltype(m_)::value; dxs[m] = bcast16<NU + m>(dx); });
             double s0 = o.y0, s1 = o.y1;
 #pragma unroll
             for (int m = 0; m < NX; m++) { s0 = fma(lxu[2 * m], dxs[m], s0); s1 = fma(lxu[2 * m + 1], dxs[m], s1); }
             load_lxu(k + 1 < N ? k + 1 : N - 1);                           // (unconditional, clamped)
+#endif
             const double u1 = -s1 * o.r1;
             const double u0 = (-s0 - o.l10 * u1) * o.r0;
+#ifdef TMPC_EXP_MERGE_FWD
+            if (rowl) dv_own[k * NV] = li == 0 ? u0 : (li == 1 ? u1 : dx);      // (one store: lane j writes component j of dv_k -- du from lanes 0, 1, dx from lanes 2..6)
+#else
             if (rowl && li == 0) { L.dv[k * NV] = u0; L.dv[k * NV + 1] = u1; }
             if (xl) dv_own[k * NV] = dx;
+#endif
             const double dpsi = dxs[ZPSI - NU], dvv = dxs[ZV - NU];
             const double e_psi = o.a_psi - i_psi, e_v = o.a_v - i_v;
             dx = dx + e_psi * dpsi + e_v * dvv + o.b_a * u0 + o.b_w * u1 + o.rbi;   // lanes 2..6 meaningful
