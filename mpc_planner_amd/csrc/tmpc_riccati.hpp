@@ -57,7 +57,13 @@ __device__ unsigned long long g_sweep_prof[SP_COUNT];
 // iterates agree to 4e-11 (the level of the kernels' rounding differences); profiles/round5_riccati_form_study.json.
 // In place of Hh_k the "factor block" (28 doubles) is written for the vector solves:
 //   [0..9]  Lxu (5x2, row-major)   [10] L10   [11] 1/L00   [12] 1/L11   [13..27] P_k (packed lower 5x5)
+#ifdef TMPC_EXP_UNIFORM_PIVOTS
 constexpr int FB_LXU = 0, FB_L10 = 10, FB_R0 = 11, FB_R1 = 12, FB_P = 13;
+#else
+// (round 6: [10] 1/L00  [11] L10  [12] 1/L11 -- the vector sweeps apply Luu on lanes 0 and 1 only and broadcast the result: lane 0 needs (1/L00, L10), lane 1
+//  (L10, 1/L11), ONE two-double load with a per-lane base where every lane loaded all three, two instructions; the arithmetic is the same)
+constexpr int FB_LXU = 0, FB_R0 = 10, FB_L10 = 11, FB_R1 = 12, FB_P = 13;
+#endif
 
 // Offset of stage k's block in Hh.  A stride of 28 doubles (56 dwords) puts the stages k, k + 8, k + 16 on the same LDS banks: the stage-parallel loops
 // (one lane per stage: the node's 28 stores of Hh <- W, the 15 + 15 loads of P in the vector solves' prologue / epilogue, the row passes' ds_add_f64)
@@ -215,8 +221,10 @@ __device__ __forceinline__ bool riccati_factor_rows(const Lds &L, const Dims &d,
             for (int j = 0; j < NV; j++) o.hk[j] = hr[j];
 #pragma unroll
             for (int m = 0; m < NX; m++) o.ba[m] = bbase[bo[m] + mul24(k, bst[m])];
+#ifdef TMPC_EXP_DN_LOADS
 #pragma unroll
             for (int q = 0; q < 8; q++) o.dn[q] = (CP ? L.tab : L.dyn8)[k * 8 + q];
+#endif
             (void)step;
         } else {
             const double *Hk = L.Hh + hoff<CP>(k);
@@ -226,14 +234,18 @@ __device__ __forceinline__ bool riccati_factor_rows(const Lds &L, const Dims &d,
                 o.ba[0] = L.tab[bc.o0 + mul24(k, bc.st)]; o.ba[1] = L.tab[bc.o1 + mul24(k, bc.st)];
 #pragma unroll
                 for (int m = 2; m < NX; m++) o.ba[m] = bac[m];
+#ifdef TMPC_EXP_DN_LOADS
 #pragma unroll
                 for (int q = 0; q < 8; q++) o.dn[q] = L.tab[k * 8 + q];
+#endif
             } else {
                 const double *BA = L.BA + k * NX * NV;
 #pragma unroll
                 for (int m = 0; m < NX; m++) o.ba[m] = BA[m * NV + ls];
+#ifdef TMPC_EXP_DN_LOADS
 #pragma unroll
                 for (int q = 0; q < 8; q++) o.dn[q] = L.dyn8[k * 8 + q];
+#endif
             }
         }
     };
@@ -314,8 +326,13 @@ __device__ __forceinline__ bool riccati_factor_rows(const Lds &L, const Dims &d,
                 for (int m = l; m < NX; m++) acc += Pm[m][l] * o.ba[m];
                 Go[l] = VEC ? fma(vmask, f[NU + l], acc) : acc;
             }
+#ifdef TMPC_EXP_DN_LOADS
             const double Xa = o.dn[D8_XA], Xw = o.dn[D8_XW], Xp = o.dn[D8_XP], Xv = o.dn[D8_XV];
             const double Ya = o.dn[D8_YA], Yw = o.dn[D8_YW], Yp = o.dn[D8_YP], Yv = o.dn[D8_YV];
+#else
+            const double Xa = bcast16<ZA>(o.ba[0]), Ya = bcast16<ZA>(o.ba[1]), Xw = bcast16<ZW>(o.ba[0]), Yw = bcast16<ZW>(o.ba[1]);
+            const double Xp = bcast16<ZPSI>(o.ba[0]), Yp = bcast16<ZPSI>(o.ba[1]), Xv = bcast16<ZV>(o.ba[0]), Yv = bcast16<ZV>(o.ba[1]);
+#endif
             double Ga[NX], Gw[NX], Gp[3], Gv[NX];
             Ga[0] = ((Pm[0][0] * Xa + Pm[1][0] * Ya) + Pm[3][0] * dt) + Pm[4][0] * shdt2;
             Ga[1] = (Pm[1][1] * Ya + Pm[3][1] * dt) + Pm[4][1] * shdt2;
@@ -365,8 +382,15 @@ __device__ __forceinline__ bool riccati_factor_rows(const Lds &L, const Dims &d,
         // F row `li`: F_ij = Hh_ij + sum_n w_n [B A]_nj with the sparse columns of [B A] (row-uniform):
         //   x: e0   y: e1   s: e4   psi: (Xp,Yp,1,0,0)   v: (Xv,Yv,0,1,dt)   a: (Xa,Ya,0,dt,dt^2/2)   w: (Xw,Yw,dt,0,0)
         {
+#ifdef TMPC_EXP_DN_LOADS
             const double Xa = o.dn[D8_XA], Xw = o.dn[D8_XW], Xp = o.dn[D8_XP], Xv = o.dn[D8_XV];
             const double Ya = o.dn[D8_YA], Yw = o.dn[D8_YW], Yp = o.dn[D8_YP], Yv = o.dn[D8_YV];
+#else
+            // (round 6) the eight stage-dependent entries of [B A] are rows x, y of the columns a, w, psi, v -- which the lanes of those columns hold as
+            // ba[0], ba[1] of their OWN column: eight row broadcasts instead of four row-uniform LDS loads of the dyn8 block (the LDS unit is the busy one)
+            const double Xa = bcast16<ZA>(o.ba[0]), Ya = bcast16<ZA>(o.ba[1]), Xw = bcast16<ZW>(o.ba[0]), Yw = bcast16<ZW>(o.ba[1]);
+            const double Xp = bcast16<ZPSI>(o.ba[0]), Yp = bcast16<ZPSI>(o.ba[1]), Xv = bcast16<ZV>(o.ba[0]), Yv = bcast16<ZV>(o.ba[1]);
+#endif
             f[ZA] = fma(w[4], shdt2, fma(w[3], dt, fma(w[1], Ya, fma(w[0], Xa, o.hk[ZA]))));
             f[ZW] = fma(w[2], dt, fma(w[1], Yw, fma(w[0], Xw, o.hk[ZW])));
             f[ZX] = o.hk[ZX] + w[0];
@@ -535,6 +559,7 @@ __device__ __forceinline__ void riccati_sweeps_rows(const Lds &L, const Dims &d,
         // (always issued before stage k runs: the sets are filled at least one stage ahead, and LDS operations of a wave
         // execute in order) has fetched by then; the closing loop adds P dx in place.
         struct Ops { double ghj, ba[NX], r0, l10, r1, lx0, lx1, q; };
+        const int l01 = li == 1 ? 1 : 0;                                   // (lanes >= 2 follow lane 0: their values are not used)
         const BaLane bc = ba_column(N, ls);
         double bac[NX];
         if constexpr (CP) {
@@ -553,7 +578,11 @@ __device__ __forceinline__ void riccati_sweeps_rows(const Lds &L, const Dims &d,
 #pragma unroll
                 for (int l = 0; l < NX; l++) o.ba[l] = BA[l * NV + ls];
             }
+#ifdef TMPC_EXP_UNIFORM_PIVOTS
             o.r0 = Fb[FB_R0]; o.l10 = Fb[FB_L10]; o.r1 = Fb[FB_R1];
+#else
+            { const double *Pv = Fb + FB_R0 + l01; o.r0 = Pv[0]; o.r1 = Pv[1]; o.l10 = 0.0; }      // lane 0: (1/L00, L10); lane 1: (L10, 1/L11)
+#endif
             o.lx0 = Fb[FB_LXU + 2 * i5]; o.lx1 = Fb[FB_LXU + 2 * i5 + 1];
             o.q = L.dpi[uni((k + 1) * NX) + i5];
         };
@@ -561,8 +590,13 @@ __device__ __forceinline__ void riccati_sweeps_rows(const Lds &L, const Dims &d,
             const double Pb = p + o.q;                                     // (P_{k+1} rb_k + p_{k+1}), lane 2+i
             double fj = o.ghj;
             static_for<0, NX>([&](auto l_) { constexpr int l = decltype(l_)::value; fj += o.ba[l] * bcast16<NU + l>(Pb); });
+#ifdef TMPC_EXP_UNIFORM_PIVOTS
             const double y0 = bcast16<0>(fj) * o.r0;
             const double y1 = (bcast16<1>(fj) - o.l10 * y0) * o.r1;
+#else
+            const double y0 = bcast16<0>(fj * o.r0);                       // lane 0: fj 1/L00
+            const double y1 = bcast16<1>((fj - o.r0 * y0) * o.r1);         // lane 1: (fj - L10 y0) 1/L11   (its o.r0 is L10)
+#endif
             p = fj - o.lx0 * y0 - o.lx1 * y1;
 #ifdef TMPC_EXP_MERGE_BWD
             if (rowl) *(li < NU ? ysl<CP>(L, k) + ls : L.pr + k * NX + i5) = li == 0 ? y0 : (li == 1 ? y1 : p);      // (one store: y from lanes 0, 1, p_k from lanes 2..6)
@@ -609,12 +643,17 @@ __device__ __forceinline__ void riccati_sweeps_rows(const Lds &L, const Dims &d,
 #endif
         };
         const double i_psi = li == ZPSI ? 1.0 : 0.0, i_v = li == ZV ? 1.0 : 0.0;
+        const int l01f = li == 1 ? 1 : 0;
         double *dv_own = L.dv + ls;
         const BaLane br = ba_row4(N, i5);
         auto load_stage = [&](Ops &o, int k) {
             const double *Fb = L.Hh + hoff<CP>(k);
             o.y0 = ysl<CP>(L, k)[0]; o.y1 = ysl<CP>(L, k)[1];
+#ifdef TMPC_EXP_UNIFORM_PIVOTS
             o.r0 = Fb[FB_R0]; o.l10 = Fb[FB_L10]; o.r1 = Fb[FB_R1];
+#else
+            { const double *Pv = Fb + FB_R0 + l01f; o.r0 = Pv[0]; o.r1 = Pv[1]; o.l10 = 0.0; }     // lane 0: (1/L00, L10); lane 1: (L10, 1/L11)
+#endif
             if constexpr (CP) {
                 const double *Tr = L.tab + br.o0 + mul24(k, br.st);              // own row of [B A] as (b_a, b_w, a_psi, a_v)
                 o.a_psi = Tr[2]; o.a_v = Tr[3];
@@ -649,8 +688,13 @@ __device__ __forceinline__ void riccati_sweeps_rows(const Lds &L, const Dims &d,
             for (int m = 0; m < NX; m++) { s0 = fma(lxu[2 * m], dxs[m], s0); s1 = fma(lxu[2 * m + 1], dxs[m], s1); }
             load_lxu(k + 1 < N ? k + 1 : N - 1);                           // (unconditional, clamped)
 #endif
+#ifdef TMPC_EXP_UNIFORM_PIVOTS
             const double u1 = -s1 * o.r1;
             const double u0 = (-s0 - o.l10 * u1) * o.r0;
+#else
+            const double u1 = bcast16<1>(-s1 * o.r1);                      // lane 1: -s1 1/L11
+            const double u0 = bcast16<0>((-s0 - o.r1 * u1) * o.r0);        // lane 0: (-s0 - L10 u1) 1/L00   (its o.r1 is L10)
+#endif
 #ifdef TMPC_EXP_MERGE_FWD
             if (rowl) dv_own[k * NV] = li == 0 ? u0 : (li == 1 ? u1 : dx);      // (one store: lane j writes component j of dv_k -- du from lanes 0, 1, dx from lanes 2..6)
 #else
