@@ -391,6 +391,8 @@ int tmpc_debug_lds_passes(int32_t N, int32_t n_pair, int32_t nh, int32_t threads
  * four-wave factorisation multiplied by zero without ever writing it).  tests/test_gpu_lds_poison.py solves after this call and demands the
  * un-poisoned results bit for bit, for every kernel family. */
 int tmpc_debug_poison_lds(tmpc_handle *h);
+/* 1 if this build of the library reads the TMPC_* lab switches from the environment (libtmpc_hip_lab.so, -DTMPC_LAB_SWITCHES), 0 for the product library. */
+int tmpc_has_lab_switches(void);
 
 int tmpc_debug_eval_stage(tmpc_handle *h, int32_t n, const double *z, const double *p, const double *pi,
                           const double *lamh, double *cost, double *cost_grad, double *cost_hess,

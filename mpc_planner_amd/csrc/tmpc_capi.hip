@@ -18,6 +18,15 @@ extern template __global__ void tmpc::tmpc_solve_fast_kernel<8, 8, 6, 128, true,
 #ifdef TMPC_WITH_LANES
 #include "tmpc_lanes_api.hpp"
 #else
+// Lab switches (kernel selection overrides for A/B measurements and for tests that have to reach one particular kernel family): environment variables
+// TMPC_* read when a handle is created.  They exist ONLY in a library built with -DTMPC_LAB_SWITCHES (mpc_planner_amd/libtmpc_hip_lab.so, which
+// __graft_entry__.build() links from the same kernel objects; tools/build_compact_variants.sh): the product library never reads the environment -- what a
+// drop-in does depends on the C-ABI calls alone (round-5 verdict, next-8).  INTEGRATION.md section 7 lists them.
+#ifdef TMPC_LAB_SWITCHES
+static inline const char *lab_env(const char *name) { return getenv(name); }
+#else
+static inline const char *lab_env(const char *) { return nullptr; }
+#endif
 namespace tmpc {
 namespace lanes {
 struct Context;
@@ -49,7 +58,7 @@ typedef void (*SolveKernel)(Dims, int, const double *, const double *, const dou
 static SolveKernel pick_fast_kernel(const Dims &d, int *threads, bool prof)
 {
     *threads = NT;
-    if (getenv("TMPC_FORCE_GENERIC")) return nullptr;
+    if (lab_env("TMPC_FORCE_GENERIC")) return nullptr;
     const int lps = (3 * d.N <= NT) ? 3 : ((2 * d.N <= NT) ? 2 : 0);
 #ifndef TMPC_GENERATED_STAGE
     if (d.cost_model == 1) {
@@ -57,7 +66,7 @@ static SolveKernel pick_fast_kernel(const Dims &d, int *threads, bool prof)
         // runtime-shape one-wave kernel, anything else on the generic kernel -- all instantiated with CM = 1 (no profiled twins)
         if (prof) return nullptr;
         const int nrc = d.n_up + d.M + 14;
-        if (lps != 3 && 4 * d.N <= 128 && d.n_up == 20 && d.M == 8 && !getenv("TMPC_NO_TWO_WAVE")) {
+        if (lps != 3 && 4 * d.N <= 128 && d.n_up == 20 && d.M == 8 && !lab_env("TMPC_NO_TWO_WAVE")) {
             *threads = 128;
             return (SolveKernel)tmpc_solve_fast_kernel<20, 8, 4, 128, false, Solo, 1>;
         }
@@ -69,7 +78,7 @@ static SolveKernel pick_fast_kernel(const Dims &d, int *threads, bool prof)
         // runtime-shape instantiations with CM = 2 -- two-wave for 22 <= N <= 32, one-wave for N <= 21, else the generic kernel
         if (prof) return nullptr;
         const int nrg = d.n_up + d.M + 14;
-        if (lps != 3 && 4 * d.N <= 128 && !getenv("TMPC_NO_TWO_WAVE")) {
+        if (lps != 3 && 4 * d.N <= 128 && !lab_env("TMPC_NO_TWO_WAVE")) {
             *threads = 128;
             if (d.n_up == 5 && d.M == 5) return (SolveKernel)tmpc_solve_fast_kernel<5, 5, 4, 128, false, Solo, 2>;     // mpc_planner_jackal's default (generate_jackal_solver.py:53-73), tuned
             if (nrg <= 4 * 6) return (SolveKernel)tmpc_solve_fast_kernel<-1, 6, 4, 128, false, Solo, 2>;
@@ -92,7 +101,7 @@ static SolveKernel pick_fast_kernel(const Dims &d, int *threads, bool prof)
     return nullptr;
 #else
     const int nr = d.n_up + d.M + 14;                    // interior-point rows per stage
-    if (lps != 3 && 4 * d.N <= 128 && !getenv("TMPC_NO_TWO_WAVE")) {
+    if (lps != 3 && 4 * d.N <= 128 && !lab_env("TMPC_NO_TWO_WAVE")) {
         // two waves per trajectory, 4 lanes per stage (22 <= N <= 32: the reference's default N = 30 and BASELINE cfg 3)
         SolveKernel k2 = nullptr;
         if (d.n_up == 8 && d.M == 8) k2 = TMPC_FAST(8, 8, 4, 128);
@@ -111,7 +120,7 @@ static SolveKernel pick_fast_kernel(const Dims &d, int *threads, bool prof)
         if (nr <= 3 * 7) return TMPC_FAST(-1, 7, 3, 64);                     // runtime-shape instantiations
         if (nr <= 3 * 10) return TMPC_FAST(-1, 10, 3, 64);
         if (nr <= 3 * 13) return TMPC_FAST(-1, 13, 3, 64);
-        if (d.N <= 2 * (64 / 6) && nr <= 6 * 9 && !getenv("TMPC_NO_TWO_WAVE")) {   // more rows: two waves, 6 lanes per stage
+        if (d.N <= 2 * (64 / 6) && nr <= 6 * 9 && !lab_env("TMPC_NO_TWO_WAVE")) {   // more rows: two waves, 6 lanes per stage
             *threads = 128;                                                  //   (mpc_planner_rosnavigation T-MPC: 24 + 12 rows)
             return TMPC_FAST(-1, 9, 6, 128);
         }
@@ -155,7 +164,11 @@ static SolveKernel pick_compact_kernel(const Dims &d, bool prof, int *lay)
 {
     *lay = 1;
 #ifndef TMPC_GENERATED_STAGE
-    if (getenv("TMPC_FORCE_GENERIC") || getenv("TMPC_NO_COMPACT") || prof || d.N > 20 || stage_model(d) != 0) return nullptr;
+    if (lab_env("TMPC_FORCE_GENERIC") || lab_env("TMPC_NO_COMPACT") || prof || d.N > 20 || (stage_model(d) != 0 && stage_model(d) != 2)) return nullptr;
+    if (stage_model(d) == 2) {                       // Gaussian chance-constraint rows (round 6): the run-time-shape instantiation with up to ten rows per lane
+        if (d.n_up + d.M + 14 <= 3 * 10) { *lay = compact_layout(-1, 10, 64); return (SolveKernel)tmpc_solve_compact_kernel<-1, 10, 3, false, 64, 2>; }
+        return nullptr;
+    }
     const int nr = d.n_up + d.M + 14;                    // interior-point rows per stage
     if (d.n_up == 8 && d.M == 8) return TMPC_CP(8, 8, 3);
     if (d.n_up == 0 && d.M == 4) return TMPC_CP(0, 4, 3);
@@ -176,7 +189,7 @@ static SolveKernel pick_compact2_kernel(const Dims &d, int *lay)
 {
     *lay = 1;
 #ifndef TMPC_GENERATED_STAGE
-    if (getenv("TMPC_FORCE_GENERIC") || getenv("TMPC_NO_COMPACT") || getenv("TMPC_NO_TWO_WAVE") || 3 * d.N <= NT || 4 * d.N > 128) return nullptr;
+    if (lab_env("TMPC_FORCE_GENERIC") || lab_env("TMPC_NO_COMPACT") || lab_env("TMPC_NO_TWO_WAVE") || 3 * d.N <= NT || 4 * d.N > 128) return nullptr;
     const int nr = d.n_up + d.M + 14, sm = stage_model(d);
     if (sm == 1) return (d.n_up == 20 && d.M == 8) ? TMPC_CP2(20, 8, 4, 1) : nullptr;      // cfg 3 as named (CA-MPC)
     if (sm == 2) {                                                                                                                   // Gaussian chance-constraint rows
@@ -201,7 +214,7 @@ static SolveKernel pick_compact2_kernel(const Dims &d, int *lay)
 static SolveKernel pick_latency_kernel(const Dims &d, bool prof)
 {
 #ifndef TMPC_GENERATED_STAGE
-    if (getenv("TMPC_FORCE_GENERIC") || getenv("TMPC_NO_TWO_WAVE") || d.N > 2 * (64 / 6) || stage_model(d) != 0) return nullptr;
+    if (lab_env("TMPC_FORCE_GENERIC") || lab_env("TMPC_NO_TWO_WAVE") || d.N > 2 * (64 / 6) || stage_model(d) != 0) return nullptr;
     if (d.n_up == 8 && d.M == 8) return TMPC_FAST(8, 8, 6, 128);
 #endif
     (void)d; (void)prof;
@@ -216,13 +229,18 @@ static SolveKernel pick_scan_kernel(const Dims &d, int *threads, int *sl)
 {
     *sl = 3;
 #ifndef TMPC_GENERATED_STAGE
-    if (getenv("TMPC_FORCE_GENERIC") || d.N > 31 || d.N < 2 || stage_model(d) != 0) return nullptr;
+    if (lab_env("TMPC_FORCE_GENERIC") || d.N > 31 || d.N < 2 || (stage_model(d) != 0 && stage_model(d) != 2)) return nullptr;
+    const bool gauss = stage_model(d) == 2;                      // Gaussian chance-constraint rows (mpc_planner_jackal's default stack): the run-time-shape instantiations, CM = 2
     if (d.N > 20) {                                              // 21 <= N <= 31 (cfg 3, the reference's N = 30 defaults): two lanes per stage in the
         if (d.n_up + d.M + 14 > 4 * 12) return nullptr;          // Newton solve, the runtime-shape two-wave kernel (4 lanes per stage, up to 34 rows) around it
         *threads = 128; *sl = 2;
-        return (SolveKernel)tmpc_solve_fast_kernel<-1, 12, 4, 128, false, ScanSoloT<2>>;
+        return gauss ? (SolveKernel)tmpc_solve_fast_kernel<-1, 12, 4, 128, false, ScanSoloT<2>, 2> : (SolveKernel)tmpc_solve_fast_kernel<-1, 12, 4, 128, false, ScanSoloT<2>>;
     }
-    const char *w = getenv("TMPC_SCAN_WAVES");               // A/B: "1" = one wave per trajectory
+    if (gauss) {
+        if (d.N <= 2 * (64 / 6) && d.n_up + d.M + 14 <= 6 * 9) { *threads = 128; return (SolveKernel)tmpc_solve_fast_kernel<-1, 9, 6, 128, false, ScanSolo, 2>; }
+        return nullptr;
+    }
+    const char *w = lab_env("TMPC_SCAN_WAVES");               // A/B: "1" = one wave per trajectory
     if (d.n_up == 8 && d.M == 8 && d.N <= 2 * (64 / 6) && !(w && atoi(w) == 1)) { *threads = 128; return (SolveKernel)tmpc_solve_fast_kernel<8, 8, 6, 128, false, ScanSolo>; }
     if (d.n_up == 8 && d.M == 8) { *threads = 64; return (SolveKernel)tmpc_solve_fast_kernel<8, 8, 3, 64, false, ScanSolo>; }
     if (d.N <= 2 * (64 / 6) && d.n_up + d.M + 14 <= 6 * 9) {     // every other row mix of the one-wave shapes (cfg 1, cfg 4, cfg 5, ...): runtime row counts, two waves
@@ -242,7 +260,8 @@ static SolveKernel pick_scan_kernel(const Dims &d, int *threads, int *sl)
 static SolveKernel pick_quad_kernel(const Dims &d, bool prof, bool ab)
 {
 #ifndef TMPC_GENERATED_STAGE
-    if (d.N > 20 || d.N < 2 || stage_model(d) != 0) return nullptr;
+    if (d.N > 20 || d.N < 2 || (stage_model(d) != 0 && stage_model(d) != 2)) return nullptr;
+    if (stage_model(d) == 2) return (!prof && d.n_up + d.M + 14 <= 12 * 4) ? (SolveKernel)tmpc_solve_fast_kernel<-1, 4, 12, 256, false, ScanQuad, 2> : nullptr;      // Gaussian rows
     if (d.n_up == 8 && d.M == 8) {
         if (prof) return (SolveKernel)tmpc_solve_fast_kernel<8, 8, 12, 256, true, ScanQuad>;
         return ab ? (SolveKernel)tmpc_solve_fast_kernel<8, 8, 12, 256, false, ScanSolo> : (SolveKernel)tmpc_solve_fast_kernel<8, 8, 12, 256, false, ScanQuad>;
@@ -291,7 +310,7 @@ static int d_load_passes(int N, int n_pair, int nh, int threads, int dstride)
 template <typename Allowed>
 static int pick_d_pad(int N, int n_pair, int nh, int threads, int max_pad, Allowed allowed)
 {
-    if (const char *e = getenv("TMPC_EXP_DPAD")) { const int v = atoi(e); return v >= 0 && v <= max_pad && allowed(v) ? v : 0; }   // experiments ("0": the bare strides)
+    if (const char *e = lab_env("TMPC_EXP_DPAD")) { const int v = atoi(e); return v >= 0 && v <= max_pad && allowed(v) ? v : 0; }   // experiments ("0": the bare strides)
     const int base = 2 * n_pair + 3 * (nh - n_pair);
     int best = 0, best_cost = d_load_passes(N, n_pair, nh, threads, base);
     for (int pad = 1; pad <= max_pad; pad++) {
@@ -474,7 +493,7 @@ int tmpc_create(tmpc_handle **out, const tmpc_dims *dims, int32_t B_max, int32_t
     d.split_rows = tmpc::split_rows_for(d.N, d.n_up + d.M) ? 1 : 0;
     h->kernel = d.riccati_form == TMPC_RICCATI_SQUARE_ROOT ? tmpc::pick_sqrt_kernel(d, &h->threads) : tmpc::pick_fast_kernel(d, &h->threads, false);
     if (d.riccati_form == TMPC_RICCATI_SQUARE_ROOT && !h->kernel) { delete h; return TMPC_ERR_INVALID; }       // (no square-root instantiation for this shape: never a silent other form)
-    if (const char *lm = getenv("TMPC_LATENCY_MODE")) {      // experiments: latency variant regardless of the caller ("0" .. "3"; anything else is ignored)
+    if (const char *lm = lab_env("TMPC_LATENCY_MODE")) {      // experiments: latency variant regardless of the caller ("0" .. "3"; anything else is ignored)
         if (lm[0] >= '0' && lm[0] <= '3' && lm[1] == '\0') h->latency_mode = lm[0] - '0';
     }
     h->fast = h->kernel != nullptr;
@@ -500,7 +519,7 @@ int tmpc_create(tmpc_handle **out, const tmpc_dims *dims, int32_t B_max, int32_t
         if (hipFuncSetAttribute((const void *)h->kernel_scan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes_scan) != hipSuccess)
             h->kernel_scan = nullptr;
     }
-    if (schur && h->fast && h->threads == tmpc::NT && (h->kernel_quad = tmpc::pick_quad_kernel(d, false, getenv("TMPC_QUAD_AB") != nullptr)) != nullptr) {
+    if (schur && h->fast && h->threads == tmpc::NT && (h->kernel_quad = tmpc::pick_quad_kernel(d, false, lab_env("TMPC_QUAD_AB") != nullptr)) != nullptr) {
         // fast layout + the W shares of the split linearisation (wave 0's N x 28, the obstacle lanes' 36 N: they lie inside the scan scratch, which is dead then) + the scan scratch
         h->lds_bytes_quad = h->lds_bytes_fast2 + sizeof(double) * (size_t)tmpc::scan::lds_doubles<3>(d.N);
         if (h->lds_bytes_quad > 160 * 1024 ||
@@ -515,7 +534,7 @@ int tmpc_create(tmpc_handle **out, const tmpc_dims *dims, int32_t B_max, int32_t
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&fast_per_cu, (const void *)h->kernel, 64, h->lds_bytes) == hipSuccess && fast_per_cu > 0 &&
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) {
             h->kernel_small = h->kernel; h->lds_bytes_small = h->lds_bytes; h->cp_min_B = fast_per_cu * cus;
-            if (const char *e = getenv("TMPC_COMPACT_MIN_B")) h->cp_min_B = atoi(e);                                              // experiments
+            if (const char *e = lab_env("TMPC_COMPACT_MIN_B")) h->cp_min_B = atoi(e);                                              // experiments
         }
         h->kernel = kc; h->compact = true;
         // padding of the packed rows' stage stride: only what keeps the residency (LDS is what bounds it: 8 x 20 KB at cfg 2)
@@ -553,9 +572,9 @@ int tmpc_create(tmpc_handle **out, const tmpc_dims *dims, int32_t B_max, int32_t
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0 || per_cu <= fast_per_cu)
             h->kernel_cp2 = nullptr;                         // (no gain in residency: the fast kernel stays alone)
         else {
-            if (const char *e = getenv("TMPC_COMPACT_PER_CU")) { const int v = atoi(e); if (v > 0 && v < per_cu) per_cu = v; }   // experiments
+            if (const char *e = lab_env("TMPC_COMPACT_PER_CU")) { const int v = atoi(e); if (v > 0 && v < per_cu) per_cu = v; }   // experiments
             h->grid_max = per_cu * cus; h->cp2_min_B = fast_per_cu * cus; h->prio_cp2 = per_cu * 2 == 8;
-            if (const char *e = getenv("TMPC_COMPACT2_MIN_B")) h->cp2_min_B = atoi(e);                                            // experiments
+            if (const char *e = lab_env("TMPC_COMPACT2_MIN_B")) h->cp2_min_B = atoi(e);                                            // experiments
         }
     }
     if (h->compact) {
@@ -563,7 +582,7 @@ int tmpc_create(tmpc_handle **out, const tmpc_dims *dims, int32_t B_max, int32_t
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)h->kernel, 64, h->lds_bytes) != hipSuccess || per_cu <= 0 ||
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0)
             return fail(TMPC_ERR_HIP);
-        if (const char *e = getenv("TMPC_COMPACT_PER_CU")) { const int v = atoi(e); if (v > 0 && v < per_cu) per_cu = v; }   // experiments
+        if (const char *e = lab_env("TMPC_COMPACT_PER_CU")) { const int v = atoi(e); if (v > 0 && v < per_cu) per_cu = v; }   // experiments
         h->grid_max = per_cu * cus; h->prio_cp = per_cu == 8;
     }
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return fail(TMPC_ERR_HIP);
@@ -899,6 +918,15 @@ __global__ __launch_bounds__(256) void tmpc_poison_lds_kernel(int n_doubles)
     if (poison_smem[(threadIdx.x * 97) % n_doubles] == 0.0) poison_smem[0] = 1.0;      // (keeps the stores alive)
 }
 
+int tmpc_has_lab_switches(void)
+{
+#ifdef TMPC_LAB_SWITCHES
+    return 1;
+#else
+    return 0;
+#endif
+}
+
 int tmpc_debug_poison_lds(tmpc_handle *h)
 {
     if (!h) return TMPC_ERR_INVALID;
@@ -1118,7 +1146,7 @@ int tmpc_scenario_halfspaces(tmpc_handle *h, const void *d_samples, int32_t n_pt
     TMPC_HIP_CHECK(h, hipMemsetAsync(overflow, 0, sizeof(int), h->stream));
     TMPC_HIP_CHECK(h, hipMemsetAsync(empty_stages, 0, sizeof(int) * (size_t)h->B, h->stream));
     int list_cap = tmpc::POLY_LIST_CAP;
-    if (const char *e = getenv("TMPC_POLY_LIST_CAP")) { const int v = atoi(e); if (v >= 64 && v <= 4096) list_cap = v; }   // experiments
+    if (const char *e = lab_env("TMPC_POLY_LIST_CAP")) { const int v = atoi(e); if (v >= 64 && v <= 4096) list_cap = v; }   // experiments
     const int cap1 = n_pts < list_cap ? n_pts : list_cap;
     for (int pass = 0; pass < (cap1 < n_pts ? 2 : 1); pass++) {
         const int cap = pass == 0 ? cap1 : n_pts;

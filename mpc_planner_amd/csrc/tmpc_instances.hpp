@@ -17,6 +17,11 @@
 // latency mode 3 (round 6): four waves per trajectory, twelve lanes per stage, the wide phases of the parallel-in-time factorisation on all four waves
 // (NLIN, MM, PROF, policy): the tuned cfg 2 shape + its profiled twin + its A/B twin whose factorisation stays on one wave; run-time shapes up to 48 rows
 #define TMPC_QUAD_SHAPES(X) X(8, 8, false, tmpc::ScanQuad) X(8, 8, true, tmpc::ScanQuad) X(8, 8, false, tmpc::ScanSolo) X(-1, 4, false, tmpc::ScanQuad)
+// Gaussian chance-constraint rows (CM = 2: mpc_planner_jackal's shipped default stack) on the latency variants and the one-wave compact kernel (round 6):
+// latency mode 2 (NLIN, MM, LPS, NTH, policy), latency mode 3 (NLIN, MM, policy), compact one-wave (NLIN, MM, LPS) -- run-time shapes
+#define TMPC_SCAN_G_SHAPES(X) X(-1, 12, 4, 128, tmpc::ScanSoloT<2>) X(-1, 9, 6, 128, tmpc::ScanSolo)
+#define TMPC_QUAD_G_SHAPES(X) X(-1, 4, tmpc::ScanQuad)
+#define TMPC_COMPACT_G_SHAPES(X) X(-1, 10, 3)
 // compact kernels, one wave per trajectory (NLIN, MM, LPS)
 #define TMPC_COMPACT_SHAPES(X) X(8, 8, 3) X(0, 4, 3) X(12, 12, 3) X(24, 0, 3) X(-1, 7, 3) X(-1, 10, 3)
 // compact kernels, two waves per trajectory (NLIN, MM, LPS, CM)
@@ -26,7 +31,8 @@
 
 #define TMPC_ALL_INSTANCES(KW)                                                                                                                     \
     TMPC_FAST_SHAPES(TMPC_I_FAST_##KW) TMPC_FAST_SHAPES(TMPC_I_PROF_##KW) TMPC_FAST_CM_SHAPES(TMPC_I_FASTCM_##KW) TMPC_SCAN_SHAPES(TMPC_I_SCAN_##KW) \
-    TMPC_COMPACT_SHAPES(TMPC_I_CP_##KW) TMPC_CP2_SHAPES(TMPC_I_CP2_##KW) TMPC_GENERIC_MODELS(TMPC_I_GEN_##KW) TMPC_SQRT_SHAPES(TMPC_I_SQRT_##KW) TMPC_QUAD_SHAPES(TMPC_I_QUAD_##KW)
+    TMPC_COMPACT_SHAPES(TMPC_I_CP_##KW) TMPC_CP2_SHAPES(TMPC_I_CP2_##KW) TMPC_GENERIC_MODELS(TMPC_I_GEN_##KW) TMPC_SQRT_SHAPES(TMPC_I_SQRT_##KW) TMPC_QUAD_SHAPES(TMPC_I_QUAD_##KW) \
+    TMPC_SCAN_G_SHAPES(TMPC_I_SCANG_##KW) TMPC_QUAD_G_SHAPES(TMPC_I_QUADG_##KW) TMPC_COMPACT_G_SHAPES(TMPC_I_CPG_##KW)
 // KW = DEF: explicit instantiation definition; KW = EXT: extern declaration
 #define TMPC_I_FAST_DEF(a, b, c, e) template __global__ void tmpc::tmpc_solve_fast_kernel<a, b, c, e, false>(TMPC_KARGS);
 #define TMPC_I_FAST_EXT(a, b, c, e) extern template __global__ void tmpc::tmpc_solve_fast_kernel<a, b, c, e, false>(TMPC_KARGS);
@@ -40,6 +46,12 @@
 #define TMPC_I_SQRT_EXT(a, b, c, e, m) extern template __global__ void tmpc::tmpc_solve_fast_kernel<a, b, c, e, false, tmpc::SoloSqrt, m>(TMPC_KARGS);
 #define TMPC_I_QUAD_DEF(a, b, pf, t) template __global__ void tmpc::tmpc_solve_fast_kernel<a, b, 12, 256, pf, t>(TMPC_KARGS);
 #define TMPC_I_QUAD_EXT(a, b, pf, t) extern template __global__ void tmpc::tmpc_solve_fast_kernel<a, b, 12, 256, pf, t>(TMPC_KARGS);
+#define TMPC_I_SCANG_DEF(a, b, c, e, t) template __global__ void tmpc::tmpc_solve_fast_kernel<a, b, c, e, false, t, 2>(TMPC_KARGS);
+#define TMPC_I_SCANG_EXT(a, b, c, e, t) extern template __global__ void tmpc::tmpc_solve_fast_kernel<a, b, c, e, false, t, 2>(TMPC_KARGS);
+#define TMPC_I_QUADG_DEF(a, b, t) template __global__ void tmpc::tmpc_solve_fast_kernel<a, b, 12, 256, false, t, 2>(TMPC_KARGS);
+#define TMPC_I_QUADG_EXT(a, b, t) extern template __global__ void tmpc::tmpc_solve_fast_kernel<a, b, 12, 256, false, t, 2>(TMPC_KARGS);
+#define TMPC_I_CPG_DEF(a, b, c) template __global__ void tmpc::tmpc_solve_compact_kernel<a, b, c, false, 64, 2>(TMPC_KARGS);
+#define TMPC_I_CPG_EXT(a, b, c) extern template __global__ void tmpc::tmpc_solve_compact_kernel<a, b, c, false, 64, 2>(TMPC_KARGS);
 #define TMPC_I_CP_DEF(a, b, c) template __global__ void tmpc::tmpc_solve_compact_kernel<a, b, c, false>(TMPC_KARGS);
 #define TMPC_I_CP_EXT(a, b, c) extern template __global__ void tmpc::tmpc_solve_compact_kernel<a, b, c, false>(TMPC_KARGS);
 #define TMPC_I_CP2_DEF(a, b, c, m) template __global__ void tmpc::tmpc_solve_compact_kernel<a, b, c, false, 128, m>(TMPC_KARGS);

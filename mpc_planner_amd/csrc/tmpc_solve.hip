@@ -5,7 +5,7 @@
 //   -DTMPC_TU_COMPACT   compact one-wave kernels and the parallel-in-time (latency mode 2) kernels
 //   -DTMPC_TU_PROF      profiled twins of the fast kernels (tmpc_debug_profile) + the profiled latency-mode-2 kernel
 //   -DTMPC_TU_CP2       compact two-wave kernels
-//   -DTMPC_TU_SQRT      the square-root-Riccati instantiations (tmpc_dims.riccati_form = 1)
+//   -DTMPC_TU_SQRT      the square-root-Riccati instantiations (tmpc_dims.riccati_form = 1) + the Gaussian-row latency (mode 2) and one-wave compact kernels
 //   -DTMPC_TU_QUAD      the four-wave tick kernels (latency mode 3)
 // The C-ABI -- dispatch tables, handle, entry points -- is tmpc_capi.hip; it declares every instantiation `extern`.
 // Experiment builds (tools/kernel_probe.sh): -DTMPC_SINGLE_KERNEL=<fast template arguments> / -DTMPC_SINGLE_COMPACT=<compact template arguments>
@@ -33,8 +33,11 @@ template __global__ void tmpc::tmpc_solve_fast_kernel<8, 8, 6, 128, true, tmpc::
 TMPC_CP2_SHAPES(TMPC_I_CP2_DEF)
 #elif defined(TMPC_TU_SQRT)
 TMPC_SQRT_SHAPES(TMPC_I_SQRT_DEF)
+TMPC_SCAN_G_SHAPES(TMPC_I_SCANG_DEF)
+TMPC_COMPACT_G_SHAPES(TMPC_I_CPG_DEF)
 #elif defined(TMPC_TU_QUAD)
 TMPC_QUAD_SHAPES(TMPC_I_QUAD_DEF)
+TMPC_QUAD_G_SHAPES(TMPC_I_QUADG_DEF)
 #else
 #error "tmpc_solve.hip: name the group to instantiate (-DTMPC_TU_FAST / _COMPACT / _PROF / _CP2 / _SQRT / _QUAD) or one kernel (-DTMPC_SINGLE_KERNEL= / -DTMPC_SINGLE_COMPACT=)"
 #endif

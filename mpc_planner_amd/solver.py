@@ -13,6 +13,9 @@ import numpy as np
 NU, NX, NV = 2, 5, 7
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TMPC_HIP_LIBRARY") or os.path.join(_HERE, "libtmpc_hip.so")     # (TMPC_HIP_LIBRARY: lab switch, an A/B build of the same C-ABI)
+# The same kernels behind a C-ABI unit built with -DTMPC_LAB_SWITCHES: the only library that reads the TMPC_* kernel-selection overrides from the environment
+# (tests that have to reach one kernel family, A/B tools).  The product library (LIB_PATH) ignores the environment.
+LAB_LIB_PATH = os.path.join(_HERE, "libtmpc_hip_lab.so")
 
 
 class TmpcDims(C.Structure):
@@ -44,7 +47,7 @@ EXPORTS = ["tmpc_default_dims", "tmpc_default_dims_ex", "tmpc_create", "tmpc_des
            "tmpc_debug_get_x0", "tmpc_debug_get_params", "tmpc_set_throughput_mode", "tmpc_solve_iterations",
            "tmpc_reset_multipliers", "tmpc_get_stream", "tmpc_kernel_info", "tmpc_set_slots", "tmpc_set_param_sharing", "tmpc_copy_state", "tmpc_scenario_empty_stages", "tmpc_sample_scenarios",
            "tmpc_scenario_discard", "tmpc_scenario_discarded", "tmpc_linearize_topology_ex", "tmpc_clear_slot", "tmpc_gather_best",
-           "tmpc_create_v2", "tmpc_set_param_sharing_ex", "tmpc_latency_mode_capacity", "tmpc_has_lane_kernels", "tmpc_debug_lds_passes", "tmpc_debug_poison_lds"]
+           "tmpc_create_v2", "tmpc_set_param_sharing_ex", "tmpc_latency_mode_capacity", "tmpc_has_lane_kernels", "tmpc_debug_lds_passes", "tmpc_debug_poison_lds", "tmpc_has_lab_switches"]
 
 class TmpcError(RuntimeError):
     pass

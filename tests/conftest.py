@@ -23,3 +23,16 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if item.get_closest_marker("lanes") is not None:
             item.add_marker(skip)
+
+
+import pytest
+
+
+@pytest.fixture
+def lab_library(monkeypatch):
+    """Tests that have to reach ONE kernel family set TMPC_* kernel-selection overrides in the environment.  Only the lab build of the library reads them
+    (mpc_planner_amd/libtmpc_hip_lab.so: the same kernel objects behind a C-ABI unit compiled with -DTMPC_LAB_SWITCHES); the product library ignores the
+    environment.  This fixture makes the lab library the default of mpc_planner_amd.solver for the test."""
+    from mpc_planner_amd import solver
+    monkeypatch.setattr(solver, "LIB_PATH", solver.LAB_LIB_PATH)
+    assert solver.load_library().tmpc_has_lab_switches() == 1

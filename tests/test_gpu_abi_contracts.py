@@ -92,6 +92,10 @@ def test_latency_mode_capacity_orders_the_variants():
     c0, c1, c2 = (s.latency_mode_capacity(m) for m in (0, 1, 2))
     assert c0 == 8 * cus                                         # the compact kernel: eight trajectories per CU
     assert 0 < c2 <= c1 <= c0 and c2 % cus == 0 and c1 % cus == 0
-    s5 = solver.BatchedSolver(solver.default_dims(N=20, S=5, n_lin=8, M=8, row_model=1), B_max=8)   # Gaussian rows: no latency variants
-    assert s5.latency_mode_capacity(1) == 0 and s5.latency_mode_capacity(2) == 0 and s5.latency_mode_capacity(0) > 0
-    s.close(); s5.close()
+    c3 = s.latency_mode_capacity(3)
+    assert c3 == cus                                             # four waves per trajectory: one workgroup per CU is what the variant serves
+    s5 = solver.BatchedSolver(solver.default_dims(N=20, S=5, n_lin=8, M=8, row_model=1), B_max=8)   # Gaussian rows: variants 2 and 3 since round 6, no two-wave Riccati variant
+    assert s5.latency_mode_capacity(1) == 0 and s5.latency_mode_capacity(2) > 0 and s5.latency_mode_capacity(3) == cus and s5.latency_mode_capacity(0) > 0
+    s6 = solver.BatchedSolver(solver.default_dims(N=30, S=5, n_lin=8, M=8, n_slk=12, slack=1, cost_model=1), B_max=8)   # curvature-aware cost: none
+    assert s6.latency_mode_capacity(1) == 0 and s6.latency_mode_capacity(2) == 0 and s6.latency_mode_capacity(3) == 0
+    s.close(); s5.close(); s6.close()

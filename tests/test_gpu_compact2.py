@@ -12,7 +12,7 @@ import pytest
 
 from test_gpu_parity import _compare
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("lab_library")]      # (TMPC_* kernel-selection overrides: the lab build of the library, tests/conftest.py)
 FIELDS = ("xtraj", "utraj", "pobj", "exit_code", "qp_status", "sqp_iter", "qp_iter_total", "res_eq")
 
 

@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("lab_library")]      # (TMPC_* kernel-selection overrides: the lab build of the library, tests/conftest.py)
 FIELDS = ("xtraj", "utraj", "pobj", "exit_code", "qp_status", "sqp_iter", "qp_iter_total", "res_eq")
 
 CASES = {

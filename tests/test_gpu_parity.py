@@ -432,7 +432,9 @@ def test_fast_and_generic_kernels_agree(N):
         "import sys, numpy as np; sys.path.insert(0, %r)\n"
         "from mpc_planner_amd import scenes, solver\n"
         "b = scenes.make_batch(range(300, 304), N=%d, M=8, B=64)\n"
-        "s = solver.BatchedSolver(solver.default_dims(N=%d), B_max=256); s.set_batch(b['xinit'], b['x0'], b['params']); s.solve(); g = s.get()\n"
+        "s = solver.BatchedSolver(solver.default_dims(N=%d), B_max=256, lib_path=solver.LAB_LIB_PATH)      # (the lab build: the only one that reads TMPC_FORCE_GENERIC)\n"
+        "s.set_batch(b['xinit'], b['x0'], b['params']); s.solve(); g = s.get()\n"
+        "assert ('generic' in s.kernel_info()) == ('TMPC_FORCE_GENERIC' in __import__('os').environ), s.kernel_info()\n"
         "np.savez(sys.argv[1], **g)\n" % (os.path.dirname(HERE), N, N))
     outs = []
     for env in ({}, {"TMPC_FORCE_GENERIC": "1"}):

@@ -14,6 +14,8 @@ import numpy as np
 import torch
 torch.cuda.init()
 from mpc_planner_amd import scenes, solver
+if not os.environ.get('TMPC_HIP_LIBRARY'):
+    solver.LIB_PATH = solver.LAB_LIB_PATH      # (round 6: the TMPC_* kernel-selection switches exist in the lab build of the library only)
 
 ap = argparse.ArgumentParser()
 ap.add_argument("ref", nargs="?", default="")

@@ -8,6 +8,8 @@ b = scenes.make_batch(range(800, 802), N=30, M=8, B=64)
 import torch
 torch.cuda.init()
 from mpc_planner_amd import solver
+if not os.environ.get('TMPC_HIP_LIBRARY'):
+    solver.LIB_PATH = solver.LAB_LIB_PATH      # (round 6: the TMPC_* kernel-selection switches exist in the lab build of the library only)
 res = []
 for env in (dict(TMPC_NO_COMPACT="1"), dict(TMPC_COMPACT2_MIN_B="0")):
     for k in ("TMPC_NO_COMPACT", "TMPC_COMPACT2_MIN_B"):

@@ -22,6 +22,8 @@ print("scenes ready", file=sys.stderr, flush=True)
 import torch
 torch.cuda.init()
 from mpc_planner_amd import solver
+if not os.environ.get('TMPC_HIP_LIBRARY'):
+    solver.LIB_PATH = solver.LAB_LIB_PATH      # (round 6: the TMPC_* kernel-selection switches exist in the lab build of the library only)
 for name, kw, dims_kw, _, sizes in SHAPES:
     batch = BATCHES[name]
     for B in sizes:

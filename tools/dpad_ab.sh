@@ -1,4 +1,6 @@
 #!/bin/bash
+# (the TMPC_* kernel-selection switches exist in the lab build of the library only: round 6)
+export TMPC_HIP_LIBRARY=${TMPC_HIP_LIBRARY:-${GRAFT_REPO_ROOT:-/root/repo}/mpc_planner_amd/libtmpc_hip_lab.so}
 # A/B of the row Jacobians' stage-stride padding in LDS (Dims::dpad, tmpc_capi.hip pick_d_pad): TMPC_EXP_DPAD=0 is the bare stride
 cd ${GRAFT_REPO_ROOT:-/root/repo}; export TMPDIR=/tmp; O=gpurun_out/round5_p_dpad_ab.jsonl; : > $O
 run() { # name, env value ('' = the model's choice), bench args...

@@ -1,4 +1,6 @@
 #!/bin/bash
+# (the TMPC_* kernel-selection switches exist in the lab build of the library only: round 6)
+export TMPC_HIP_LIBRARY=${TMPC_HIP_LIBRARY:-${GRAFT_REPO_ROOT:-/root/repo}/mpc_planner_amd/libtmpc_hip_lab.so}
 # Throughput of the compact kernel against residency (workgroups per CU), TMPC_COMPACT_PER_CU lab switch.
 mkdir -p gpurun_out
 out=gpurun_out/round5_l_per_cu.jsonl

@@ -1,4 +1,6 @@
 #!/bin/bash
+# (the TMPC_* kernel-selection switches exist in the lab build of the library only: round 6)
+export TMPC_HIP_LIBRARY=${TMPC_HIP_LIBRARY:-${GRAFT_REPO_ROOT:-/root/repo}/mpc_planner_amd/libtmpc_hip_lab.so}
 # round 4, GPU call 1: one-wave vs two-wave parallel-in-time kernels on saturated launches + SQ counters (tools/scan_one_wave_slope.py)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out

@@ -10,6 +10,8 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mpc_planner_amd import scenes, solver
+if not os.environ.get('TMPC_HIP_LIBRARY'):
+    solver.LIB_PATH = solver.LAB_LIB_PATH      # (round 6: the TMPC_* kernel-selection switches exist in the lab build of the library only)
 
 modes = [int(m) for m in sys.argv[1:]] or [2]
 dims = solver.default_dims(N=20)
