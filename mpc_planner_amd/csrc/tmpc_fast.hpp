@@ -640,8 +640,14 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
         double sigma = mu > 0.0 ? mu_aff / mu : 0.0;
         sigma = sigma * sigma * sigma;
         // ---- corrector rhs: gh = rg + sum c (qt + d rd) ----
+        // Round 6: the predictor's right-hand side is still in gh (the factorisation and the solves only read it) and differs from the corrector's by
+        // sum c (qt - lam) -- gh_pred = rg0 + sum c d rd, gh_corr = rg0 - sum lam c + sum c (qt + d rd) --, so the row pass ADDS that difference in place: no
+        // copy of rg into gh, no barrier before the pass, no row residuals in it (-DTMPC_EXP_RHS_COPY rebuilds the copy form; the sums associate differently:
+        // rounding level)
+#ifdef TMPC_EXP_RHS_COPY
         for (int e = tl; e < (N + 1) * NV; e += NT) L.gh[e] = L.rg[e];
         team.sync();
+#endif
         ROW_PASS_BEGIN();
         {
             double cs0 = 0, cs1 = 0, cs2 = 0;
@@ -656,8 +662,12 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
                 qt[s] = a ? lam[s] + (dta * dl - sigma * mu) * INVT(s) : 0.0;
                 double c0s, c1s, c2s;
                 coef(s_, c0s, c1s, c2s);
+#ifdef TMPC_EXP_RHS_COPY
                 const double rr = rowdot(s_, c0s, c1s, c2s, vx, vy, vp, L.v + mul24(kk, NV)) - sb[s] - t[s];
                 const double w = qt[s] + lam[s] * INVT(s) * (a ? rr : 0.0);
+#else
+                const double w = a ? qt[s] - lam[s] : 0.0;
+#endif
                 if constexpr (K != 1) { cs0 += w * c0s; cs1 += w * c1s; cs2 += w * c2s; }
                 if constexpr (K != 0) { if (a && (K == 1 || (box >> s & 1))) lds_add(&L.gh[mul24(k, NV) + VARK(s_)], w * CUK(s_)); }
             });

@@ -752,8 +752,12 @@ __device__ __forceinline__ void riccati_forward(const Lds &L, const Dims &d, int
     riccati_sweeps_rows<CP, false>(L, d, lane, true, sweeper, [] {});
     TMPC_PRIO_LOW();
     __syncthreads();
+#ifdef TMPC_EXP_PREDICTOR_POST
     riccati_solve_post<CP, SQ, SQ>(L, d, tid, NTH);      // (square-root form: the extra row left lx, not p)
     __syncthreads();
+#endif
+    // (round 6: no closing loop here.  dpi = P dx + p is the step of the dynamics multipliers, and the PREDICTOR's is never used -- the row passes between
+    //  predictor and corrector read dv only, the update takes the corrector's dpi: one stage-parallel pass and one barrier per interior-point iteration less)
 }
 
 }  // namespace tmpc
