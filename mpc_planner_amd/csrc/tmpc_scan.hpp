@@ -14,7 +14,9 @@
 //   factor, cyclic reduction one lane per COLUMN of the couplings [Lc Rc] of an eliminated block (two per lane at level 0, ten
 //                            blocks): in-register Cholesky of D_j (5 x 5), w = D_j^-1 column, Lc^T w / Rc^T w update the neighbours'
 //                            diagonal blocks and create their new coupling; W = D^-1 [Lc Rc] replaces [Lc Rc]
-//   solve (per right-hand side)  beta from P_k g_k (the predictor's rides through the stage phase); forward elimination beta_{j -+ s} -= W^T beta_j and back
+//   solve (per right-hand side)  beta from P_k g_k; forward elimination beta_{j -+ s} -= W^T beta_j and back  (round 6: for the right-hand side the factorisation
+//                            saw -- the predictor's -- beta and its forward elimination ride through the stage phase and the reduction levels, whose lanes
+//                            hold the columns of W anyway: one dot product and one ds_add_f64 per lane and level; solve(pred) starts at D^-1 beta)
 //                            substitution pi_j = D_j^-1 beta_j - W_L pi_{j-s} - W_R pi_{j+s} with one lane per row of a block; the
 //                            steps dv_k per stage.  Only g changes between predictor and corrector: the factor is reused.
 // dx_0 = 0 and du_N = 0 enter as decoupled blocks of H_0 / H_N (a 1e40 weight on dx_0), so every stage runs the same code.
@@ -244,6 +246,10 @@ __device__ __forceinline__ bool stage_phase(const ViewT<SL> &V, int lane)
         if (s == 10 / CL) {
 #pragma unroll
             for (int i = 0; i < SNV; i++) V.zg()[k * SNV + i] = z[10 % CL][i];
+            if (k < N) {                                     // beta_k = rb_k - F_k P_k g_k (stored) ... + E P_{k+1} g_{k+1} (added below: program order of the wave)
+#pragma unroll
+                for (int i = 0; i < SNX; i++) blk[k * BS + OB + i] = V.rb[k * SNX + i] - o[10 % CL][i];
+            }
         }
         // D_k = F P F^T (stored: every column of every block exactly once) ...
 #pragma unroll
@@ -267,6 +273,10 @@ __device__ __forceinline__ bool stage_phase(const ViewT<SL> &V, int lane)
                 }
             }
         }
+        if (s == 10 / CL && k >= 1) {
+#pragma unroll
+            for (int i = 0; i < SNX; i++) add_lds(&blk[(k - 1) * BS + OB + i], z[10 % CL][SNU + i]);
+        }
     }
     fence();
     SCAN_T(3);
@@ -286,7 +296,7 @@ __device__ __forceinline__ bool cr_level(const ViewT<SL> &V, int lane, int s)
     const int o = s * (2 * m + 1), el = o - s, er = o + s;   // eliminated block and its neighbours at this level
     const bool act = o < N, has_r = er < N;
     bool bad = false;
-    double w[CPL][SNX], a[CPL][SNX], b[CPL][SNX];
+    double w[CPL][SNX], a[CPL][SNX], b[CPL][SNX], wb[CPL];
     double *bo = blk + (act ? o : 0) * BS;
     const double *br = (act && has_r) ? blk + er * BS + OL : V.zeros();   // Rc_o = Lc_er^T (zeros without a right neighbour: no selects on the data)
     SCAN_T0();
@@ -309,6 +319,9 @@ __device__ __forceinline__ bool cr_level(const ViewT<SL> &V, int lane, int s)
 #pragma unroll
             for (int i = 0; i < SNX; i++) w[t][i] = wp[i * ws];
         }
+        double beo[SNX];                                     // beta_o of the right-hand side riding along (complete: every earlier level has fenced)
+#pragma unroll
+        for (int i = 0; i < SNX; i++) beo[i] = bo[OB + i];
         loads_done();
         SCAN_T(10);
         bad = chol_inlane<SNX>(L);
@@ -318,6 +331,13 @@ __device__ __forceinline__ bool cr_level(const ViewT<SL> &V, int lane, int s)
             for (int e = 0; e < 15; e++) bo[OLD + e] = L[e];
         }
         chol_solve<SNX, CPL>(L, w);
+#pragma unroll
+        for (int t = 0; t < CPL; t++) {                      // (W^T beta_o)_c = w_c . beta_o
+            double dsum = 0.0;
+#pragma unroll
+            for (int r = 0; r < SNX; r++) dsum = fma(w[t][r], beo[r], dsum);
+            wb[t] = dsum;
+        }
 #pragma unroll
         for (int t = 0; t < CPL; t++)
 #pragma unroll
@@ -343,6 +363,7 @@ __device__ __forceinline__ bool cr_level(const ViewT<SL> &V, int lane, int s)
             if (cid < 5) {
 #pragma unroll
                 for (int i = 0; i < SNX; i++) add_lds(&blk[el * BS + OD + c * 5 + i], -a[0][i]);
+                add_lds(&blk[el * BS + OB + c], -wb[0]);                                           // beta_el -= W_L^T beta_o
             }
         }
         __syncthreads();
@@ -352,6 +373,7 @@ __device__ __forceinline__ bool cr_level(const ViewT<SL> &V, int lane, int s)
                 blk[er * BS + OL + i * 5 + c] = -a[0][i];
                 add_lds(&blk[er * BS + OD + c * 5 + i], -b[0][i]);
             }
+            add_lds(&blk[er * BS + OB + c], -wb[0]);                                               // beta_er -= W_R^T beta_o
         }
         __syncthreads();
         return bad;
@@ -366,12 +388,14 @@ __device__ __forceinline__ bool cr_level(const ViewT<SL> &V, int lane, int s)
             if (cid < 5) {
 #pragma unroll
                 for (int i = 0; i < SNX; i++) add_lds(&blk[el * BS + OD + c * 5 + i], -a[t][i]);       // D_el -= Lc^T D^-1 Lc (whole columns: masking the unused upper triangle costs more than it saves)
+                add_lds(&blk[el * BS + OB + c], -wb[t]);                                               // beta_el -= W_L^T beta_o (the right-hand side riding along)
             } else if (has_r) {
 #pragma unroll
                 for (int i = 0; i < SNX; i++) {
                     blk[er * BS + OL + i * 5 + c] = -a[t][i];                                          // new coupling er -- el: -(Lc^T D^-1 Rc)^T
                     add_lds(&blk[er * BS + OD + c * 5 + i], -b[t][i]);                                 // D_er -= Rc^T D^-1 Rc
                 }
+                add_lds(&blk[er * BS + OB + c], -wb[t]);                                               // beta_er -= W_R^T beta_o
             }
         }
     }
@@ -496,6 +520,10 @@ __device__ __forceinline__ bool stage_phase4(const ViewT<SL> &V, int tid)
 #pragma unroll
             for (int i = 0; i < SNX; i++) blk[kc * BS + OD + cid * 5 + i] = o[i];
         }
+        if (cid == 10 && kc < N) {                                            // beta_k = rb_k - F_k P_k g_k: stored here, E P_{k+1} g_{k+1} added after the barrier
+#pragma unroll
+            for (int i = 0; i < SNX; i++) blk[kc * BS + OB + i] = V.rb[kc * SNX + i] - o[i];
+        }
         if (!reg && cid < 10) {                                               // node 20 on the spare lanes: its columns 0 .. 4 (F^T, no F there) are zero --
             double *Z0 = V.Zs() + (SL * kc + (cid - 5) / CL) * ZL + ((cid - 5) % CL) * SNV;      // stored, because solve() multiplies them (by zero)
 #pragma unroll
@@ -511,6 +539,10 @@ __device__ __forceinline__ bool stage_phase4(const ViewT<SL> &V, int tid)
 #pragma unroll
             for (int i = 0; i < SNX; i++) blk[kc * BS + OL + c * 5 + i] = -o[i];
         }
+    }
+    if (live && cid == 10 && kc >= 1) {
+#pragma unroll
+        for (int i = 0; i < SNX; i++) add_lds(&blk[(kc - 1) * BS + OB + i], z[0][SNU + i]);
     }
     __syncthreads();
     return bad;
@@ -555,9 +587,9 @@ __device__ __forceinline__ void solve(const ViewT<SL> &V, int lane, bool pred)
     double *blk = V.blk;
     const int k = lane / SL, s3 = lane - SL * k;
     SCAN_T0();
-    for (int e = lane; e < N * SNX; e += 64) blk[(e / SNX) * BS + OB + e % SNX] = V.rb[e];
     const bool stage_lane = lane < SL * (N + 1) && s3 == 0;
     if (!pred) {
+        for (int e = lane; e < N * SNX; e += 64) blk[(e / SNX) * BS + OB + e % SNX] = V.rb[e];
         if (stage_lane) {
             double L[28], z[1][SNV];
 #pragma unroll
@@ -572,7 +604,7 @@ __device__ __forceinline__ void solve(const ViewT<SL> &V, int lane, bool pred)
     }
     fence();
     SCAN_T(4);
-    {                                                        // beta_j = rb_j - F_j P_j g_j + E P_{j+1} g_{j+1}
+    if (!pred) {                                             // beta_j = rb_j - F_j P_j g_j + E P_{j+1} g_{j+1}   (pred: the factorisation left beta forward-eliminated)
         const int kc = stage_lane ? k : 0;
         BaRow F;
         ba_load(kc < N ? V.BA + kc * SNX * SNV : V.zeros(), F, true);
@@ -594,7 +626,7 @@ __device__ __forceinline__ void solve(const ViewT<SL> &V, int lane, bool pred)
     SCAN_T(5);
     const int m = lane / 5, i5 = lane - 5 * m;              // one lane per row of a block: 12 blocks per pass
 #pragma unroll 1
-    for (int s = 1; s < N; s *= 2) {                         // forward elimination: beta_{o -+ s} -= W^T beta_o
+    for (int s = pred ? N : 1; s < N; s *= 2) {              // forward elimination: beta_{o -+ s} -= W^T beta_o
 #pragma unroll 1
         for (int m0 = 0; s * (2 * m0 + 1) < N && (SL == 2 || m0 == 0); m0 += 12) {      // (N <= 20: at most ten blocks per level, one pass)
             const int o = s * (2 * (m0 + m) + 1), el = o - s, er = o + s;

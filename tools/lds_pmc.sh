@@ -17,4 +17,4 @@ for r in rows:
 print(json.dumps({'counters': sys.argv[1], 'mean_per_launch': {k: sum(v) / len(v) for k, v in acc.items()}, 'launches': {k: len(v) for k, v in acc.items()}}))
 PY
   rm -rf $d
-done | tee gpurun_out/round5_s_lds_pmc_after.jsonl
+done | tee gpurun_out/${OUT:-round6_lds_pmc.jsonl}
