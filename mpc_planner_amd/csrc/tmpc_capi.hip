@@ -257,9 +257,19 @@ static SolveKernel pick_scan_kernel(const Dims &d, int *threads, int *sl)
 // factorisation (the stage phase: one column per lane instead of four; level 0 of the cyclic reduction: one instead of two) use all 256 lanes
 // (csrc/tmpc_scan.hpp factor4).  Same algorithm as variant 2 (sums associate differently: rounding level).  N <= 20, hand-written MPCC stages.
 // `ab`: TMPC_QUAD_AB=1 in a lab build picks the twin whose factorisation stays on one wave (A/B of the factorisation split alone).
-static SolveKernel pick_quad_kernel(const Dims &d, bool prof, bool ab)
+static SolveKernel pick_quad_kernel(const Dims &d, bool prof, bool ab, int *sl = nullptr)
 {
+    if (sl) *sl = 3;
 #ifndef TMPC_GENERATED_STAGE
+    if (d.N > 20 && d.N <= 31 && !prof && !ab && d.n_up + d.M + 14 <= 8 * 6) {
+        // 21 <= N <= 31 (the horizon the reference ships for jackal / jackalsimulator: N = 30): eight lanes per stage around the two-lanes-per-stage Newton solve;
+        // every stage model (the four-wave linearisation regularises a coupled W -- curvature-aware cost -- on wave 0)
+        if (sl) *sl = 2;
+        const int sm = stage_model(d);
+        return sm == 0 ? (SolveKernel)tmpc_solve_fast_kernel<-1, 6, 8, 256, false, ScanQuadT<2>, 0>
+             : sm == 1 ? (SolveKernel)tmpc_solve_fast_kernel<-1, 6, 8, 256, false, ScanQuadT<2>, 1>
+             : sm == 2 ? (SolveKernel)tmpc_solve_fast_kernel<-1, 6, 8, 256, false, ScanQuadT<2>, 2> : nullptr;
+    }
     if (d.N > 20 || d.N < 2 || (stage_model(d) != 0 && stage_model(d) != 2)) return nullptr;
     if (stage_model(d) == 2) return (!prof && d.n_up + d.M + 14 <= 12 * 4) ? (SolveKernel)tmpc_solve_fast_kernel<-1, 4, 12, 256, false, ScanQuad, 2> : nullptr;      // Gaussian rows
     if (d.n_up == 8 && d.M == 8) {
@@ -519,9 +529,10 @@ int tmpc_create(tmpc_handle **out, const tmpc_dims *dims, int32_t B_max, int32_t
         if (hipFuncSetAttribute((const void *)h->kernel_scan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes_scan) != hipSuccess)
             h->kernel_scan = nullptr;
     }
-    if (schur && h->fast && h->threads == tmpc::NT && (h->kernel_quad = tmpc::pick_quad_kernel(d, false, lab_env("TMPC_QUAD_AB") != nullptr)) != nullptr) {
-        // fast layout + the W shares of the split linearisation (wave 0's N x 28, the obstacle lanes' 36 N: they lie inside the scan scratch, which is dead then) + the scan scratch
-        h->lds_bytes_quad = h->lds_bytes_fast2 + sizeof(double) * (size_t)tmpc::scan::lds_doubles<3>(d.N);
+    int quad_sl = 3;
+    if (schur && h->fast && (h->threads == tmpc::NT || d.N > 20) && (h->kernel_quad = tmpc::pick_quad_kernel(d, false, lab_env("TMPC_QUAD_AB") != nullptr, &quad_sl)) != nullptr) {
+        // fast layout + the W shares of the split linearisation (wave 0's N x 28, the obstacle lanes' 36 N / 24 N: they lie inside the scan scratch, which is dead then) + the scan scratch
+        h->lds_bytes_quad = h->lds_bytes_fast2 + sizeof(double) * (size_t)(quad_sl == 3 ? tmpc::scan::lds_doubles<3>(d.N) : tmpc::scan::lds_doubles<2>(d.N));
         if (h->lds_bytes_quad > 160 * 1024 ||
             hipFuncSetAttribute((const void *)h->kernel_quad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes_quad) != hipSuccess)
             h->kernel_quad = nullptr;

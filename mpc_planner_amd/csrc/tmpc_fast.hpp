@@ -186,9 +186,10 @@ struct ScanSoloT {
 };
 using ScanSolo = ScanSoloT<3>;
 
-// Four waves per trajectory (NTH = 256, N <= 20; round 6): the factorisation's wide phases -- the stage phase and level 0 of the cyclic reduction -- run
-// on all four waves (scan::factor4), the solves on wave 0 (their levels are a few lanes wide: more waves have nothing to do there).
-struct ScanQuad {
+// Four waves per trajectory (NTH = 256; round 6): the factorisation's wide phases -- the stage phase and level 0 of the cyclic reduction -- run
+// on all four waves (scan::factor4), the solves on wave 0 (their levels are a few lanes wide: more waves have nothing to do there).  SL as in ScanSoloT.
+template <int SL>
+struct ScanQuadT {
     static constexpr int NQ = 1;
     __device__ __forceinline__ bool alive() const { return true; }
     __device__ __forceinline__ void sync() const { __syncthreads(); }
@@ -198,7 +199,7 @@ struct ScanQuad {
     {
         static_assert(!CP && NTH == 256, "fast layout, four waves");
         asm volatile("" : "+v"(tl));
-        const scan::ViewT<3> V{L.Hh, L.BA, L.gh, L.rb, L.dv, L.dpi, L.scan + d.N * NP28, d.N};
+        const scan::ViewT<SL> V{L.Hh, L.BA, L.gh, L.rb, L.dv, L.dpi, L.scan + d.N * NP28, d.N};
         return scan::factor4(V, tl, L.scr + 48);
     }
     template <int NTH, int CP>
@@ -206,12 +207,13 @@ struct ScanQuad {
     {
         asm volatile("" : "+v"(tl));
         if (tl < 64) {
-            const scan::ViewT<3> V{L.Hh, L.BA, L.gh, L.rb, L.dv, L.dpi, L.scan + d.N * NP28, d.N};
+            const scan::ViewT<SL> V{L.Hh, L.BA, L.gh, L.rb, L.dv, L.dpi, L.scan + d.N * NP28, d.N};
             scan::solve(V, tl, phase == 1);
         }
         __syncthreads();
     }
 };
+using ScanQuad = ScanQuadT<3>;
 
 template <int NLIN, int MM, int LPS, int NTH, int CP, typename PF, typename TEAM = Solo>
 __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, const double *xi, int *iters_out, PF &pf,
@@ -221,6 +223,8 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
     using C = FastCfg<NLIN, MM, LPS>;
     constexpr int RPL = C::RPL;
     constexpr bool OCC2 = CP;                       // compact instantiations are built for two waves per SIMD (<= 256 registers)
+    constexpr bool QSUM = NTH == 256;               // four-wave kernels (12 or 8 lanes per stage): the stage sums are pre-reduced per aligned quad
+    static_assert(!QSUM || LPS % 4 == 0, "quad pre-reduction: whole quads per stage");
     // compile-time constants for the tuned shapes, kernel arguments for runtime-shape instantiations
     const int NH = C::RT ? L.nh : C::NH, NR = NH + 14, NLIN_ = C::RT ? d.n_up : NLIN;
     constexpr bool DIET = (LPS == 6 && NLIN == 8) || OCC2;                // 256-register budget (two waves per SIMD): recompute per-row values instead of storing them
@@ -552,12 +556,12 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
             // Twelve lanes per stage (the four-wave kernel): a ds_add_f64 whose lanes hit the same address is serialised, and twelve lanes of a stage adding to
             // one entry cost that phase twice what six did (measured: 328 k instead of 164 k cycles per solve).  The stage's lanes 12 s .. 12 s + 11 are three
             // aligned quads: two DPP quad permutations sum each quad in registers, its first lane adds -- three-way conflicts, like the one-wave kernels.
-            if constexpr (LPS == 12) {
+            if constexpr (QSUM) {
                 auto quad = [](double x) { x += dpp_move<0xB1, 0xf>(x, 0.0); x += dpp_move<0x4E, 0xf>(x, 0.0); return x; };      // quad_perm [1,0,3,2], then [2,3,0,1]
                 gs0 = quad(gs0); gs1 = quad(gs1); gs2 = quad(gs2); rs0 = quad(rs0); rs1 = quad(rs1); rs2 = quad(rs2);
                 h00 = quad(h00); h10 = quad(h10); h11 = quad(h11); h20 = quad(h20); h21 = quad(h21); h22 = quad(h22);
             }
-            if (stage_lane && (LPS != 12 || (c & 3) == 0)) {
+            if (stage_lane && (!QSUM || (c & 3) == 0)) {
                 lds_add(&L.rg[mul24(k, NV) + ZX], -gs0); lds_add(&L.rg[mul24(k, NV) + ZY], -gs1); lds_add(&L.rg[mul24(k, NV) + ZPSI], -gs2);
                 lds_add(&L.gh[mul24(k, NV) + ZX], rs0); lds_add(&L.gh[mul24(k, NV) + ZY], rs1); lds_add(&L.gh[mul24(k, NV) + ZPSI], rs2);
                 double *Hk = L.Hh + hoff_lane<CP>(k);
@@ -671,11 +675,11 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
                 if constexpr (K != 1) { cs0 += w * c0s; cs1 += w * c1s; cs2 += w * c2s; }
                 if constexpr (K != 0) { if (a && (K == 1 || (box >> s & 1))) lds_add(&L.gh[mul24(k, NV) + VARK(s_)], w * CUK(s_)); }
             });
-            if constexpr (LPS == 12) {
+            if constexpr (QSUM) {
                 auto quad = [](double x) { x += dpp_move<0xB1, 0xf>(x, 0.0); x += dpp_move<0x4E, 0xf>(x, 0.0); return x; };
                 cs0 = quad(cs0); cs1 = quad(cs1); cs2 = quad(cs2);
             }
-            if (stage_lane && (LPS != 12 || (c & 3) == 0)) { lds_add(&L.gh[mul24(k, NV) + ZX], cs0); lds_add(&L.gh[mul24(k, NV) + ZY], cs1); lds_add(&L.gh[mul24(k, NV) + ZPSI], cs2); }
+            if (stage_lane && (!QSUM || (c & 3) == 0)) { lds_add(&L.gh[mul24(k, NV) + ZX], cs0); lds_add(&L.gh[mul24(k, NV) + ZY], cs1); lds_add(&L.gh[mul24(k, NV) + ZPSI], cs2); }
         }
         team.sync();
         }

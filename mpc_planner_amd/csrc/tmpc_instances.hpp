@@ -21,6 +21,8 @@
 // latency mode 2 (NLIN, MM, LPS, NTH, policy), latency mode 3 (NLIN, MM, policy), compact one-wave (NLIN, MM, LPS) -- run-time shapes
 #define TMPC_SCAN_G_SHAPES(X) X(-1, 12, 4, 128, tmpc::ScanSoloT<2>) X(-1, 9, 6, 128, tmpc::ScanSolo)
 #define TMPC_QUAD_G_SHAPES(X) X(-1, 4, tmpc::ScanQuad)
+// latency mode 3 for 21 <= N <= 31 (the shipped jackal / jackalsimulator horizon N = 30): eight lanes per stage, run-time row mix up to 34 rows (MM, CM)
+#define TMPC_QUAD_W_SHAPES(X) X(6, 0) X(6, 1) X(6, 2)
 #define TMPC_COMPACT_G_SHAPES(X) X(-1, 10, 3)
 // compact kernels, one wave per trajectory (NLIN, MM, LPS)
 #define TMPC_COMPACT_SHAPES(X) X(8, 8, 3) X(0, 4, 3) X(12, 12, 3) X(24, 0, 3) X(-1, 7, 3) X(-1, 10, 3)
@@ -32,7 +34,7 @@
 #define TMPC_ALL_INSTANCES(KW)                                                                                                                     \
     TMPC_FAST_SHAPES(TMPC_I_FAST_##KW) TMPC_FAST_SHAPES(TMPC_I_PROF_##KW) TMPC_FAST_CM_SHAPES(TMPC_I_FASTCM_##KW) TMPC_SCAN_SHAPES(TMPC_I_SCAN_##KW) \
     TMPC_COMPACT_SHAPES(TMPC_I_CP_##KW) TMPC_CP2_SHAPES(TMPC_I_CP2_##KW) TMPC_GENERIC_MODELS(TMPC_I_GEN_##KW) TMPC_SQRT_SHAPES(TMPC_I_SQRT_##KW) TMPC_QUAD_SHAPES(TMPC_I_QUAD_##KW) \
-    TMPC_SCAN_G_SHAPES(TMPC_I_SCANG_##KW) TMPC_QUAD_G_SHAPES(TMPC_I_QUADG_##KW) TMPC_COMPACT_G_SHAPES(TMPC_I_CPG_##KW)
+    TMPC_SCAN_G_SHAPES(TMPC_I_SCANG_##KW) TMPC_QUAD_G_SHAPES(TMPC_I_QUADG_##KW) TMPC_QUAD_W_SHAPES(TMPC_I_QUADW_##KW) TMPC_COMPACT_G_SHAPES(TMPC_I_CPG_##KW)
 // KW = DEF: explicit instantiation definition; KW = EXT: extern declaration
 #define TMPC_I_FAST_DEF(a, b, c, e) template __global__ void tmpc::tmpc_solve_fast_kernel<a, b, c, e, false>(TMPC_KARGS);
 #define TMPC_I_FAST_EXT(a, b, c, e) extern template __global__ void tmpc::tmpc_solve_fast_kernel<a, b, c, e, false>(TMPC_KARGS);
@@ -50,6 +52,8 @@
 #define TMPC_I_SCANG_EXT(a, b, c, e, t) extern template __global__ void tmpc::tmpc_solve_fast_kernel<a, b, c, e, false, t, 2>(TMPC_KARGS);
 #define TMPC_I_QUADG_DEF(a, b, t) template __global__ void tmpc::tmpc_solve_fast_kernel<a, b, 12, 256, false, t, 2>(TMPC_KARGS);
 #define TMPC_I_QUADG_EXT(a, b, t) extern template __global__ void tmpc::tmpc_solve_fast_kernel<a, b, 12, 256, false, t, 2>(TMPC_KARGS);
+#define TMPC_I_QUADW_DEF(b, m) template __global__ void tmpc::tmpc_solve_fast_kernel<-1, b, 8, 256, false, tmpc::ScanQuadT<2>, m>(TMPC_KARGS);
+#define TMPC_I_QUADW_EXT(b, m) extern template __global__ void tmpc::tmpc_solve_fast_kernel<-1, b, 8, 256, false, tmpc::ScanQuadT<2>, m>(TMPC_KARGS);
 #define TMPC_I_CPG_DEF(a, b, c) template __global__ void tmpc::tmpc_solve_compact_kernel<a, b, c, false, 64, 2>(TMPC_KARGS);
 #define TMPC_I_CPG_EXT(a, b, c) extern template __global__ void tmpc::tmpc_solve_compact_kernel<a, b, c, false, 64, 2>(TMPC_KARGS);
 #define TMPC_I_CP_DEF(a, b, c) template __global__ void tmpc::tmpc_solve_compact_kernel<a, b, c, false>(TMPC_KARGS);

@@ -697,15 +697,18 @@ __device__ __forceinline__ void linearise(const Lds &L, const Dims &d, int tid, 
         // share of the Hessian), wave 1 the cost and the halfspace / scenario rows, waves 2 and 3 the obstacle rows -- three lanes per stage each, so a
         // lane evaluates at most ceil(M / 6) rows.  The shares of W meet in LDS (the scan scratch behind the layout is dead while the stage blocks are
         // built); MIRROR's two diagonal blocks then run on waves 0 and 1 as in the two-wave kernels.  W = W_dyn + W_cost + sum of the six obstacle
-        // shares, in that order (associates differently from the one-wave sum: rounding level).  Fast layout only (N <= 20: 3 N <= 64 lanes per wave).
+        // shares, in that order (associates differently from the one-wave sum: rounding level).  Fast layout only.  N <= 21: three lanes per stage on the
+        // obstacle waves (six shares); 22 <= N <= 32 (the shipped jackal / jackalsimulator horizon, N = 30): two (four shares).
         static_assert(!CP, "four-wave linearisation: fast layout");
         int tid_l = tid;
         asm volatile("" : "+v"(tid_l));
         const int wv = tid_l >> 6, ln = tid_l & 63;
+        const int G = 3 * N <= 64 ? 3 : 2;                         // lane groups of a wave
         const int grp = ln >= 2 * N ? 2 : (ln >= N ? 1 : 0);       // lane group inside the wave: 0 owner, 1 / 2 helpers (waves 2, 3 only)
         const bool owner = ln < N;                                  // (full EXEC mask: other lanes redo a stage and do not store)
-        const bool rowlane = wv >= 2 && ln < 3 * N;                 // an obstacle-row lane
-        const int k = ln < 3 * N ? ln - grp * N : N - 1;
+        const bool inrng = ln < G * N;
+        const bool rowlane = wv >= 2 && inrng;                      // an obstacle-row lane
+        const int k = inrng ? ln - grp * N : N - 1;
         double z[NV];
 #pragma unroll
         for (int i = 0; i < NV; i++) z[i] = L.z[k * NV + i];
@@ -724,7 +727,7 @@ __device__ __forceinline__ void linearise(const Lds &L, const Dims &d, int tid, 
                 L.beta[k * nh + r] = bound - ro.h;
             }
         };
-        // exchange region: [0, N 28): wave 0's share of W (as in the two-wave kernels); [N 28, N 28 + 6 N 6): the obstacle lanes' shares (x, y, psi block)
+        // exchange region: [0, N 28): wave 0's share of W (as in the two-wave kernels); [N 28, N 28 + 2 G N 6): the obstacle lanes' shares (x, y, psi block)
         double *W0s = L.scan + k * NP28;
         double *Wes = L.scan + N * NP28;
         if (wv == 0) {                                           // dynamics
@@ -753,8 +756,8 @@ __device__ __forceinline__ void linearise(const Lds &L, const Dims &d, int tid, 
                     for (int j = 0; j <= i; j++) L.W[k * NP28 + pidx(i, j)] = W[i][j];
             }
         } else {                                                 // obstacle rows: lane (wave, group) takes rows first, first + 6, ...
-            const int first_ = (wv - 2) * 3 + grp;
-            stage_linearise<CM>(d, z, p, 1, 0.0, 0.0, lamh, sink, W, g, BA, xn, slack, nullptr, own_delta, 5, [&]() { return first_; }, 6, true);
+            const int first_ = (wv - 2) * G + grp;
+            stage_linearise<CM>(d, z, p, 1, 0.0, 0.0, lamh, sink, W, g, BA, xn, slack, nullptr, own_delta, 5, [&]() { return first_; }, 2 * G, true);
             if (rowlane) {
                 double *x = Wes + (first_ * N + k) * 6;
                 x[0] = W[ZX][ZX]; x[1] = W[ZX][ZY]; x[2] = W[ZY][ZY]; x[3] = W[ZX][ZPSI]; x[4] = W[ZY][ZPSI]; x[5] = W[ZPSI][ZPSI];
@@ -775,6 +778,7 @@ __device__ __forceinline__ void linearise(const Lds &L, const Dims &d, int tid, 
             for (int q = 0; q < 6; q++) e6[q] = 0.0;
 #pragma unroll
             for (int s6 = 0; s6 < 6; s6++) {
+                if (s6 >= 2 * G) break;
                 const double *x = Wes + (s6 * N + k) * 6;
 #pragma unroll
                 for (int q = 0; q < 6; q++) e6[q] += x[q];

@@ -548,18 +548,115 @@ __device__ __forceinline__ bool stage_phase4(const ViewT<SL> &V, int tid)
     return bad;
 }
 
+// The same phase for 21 <= N <= 31 (SL = 2: the shipped jackal / jackalsimulator horizon N = 30): TWO columns per lane -- six lanes per stage, ten stages per wave
+// (60 lanes), so the 32 nodes fit the four waves without spare-lane tricks.  Lane s6 of a stage takes the columns 2 s6 and 2 s6 + 1; slot 11 is the zero
+// column (computed and stored like the one-wave phase does: solve() multiplies it).  Stores, barrier, adds as above.
+template <int SL>
+__device__ __forceinline__ bool stage_phase4_pairs(const ViewT<SL> &V, int tid)
+{
+    constexpr int CL = Cfg<SL>::CL, ZL = Cfg<SL>::ZL;
+    const int N = V.N;
+    double *blk = V.blk;
+    pin_structural_entries(V, tid);
+    __syncthreads();
+    const int wv = tid >> 6, l = tid & 63;
+    const int k = 10 * wv + l / 6, s6 = l % 6;
+    const bool live = l < 60 && k <= N;
+    const int kc = live ? k : 0;
+    bool bad = false;
+    double z[2][SNV], o[2][SNX];
+    {
+        double L[28];
+        const double *Hk = V.Hh + kc * 28;
+#pragma unroll
+        for (int e = 0; e < 28; e++) L[e] = Hk[e];
+        BaRow F;
+        ba_load(kc < N ? V.BA + kc * SNX * SNV : V.zeros(), F, true);
+        double gk[SNV];
+#pragma unroll
+        for (int i = 0; i < SNV; i++) gk[i] = V.gh[kc * SNV + i];
+        loads_done();
+        bad = chol_inlane<SNV>(L) && live;
+        if (live && s6 == 0) {                                                // one lane per stage keeps chol(H_k)
+#pragma unroll
+            for (int e = 0; e < 28; e++) V.Ls()[kc * LS + e] = L[e];
+        }
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const int cid = 2 * s6 + t;
+            double fc[SNV];
+            ba_column(F, cid < 5 ? cid : 0, fc);
+#pragma unroll
+            for (int i = 0; i < SNV; i++) {
+                const double e = (i == cid - 5 + SNU) ? 1.0 : 0.0;            // (cid = 11: i == 6 + SNU never holds -- the zero column)
+                z[t][i] = cid < 5 ? fc[i] : (cid == 10 ? (g_live(kc, N, i) ? gk[i] : 0.0) : e);
+            }
+        }
+        chol_solve<SNV, 2>(L, z);
+        ba_apply(F, z[0], o[0]);
+        ba_apply(F, z[1], o[1]);
+    }
+    if (live) {
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const int cid = 2 * s6 + t;
+            double *Zl = V.Zs() + (SL * kc + cid / CL) * ZL + (cid % CL) * SNV;      // (the one-wave phase's layout)
+#pragma unroll
+            for (int i = 0; i < SNV; i++) Zl[i] = z[t][i];
+            if (cid < 5 && kc < N) {                                          // D_k = F P F^T: stored, every column of every block exactly once
+#pragma unroll
+                for (int i = 0; i < SNX; i++) blk[kc * BS + OD + cid * 5 + i] = o[t][i];
+            }
+        }
+        if (s6 == 5) {                                                        // column 10 (t = 0): P g, and beta_k = rb_k - F_k P_k g_k (E P_{k+1} g_{k+1} added after the barrier)
+#pragma unroll
+            for (int i = 0; i < SNV; i++) V.zg()[kc * SNV + i] = z[0][i];
+            if (kc < N) {
+#pragma unroll
+                for (int i = 0; i < SNX; i++) blk[kc * BS + OB + i] = V.rb[kc * SNX + i] - o[0][i];
+            }
+        }
+    }
+    __syncthreads();
+    if (live && kc >= 1) {
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const int cid = 2 * s6 + t, c = cid - 5;
+            if (cid >= 5 && cid < 10) {                                       // ... + E P_{k+1} E^T (added), and the couplings Y_{k,k-1} = -F_k P_k E^T
+#pragma unroll
+                for (int i = 0; i < SNX; i++) add_lds(&blk[(kc - 1) * BS + OD + c * 5 + i], z[t][SNU + i]);
+                if (kc < N) {
+#pragma unroll
+                    for (int i = 0; i < SNX; i++) blk[kc * BS + OL + c * 5 + i] = -o[t][i];
+                }
+            }
+        }
+        if (s6 == 5) {
+#pragma unroll
+            for (int i = 0; i < SNX; i++) add_lds(&blk[(kc - 1) * BS + OB + i], z[0][SNU + i]);
+        }
+    }
+    __syncthreads();
+    return bad;
+}
+
 // Four-wave factorisation.  `flag`: four doubles of LDS for the waves' pivot flags.  Level 0 of the cyclic reduction eliminates ten blocks with ten
 // coupling columns each: one column per lane on 100 lanes (waves 0 and 1) instead of two per lane on 50; the later levels fit one wave and run there
-// while the others wait.  Returns true (workgroup-uniform) on a non-positive pivot anywhere.  N <= 20.
+// while the others wait.  Returns true (workgroup-uniform) on a non-positive pivot anywhere.  SL = 3: N <= 20; SL = 2: N <= 31 (up to 15 blocks at level 0: 150
+// lanes on three waves; level 1 has up to eight blocks: two columns per lane on wave 0).
 template <int SL>
 __device__ __forceinline__ bool factor4(const ViewT<SL> &V, int tid, double *flag)
 {
     const int N = V.N;
-    bool bad = stage_phase4(V, tid);
+    bool bad;
+    if constexpr (SL == 3) bad = stage_phase4(V, tid); else bad = stage_phase4_pairs(V, tid);
     bad |= cr_level<1, SL, true>(V, tid, 1);
     if (tid < 64) {
 #pragma unroll 1
-        for (int s = 2; s < N; s *= 2) bad |= cr_level<1>(V, tid, s);
+        for (int s = 2; s < N; s *= 2) {
+            if (SL == 3 || ((N - s + 2 * s - 1) / (2 * s)) * 10 <= 64) bad |= cr_level<1>(V, tid, s);
+            else bad |= cr_level<2>(V, tid, s);
+        }
         if (tid == 0) {                                          // what is left: block 0
             double L[15];
 #pragma unroll

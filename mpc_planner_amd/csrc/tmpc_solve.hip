@@ -7,6 +7,7 @@
 //   -DTMPC_TU_CP2       compact two-wave kernels
 //   -DTMPC_TU_SQRT      the square-root-Riccati instantiations (tmpc_dims.riccati_form = 1) + the Gaussian-row latency (mode 2) and one-wave compact kernels
 //   -DTMPC_TU_QUAD      the four-wave tick kernels (latency mode 3)
+//   -DTMPC_TU_QUADW     ... for 21 <= N <= 31
 // The C-ABI -- dispatch tables, handle, entry points -- is tmpc_capi.hip; it declares every instantiation `extern`.
 // Experiment builds (tools/kernel_probe.sh): -DTMPC_SINGLE_KERNEL=<fast template arguments> / -DTMPC_SINGLE_COMPACT=<compact template arguments>
 // compile ONE instantiation and nothing else -- seconds instead of minutes when looking at one kernel's registers / ISA.
@@ -38,6 +39,8 @@ TMPC_COMPACT_G_SHAPES(TMPC_I_CPG_DEF)
 #elif defined(TMPC_TU_QUAD)
 TMPC_QUAD_SHAPES(TMPC_I_QUAD_DEF)
 TMPC_QUAD_G_SHAPES(TMPC_I_QUADG_DEF)
+#elif defined(TMPC_TU_QUADW)
+TMPC_QUAD_W_SHAPES(TMPC_I_QUADW_DEF)
 #else
-#error "tmpc_solve.hip: name the group to instantiate (-DTMPC_TU_FAST / _COMPACT / _PROF / _CP2 / _SQRT / _QUAD) or one kernel (-DTMPC_SINGLE_KERNEL= / -DTMPC_SINGLE_COMPACT=)"
+#error "tmpc_solve.hip: name the group to instantiate (-DTMPC_TU_FAST / _COMPACT / _PROF / _CP2 / _SQRT / _QUAD / _QUADW) or one kernel (-DTMPC_SINGLE_KERNEL= / -DTMPC_SINGLE_COMPACT=)"
 #endif

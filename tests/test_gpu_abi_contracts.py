@@ -96,6 +96,8 @@ def test_latency_mode_capacity_orders_the_variants():
     assert c3 == cus                                             # four waves per trajectory: one workgroup per CU is what the variant serves
     s5 = solver.BatchedSolver(solver.default_dims(N=20, S=5, n_lin=8, M=8, row_model=1), B_max=8)   # Gaussian rows: variants 2 and 3 since round 6, no two-wave Riccati variant
     assert s5.latency_mode_capacity(1) == 0 and s5.latency_mode_capacity(2) > 0 and s5.latency_mode_capacity(3) == cus and s5.latency_mode_capacity(0) > 0
-    s6 = solver.BatchedSolver(solver.default_dims(N=30, S=5, n_lin=8, M=8, n_slk=12, slack=1, cost_model=1), B_max=8)   # curvature-aware cost: none
-    assert s6.latency_mode_capacity(1) == 0 and s6.latency_mode_capacity(2) == 0 and s6.latency_mode_capacity(3) == 0
-    s.close(); s5.close(); s6.close()
+    s6 = solver.BatchedSolver(solver.default_dims(N=30, S=5, n_lin=8, M=8, n_slk=12, slack=1, cost_model=1), B_max=8)   # curvature-aware cost: the four-wave variant alone
+    assert s6.latency_mode_capacity(1) == 0 and s6.latency_mode_capacity(2) == 0 and s6.latency_mode_capacity(3) == cus
+    s7 = solver.BatchedSolver(solver.default_dims(N=32, S=5, n_lin=8, M=8), B_max=8)                                    # beyond the parallel-in-time solve's 31 stages: none
+    assert s7.latency_mode_capacity(1) == 0 and s7.latency_mode_capacity(2) == 0 and s7.latency_mode_capacity(3) == 0
+    s.close(); s5.close(); s6.close(); s7.close()

@@ -72,8 +72,49 @@ def test_equal_to_mode_2_to_rounding():
     assert np.abs(res[2]["xtraj"][ok] - res[3]["xtraj"][ok]).max() < 1e-8
 
 
-def test_no_four_wave_variant_beyond_n_20():
+def test_no_four_wave_variant_beyond_n_31():
     from mpc_planner_amd import solver
-    s = solver.BatchedSolver(solver.default_dims(N=30, S=5, n_lin=8, M=8, n_slk=12, slack=1), B_max=8)
+    s = solver.BatchedSolver(solver.default_dims(N=32, S=5, n_lin=8, M=8), B_max=8)
     assert not s.set_latency_mode(3) and s.latency_mode_capacity(3) == 0
     s.close()
+
+
+# ---- 21 <= N <= 31: the horizon the reference ships (mpc_planner_jackalsimulator/config/settings.yaml N: 30, mpc_planner_jackal likewise) ----------------
+WIDE = {
+    "cfg3 (rosnavigation stack: slack model, decomp rows)": (dict(N=30, S=5, n_lin=8, M=8, n_slk=12, slack=1), dict(N=30, M=8, slack=True, n_decomp=12), 16, None),
+    "cfg3 with the curvature-aware cost": (dict(N=30, S=5, n_lin=8, M=8, n_slk=12, slack=1, cost_model=1), dict(N=30, M=8, slack=True, n_decomp=12), 16, None),
+    "jackalsimulator stack at its shipped horizon (8 + 8 rows, N = 30)": (dict(N=30, S=5, n_lin=8, M=8), dict(N=30, M=8), 16, None),
+    "12 + 12 rows, N = 30": (dict(N=30, S=5, n_lin=12, M=12), dict(N=30, M=12), 16, None),
+    "scenario rows, slack, N = 30": (dict(N=30, S=5, n_lin=0, M=0, n_slk=24, slack=1), dict(N=30, M=8, slack=True, n_scenario=24), 8, None),
+}
+
+
+@pytest.mark.parametrize("name", sorted(WIDE))
+def test_shipped_horizon_n30_matches_oracle(name):
+    dims_kw, scene_kw, B, orc_kw = WIDE[name]
+    for scene in (1, 6):
+        _run(dims_kw, scene_kw, B, scene, orc_kw)
+
+
+def test_deployed_size_4_plus_1_planners_at_the_shipped_horizon():
+    _run(dict(N=30, S=5, n_lin=8, M=8), dict(N=30, M=8, tmpc_pp=True), 4)
+
+
+def test_horizons_between_21_and_31():
+    """Every lane map of the wide variant: N = 21 is the first horizon on it, N = 31 fills the 32 node slots; odd / even block counts per reduction level."""
+    for N in (21, 22, 25, 28, 31):
+        _run(dict(N=N, S=5, n_lin=8, M=8), dict(N=N, M=8), 6)
+
+
+def test_wide_variant_equal_to_mode_2_to_rounding():
+    from mpc_planner_amd import scenes, solver
+    sc = scenes.make_scene(2, N=30, M=8, B=16, slack=True, n_decomp=12)
+    n = sc["xinit"].shape[0]
+    res = {}
+    for mode in (2, 3):
+        s = solver.BatchedSolver(solver.default_dims(N=30, S=5, n_lin=8, M=8, n_slk=12, slack=1), B_max=n)
+        assert s.set_latency_mode(mode)
+        s.set_batch(sc["xinit"], sc["x0"], sc["params"]); s.solve(); res[mode] = s.get(); s.close()
+    assert (res[2]["exit_code"] == res[3]["exit_code"]).all() and (res[2]["qp_iter_total"] == res[3]["qp_iter_total"]).all()
+    ok = res[2]["exit_code"] == 1
+    assert np.abs(res[2]["xtraj"][ok] - res[3]["xtraj"][ok]).max() < 1e-8

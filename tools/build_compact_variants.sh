@@ -7,7 +7,7 @@ for spec in "$@"; do
   ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c -mllvm -disable-machine-licm -D${TU:-TMPC_TU_COMPACT} $flags -Rpass-analysis=kernel-resource-usage \
       -o $R/build/exp/compact_$name.o $R/mpc_planner_amd/csrc/tmpc_solve.hip 2> $R/build/exp/compact_$name.log \
     && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -Wl,--no-undefined -o $R/build/exp/libtmpc_hip_$name.so $R/build/obj/tmpc_solve_fast.o $([ "${TU:-TMPC_TU_COMPACT}" = TMPC_TU_COMPACT ] && echo $R/build/exp/compact_$name.o || echo $R/build/obj/tmpc_solve_compact.o) \
-         $R/build/obj/tmpc_solve_prof.o $([ "${TU:-TMPC_TU_COMPACT}" = TMPC_TU_CP2 ] && echo $R/build/exp/compact_$name.o || echo $R/build/obj/tmpc_solve_cp2.o) $R/build/obj/tmpc_solve_sqrt.o $R/build/obj/tmpc_solve_quad.o $R/build/obj/tmpc_capi_lab.o \
+         $R/build/obj/tmpc_solve_prof.o $([ "${TU:-TMPC_TU_COMPACT}" = TMPC_TU_CP2 ] && echo $R/build/exp/compact_$name.o || echo $R/build/obj/tmpc_solve_cp2.o) $R/build/obj/tmpc_solve_sqrt.o $R/build/obj/tmpc_solve_quad.o $R/build/obj/tmpc_solve_quadw.o $R/build/obj/tmpc_capi_lab.o \
     && echo "$name: $(grep -c 'ScratchSize \[bytes/lane\]: [1-9]' $R/build/exp/compact_$name.log) kernels with scratch" ) &
 done
 wait
