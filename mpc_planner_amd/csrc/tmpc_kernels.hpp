@@ -614,6 +614,20 @@ __device__ int ipm_solve(const Lds &L, const Dims &d, int tid, int *iters_out, P
     return status;
 }
 
+// four-wave linearisation: parts of stage_linearise on wave 1 | waves 2, 3 (-DTMPC_EXP_QUAD_ROWS_ON_COST_WAVE: the first form, halfspace / scenario rows next to the cost)
+#ifdef TMPC_EXP_QUAD_ROWS_ON_COST_WAVE
+#define TMPC_QUAD_COST_PART 4
+#define TMPC_QUAD_ROWS_PART 5
+#else
+#define TMPC_QUAD_COST_PART 6
+#define TMPC_QUAD_ROWS_PART 7
+#endif
+// the latency kernels' (two / four waves per trajectory) 4 x 4 block: paired round-robin sweep (mirror_n, tmpc_stage.hpp)
+#ifdef TMPC_EXP_NO_PAIR4
+constexpr bool MIRROR_PAIR = false;
+#else
+constexpr bool MIRROR_PAIR = true;
+#endif
 // MIRROR of the one-wave kernels (round 5).  Lane k < N linearises stage k; the other lanes of the wave are idle copies.  With a zero disc
 // offset the Lagrangian Hessian is block diagonal under {a, w, psi, v} | {x, y, spline} (mirror7), and the two blocks' Jacobi iterations are
 // independent: lane k keeps the 4 x 4 block, lane N + k takes the 3 x 3 block of stage k -- padded to 4 x 4 with a zero row / column, which the
@@ -694,8 +708,8 @@ __device__ __forceinline__ void linearise(const Lds &L, const Dims &d, int tid, 
     if constexpr (FAST && NTH == 256) {
         // Four waves per trajectory (round 6, the control-tick kernel: a whole CU serves one trajectory, one wave per SIMD).  The stage evaluation is
         // split FOUR ways, by what is computed rather than by stage: wave 0 the dynamics (rollout with sensitivities, [B A], defects, the multipliers'
-        // share of the Hessian), wave 1 the cost and the halfspace / scenario rows, waves 2 and 3 the obstacle rows -- three lanes per stage each, so a
-        // lane evaluates at most ceil(M / 6) rows.  The shares of W meet in LDS (the scan scratch behind the layout is dead while the stage blocks are
+        // share of the Hessian), wave 1 the cost, waves 2 and 3 the rows (halfspace, scenario / decomp, obstacle) -- three lanes per stage each, so a
+        // lane evaluates at most ceil(n / 6) rows of each class.  The shares of W meet in LDS (the scan scratch behind the layout is dead while the stage blocks are
         // built); MIRROR's two diagonal blocks then run on waves 0 and 1 as in the two-wave kernels.  W = W_dyn + W_cost + sum of the six obstacle
         // shares, in that order (associates differently from the one-wave sum: rounding level).  Fast layout only.  N <= 21: three lanes per stage on the
         // obstacle waves (six shares); 22 <= N <= 32 (the shipped jackal / jackalsimulator horizon, N = 30): two (four shares).
@@ -745,8 +759,8 @@ __device__ __forceinline__ void linearise(const Lds &L, const Dims &d, int tid, 
 #pragma unroll
                     for (int j = 0; j <= i; j++) W0s[pidx(i, j)] = W[i][j];
             }
-        } else if (wv == 1) {                                    // cost, halfspace and scenario / decomp rows
-            stage_linearise<CM>(d, z, p, 1, 0.0, 0.0, lamh, sink, W, g, BA, xn, slack, nullptr, own_delta, 4);
+        } else if (wv == 1) {                                    // the cost
+            stage_linearise<CM>(d, z, p, 1, 0.0, 0.0, lamh, sink, W, g, BA, xn, slack, nullptr, own_delta, TMPC_QUAD_COST_PART);
             if (owner) {
 #pragma unroll
                 for (int i = 0; i < NV; i++) L.g[k * NV + i] = g[i];
@@ -755,9 +769,9 @@ __device__ __forceinline__ void linearise(const Lds &L, const Dims &d, int tid, 
 #pragma unroll
                     for (int j = 0; j <= i; j++) L.W[k * NP28 + pidx(i, j)] = W[i][j];
             }
-        } else {                                                 // obstacle rows: lane (wave, group) takes rows first, first + 6, ...
+        } else {                                                 // the rows (halfspace, scenario / decomp, obstacle): lane (wave, group) takes rows first, first + 2 G, ... of each class
             const int first_ = (wv - 2) * G + grp;
-            stage_linearise<CM>(d, z, p, 1, 0.0, 0.0, lamh, sink, W, g, BA, xn, slack, nullptr, own_delta, 5, [&]() { return first_; }, 2 * G, true);
+            stage_linearise<CM>(d, z, p, 1, 0.0, 0.0, lamh, sink, W, g, BA, xn, slack, nullptr, own_delta, TMPC_QUAD_ROWS_PART, [&]() { return first_; }, 2 * G, true);
             if (rowlane) {
                 double *x = Wes + (first_ * N + k) * 6;
                 x[0] = W[ZX][ZX]; x[1] = W[ZX][ZY]; x[2] = W[ZY][ZY]; x[3] = W[ZX][ZPSI]; x[4] = W[ZY][ZPSI]; x[5] = W[ZPSI][ZPSI];
@@ -810,7 +824,7 @@ __device__ __forceinline__ void linearise(const Lds &L, const Dims &d, int tid, 
                 for (int i = 0; i < 4; i++)
 #pragma unroll
                     for (int j = 0; j < 4; j++) Ba[i][j] = W[IA[i]][IA[j]];
-                mirror_n<4>(Ba, d.reg_eps);
+                mirror_n<4, MIRROR_PAIR>(Ba, d.reg_eps);
                 if (owner) {
 #pragma unroll
                     for (int i = 0; i < 4; i++)
@@ -938,7 +952,7 @@ __device__ __forceinline__ void linearise(const Lds &L, const Dims &d, int tid, 
                 for (int i = 0; i < 4; i++)
 #pragma unroll
                     for (int j = 0; j < 4; j++) Ba[i][j] = W[IA[i]][IA[j]];
-                mirror_n<4>(Ba, d.reg_eps);
+                mirror_n<4, MIRROR_PAIR>(Ba, d.reg_eps);
                 if (owner) {
 #pragma unroll
                     for (int i = 0; i < 4; i++)

@@ -593,9 +593,63 @@ TMPC_HD double st_rcp(double x)
 #ifndef TMPC_MIRROR_TOL2
 #define TMPC_MIRROR_TOL2 1e-32
 #endif
+// One Jacobi rotation's parameters from the pivot block (a_pp, a_qq, a_pq): c = cos, s = sin, t = tan of the angle |theta| <= pi / 4 that annihilates a_pq:
+// t = sgn(theta) / (|theta| + sqrt(theta^2 + 1)), theta = (a_qq - a_pp) / (2 a_pq), written division-free:
+// t = a_pq sgn(tau) / (|tau| + sqrt(tau^2 + a_pq^2)), tau = (a_qq - a_pp) / 2;  c = 1 / sqrt(t^2 + 1), s = t c.
+// (Round 6 measured a form with TWO reciprocal square roots on the dependent chain instead of rsqrt -> reciprocal -> rsqrt -- cos^2 = (1 + |tau| / h) / 2 =: x,
+// c = x rsqrt(x), s = g rsqrt(x), t = g rsqrt(x)^2, g = sgn(tau) a_pq / (2 h): -DTMPC_EXP_ROT2 -- the same rotation to rounding, every parity test green, and
+// 0.4 % SLOWER on the saturated compact kernel, +-0.5 % on the ticks: profiles/round6_mirror_rotation_ab.jsonl.  Not taken.)
+// `live` false (|a_pq| <= 1e-150): the identity (c = 1, s = t = 0) -- by selects, for the branch-free callers.
+struct JacobiRot { double c, s, t; };
+template <bool SELECT>
+TMPC_HD JacobiRot jacobi_rot(double app, double aqq, double apq, bool live)
+{
+    const double tau = 0.5 * (aqq - app);
+    double h2 = tau * tau + apq * apq;
+    if (SELECT) h2 = live ? h2 : 1.0;                       // (keeps the reciprocal square root finite)
+    JacobiRot r;
+#ifndef TMPC_EXP_ROT2
+    const double hyp = h2 * st_rsqrt(h2);
+    r.t = (tau >= 0.0 ? apq : -apq) * st_rcp(fabs(tau) + hyp);
+    r.c = st_rsqrt(r.t * r.t + 1.0); r.s = r.t * r.c;
+#else
+    const double rh = st_rsqrt(h2);
+    const double g = (tau >= 0.0 ? 0.5 : -0.5) * apq * rh;
+    const double x = fma(0.5 * fabs(tau), rh, 0.5);
+    const double rc = st_rsqrt(x);
+    r.c = x * rc; r.s = g * rc; r.t = r.s * rc;
+#endif
+    if (SELECT) { r.c = live ? r.c : 1.0; r.s = live ? r.s : 0.0; r.t = live ? r.t : 0.0; }
+    return r;
+}
+// A <- G^T A G on the symmetric matrix, V <- V G: the pivot block in closed form (a_pp - t a_pq, a_qq + t a_pq, 0), the other rows' (p, q) entries once and
+// mirrored -- (NN - 2) pairs where the two full passes over columns and rows (round 1-3) took 2 NN: a third of the rotation's arithmetic (round 4)
 template <int NN>
+TMPC_HD void jacobi_apply(double (&A)[NN][NN], double (&V)[NN][NN], int p, int q, const JacobiRot &r, double apq, double apq_after)
+{
+    const double c = r.c, s = r.s;
+    A[p][p] -= r.t * apq; A[q][q] += r.t * apq; A[p][q] = apq_after; A[q][p] = apq_after;
+#pragma unroll
+    for (int k = 0; k < NN; k++) {
+        if (k == p || k == q) continue;
+        const double akp = A[k][p], akq = A[k][q];
+        const double np_ = c * akp - s * akq, nq_ = s * akp + c * akq;
+        A[k][p] = np_; A[p][k] = np_; A[k][q] = nq_; A[q][k] = nq_;
+    }
+#pragma unroll
+    for (int k = 0; k < NN; k++) {
+        const double vkp = V[k][p], vkq = V[k][q];
+        V[k][p] = c * vkp - s * vkq; V[k][q] = s * vkp + c * vkq;
+    }
+}
+// PAIR (4 x 4 only; the latency kernels, where one wave per SIMD leaves a rotation's dependent chain exposed): the sweep visits the pivots in the round-robin
+// order (0,1)(2,3) | (0,2)(1,3) | (0,3)(1,2) -- the two rotations of a round touch disjoint index pairs, so the second one's parameters do not depend on the
+// first one's update and both chains are computed side by side, branch-free; applied one after the other.  Another (equally valid) cyclic ordering than
+// the row-wise one: the same limit V |e| V^T, to rounding.
+template <int NN, bool PAIR = false>
 TMPC_HD void mirror_n(double (&A)[NN][NN], double eps)
 {
+    static_assert(!PAIR || NN == 4, "paired sweep: 4 x 4");
     double V[NN][NN];
 #pragma unroll
     for (int i = 0; i < NN; i++)
@@ -610,6 +664,18 @@ TMPC_HD void mirror_n(double (&A)[NN][NN], double eps)
             for (int j = i + 1; j < NN; j++) off += A[i][j] * A[i][j];
         }
         if (off <= TMPC_MIRROR_TOL2 * (dg + off) || off == 0.0) break;
+        if constexpr (PAIR) {
+            constexpr int RR[3][4] = {{0, 1, 2, 3}, {0, 2, 1, 3}, {0, 3, 1, 2}};
+#pragma unroll
+            for (int rd = 0; rd < 3; rd++) {
+                const int p = RR[rd][0], q = RR[rd][1], u = RR[rd][2], w = RR[rd][3];
+                const double apq = A[p][q], auw = A[u][w];
+                const bool l1 = fabs(apq) > 1e-150, l2 = fabs(auw) > 1e-150;
+                const JacobiRot r1 = jacobi_rot<true>(A[p][p], A[q][q], apq, l1), r2 = jacobi_rot<true>(A[u][u], A[w][w], auw, l2);
+                jacobi_apply<NN>(A, V, p, q, r1, apq, l1 ? 0.0 : apq);
+                jacobi_apply<NN>(A, V, u, w, r2, auw, l2 ? 0.0 : auw);
+            }
+        } else {
 #pragma unroll
         for (int p = 0; p < NN - 1; p++) {
 #pragma unroll
@@ -619,31 +685,11 @@ TMPC_HD void mirror_n(double (&A)[NN][NN], double eps)
                 // branch-free form -- t = 0, c = 1 by selects -- removes them; measured in round 5 it is 3.6 % faster on a lone wave and 0.4 % SLOWER
                 // on the saturated compact kernel, profiles/round5_m_factor_unroll_rotation_ab.jsonl: not taken)
                 if (fabs(apq) > 1e-150) {                       // (also keeps tau^2 + apq^2 away from underflow)
-                    // t = sgn(theta) / (|theta| + sqrt(theta^2 + 1)), theta = (aqq - app) / (2 apq), written division-free:
-                    // t = apq sgn(tau) / (|tau| + sqrt(tau^2 + apq^2)), tau = (aqq - app)/2
-                    const double tau = 0.5 * (A[q][q] - A[p][p]);
-                    const double h2 = tau * tau + apq * apq;
-                    const double hyp = h2 * st_rsqrt(h2);
-                    const double t = (tau >= 0.0 ? apq : -apq) * st_rcp(fabs(tau) + hyp);
-                    const double c = st_rsqrt(t * t + 1.0), s = t * c;
-                    // A <- G^T A G on the symmetric matrix: the pivot block in closed form (a_pp - t a_pq, a_qq + t a_pq, 0), the other rows'
-                    // (p, q) entries once and mirrored -- (NN - 2) pairs where the two full passes over columns and rows (round 1-3) took
-                    // 2 NN: a third of the rotation's arithmetic (round 4; the rotation itself is unchanged)
-                    A[p][p] -= t * apq; A[q][q] += t * apq; A[p][q] = 0.0; A[q][p] = 0.0;
-#pragma unroll
-                    for (int k = 0; k < NN; k++) {
-                        if (k == p || k == q) continue;
-                        const double akp = A[k][p], akq = A[k][q];
-                        const double np_ = c * akp - s * akq, nq_ = s * akp + c * akq;
-                        A[k][p] = np_; A[p][k] = np_; A[k][q] = nq_; A[q][k] = nq_;
-                    }
-#pragma unroll
-                    for (int k = 0; k < NN; k++) {
-                        const double vkp = V[k][p], vkq = V[k][q];
-                        V[k][p] = c * vkp - s * vkq; V[k][q] = s * vkp + c * vkq;
-                    }
+                    const JacobiRot r = jacobi_rot<false>(A[p][p], A[q][q], apq, true);
+                    jacobi_apply<NN>(A, V, p, q, r, apq, 0.0);
                 }
             }
+        }
         }
     }
     double e[NN];
@@ -733,7 +779,8 @@ TMPC_HD void stage_linearise(const Dims &d, const double *z, const double *p, in
     // (linearise, tmpc_solve.hip).  Measured shares of a stage's 46 k cycles (cfg 2): dynamics 5.5 k, eight ellipsoid rows 10.2 k, cost and
     // halfspace rows 8.3 k -- and 22.3 k for MIRROR, which needs the complete W and stays on one wave.
     // Round 6, the four-wave kernels: 3 = dynamics alone; 4 = cost, topology and scenario / decomp rows (no obstacle rows); 5 = obstacle rows alone
-    // (this lane's share of them: ell_first / ell_step; call with rows_only).
+    // (this lane's share of them: ell_first / ell_step; call with rows_only); 6 = the cost alone; 7 = every row class alone (this lane's share of each:
+    // ell_first / ell_step; call with rows_only) -- the four-wave linearisation runs 3 | 6 | 7 | 7: the halfspace and scenario rows leave the cost's wave.
     // own_delta (doubles, wave-uniform): distance from `p` to the trajectory's OWN parameter row when `p` is a row it shares with others
     // (tmpc_set_param_sharing): the topology and scenario halfspaces (ip_lin / ip_slk) are read from p + own_delta, everything else
     // from p.  A delta, not a second pointer: the second address then lives only across the halfspace loads (the linearisation is the
@@ -755,7 +802,7 @@ TMPC_HD void stage_linearise(const Dims &d, const double *z, const double *p, in
 #pragma unroll
         for (int j = 0; j < NV; j++) W[i][j] = 0.0;
 #ifndef TMPC_GENERATED_STAGE
-    if (part != 2 && part != 4 && part != 5)
+    if (part != 2 && part != 4 && part != 5 && part != 6 && part != 7)
 #endif
     {
         DynOut dy;
@@ -790,7 +837,7 @@ TMPC_HD void stage_linearise(const Dims &d, const double *z, const double *p, in
 #else
     RowOut ro;
     if (part == 3) return;
-    if (part != 1 && part != 5) {
+    if (part != 1 && part != 5 && part != 7) {
         if constexpr (cm_curvature_aware(CM)) {
             CostOutCA co;
             cost_eval_ca(d, z, p, pstride, co, true, slack);
@@ -805,6 +852,9 @@ TMPC_HD void stage_linearise(const Dims &d, const double *z, const double *p, in
                                                                             // does not depend on psi: literal 0, not a hoisted dt * 0)
         cost_add_hessian(co, rows_only ? 0.0 : d.dt, W);
         }
+    }
+    if (part == 6) return;
+    if (part != 1 && part != 5) {
         for (int j = ell_first(); j < d.n_lin; j += ell_step) {   // (halfspace rows have no curvature: nothing of them enters W)
             lin_row_eval(d, z, p + own_delta, pstride, j, ro);
             sink(j, ro);
