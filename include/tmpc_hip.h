@@ -197,9 +197,10 @@ int tmpc_reset_multipliers(tmpc_handle *h);
  * tolerance, and the interior-point iteration count of a solve can differ by one where a residual sits at the tolerance.
  * 3 (round 6) = FOUR waves per trajectory, for the launches that leave a whole CU to each trajectory (<= one workgroup per CU: the
  * reference's deployed 4 + 1 planners, a 64-trajectory tick): the algorithm of mode 2 with the stage evaluation split four ways by content,
- * the row passes at twelve lanes per stage and the wide phases of the factorisation on all 256 lanes -- 10 % less kernel time per tick than
- * mode 2 (tick of 64: p50 1.21 ms; 4 + 1 planners: 0.97 ms), results equal to mode 2's to rounding; N <= 20, MPCC or Gaussian rows.  A shape
- * without it runs mode 2 (return value 1).  tmpc_latency_mode_capacity says how many trajectories a variant serves well in one launch. */
+ * the row passes at twelve (N <= 20) or eight (21 <= N <= 31: the horizon the reference ships, N = 30) lanes per stage and the wide phases of
+ * the factorisation on all 256 lanes -- 10-15 % less kernel time per tick than mode 2 (measured ticks: DESIGN.md section 5), results equal to
+ * mode 2's to rounding; N <= 20: MPCC or Gaussian rows; 21 <= N <= 31: every stage model, up to 34 rows per stage.  A shape without it runs
+ * mode 2 (return value 1).  tmpc_latency_mode_capacity says how many trajectories a variant serves well in one launch. */
 int tmpc_set_latency_mode(tmpc_handle *h, int32_t on);
 /* How many trajectories ONE launch of kernel variant `mode` (0 .. 3 as above) holds resident on this device (workgroups per CU x CUs; variant 3: ONE workgroup per CU, what it is built for), 0 if the
  * handle's shape has no such variant, < 0 on error.  A latency variant pays off while the launch fits (one dependent chain deep); above it the

@@ -5,6 +5,7 @@
 // experiment builds that pass -DTMPC_SINGLE_TU compile this file ALONE: without the extern declarations every kernel the tables name is
 // instantiated here.
 #include <algorithm>
+#include <cstring>
 #include "tmpc_kernels.hpp"
 #include "tmpc_instances.hpp"
 #if !defined(TMPC_GENERATED_STAGE) && !defined(TMPC_SINGLE_TU)
@@ -342,6 +343,14 @@ struct tmpc_handle {
     double *xtraj = nullptr, *utraj = nullptr, *pobj = nullptr, *res_eq = nullptr, *d_weight = nullptr;
     int *exit_code = nullptr, *qp_status = nullptr, *sqp_iter = nullptr, *qp_iter = nullptr, *d_best = nullptr;
     uint8_t *d_disabled = nullptr;
+    // Control-tick handles (inputs and outputs of B_max trajectories <= TICK_SLAB_MAX bytes each): the owned input buffers (+ the slot map) are ONE device
+    // allocation, the outputs another, each mirrored in pinned host memory with the same layout -- tmpc_set_batch is one asynchronous H2D copy instead of
+    // three staged ones, tmpc_set_slots needs no stream synchronisation, tmpc_get is one D2H copy instead of eight (round 6: the C++ BatchContext's tick
+    // spent ~0.2 ms of 1.1 ms in those thirteen transfers).  Larger handles (the bench's 32768 trajectories) keep separate allocations and direct copies.
+    char *slab_in = nullptr, *slab_out = nullptr, *pin_in = nullptr, *pin_out = nullptr;
+    size_t slab_in_bytes = 0, slab_out_bytes = 0;
+    hipEvent_t in_done = nullptr;    // the last H2D copy out of pin_in (the mirror is rewritten only after it)
+    bool in_pending = false;
     size_t lds_bytes = 0;
     tmpc::SolveKernel kernel = nullptr;
     int threads = tmpc::NT;          // threads per trajectory (64, or 128 for the two-wave fast variant)
@@ -600,18 +609,41 @@ int tmpc_create(tmpc_handle **out, const tmpc_dims *dims, int32_t B_max, int32_t
     const size_t N = d.N, B = B_max;
     bool ok = true;
     const size_t nxe = tmpc::ext_nx(d), nve = tmpc::ext_nv(d);
-    ok &= hipMalloc(&h->o_xinit, B * nxe * 8) == hipSuccess;
-    ok &= hipMalloc(&h->o_x0, B * (N + 1) * nve * 8) == hipSuccess;
-    ok &= hipMalloc(&h->o_params, B * N * d.npar * 8) == hipSuccess;
-    ok &= hipMalloc(&h->xtraj, B * (N + 1) * nxe * 8) == hipSuccess;
-    ok &= hipMalloc(&h->utraj, B * N * tmpc::NU * 8) == hipSuccess;
-    ok &= hipMalloc(&h->pobj, B * 8) == hipSuccess;
-    ok &= hipMalloc(&h->res_eq, B * 8) == hipSuccess;
+    {
+        constexpr size_t TICK_SLAB_MAX = 2u << 20;
+        auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+        const size_t in_sz[4] = {B * nxe * 8, B * (N + 1) * nve * 8, B * N * d.npar * 8, B * 4};
+        const size_t out_sz[8] = {B * (N + 1) * nxe * 8, B * N * tmpc::NU * 8, B * 8, B * 8, B * 4, B * 4, B * 4, B * 4};
+        size_t in_off[5] = {0}, out_off[9] = {0};
+        for (int i = 0; i < 4; i++) in_off[i + 1] = in_off[i] + up(in_sz[i]);
+        for (int i = 0; i < 8; i++) out_off[i + 1] = out_off[i] + up(out_sz[i]);
+        if (in_off[4] <= TICK_SLAB_MAX && out_off[8] <= TICK_SLAB_MAX) {
+            h->slab_in_bytes = in_off[4]; h->slab_out_bytes = out_off[8];
+            ok &= hipMalloc(&h->slab_in, in_off[4]) == hipSuccess && hipMalloc(&h->slab_out, out_off[8]) == hipSuccess;
+            ok &= hipHostMalloc(&h->pin_in, in_off[4], hipHostMallocDefault) == hipSuccess && hipHostMalloc(&h->pin_out, out_off[8], hipHostMallocDefault) == hipSuccess;
+            ok &= hipEventCreateWithFlags(&h->in_done, hipEventDisableTiming) == hipSuccess;
+            if (ok) {
+                h->o_xinit = (double *)(h->slab_in + in_off[0]); h->o_x0 = (double *)(h->slab_in + in_off[1]); h->o_params = (double *)(h->slab_in + in_off[2]);
+                h->d_slot = (int *)(h->slab_in + in_off[3]);
+                h->xtraj = (double *)(h->slab_out + out_off[0]); h->utraj = (double *)(h->slab_out + out_off[1]); h->pobj = (double *)(h->slab_out + out_off[2]);
+                h->res_eq = (double *)(h->slab_out + out_off[3]); h->exit_code = (int *)(h->slab_out + out_off[4]); h->qp_status = (int *)(h->slab_out + out_off[5]);
+                h->sqp_iter = (int *)(h->slab_out + out_off[6]); h->qp_iter = (int *)(h->slab_out + out_off[7]);
+            }
+        } else {
+            ok &= hipMalloc(&h->o_xinit, in_sz[0]) == hipSuccess;
+            ok &= hipMalloc(&h->o_x0, in_sz[1]) == hipSuccess;
+            ok &= hipMalloc(&h->o_params, in_sz[2]) == hipSuccess;
+            ok &= hipMalloc(&h->xtraj, out_sz[0]) == hipSuccess;
+            ok &= hipMalloc(&h->utraj, out_sz[1]) == hipSuccess;
+            ok &= hipMalloc(&h->pobj, out_sz[2]) == hipSuccess;
+            ok &= hipMalloc(&h->res_eq, out_sz[3]) == hipSuccess;
+            ok &= hipMalloc(&h->exit_code, out_sz[4]) == hipSuccess;
+            ok &= hipMalloc(&h->qp_status, out_sz[5]) == hipSuccess;
+            ok &= hipMalloc(&h->sqp_iter, out_sz[6]) == hipSuccess;
+            ok &= hipMalloc(&h->qp_iter, out_sz[7]) == hipSuccess;
+        }
+    }
     ok &= hipMalloc(&h->d_weight, B * 8) == hipSuccess;
-    ok &= hipMalloc(&h->exit_code, B * 4) == hipSuccess;
-    ok &= hipMalloc(&h->qp_status, B * 4) == hipSuccess;
-    ok &= hipMalloc(&h->sqp_iter, B * 4) == hipSuccess;
-    ok &= hipMalloc(&h->qp_iter, B * 4) == hipSuccess;
     ok &= hipMalloc(&h->d_best, 4) == hipSuccess;
     ok &= hipMalloc(&h->d_disabled, B) == hipSuccess;
     if (h->compact || h->kernel_cp2) {
@@ -631,7 +663,16 @@ void tmpc_destroy(tmpc_handle *h)
     void *ptrs[] = {h->o_xinit, h->o_x0, h->o_params, h->xtraj, h->utraj, h->pobj, h->res_eq, h->d_weight,
                     h->exit_code, h->qp_status, h->sqp_iter, h->qp_iter, h->d_best, h->d_disabled,
                     h->st_z, h->st_pi, h->st_lamh, h->st_stopped, h->st_has, h->d_slot, h->d_share, h->scn_sample, h->scn_discard, h->ws, h->ticket};
-    for (void *p : ptrs) if (p) (void)hipFree(p);
+    auto in_slab = [&](void *p) {
+        return (h->slab_in && (char *)p >= h->slab_in && (char *)p < h->slab_in + h->slab_in_bytes) ||
+               (h->slab_out && (char *)p >= h->slab_out && (char *)p < h->slab_out + h->slab_out_bytes);
+    };
+    for (void *p : ptrs) if (p && !in_slab(p)) (void)hipFree(p);
+    if (h->slab_in) (void)hipFree(h->slab_in);
+    if (h->slab_out) (void)hipFree(h->slab_out);
+    if (h->pin_in) (void)hipHostFree(h->pin_in);
+    if (h->pin_out) (void)hipHostFree(h->pin_out);
+    if (h->in_done) (void)hipEventDestroy(h->in_done);
     for (auto &e : h->ev) (void)hipEventDestroy(e);
     tmpc::lanes::destroy(h->lanes);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -645,9 +686,28 @@ int tmpc_set_batch(tmpc_handle *h, int32_t B, const double *xinit, const double 
     if (!h || B <= 0 || B > h->B_max || !xinit || !x0 || !params) { if (h) h->err = "tmpc_set_batch: bad argument"; return TMPC_ERR_INVALID; }
     TMPC_HIP_CHECK(h, hipSetDevice(h->device));
     const size_t N = h->d.N;
+    const size_t in_bytes_B = (size_t)B * (tmpc::ext_nx(h->d) + (N + 1) * tmpc::ext_nv(h->d) + N * h->d.npar) * 8;
+    if (h->slab_in && in_bytes_B <= (512u << 10)) {                // (measured: at 64 trajectories = 1.4 MB the runtime's own path for pageable memory is 12 us faster than a host copy into the mirror)
+        // through the pinned mirror: one asynchronous copy of [xinit | x0 | params of the first B trajectories] (the regions of B_max trajectories lie in this order)
+        if (h->in_pending) { TMPC_HIP_CHECK(h, hipEventSynchronize(h->in_done)); h->in_pending = false; }
+        const size_t o0 = (char *)h->o_xinit - h->slab_in, o1 = (char *)h->o_x0 - h->slab_in, o2 = (char *)h->o_params - h->slab_in;
+        const size_t n_par = (size_t)B * N * h->d.npar * 8;
+        std::memcpy(h->pin_in + o0, xinit, (size_t)B * tmpc::ext_nx(h->d) * 8);
+        std::memcpy(h->pin_in + o1, x0, (size_t)B * (N + 1) * tmpc::ext_nv(h->d) * 8);
+        std::memcpy(h->pin_in + o2, params, n_par);
+        if (o2 <= (256u << 10)) {                                   // (B_max close to B, as for a control tick's handle: the gaps cost less than two more copies)
+            TMPC_HIP_CHECK(h, hipMemcpyAsync(h->slab_in, h->pin_in, o2 + n_par, hipMemcpyHostToDevice, h->stream));
+        } else {
+            TMPC_HIP_CHECK(h, hipMemcpyAsync(h->o_xinit, h->pin_in + o0, (size_t)B * tmpc::ext_nx(h->d) * 8, hipMemcpyHostToDevice, h->stream));
+            TMPC_HIP_CHECK(h, hipMemcpyAsync(h->o_x0, h->pin_in + o1, (size_t)B * (N + 1) * tmpc::ext_nv(h->d) * 8, hipMemcpyHostToDevice, h->stream));
+            TMPC_HIP_CHECK(h, hipMemcpyAsync(h->o_params, h->pin_in + o2, n_par, hipMemcpyHostToDevice, h->stream));
+        }
+        TMPC_HIP_CHECK(h, hipEventRecord(h->in_done, h->stream)); h->in_pending = true;
+    } else {
     TMPC_HIP_CHECK(h, hipMemcpyAsync(h->o_xinit, xinit, (size_t)B * tmpc::ext_nx(h->d) * 8, hipMemcpyHostToDevice, h->stream));
     TMPC_HIP_CHECK(h, hipMemcpyAsync(h->o_x0, x0, (size_t)B * (N + 1) * tmpc::ext_nv(h->d) * 8, hipMemcpyHostToDevice, h->stream));
     TMPC_HIP_CHECK(h, hipMemcpyAsync(h->o_params, params, (size_t)B * N * h->d.npar * 8, hipMemcpyHostToDevice, h->stream));
+    }
     h->xinit = h->o_xinit; h->x0 = h->o_x0; h->params = h->o_params; h->B = B;
     h->scn_B = 0;                      // new parameter rows: the scenario-row bookkeeping of the previous batch no longer describes them
     h->scn_discard_B = 0;
@@ -846,9 +906,17 @@ int tmpc_set_slots(tmpc_handle *h, const int32_t *slots)
         seen[slots[b]] = 1;
     }
     TMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    if (h->slab_in) {                                               // pinned mirror: asynchronous, nothing to wait for (the caller's array is copied here)
+        if (h->in_pending) { TMPC_HIP_CHECK(h, hipEventSynchronize(h->in_done)); h->in_pending = false; }
+        const size_t o3 = (char *)h->d_slot - h->slab_in;
+        std::memcpy(h->pin_in + o3, slots, (size_t)h->B * 4);
+        TMPC_HIP_CHECK(h, hipMemcpyAsync(h->d_slot, h->pin_in + o3, (size_t)h->B * 4, hipMemcpyHostToDevice, h->stream));
+        TMPC_HIP_CHECK(h, hipEventRecord(h->in_done, h->stream)); h->in_pending = true;
+    } else {
     if (!h->d_slot) TMPC_HIP_CHECK(h, hipMalloc(&h->d_slot, (size_t)h->B_max * 4));
     TMPC_HIP_CHECK(h, hipMemcpyAsync(h->d_slot, slots, (size_t)h->B * 4, hipMemcpyHostToDevice, h->stream));
     TMPC_HIP_CHECK(h, hipStreamSynchronize(h->stream));            // (the caller's array may go away)
+    }
     h->slots_set = true; h->slots_B = h->B;
     return TMPC_OK;
 }
@@ -998,6 +1066,25 @@ int tmpc_get(tmpc_handle *h, double *xtraj, double *utraj, double *pobj, int32_t
     if (!h || h->B <= 0) return TMPC_ERR_INVALID;
     TMPC_HIP_CHECK(h, hipSetDevice(h->device));
     const size_t N = h->d.N, B = h->B;
+    if (h->slab_out) {                                              // one D2H copy of the output slab into its pinned mirror, then host copies of what was asked for
+        if (h->slab_out_bytes <= (256u << 10)) {
+            TMPC_HIP_CHECK(h, hipMemcpyAsync(h->pin_out, h->slab_out, h->slab_out_bytes, hipMemcpyDeviceToHost, h->stream));
+        } else {                                                    // B_max well above a tick's size: the first B entries of every array the caller asked for
+            auto dc = [&](const void *want, const void *dev, size_t n) {
+                return want ? hipMemcpyAsync(h->pin_out + ((const char *)dev - h->slab_out), dev, n, hipMemcpyDeviceToHost, h->stream) : hipSuccess;
+            };
+            TMPC_HIP_CHECK(h, dc(xtraj, h->xtraj, B * (N + 1) * tmpc::ext_nx(h->d) * 8)); TMPC_HIP_CHECK(h, dc(utraj, h->utraj, B * N * tmpc::NU * 8));
+            TMPC_HIP_CHECK(h, dc(pobj, h->pobj, B * 8)); TMPC_HIP_CHECK(h, dc(res_eq, h->res_eq, B * 8));
+            TMPC_HIP_CHECK(h, dc(exit_code, h->exit_code, B * 4)); TMPC_HIP_CHECK(h, dc(qp_status, h->qp_status, B * 4));
+            TMPC_HIP_CHECK(h, dc(sqp_iter, h->sqp_iter, B * 4)); TMPC_HIP_CHECK(h, dc(qp_iter_total, h->qp_iter, B * 4));
+        }
+        TMPC_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+        auto hc = [&](void *dst, const void *dev, size_t n) { if (dst) std::memcpy(dst, h->pin_out + ((const char *)dev - h->slab_out), n); };
+        hc(xtraj, h->xtraj, B * (N + 1) * tmpc::ext_nx(h->d) * 8); hc(utraj, h->utraj, B * N * tmpc::NU * 8);
+        hc(pobj, h->pobj, B * 8); hc(res_eq, h->res_eq, B * 8);
+        hc(exit_code, h->exit_code, B * 4); hc(qp_status, h->qp_status, B * 4); hc(sqp_iter, h->sqp_iter, B * 4); hc(qp_iter_total, h->qp_iter, B * 4);
+        return TMPC_OK;
+    }
     auto cp = [&](void *dst, const void *src, size_t n) { return dst ? hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, h->stream) : hipSuccess; };
     TMPC_HIP_CHECK(h, cp(xtraj, h->xtraj, B * (N + 1) * tmpc::ext_nx(h->d) * 8));
     TMPC_HIP_CHECK(h, cp(utraj, h->utraj, B * N * tmpc::NU * 8));
