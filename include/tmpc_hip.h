@@ -73,8 +73,9 @@ typedef struct tmpc_dims {
     int32_t row_model;    /* what the M obstacle rows are.  0: EllipsoidConstraintModule (ellipsoid_constraints.py:66-110: 7 parameters per
                              obstacle, h >= 1); 1: GaussianConstraintModule (gaussian_constraints.py:33-113: 6 parameters per obstacle -- x, y,
                              major, minor, risk, r --, h >= 0; the collision-avoidance submodule of mpc_planner_jackal's default T-MPC,
-                             generate_jackal_solver.py:53-73).  npar follows: 6 instead of 7 entries per obstacle.  Set by tmpc_default_dims* to 0; not
-                             together with cost_model 1.  Hand-written kernels only. */
+                             generate_jackal_solver.py:53-73).  npar follows: 6 instead of 7 entries per obstacle.  Set by tmpc_default_dims* to 0.
+                             Together with cost_model 1 (round 6): the generic kernel, and the four-wave tick kernel for 21 <= N <= 31.
+                             Hand-written kernels only. */
     int32_t riccati_form; /* form of the Riccati recursion inside the interior-point QP solver (round 6).  TMPC_RICCATI_SCHUR (0, what
                              tmpc_default_dims* sets): the cost-to-go Hessian P_k is kept as the Schur complement F_xx - Lxu Lxu^T (HPIPM's
                              square_root_alg = 0 [UPSTREAM]) -- every kernel family, every latency mode.  TMPC_RICCATI_SQUARE_ROOT (1): P_k is

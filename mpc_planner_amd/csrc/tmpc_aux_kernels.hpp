@@ -778,7 +778,8 @@ __global__ void tmpc_debug_eval_kernel(Dims d, int n, const double *z, const dou
         J[ZX] = ro.gx; J[ZY] = ro.gy; J[ZPSI] = ro.gp;
     };
 #ifndef TMPC_GENERATED_STAGE
-    if (d.cost_model == 1) stage_linearise<1>(d, zz, pe, 1, pi ? pi[(size_t)e * NX] : 0.0, pi ? pi[(size_t)e * NX + 1] : 0.0, lam, sink, W, g, BA, xn, slack);
+    if (d.cost_model == 1 && d.row_model == 1) stage_linearise<3>(d, zz, pe, 1, pi ? pi[(size_t)e * NX] : 0.0, pi ? pi[(size_t)e * NX + 1] : 0.0, lam, sink, W, g, BA, xn, slack);
+    else if (d.cost_model == 1) stage_linearise<1>(d, zz, pe, 1, pi ? pi[(size_t)e * NX] : 0.0, pi ? pi[(size_t)e * NX + 1] : 0.0, lam, sink, W, g, BA, xn, slack);
     else if (d.row_model == 1) stage_linearise<2>(d, zz, pe, 1, pi ? pi[(size_t)e * NX] : 0.0, pi ? pi[(size_t)e * NX + 1] : 0.0, lam, sink, W, g, BA, xn, slack);
     else
 #endif

@@ -62,6 +62,7 @@ static SolveKernel pick_fast_kernel(const Dims &d, int *threads, bool prof)
     if (lab_env("TMPC_FORCE_GENERIC")) return nullptr;
     const int lps = (3 * d.N <= NT) ? 3 : ((2 * d.N <= NT) ? 2 : 0);
 #ifndef TMPC_GENERATED_STAGE
+    if (d.cost_model == 1 && d.row_model == 1) return nullptr;      // curvature-aware cost AND Gaussian rows (CM = 3, round 6): the generic kernel and the four-wave tick kernel of 21 <= N <= 31
     if (d.cost_model == 1) {
         // curvature-aware contouring (BASELINE configs[2]): the cfg-3 shape on the two-wave kernel, every other row mix of N <= 20 on the
         // runtime-shape one-wave kernel, anything else on the generic kernel -- all instantiated with CM = 1 (no profiled twins)
@@ -269,7 +270,8 @@ static SolveKernel pick_quad_kernel(const Dims &d, bool prof, bool ab, int *sl =
         const int sm = stage_model(d);
         return sm == 0 ? (SolveKernel)tmpc_solve_fast_kernel<-1, 6, 8, 256, false, ScanQuadT<2>, 0>
              : sm == 1 ? (SolveKernel)tmpc_solve_fast_kernel<-1, 6, 8, 256, false, ScanQuadT<2>, 1>
-             : sm == 2 ? (SolveKernel)tmpc_solve_fast_kernel<-1, 6, 8, 256, false, ScanQuadT<2>, 2> : nullptr;
+             : sm == 2 ? (SolveKernel)tmpc_solve_fast_kernel<-1, 6, 8, 256, false, ScanQuadT<2>, 2>
+             : sm == 3 ? (SolveKernel)tmpc_solve_fast_kernel<-1, 6, 8, 256, false, ScanQuadT<2>, 3> : nullptr;
     }
     if (d.N > 20 || d.N < 2 || (stage_model(d) != 0 && stage_model(d) != 2)) return nullptr;
     if (stage_model(d) == 2) return (!prof && d.n_up + d.M + 14 <= 12 * 4) ? (SolveKernel)tmpc_solve_fast_kernel<-1, 4, 12, 256, false, ScanQuad, 2> : nullptr;      // Gaussian rows
@@ -485,7 +487,6 @@ int tmpc_create(tmpc_handle **out, const tmpc_dims *dims, int32_t B_max, int32_t
             (dims->slack != 0 && dims->slack != 1) || dims->npar != tmpc::expected_npar(t) || dims->erk_steps < 1 ||
             dims->n_sqp < 1 || dims->qp_iter_max < 1 || !(dims->dt > 0.0) || !(dims->qp_tol > 0.0) || !(dims->reg_eps > 0.0) ||
             !(dims->ipm_mu0 > 0.0) || !(dims->ipm_thr0 > 0.0) || (dims->cost_model != 0 && dims->cost_model != 1) ||
-            (dims->cost_model == 1 && dims->row_model == 1) ||      // (no instantiation carries the curvature-aware cost AND Gaussian rows)
             (dims->riccati_form != TMPC_RICCATI_SCHUR && dims->riccati_form != TMPC_RICCATI_SQUARE_ROOT))
             return TMPC_ERR_INVALID;
 #ifdef TMPC_GENERATED_STAGE
@@ -517,10 +518,11 @@ int tmpc_create(tmpc_handle **out, const tmpc_dims *dims, int32_t B_max, int32_t
     }
     h->fast = h->kernel != nullptr;
     if (h->fast) h->lds_bytes = sizeof(double) * (size_t)tmpc::lds_doubles_fast(d.N, d.n_up + d.M);
-    else { h->kernel = d.cost_model == 1 ? tmpc::tmpc_solve_kernel<1> : (d.row_model == 1 ? tmpc::tmpc_solve_kernel<2> : tmpc::tmpc_solve_kernel<0>); h->lds_bytes = sizeof(double) * (size_t)tmpc::lds_doubles(d.N, d.n_up + d.M); }
+    else { const int sm = tmpc::stage_model(d); h->kernel = sm == 3 ? tmpc::tmpc_solve_kernel<3> : sm == 1 ? tmpc::tmpc_solve_kernel<1> : (sm == 2 ? tmpc::tmpc_solve_kernel<2> : tmpc::tmpc_solve_kernel<0>); h->lds_bytes = sizeof(double) * (size_t)tmpc::lds_doubles(d.N, d.n_up + d.M); }
     h->lds_bytes_fast = h->lds_bytes;
     // two-wave (128-thread) fast kernels park one share of W per stage behind the layout while they linearise (linearise<.., 128>)
-    h->lds_bytes_fast2 = h->lds_bytes_fast + sizeof(double) * (size_t)d.N * tmpc::NP28;
+    // (a shape whose default is the generic kernel may still have a four-wave tick kernel -- curvature-aware cost + Gaussian rows: the fast LAYOUT's size then)
+    h->lds_bytes_fast2 = (h->fast ? h->lds_bytes_fast : sizeof(double) * (size_t)tmpc::lds_doubles_fast(d.N, d.n_up + d.M)) + sizeof(double) * (size_t)d.N * tmpc::NP28;
     if (h->fast && h->threads == 128) h->lds_bytes = h->lds_bytes_fast2;
     auto fail = [&](int code) { delete h; return code; };
     if (hipSetDevice(device) != hipSuccess) return fail(TMPC_ERR_HIP);
@@ -539,7 +541,7 @@ int tmpc_create(tmpc_handle **out, const tmpc_dims *dims, int32_t B_max, int32_t
             h->kernel_scan = nullptr;
     }
     int quad_sl = 3;
-    if (schur && h->fast && (h->threads == tmpc::NT || d.N > 20) && (h->kernel_quad = tmpc::pick_quad_kernel(d, false, lab_env("TMPC_QUAD_AB") != nullptr, &quad_sl)) != nullptr) {
+    if (schur && (h->fast || tmpc::stage_model(d) == 3) && (h->threads == tmpc::NT || d.N > 20) && (h->kernel_quad = tmpc::pick_quad_kernel(d, false, lab_env("TMPC_QUAD_AB") != nullptr, &quad_sl)) != nullptr) {
         // fast layout + the W shares of the split linearisation (wave 0's N x 28, the obstacle lanes' 36 N / 24 N: they lie inside the scan scratch, which is dead then) + the scan scratch
         h->lds_bytes_quad = h->lds_bytes_fast2 + sizeof(double) * (size_t)(quad_sl == 3 ? tmpc::scan::lds_doubles<3>(d.N) : tmpc::scan::lds_doubles<2>(d.N));
         if (h->lds_bytes_quad > 160 * 1024 ||

@@ -22,14 +22,14 @@
 #define TMPC_SCAN_G_SHAPES(X) X(-1, 12, 4, 128, tmpc::ScanSoloT<2>) X(-1, 9, 6, 128, tmpc::ScanSolo)
 #define TMPC_QUAD_G_SHAPES(X) X(-1, 4, tmpc::ScanQuad)
 // latency mode 3 for 21 <= N <= 31 (the shipped jackal / jackalsimulator horizon N = 30): eight lanes per stage, run-time row mix up to 34 rows (MM, CM)
-#define TMPC_QUAD_W_SHAPES(X) X(6, 0) X(6, 1) X(6, 2)
+#define TMPC_QUAD_W_SHAPES(X) X(6, 0) X(6, 1) X(6, 2) X(6, 3)
 #define TMPC_COMPACT_G_SHAPES(X) X(-1, 10, 3)
 // compact kernels, one wave per trajectory (NLIN, MM, LPS)
 #define TMPC_COMPACT_SHAPES(X) X(8, 8, 3) X(0, 4, 3) X(12, 12, 3) X(24, 0, 3) X(-1, 7, 3) X(-1, 10, 3)
 // compact kernels, two waves per trajectory (NLIN, MM, LPS, CM)
 #define TMPC_CP2_SHAPES(X) X(20, 8, 4, 0) X(20, 8, 4, 1) X(12, 12, 4, 0) X(8, 8, 4, 0) X(-1, 6, 4, 0) X(-1, 9, 4, 0) X(-1, 6, 4, 2) X(5, 5, 4, 2)
 // generic kernel (CM)
-#define TMPC_GENERIC_MODELS(X) X(0) X(1) X(2)
+#define TMPC_GENERIC_MODELS(X) X(0) X(1) X(2) X(3)
 
 #define TMPC_ALL_INSTANCES(KW)                                                                                                                     \
     TMPC_FAST_SHAPES(TMPC_I_FAST_##KW) TMPC_FAST_SHAPES(TMPC_I_PROF_##KW) TMPC_FAST_CM_SHAPES(TMPC_I_FASTCM_##KW) TMPC_SCAN_SHAPES(TMPC_I_SCAN_##KW) \

@@ -19,6 +19,7 @@ SHAPES = [
     ("rosnav", dict(N=20, M=12, S=8, B=32, slack=True, n_decomp=12), dict(N=20, S=8, n_lin=12, M=12, n_slk=12, slack=1), {}),
     ("jackal-shape", dict(N=30, M=5, S=3, B=32), dict(N=30, S=3, n_lin=5, M=5), {}),
     ("jackal-default (Gaussian rows)", dict(N=30, M=5, S=3, B=32, chance=True), dict(N=30, S=3, n_lin=5, M=5, row_model=1), dict(oracle=dict(N=30, S=3, n_lin=5, M=0, n_gauss=5))),
+    ("jackal-default with the CA cost (CM = 3)", dict(N=30, M=5, S=3, B=32, chance=True), dict(N=30, S=3, n_lin=5, M=5, row_model=1, cost_model=1), dict(oracle=dict(N=30, S=3, n_lin=5, M=0, n_gauss=5, cost_model=1))),
     ("cfg3 as named (CA cost)", dict(N=30, M=8, B=32, slack=True, n_decomp=12), dict(N=30, S=5, n_lin=8, M=8, n_slk=12, slack=1, cost_model=1), {}),
 ]
 n_scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 24

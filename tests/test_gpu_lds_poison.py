@@ -15,6 +15,7 @@ CASES = {
     "N = 11": (dict(N=11, S=5, n_lin=8, M=8), dict(N=11, M=8), 16),
     "cfg3 N = 30": (dict(N=30, S=5, n_lin=8, M=8, n_slk=12, slack=1), dict(N=30, M=8, slack=True, n_decomp=12), 32),
     "cfg3 N = 30, CA cost": (dict(N=30, S=5, n_lin=8, M=8, n_slk=12, slack=1, cost_model=1), dict(N=30, M=8, slack=True, n_decomp=12), 32),
+    "jackal default with the CA cost (CM = 3: generic + four-wave kernels)": (dict(N=30, S=3, n_lin=5, M=5, row_model=1, cost_model=1), dict(N=30, M=5, S=3, chance=True), 16),
     "jackal default, Gaussian rows": (dict(N=30, S=3, n_lin=5, M=5, row_model=1), dict(N=30, M=5, S=3, chance=True), 32),
 }
 
