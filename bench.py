@@ -809,6 +809,7 @@ def main():
     # ---- p50 latency of one control tick (64 trajectories, host call -> best index on host) --------------
     lat = None
     lat5 = None
+    lat5_n30 = None
     lanes = None
     if rank == 0 and a.lanes and not use_dist and not dims.cost_model and not dims.row_model and solver.has_lane_kernels():
         # the lane-per-trajectory variant (tmpc_set_throughput_mode) on the same resident batch: the measured alternative design
@@ -831,7 +832,7 @@ def main():
                    3: "latency 3 (FOUR waves per trajectory: stage evaluation split four ways, row passes at twelve lanes per stage, the wide phases of the "
                       "parallel-in-time factorisation on all four waves)"}
 
-        def tick_block(nb, label):
+        def tick_block(nb, label, dims=dims, batch=batch, wl=wl):
             """One control tick of `nb` planners, host call -> best index on host, in every kernel variant the library offers for it."""
             one = solver.BatchedSolver(dims, B_max=nb, device=local_rank)
             hx, h0, hp = batch["xinit"][:nb], batch["x0"][:nb], batch["params"][:nb]
@@ -881,6 +882,13 @@ def main():
         # the reference's DEPLOYED size: 4 guidance planners + the non-guided T-MPC++ planner (mpc_planner_jackalsimulator/config/guidance_planner.yaml:11,
         # guidance_constraints.cpp:40-52): the first five trajectories of the same set
         lat5 = tick_block(5, "the reference's deployed size: n_paths = 4 guidance planners + the non-guided planner (guidance_planner.yaml:11)")
+        # ... and at the horizon the reference SHIPS for this stack (mpc_planner_jackalsimulator/config/settings.yaml N: 30; BASELINE's configs[1] says N = 20):
+        # the same module stack, N = 30, 4 guidance planners + the non-guided one
+        from mpc_planner_amd import scenes
+        wl30 = dict(dims=dict(N=30, S=5, n_lin=8, M=8), scene=dict(N=30, M=8, tmpc_pp=True))
+        sc30 = scenes.make_scene(11, B=4, **wl30["scene"])
+        lat5_n30 = tick_block(5, "the reference's deployed size AND shipped horizon: 4 + 1 planners, N = 30 (settings.yaml; same module stack as configs[1])",
+                              dims=solver.default_dims(**wl30["dims"]), batch=sc30, wl=wl30)
 
     if rank == 0:
         solves = B * world * a.steps
@@ -947,6 +955,7 @@ def main():
             "lanes_variant": lanes,
             "latency_b64": lat,
             "latency_b5": lat5,
+            "latency_b5_n30": lat5_n30,
             "best_index_sample": best[:4].tolist(),
             "scenario_pipeline": scenario_info,
         }

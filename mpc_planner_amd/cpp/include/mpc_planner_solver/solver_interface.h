@@ -205,6 +205,7 @@ namespace MPCPlanner
         int _capacity{0}, _device{-1}, _iterations{-1}, _next_slot{0};
         double _dt{0.}, _last_launch_s{0.};
         std::map<const Solver *, int> _slot;
+        std::vector<double> _stage_xinit, _stage_x0, _stage_par;      // host staging of a tick's inputs (kept between ticks)
         std::vector<int> _free_slots;           // slots of forgotten Solvers, cleared (tmpc_clear_slot) before they are handed out again
         int takeSlot();
     };

@@ -346,7 +346,9 @@ namespace MPCPlanner
         for (Solver *s : solvers)
             if (!_slot.count(s)) { _slot[s] = takeSlot(); s->_contexts.push_back(this); }   // (a reused slot was cleared: the previous owner's state is not inherited)
         const size_t n0 = (SOLVER_NU + SOLVER_NX) * (SOLVER_N + 1), np = (size_t)SOLVER_NP * SOLVER_N;
-        std::vector<double> xinit((size_t)B * SOLVER_NX), x0(B * n0), par(B * np);
+        // (members, grown as needed: a tick does not allocate and zero ~23 KB per planner)
+        std::vector<double> &xinit = _stage_xinit, &x0 = _stage_x0, &par = _stage_par;
+        if (xinit.size() < (size_t)B * SOLVER_NX) { xinit.resize((size_t)B * SOLVER_NX); x0.resize(B * n0); par.resize(B * np); }
         std::vector<int32_t> slots(B);
         for (int b = 0; b < B; b++) {
             std::memcpy(&xinit[(size_t)b * SOLVER_NX], solvers[b]->_params.xinit, sizeof(double) * SOLVER_NX);

@@ -351,8 +351,8 @@ struct tmpc_handle {
     // spent ~0.2 ms of 1.1 ms in those thirteen transfers).  Larger handles (the bench's 32768 trajectories) keep separate allocations and direct copies.
     char *slab_in = nullptr, *slab_out = nullptr, *pin_in = nullptr, *pin_out = nullptr;
     size_t slab_in_bytes = 0, slab_out_bytes = 0;
-    hipEvent_t in_done = nullptr;    // the last H2D copy out of pin_in (the mirror is rewritten only after it)
-    bool in_pending = false;
+    hipEvent_t in_done = nullptr, slot_done = nullptr;    // the last H2D copies out of pin_in -- batch inputs / slot map: disjoint regions of the mirror, each rewritten only after ITS copy
+    bool in_pending = false, slot_pending = false;
     size_t lds_bytes = 0;
     tmpc::SolveKernel kernel = nullptr;
     int threads = tmpc::NT;          // threads per trajectory (64, or 128 for the two-wave fast variant)
@@ -623,7 +623,7 @@ int tmpc_create(tmpc_handle **out, const tmpc_dims *dims, int32_t B_max, int32_t
             h->slab_in_bytes = in_off[4]; h->slab_out_bytes = out_off[8];
             ok &= hipMalloc(&h->slab_in, in_off[4]) == hipSuccess && hipMalloc(&h->slab_out, out_off[8]) == hipSuccess;
             ok &= hipHostMalloc(&h->pin_in, in_off[4], hipHostMallocDefault) == hipSuccess && hipHostMalloc(&h->pin_out, out_off[8], hipHostMallocDefault) == hipSuccess;
-            ok &= hipEventCreateWithFlags(&h->in_done, hipEventDisableTiming) == hipSuccess;
+            ok &= hipEventCreateWithFlags(&h->in_done, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&h->slot_done, hipEventDisableTiming) == hipSuccess;
             if (ok) {
                 h->o_xinit = (double *)(h->slab_in + in_off[0]); h->o_x0 = (double *)(h->slab_in + in_off[1]); h->o_params = (double *)(h->slab_in + in_off[2]);
                 h->d_slot = (int *)(h->slab_in + in_off[3]);
@@ -675,6 +675,7 @@ void tmpc_destroy(tmpc_handle *h)
     if (h->pin_in) (void)hipHostFree(h->pin_in);
     if (h->pin_out) (void)hipHostFree(h->pin_out);
     if (h->in_done) (void)hipEventDestroy(h->in_done);
+    if (h->slot_done) (void)hipEventDestroy(h->slot_done);
     for (auto &e : h->ev) (void)hipEventDestroy(e);
     tmpc::lanes::destroy(h->lanes);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -909,11 +910,11 @@ int tmpc_set_slots(tmpc_handle *h, const int32_t *slots)
     }
     TMPC_HIP_CHECK(h, hipSetDevice(h->device));
     if (h->slab_in) {                                               // pinned mirror: asynchronous, nothing to wait for (the caller's array is copied here)
-        if (h->in_pending) { TMPC_HIP_CHECK(h, hipEventSynchronize(h->in_done)); h->in_pending = false; }
+        if (h->slot_pending) { TMPC_HIP_CHECK(h, hipEventSynchronize(h->slot_done)); h->slot_pending = false; }      // (not the batch copy just enqueued: it reads other bytes)
         const size_t o3 = (char *)h->d_slot - h->slab_in;
         std::memcpy(h->pin_in + o3, slots, (size_t)h->B * 4);
         TMPC_HIP_CHECK(h, hipMemcpyAsync(h->d_slot, h->pin_in + o3, (size_t)h->B * 4, hipMemcpyHostToDevice, h->stream));
-        TMPC_HIP_CHECK(h, hipEventRecord(h->in_done, h->stream)); h->in_pending = true;
+        TMPC_HIP_CHECK(h, hipEventRecord(h->slot_done, h->stream)); h->slot_pending = true;
     } else {
     if (!h->d_slot) TMPC_HIP_CHECK(h, hipMalloc(&h->d_slot, (size_t)h->B_max * 4));
     TMPC_HIP_CHECK(h, hipMemcpyAsync(h->d_slot, slots, (size_t)h->B * 4, hipMemcpyHostToDevice, h->stream));
