@@ -223,7 +223,11 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
     using C = FastCfg<NLIN, MM, LPS>;
     constexpr int RPL = C::RPL;
     constexpr bool OCC2 = CP;                       // compact instantiations are built for two waves per SIMD (<= 256 registers)
-    constexpr bool QSUM = NTH == 256;               // four-wave kernels (12 or 8 lanes per stage): the stage sums are pre-reduced per aligned quad
+#ifdef TMPC_EXP_NO_QSUM4
+    constexpr bool QSUM = NTH == 256;
+#else
+    constexpr bool QSUM = NTH == 256 || (NTH == 128 && LPS == 4);      // four-wave kernels (12 or 8 lanes per stage), two-wave kernels at four: the stage sums are pre-reduced per aligned quad
+#endif
     static_assert(!QSUM || LPS % 4 == 0, "quad pre-reduction: whole quads per stage");
     // compile-time constants for the tuned shapes, kernel arguments for runtime-shape instantiations
     const int NH = C::RT ? L.nh : C::NH, NR = NH + 14, NLIN_ = C::RT ? d.n_up : NLIN;
