@@ -223,6 +223,13 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
     using C = FastCfg<NLIN, MM, LPS>;
     constexpr int RPL = C::RPL;
     constexpr bool OCC2 = CP;                       // compact instantiations are built for two waves per SIMD (<= 256 registers)
+    // one-wave kernels (three lanes per stage; a stage may straddle two 16-lane rows): the same pre-reduction by two WAVE shifts (DPP wave_shl:1) -- the
+    // saturated compact kernel +0.5 % (profiles/round6_one_wave_shift_prereduce_ab.jsonl: three-way same-address ds_add_f64 were 2.6 % of the LDS unit's cycles)
+#ifdef TMPC_EXP_NO_WSHL3
+    constexpr bool TSUM = false;
+#else
+    constexpr bool TSUM = LPS == 3;
+#endif
 #ifdef TMPC_EXP_NO_QSUM4
     constexpr bool QSUM = NTH == 256;
 #else
@@ -565,7 +572,12 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
                 gs0 = quad(gs0); gs1 = quad(gs1); gs2 = quad(gs2); rs0 = quad(rs0); rs1 = quad(rs1); rs2 = quad(rs2);
                 h00 = quad(h00); h10 = quad(h10); h11 = quad(h11); h20 = quad(h20); h21 = quad(h21); h22 = quad(h22);
             }
-            if (stage_lane && (!QSUM || (c & 3) == 0)) {
+            if constexpr (TSUM) {                 // three lanes per stage: x[l] + x[l + 1] + x[l + 2] by two wave shifts (wave_shl:1), the stage's first lane adds
+                auto tri3 = [](double x) { const double t = x + dpp_shift_zero<0x130>(x); return x + dpp_shift_zero<0x130>(t); };
+                gs0 = tri3(gs0); gs1 = tri3(gs1); gs2 = tri3(gs2); rs0 = tri3(rs0); rs1 = tri3(rs1); rs2 = tri3(rs2);
+                h00 = tri3(h00); h10 = tri3(h10); h11 = tri3(h11); h20 = tri3(h20); h21 = tri3(h21); h22 = tri3(h22);
+            }
+            if (stage_lane && (!QSUM || (c & 3) == 0) && (!TSUM || c == 0)) {
                 lds_add(&L.rg[mul24(k, NV) + ZX], -gs0); lds_add(&L.rg[mul24(k, NV) + ZY], -gs1); lds_add(&L.rg[mul24(k, NV) + ZPSI], -gs2);
                 lds_add(&L.gh[mul24(k, NV) + ZX], rs0); lds_add(&L.gh[mul24(k, NV) + ZY], rs1); lds_add(&L.gh[mul24(k, NV) + ZPSI], rs2);
                 double *Hk = L.Hh + hoff_lane<CP>(k);
@@ -683,7 +695,11 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
                 auto quad = [](double x) { x += dpp_move<0xB1, 0xf>(x, 0.0); x += dpp_move<0x4E, 0xf>(x, 0.0); return x; };
                 cs0 = quad(cs0); cs1 = quad(cs1); cs2 = quad(cs2);
             }
-            if (stage_lane && (!QSUM || (c & 3) == 0)) { lds_add(&L.gh[mul24(k, NV) + ZX], cs0); lds_add(&L.gh[mul24(k, NV) + ZY], cs1); lds_add(&L.gh[mul24(k, NV) + ZPSI], cs2); }
+            if constexpr (TSUM) {
+                auto tri3 = [](double x) { const double t = x + dpp_shift_zero<0x130>(x); return x + dpp_shift_zero<0x130>(t); };
+                cs0 = tri3(cs0); cs1 = tri3(cs1); cs2 = tri3(cs2);
+            }
+            if (stage_lane && (!QSUM || (c & 3) == 0) && (!TSUM || c == 0)) { lds_add(&L.gh[mul24(k, NV) + ZX], cs0); lds_add(&L.gh[mul24(k, NV) + ZY], cs1); lds_add(&L.gh[mul24(k, NV) + ZPSI], cs2); }
         }
         team.sync();
         }
