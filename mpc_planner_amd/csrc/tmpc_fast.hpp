@@ -228,7 +228,7 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
 #ifdef TMPC_EXP_NO_WSHL3
     constexpr bool TSUM = false;
 #else
-    constexpr bool TSUM = LPS == 3;
+    constexpr bool TSUM = LPS == 3 || (LPS == 6 && NTH == 128);      // (six lanes per stage -- the two-wave latency kernels of N <= 21 --: two triples, two adds per entry)
 #endif
 #ifdef TMPC_EXP_NO_QSUM4
     constexpr bool QSUM = NTH == 256;
@@ -568,7 +568,8 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
             // one entry cost that phase twice what six did (measured: 328 k instead of 164 k cycles per solve).  The stage's lanes 12 s .. 12 s + 11 are three
             // aligned quads: two DPP quad permutations sum each quad in registers, its first lane adds -- three-way conflicts, like the one-wave kernels.
             if constexpr (QSUM) {
-                auto quad = [](double x) { x += dpp_move<0xB1, 0xf>(x, 0.0); x += dpp_move<0x4E, 0xf>(x, 0.0); return x; };      // quad_perm [1,0,3,2], then [2,3,0,1]
+                // (eight lanes per stage: a stage is half a 16-lane row, so one row shift by four folds its second quad into the first: no conflict left)
+                auto quad = [](double x) { x += dpp_move<0xB1, 0xf>(x, 0.0); x += dpp_move<0x4E, 0xf>(x, 0.0); if constexpr (LPS == 8) x += dpp_shift_zero<0x104>(x); return x; };      // quad_perm [1,0,3,2], then [2,3,0,1]; row_shl:4
                 gs0 = quad(gs0); gs1 = quad(gs1); gs2 = quad(gs2); rs0 = quad(rs0); rs1 = quad(rs1); rs2 = quad(rs2);
                 h00 = quad(h00); h10 = quad(h10); h11 = quad(h11); h20 = quad(h20); h21 = quad(h21); h22 = quad(h22);
             }
@@ -577,7 +578,7 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
                 gs0 = tri3(gs0); gs1 = tri3(gs1); gs2 = tri3(gs2); rs0 = tri3(rs0); rs1 = tri3(rs1); rs2 = tri3(rs2);
                 h00 = tri3(h00); h10 = tri3(h10); h11 = tri3(h11); h20 = tri3(h20); h21 = tri3(h21); h22 = tri3(h22);
             }
-            if (stage_lane && (!QSUM || (c & 3) == 0) && (!TSUM || c == 0)) {
+            if (stage_lane && (!QSUM || (c & (LPS == 8 ? 7 : 3)) == 0) && (!TSUM || c == 0 || c == 3)) {
                 lds_add(&L.rg[mul24(k, NV) + ZX], -gs0); lds_add(&L.rg[mul24(k, NV) + ZY], -gs1); lds_add(&L.rg[mul24(k, NV) + ZPSI], -gs2);
                 lds_add(&L.gh[mul24(k, NV) + ZX], rs0); lds_add(&L.gh[mul24(k, NV) + ZY], rs1); lds_add(&L.gh[mul24(k, NV) + ZPSI], rs2);
                 double *Hk = L.Hh + hoff_lane<CP>(k);
@@ -692,14 +693,14 @@ __device__ __forceinline__ int ipm_fast(const Lds &L, const Dims &d, int tid, co
                 if constexpr (K != 0) { if (a && (K == 1 || (box >> s & 1))) lds_add(&L.gh[mul24(k, NV) + VARK(s_)], w * CUK(s_)); }
             });
             if constexpr (QSUM) {
-                auto quad = [](double x) { x += dpp_move<0xB1, 0xf>(x, 0.0); x += dpp_move<0x4E, 0xf>(x, 0.0); return x; };
+                auto quad = [](double x) { x += dpp_move<0xB1, 0xf>(x, 0.0); x += dpp_move<0x4E, 0xf>(x, 0.0); if constexpr (LPS == 8) x += dpp_shift_zero<0x104>(x); return x; };
                 cs0 = quad(cs0); cs1 = quad(cs1); cs2 = quad(cs2);
             }
             if constexpr (TSUM) {
                 auto tri3 = [](double x) { const double t = x + dpp_shift_zero<0x130>(x); return x + dpp_shift_zero<0x130>(t); };
                 cs0 = tri3(cs0); cs1 = tri3(cs1); cs2 = tri3(cs2);
             }
-            if (stage_lane && (!QSUM || (c & 3) == 0) && (!TSUM || c == 0)) { lds_add(&L.gh[mul24(k, NV) + ZX], cs0); lds_add(&L.gh[mul24(k, NV) + ZY], cs1); lds_add(&L.gh[mul24(k, NV) + ZPSI], cs2); }
+            if (stage_lane && (!QSUM || (c & (LPS == 8 ? 7 : 3)) == 0) && (!TSUM || c == 0 || c == 3)) { lds_add(&L.gh[mul24(k, NV) + ZX], cs0); lds_add(&L.gh[mul24(k, NV) + ZY], cs1); lds_add(&L.gh[mul24(k, NV) + ZPSI], cs2); }
         }
         team.sync();
         }
