@@ -14,17 +14,25 @@ N, M, S = 20, 8, 5
 B = 7                                                     # 7 guidance trajectories + the non-guided planner = 8 planners = the reference's num_threads(8)
 
 
-def _build():
+def _paths(horizon):
+    """Generated sources + binary per horizon: N = 20 is BASELINE's configs[1]; N = 30 the horizon the reference ships (settings.yaml)."""
+    if horizon == N:
+        return GEN, BIN
+    return os.path.join(ROOT, "build", f"generated_cfg2_n{horizon}"), os.path.join(ROOT, "build", f"test_omp_solvers_n{horizon}")
+
+
+def _build(horizon=N):
     import __graft_entry__ as g
     g.build()
     from mpc_planner_amd.generate_solver import generate_solver
-    generate_solver(GEN, N=N, max_obstacles=M, num_segments=S, guidance=True)
+    gen, binary = _paths(horizon)
+    generate_solver(gen, N=horizon, max_obstacles=M, num_segments=S, guidance=True)
     cpp = os.path.join(ROOT, "mpc_planner_amd", "cpp")
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-fopenmp", "-I", os.path.join(cpp, "include"), "-I", os.path.join(GEN, "include"),
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-fopenmp", "-I", os.path.join(cpp, "include"), "-I", os.path.join(gen, "include"),
                            "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "test_omp_solvers.cpp"),
-                           os.path.join(cpp, "src", "solver_interface.cpp"), os.path.join(GEN, "src", "mpc_planner_parameters.cpp"),
+                           os.path.join(cpp, "src", "solver_interface.cpp"), os.path.join(gen, "src", "mpc_planner_parameters.cpp"),
                            "-L", os.path.join(ROOT, "mpc_planner_amd"), "-ltmpc_hip", "-Wl,-rpath," + os.path.join(ROOT, "mpc_planner_amd"),
-                           "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-lamdhip64", "-o", BIN])
+                           "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-lamdhip64", "-o", binary])
 
 
 def test_omp_drop_in_compiles():
@@ -32,24 +40,25 @@ def test_omp_drop_in_compiles():
     assert os.path.exists(BIN)
 
 
-def run_omp_ticks(tmp_dir, reps=30, planners=B, tmpc_pp=True):
+def run_omp_ticks(tmp_dir, reps=30, planners=B, tmpc_pp=True, horizon=N):
     """Run the binary on a cfg-2 tick with `planners` guidance trajectories (+ the non-guided planner); returns the parsed output lines."""
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from mpc_planner_amd import scenes
     import test_cpp_optimize as tco
-    if not os.path.exists(BIN) or os.path.getmtime(BIN) < os.path.getmtime(os.path.join(ROOT, "mpc_planner_amd", "libtmpc_hip.so")):
-        _build()
-    sc = scenes.make_scene(21, N=N, M=M, B=planners, tmpc_pp=tmpc_pp)
-    f = os.path.join(str(tmp_dir), f"scene_omp_{planners}.bin")
+    gen, binary = _paths(horizon)
+    if not os.path.exists(binary) or os.path.getmtime(binary) < os.path.getmtime(os.path.join(ROOT, "mpc_planner_amd", "libtmpc_hip.so")):
+        _build(horizon)
+    sc = scenes.make_scene(21, N=horizon, M=M, B=planners, tmpc_pp=tmpc_pp)
+    f = os.path.join(str(tmp_dir), f"scene_omp_{planners}_{horizon}.bin")
     old_b = tco.B
     tco.B = planners                                       # (_scene_file writes the module-level B into the header)
     try:
-        tco._scene_file(sc, f, 2)
+        tco._scene_file(sc, f, 2, dims=(horizon, M, S))
     finally:
         tco.B = old_b
     env = dict(os.environ, OMP_NUM_THREADS="8")
-    out = subprocess.run([BIN, os.path.join(GEN, "config"), f, str(reps)], capture_output=True, text=True, timeout=600, env=env)
+    out = subprocess.run([binary, os.path.join(gen, "config"), f, str(reps)], capture_output=True, text=True, timeout=600, env=env)
     return out, {l.split()[0]: l.split()[1:] for l in out.stdout.splitlines() if l.strip()}
 
 
@@ -63,3 +72,14 @@ def test_omp_drop_in_matches_serial_loop_and_solve_batch(tmp_path):
     assert int(kv["exit_code"][4]) >= 1                                                        # (the tick has successful planners: a comparison of failures proves nothing)
     p50 = kv["tick_ms_p50"]
     assert float(p50[1]) > 0 and float(p50[3]) > 0
+
+
+@pytest.mark.gpu
+def test_omp_drop_in_at_the_shipped_horizon(tmp_path):
+    """The same three-way bitwise comparison for a solver generated at the horizon the reference ships (mpc_planner_jackalsimulator/config/settings.yaml N: 30)
+    and its deployed size (guidance_planner.yaml n_paths: 4, + the non-guided planner): the C++ mirror asks for the four-wave tick kernel there too."""
+    out, kv = run_omp_ticks(tmp_path, reps=10, planners=4, horizon=30)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert kv["planners"][0] == "5"
+    assert kv["omp_vs_serial_bitwise"] == ["1"] and kv["omp_vs_batch_bitwise"] == ["1"], out.stdout
+    assert kv["repeated_ticks"][2] == "1" and int(kv["exit_code"][4]) >= 1, out.stdout

@@ -22,9 +22,9 @@ python - > $O/round6_final_omp_dropin.log 2>&1 <<'PY'
 import sys, tempfile
 sys.path.insert(0, "tests")
 import test_cpp_omp as t
-for planners, pp in ((7, True), (4, True)):
-    out, kv = t.run_omp_ticks(tempfile.mkdtemp(), reps=100, planners=planners, tmpc_pp=pp)
-    print("guidance planners", planners, "+ the non-guided planner; return code", out.returncode)
+for planners, pp, horizon in ((7, True, 20), (4, True, 20), (4, True, 30)):
+    out, kv = t.run_omp_ticks(tempfile.mkdtemp(), reps=100, planners=planners, tmpc_pp=pp, horizon=horizon)
+    print("guidance planners", planners, "+ the non-guided planner; horizon N =", horizon, "; return code", out.returncode)
     print(out.stdout)
 PY
 cat $O/round6_final_omp_dropin.log | grep -v "^planner\|^$"
