@@ -361,6 +361,11 @@ __device__ __forceinline__ void poly_clip_fast(PolyFrac &w, double ai1, double a
 }
 __device__ __forceinline__ bool poly_frac_alive(const PolyFrac &w) { return w.nh * w.dl - w.nl * w.dh >= -POLY_SEED_MARGIN * (w.dh * w.dl); }   // (>=: both sides are 0 while a bound is infinite)
 
+#ifdef TMPC_POLY_PROFILE
+#define POLY_T(n) do { __syncthreads(); if (tid == 0) { const long long t_ = wall_clock64(); if (t_ - t_prev > 2500) printf("poly unit %d seg %d: %lld (x10 ns) nk %d ns %d ne %d\n", unit, n, t_ - t_prev, s_nk, s_ns, s_ne); t_prev = wall_clock64(); } } while (0)
+#else
+#define POLY_T(n) do { } while (0)
+#endif
 // one (trajectory, stage) = `unit` by one workgroup of 256 threads
 __device__ __forceinline__ void poly_stage(int unit, const Dims &d, int B, const double *x0, double *params, const double *samples, int n_pts,
                                            int n_rows, const int *scene_of, const double *state_x, double radius, double disc_offset,
@@ -370,7 +375,7 @@ __device__ __forceinline__ void poly_stage(int unit, const Dims &d, int B, const
     extern __shared__ double s_dyn[];                                    // the candidates, compact: normal, margin, sample index (~index: not an edge)
     __shared__ unsigned long long s_best[POLY_SEC1];
     __shared__ double sd_ax[POLY_SEC1], sd_ay[POLY_SEC1], sd_dm[POLY_SEC1];
-    __shared__ int s_seed[POLY_SEC1];
+    __shared__ int s_seed[POLY_SEC1], s_pick[POLY_SEC1];
     __shared__ short s_next[POLY_SEC1], s_prev[POLY_SEC1];              // nearest sector with a seed, counter-clockwise / clockwise (-1: none)
     __shared__ int s_nk, s_ns, s_nw, s_ne;
     __shared__ unsigned long long s_mask[4];
@@ -387,8 +392,12 @@ __device__ __forceinline__ void poly_stage(int unit, const Dims &d, int B, const
         if (tid < n_rows) { p[ip_slk(d, tid, 0)] = 1.0; p[ip_slk(d, tid, 1)] = 0.0; p[ip_slk(d, tid, 2)] = state_x[sc] + 100.0; which[tid] = -1; }
         return;
     }
+    long long t_prev = 0; (void)t_prev;
+#ifdef TMPC_POLY_PROFILE
+    t_prev = wall_clock64();
+#endif
     s_best[tid] = ~0ull; s_seed[tid] = POLY_NONE;
-    if (tid == 0) { s_nk = 0; s_ne = 0; }
+    if (tid == 0) { s_nk = 0; s_ne = 0; s_ns = 0; }
     __syncthreads();
     const double px = x0[((size_t)b * (N + 1) + k) * ext_nv(d) + ZX], py = x0[((size_t)b * (N + 1) + k) * ext_nv(d) + ZY];
     const double2 *o = reinterpret_cast<const double2 *>(samples) + ((size_t)sc * N + (k - 1)) * n_pts;
@@ -412,6 +421,7 @@ __device__ __forceinline__ void poly_stage(int unit, const Dims &d, int B, const
         for (int c = 0; c < CACHE; c++) if (r_alive >> c & 1) f(tid + c * 256, r_ax[c], r_ay[c], r_dm[c], r_sec[c]);
         for (int i = tid + CACHE * 256; i < n_pts; i += 256) if (alive(i)) { double ax, ay, dm; halfspace(i, ax, ay, dm); f(i, ax, ay, dm, poly_sector_angular(ax, ay)); }
     };
+    POLY_T(0);
     every_sample([&](int, double, double, double dm, int sec) { atomicMin(&s_best[sec], poly_key(dm)); });
     __syncthreads();
     every_sample([&](int i, double, double, double dm, int sec) { if (poly_key(dm) == s_best[sec]) atomicMin(&s_seed[sec], i); });
@@ -435,6 +445,7 @@ __device__ __forceinline__ void poly_stage(int unit, const Dims &d, int B, const
         s_next[tid] = (short)nx; s_prev[tid] = (short)pv;
     }
     __syncthreads();
+    POLY_T(1);
     // a halfspace is clipped by the seed of its own sector and the two nearest seeds on either side; the interval only shrinks,
     // so once it is empty the halfspace is out, whatever other seeds would do
     every_sample([&](int i, double ax, double ay, double dm, int sec) {
@@ -447,6 +458,7 @@ __device__ __forceinline__ void poly_stage(int unit, const Dims &d, int B, const
         if (poly_frac_alive(w)) { const int e = atomicAdd(&s_nk, 1); if (e < cap) { c_ax[e] = ax; c_ay[e] = ay; c_dm[e] = dm; c_idx[e] = i; } }
     });
     __syncthreads();
+    POLY_T(2);
     if (s_nk > cap) { if (tid == 0) overflow[1 + atomicAdd(&overflow[0], 1)] = unit; return; }          // (uniform: s_nk is final after the barrier; only in the first pass)
     // ---- filter, second round, on the list (~100 -> ~11): seeds = the closest candidate of each of 2048 sectors (pairwise comparison:
     //      the list is short; the sector rides in bits 13-23 of the index word), every seed clips every candidate -- G threads per
@@ -456,22 +468,32 @@ __device__ __forceinline__ void poly_stage(int unit, const Dims &d, int B, const
         for (int ci = tid; ci < nk1; ci += 256) c_idx[ci] |= poly_sector(c_ax[ci], c_ay[ci], 256) << 13;
         if (tid == 0) { s_ns = 0; s_nw = 0; }
         __syncthreads();
-        for (int ci = tid; ci < nk1; ci += 256) {
-            const double dmi = c_dm[ci];
-            const int me = c_idx[ci], i = me & POLY_IDX_MASK, sec = me >> 13;
-            bool seed = true;
-#pragma unroll 8
-            for (int cj = 0; cj < nk1; cj++) {                    // (no early exit: the reads pipeline)
-                const int other = c_idx[cj];
-                const double dmj = c_dm[cj];
-                if ((other >> 13) == sec && (dmj < dmi || (dmj == dmi && (other & POLY_IDX_MASK) < i))) seed = false;
+        // Seeds by table (round 6): one pass per octant over the 256 bins of the octant -- keys in s_best, the lowest sample index among equal keys in s_pick --
+        // O(nk1) where the pairwise comparison of rounds 2-5 was O(nk1^2 / 256): the units that keep 300 - 600 candidates (stage 1 of a horizon: the 256
+        // scenarios of an obstacle still nearly coincide) took 400 us and with them the whole launch, 27 % of cfg 5's step.  (Both forms behind a branch on nk1
+        // cost the kernel 20 B of scratch more and the saturated launch 6 %: one form.)
+        for (int oct = 0; oct < 8; oct++) {
+            s_best[tid] = ~0ull; s_pick[tid] = POLY_NONE;
+            __syncthreads();
+            for (int ci = tid; ci < nk1; ci += 256) {
+                const int sec = c_idx[ci] >> 13;
+                if ((sec >> 8) == oct) atomicMin(&s_best[sec & 255], poly_key(c_dm[ci]));
             }
-            if (seed) {                                           // (the round-1 seed table is free; seeds beyond its size are not used: a looser filter)
-                const int e = atomicAdd(&s_ns, 1);
-                if (e < POLY_SEC1) { sd_ax[e] = c_ax[ci]; sd_ay[e] = c_ay[ci]; sd_dm[e] = dmi; s_seed[e] = i; }
+            __syncthreads();
+            for (int ci = tid; ci < nk1; ci += 256) {
+                const int me = c_idx[ci], sec = me >> 13;
+                if ((sec >> 8) == oct && poly_key(c_dm[ci]) == s_best[sec & 255]) atomicMin(&s_pick[sec & 255], me & POLY_IDX_MASK);
             }
+            __syncthreads();
+            for (int ci = tid; ci < nk1; ci += 256) {
+                const int me = c_idx[ci], i = me & POLY_IDX_MASK, sec = me >> 13;
+                if ((sec >> 8) == oct && s_pick[sec & 255] == i) {   // (the round-1 seed table is free; seeds beyond its size are not used: a looser filter)
+                    const int e = atomicAdd(&s_ns, 1);
+                    if (e < POLY_SEC1) { sd_ax[e] = c_ax[ci]; sd_ay[e] = c_ay[ci]; sd_dm[e] = c_dm[ci]; s_seed[e] = i; }
+                }
+            }
+            __syncthreads();
         }
-        __syncthreads();
         const int ns = s_ns < POLY_SEC1 ? s_ns : POLY_SEC1;
         int G = 1;
         while (G < 64 && 2 * G * nk1 <= 256) G *= 2;
@@ -493,6 +515,7 @@ __device__ __forceinline__ void poly_stage(int unit, const Dims &d, int B, const
             if (valid && g == 0 && !poly_frac_alive(w)) c_idx[ci] |= POLY_DROP_FLAG;
         }
         __syncthreads();
+        POLY_T(4);
         for (int c0 = 0; c0 < nk1; c0 += 256) {                   // in-place compaction, chunk-wise: read, then append below the chunk
             const int ci = c0 + tid;
             double ax = 0.0, ay = 0.0, dm = 0.0; int me = POLY_DROP_FLAG;
@@ -504,15 +527,26 @@ __device__ __forceinline__ void poly_stage(int unit, const Dims &d, int B, const
         if (tid == 0) s_nk = s_nw;
         __syncthreads();
     }
+    POLY_T(5);
     // ---- edge test among the candidates, G threads per candidate (G = 256 / candidates, rounded down to a power of two): each takes
     //      every G-th of the other candidates, then min / max / or across the G lanes.  Every candidate clips every other, like in
     //      the mirror, and a quotient is the same whichever thread computes it, so the split does not change the result.  A
     //      candidate found redundant stays in the list as ~index (readers decode it): it still clips the others.
     const int nk = s_nk;
+    // G by cost (round 6): trips x (clips per thread + combination) = ceil(nk G / 256) (ceil(nk / G) + ...).  One thread per candidate (the rule until round 5 for nk > 128) leaves a long
+    // list -- stage 1 of a horizon, where the 256 scenarios of an obstacle still nearly coincide and ~300 nearly parallel candidates pass the filter -- with two
+    // trips of nk sequential clips, the second with 44 busy threads: the tail of the whole launch.  (A pre-test against the seeds alone was tried and prunes nothing
+    // there: the near-duplicates of an edge are near-edges.)
     int G = 1;
-    while (G < 64 && 2 * G * nk <= 256) G *= 2;
+    {
+        int best = ((nk + 255) / 256) * nk * 100;                    // (a clip ~ 100 instructions, a combination step over the G lanes ~ 15)
+        for (int cand = 2, lg = 1; cand <= 64; cand *= 2, lg++) {
+            const int cost = ((nk * cand + 255) / 256) * (((nk + cand - 1) / cand) * 100 + 15 * lg);
+            if (cost < best) { best = cost; G = cand; }
+        }
+    }
     const int g = tid & (G - 1);
-    for (int base = 0; base < nk; base += 256 / G) {                 // (more than one trip only if nk > 256)
+    for (int base = 0; base < nk; base += 256 / G) {                 // (several trips when nk G > 256)
         const int ci = base + tid / G;
         const bool valid = ci < nk;
         const int i = valid ? c_idx[ci] : -1;                         // (entry ci is rewritten only below, by this group)
@@ -535,6 +569,7 @@ __device__ __forceinline__ void poly_stage(int unit, const Dims &d, int B, const
         }
     }
     __syncthreads();
+    POLY_T(6);
     // ---- rows: an edge's row is its rank by (margin, sample index)
     for (int ci = tid; ci < nk; ci += 256) {
         const int i = c_idx[ci];
@@ -552,6 +587,7 @@ __device__ __forceinline__ void poly_stage(int unit, const Dims &d, int B, const
             which[rank] = i;
         }
     }
+    POLY_T(7);
     int n_real = s_ne;
     if (s_ne == 0 && n_pts > 0) {
         // EMPTY polygon: the halfspaces contradict each other (the guess sits in the overlap of inflated discs on opposite sides).

@@ -1,0 +1,10 @@
+#!/bin/bash
+# polygon kernel: launch bounds (256, 4) [HEAD, 112 B scratch] vs (256, 3) / (256, 2) [no scratch]
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; cd $R; export TMPDIR=/tmp
+for v in HEAD lb3 lb2; do
+  [ $v = HEAD ] && unset TMPC_HIP_LIBRARY || export TMPC_HIP_LIBRARY=$R/build/exp/libtmpc_hip_$v.so
+  python tools/bench_polygon.py 8 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$v saturated 2048', round(d['kernel_ms'],3))"
+  python bench.py --workload cfg5 --latency-mode 3 --no-tight --latency-reps 0 --no-cpu-baseline --steps 50 --warmup 5 --index-check-sets 0 2>/dev/null | python -c "
+import json,sys
+d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('$v cfg5 mode 3', round(d['ms_per_step'],4))"
+done
