@@ -339,12 +339,16 @@ __device__ __forceinline__ void poly_clip(PolyClip &w, double ai1, double ai2, d
     const double rhs = dmj - dmi * dot;
     // hi = min(hi, rhs / c), lo = max(lo, rhs / c); the division only when the bound may move: a quotient that is clearly (1e-9
     // relative) on the far side of the current bound leaves it as it is, so the result equals the plain min / max
-    if (c > POLY_EPS_PARALLEL) {
-        const double t = w.hi * c;
-        if (!(rhs > t + 1e-9 * fabs(t))) { const double r = rhs / c; w.hi = r < w.hi ? r : w.hi; }
-    } else if (c < -POLY_EPS_PARALLEL) {
-        const double t = w.lo * c;                                // c < 0:  rhs / c > lo  <=>  rhs < lo c
-        if (!(rhs > t + 1e-9 * fabs(t))) { const double r = rhs / c; w.lo = r > w.lo ? r : w.lo; }
+    // (one code path for both signs of c -- round 6: as two branches the lanes of a wave diverged and every clip paid for two divisions; the expressions
+    //  evaluated per case are the same: bit for bit the same bounds)
+    const bool pos = c > POLY_EPS_PARALLEL;
+    if (pos || c < -POLY_EPS_PARALLEL) {
+        const double t = (pos ? w.hi : w.lo) * c;                 // c < 0:  rhs / c > lo  <=>  rhs < lo c
+        if (!(rhs > t + 1e-9 * fabs(t))) {
+            const double r = rhs / c;
+            const double nhi = r < w.hi ? r : w.hi, nlo = r > w.lo ? r : w.lo;
+            w.hi = pos ? nhi : w.hi; w.lo = pos ? w.lo : nlo;
+        }
     } else if (dot > 0.0 ? (dmj < dmi || (dmj == dmi && j < i)) : rhs < 0.0) w.kill = true;   // parallel: same direction -> the closer one (lowest index) wins
 }
 
