@@ -80,6 +80,10 @@ static SolveKernel pick_fast_kernel(const Dims &d, int *threads, bool prof)
         // runtime-shape instantiations with CM = 2 -- two-wave for 22 <= N <= 32, one-wave for N <= 21, else the generic kernel
         if (prof) return nullptr;
         const int nrg = d.n_up + d.M + 14;
+        // mpc_planner_jackal's default (generate_jackal_solver.py:53-73: N = 30, 5 + 5 rows) on ONE wave at two lanes per stage (round 6): twelve rows per lane
+        // fit the registers, and eight one-wave trajectories per CU keep eight waves busy where four two-wave ones idle a wave through every Riccati sweep --
+        // saturated +27 % (585 -> 741 k solves/s).  Its small-launch twin below, the compact kernel in pick_compact_kernel; ticks: latency modes 2 / 3.
+        if (lps == 2 && d.n_up == 5 && d.M == 5 && !lab_env("TMPC_NO_ONE_WAVE_N30")) return (SolveKernel)tmpc_solve_fast_kernel<5, 5, 2, 64, false, Solo, 2>;
         if (lps != 3 && 4 * d.N <= 128 && !lab_env("TMPC_NO_TWO_WAVE")) {
             *threads = 128;
             if (d.n_up == 5 && d.M == 5) return (SolveKernel)tmpc_solve_fast_kernel<5, 5, 4, 128, false, Solo, 2>;     // mpc_planner_jackal's default (generate_jackal_solver.py:53-73), tuned
@@ -103,6 +107,9 @@ static SolveKernel pick_fast_kernel(const Dims &d, int *threads, bool prof)
     return nullptr;
 #else
     const int nr = d.n_up + d.M + 14;                    // interior-point rows per stage
+    // the jackalsimulator T-MPC stack at the horizon it ships with (8 + 8 rows, N = 30; settings.yaml) on ONE wave at two lanes per stage (round 6, like
+    // mpc_planner_jackal's default above: fifteen rows per lane still fit the registers); its compact twin in pick_compact_kernel
+    if (lps == 2 && d.n_up == 8 && d.M == 8 && !prof && !lab_env("TMPC_NO_ONE_WAVE_N30")) return (SolveKernel)tmpc_solve_fast_kernel<8, 8, 2, 64, false, Solo, 0>;
     if (lps != 3 && 4 * d.N <= 128 && !lab_env("TMPC_NO_TWO_WAVE")) {
         // two waves per trajectory, 4 lanes per stage (22 <= N <= 32: the reference's default N = 30 and BASELINE cfg 3)
         SolveKernel k2 = nullptr;
@@ -166,6 +173,11 @@ static SolveKernel pick_compact_kernel(const Dims &d, bool prof, int *lay)
 {
     *lay = 1;
 #ifndef TMPC_GENERATED_STAGE
+    if (!lab_env("TMPC_FORCE_GENERIC") && !lab_env("TMPC_NO_COMPACT") && !lab_env("TMPC_NO_ONE_WAVE_N30") && !prof && 2 * d.N <= NT && 3 * d.N > NT) {
+        // 22 <= N <= 32 on one wave, two lanes per stage (pick_fast_kernel): mpc_planner_jackal's default, the jackalsimulator stack
+        if (stage_model(d) == 2 && d.n_up == 5 && d.M == 5) { *lay = compact_layout(5, 5, 64); return (SolveKernel)tmpc_solve_compact_kernel<5, 5, 2, false, 64, 2>; }
+        if (stage_model(d) == 0 && d.n_up == 8 && d.M == 8) { *lay = compact_layout(8, 8, 64); return (SolveKernel)tmpc_solve_compact_kernel<8, 8, 2, false>; }
+    }
     if (lab_env("TMPC_FORCE_GENERIC") || lab_env("TMPC_NO_COMPACT") || prof || d.N > 20 || (stage_model(d) != 0 && stage_model(d) != 2)) return nullptr;
     if (stage_model(d) == 2) {                       // Gaussian chance-constraint rows (round 6): the run-time-shape instantiation with up to ten rows per lane
         if (d.n_up + d.M + 14 <= 3 * 10) { *lay = compact_layout(-1, 10, 64); return (SolveKernel)tmpc_solve_compact_kernel<-1, 10, 3, false, 64, 2>; }
@@ -187,10 +199,11 @@ static SolveKernel pick_compact_kernel(const Dims &d, bool prof, int *lay)
 // fast two-wave kernel (57-70 KB of LDS) holds two.  Bitwise the same results; a trajectory takes longer on it (NLP data in the global
 // workspace, the linearisation on one of the two waves), so launch_solve uses it only for launches that the fast kernel could not hold
 // resident at once (more than two trajectories per CU).  The runtime-shape instantiation with 12 rows per lane spills (144 B): not registered.
-static SolveKernel pick_compact2_kernel(const Dims &d, int *lay)
+static SolveKernel pick_compact2_kernel(const Dims &d, int *lay, int *threads)
 {
-    *lay = 1;
+    *lay = 1; *threads = 128;
 #ifndef TMPC_GENERATED_STAGE
+
     if (lab_env("TMPC_FORCE_GENERIC") || lab_env("TMPC_NO_COMPACT") || lab_env("TMPC_NO_TWO_WAVE") || 3 * d.N <= NT || 4 * d.N > 128) return nullptr;
     const int nr = d.n_up + d.M + 14, sm = stage_model(d);
     if (sm == 1) return (d.n_up == 20 && d.M == 8) ? TMPC_CP2(20, 8, 4, 1) : nullptr;      // cfg 3 as named (CA-MPC)
@@ -374,6 +387,7 @@ struct tmpc_handle {
     tmpc::SolveKernel kernel_cp2 = nullptr;   // optional two-wave compact variant (22 <= N <= 32): launches of more than cp2_min_B trajectories
     size_t lds_bytes_cp2 = 0;
     int cp2_min_B = 0;                        // what the fast two-wave kernel holds resident at once (workgroups per CU x CUs)
+    int cp2_threads = 128;
     int dpad_cp = 0, dpad_cp2 = 0;            // Dims::dpad of the compact one-wave / two-wave kernel (pick_d_pad); the fast layouts do not pad
     int lay_cp = 1, lay_cp2 = 1;              // the compact kernels' Hh layout (pick_compact*_kernel)
     bool prio_cp = false, prio_cp2 = false;   // wave issue priorities (Dims::prio) for the compact one-wave / two-wave kernel: only when its residency puts two waves on
@@ -574,28 +588,28 @@ int tmpc_create(tmpc_handle **out, const tmpc_dims *dims, int32_t B_max, int32_t
     if (hipFuncSetAttribute((const void *)h->kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)h->lds_bytes) != hipSuccess)
         return fail(TMPC_ERR_NO_DEVICE);
-    if (schur && h->fast && h->threads == 128 && !h->compact && (h->kernel_cp2 = tmpc::pick_compact2_kernel(d, &h->lay_cp2)) != nullptr) {
+    if (schur && h->fast && h->threads == 128 && !h->compact && (h->kernel_cp2 = tmpc::pick_compact2_kernel(d, &h->lay_cp2, &h->cp2_threads)) != nullptr) {
         {
-            auto lds_cp2 = [&](int pad) { return sizeof(double) * (size_t)tmpc::lds_doubles_compact(d.N, d.n_lin, d.n_up + d.M, 128, pad, h->lay_cp2); };
+            auto lds_cp2 = [&](int pad) { return sizeof(double) * (size_t)tmpc::lds_doubles_compact(d.N, d.n_lin, d.n_up + d.M, h->cp2_threads, pad, h->lay_cp2); };
             auto per_cu_cp2 = [&](int pad) {
                 int n = 0;
                 if (hipFuncSetAttribute((const void *)h->kernel_cp2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cp2(pad)) != hipSuccess ||
-                    hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)h->kernel_cp2, 128, lds_cp2(pad)) != hipSuccess) return 0;
+                    hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)h->kernel_cp2, h->cp2_threads, lds_cp2(pad)) != hipSuccess) return 0;
                 return n;
             };
             const int per_cu0 = per_cu_cp2(0);
-            h->dpad_cp2 = tmpc::pick_d_pad(d.N, d.n_lin, d.n_up + d.M, 128, tmpc::DPAD_MAX, [&](int pad) { return pad == 0 || (per_cu0 > 0 && per_cu_cp2(pad) == per_cu0); });
+            h->dpad_cp2 = tmpc::pick_d_pad(d.N, d.n_lin, d.n_up + d.M, h->cp2_threads, tmpc::DPAD_MAX, [&](int pad) { return pad == 0 || (per_cu0 > 0 && per_cu_cp2(pad) == per_cu0); });
             h->lds_bytes_cp2 = lds_cp2(h->dpad_cp2);
         }
         int per_cu = 0, fast_per_cu = 0, cus = 0;
         if (hipFuncSetAttribute((const void *)h->kernel_cp2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes_cp2) != hipSuccess ||
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)h->kernel_cp2, 128, h->lds_bytes_cp2) != hipSuccess || per_cu <= 0 ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)h->kernel_cp2, h->cp2_threads, h->lds_bytes_cp2) != hipSuccess || per_cu <= 0 ||
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&fast_per_cu, (const void *)h->kernel, 128, h->lds_bytes) != hipSuccess || fast_per_cu <= 0 ||
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0 || per_cu <= fast_per_cu)
             h->kernel_cp2 = nullptr;                         // (no gain in residency: the fast kernel stays alone)
         else {
             if (const char *e = lab_env("TMPC_COMPACT_PER_CU")) { const int v = atoi(e); if (v > 0 && v < per_cu) per_cu = v; }   // experiments
-            h->grid_max = per_cu * cus; h->cp2_min_B = fast_per_cu * cus; h->prio_cp2 = per_cu * 2 == 8;
+            h->grid_max = per_cu * cus; h->cp2_min_B = fast_per_cu * cus; h->prio_cp2 = per_cu * (h->cp2_threads / 64) == 8;
             if (const char *e = lab_env("TMPC_COMPACT2_MIN_B")) h->cp2_min_B = atoi(e);                                            // experiments
         }
     }
@@ -649,7 +663,7 @@ int tmpc_create(tmpc_handle **out, const tmpc_dims *dims, int32_t B_max, int32_t
     ok &= hipMalloc(&h->d_best, 4) == hipSuccess;
     ok &= hipMalloc(&h->d_disabled, B) == hipSuccess;
     if (h->compact || h->kernel_cp2) {
-        ok &= hipMalloc(&h->ws, (size_t)h->grid_max * tmpc::ws_doubles(d.N, h->kernel_cp2 != nullptr) * 8) == hipSuccess;
+        ok &= hipMalloc(&h->ws, (size_t)h->grid_max * tmpc::ws_doubles(d.N, h->kernel_cp2 != nullptr && h->cp2_threads == 128) * 8) == hipSuccess;
         ok &= hipMalloc(&h->ticket, 8 * 4) == hipSuccess;         // one work counter per XCD (next_trajectory)
     }
     if (!ok) { tmpc_destroy(h); return TMPC_ERR_HIP; }
@@ -758,7 +772,7 @@ static int launch_solve(tmpc_handle *h, int n_iter, int st_flags)
         if (cp) TMPC_HIP_CHECK(h, hipMemsetAsync(h->ticket, 0, 8 * 4, h->stream));    // the persistent launch's work counters (one per XCD)
         hipLaunchKernelGGL(lat3 ? h->kernel_quad : lat2 ? h->kernel_scan : lat ? h->kernel_lat : cp2 ? h->kernel_cp2 : small ? h->kernel_small : h->kernel,
                            dim3(cp ? (h->B < h->grid_max ? h->B : h->grid_max) : h->B),   // (persistent launch: at most the resident workgroups)
-                           dim3(lat3 ? 256 : lat2 ? h->scan_threads : lat ? 128 : cp2 ? 128 : ((cp || small) ? 64 : h->threads)),
+                           dim3(lat3 ? 256 : lat2 ? h->scan_threads : lat ? 128 : cp2 ? h->cp2_threads : ((cp || small) ? 64 : h->threads)),
                            lat3 ? h->lds_bytes_quad : lat2 ? h->lds_bytes_scan : lat ? h->lds_bytes_fast2 : cp2 ? h->lds_bytes_cp2 : small ? h->lds_bytes_small : h->lds_bytes, h->stream, dd, h->B,
                            h->xinit, h->x0, h->params, h->xtraj, h->utraj, h->pobj, h->exit_code, h->qp_status,
                            h->sqp_iter, h->res_eq, h->qp_iter, (long long *)nullptr, io);

@@ -9,7 +9,7 @@
 #define TMPC_FAST_SHAPES(X) X(8, 8, 4, 128) X(12, 12, 4, 128) X(20, 8, 4, 128) X(-1, 6, 4, 128) X(-1, 9, 4, 128) X(-1, 12, 4, 128) X(0, 4, 3, 64) \
     X(8, 8, 3, 64) X(12, 12, 3, 64) X(24, 0, 3, 64) X(-1, 7, 3, 64) X(-1, 10, 3, 64) X(-1, 13, 3, 64) X(-1, 9, 6, 128) X(0, 4, 2, 64) X(8, 8, 6, 128)
 // fast kernels with another stage model (NLIN, MM, LPS, NTH, CM): CM = 1 curvature-aware cost, CM = 2 Gaussian rows
-#define TMPC_FAST_CM_SHAPES(X) X(20, 8, 4, 128, 1) X(-1, 13, 3, 64, 1) X(5, 5, 4, 128, 2) X(-1, 6, 4, 128, 2) X(-1, 12, 4, 128, 2) X(-1, 13, 3, 64, 2)
+#define TMPC_FAST_CM_SHAPES(X) X(20, 8, 4, 128, 1) X(-1, 13, 3, 64, 1) X(5, 5, 4, 128, 2) X(5, 5, 2, 64, 2) X(8, 8, 2, 64, 0) X(-1, 6, 4, 128, 2) X(-1, 12, 4, 128, 2) X(-1, 13, 3, 64, 2)
 // latency mode 2: the parallel-in-time Newton solve (NLIN, MM, LPS, NTH, policy)
 #define TMPC_SCAN_SHAPES(X) X(-1, 12, 4, 128, tmpc::ScanSoloT<2>) X(8, 8, 6, 128, tmpc::ScanSolo) X(8, 8, 3, 64, tmpc::ScanSolo) X(-1, 9, 6, 128, tmpc::ScanSolo)
 // square-root form of the Riccati recursion (tmpc_dims.riccati_form = 1): run-time-shape fast kernels (NLIN, MM, LPS, NTH, CM)
@@ -23,9 +23,9 @@
 #define TMPC_QUAD_G_SHAPES(X) X(-1, 4, tmpc::ScanQuad)
 // latency mode 3 for 21 <= N <= 31 (the shipped jackal / jackalsimulator horizon N = 30): eight lanes per stage, run-time row mix up to 34 rows (MM, CM)
 #define TMPC_QUAD_W_SHAPES(X) X(6, 0) X(6, 1) X(6, 2) X(6, 3)
-#define TMPC_COMPACT_G_SHAPES(X) X(-1, 10, 3)
+#define TMPC_COMPACT_G_SHAPES(X) X(-1, 10, 3) X(5, 5, 2)
 // compact kernels, one wave per trajectory (NLIN, MM, LPS)
-#define TMPC_COMPACT_SHAPES(X) X(8, 8, 3) X(0, 4, 3) X(12, 12, 3) X(24, 0, 3) X(-1, 7, 3) X(-1, 10, 3)
+#define TMPC_COMPACT_SHAPES(X) X(8, 8, 3) X(0, 4, 3) X(12, 12, 3) X(24, 0, 3) X(-1, 7, 3) X(-1, 10, 3) X(8, 8, 2)
 // compact kernels, two waves per trajectory (NLIN, MM, LPS, CM)
 #define TMPC_CP2_SHAPES(X) X(20, 8, 4, 0) X(20, 8, 4, 1) X(12, 12, 4, 0) X(8, 8, 4, 0) X(-1, 6, 4, 0) X(-1, 9, 4, 0) X(-1, 6, 4, 2) X(5, 5, 4, 2)
 // generic kernel (CM)

@@ -19,16 +19,18 @@ FIELDS = ("xtraj", "utraj", "pobj", "exit_code", "qp_status", "sqp_iter", "qp_it
 def _solver(force, B_max, **pkw):
     """force: "compact" / "fast" / None (the library's own rule)."""
     from mpc_planner_amd import solver
-    for k in ("TMPC_NO_COMPACT", "TMPC_COMPACT2_MIN_B"):
+    for k in ("TMPC_NO_COMPACT", "TMPC_COMPACT2_MIN_B", "TMPC_NO_ONE_WAVE_N30"):
         os.environ.pop(k, None)
     if force == "compact":
         os.environ["TMPC_COMPACT2_MIN_B"] = "0"
     elif force == "fast":
         os.environ["TMPC_NO_COMPACT"] = "1"
+    if (pkw.get("row_model") == 1 and pkw.get("n_lin") == 5 and pkw.get("M") == 5) or (pkw.get("n_lin") == 8 and pkw.get("M") == 8 and not pkw.get("n_slk") and pkw.get("N", 20) > 21):
+        os.environ["TMPC_NO_ONE_WAVE_N30"] = "1"          # (round 6: these shapes run on one-wave kernels at two lanes per stage; their two-wave twins stay in the library and are tested here)
     try:
         return solver.BatchedSolver(solver.default_dims(**pkw), B_max=B_max)
     finally:
-        for k in ("TMPC_NO_COMPACT", "TMPC_COMPACT2_MIN_B"):
+        for k in ("TMPC_NO_COMPACT", "TMPC_COMPACT2_MIN_B", "TMPC_NO_ONE_WAVE_N30"):
             os.environ.pop(k, None)
 
 
@@ -182,3 +184,50 @@ def test_param_sharing_hint_on_the_compact_kernels(N):
         np.testing.assert_array_equal(got[k], ref[k], err_msg=k)
     assert (ref["exit_code"] == 1).mean() > 0.9
     s.close()
+
+
+ONE_WAVE_N30 = {
+    "jackal default (5 + 5 Gaussian rows, N = 30)": (dict(N=30, S=3, n_lin=5, M=5, row_model=1), dict(N=30, M=5, S=3, chance=True), dict(N=30, S=3, n_lin=5, M=0, n_gauss=5)),
+    "jackalsimulator stack at its shipped horizon (8 + 8, N = 30)": (dict(N=30, S=5, n_lin=8, M=8), dict(N=30, M=8), dict(N=30, S=5, n_lin=8, M=8)),
+    "8 + 8, N = 22": (dict(N=22, S=5, n_lin=8, M=8), dict(N=22, M=8), dict(N=22, S=5, n_lin=8, M=8)),
+    "8 + 8, N = 32 (every lane of the wave in use)": (dict(N=32, S=5, n_lin=8, M=8), dict(N=32, M=8), dict(N=32, S=5, n_lin=8, M=8)),
+}
+
+
+@pytest.mark.parametrize("name", sorted(ONE_WAVE_N30))
+def test_one_wave_kernels_at_two_lanes_per_stage(name):
+    """Round 6: mpc_planner_jackal's default stack (N = 30, 5 topology + 5 Gaussian rows: generate_jackal_solver.py:53-73) and the jackalsimulator stack at its shipped
+    horizon run on ONE wave per trajectory at two lanes per stage -- the compact kernel for launches beyond the fast one-wave kernel's resident set, the fast one
+    below: bit for bit the same, and the oracle's integers; the product library's own rule picks them (no switch)."""
+    import oracle_lib as O
+    from mpc_planner_amd import scenes, solver
+    dkw, skw, okw = ONE_WAVE_N30[name]
+    B = 32
+    sc = scenes.make_scene(41, B=B, **skw)
+    out = {}
+    for force in ("fast", "compact"):
+        for k in ("TMPC_NO_COMPACT", "TMPC_COMPACT_MIN_B"):
+            os.environ.pop(k, None)
+        os.environ["TMPC_NO_COMPACT" if force == "fast" else "TMPC_COMPACT_MIN_B"] = "1" if force == "fast" else "0"
+        try:
+            s = solver.BatchedSolver(solver.default_dims(**dkw), B_max=B)
+        finally:
+            os.environ.pop("TMPC_NO_COMPACT", None); os.environ.pop("TMPC_COMPACT_MIN_B", None)
+        info = s.kernel_info()
+        assert "two waves per trajectory" not in info.split(";")[0], info
+        assert ("compact" in info.split(";")[0]) == (force == "compact"), info
+        s.set_batch(sc["xinit"], sc["x0"], sc["params"]); s.solve(); out[force] = s.get(); s.close()
+    for k in FIELDS:
+        np.testing.assert_array_equal(out["compact"][k], out["fast"][k], err_msg=k)
+    pb = O.problem(**okw)
+    xt, ut, info = O.solve_batch(pb, sc["xinit"], sc["x0"].reshape(B, -1), sc["params"].reshape(B, -1))
+    _compare(out["compact"], xt, ut, info)
+    assert (info["exit_code"] == 1).sum() >= B // 2
+    # the library's own rule: a saturated launch takes the compact kernel, a tick-size one the fast kernel -- same results for a trajectory in either
+    s = solver.BatchedSolver(solver.default_dims(**dkw), B_max=4096)
+    big = [np.tile(sc[k], (128,) + (1,) * (sc[k].ndim - 1)) for k in ("xinit", "x0", "params")]
+    s.set_batch(*big); s.solve(); g_big = s.get()
+    s.set_batch(sc["xinit"], sc["x0"], sc["params"]); s.solve(); g_small = s.get(); s.close()
+    for k in FIELDS:
+        np.testing.assert_array_equal(g_big[k][:B], g_small[k], err_msg=k)
+        np.testing.assert_array_equal(g_small[k], out["fast"][k], err_msg=k)
