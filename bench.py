@@ -887,7 +887,7 @@ def main():
         from mpc_planner_amd import scenes
         wl30 = dict(dims=dict(N=30, S=5, n_lin=8, M=8), scene=dict(N=30, M=8, tmpc_pp=True))
         sc30 = scenes.make_scene(11, B=4, **wl30["scene"])
-        lat5_n30 = tick_block(5, "the reference's deployed size AND shipped horizon: 4 + 1 planners, N = 30 (settings.yaml; same module stack as configs[1])",
+        lat5_n30 = tick_block(5, "the reference's deployed size AND shipped horizon: 4 + 1 planners, N = 30 (settings.yaml; module stack and obstacle count of configs[1]: 8 + 8 rows; settings.yaml's max_obstacles 12 -> tools/tick_shapes.py)",
                               dims=solver.default_dims(**wl30["dims"]), batch=sc30, wl=wl30)
 
     if rank == 0:

@@ -43,7 +43,7 @@ d = json.loads([l for l in open('gpurun_out/round6_final_bench.json') if l.start
 print('e2e', d.get('value_end_to_end'), 'tight 1e-8', d.get('value_qp_tol_1e_8'), d['qp_tol_1e_8']['parity'], 'beyond 1e-9', d['qp_tol_1e_8']['beyond_the_noise_floor_1e_9']['parity'])
 for l in open('gpurun_out/round6_final_tick_shapes.jsonl'):
     t = json.loads(l)
-    print('tick', t['shape'][:44], t['planners'], {m: (v['p50_ms'], v['exit_code_mismatch'] + v['sqp_iter_mismatch'] + v['ipm_iter_mismatch']) for m, v in t['by_mode'].items()})
+    print('tick', t['shape'][:60], t['planners'], {m: (v['p50_ms'], v['exit_code_mismatch'] + v['sqp_iter_mismatch'] + v['ipm_iter_mismatch']) for m, v in t['by_mode'].items()})
 print('lat64', d['latency_b64']['p50_ms'], d['latency_b64']['fastest_mode'], 'lat5', d['latency_b5']['p50_ms'], 'cpu', d['cpu_baseline']['value'], d['cpu_baseline']['cores'], 'best_index', d['parity'].get('best_index'))
 PY
 tail -4 $O/round6_final_bench.err

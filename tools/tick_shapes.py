@@ -15,7 +15,8 @@ import oracle_lib as O  # noqa: E402
 from mpc_planner_amd import scenes, solver  # noqa: E402
 
 SHAPES = {
-    "jackalsimulator stack at the shipped horizon (N 30, 8 + 8 rows)": (dict(N=30, S=5, n_lin=8, M=8), None, dict(N=30, M=8, tmpc_pp=True)),
+    "jackalsimulator as shipped (settings.yaml: N 30, max_obstacles 12 -> 12 + 12 rows)": (dict(N=30, S=5, n_lin=12, M=12), None, dict(N=30, M=12, tmpc_pp=True)),
+    "jackalsimulator stack at the shipped horizon, configs[1]'s 8 obstacles (N 30, 8 + 8 rows)": (dict(N=30, S=5, n_lin=8, M=8), None, dict(N=30, M=8, tmpc_pp=True)),
     "jackal default (N 30, Gaussian rows, 5 obstacles)": (dict(N=30, S=3, n_lin=5, M=5, row_model=1), dict(N=30, S=3, n_lin=5, M=0, n_gauss=5), dict(N=30, M=5, S=3, chance=True)),
     "cfg3 rosnavigation stack (N 30, slack, 8 + 12 + 8 rows)": (dict(N=30, S=5, n_lin=8, M=8, n_slk=12, slack=1), None, dict(N=30, M=8, slack=True, n_decomp=12)),
     "cfg3 as named (curvature-aware cost)": (dict(N=30, S=5, n_lin=8, M=8, n_slk=12, slack=1, cost_model=1), None, dict(N=30, M=8, slack=True, n_decomp=12)),
